@@ -1,0 +1,483 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference); the fixtures it writes are
+plain data (inputs + expected outputs) and are what travels to the GPU box.
+
+    python tests/golden/gen_golden.py            # rewrites tests/golden/*.json / *.npz
+
+How the reference is imported: the reference source is used as
+is; only its missing third-party imports are shimmed in sys.modules --
+  * cachetools / compress_pickle: not on the path we call, stubbed so imports succeed;
+  * Crypto.Cipher.AES (pycryptodome 3.9.9, absent here): AES.new(key, MODE_ECB)
+    .encrypt(block) is forwarded to the system libcrypto 3 EVP aes-256-ecb (no padding)
+    through ctypes.  AES-256 is FIPS-197, so any conformant implementation gives the
+    same bytes; the shim itself is checked against FIPS-197 C.3 below.
+jzf_aggregator.py cannot be imported at all (it imports modules that are not in the
+tree), so the two arbiter reduces (jzf_aggregator.py:406-419, :424-430) are evaluated
+here exactly as written there: reduce(lambda x, y: (x + y) % mod, models) on Python ints /
+object arrays.
+"""
+import collections
+import collections.abc
+import ctypes
+import ctypes.util
+import json
+import os
+import sys
+import types
+from functools import reduce
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+KEY = bytes(range(32))
+
+
+# --------------------------------------------------------------------------- shims
+def install_shims():
+    sys.dont_write_bytecode = True
+    ct = types.ModuleType("cachetools")
+
+    class LRUCache(dict):
+        def __init__(self, maxsize=None, *a, **k):
+            super().__init__()
+
+    def cached(cache=None, **_):
+        return lambda f: f
+
+    ct.LRUCache, ct.cached = LRUCache, cached
+    sys.modules["cachetools"] = ct
+    sys.modules["compress_pickle"] = types.ModuleType("compress_pickle")
+    collections.Iterable = collections.abc.Iterable
+
+    crypto = ctypes.CDLL(ctypes.util.find_library("crypto"))
+    crypto.EVP_CIPHER_CTX_new.restype = ctypes.c_void_p
+    crypto.EVP_aes_256_ecb.restype = ctypes.c_void_p
+    crypto.EVP_EncryptInit_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_char_p, ctypes.c_char_p]
+    crypto.EVP_CIPHER_CTX_set_padding.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    crypto.EVP_EncryptUpdate.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int),
+                                         ctypes.c_char_p, ctypes.c_int]
+
+    class _Ecb:
+        def __init__(self, key):
+            assert len(key) == 32
+            self.ctx = crypto.EVP_CIPHER_CTX_new()
+            assert crypto.EVP_EncryptInit_ex(self.ctx, crypto.EVP_aes_256_ecb(), None, key, None) == 1
+            crypto.EVP_CIPHER_CTX_set_padding(self.ctx, 0)
+
+        def encrypt(self, data):
+            out = ctypes.create_string_buffer(len(data) + 16)
+            n = ctypes.c_int(0)
+            assert crypto.EVP_EncryptUpdate(self.ctx, out, ctypes.byref(n), bytes(data), len(data)) == 1
+            return out.raw[:n.value]
+
+    aes = types.ModuleType("Crypto.Cipher.AES")
+    aes.MODE_ECB, aes.MODE_CTR = 1, 6
+
+    def new(key, mode, **kw):
+        if mode != aes.MODE_ECB:
+            raise NotImplementedError("only ECB is on the hot path")
+        return _Ecb(key)
+
+    aes.new = new
+    m_crypto = types.ModuleType("Crypto")
+    m_cipher = types.ModuleType("Crypto.Cipher")
+    m_util = types.ModuleType("Crypto.Util")
+    m_counter = types.ModuleType("Crypto.Util.Counter")
+    m_counter.new = lambda *a, **k: None
+    m_cipher.AES = aes
+    m_util.Counter = m_counter
+    m_crypto.Cipher, m_crypto.Util = m_cipher, m_util
+    sys.modules.update({"Crypto": m_crypto, "Crypto.Cipher": m_cipher, "Crypto.Cipher.AES": aes,
+                        "Crypto.Util": m_util, "Crypto.Util.Counter": m_counter})
+    sys.path.insert(0, REF)
+    # FIPS-197 Appendix C.3 through the shim
+    got = _Ecb(bytes(range(32))).encrypt(bytes.fromhex("00112233445566778899aabbccddeeff")).hex()
+    assert got == "8ea2b7ca516745bfeafc49904b496089", got
+
+
+install_shims()
+from federatedml.secureprotol import jzf_flashe as RF                      # noqa: E402
+from federatedml.secureprotol.jzf_aes_prp import PsuedoRandomPermutation   # noqa: E402
+from federatedml.framework import jzf_weights as RW                        # noqa: E402
+from federatedml.secureprotol import jzf_quantize as RQ                    # noqa: E402
+from federatedml.secureprotol.jzf_aciq import ACIQ                         # noqa: E402
+
+
+def hx(v):
+    return format(int(v), "x")
+
+
+def hxl(vs):
+    return [hx(v) for v in vs]
+
+
+def dump(name, obj):
+    p = os.path.join(HERE, name)
+    with open(p, "w") as f:
+        json.dump(obj, f, separators=(",", ":"))
+    print(f"wrote {name}: {os.path.getsize(p)} bytes")
+
+
+def new_cipher(b, scheme, idx, it, num_clients=None):
+    c = RF.FlasheCipher(b, mask=scheme)
+    if num_clients is not None:
+        c.set_num_clients(num_clients)
+    c.generate_prp_seed(KEY)
+    c.set_iter_index(it)
+    c.idx = idx
+    return c
+
+
+def rand_ints(rng, n, bits):
+    return [int.from_bytes(rng.bytes(16), "little") & ((1 << bits) - 1) for _ in range(n)]
+
+
+# --------------------------------------------------------------------------- AES anchors
+def gen_aes():
+    prp = PsuedoRandomPermutation()
+    prp.generate_key(assigned_key=KEY)
+    cases = []
+    for it, idx, ctr in [(3, 0, 0), (3, 0, 6), (3, 0, 13), (3, 1, 0), (0, 0, 0), (0, 10, 9999999),
+                         (2 ** 32 - 1, 2 ** 32 - 1, 2 ** 64 - 1), (7, 5, 2 ** 32), (1, 2, 2 ** 40 + 12345)]:
+        block = it.to_bytes(4, "big") + idx.to_bytes(4, "big") + ctr.to_bytes(8, "big")
+        cases.append({"iter": it, "idx": idx, "counter": str(ctr), "block": block.hex(),
+                      "out": prp.get_permutation(block).hex()})
+    # key normalisation (jzf_aes.py:21-28): int and over-long bytes seeds collapse to the low 32 bytes
+    norm = []
+    for seed in [KEY, b"\x00" * 224 + KEY, b"\xaa" * 7 + KEY]:
+        c = RF.FlasheCipher(128)
+        c.generate_prp_seed(seed)
+        norm.append({"seed": seed.hex(), "aes_key": c.prp.aes.get_key().hex(),
+                     "prp_seed_len": len(c.get_prp_seed())})
+    c = RF.FlasheCipher(128)
+    c.generate_prp_seed(int.from_bytes(KEY, "big"))
+    norm.append({"seed_int": hx(int.from_bytes(KEY, "big")), "aes_key": c.prp.aes.get_key().hex(),
+                 "prp_seed_len": len(c.get_prp_seed())})
+    dump("aes_anchors.json", {"key": KEY.hex(), "fips197_c3": {
+        "key": bytes(range(32)).hex(), "pt": "00112233445566778899aabbccddeeff",
+        "ct": "8ea2b7ca516745bfeafc49904b496089"}, "blocks": cases, "key_norm": norm})
+
+
+# --------------------------------------------------------------------------- mask streams
+def ref_stream(b, it, idx, n, n_jobs):
+    """What _multiprocessing_encrypt_single concatenates (jzf_flashe.py:436-445), in-process."""
+    prefix = it.to_bytes(4, "big") + idx.to_bytes(4, "big")
+    out = []
+    for begin, end in RF.chunks_idx(range(n), n_jobs):
+        out += RF._static_prepare_encrypt_single(begin, end, KEY, b, prefix)
+    return out
+
+
+def gen_masks():
+    cases = []
+    for b in [1, 7, 8, 20, 23, 32, 33, 63, 64, 65, 100, 120, 127, 128]:
+        for n, n_jobs in [(1, 1), (5, 3), (7, 1), (50, 1), (50, 4), (50, 16), (131, 8), (3, 16)]:
+            it, idx = 3, (0 if b % 2 else 1)
+            cases.append({"b": b, "n": n, "n_jobs": n_jobs, "iter": it, "idx": idx,
+                          "chunks": [list(x) for x in RF.chunks_idx(range(n), n_jobs)],
+                          "stream": hxl(ref_stream(b, it, idx, n, n_jobs))})
+    # one larger case with ragged chunks
+    for b, n, n_jobs in [(20, 4099, 16), (64, 4099, 8), (128, 4099, 3), (23, 1000, 16)]:
+        cases.append({"b": b, "n": n, "n_jobs": n_jobs, "iter": 11, "idx": 9,
+                      "chunks": [list(x) for x in RF.chunks_idx(range(n), n_jobs)],
+                      "stream": hxl(ref_stream(b, 11, 9, n, n_jobs))})
+    # multi-prefix sums, both halves of _static_prepare_decrypt (jzf_flashe.py:115-152)
+    sums = []
+    for b, n, n_jobs in [(128, 9, 2), (64, 21, 4), (20, 40, 3), (7, 100, 8)]:
+        add_idx, minus_idx = [3, 5, 5], [0, 4]
+        pa = [(2).to_bytes(4, "big") + i.to_bytes(4, "big") for i in add_idx]
+        pm = [(2).to_bytes(4, "big") + i.to_bytes(4, "big") for i in minus_idx]
+        A, M = [], []
+        for begin, end in RF.chunks_idx(range(n), n_jobs):
+            a, m = RF._static_prepare_decrypt(begin, end, KEY, b, pa, pm)
+            A += a
+            M += m
+        S = []
+        for begin, end in RF.chunks_idx(range(n), n_jobs):
+            S += RF._static_prepare_decrypt_single(begin, end, KEY, b, pm)
+        assert S == M
+        sums.append({"b": b, "n": n, "n_jobs": n_jobs, "iter": 2, "add_idx": add_idx,
+                     "minus_idx": minus_idx, "add": hxl(A), "minus": hxl(M)})
+    dump("mask_streams.json", {"key": KEY.hex(), "cases": cases, "sums": sums})
+
+
+# --------------------------------------------------------------------------- full cipher rounds
+def packed_int(vals, b):
+    return RW._to_bytes_old(list(vals), b)[0]
+
+
+def gen_rounds():
+    rng = np.random.RandomState(20240923)
+    cases = []
+    grid = [
+        # (scheme, b, pt_bits, n, n_jobs, C, uploaded idx list, iter)
+        ("double", 128, 64, 37, 1, 3, [0, 1, 2], 0),
+        ("double", 128, 64, 37, 8, 5, [0, 1, 2, 4], 3),          # dropout of client 3
+        ("double", 128, 128, 16, 3, 4, [0, 0, 0, 0], 1),         # notebook-style duplicates
+        ("double", 120, 100, 50, 16, 6, [5, 0, 2, 3], 7),        # unsorted, two gaps
+        ("double", 64, 60, 50, 4, 3, [0, 1, 2], 2),
+        ("double", 64, 64, 131, 8, 2, [1], 2),
+        ("double", 20, 16, 257, 16, 10, list(range(10)), 0),
+        ("double", 23, 16, 100, 16, 4, [0, 1, 3], 5),
+        ("double", 7, 4, 64, 3, 3, [0, 2], 9),
+        ("double", 1, 1, 40, 2, 2, [0, 1], 0),
+        ("double", 33, 30, 19, 5, 2, [0, 1], 4),
+        ("double", 65, 64, 19, 5, 2, [0, 1], 4),
+        ("single", 64, 34, 100, 8, 2, [0, 1], 0),
+        ("single", 128, 64, 21, 2, 4, [0, 2, 3], 6),
+        ("single", 20, 16, 90, 16, 3, [2, 0, 1], 1),
+        ("double", 128, 64, 0, 4, 2, [0, 1], 0),                  # empty vector
+        ("double", 128, 64, 3, 16, 2, [0, 1], 0),                 # n < n_jobs: empty chunks
+    ]
+    for scheme, b, pt_bits, n, n_jobs, C, up, it in grid:
+        RF.N_JOBS = n_jobs
+        pts, cts = {}, {}
+        for i in sorted(set(up)):
+            pts[i] = rand_ints(rng, n, pt_bits)
+            c = new_cipher(b, scheme, i, it, C)
+            out = c.encrypt(np.array(pts[i], dtype=object))
+            cts[i] = [int(x) for x in out]
+        models = [np.array(cts[i], dtype=object) for i in up]
+        mod = 1 << b
+        agg_elem = reduce(lambda x, y: (x + y) % mod, models) if n else np.array([], dtype=object)
+        if len(models) == 1:
+            agg_elem = models[0] % mod
+        # packed reduce, jzf_aggregator.py:406-419
+        if n:
+            pmod = 1 << (b * n)
+            pk = [packed_int(cts[i], b) for i in up]
+            agg_packed_int = reduce(lambda x, y: (x + y) % pmod, pk) if len(pk) > 1 else pk[0] % pmod
+            agg_packed = RW._from_bytes_old(agg_packed_int, n, b)
+            agg_packed.reverse()
+        else:
+            agg_packed_int, agg_packed = 0, []
+        d = new_cipher(b, scheme, 0, it, C)
+        raw = list(up)
+        d.set_idx_list(raw_idx_list=raw, mode="decrypt")
+        pre_add = [p.hex() for p in d.index_prefix_for_add] if scheme == "double" else []
+        pre_minus = [p.hex() for p in d.index_prefix_for_minus]
+        dec_elem = d.decrypt(np.array([int(x) for x in agg_elem], dtype=object)) if n else []
+        d2 = new_cipher(b, scheme, 0, it, C)
+        d2.set_idx_list(raw_idx_list=list(up), mode="decrypt")
+        dec_packed = d2.decrypt(np.array(agg_packed, dtype=object)) if n else []
+        true_sum = [sum(pts[i][j] for i in up) % mod for j in range(n)]
+        if n:
+            assert [int(x) for x in dec_elem] == true_sum, (scheme, b, n)
+        cases.append({
+            "scheme": scheme, "b": b, "n": n, "n_jobs": n_jobs, "num_clients": C, "uploaded": up,
+            "iter": it, "pt": {str(i): hxl(v) for i, v in pts.items()},
+            "ct": {str(i): hxl(v) for i, v in cts.items()},
+            "agg_elem": hxl(agg_elem), "agg_packed_int": hx(agg_packed_int),
+            "agg_packed": hxl(agg_packed), "prefix_add": pre_add, "prefix_minus": pre_minus,
+            "dec_elem": hxl(dec_elem), "dec_packed": hxl(dec_packed)})
+    dump("cipher_rounds.json", {"key": KEY.hex(), "cases": cases})
+
+
+# --------------------------------------------------------------------------- precompute
+def gen_precompute():
+    rng = np.random.RandomState(77)
+    cases = []
+    for b, n, n_jobs, C, up in [(128, 29, 4, 3, [0, 1, 2]), (23, 61, 16, 4, [0, 1, 3]), (64, 33, 2, 5, [1, 2, 3])]:
+        RF.N_JOBS = n_jobs
+        it = 4
+        pts, cts = {}, {}
+        for i in sorted(set(up)):
+            pts[i] = rand_ints(rng, n, min(b, 64) - 3)
+            c = new_cipher(b, "double", i, it - 1, C)
+            c.set_num_params(n)
+            c.prepare_encrypt()                       # masks for iteration `it`
+            pre_add = hxl(c.next_iter_encrypt_prepared["add"])
+            pre_minus = hxl(c.next_iter_encrypt_prepared["minus"])
+            c.set_iter_index(it)
+            out = c.encrypt(np.array(pts[i], dtype=object))
+            assert c.next_iter_encrypt_prepared == {}
+            cts[i] = {"ct": hxl(out), "pre_add": pre_add, "pre_minus": pre_minus}
+        mod = 1 << b
+        agg = reduce(lambda x, y: (x + y) % mod,
+                     [np.array([int(v, 16) for v in cts[i]["ct"]], dtype=object) for i in up])
+        d = new_cipher(b, "double", 0, it, C)
+        d.set_num_params(n)
+        d.prepare_decrypt()
+        dpre_add = hxl(d.next_iter_decrypt_prepared["add"])
+        dpre_minus = hxl(d.next_iter_decrypt_prepared["minus"])
+        d.set_idx_list(raw_idx_list=list(up), mode="decrypt")
+        extra_add = [p.hex() for p in d.index_prefix_for_add]
+        extra_minus = [p.hex() for p in d.index_prefix_for_minus]
+        dec = d.decrypt(agg)
+        # NB the reference applies the precomputed {add: C, minus: 0} masks unconditionally
+        # (jzf_flashe.py:557-571), so when client 0 or client C-1 dropped out the result is NOT
+        # the plaintext sum.  The fixture records what the reference returns either way.
+        ok = [int(x) for x in dec] == [sum(pts[i][j] for i in up) % mod for j in range(n)]
+        assert ok == (0 in up and C - 1 in up), (b, up)
+        cases.append({"roundtrip": ok, "b": b, "n": n, "n_jobs": n_jobs, "num_clients": C, "uploaded": up, "iter": it,
+                      "pt": {str(i): hxl(v) for i, v in pts.items()}, "clients": {str(i): v for i, v in cts.items()},
+                      "agg": hxl(agg), "dec_pre_add": dpre_add, "dec_pre_minus": dpre_minus,
+                      "extra_prefix_add": extra_add, "extra_prefix_minus": extra_minus, "dec": hxl(dec)})
+    dump("precompute.json", {"key": KEY.hex(), "cases": cases})
+
+
+# --------------------------------------------------------------------------- bit packing
+def gen_pack():
+    rng = np.random.RandomState(5)
+    cases = []
+    for b, n in [(1, 70), (7, 33), (8, 9), (20, 13), (23, 50), (32, 5), (33, 7), (64, 6), (65, 5), (120, 9), (128, 4),
+                 (20, 1), (128, 1)]:
+        v = rand_ints(rng, n, b)
+        big, l = RW._to_bytes_old(v, b)
+        assert l == n
+        back = RW._from_bytes_old(big, n, b)
+        back.reverse()
+        assert back == v
+        cases.append({"b": b, "n": n, "vals": hxl(v), "packed_int": hx(big)})
+    # compress()'s chunk merge (jzf_weights.py:171-182) restated on _to_bytes_old outputs
+    merges = []
+    for b, n, n_jobs in [(20, 50, 4), (23, 61, 16), (128, 10, 3)]:
+        v = rand_ints(rng, n, b)
+        sizes, outs = [], []
+        for begin, end in RW.chunks_idx(range(n), n_jobs):
+            sizes.append(end - begin)
+            outs.append(RW._to_bytes_old(v[begin:end], b)[0])
+        s = 0
+        for i, o in enumerate(outs):
+            s += o << (int(np.sum(sizes[i + 1:])) * b)
+        assert s == RW._to_bytes_old(v, b)[0]
+        merges.append({"b": b, "n": n, "n_jobs": n_jobs, "vals": hxl(v), "packed_int": hx(s)})
+    # the survey's carry example (b = 8)
+    a, c = [0xff, 0x01, 0x80], [0x00, 0xff, 0x90]
+    pa, pc = RW._to_bytes_old(a, 8)[0], RW._to_bytes_old(c, 8)[0]
+    tot = (pa + pc) % (1 << 24)
+    un = RW._from_bytes_old(tot, 3, 8)
+    un.reverse()
+    carry = {"b": 8, "a": hxl(a), "c": hxl(c), "packed_sum": hxl(un),
+             "elem_sum": hxl([(x + y) % 256 for x, y in zip(a, c)])}
+    dump("pack.json", {"cases": cases, "merges": merges, "carry_example": carry})
+
+
+# --------------------------------------------------------------------------- sparse
+def gen_sparse():
+    rng = np.random.RandomState(9)
+    cases = []
+    for b, total, n_jobs, C, frac, it in [(128, 200, 4, 3, 0.2, 2), (64, 301, 8, 4, 0.1, 0), (20, 150, 3, 2, 0.3, 5)]:
+        RF.N_JOBS = n_jobs
+        mod = 1 << b
+        locs, pts, ups, zeros = [], [], [], []
+        for c in range(C):
+            k = max(1, int(total * frac))
+            loc = sorted(rng.choice(total, size=k, replace=False).tolist())
+            locs.append(loc)
+            pt = rand_ints(rng, k, min(b, 64) - 4)
+            pts.append(pt)
+            ci = new_cipher(b, "single", c, it, C)
+            ct = [int(x) for x in ci.encrypt(np.array(pt, dtype=object))]     # compact positions
+            zero = int(rng.randint(0, 1 << 15))                               # trailing plain value
+            zeros.append(zero)
+            ups.append(ct + [zero])
+        # Arbiter.expand_to_dense (jzf_aggregator.py:150-165) restated, then the element-wise reduce
+        dense = []
+        for c in range(C):
+            a = np.array(ups[c], dtype=object)
+            zero, a = a[-1], a[:-1]
+            e = np.zeros(total, dtype=object)
+            e[locs[c]] = a
+            zl = list(set(np.arange(total).tolist()) - set(locs[c]))
+            e[zl] = zero
+            dense.append(e)
+        agg = reduce(lambda x, y: (x + y) % mod, dense)
+        d = new_cipher(b, "single", 0, it, C)
+        d.masks = [list(l) for l in locs]
+        d.total = total
+        d.set_idx_list(raw_idx_list=None, mode="decrypt")
+        minus = [int(x) for x in d.next_iter_decrypt_prepared["minus"]]
+        dec = [int(x) for x in d.decrypt(agg)]
+        exp = [0] * total
+        for c in range(C):
+            inloc = set(locs[c])
+            for p in range(total):
+                if p not in inloc:
+                    exp[p] = (exp[p] + zeros[c]) % mod
+            for q, p in enumerate(locs[c]):
+                exp[p] = (exp[p] + pts[c][q]) % mod
+        assert dec == exp
+        cases.append({"b": b, "total": total, "n_jobs": n_jobs, "num_clients": C, "iter": it, "locs": locs,
+                      "pt": [hxl(p) for p in pts], "uploads": [hxl(u) for u in ups],
+                      "dense": [hxl(e) for e in dense], "agg": hxl(agg), "minus_mask": hxl(minus),
+                      "dec": hxl(dec)})
+    # dense-position double-mask sparse masks: direct call of _static_prepare_decrypt_spar with one chunk
+    dcases = []
+    for b, total, C, it in [(128, 60, 3, 1), (20, 77, 4, 3)]:
+        one_hots = []
+        for c in range(C):
+            a = np.zeros(total, dtype=object)
+            a[sorted(rng.choice(total, size=total // 3, replace=False).tolist())] = 1
+            one_hots.append(a)
+        minus, add = [], [np.zeros(total, dtype=object)]
+        for c in range(C):          # jzf_flashe.py:398-407
+            minus.append(one_hots[c] & ~one_hots[c - 1] if c > 0 else one_hots[c])
+            add.append(one_hots[c] & ~one_hots[c + 1] if c < C - 1 else one_hots[c])
+        ta, tm = RF._static_prepare_decrypt_spar(0, total, KEY, b, it.to_bytes(4, "big"), add, minus)
+        dcases.append({"b": b, "total": total, "iter": it,
+                       "add_sel": [[int(x) & 1 for x in a] for a in add],
+                       "minus_sel": [[int(x) & 1 for x in m] for m in minus],
+                       "add": hxl(ta), "minus": hxl(tm)})
+    dump("sparse.json", {"key": KEY.hex(), "single": cases, "dense_double": dcases})
+
+
+# --------------------------------------------------------------------------- config 1 (plumbing)
+def gen_config1():
+    """BASELINE config 1 / SURVEY 8(d): 1e4 fp32, 32-bit quantise, 64-bit modulus, 2 clients,
+    single mask, n_jobs = 8.  Arrays go to an .npz (uint64)."""
+    n, C, b, eb, n_jobs, it = 10000, 2, 64, 32, 8, 0
+    RF.N_JOBS = n_jobs
+    alpha = ACIQ(eb).get_alpha_gaus_direct(1.0)
+    out = {"alpha": np.float64(alpha)}
+    qs, cts = [], []
+    for c in range(C):
+        x = np.random.RandomState(100 + c).standard_normal(n).astype(np.float32)
+        np.random.seed(7 + c)
+        q = RQ._static_quantize_padding_asymmetric(x, alpha, eb)
+        q = np.array([int(v) for v in q], dtype=object)
+        ci = new_cipher(b, "single", c, it, C)
+        ct = ci.encrypt(q)
+        out[f"x{c}"] = x
+        out[f"q{c}"] = np.array([int(v) for v in q], dtype=np.uint64)
+        out[f"ct{c}"] = np.array([int(v) for v in ct], dtype=np.uint64)
+        qs.append(q)
+        cts.append(ct)
+    mod = 1 << b
+    agg = reduce(lambda x, y: (x + y) % mod, cts)
+    pmod = 1 << (b * n)
+    pk = [RW._to_bytes_old([int(v) for v in ct], b)[0] for ct in cts]
+    aggp = RW._from_bytes_old(reduce(lambda x, y: (x + y) % pmod, pk), n, b)
+    aggp.reverse()
+    d = new_cipher(b, "single", 0, it, C)
+    d.set_idx_list(raw_idx_list=[0, 1], mode="decrypt")
+    dec = d.decrypt(agg)
+    d2 = new_cipher(b, "single", 0, it, C)
+    d2.set_idx_list(raw_idx_list=[0, 1], mode="decrypt")
+    decp = d2.decrypt(np.array(aggp, dtype=object))
+    out["agg_elem"] = np.array([int(v) for v in agg], dtype=np.uint64)
+    out["agg_packed"] = np.array([int(v) for v in aggp], dtype=np.uint64)
+    out["dec_elem"] = np.array([int(v) for v in dec], dtype=np.uint64)
+    out["dec_packed"] = np.array([int(v) for v in decp], dtype=np.uint64)
+    out["unq_elem"] = RQ._static_unquantize_padding_asymmetric(
+        np.array([int(v) for v in dec], dtype=object), alpha, eb, C).astype(np.float64)
+    out["unq_packed"] = RQ._static_unquantize_padding_asymmetric(
+        np.array([int(v) for v in decp], dtype=object), alpha, eb, C).astype(np.float64)
+    assert [int(v) for v in dec] == [(int(a) + int(c)) % mod for a, c in zip(qs[0], qs[1])]
+    p = os.path.join(HERE, "config1.npz")
+    np.savez_compressed(p, **out)
+    print(f"wrote config1.npz: {os.path.getsize(p)} bytes; q0[:3] = {[int(v) for v in qs[0][:3]]}")
+
+
+if __name__ == "__main__":
+    gen_aes()
+    gen_masks()
+    gen_rounds()
+    gen_precompute()
+    gen_pack()
+    gen_sparse()
+    gen_config1()
