@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ciphertexts/sec for one FLASHE round (C client encrypts + one C-way
+aggregate + one decrypt) on a 1e7-element vector, 64-bit plaintext / 128-bit modulus, double
+mask -- BASELINE.json config 2 -- with every buffer resident in HBM when the clock starts.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one round.  With N > 1 every rank plays C clients (weak scaling: N*C ciphertext
+vectors per round), partial aggregates are reduce-scattered over RCCL (all-to-all + local
+mod-add), every rank decrypts its slice and an all-gather returns the plaintext aggregate to
+all ranks (flashe_amd/dist.py).  Rank 0 prints ONE JSON line.
+
+The JSON carries `roofline` for the dominant kernel (the fused PRF+encrypt kernel, timed live
+with HIP events on the stream it runs on) and, at N = 1, `cpu_baseline`: the CPU oracle (a port
+of the reference algorithm, oracle/flashe_oracle.c) timed on this host's cores on a bounded
+sample of the same workload.  The oracle is only the baseline / checker here, never the thing
+measured.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--clients", type=int, default=10, help="clients per GPU")
+    ap.add_argument("--bits", type=int, default=128)
+    ap.add_argument("--n-jobs", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, pts_sample_fn):
+    """Oracle (port of the reference arithmetic) on the host cores, one full round on a bounded sample."""
+    import numpy as np
+    from oracle import flashe_oracle as orc
+    orc.build()
+    key = bytes(range(32))
+    ns, C, b = min(args.cpu_sample, args.n), args.clients, args.bits
+    pts = [pts_sample_fn(c, ns) for c in range(C)]
+    cores = orc.num_threads()
+    orc.mask(key, 0, 0, 1000, 1, b)          # table init outside the clock
+    t0 = time.perf_counter()
+    cts = [orc.encrypt(key, 0, c, "double", args.n_jobs, b, pts[c]) for c in range(C)]
+    t1 = time.perf_counter()
+    agg = orc.aggregate_elem(cts, b)
+    t2 = time.perf_counter()
+    dec = orc.decrypt(key, 0, [C], [0], args.n_jobs, b, agg)
+    t3 = time.perf_counter()
+    want = np.zeros(ns, dtype=np.uint64)
+    for p in pts:
+        want += p
+    assert np.array_equal(dec[:, 0], want), "cpu baseline round trip failed"
+    return {"value": C * ns / (t3 - t0), "unit": "ciphertexts/s", "cores": cores, "kind": "port",
+            "sample": f"one full round (C={C} encrypts + aggregate + decrypt, b={b}, double mask) on the first {ns} "
+                      f"elements of the workload; oracle/flashe_oracle.c (T-table AES-256, OpenMP x{cores})",
+            "phases_s": {"encrypt_xC": t1 - t0, "aggregate": t2 - t1, "decrypt": t3 - t2}}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # launched bare: start the per-GPU processes as a child BEFORE anything touches the GPU
+        port = 29400 + os.getpid() % 500
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from flashe_amd.dist import HipOps, ShardedRound
+    from flashe_amd.engine import SCHEME_DOUBLE, Engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    n, C, b, K, W = args.n, args.clients, args.bits, args.steps, args.warmup
+    L = 2 if b > 64 else 1
+    key = bytes(range(32))
+    stream = torch.cuda.Stream(device=device)
+
+    def plaintext(global_client, count=n):
+        # Generator(PCG64(1000 + c)).integers(0, 2**64, n, uint64)
+        hi = 2 ** 64 if b >= 64 else 2 ** max(b - 8, 1)
+        return np.random.Generator(np.random.PCG64(1000 + global_client)).integers(0, hi, count, dtype=np.uint64)
+
+    with torch.cuda.stream(stream):
+        eng = Engine(key, b, device=local_rank, stream=stream.cuda_stream)
+        eng.selftest()
+        ops = HipOps(eng)
+        rnd = ShardedRound(ops, n, b, C, args.n_jobs, device, rank=rank, world=world)
+        host_pts = [plaintext(rank * C + c) for c in range(C)]
+        pts = [torch.from_numpy(p.view(np.int64)).to(device) for p in host_pts]
+
+        # HIP events on the engine's stream: per encrypt launch + per phase
+        enc_ev = [(eng.event(), eng.event()) for _ in range(K * C)]
+        ph_ev = [[eng.event() for _ in range(4)] for _ in range(K)]
+
+        def timed_round(it, k):
+            # same sequence as ShardedRound.run, with event brackets around the launches
+            eng.record(ph_ev[k][0])
+            for c in range(C):
+                e0, e1 = enc_ev[k * C + c]
+                eng.record(e0)
+                ops.encrypt(it, rank * C + c, SCHEME_DOUBLE, n, args.n_jobs, pts[c], 1, rnd.ct[c])
+                eng.record(e1)
+            eng.record(ph_ev[k][1])
+            rnd.aggregate_phase()
+            eng.record(ph_ev[k][2])
+            rnd.decrypt_phase(it)
+            eng.record(ph_ev[k][3])
+
+        for w in range(W):
+            rnd.run(w, pts, 1)
+        # parity gate before any timing counts: decrypted aggregate == plaintext sum (mod 2^b)
+        res = rnd.run(0, pts, 1)
+        torch.cuda.synchronize()
+        got = res[: n * L].cpu().numpy().view(np.uint64).reshape(n, L)
+        lo = np.zeros(n, dtype=np.uint64)
+        hi = np.zeros(n, dtype=np.uint64)
+        for g in range(world * C):
+            p = host_pts[g - rank * C] if rank * C <= g < (rank + 1) * C else plaintext(g)
+            new = lo + p
+            hi += (new < lo).astype(np.uint64)
+            lo = new
+        if b < 64:
+            lo &= np.uint64((1 << b) - 1)
+        ok = np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi if b == 128 else hi & np.uint64((1 << (b - 64)) - 1)))
+        if not ok:
+            raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum")
+
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(K):
+            timed_round(k, k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+
+        elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        elapsed = float(elapsed.item())
+
+        enc_ms = [eng.elapsed_ms(e0, e1) for e0, e1 in enc_ev]
+        ph = np.array([[eng.elapsed_ms(p[i], p[i + 1]) for i in range(3)] for p in ph_ev])
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / K
+        value = world * C * n / (elapsed / K)
+        enc_avg_ms = float(np.mean(enc_ms))
+        pt_bytes = 8
+        alg_bytes = n * (pt_bytes + 8 * L)                  # u64 plaintext in + L-limb ciphertext out
+        achieved = alg_bytes / (enc_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("encrypt_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "ciphertexts/sec (enc+agg+dec), 1e7-elem vector; achieved HBM GB/s fraction",
+            "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u128" if L == 2 else "u64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 2: n={n}-element vector, 64-bit plaintext / {b}-bit modulus, "
+                                   f"{C} clients per GPU, double mask, n_jobs={args.n_jobs}; round = {C} encrypts + "
+                                   f"{C}-way aggregate + 1 decrypt" + (f"; {world} GPUs: all-to-all reduce-scatter + "
+                                   "sliced decrypt + all-gather" if world > 1 else ""),
+                       "n": n, "int_bits": b, "clients_per_gpu": C, "mask": "double", "parity": "bit-exact (checked in-run)"},
+            "roofline": {"kernel": "prf_wide_kernel<1> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt)",
+                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": enc_avg_ms,
+                         "launches_timed": len(enc_ms),
+                         "aes_blocks_per_s": 2 * n / (enc_avg_ms * 1e-3),
+                         "note": "integer path: the kernel is AES(LDS/VALU)-rate bound, HBM fraction reported as required"},
+            "phases_ms": {"encrypt_xC": float(ph[:, 0].mean()), "aggregate": float(ph[:, 1].mean()),
+                          "decrypt": float(ph[:, 2].mean())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, lambda c, ns: plaintext(c, n)[:ns].copy())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""ctypes binding of libflashe_hip.so -- the ONLY compute path of this package.
+
+There is deliberately no CPU fallback: if the shared library is missing or no HIP device is
+usable, loading / context creation raises.  Signatures follow include/flashe.h.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflashe_hip.so")
+
+OK = 0
+SCHEME_SINGLE = 0
+SCHEME_DOUBLE = 1
+
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_u32p = ctypes.POINTER(ctypes.c_uint32)
+c_u64p = ctypes.POINTER(ctypes.c_uint64)
+c_u64pp = ctypes.POINTER(c_u64p)
+c_vp = ctypes.c_void_p
+c_int = ctypes.c_int
+c_u32 = ctypes.c_uint32
+c_u64 = ctypes.c_uint64
+c_size = ctypes.c_size_t
+
+
+class FlasheError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"flashe error {code}: {msg}")
+        self.code = code
+
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "flashe_abi_version": (c_int, []),
+    "flashe_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "flashe_limbs": (c_int, [c_int]),
+    "flashe_ctx_create": (c_int, [ctypes.POINTER(c_vp), c_u8p, c_int, c_int, c_vp]),
+    "flashe_ctx_destroy": (c_int, [c_vp]),
+    "flashe_ctx_set_key": (c_int, [c_vp, c_u8p]),
+    "flashe_ctx_int_bits": (c_int, [c_vp]),
+    "flashe_last_error": (ctypes.c_char_p, [c_vp]),
+    "flashe_selftest": (c_int, [c_vp]),
+    "flashe_chunks": (c_int, [c_u64, c_u32, c_u64p]),
+    "flashe_telescope": (c_int, [c_u32p, c_int, c_u32p, c_u32p, ctypes.POINTER(c_int)]),
+    "flashe_prp_block": (c_int, [c_u8p, c_u8p, c_u8p]),
+    "flashe_dev_alloc": (c_int, [c_vp, c_size, ctypes.POINTER(c_vp)]),
+    "flashe_dev_free": (c_int, [c_vp, c_vp]),
+    "flashe_memcpy_h2d": (c_int, [c_vp, c_vp, c_vp, c_size]),
+    "flashe_memcpy_d2h": (c_int, [c_vp, c_vp, c_vp, c_size]),
+    "flashe_memcpy_d2d": (c_int, [c_vp, c_vp, c_vp, c_size]),
+    "flashe_memset_dev": (c_int, [c_vp, c_vp, c_int, c_size]),
+    "flashe_sync": (c_int, [c_vp]),
+    "flashe_event_create": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
+    "flashe_event_destroy": (c_int, [c_vp, c_vp]),
+    "flashe_event_record": (c_int, [c_vp, c_vp]),
+    "flashe_event_elapsed_ms": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_float)]),
+    "flashe_mask_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_vp]),
+    "flashe_mask": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_vp]),
+    "flashe_encrypt_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, c_vp]),
+    "flashe_encrypt": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, c_vp]),
+    "flashe_decrypt_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
+    "flashe_decrypt": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
+    "flashe_mask_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_vp]),
+    "flashe_encrypt_range_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_u64, c_u64, c_vp, c_int, c_vp]),
+    "flashe_decrypt_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_vp, c_vp]),
+    "flashe_combine_dev": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "flashe_combine": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "flashe_aggregate_elem_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
+    "flashe_aggregate_elem": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
+    "flashe_aggregate_packed_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_u64, c_vp]),
+    "flashe_aggregate_packed": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_u64, c_vp]),
+    "flashe_pack_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
+    "flashe_pack": (c_int, [c_vp, c_u64, c_vp, c_vp]),
+    "flashe_unpack_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
+    "flashe_unpack": (c_int, [c_vp, c_u64, c_vp, c_vp]),
+    "flashe_expand_to_dense_dev": (c_int, [c_vp, c_u64, c_u64, c_vp, c_vp, c_u64p, c_vp]),
+    "flashe_expand_to_dense": (c_int, [c_vp, c_u64, c_u64, c_vp, c_vp, c_u64p, c_vp]),
+    "flashe_sparse_minus_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
+    "flashe_sparse_minus_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
+    "flashe_sparse_dense_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
+    "flashe_sparse_dense_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load libflashe_hip.so (built by `python -c 'import __graft_entry__ as g; g.build()'`
+    or `make -C flashe_amd/csrc`).  Raises if it is missing -- there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FlasheError(-2, f"{LIB_PATH} not found: build it with `make -C flashe_amd/csrc` "
+                              "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc):
+    if rc != OK:
+        msg = load().flashe_last_error(ctx_handle)
+        raise FlasheError(rc, msg.decode() if msg else "unknown")
+    return rc

@@ -1,0 +1,427 @@
+"""`FlasheCipher` -- host-side mirror of the reference class of the same name
+(federatedml/secureprotol/jzf_flashe.py:228-666) on top of the MI355X engine.
+
+Same constructor, methods, attributes, state machine and error behaviour as the
+reference, so the adapter that drives it (jzf_flashe_block._Client, jzf_flashe_block.py:
+142-174) and the notebook harness (encrypt_test/final_big_table.ipynb cell 14) can switch
+by changing one import.  What differs is where the arithmetic runs: every mask stream,
+encrypt, decrypt and aggregate goes through libflashe_hip.so (HIP kernels); nothing is
+computed in Python and there is no CPU fallback.
+
+Data convention: like the reference, `encrypt` / `decrypt` take a 1-D
+``np.ndarray(dtype=object)`` of Python ints and return a NEW array of the same kind.
+As a fast path they also accept ``uint64`` arrays -- shape ``[n]`` (values < 2**64) or
+``[n, L]`` little-endian limbs, L = ceil(int_bits / 64) -- and then return ``[n, L]``
+(``[n]`` when L == 1 and the input was 1-D) without ever building Python ints.
+
+`N_JOBS` mirrors the reference's module global (jzf_flashe.py:7): for int_bits <= 64 the
+PRF counters depend on chunks_idx(range(n), N_JOBS), so every party must use the same
+value (the reference uses cpu_count(); set `flashe_amd.cipher.N_JOBS` to match a peer).
+"""
+import os
+from multiprocessing import cpu_count
+
+import numpy as np
+
+from . import engine as _engine
+from .engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine
+
+N_JOBS = cpu_count()
+BITS_PER_BYTES = 8
+_M64 = (1 << 64) - 1
+
+__all__ = ["FlasheCipher", "aggregate", "N_JOBS"]
+
+
+# ------------------------------------------------------------------------------ conversions
+def _to_limbs(value, limbs):
+    """ndarray (object ints | uint64) -> (uint64 [n, k] array, kind) with k in {1, limbs}."""
+    if value.dtype == object:
+        if value.ndim != 1:
+            value = value.reshape(-1)
+        n = value.shape[0]
+        out = np.empty((n, limbs), dtype=np.uint64)
+        if n:
+            out[:, 0] = (value & _M64).astype(np.uint64)
+            if limbs == 2:
+                out[:, 1] = ((value >> 64) & _M64).astype(np.uint64)
+        return out, "object"
+    if value.dtype == np.uint64:
+        if value.ndim == 1:
+            return np.ascontiguousarray(value).reshape(-1, 1), "u64_1d"
+        if value.ndim == 2 and value.shape[1] in (1, limbs):
+            return np.ascontiguousarray(value), "u64_2d"
+        raise ValueError(f"uint64 input must be [n] or [n, {limbs}], got {value.shape}")
+    if np.issubdtype(value.dtype, np.integer):
+        return _to_limbs(value.astype(object), limbs)
+    raise TypeError(f"unsupported dtype {value.dtype}: pass object ints or uint64 limbs")
+
+
+def _from_limbs(arr, kind):
+    if kind == "object":
+        out = arr[:, 0].astype(object)
+        if arr.shape[1] == 2:
+            out = out | (arr[:, 1].astype(object) << 64)
+        return out
+    if kind == "u64_1d" and arr.shape[1] == 1:
+        return arr[:, 0]
+    return arr
+
+
+class _DevVec:
+    """A mask vector resident in HBM (the cached `next_iter_*_prepared` entries)."""
+
+    def __init__(self, eng, n):
+        self.n = n
+        self.buf = eng.alloc_vec(n)
+
+    def __len__(self):
+        return self.n
+
+    def to_host(self, eng):
+        return self.buf.download(np.uint64, self.n * eng.limbs).reshape(self.n, eng.limbs)
+
+
+class FlasheCipher(object):
+    """Drop-in for federatedml.secureprotol.jzf_flashe.FlasheCipher (jzf_flashe.py:228-666)."""
+
+    _engine_cls = Engine      # the device context type (the HIP engine; tests may inject a double)
+
+    def __init__(self, int_bits, mask="double", device=0):
+        # attribute set mirrors jzf_flashe.py:230-260
+        self.uuid = None
+        self.exchanged_keys = None
+        self.masking_scheme = mask
+        self.masks = None
+        self.total = None
+
+        self.prp_seed = None
+        self.prp_seed_len = 256
+        self.guest_uuid = None
+
+        self.idx = None
+        self.index_prefix_for_add = None
+        self.index_prefix_for_minus = None
+
+        self.iter_index = -1
+        self.iter_index_bytes = None
+
+        if 128 // int_bits < 1:          # the reference divides by merge_size = 128 // int_bits
+            raise ZeroDivisionError("integer division or modulo by zero")
+        self.int_bits = int_bits
+
+        self.num_clients = None
+        self.next_iter_encrypt_prepared = {}
+        self.next_iter_decrypt_prepared = {}
+        self.next_iter_decrypt_prepared_idx = {}
+        self.num_params = None
+
+        self.encrypt_base = 0
+        self.decrypt_base = 0
+
+        self._device = device
+        self._engine = None
+        self._key = None
+
+    # ------------------------------------------------------------------ simple setters
+    def set_num_clients(self, num_clients):
+        self.num_clients = num_clients
+
+    def set_self_uuid(self, uuid):
+        self.uuid = uuid
+
+    def set_exchanged_keys(self, exchanged_keys):     # jzf_flashe.py:268-275
+        self.exchanged_keys = exchanged_keys
+        for k, v in exchanged_keys.items():
+            if k == self.uuid:
+                self.idx = v[0]
+            elif v[2] == "guest":
+                self.guest_uuid = k
+
+    def get_guest_uuid(self):
+        return self.guest_uuid
+
+    def generate_prp_seed(self, assigned_seed=None):  # jzf_flashe.py:280-295
+        if assigned_seed is None:
+            seed = os.urandom(self.prp_seed_len // BITS_PER_BYTES)
+        else:
+            if isinstance(assigned_seed, int):
+                seed = int(assigned_seed & int(2 ** self.prp_seed_len - 1)).to_bytes(self.prp_seed_len, 'big')
+            else:
+                seed = int(int.from_bytes(assigned_seed, 'big') & int(2 ** self.prp_seed_len - 1)).to_bytes(
+                    self.prp_seed_len, 'big')
+        self.prp_seed = seed
+        # AESCipher.generate_key (jzf_aes.py:21-28): the AES-256 key is the low 256 bits, big-endian
+        self._key = (int.from_bytes(seed, 'big') & (256 ** 32 - 1)).to_bytes(32, 'big')
+        if self._engine is None:
+            self._engine = self._engine_cls(self._key, self.int_bits, device=self._device)
+        else:
+            self._engine.set_key(self._key)
+
+    def get_prp_seed(self):
+        return self.prp_seed
+
+    def set_iter_index(self, iter_index):             # jzf_flashe.py:300-304
+        self.encrypt_base = 0
+        self.decrypt_base = 0
+        self.iter_index = iter_index
+        self.iter_index_bytes = iter_index.to_bytes(4, 'big')
+
+    def get_idx_list(self):
+        return [self.idx]
+
+    def set_num_params(self, num_params):
+        self.num_params = num_params
+
+    @property
+    def engine(self):
+        """The device context (None until a PRP seed is set)."""
+        return self._engine
+
+    # ------------------------------------------------------------------ prefix selection
+    @staticmethod
+    def _idx_of(prefix):
+        return int.from_bytes(prefix[4:8], 'big')
+
+    def set_idx_list_single(self, raw_idx_list=None, mode="encrypt"):   # jzf_flashe.py:306-343
+        if mode == "encrypt":
+            self.index_prefix_for_add = self.iter_index_bytes + self.idx.to_bytes(4, 'big')
+        else:
+            if self.masks is None:
+                self.index_prefix_for_minus = [self.iter_index_bytes + idx.to_bytes(4, 'big') for idx in raw_idx_list]
+            else:
+                # dense minus-mask: client c's COMPACT stream scattered to its location list
+                eng = self._engine
+                locs = [np.asarray(m, dtype=np.uint32) for m in self.masks]
+                for c, l in enumerate(locs):
+                    if len(l) and int(l.max()) >= self.total:
+                        raise IndexError(f"index {int(l.max())} is out of bounds for axis 0 with size {self.total}")
+                dloc = [eng.upload(l) for l in locs]
+                vec = _DevVec(eng, self.total)
+                eng.sparse_minus_mask_dev(self.iter_index, dloc, [len(l) for l in locs], self.total, N_JOBS, vec.buf)
+                eng.sync()
+                self.next_iter_decrypt_prepared["minus"] = vec
+
+    def set_idx_list(self, raw_idx_list=None, mode="encrypt"):          # jzf_flashe.py:345-426
+        if self.masking_scheme == "single":
+            return self.set_idx_list_single(raw_idx_list, mode)
+
+        if mode == "encrypt":
+            self.index_prefix_for_add = self.iter_index_bytes + self.idx.to_bytes(4, 'big')
+            self.index_prefix_for_minus = self.iter_index_bytes + (self.idx + 1).to_bytes(4, 'big')
+        else:
+            if self.masks is None:
+                raw_idx_list.sort()                                   # in place, like the reference
+                temp_add, temp_minus = _engine.telescope(raw_idx_list)
+                self.index_prefix_for_add = []
+                self.index_prefix_for_minus = []
+                for idx in temp_add:
+                    if 'add' in self.next_iter_decrypt_prepared_idx and idx in self.next_iter_decrypt_prepared_idx['add']:
+                        pass
+                    else:
+                        self.index_prefix_for_add.append(self.iter_index_bytes + idx.to_bytes(4, 'big'))
+                for idx in temp_minus:
+                    if 'minus' in self.next_iter_decrypt_prepared_idx and idx in self.next_iter_decrypt_prepared_idx['minus']:
+                        pass
+                    else:
+                        self.index_prefix_for_minus.append(self.iter_index_bytes + idx.to_bytes(4, 'big'))
+            else:
+                # sparse + double: per-client run analysis on one-hot location vectors (:388-407),
+                # masks indexed by DENSE position (_static_prepare_decrypt_spar as one chunk; the
+                # reference's per-chunk slicing of the client list (:413-414) is a defect that
+                # crashes for N_JOBS > 1 -- see DESIGN.md)
+                eng = self._engine
+                total = self.total
+                one_hots = []
+                for m in self.masks:
+                    a = np.zeros(total, dtype=np.uint8)
+                    a[np.asarray(m, dtype=np.int64)] = 1
+                    one_hots.append(a)
+                num_clients = len(self.masks)
+                minus, add = [], [np.zeros(total, dtype=np.uint8)]
+                for c in range(num_clients):
+                    minus.append(one_hots[c] & (1 - one_hots[c - 1]) if c > 0 else one_hots[c])
+                    add.append(one_hots[c] & (1 - one_hots[c + 1]) if c < num_clients - 1 else one_hots[c])
+                va, vm = _DevVec(eng, total), _DevVec(eng, total)
+                da = [eng.upload(a) for a in add]
+                dm = [eng.upload(m) for m in minus]
+                eng.sparse_dense_mask_dev(self.iter_index, da, total, va.buf)
+                eng.sparse_dense_mask_dev(self.iter_index, dm, total, vm.buf)
+                eng.sync()
+                self.next_iter_decrypt_prepared['add'] = va
+                self.next_iter_decrypt_prepared['minus'] = vm
+
+    # ------------------------------------------------------------------ encrypt
+    def _check_prepared_len(self, vec, n):
+        if len(vec) != n:
+            raise ValueError(f"operands could not be broadcast together with shapes ({n},) ({len(vec)},) ")
+
+    def _encrypt_single(self, value):                                    # jzf_flashe.py:431-454
+        eng = self._engine
+        limbs, kind = _to_limbs(value, eng.limbs)
+        ct = eng.encrypt(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_SINGLE, N_JOBS, limbs)
+        if 'add' in self.next_iter_encrypt_prepared:
+            del self.next_iter_encrypt_prepared['add']
+        return _from_limbs(ct, kind)
+
+    def _encrypt_double(self, value):                                    # jzf_flashe.py:456-488
+        eng = self._engine
+        limbs, kind = _to_limbs(value, eng.limbs)
+        n = limbs.shape[0]
+        if 'add' not in self.next_iter_encrypt_prepared:
+            ct = eng.encrypt(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_DOUBLE, N_JOBS, limbs)
+        else:
+            add = self.next_iter_encrypt_prepared['add']
+            minus = self.next_iter_encrypt_prepared['minus']
+            self._check_prepared_len(add, n)
+            dpt = eng.upload(limbs)
+            dct = eng.alloc_vec(n)
+            eng.combine_dev(n, dpt, limbs.shape[1], add.buf, minus.buf, dct)
+            ct = dct.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
+        if 'add' in self.next_iter_encrypt_prepared:
+            del self.next_iter_encrypt_prepared['add']
+        if 'minus' in self.next_iter_encrypt_prepared:
+            del self.next_iter_encrypt_prepared['minus']
+        return _from_limbs(ct, kind)
+
+    def encrypt(self, plaintext):                                        # jzf_flashe.py:490-504
+        if self.prp_seed is not None:
+            if self.masking_scheme == "double":
+                self.set_idx_list(mode="encrypt")
+            else:
+                self.set_idx_list_single(mode="encrypt")
+            if not isinstance(plaintext, np.ndarray):
+                return None
+            if self.masking_scheme == "double":
+                return self._encrypt_double(plaintext)
+            return self._encrypt_single(plaintext)
+        return None
+
+    # ------------------------------------------------------------------ decrypt
+    def _decrypt_single(self, value):                                    # jzf_flashe.py:506-535
+        eng = self._engine
+        limbs, kind = _to_limbs(value, eng.limbs)
+        n = limbs.shape[0]
+        if limbs.shape[1] != eng.limbs:
+            limbs = np.concatenate([limbs, np.zeros((n, eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
+        if self.masks is None:
+            minus_idx = [self._idx_of(p) for p in self.index_prefix_for_minus]
+            out = eng.decrypt(self.iter_index, [], minus_idx, N_JOBS, limbs)
+        else:
+            minus = self.next_iter_decrypt_prepared['minus']
+            self._check_prepared_len(minus, n)
+            din = eng.upload(limbs)
+            dout = eng.alloc_vec(n)
+            eng.combine_dev(n, din, eng.limbs, None, minus.buf, dout)
+            out = dout.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
+        if 'minus' in self.next_iter_decrypt_prepared:
+            del self.next_iter_decrypt_prepared['minus']
+        return _from_limbs(out, kind)
+
+    def _decrypt_double(self, value):                                    # jzf_flashe.py:537-582
+        eng = self._engine
+        limbs, kind = _to_limbs(value, eng.limbs)
+        n = limbs.shape[0]
+        if limbs.shape[1] != eng.limbs:
+            limbs = np.concatenate([limbs, np.zeros((n, eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
+        add_idx, minus_idx = [], []
+        if self.masks is None and (self.index_prefix_for_minus or self.index_prefix_for_add):
+            add_idx = [self._idx_of(p) for p in self.index_prefix_for_add]
+            minus_idx = [self._idx_of(p) for p in self.index_prefix_for_minus]
+        online = bool(add_idx or minus_idx)
+        if 'add' not in self.next_iter_decrypt_prepared:
+            if not online:
+                raise KeyError('add')                                     # what the reference raises (:570)
+            out = eng.decrypt(self.iter_index, add_idx, minus_idx, N_JOBS, limbs)
+        else:
+            padd = self.next_iter_decrypt_prepared['add']
+            pminus = self.next_iter_decrypt_prepared['minus']
+            self._check_prepared_len(padd, n)
+            din = eng.upload(limbs)
+            dout = eng.alloc_vec(n)
+            eng.combine_dev(n, din, eng.limbs, padd.buf, pminus.buf, dout)
+            if online:                                                    # extras merged in (:557-564)
+                eng.decrypt_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, dout, dout)
+            out = dout.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
+        for d in (self.next_iter_decrypt_prepared, self.next_iter_decrypt_prepared_idx):
+            for k in ('add', 'minus'):
+                if k in d:
+                    del d[k]
+        return _from_limbs(out, kind)
+
+    def decrypt(self, ciphertext):                                       # jzf_flashe.py:584-594
+        if self.prp_seed is not None:
+            if not isinstance(ciphertext, np.ndarray):
+                return None
+            if self.masking_scheme == "double":
+                return self._decrypt_double(ciphertext)
+            return self._decrypt_single(ciphertext)
+        return None
+
+    # ------------------------------------------------------------------ mask precompute
+    def _prepare(self, it, add_idx, minus_idx):
+        eng = self._engine
+        n = self.num_params
+        va, vm = _DevVec(eng, n), _DevVec(eng, n)
+        eng.mask_dev(it, [add_idx], n, N_JOBS, va.buf)
+        eng.mask_dev(it, [minus_idx], n, N_JOBS, vm.buf)
+        eng.sync()
+        return va, vm
+
+    def prepare_encrypt(self):                                           # jzf_flashe.py:599-631
+        (self.iter_index + 1).to_bytes(4, 'big')                          # same range check as the reference
+        va, vm = self._prepare(self.iter_index + 1, self.idx, self.idx + 1)
+        self.next_iter_encrypt_prepared = {'add': va, 'minus': vm}
+
+    def prepare_decrypt(self):                                           # jzf_flashe.py:633-666
+        va, vm = self._prepare(self.iter_index, self.num_clients, 0)
+        self.next_iter_decrypt_prepared['add'] = va
+        self.next_iter_decrypt_prepared['minus'] = vm
+        self.next_iter_decrypt_prepared_idx['add'] = [self.num_clients]
+        self.next_iter_decrypt_prepared_idx['minus'] = [0]
+
+    # ------------------------------------------------------------------ arbiter reduce (new)
+    def aggregate(self, ciphertexts, packed=False):
+        """Server-side reduce of a list of ciphertext vectors.  The reference has no such method;
+        this equals Arbiter.aggregate_model's flashe branch: element-wise
+        (jzf_aggregator.py:424-430) or, with packed=True, on the bit-packed integers
+        (jzf_aggregator.py:406-419), returned unpacked."""
+        eng = self._engine or self._engine_cls(bytes(32), self.int_bits, device=self._device)
+        return aggregate(ciphertexts, self.int_bits, packed=packed, device=self._device, _engine=eng)
+
+
+def aggregate(ciphertexts, int_bits, packed=False, device=0, _engine=None):
+    """reduce(lambda x, y: (x + y) % mod, models) on the GPU.
+
+    packed=False: mod = 1 << int_bits per element (jzf_aggregator.py:424-430).
+    packed=True : every operand is bit-packed (JZFTransferableWeights.compress,
+    jzf_weights.py:155-195), added mod 1 << (int_bits * n) with carries crossing element
+    boundaries (jzf_aggregator.py:406-419), then unpacked again (decompress, :197-231)."""
+    if len(ciphertexts) == 0:
+        raise TypeError("reduce() of empty sequence with no initial value")
+    eng = _engine or Engine(bytes(32), int_bits, device=device)
+    conv = [_to_limbs(np.asarray(c) if not isinstance(c, np.ndarray) else c, eng.limbs) for c in ciphertexts]
+    kind = conv[0][1]
+    arrs = []
+    for a, _k in conv:
+        if a.shape[1] != eng.limbs:
+            a = np.concatenate([a, np.zeros((a.shape[0], eng.limbs - a.shape[1]), dtype=np.uint64)], axis=1)
+        arrs.append(a)
+    n = arrs[0].shape[0]
+    if any(a.shape[0] != n for a in arrs):
+        raise ValueError("operands could not be broadcast together")
+    if not packed:
+        out = eng.aggregate_elem(arrs)
+    else:
+        total_bits = n * int_bits
+        n_limbs = (total_bits + 63) // 64
+        dsrc = [eng.upload(a) for a in arrs]
+        dpk = [eng.alloc(max(n_limbs * 8, 16)) for _ in arrs]
+        for s, p in zip(dsrc, dpk):
+            eng.pack_dev(n, s, p)
+        dsum = eng.alloc(max(n_limbs * 8, 16))
+        eng.aggregate_packed_dev(dpk, n_limbs, total_bits, dsum)
+        dout = eng.alloc_vec(n)
+        eng.unpack_dev(n, dsum, dout)
+        out = dout.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
+    return _from_limbs(out, kind)

@@ -1,0 +1,869 @@
+// C ABI of libflashe_hip.so (see include/flashe.h).  Host-side glue only: context, key
+// schedule, device buffers, argument checks, and the host-pointer convenience wrappers.
+#include "flashe.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace flashe;
+
+// ------------------------------------------------------------------------------------------
+// Host AES-256 (key schedule + one-block encrypt).  GF(2^8) via log/antilog tables, generator 3.
+// ------------------------------------------------------------------------------------------
+namespace {
+
+struct AesTables {
+    uint8_t sbox[256];
+    uint32_t te0[256];
+    AesTables()
+    {
+        uint8_t alog[256], lg[256];
+        uint8_t x = 1;
+        for (int i = 0; i < 255; i++) {
+            alog[i] = x; lg[x] = static_cast<uint8_t>(i);
+            x = static_cast<uint8_t>(x ^ (x << 1) ^ ((x & 0x80) ? 0x1b : 0));   // x *= 3
+        }
+        alog[255] = alog[0];
+        for (int v = 0; v < 256; v++) {
+            const uint8_t inv = v ? alog[(255 - lg[v]) % 255] : 0;
+            uint8_t s = inv, r = inv;
+            for (int k = 0; k < 4; k++) { r = static_cast<uint8_t>((r << 1) | (r >> 7)); s ^= r; }
+            sbox[v] = static_cast<uint8_t>(s ^ 0x63);
+        }
+        for (int v = 0; v < 256; v++) {
+            const uint8_t s = sbox[v];
+            const uint8_t s2 = static_cast<uint8_t>((s << 1) ^ ((s & 0x80) ? 0x1b : 0));
+            const uint8_t s3 = static_cast<uint8_t>(s2 ^ s);
+            te0[v] = (static_cast<uint32_t>(s2) << 24) | (static_cast<uint32_t>(s) << 16) |
+                     (static_cast<uint32_t>(s) << 8) | s3;
+        }
+    }
+};
+
+const AesTables &aes_tables()
+{
+    static const AesTables t;
+    return t;
+}
+
+uint32_t sub_word(uint32_t w)
+{
+    const uint8_t *sb = aes_tables().sbox;
+    return (static_cast<uint32_t>(sb[w >> 24]) << 24) | (static_cast<uint32_t>(sb[(w >> 16) & 0xff]) << 16) |
+           (static_cast<uint32_t>(sb[(w >> 8) & 0xff]) << 8) | sb[w & 0xff];
+}
+
+void expand_key(const uint8_t key[32], RoundKeys *rk)
+{
+    uint32_t *w = rk->w;
+    for (int i = 0; i < 8; i++)
+        w[i] = (static_cast<uint32_t>(key[4 * i]) << 24) | (static_cast<uint32_t>(key[4 * i + 1]) << 16) |
+               (static_cast<uint32_t>(key[4 * i + 2]) << 8) | key[4 * i + 3];
+    uint32_t rcon = 0x01000000u;
+    for (int i = 8; i < 60; i++) {
+        uint32_t t = w[i - 1];
+        if (i % 8 == 0) {
+            t = sub_word((t << 8) | (t >> 24)) ^ rcon;
+            rcon = (rcon << 1) ^ ((rcon & 0x80000000u) ? 0x1b000000u : 0);
+        } else if (i % 8 == 4) {
+            t = sub_word(t);
+        }
+        w[i] = w[i - 8] ^ t;
+    }
+}
+
+inline uint32_t ror(uint32_t v, int r) { return (v >> r) | (v << (32 - r)); }
+
+void host_encrypt_block(const RoundKeys &rk, const uint8_t in[16], uint8_t out[16])
+{
+    const AesTables &T = aes_tables();
+    uint32_t s[4], t[4];
+    for (int i = 0; i < 4; i++)
+        s[i] = ((static_cast<uint32_t>(in[4 * i]) << 24) | (static_cast<uint32_t>(in[4 * i + 1]) << 16) |
+                (static_cast<uint32_t>(in[4 * i + 2]) << 8) | in[4 * i + 3]) ^ rk.w[i];
+    for (int r = 1; r < 14; r++) {
+        for (int j = 0; j < 4; j++)
+            t[j] = T.te0[s[j] >> 24] ^ ror(T.te0[(s[(j + 1) & 3] >> 16) & 0xff], 8) ^
+                   ror(T.te0[(s[(j + 2) & 3] >> 8) & 0xff], 16) ^ ror(T.te0[s[(j + 3) & 3] & 0xff], 24) ^ rk.w[4 * r + j];
+        memcpy(s, t, sizeof s);
+    }
+    for (int j = 0; j < 4; j++) {
+        t[j] = ((static_cast<uint32_t>(T.sbox[s[j] >> 24]) << 24) |
+                (static_cast<uint32_t>(T.sbox[(s[(j + 1) & 3] >> 16) & 0xff]) << 16) |
+                (static_cast<uint32_t>(T.sbox[(s[(j + 2) & 3] >> 8) & 0xff]) << 8) |
+                T.sbox[s[(j + 3) & 3] & 0xff]) ^ rk.w[56 + j];
+    }
+    for (int i = 0; i < 4; i++) {
+        out[4 * i] = static_cast<uint8_t>(t[i] >> 24); out[4 * i + 1] = static_cast<uint8_t>(t[i] >> 16);
+        out[4 * i + 2] = static_cast<uint8_t>(t[i] >> 8); out[4 * i + 3] = static_cast<uint8_t>(t[i]);
+    }
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// Context
+// ------------------------------------------------------------------------------------------
+struct flashe_ctx {
+    int device = 0;
+    int int_bits = 0;
+    int limbs = 0;
+    bool own_stream = false;
+    LaunchEnv env{};
+    uint32_t *te0_dev = nullptr;
+    std::string err;
+    // scratch buffers owned by the ctx (grown on demand, reused across calls)
+    struct Buf { void *p = nullptr; size_t cap = 0; };
+    Buf summaries;    // packed-aggregate block summaries
+    Buf stream_tmp;   // whole-vector mask stream for the sparse paths
+    Buf acc_tmp[2];   // ping-pong partial sums when a packed reduce has more than kMaxOps operands
+};
+
+namespace {
+
+int fail(flashe_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                           \
+    do {                                                                                             \
+        hipError_t e_ = (expr);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? FLASHE_ENOMEM : FLASHE_EIO, "%s failed: %s", #expr, \
+                        hipGetErrorString(e_));                                                      \
+    } while (0)
+
+#define CHECK_CTX(ctx)                                                        \
+    do {                                                                      \
+        if (!(ctx)) return FLASHE_EINVAL;                                     \
+        HIP_TRY(ctx, hipSetDevice((ctx)->device));                            \
+    } while (0)
+
+int ensure(flashe_ctx *ctx, flashe_ctx::Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return FLASHE_OK;
+    if (b.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t cap = std::max<size_t>(bytes, 4096);
+    HIP_TRY(ctx, hipMalloc(&b.p, cap));
+    b.cap = cap;
+    return FLASHE_OK;
+}
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+size_t vec_bytes(const flashe_ctx *ctx, uint64_t n) { return static_cast<size_t>(n) * ctx->limbs * 8; }
+
+// RAII temp device buffer for the host-pointer wrappers
+struct Tmp {
+    void *p = nullptr;
+    ~Tmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int flashe_abi_version(void) { return 1; }
+
+int flashe_device_count(int *count)
+{
+    if (!count) return FLASHE_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return FLASHE_ENODEV; }
+    *count = n;
+    return FLASHE_OK;
+}
+
+int flashe_limbs(int int_bits) { return int_bits < 1 || int_bits > 128 ? 0 : (int_bits > 64 ? 2 : 1); }
+
+int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int device, void *stream)
+{
+    if (!out || !key) return fail(nullptr, FLASHE_EINVAL, "flashe_ctx_create: null argument");
+    *out = nullptr;
+    if (int_bits < 1 || int_bits > 128) return fail(nullptr, FLASHE_EINVAL, "int_bits must be in [1, 128], got %d", int_bits);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, FLASHE_ENODEV, "no HIP device available (this engine has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, FLASHE_ENODEV, "device %d out of range (0..%d)", device, ndev - 1);
+    flashe_ctx *ctx = new (std::nothrow) flashe_ctx();
+    if (!ctx) return fail(nullptr, FLASHE_ENOMEM, "out of host memory");
+    ctx->device = device;
+    ctx->int_bits = int_bits;
+    ctx->limbs = int_bits > 64 ? 2 : 1;
+    auto bail = [&](int code, const char *what, hipError_t e) {
+        fail(nullptr, code, "%s: %s", what, hipGetErrorString(e));
+        delete ctx;
+        return code;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(FLASHE_EIO, "hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail(FLASHE_EIO, "hipGetDeviceProperties", e);
+    if (stream) { ctx->env.stream = static_cast<hipStream_t>(stream); }
+    else {
+        if ((e = hipStreamCreateWithFlags(&ctx->env.stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail(FLASHE_EIO, "hipStreamCreate", e);
+        ctx->own_stream = true;
+    }
+    ctx->env.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->env.b = int_bits;
+    if ((e = hipMalloc(&ctx->te0_dev, 1024)) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(te0)", e);
+    if ((e = hipMemcpy(ctx->te0_dev, aes_tables().te0, 1024, hipMemcpyHostToDevice)) != hipSuccess)
+        return bail(FLASHE_EIO, "hipMemcpy(te0)", e);
+    ctx->env.te0_dev = ctx->te0_dev;
+    expand_key(key, &ctx->env.rk);
+    *out = ctx;
+    return FLASHE_OK;
+}
+
+int flashe_ctx_destroy(flashe_ctx *ctx)
+{
+    if (!ctx) return FLASHE_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->env.stream);
+    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1]})
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->env.stream);
+    delete ctx;
+    return FLASHE_OK;
+}
+
+int flashe_ctx_set_key(flashe_ctx *ctx, const uint8_t key[32])
+{
+    if (!ctx || !key) return FLASHE_EINVAL;
+    expand_key(key, &ctx->env.rk);
+    return FLASHE_OK;
+}
+
+int flashe_ctx_int_bits(const flashe_ctx *ctx) { return ctx ? ctx->int_bits : FLASHE_EINVAL; }
+
+const char *flashe_last_error(const flashe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int flashe_selftest(flashe_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    // FIPS-197 C.3 uses its own key; test with the ctx key against the host implementation
+    // and with the FIPS key through a temporary key schedule.
+    static const uint8_t fips_key[32] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                                         16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31};
+    static const uint8_t fips_pt[16] = {0x00, 0x11, 0x22, 0x33, 0x44, 0x55, 0x66, 0x77, 0x88, 0x99, 0xaa, 0xbb, 0xcc, 0xdd, 0xee, 0xff};
+    static const uint8_t fips_ct[16] = {0x8e, 0xa2, 0xb7, 0xca, 0x51, 0x67, 0x45, 0xbf, 0xea, 0xfc, 0x49, 0x90, 0x4b, 0x49, 0x60, 0x89};
+    const int nblk = 2048 + 3;
+    std::vector<uint32_t> in(4 * nblk), out(4 * nblk);
+    for (int i = 0; i < nblk; i++) {
+        for (int j = 0; j < 4; j++)
+            in[4 * i + j] = i == 0 ? ((static_cast<uint32_t>(fips_pt[4 * j]) << 24) | (static_cast<uint32_t>(fips_pt[4 * j + 1]) << 16) |
+                                      (static_cast<uint32_t>(fips_pt[4 * j + 2]) << 8) | fips_pt[4 * j + 3])
+                                   : static_cast<uint32_t>(0x9e3779b9u * (4 * i + j + 1) ^ (i << 7));
+    }
+    Tmp din, dout;
+    HIP_TRY(ctx, din.alloc(in.size() * 4));
+    HIP_TRY(ctx, dout.alloc(out.size() * 4));
+    LaunchEnv env = ctx->env;
+    expand_key(fips_key, &env.rk);
+    HIP_TRY(ctx, hipMemcpyAsync(din.p, in.data(), in.size() * 4, hipMemcpyHostToDevice, env.stream));
+    HIP_TRY(ctx, launch_aes_blocks(env, nblk, din.as<uint32_t>(), dout.as<uint32_t>()));
+    HIP_TRY(ctx, hipMemcpyAsync(out.data(), dout.p, out.size() * 4, hipMemcpyDeviceToHost, env.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(env.stream));
+    for (int i = 0; i < nblk; i++) {
+        uint8_t bi[16], bo[16];
+        for (int j = 0; j < 4; j++) {
+            bi[4 * j] = static_cast<uint8_t>(in[4 * i + j] >> 24); bi[4 * j + 1] = static_cast<uint8_t>(in[4 * i + j] >> 16);
+            bi[4 * j + 2] = static_cast<uint8_t>(in[4 * i + j] >> 8); bi[4 * j + 3] = static_cast<uint8_t>(in[4 * i + j]);
+        }
+        host_encrypt_block(env.rk, bi, bo);
+        if (i == 0 && memcmp(bo, fips_ct, 16) != 0) return fail(ctx, FLASHE_EIO, "host AES fails FIPS-197 C.3");
+        for (int j = 0; j < 4; j++) {
+            const uint32_t w = (static_cast<uint32_t>(bo[4 * j]) << 24) | (static_cast<uint32_t>(bo[4 * j + 1]) << 16) |
+                               (static_cast<uint32_t>(bo[4 * j + 2]) << 8) | bo[4 * j + 3];
+            if (w != out[4 * i + j])
+                return fail(ctx, FLASHE_EIO, "device AES mismatch at block %d word %d: got %08x want %08x", i, j, out[4 * i + j], w);
+        }
+    }
+    return FLASHE_OK;
+}
+
+// ---- host logic ----
+int flashe_chunks(uint64_t n, uint32_t n_jobs, uint64_t *begins)
+{
+    if (!begins || n_jobs == 0) return FLASHE_EINVAL;
+    const uint64_t d = n / n_jobs, r = n % n_jobs;
+    for (uint64_t i = 0; i <= n_jobs; i++) begins[i] = i < r ? (d + 1) * i : (d + 1) * r + d * (i - r);
+    return FLASHE_OK;
+}
+
+int flashe_telescope(uint32_t *raw, int n_raw, uint32_t *add_out, uint32_t *minus_out, int *n_runs)
+{
+    if (n_raw < 0 || !n_runs || (n_raw && (!raw || !add_out || !minus_out))) return FLASHE_EINVAL;
+    std::sort(raw, raw + n_raw);
+    int k = 0;
+    for (int i = 0; i < n_raw; i++) {
+        // a value equal to the open run's end (last + 1) extends it; anything else, duplicates
+        // included, opens a new run
+        if (k > 0 && raw[i] == add_out[k - 1]) { add_out[k - 1] = raw[i] + 1; continue; }
+        add_out[k] = raw[i] + 1; minus_out[k] = raw[i]; k++;
+    }
+    *n_runs = k;
+    return FLASHE_OK;
+}
+
+int flashe_prp_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16])
+{
+    if (!key || !in || !out) return FLASHE_EINVAL;
+    RoundKeys rk;
+    expand_key(key, &rk);
+    host_encrypt_block(rk, in, out);
+    return FLASHE_OK;
+}
+
+// ---- memory / stream / events ----
+int flashe_dev_alloc(flashe_ctx *ctx, size_t bytes, void **dptr)
+{
+    CHECK_CTX(ctx);
+    if (!dptr) return fail(ctx, FLASHE_EINVAL, "flashe_dev_alloc: null out pointer");
+    HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    return FLASHE_OK;
+}
+int flashe_dev_free(flashe_ctx *ctx, void *dptr)
+{
+    CHECK_CTX(ctx);
+    if (dptr) { HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); HIP_TRY(ctx, hipFree(dptr)); }
+    return FLASHE_OK;
+}
+int flashe_memcpy_h2d(flashe_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    if (bytes) { HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->env.stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); }
+    return FLASHE_OK;
+}
+int flashe_memcpy_d2h(flashe_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    if (bytes) { HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->env.stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); }
+    return FLASHE_OK;
+}
+int flashe_memcpy_d2d(flashe_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->env.stream));
+    return FLASHE_OK;
+}
+int flashe_memset_dev(flashe_ctx *ctx, void *dst, int byte, size_t bytes)
+{
+    CHECK_CTX(ctx);
+    if (bytes) HIP_TRY(ctx, hipMemsetAsync(dst, byte, bytes, ctx->env.stream));
+    return FLASHE_OK;
+}
+int flashe_sync(flashe_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
+    return FLASHE_OK;
+}
+int flashe_event_create(flashe_ctx *ctx, void **event)
+{
+    CHECK_CTX(ctx);
+    if (!event) return fail(ctx, FLASHE_EINVAL, "null event pointer");
+    hipEvent_t ev;
+    HIP_TRY(ctx, hipEventCreate(&ev));
+    *event = ev;
+    return FLASHE_OK;
+}
+int flashe_event_destroy(flashe_ctx *ctx, void *event)
+{
+    CHECK_CTX(ctx);
+    if (event) HIP_TRY(ctx, hipEventDestroy(static_cast<hipEvent_t>(event)));
+    return FLASHE_OK;
+}
+int flashe_event_record(flashe_ctx *ctx, void *event)
+{
+    CHECK_CTX(ctx);
+    HIP_TRY(ctx, hipEventRecord(static_cast<hipEvent_t>(event), ctx->env.stream));
+    return FLASHE_OK;
+}
+int flashe_event_elapsed_ms(flashe_ctx *ctx, void *start, void *stop, float *ms)
+{
+    CHECK_CTX(ctx);
+    if (!ms) return fail(ctx, FLASHE_EINVAL, "null ms pointer");
+    HIP_TRY(ctx, hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+    HIP_TRY(ctx, hipEventElapsedTime(ms, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+    return FLASHE_OK;
+}
+
+// ---- PRF / encrypt / decrypt ----
+static int check_prf_args(flashe_ctx *ctx, int n_add, int n_minus, uint32_t n_jobs, const void *out, const void *in, int in_limbs)
+{
+    if (n_add < 0 || n_minus < 0 || n_add > kMaxIdx || n_minus > kMaxIdx)
+        return fail(ctx, FLASHE_EINVAL, "prefix list length out of range (max %d): add %d minus %d", kMaxIdx, n_add, n_minus);
+    if (n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "n_jobs must be >= 1");
+    if (in && in_limbs != 1 && in_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 or %d, got %d", ctx->limbs, in_limbs);
+    if (in && ctx->limbs == 1 && in_limbs != 1) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 for int_bits <= 64");
+    if (ctx->limbs == 2 && (!aligned16(out) || (in && in_limbs == 2 && !aligned16(in))))
+        return fail(ctx, FLASHE_EINVAL, "device vectors of 2-limb elements must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) & 7u)
+        return fail(ctx, FLASHE_EINVAL, "device vectors must be 8-byte aligned");
+    return FLASHE_OK;
+}
+
+int flashe_mask_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx, uint64_t n, uint32_t n_jobs, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && !out_dev) return fail(ctx, FLASHE_EINVAL, "null output");
+    int rc = check_prf_args(ctx, n_idx, 0, n_jobs, out_dev, nullptr, 0);
+    if (rc) return rc;
+    if (n_idx == 0) { if (n) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, n), ctx->env.stream)); return FLASHE_OK; }
+    HIP_TRY(ctx, launch_prf(ctx->env, iter, idx, n_idx, nullptr, 0, n, n_jobs, 0, n, nullptr, 0, out_dev));
+    return FLASHE_OK;
+}
+
+int flashe_encrypt_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uint64_t n, uint32_t n_jobs,
+                       const uint64_t *pt_dev, int pt_limbs, uint64_t *ct_dev)
+{
+    CHECK_CTX(ctx);
+    if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    if (n && (!pt_dev || !ct_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev, pt_dev, pt_limbs);
+    if (rc) return rc;
+    const uint32_t add = idx, minus = idx + 1;
+    HIP_TRY(ctx, launch_prf(ctx->env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, 0, n, pt_dev, pt_limbs, ct_dev));
+    return FLASHE_OK;
+}
+
+int flashe_decrypt_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                       uint64_t n, uint32_t n_jobs, const uint64_t *in_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_prf_args(ctx, n_add, n_minus, n_jobs, out_dev, in_dev, ctx->limbs);
+    if (rc) return rc;
+    if (n_add == 0 && n_minus == 0) {
+        HIP_TRY(ctx, launch_combine(ctx->env, n, in_dev, ctx->limbs, nullptr, nullptr, out_dev));
+        return FLASHE_OK;
+    }
+    HIP_TRY(ctx, launch_prf(ctx->env, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, 0, n, in_dev, ctx->limbs, out_dev));
+    return FLASHE_OK;
+}
+
+// Range twins: operate on global elements [first, first + count) of an n-element vector.
+static int check_range(flashe_ctx *ctx, uint64_t n, uint64_t first, uint64_t count)
+{
+    if (first > n || count > n - first) return fail(ctx, FLASHE_EINVAL, "range [%llu, +%llu) exceeds n = %llu",
+                                                    static_cast<unsigned long long>(first), static_cast<unsigned long long>(count),
+                                                    static_cast<unsigned long long>(n));
+    return FLASHE_OK;
+}
+
+int flashe_mask_range_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx, uint64_t n, uint32_t n_jobs,
+                          uint64_t first, uint64_t count, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (count && !out_dev) return fail(ctx, FLASHE_EINVAL, "null output");
+    int rc = check_prf_args(ctx, n_idx, 0, n_jobs, out_dev, nullptr, 0);
+    if (rc || (rc = check_range(ctx, n, first, count))) return rc;
+    if (n_idx == 0) { if (count) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, count), ctx->env.stream)); return FLASHE_OK; }
+    HIP_TRY(ctx, launch_prf(ctx->env, iter, idx, n_idx, nullptr, 0, n, n_jobs, first, count, nullptr, 0, out_dev));
+    return FLASHE_OK;
+}
+
+int flashe_encrypt_range_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uint64_t n, uint32_t n_jobs,
+                             uint64_t first, uint64_t count, const uint64_t *pt_dev, int pt_limbs, uint64_t *ct_dev)
+{
+    CHECK_CTX(ctx);
+    if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    if (count && (!pt_dev || !ct_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev, pt_dev, pt_limbs);
+    if (rc || (rc = check_range(ctx, n, first, count))) return rc;
+    const uint32_t add = idx, minus = idx + 1;
+    HIP_TRY(ctx, launch_prf(ctx->env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, first, count,
+                            pt_dev, pt_limbs, ct_dev));
+    return FLASHE_OK;
+}
+
+int flashe_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx,
+                             int n_minus, uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
+                             const uint64_t *in_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (count && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_prf_args(ctx, n_add, n_minus, n_jobs, out_dev, in_dev, ctx->limbs);
+    if (rc || (rc = check_range(ctx, n, first, count))) return rc;
+    if (n_add == 0 && n_minus == 0) {
+        HIP_TRY(ctx, launch_combine(ctx->env, count, in_dev, ctx->limbs, nullptr, nullptr, out_dev));
+        return FLASHE_OK;
+    }
+    HIP_TRY(ctx, launch_prf(ctx->env, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, first, count, in_dev, ctx->limbs, out_dev));
+    return FLASHE_OK;
+}
+
+int flashe_combine_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, int in_limbs, const uint64_t *add_dev,
+                       const uint64_t *minus_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (in_limbs != 1 && in_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 or %d", ctx->limbs);
+    if (ctx->limbs == 2 && (!aligned16(out_dev) || !aligned16(add_dev) || !aligned16(minus_dev) || (in_limbs == 2 && !aligned16(in_dev))))
+        return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    HIP_TRY(ctx, launch_combine(ctx->env, n, in_dev, in_limbs, add_dev, minus_dev, out_dev));
+    return FLASHE_OK;
+}
+
+// ---- arbiter reduce ----
+int flashe_aggregate_elem_dev(flashe_ctx *ctx, int C, const uint64_t *const *cts_dev, uint64_t n, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (C < 1 || !cts_dev || (n && !out_dev)) return fail(ctx, FLASHE_EINVAL, "aggregate_elem: bad arguments (C = %d)", C);
+    if (!aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    for (int c = 0; c < C; c++)
+        if (!cts_dev[c] || !aligned16(cts_dev[c])) return fail(ctx, FLASHE_EINVAL, "operand %d is null or not 16-byte aligned", c);
+    if (n == 0) return FLASHE_OK;
+    // at most kMaxOps operands per pass; later passes fold the running sum (out) back in
+    std::vector<const uint64_t *> ops;
+    int done = 0;
+    while (done < C) {
+        ops.clear();
+        if (done) ops.push_back(out_dev);
+        while (done < C && static_cast<int>(ops.size()) < kMaxOps) ops.push_back(cts_dev[done++]);
+        HIP_TRY(ctx, launch_aggregate_elem(ctx->env, static_cast<int>(ops.size()), ops.data(), n, out_dev));
+    }
+    return FLASHE_OK;
+}
+
+int flashe_aggregate_packed_dev(flashe_ctx *ctx, int C, const uint64_t *const *packed_dev, uint64_t n_limbs, uint64_t total_bits,
+                                uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (C < 1 || !packed_dev || (n_limbs && !out_dev)) return fail(ctx, FLASHE_EINVAL, "aggregate_packed: bad arguments (C = %d)", C);
+    if (n_limbs != (total_bits + 63) / 64) return fail(ctx, FLASHE_EINVAL, "n_limbs must equal ceil(total_bits / 64)");
+    if (!aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    for (int c = 0; c < C; c++)
+        if (!packed_dev[c] || !aligned16(packed_dev[c])) return fail(ctx, FLASHE_EINVAL, "operand %d is null or not 16-byte aligned", c);
+    for (int c = 0; c < C; c++)
+        if (packed_dev[c] == out_dev) return fail(ctx, FLASHE_EINVAL, "aggregate_packed: out must not alias operand %d", c);
+    if (n_limbs == 0) return FLASHE_OK;
+    int rc = ensure(ctx, ctx->summaries, packed_num_blocks(n_limbs) * sizeof(uint32_t));
+    if (rc) return rc;
+    uint32_t *summ = static_cast<uint32_t *>(ctx->summaries.p);
+    // at most kMaxOps operands per pass; partial sums ping-pong through ctx scratch so that a
+    // pass never writes a buffer it reads
+    std::vector<const uint64_t *> ops;
+    const uint64_t *partial = nullptr;
+    int done = 0, flip = 0;
+    while (done < C) {
+        ops.clear();
+        if (partial) ops.push_back(partial);
+        while (done < C && static_cast<int>(ops.size()) < kMaxOps) ops.push_back(packed_dev[done++]);
+        uint64_t *dst = out_dev;
+        if (done < C) {
+            rc = ensure(ctx, ctx->acc_tmp[flip], static_cast<size_t>(n_limbs) * 8);
+            if (rc) return rc;
+            dst = static_cast<uint64_t *>(ctx->acc_tmp[flip].p);
+            flip ^= 1;
+        }
+        HIP_TRY(ctx, launch_aggregate_packed(ctx->env, static_cast<int>(ops.size()), ops.data(), n_limbs, total_bits, dst, summ));
+        partial = dst;
+    }
+    return FLASHE_OK;
+}
+
+// ---- codec ----
+int flashe_pack_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (ctx->limbs == 2 && !aligned16(in_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    HIP_TRY(ctx, launch_pack(ctx->env, n, in_dev, out_dev));
+    return FLASHE_OK;
+}
+int flashe_unpack_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    HIP_TRY(ctx, launch_unpack(ctx->env, n, in_dev, out_dev));
+    return FLASHE_OK;
+}
+
+// ---- sparse ----
+int flashe_expand_to_dense_dev(flashe_ctx *ctx, uint64_t total, uint64_t k, const uint32_t *loc_dev, const uint64_t *vals_dev,
+                               const uint64_t *zero, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (!zero || (total && !out_dev) || (k && (!loc_dev || !vals_dev))) return fail(ctx, FLASHE_EINVAL, "null argument");
+    if (ctx->limbs == 2 && (!aligned16(out_dev) || !aligned16(vals_dev))) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    HIP_TRY(ctx, launch_fill(ctx->env, total, zero[0], ctx->limbs == 2 ? zero[1] : 0, out_dev));
+    HIP_TRY(ctx, launch_scatter(ctx->env, k, loc_dev, vals_dev, out_dev, false));
+    return FLASHE_OK;
+}
+
+int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                 uint64_t total, uint32_t n_jobs, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (C < 0 || (C && (!loc_dev || !k)) || (total && !out_dev) || n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "bad arguments");
+    if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    if (total) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
+    uint64_t kmax = 0;
+    for (int c = 0; c < C; c++) kmax = std::max(kmax, k[c]);
+    int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kmax));
+    if (rc) return rc;
+    uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
+    for (int c = 0; c < C; c++) {
+        if (!k[c]) continue;
+        const uint32_t idx = static_cast<uint32_t>(c);
+        HIP_TRY(ctx, launch_prf(ctx->env, iter, &idx, 1, nullptr, 0, k[c], n_jobs, 0, k[c], nullptr, 0, tmp));
+        HIP_TRY(ctx, launch_scatter(ctx->env, k[c], loc_dev[c], tmp, out_dev, true));
+    }
+    return FLASHE_OK;
+}
+
+int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel_dev, uint64_t total,
+                                 uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n_lists < 0 || (n_lists && !sel_dev) || (total && !out_dev)) return fail(ctx, FLASHE_EINVAL, "bad arguments");
+    if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    if (total) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
+    int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, total));
+    if (rc) return rc;
+    uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
+    for (int i = 0; i < n_lists; i++) {
+        const uint32_t idx = static_cast<uint32_t>(i);
+        // one chunk with begin = 0 (n_jobs = 1): counters are dense-position block indices
+        HIP_TRY(ctx, launch_prf(ctx->env, iter, &idx, 1, nullptr, 0, total, 1, 0, total, nullptr, 0, tmp));
+        HIP_TRY(ctx, launch_sel_accumulate(ctx->env, total, sel_dev[i], tmp, out_dev));
+    }
+    return FLASHE_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-pointer twins: H2D, the _dev call, D2H, synchronous.
+// ------------------------------------------------------------------------------------------
+#define H2D(dst, src, bytes) HIP_TRY(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, ctx->env.stream))
+#define D2H(dst, src, bytes)                                                                         \
+    do {                                                                                             \
+        HIP_TRY(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, ctx->env.stream)); \
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));                                         \
+    } while (0)
+
+int flashe_mask(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx, uint64_t n, uint32_t n_jobs, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!out) return fail(ctx, FLASHE_EINVAL, "null output");
+    Tmp d;
+    HIP_TRY(ctx, d.alloc(vec_bytes(ctx, n)));
+    int rc = flashe_mask_dev(ctx, iter, idx, n_idx, n, n_jobs, d.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, d.p, vec_bytes(ctx, n));
+    return FLASHE_OK;
+}
+
+int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uint64_t n, uint32_t n_jobs, const uint64_t *pt,
+                   int pt_limbs, uint64_t *ct)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!pt || !ct) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (pt_limbs != 1 && pt_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "pt_limbs must be 1 or %d", ctx->limbs);
+    Tmp dp, dc;
+    HIP_TRY(ctx, dp.alloc(static_cast<size_t>(n) * pt_limbs * 8));
+    HIP_TRY(ctx, dc.alloc(vec_bytes(ctx, n)));
+    H2D(dp.p, pt, static_cast<size_t>(n) * pt_limbs * 8);
+    int rc = flashe_encrypt_dev(ctx, iter, idx, scheme, n, n_jobs, dp.as<uint64_t>(), pt_limbs, dc.as<uint64_t>());
+    if (rc) return rc;
+    D2H(ct, dc.p, vec_bytes(ctx, n));
+    return FLASHE_OK;
+}
+
+int flashe_decrypt(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                   uint64_t n, uint32_t n_jobs, const uint64_t *in, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
+    Tmp di, dout;
+    HIP_TRY(ctx, di.alloc(vec_bytes(ctx, n)));
+    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, n)));
+    H2D(di.p, in, vec_bytes(ctx, n));
+    int rc = flashe_decrypt_dev(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, di.as<uint64_t>(), dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, n));
+    return FLASHE_OK;
+}
+
+int flashe_combine(flashe_ctx *ctx, uint64_t n, const uint64_t *in, int in_limbs, const uint64_t *add, const uint64_t *minus, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (in_limbs != 1 && in_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 or %d", ctx->limbs);
+    Tmp di, da, dm, dout;
+    HIP_TRY(ctx, di.alloc(static_cast<size_t>(n) * in_limbs * 8));
+    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, n)));
+    H2D(di.p, in, static_cast<size_t>(n) * in_limbs * 8);
+    if (add) { HIP_TRY(ctx, da.alloc(vec_bytes(ctx, n))); H2D(da.p, add, vec_bytes(ctx, n)); }
+    if (minus) { HIP_TRY(ctx, dm.alloc(vec_bytes(ctx, n))); H2D(dm.p, minus, vec_bytes(ctx, n)); }
+    int rc = flashe_combine_dev(ctx, n, di.as<uint64_t>(), in_limbs, add ? da.as<uint64_t>() : nullptr,
+                                minus ? dm.as<uint64_t>() : nullptr, dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, n));
+    return FLASHE_OK;
+}
+
+int flashe_aggregate_elem(flashe_ctx *ctx, int C, const uint64_t *const *cts, uint64_t n, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (C < 1 || !cts) return fail(ctx, FLASHE_EINVAL, "aggregate_elem: bad arguments (C = %d)", C);
+    if (n == 0) return FLASHE_OK;
+    if (!out) return fail(ctx, FLASHE_EINVAL, "null output");
+    const size_t vb = (vec_bytes(ctx, n) + 15) & ~static_cast<size_t>(15);
+    Tmp all, dout;
+    HIP_TRY(ctx, all.alloc(vb * C));
+    HIP_TRY(ctx, dout.alloc(vb));
+    std::vector<const uint64_t *> ptrs(C);
+    for (int c = 0; c < C; c++) {
+        if (!cts[c]) return fail(ctx, FLASHE_EINVAL, "operand %d is null", c);
+        ptrs[c] = reinterpret_cast<const uint64_t *>(all.as<char>() + vb * c);
+        H2D(const_cast<uint64_t *>(ptrs[c]), cts[c], vec_bytes(ctx, n));
+    }
+    int rc = flashe_aggregate_elem_dev(ctx, C, ptrs.data(), n, dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, n));
+    return FLASHE_OK;
+}
+
+int flashe_aggregate_packed(flashe_ctx *ctx, int C, const uint64_t *const *packed, uint64_t n_limbs, uint64_t total_bits, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (C < 1 || !packed) return fail(ctx, FLASHE_EINVAL, "aggregate_packed: bad arguments (C = %d)", C);
+    if (n_limbs != (total_bits + 63) / 64) return fail(ctx, FLASHE_EINVAL, "n_limbs must equal ceil(total_bits / 64)");
+    if (n_limbs == 0) return FLASHE_OK;
+    if (!out) return fail(ctx, FLASHE_EINVAL, "null output");
+    const size_t vb = (static_cast<size_t>(n_limbs) * 8 + 15) & ~static_cast<size_t>(15);
+    Tmp all, dout;
+    HIP_TRY(ctx, all.alloc(vb * C));
+    HIP_TRY(ctx, dout.alloc(vb));
+    std::vector<const uint64_t *> ptrs(C);
+    for (int c = 0; c < C; c++) {
+        if (!packed[c]) return fail(ctx, FLASHE_EINVAL, "operand %d is null", c);
+        ptrs[c] = reinterpret_cast<const uint64_t *>(all.as<char>() + vb * c);
+        H2D(const_cast<uint64_t *>(ptrs[c]), packed[c], static_cast<size_t>(n_limbs) * 8);
+    }
+    int rc = flashe_aggregate_packed_dev(ctx, C, ptrs.data(), n_limbs, total_bits, dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, static_cast<size_t>(n_limbs) * 8);
+    return FLASHE_OK;
+}
+
+int flashe_pack(flashe_ctx *ctx, uint64_t n, const uint64_t *in, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
+    const size_t ob = static_cast<size_t>((n * ctx->int_bits + 63) / 64) * 8;
+    Tmp di, dout;
+    HIP_TRY(ctx, di.alloc(vec_bytes(ctx, n)));
+    HIP_TRY(ctx, dout.alloc(ob));
+    H2D(di.p, in, vec_bytes(ctx, n));
+    int rc = flashe_pack_dev(ctx, n, di.as<uint64_t>(), dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, ob);
+    return FLASHE_OK;
+}
+
+int flashe_unpack(flashe_ctx *ctx, uint64_t n, const uint64_t *in, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
+    const size_t ib = static_cast<size_t>((n * ctx->int_bits + 63) / 64) * 8;
+    Tmp di, dout;
+    HIP_TRY(ctx, di.alloc(ib));
+    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, n)));
+    H2D(di.p, in, ib);
+    int rc = flashe_unpack_dev(ctx, n, di.as<uint64_t>(), dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, n));
+    return FLASHE_OK;
+}
+
+int flashe_expand_to_dense(flashe_ctx *ctx, uint64_t total, uint64_t k, const uint32_t *loc, const uint64_t *vals,
+                           const uint64_t *zero, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (total == 0) return FLASHE_OK;
+    if (!out || !zero || (k && (!loc || !vals))) return fail(ctx, FLASHE_EINVAL, "null argument");
+    for (uint64_t q = 0; q < k; q++)
+        if (loc[q] >= total) return fail(ctx, FLASHE_EINVAL, "location %llu out of range", static_cast<unsigned long long>(loc[q]));
+    Tmp dl, dv, dout;
+    HIP_TRY(ctx, dl.alloc(static_cast<size_t>(k) * 4));
+    HIP_TRY(ctx, dv.alloc(vec_bytes(ctx, k)));
+    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, total)));
+    if (k) { H2D(dl.p, loc, static_cast<size_t>(k) * 4); H2D(dv.p, vals, vec_bytes(ctx, k)); }
+    int rc = flashe_expand_to_dense_dev(ctx, total, k, dl.as<uint32_t>(), dv.as<uint64_t>(), zero, dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, total));
+    return FLASHE_OK;
+}
+
+int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc, const uint64_t *k, uint64_t total,
+                             uint32_t n_jobs, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (total == 0) return FLASHE_OK;
+    if (C < 0 || (C && (!loc || !k)) || !out) return fail(ctx, FLASHE_EINVAL, "bad arguments");
+    std::vector<Tmp> dl(C);
+    std::vector<const uint32_t *> ptrs(C);
+    for (int c = 0; c < C; c++) {
+        for (uint64_t q = 0; q < k[c]; q++)
+            if (loc[c][q] >= total) return fail(ctx, FLASHE_EINVAL, "client %d location out of range", c);
+        HIP_TRY(ctx, dl[c].alloc(static_cast<size_t>(k[c]) * 4));
+        if (k[c]) H2D(dl[c].p, loc[c], static_cast<size_t>(k[c]) * 4);
+        ptrs[c] = dl[c].as<uint32_t>();
+    }
+    Tmp dout;
+    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, total)));
+    int rc = flashe_sparse_minus_mask_dev(ctx, iter, C, ptrs.data(), k, total, n_jobs, dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, total));
+    return FLASHE_OK;
+}
+
+int flashe_sparse_dense_mask(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel, uint64_t total, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (total == 0) return FLASHE_OK;
+    if (n_lists < 0 || (n_lists && !sel) || !out) return fail(ctx, FLASHE_EINVAL, "bad arguments");
+    std::vector<Tmp> ds(n_lists);
+    std::vector<const uint8_t *> ptrs(n_lists);
+    for (int i = 0; i < n_lists; i++) {
+        HIP_TRY(ctx, ds[i].alloc(static_cast<size_t>(total)));
+        H2D(ds[i].p, sel[i], static_cast<size_t>(total));
+        ptrs[i] = ds[i].as<uint8_t>();
+    }
+    Tmp dout;
+    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, total)));
+    int rc = flashe_sparse_dense_mask_dev(ctx, iter, n_lists, ptrs.data(), total, dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, total));
+    return FLASHE_OK;
+}
+
+}  // extern "C"

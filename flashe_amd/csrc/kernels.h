@@ -1,0 +1,62 @@
+// Internal launch interface between the C ABI (abi.hip) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace flashe {
+
+// AES-256 expanded key, 60 big-endian words; passed to kernels by value (lands in SGPRs).
+struct RoundKeys { uint32_t w[60]; };
+
+// Everything a launch needs that is not a per-call argument.
+struct LaunchEnv {
+    hipStream_t stream;
+    int num_cus;
+    const uint32_t *te0_dev;   // 256-entry Te0 table in device memory (1 KiB)
+    RoundKeys rk;
+    int b;                     // int_bits
+};
+
+// out = (in? + sum_{k<n_add} term(iter, add[k]) - sum_{k<n_minus} term(iter, minus[k])) mod 2^b.
+// add/minus are HOST arrays (copied into the kernel argument block; at most kMaxIdx each).
+constexpr int kMaxIdx = 96;
+// The launch covers global elements [first, first + count) of an n-element vector; in_dev / out_dev
+// are indexed by (element - first).  n and n_jobs define the chunking (b <= 64).
+hipError_t launch_prf(const LaunchEnv &env, uint32_t iter,
+                      const uint32_t *add, int n_add, const uint32_t *minus, int n_minus,
+                      uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
+                      const uint64_t *in_dev, int in_limbs, uint64_t *out_dev);
+
+hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
+                          const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);
+
+// Operand pointers of one reduce pass travel in the kernel argument block (scalar loads).
+constexpr int kMaxOps = 64;
+struct PtrTable { const uint64_t *p[kMaxOps]; };
+
+// ops: HOST array of C <= kMaxOps device pointers.  out may alias an operand.
+hipError_t launch_aggregate_elem(const LaunchEnv &env, int C, const uint64_t *const *ops,
+                                 uint64_t n, uint64_t *out_dev);
+
+// summaries_dev: scratch of at least packed_num_blocks(n_limbs) uint32 words.
+// out must NOT alias an operand (blocks re-read their left neighbour's inputs).
+uint64_t packed_num_blocks(uint64_t n_limbs);
+hipError_t launch_aggregate_packed(const LaunchEnv &env, int C, const uint64_t *const *ops,
+                                   uint64_t n_limbs, uint64_t total_bits, uint64_t *out_dev,
+                                   uint32_t *summaries_dev);
+
+hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
+hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
+
+hipError_t launch_fill(const LaunchEnv &env, uint64_t n, uint64_t lo, uint64_t hi, uint64_t *out_dev);
+hipError_t launch_scatter(const LaunchEnv &env, uint64_t k, const uint32_t *loc_dev,
+                          const uint64_t *vals_dev, uint64_t *out_dev, bool accumulate);
+// out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
+hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uint8_t *sel_dev,
+                                 const uint64_t *stream_dev, uint64_t *out_dev);
+
+// Device KAT: encrypts `nblk` 16-byte blocks (big-endian words in) with the PRF core.
+hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t *in_words_dev,
+                             uint32_t *out_words_dev);
+
+}  // namespace flashe

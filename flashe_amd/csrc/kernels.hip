@@ -1,0 +1,792 @@
+// gfx950 (MI355X / CDNA4) kernels of the FLASHE cipher engine.
+//
+// Everything here is integer / byte work, bounded either by the AES-256 PRF rate (LDS
+// T-table lookups + VALU) or by HBM streaming -- no MFMA.  Design notes:
+//   * PRF = AES-256 over (iter | idx | counter) blocks.  The four T-tables live in LDS,
+//     replicated 32x so that every lane of a 32-lane LDS service group owns a private bank
+//     (ds_read_b32 banks = (addr/4) mod 32): entry stride 256 B, two tables per 64-KiB half.
+//     A lookup address is built by ONE v_perm_b32 (state byte -> address byte 1, lane offset ->
+//     byte 0, half select -> byte 2) and the table choice rides in the ds_read immediate offset.
+//   * one lane = one element (b > 64) or one AES block = m elements (b <= 64); 16 B per lane
+//     on every global access of the wide path, so loads and stores are full 1-KiB wave bursts.
+//   * persistent launch: one 1024-thread workgroup per CU (128 KiB of LDS tables), tiles dealt
+//     round-robin; there is no inter-workgroup reuse, so no XCD remap is needed.
+#include "kernels.h"
+
+namespace flashe {
+
+typedef unsigned __int128 u128;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
+// ------------------------------------------------------------------------------------------
+// AES-256 core
+// ------------------------------------------------------------------------------------------
+constexpr int kTabWords = 32768;                 // 128 KiB: 4 tables x 256 entries x 32 copies
+constexpr int kPrfThreads = 1024;
+
+// v_perm_b32 selectors: D = {0x00, lanereg.byte2, state.byte_k, lanereg.byte0}
+// (selector bytes 0-3 pick from the second operand, 4-7 from the first, 0x0c = zero)
+#define SEL_B0 0x0c020400u
+#define SEL_B1 0x0c020500u
+#define SEL_B2 0x0c020600u
+#define SEL_B3 0x0c020700u
+
+// LDS byte offset of a __shared__ object (address-space cast, folded at compile time).
+__device__ __forceinline__ uint32_t lds_offset(uint32_t *shared_obj)
+{
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u32 *)shared_obj));
+}
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t v, int r) { return (v >> r) | (v << ((32 - r) & 31)); }
+
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+
+// Replicated T-tables.  Table t, entry x, copy k (k = lane & 31) at byte
+//   (t >> 1) * 65536 + x * 256 + (t & 1) * 128 + k * 4
+__device__ __forceinline__ void fill_tables(uint32_t *tab, const uint32_t *te0)
+{
+    for (int e = threadIdx.x; e < 1024; e += blockDim.x) {
+        const int t = e >> 8, x = e & 255;
+        const uint32_t v = rotr32(te0[x], 8 * t);
+        uint4 vv = make_uint4(v, v, v, v);
+        uint4 *dst = reinterpret_cast<uint4 *>(tab + ((t >> 1) * 16384 + x * 64 + (t & 1) * 32));
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = vv;
+    }
+    __syncthreads();
+}
+
+struct LaneRegs { uint32_t a, b; };   // a: tables 0/1 (low half), b: tables 2/3 (high half)
+
+__device__ __forceinline__ LaneRegs lane_regs()
+{
+    const uint32_t lane4 = (threadIdx.x & 31u) * 4u;
+    return LaneRegs{lane4, lane4 | 0x00010000u};
+}
+
+template <int OFF>
+__device__ __forceinline__ uint32_t lut(uint32_t w, uint32_t lanereg, uint32_t sel)
+{
+    const uint32_t addr = __builtin_amdgcn_perm(w, lanereg, sel);
+    return *reinterpret_cast<lds_u32 *>(static_cast<uintptr_t>(addr + OFF));
+}
+
+#define T0(w, sel) lut<0>(w, lr.a, sel)
+#define T1(w, sel) lut<128>(w, lr.a, sel)
+#define T2(w, sel) lut<0>(w, lr.b, sel)
+#define T3(w, sel) lut<128>(w, lr.b, sel)
+
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)
+{
+    return (a & mask) | (b & ~mask);   // v_bfi_b32
+}
+
+// NB independent blocks, state = 4 big-endian column words each; s already holds plaintext.
+template <int NB>
+__device__ __forceinline__ void aes256_encrypt(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4])
+{
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        s[q][0] ^= rk.w[0]; s[q][1] ^= rk.w[1]; s[q][2] ^= rk.w[2]; s[q][3] ^= rk.w[3];
+    }
+#pragma unroll
+    for (int r = 1; r < 14; r++) {
+#pragma unroll
+        for (int q = 0; q < NB; q++) {
+            uint32_t t[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t x = xor3(T0(s[q][j], SEL_B3), T1(s[q][(j + 1) & 3], SEL_B2),
+                                        T2(s[q][(j + 2) & 3], SEL_B1));
+                t[j] = xor3(x, T3(s[q][(j + 3) & 3], SEL_B0), rk.w[4 * r + j]);
+            }
+            s[q][0] = t[0]; s[q][1] = t[1]; s[q][2] = t[2]; s[q][3] = t[3];
+        }
+    }
+    // final round: SubBytes + ShiftRows + AddRoundKey.  S[x] sits in byte 3 of T2[x], byte 2 of
+    // T3[x], byte 1 of T0[x] and byte 0 of T1[x].
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        uint32_t t[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t v = bfi(0xff000000u, T2(s[q][j], SEL_B3),
+                               bfi(0x00ff0000u, T3(s[q][(j + 1) & 3], SEL_B2),
+                               bfi(0x0000ff00u, T0(s[q][(j + 2) & 3], SEL_B1),
+                                                T1(s[q][(j + 3) & 3], SEL_B0))));
+            t[j] = v ^ rk.w[56 + j];
+        }
+        s[q][0] = t[0]; s[q][1] = t[1]; s[q][2] = t[2]; s[q][3] = t[3];
+    }
+}
+
+__device__ __forceinline__ u128 words_to_u128(const uint32_t (&s)[4])
+{
+    const uint64_t hi = (static_cast<uint64_t>(s[0]) << 32) | s[1];
+    const uint64_t lo = (static_cast<uint64_t>(s[2]) << 32) | s[3];
+    return (static_cast<u128>(hi) << 64) | lo;
+}
+
+__device__ __forceinline__ void set_block(uint32_t (&s)[4], uint32_t iter, uint32_t idx, uint64_t ctr)
+{
+    s[0] = iter; s[1] = idx; s[2] = static_cast<uint32_t>(ctr >> 32); s[3] = static_cast<uint32_t>(ctr);
+}
+
+__device__ __forceinline__ u128 ld128(const uint64_t *p)
+{
+    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(p);
+    return (static_cast<u128>(v.y) << 64) | v.x;
+}
+__device__ __forceinline__ void st128(uint64_t *p, u128 v)
+{
+    *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(static_cast<uint64_t>(v), static_cast<uint64_t>(v >> 64));
+}
+
+struct IdxLists {
+    uint32_t add[kMaxIdx];
+    uint32_t minus[kMaxIdx];
+};
+
+struct PrfParams {
+    const uint64_t *in;    // may be null
+    uint64_t *out;
+    const uint32_t *te0;
+    uint64_t n;            // length of the WHOLE vector (defines the chunking)
+    uint64_t first, count; // this launch covers global elements [first, first + count); in/out are
+                           // indexed by (element - first)
+    uint64_t blk_first, blk_count;   // b <= 64: AES blocks intersecting that range
+    uint64_t mask_lo, mask_hi;
+    uint32_t iter;
+    int in_limbs;
+    int n_add, n_minus;
+    // b <= 64 only:
+    uint32_t n_jobs;
+    int b, m;
+};
+
+// ---- b > 64: one element per lane, counter = element index (m = 1 makes chunks irrelevant) ----
+// MODE 0: generic prefix lists; 1: one add + one minus (encrypt double, no-dropout decrypt);
+// 2: one add, no minus (encrypt single, single mask stream).
+template <int MODE>
+__global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys rk, const PrfParams p, const IdxLists lists)
+{
+    __shared__ uint32_t tab[kTabWords];
+    if (lds_offset(tab) != 0u) __builtin_trap();   // lut() addresses LDS from offset 0
+    fill_tables(tab, p.te0);
+    const LaneRegs lr = lane_regs();
+    const u128 mask = (static_cast<u128>(p.mask_hi) << 64) | p.mask_lo;
+
+    for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kPrfThreads; base < p.count;
+         base += static_cast<uint64_t>(gridDim.x) * kPrfThreads) {
+        const uint64_t e = base + threadIdx.x;          // index into in / out
+        if (e >= p.count) continue;
+        const uint64_t j = p.first + e;                 // global element = PRF counter (m = 1)
+        u128 acc = 0;
+        if (p.in) acc = p.in_limbs == 2 ? ld128(p.in + 2 * e) : static_cast<u128>(p.in[e]);
+        if (MODE == 1) {
+            uint32_t s[2][4];
+            set_block(s[0], p.iter, lists.add[0], j);
+            set_block(s[1], p.iter, lists.minus[0], j);
+            aes256_encrypt<2>(rk, lr, s);
+            acc += words_to_u128(s[0]);
+            acc -= words_to_u128(s[1]);
+        } else if (MODE == 2) {
+            uint32_t s[1][4];
+            set_block(s[0], p.iter, lists.add[0], j);
+            aes256_encrypt<1>(rk, lr, s);
+            acc += words_to_u128(s[0]);
+        } else {
+            int k = 0;
+            for (; k + 1 < p.n_add; k += 2) {
+                uint32_t s[2][4];
+                set_block(s[0], p.iter, lists.add[k], j);
+                set_block(s[1], p.iter, lists.add[k + 1], j);
+                aes256_encrypt<2>(rk, lr, s);
+                acc += words_to_u128(s[0]);
+                acc += words_to_u128(s[1]);
+            }
+            if (k < p.n_add) {
+                uint32_t s[1][4];
+                set_block(s[0], p.iter, lists.add[k], j);
+                aes256_encrypt<1>(rk, lr, s);
+                acc += words_to_u128(s[0]);
+            }
+            k = 0;
+            for (; k + 1 < p.n_minus; k += 2) {
+                uint32_t s[2][4];
+                set_block(s[0], p.iter, lists.minus[k], j);
+                set_block(s[1], p.iter, lists.minus[k + 1], j);
+                aes256_encrypt<2>(rk, lr, s);
+                acc -= words_to_u128(s[0]);
+                acc -= words_to_u128(s[1]);
+            }
+            if (k < p.n_minus) {
+                uint32_t s[1][4];
+                set_block(s[0], p.iter, lists.minus[k], j);
+                aes256_encrypt<1>(rk, lr, s);
+                acc -= words_to_u128(s[0]);
+            }
+        }
+        st128(p.out + 2 * e, acc & mask);
+    }
+}
+
+// ---- b <= 64: one AES block (m = 128 / b elements) per lane, chunk-dependent counters ----
+// Bits [sh, sh + 64) of S (caller masks to b bits).
+__device__ __forceinline__ uint64_t extract64(u128 S, int sh)
+{
+    return sh >= 128 ? 0ull : static_cast<uint64_t>(S >> sh);
+}
+
+constexpr int kSmallThreads = 1024;
+constexpr int kTch = 8;    // elements accumulated in registers per pass
+
+__global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKeys rk, const PrfParams p, const IdxLists lists)
+{
+    __shared__ uint32_t tab[kTabWords];
+    if (lds_offset(tab) != 0u) __builtin_trap();   // lut() addresses LDS from offset 0
+    fill_tables(tab, p.te0);
+    const LaneRegs lr = lane_regs();
+
+    // chunks_idx(range(n), n_jobs) in closed form: the first r chunks have d + 1 elements.
+    const uint64_t J = p.n_jobs, d = p.n / J, r = p.n % J;
+    const uint64_t m = static_cast<uint64_t>(p.m);
+    const uint64_t nb1 = (d + 1 + m - 1) / m;           // AES blocks in a (d+1)-element chunk
+    const uint64_t nb0 = d ? (d + m - 1) / m : 0;       // ... in a d-element chunk
+    const uint64_t range_end = p.first + p.count;
+
+    for (uint64_t Bl = static_cast<uint64_t>(blockIdx.x) * kSmallThreads + threadIdx.x; Bl < p.blk_count;
+         Bl += static_cast<uint64_t>(gridDim.x) * kSmallThreads) {
+        const uint64_t B = p.blk_first + Bl;
+        uint64_t begin, len, i;
+        if (B < r * nb1) {
+            const uint64_t c = B / nb1;
+            i = B - c * nb1; begin = c * (d + 1); len = d + 1;
+        } else {
+            const uint64_t B2 = B - r * nb1, c = B2 / nb0;
+            i = B2 - c * nb0; begin = r * (d + 1) + c * d; len = d;
+        }
+        const uint64_t j0 = begin + i * m;
+        const uint64_t rem = len - i * m;
+        const int cnt = rem < m ? static_cast<int>(rem) : static_cast<int>(m);
+        const uint64_t ctr = begin + i;
+
+        for (int t0 = 0; t0 < cnt; t0 += kTch) {
+            uint64_t acc[kTch];
+#pragma unroll
+            for (int u = 0; u < kTch; u++) {
+                const uint64_t j = j0 + t0 + u;
+                acc[u] = (p.in && t0 + u < cnt && j >= p.first && j < range_end) ? p.in[j - p.first] : 0ull;
+            }
+            int k = 0;
+            for (; k + 1 < p.n_add; k += 2) {
+                uint32_t s[2][4];
+                set_block(s[0], p.iter, lists.add[k], ctr);
+                set_block(s[1], p.iter, lists.add[k + 1], ctr);
+                aes256_encrypt<2>(rk, lr, s);
+                const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
+#pragma unroll
+                for (int u = 0; u < kTch; u++) acc[u] += extract64(S0, p.b * (t0 + u)) + extract64(S1, p.b * (t0 + u));
+            }
+            if (k < p.n_add) {
+                uint32_t s[1][4];
+                set_block(s[0], p.iter, lists.add[k], ctr);
+                aes256_encrypt<1>(rk, lr, s);
+                const u128 S0 = words_to_u128(s[0]);
+#pragma unroll
+                for (int u = 0; u < kTch; u++) acc[u] += extract64(S0, p.b * (t0 + u));
+            }
+            k = 0;
+            for (; k + 1 < p.n_minus; k += 2) {
+                uint32_t s[2][4];
+                set_block(s[0], p.iter, lists.minus[k], ctr);
+                set_block(s[1], p.iter, lists.minus[k + 1], ctr);
+                aes256_encrypt<2>(rk, lr, s);
+                const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
+#pragma unroll
+                for (int u = 0; u < kTch; u++) acc[u] -= extract64(S0, p.b * (t0 + u)) + extract64(S1, p.b * (t0 + u));
+            }
+            if (k < p.n_minus) {
+                uint32_t s[1][4];
+                set_block(s[0], p.iter, lists.minus[k], ctr);
+                aes256_encrypt<1>(rk, lr, s);
+                const u128 S0 = words_to_u128(s[0]);
+#pragma unroll
+                for (int u = 0; u < kTch; u++) acc[u] -= extract64(S0, p.b * (t0 + u));
+            }
+#pragma unroll
+            for (int u = 0; u < kTch; u++) {
+                const uint64_t j = j0 + t0 + u;
+                if (t0 + u < cnt && j >= p.first && j < range_end) p.out[j - p.first] = acc[u] & p.mask_lo;
+            }
+        }
+    }
+}
+
+// Known-answer helper: raw AES of nblk blocks given as big-endian words.
+__global__ __launch_bounds__(kPrfThreads) void aes_blocks_kernel(const RoundKeys rk, const uint32_t *te0, uint32_t nblk,
+                                                                 const uint32_t *in, uint32_t *out)
+{
+    __shared__ uint32_t tab[kTabWords];
+    fill_tables(tab, te0);
+    const LaneRegs lr = lane_regs();
+    for (uint32_t i = blockIdx.x * kPrfThreads + threadIdx.x; i < nblk; i += gridDim.x * kPrfThreads) {
+        uint32_t s[1][4] = {{in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]}};
+        aes256_encrypt<1>(rk, lr, s);
+        out[4 * i] = s[0][0]; out[4 * i + 1] = s[0][1]; out[4 * i + 2] = s[0][2]; out[4 * i + 3] = s[0][3];
+    }
+}
+
+static inline void masks_of(int b, uint64_t *lo, uint64_t *hi)
+{
+    if (b >= 128) { *lo = ~0ull; *hi = ~0ull; }
+    else if (b > 64) { *lo = ~0ull; *hi = (1ull << (b - 64)) - 1; }
+    else if (b == 64) { *lo = ~0ull; *hi = 0; }
+    else { *lo = (1ull << b) - 1; *hi = 0; }
+}
+
+static inline int grid_for(const LaunchEnv &env, uint64_t work_items, int threads)
+{
+    uint64_t blocks = (work_items + threads - 1) / threads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > static_cast<uint64_t>(env.num_cus)) blocks = env.num_cus;
+    return static_cast<int>(blocks);
+}
+
+// AES-block index (in the kernel's global block numbering) of element j of an n-vector.
+static uint64_t block_of(uint64_t j, uint64_t n, uint64_t J, uint64_t m)
+{
+    const uint64_t d = n / J, r = n % J;
+    const uint64_t nb1 = (d + 1 + m - 1) / m, nb0 = d ? (d + m - 1) / m : 0;
+    if (j < r * (d + 1)) { const uint64_t c = j / (d + 1); return c * nb1 + (j - c * (d + 1)) / m; }
+    const uint64_t j2 = j - r * (d + 1), c = j2 / d;
+    return r * nb1 + c * nb0 + (j2 - c * d) / m;
+}
+
+hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, int n_add,
+                      const uint32_t *minus, int n_minus, uint64_t n, uint32_t n_jobs,
+                      uint64_t first, uint64_t count,
+                      const uint64_t *in_dev, int in_limbs, uint64_t *out_dev)
+{
+    if (count == 0) return hipSuccess;
+    IdxLists lists;
+    for (int k = 0; k < kMaxIdx; k++) { lists.add[k] = k < n_add ? add[k] : 0; lists.minus[k] = k < n_minus ? minus[k] : 0; }
+    PrfParams p{};
+    p.in = in_dev; p.out = out_dev; p.te0 = env.te0_dev; p.n = n; p.iter = iter;
+    p.first = first; p.count = count;
+    p.in_limbs = in_limbs; p.n_add = n_add; p.n_minus = n_minus; p.n_jobs = n_jobs;
+    p.b = env.b; p.m = 128 / env.b;
+    masks_of(env.b, &p.mask_lo, &p.mask_hi);
+    if (env.b > 64) {
+        const int grid = grid_for(env, count, kPrfThreads);
+        if (n_add == 1 && n_minus == 1)
+            hipLaunchKernelGGL(prf_wide_kernel<1>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);
+        else if (n_add == 1 && n_minus == 0)
+            hipLaunchKernelGGL(prf_wide_kernel<2>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);
+        else
+            hipLaunchKernelGGL(prf_wide_kernel<0>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);
+    } else {
+        p.blk_first = block_of(first, n, n_jobs, p.m);
+        p.blk_count = block_of(first + count - 1, n, n_jobs, p.m) - p.blk_first + 1;
+        const int grid = grid_for(env, p.blk_count, kSmallThreads);
+        hipLaunchKernelGGL(prf_small_kernel, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, p, lists);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t *in_words_dev, uint32_t *out_words_dev)
+{
+    hipLaunchKernelGGL(aes_blocks_kernel, dim3(1), dim3(kPrfThreads), 0, env.stream, env.rk, env.te0_dev, nblk,
+                       in_words_dev, out_words_dev);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming kernels (HBM-bound)
+// ------------------------------------------------------------------------------------------
+constexpr int kStreamThreads = 256;
+
+static inline int stream_grid(const LaunchEnv &env, uint64_t items)
+{
+    uint64_t blocks = (items + kStreamThreads - 1) / kStreamThreads;
+    const uint64_t cap = static_cast<uint64_t>(env.num_cus) * 8;     // 8 x 256-thread blocks per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return static_cast<int>(blocks);
+}
+
+// out = (in + add - minus) & mask.  L = 2: one 16-B element per lane-iteration.
+__global__ __launch_bounds__(kStreamThreads) void combine_wide_kernel(uint64_t n, const uint64_t *in, int in_limbs,
+                                                                      const uint64_t *add, const uint64_t *minus,
+                                                                      uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        u128 v = in_limbs == 2 ? ld128(in + 2 * j) : static_cast<u128>(in[j]);
+        if (add) v += ld128(add + 2 * j);
+        if (minus) v -= ld128(minus + 2 * j);
+        st128(out + 2 * j, v & mask);
+    }
+}
+
+__global__ __launch_bounds__(kStreamThreads) void combine_small_kernel(uint64_t n, const uint64_t *in, const uint64_t *add,
+                                                                       const uint64_t *minus, uint64_t *out, uint64_t mask)
+{
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        uint64_t v = in[j];
+        if (add) v += add[j];
+        if (minus) v -= minus[j];
+        out[j] = v & mask;
+    }
+}
+
+hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
+                          const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const int grid = stream_grid(env, n);
+    if (env.b > 64)
+        hipLaunchKernelGGL(combine_wide_kernel, dim3(grid), dim3(kStreamThreads), 0, env.stream, n, in_dev, in_limbs,
+                           add_dev, minus_dev, out_dev, lo, hi);
+    else
+        hipLaunchKernelGGL(combine_small_kernel, dim3(grid), dim3(kStreamThreads), 0, env.stream, n, in_dev, add_dev,
+                           minus_dev, out_dev, lo);
+    return hipGetLastError();
+}
+
+// C-way element-wise mod-add.  WIDE: 128-bit elements (carry between the two limbs);
+// otherwise each limb is its own element and a 16-B slot simply carries two of them.
+template <bool WIDE>
+__global__ __launch_bounds__(kStreamThreads) void aggregate_elem_kernel(int C, const PtrTable ops, uint64_t n_limbs,
+                                                                        uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const uint64_t *const *tab = ops.p;
+    const uint64_t n_slots = n_limbs / 2;
+    for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; s < n_slots;
+         s += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        uint64_t a0 = 0, a1 = 0;
+        u128 acc = 0;
+#pragma unroll 4
+        for (int c = 0; c < C; c++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(tab[c] + 2 * s);
+            if (WIDE) acc += (static_cast<u128>(v.y) << 64) | v.x;
+            else { a0 += v.x; a1 += v.y; }
+        }
+        if (WIDE) { a0 = static_cast<uint64_t>(acc); a1 = static_cast<uint64_t>(acc >> 64); }
+        *reinterpret_cast<ulonglong2 *>(out + 2 * s) = make_ulonglong2(a0 & mask_lo, a1 & (WIDE ? mask_hi : mask_lo));
+    }
+    if (!WIDE && (n_limbs & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t a = 0;
+        for (int c = 0; c < C; c++) a += tab[c][n_limbs - 1];
+        out[n_limbs - 1] = a & mask_lo;
+    }
+}
+
+static inline PtrTable make_table(int C, const uint64_t *const *ops)
+{
+    PtrTable t;
+    for (int c = 0; c < kMaxOps; c++) t.p[c] = c < C ? ops[c] : nullptr;
+    return t;
+}
+
+hipError_t launch_aggregate_elem(const LaunchEnv &env, int C, const uint64_t *const *ops, uint64_t n, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    if (C > kMaxOps) return hipErrorInvalidValue;
+    const PtrTable tab_dev = make_table(C, ops);
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_limbs = env.b > 64 ? 2 * n : n;
+    const int grid = stream_grid(env, n_limbs / 2 + 1);
+    if (env.b > 64)
+        hipLaunchKernelGGL(aggregate_elem_kernel<true>, dim3(grid), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n_limbs,
+                           out_dev, lo, hi);
+    else
+        hipLaunchKernelGGL(aggregate_elem_kernel<false>, dim3(grid), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n_limbs,
+                           out_dev, lo, hi);
+    return hipGetLastError();
+}
+
+// ---- packed aggregate: C-way add of n_limbs-limb integers with full carry propagation ----
+// Stage 1 (this kernel): per 16-B slot the C-way column sums (lo, hi = overflow count), the
+// fold hi -> next limb, and a (generate, propagate) carry scan inside the 256-slot block via
+// wave ballots + the integer-add trick; the block is resolved with carry-in 0 and publishes
+// (G, P).  Stage 2 (packed_fixup_kernel): look-back over the block summaries and ripple the
+// (rare) +1 into blocks whose carry-in is 1.
+constexpr int kPackedThreads = 256;
+uint64_t packed_num_blocks(uint64_t n_limbs) { return ((n_limbs + 1) / 2 + kPackedThreads - 1) / kPackedThreads; }
+
+__device__ __forceinline__ void column_sums(int C, const PtrTable &ops, uint64_t slot, uint64_t n_limbs,
+                                            uint64_t &lo0, uint64_t &hi0, uint64_t &lo1, uint64_t &hi1)
+{
+    const uint64_t *const *tab = ops.p;
+    u128 a0 = 0, a1 = 0;
+    const bool full = 2 * slot + 1 < n_limbs;
+    if (full) {
+#pragma unroll 4
+        for (int c = 0; c < C; c++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(tab[c] + 2 * slot);
+            a0 += v.x; a1 += v.y;
+        }
+    } else {
+        for (int c = 0; c < C; c++) a0 += tab[c][2 * slot];
+    }
+    lo0 = static_cast<uint64_t>(a0); hi0 = static_cast<uint64_t>(a0 >> 64);
+    lo1 = static_cast<uint64_t>(a1); hi1 = static_cast<uint64_t>(a1 >> 64);
+}
+
+__global__ __launch_bounds__(kPackedThreads) void aggregate_packed_kernel(int C, const PtrTable tab, uint64_t n_limbs,
+                                                                          uint64_t top_mask, uint64_t *out, uint32_t *summaries)
+{
+    __shared__ uint64_t sh_hi[kPackedThreads];
+    __shared__ uint32_t sh_zc[kPackedThreads];
+    __shared__ uint32_t sh_wg[kPackedThreads / 64], sh_wp[kPackedThreads / 64];
+    const uint64_t n_slots = (n_limbs + 1) / 2;
+    const uint64_t slot = static_cast<uint64_t>(blockIdx.x) * kPackedThreads + threadIdx.x;
+    const bool live = slot < n_slots;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    uint64_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+    if (live) column_sums(C, tab, slot, n_limbs, lo0, hi0, lo1, hi1);
+    // limb 2s+1: z1 = lo1 + hi0
+    const uint64_t zl1 = lo1 + hi0;
+    const uint32_t zc1 = zl1 < lo1;
+    sh_hi[tid] = hi1;
+    sh_zc[tid] = zc1;
+    __syncthreads();
+    uint64_t hi_prev = 0; uint32_t zc_prev = 0;
+    if (tid > 0) { hi_prev = sh_hi[tid - 1]; zc_prev = sh_zc[tid - 1]; }
+    else if (slot > 0 && live) {
+        uint64_t pl0, ph0, pl1, ph1;
+        column_sums(C, tab, slot - 1, n_limbs, pl0, ph0, pl1, ph1);
+        const uint64_t pz = pl1 + ph0;
+        hi_prev = ph1; zc_prev = pz < pl1;
+    }
+    // limb 2s: z0 = lo0 + hi_prev
+    const uint64_t zl0 = lo0 + hi_prev;
+    const uint32_t zc0 = zl0 < lo0;
+    // X + Y with Y = z-carry of the previous limb
+    const uint64_t s0 = zl0 + zc_prev;
+    const uint32_t g0 = s0 < zl0, p0 = s0 == ~0ull;
+    const uint64_t s1 = zl1 + zc0;
+    const uint32_t g1 = s1 < zl1, p1 = s1 == ~0ull;
+    const uint32_t Gt = live ? (g1 | (p1 & g0)) : 0u;
+    const uint32_t Pt = live ? (p1 & p0) : 1u;      // dead lanes are transparent
+    const uint64_t Gm = __ballot(Gt), Pm = __ballot(Pt);
+    const uint64_t a = Gm | Pm, bb = Gm;
+    const uint64_t sum0 = a + bb;
+    if (lane == 0) { sh_wg[wave] = sum0 < a; sh_wp[wave] = Pm == ~0ull; }
+    __syncthreads();
+    uint32_t cin = 0;
+    for (int v = 0; v < wave; v++) cin = sh_wg[v] | (sh_wp[v] & cin);
+    const uint64_t cv = (a + bb + cin) ^ Pm;
+    const uint32_t ct = (cv >> lane) & 1u;
+    const uint64_t r0 = s0 + ct;
+    const uint32_t k0 = g0 | (p0 & ct);
+    const uint64_t r1 = s1 + k0;
+    if (live) {
+        const uint64_t i0 = 2 * slot, i1 = i0 + 1;
+        if (i1 < n_limbs) {
+            *reinterpret_cast<ulonglong2 *>(out + i0) =
+                make_ulonglong2(r0, i1 == n_limbs - 1 ? (r1 & top_mask) : r1);
+        } else {
+            out[i0] = r0 & top_mask;
+        }
+    }
+    if (tid == 0) {
+        uint32_t c = 0, pall = 1;
+        for (int v = 0; v < kPackedThreads / 64; v++) { c = sh_wg[v] | (sh_wp[v] & c); pall &= sh_wp[v]; }
+        summaries[blockIdx.x] = c | (pall << 1);
+    }
+}
+
+__global__ void packed_fixup_kernel(uint64_t n_blocks, uint64_t n_limbs, uint64_t top_mask, const uint32_t *summaries, uint64_t *out)
+{
+    const uint64_t B = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x + 1;
+    if (B >= n_blocks) return;
+    uint32_t cin = 0;
+    for (uint64_t v = B; v-- > 0;) {
+        const uint32_t s = summaries[v];
+        if (s & 1u) { cin = 1; break; }
+        if (!(s & 2u)) break;
+    }
+    if (!cin) return;
+    const uint64_t first = B * kPackedThreads * 2;
+    uint64_t last = first + kPackedThreads * 2;
+    if (last > n_limbs) last = n_limbs;
+    for (uint64_t i = first; i < last; i++) {
+        uint64_t v = out[i] + 1;
+        if (i == n_limbs - 1) v &= top_mask;
+        out[i] = v;
+        if (v != 0) break;
+    }
+}
+
+hipError_t launch_aggregate_packed(const LaunchEnv &env, int C, const uint64_t *const *ops, uint64_t n_limbs,
+                                   uint64_t total_bits, uint64_t *out_dev, uint32_t *summaries_dev)
+{
+    if (n_limbs == 0) return hipSuccess;
+    if (C > kMaxOps) return hipErrorInvalidValue;
+    const PtrTable tab_dev = make_table(C, ops);
+    const unsigned top = static_cast<unsigned>(total_bits % 64);
+    const uint64_t top_mask = top ? ((1ull << top) - 1) : ~0ull;
+    const uint64_t nb = packed_num_blocks(n_limbs);
+    hipLaunchKernelGGL(aggregate_packed_kernel, dim3(static_cast<unsigned>(nb)), dim3(kPackedThreads), 0, env.stream, C, tab_dev,
+                       n_limbs, top_mask, out_dev, summaries_dev);
+    if (nb > 1) {
+        const unsigned fb = static_cast<unsigned>((nb - 1 + 255) / 256);
+        hipLaunchKernelGGL(packed_fixup_kernel, dim3(fb), dim3(256), 0, env.stream, nb, n_limbs, top_mask, summaries_dev, out_dev);
+    }
+    return hipGetLastError();
+}
+
+// ---- bit-packing codec ----
+// pack: one output limb per lane, gathering every element that overlaps bits [64w, 64w + 64).
+__global__ __launch_bounds__(kStreamThreads) void pack_kernel(uint64_t n, int b, int L, const uint64_t *in, uint64_t *out,
+                                                              uint64_t n_limbs, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; w < n_limbs;
+         w += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const uint64_t bit0 = 64 * w;
+        uint64_t e = bit0 / b;
+        uint64_t e_last = (bit0 + 63) / b;
+        if (e_last >= n) e_last = n - 1;
+        uint64_t acc = 0;
+        for (; e <= e_last; e++) {
+            const uint64_t j = n - 1 - e;
+            const u128 v = (L == 2 ? ld128(in + 2 * j) : static_cast<u128>(in[j])) & mask;
+            const uint64_t pos = e * b;
+            if (pos >= bit0) acc |= static_cast<uint64_t>(v) << (pos - bit0);
+            else acc |= static_cast<uint64_t>(v >> (bit0 - pos));
+        }
+        out[w] = acc;
+    }
+}
+
+__global__ __launch_bounds__(kStreamThreads) void unpack_kernel(uint64_t n, int b, int L, const uint64_t *in, uint64_t *out,
+                                                                uint64_t n_limbs, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const uint64_t pos = (n - 1 - j) * b;
+        const uint64_t w = pos / 64;
+        const unsigned s = static_cast<unsigned>(pos % 64);
+        const u128 l0 = in[w];
+        const u128 l1 = w + 1 < n_limbs ? in[w + 1] : 0;
+        const u128 l2 = w + 2 < n_limbs ? in[w + 2] : 0;
+        u128 v = l0 >> s;
+        if (s) { v |= l1 << (64 - s); v |= l2 << (128 - s); }
+        else v |= l1 << 64;
+        v &= mask;
+        if (L == 2) st128(out + 2 * j, v);
+        else out[j] = static_cast<uint64_t>(v);
+    }
+}
+
+hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_limbs = (n * static_cast<uint64_t>(env.b) + 63) / 64;
+    hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(env, n_limbs)), dim3(kStreamThreads), 0, env.stream, n, env.b,
+                       env.b > 64 ? 2 : 1, in_dev, out_dev, n_limbs, lo, hi);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_limbs = (n * static_cast<uint64_t>(env.b) + 63) / 64;
+    hipLaunchKernelGGL(unpack_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, env.b,
+                       env.b > 64 ? 2 : 1, in_dev, out_dev, n_limbs, lo, hi);
+    return hipGetLastError();
+}
+
+// ---- sparse helpers ----
+__global__ __launch_bounds__(kStreamThreads) void fill_kernel(uint64_t n, int L, uint64_t lo, uint64_t hi, uint64_t *out)
+{
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        if (L == 2) *reinterpret_cast<ulonglong2 *>(out + 2 * j) = make_ulonglong2(lo, hi);
+        else out[j] = lo;
+    }
+}
+
+// out[loc[q]] = vals[q]  or  out[loc[q]] = (out[loc[q]] + vals[q]) mod 2^b.  loc must hold
+// distinct positions within one launch (the reference's location lists are sets).
+__global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t k, int L, const uint32_t *loc, const uint64_t *vals,
+                                                                 uint64_t *out, bool accumulate, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; q < k;
+         q += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const uint64_t p = loc[q];
+        if (L == 2) {
+            u128 v = ld128(vals + 2 * q);
+            if (accumulate) v += ld128(out + 2 * p);
+            st128(out + 2 * p, v & mask);
+        } else {
+            uint64_t v = vals[q];
+            if (accumulate) v += out[p];
+            out[p] = v & mask_lo;
+        }
+    }
+}
+
+// out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
+__global__ __launch_bounds__(kStreamThreads) void sel_accumulate_kernel(uint64_t n, int L, const uint8_t *sel, const uint64_t *stream,
+                                                                        uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; p < n;
+         p += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        if (!sel[p]) continue;
+        if (L == 2) st128(out + 2 * p, (ld128(out + 2 * p) + ld128(stream + 2 * p)) & mask);
+        else out[p] = (out[p] + stream[p]) & mask_lo;
+    }
+}
+
+hipError_t launch_fill(const LaunchEnv &env, uint64_t n, uint64_t lo, uint64_t hi, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, env.b > 64 ? 2 : 1, lo, hi, out_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter(const LaunchEnv &env, uint64_t k, const uint32_t *loc_dev, const uint64_t *vals_dev,
+                          uint64_t *out_dev, bool accumulate)
+{
+    if (k == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    hipLaunchKernelGGL(scatter_kernel, dim3(stream_grid(env, k)), dim3(kStreamThreads), 0, env.stream, k, env.b > 64 ? 2 : 1,
+                       loc_dev, vals_dev, out_dev, accumulate, lo, hi);
+    return hipGetLastError();
+}
+
+// One list entry of _static_prepare_decrypt_spar: the whole-vector stream for prefix iter|list_idx
+// (one chunk, begin = 0) must already be in stream_dev; selected positions are accumulated.
+hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uint8_t *sel_dev, const uint64_t *stream_dev,
+                                 uint64_t *out_dev)
+{
+    if (total == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    hipLaunchKernelGGL(sel_accumulate_kernel, dim3(stream_grid(env, total)), dim3(kStreamThreads), 0, env.stream, total,
+                       env.b > 64 ? 2 : 1, sel_dev, stream_dev, out_dev, lo, hi);
+    return hipGetLastError();
+}
+
+}  // namespace flashe

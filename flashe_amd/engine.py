@@ -1,0 +1,337 @@
+"""Thin object layer over the C ABI: one `Engine` = one flashe_ctx (device + stream + key +
+int_bits); `DeviceBuffer` = a vector resident in HBM.  No arithmetic happens in Python.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import SCHEME_DOUBLE, SCHEME_SINGLE, FlasheError, c_int, c_u32, c_u32p, c_u64, c_u64p, c_vp
+
+__all__ = ["Engine", "DeviceBuffer", "limbs_of", "SCHEME_SINGLE", "SCHEME_DOUBLE", "FlasheError",
+           "chunks", "telescope", "prp_block"]
+
+
+def limbs_of(int_bits):
+    return 2 if int_bits > 64 else 1
+
+
+def _u32_list(vals):
+    arr = (c_u32 * max(len(vals), 1))(*[int(v) & 0xFFFFFFFF for v in vals])
+    return ctypes.cast(arr, c_u32p), arr
+
+
+def chunks(n, n_jobs):
+    """chunks_idx(range(n), n_jobs) boundaries -- jzf_flashe.py:12-16."""
+    out = (c_u64 * (n_jobs + 1))()
+    rc = _lib.load().flashe_chunks(n, n_jobs, ctypes.cast(out, c_u64p))
+    if rc:
+        raise FlasheError(rc, "flashe_chunks: bad arguments")
+    return [int(v) for v in out]
+
+
+def telescope(raw_idx_list):
+    """(add_idx, minus_idx) of set_idx_list(mode='decrypt') -- jzf_flashe.py:356-367."""
+    k = len(raw_idx_list)
+    raw, _r = _u32_list(list(raw_idx_list))
+    add = (c_u32 * max(k, 1))()
+    minus = (c_u32 * max(k, 1))()
+    runs = c_int(0)
+    rc = _lib.load().flashe_telescope(raw, k, ctypes.cast(add, c_u32p), ctypes.cast(minus, c_u32p), ctypes.byref(runs))
+    if rc:
+        raise FlasheError(rc, "flashe_telescope: bad arguments")
+    return [int(v) for v in add[:runs.value]], [int(v) for v in minus[:runs.value]]
+
+
+def prp_block(key, block):
+    """AES-256-ECB of one 16-byte block on the host -- jzf_aes_prp.py:24-30."""
+    out = (ctypes.c_uint8 * 16)()
+    rc = _lib.load().flashe_prp_block((ctypes.c_uint8 * 32).from_buffer_copy(bytes(key)),
+                                      (ctypes.c_uint8 * 16).from_buffer_copy(bytes(block)), out)
+    if rc:
+        raise FlasheError(rc, "flashe_prp_block: bad arguments")
+    return bytes(out)
+
+
+class DeviceBuffer:
+    """`nbytes` of HBM owned by an Engine.  `.ptr` is the raw device address."""
+
+    def __init__(self, engine, nbytes):
+        self.engine = engine
+        self.nbytes = int(nbytes)
+        p = c_vp()
+        engine._check(engine._lib.flashe_dev_alloc(engine._h, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr is not None and self.engine._h is not None:
+            self.engine._check(self.engine._lib.flashe_dev_free(self.engine._h, self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.engine._check(self.engine._lib.flashe_memcpy_h2d(self.engine._h, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype=np.uint64, count=None):
+        n = self.nbytes // np.dtype(dtype).itemsize if count is None else count
+        out = np.empty(n, dtype=dtype)
+        self.engine._check(self.engine._lib.flashe_memcpy_d2h(self.engine._h, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+
+class Engine:
+    """One device context of the cipher engine (wraps flashe_ctx)."""
+
+    def __init__(self, key, int_bits, device=0, stream=None):
+        self._lib = _lib.load()
+        self._h = None
+        key = bytes(key)
+        if len(key) != 32:
+            raise ValueError("key must be 32 bytes (AES-256)")
+        h = c_vp()
+        rc = self._lib.flashe_ctx_create(ctypes.byref(h), (ctypes.c_uint8 * 32).from_buffer_copy(key),
+                                         int(int_bits), int(device), c_vp(stream) if stream else None)
+        if rc:
+            msg = self._lib.flashe_last_error(None)
+            raise FlasheError(rc, msg.decode() if msg else "flashe_ctx_create failed")
+        self._h = h.value
+        self.int_bits = int(int_bits)
+        self.limbs = limbs_of(int_bits)
+        self.device = device
+
+    # -- plumbing -------------------------------------------------------------------------
+    def _check(self, rc):
+        return _lib.check(self._h, rc)
+
+    def close(self):
+        if self._h is not None:
+            self._lib.flashe_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_key(self, key):
+        key = bytes(key)
+        assert len(key) == 32
+        self._check(self._lib.flashe_ctx_set_key(self._h, (ctypes.c_uint8 * 32).from_buffer_copy(key)))
+
+    def selftest(self):
+        self._check(self._lib.flashe_selftest(self._h))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def alloc_vec(self, n, limbs=None):
+        return DeviceBuffer(self, max(int(n) * (limbs or self.limbs) * 8, 16))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 16)).upload(arr)
+
+    def sync(self):
+        self._check(self._lib.flashe_sync(self._h))
+
+    def event(self):
+        ev = c_vp()
+        self._check(self._lib.flashe_event_create(self._h, ctypes.byref(ev)))
+        return ev.value
+
+    def record(self, ev):
+        self._check(self._lib.flashe_event_record(self._h, ev))
+
+    def elapsed_ms(self, start, stop):
+        ms = ctypes.c_float(0)
+        self._check(self._lib.flashe_event_elapsed_ms(self._h, start, stop, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def event_destroy(self, ev):
+        self._check(self._lib.flashe_event_destroy(self._h, ev))
+
+    @staticmethod
+    def _ptr(x):
+        if x is None:
+            return None
+        return x.ptr if isinstance(x, DeviceBuffer) else int(x)
+
+    # -- device-pointer API (asynchronous on the ctx stream) -----------------------------------
+    def mask_dev(self, it, idx_list, n, n_jobs, out):
+        p, _keep = _u32_list(idx_list)
+        self._check(self._lib.flashe_mask_dev(self._h, it, p, len(idx_list), n, n_jobs, self._ptr(out)))
+
+    def encrypt_dev(self, it, idx, scheme, n, n_jobs, pt, pt_limbs, ct):
+        self._check(self._lib.flashe_encrypt_dev(self._h, it, idx, scheme, n, n_jobs, self._ptr(pt), pt_limbs, self._ptr(ct)))
+
+    def decrypt_dev(self, it, add_idx, minus_idx, n, n_jobs, inp, out):
+        pa, _a = _u32_list(add_idx)
+        pm, _m = _u32_list(minus_idx)
+        self._check(self._lib.flashe_decrypt_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs,
+                                                 self._ptr(inp), self._ptr(out)))
+
+    def mask_range_dev(self, it, idx_list, n, n_jobs, first, count, out):
+        p, _keep = _u32_list(idx_list)
+        self._check(self._lib.flashe_mask_range_dev(self._h, it, p, len(idx_list), n, n_jobs, first, count, self._ptr(out)))
+
+    def encrypt_range_dev(self, it, idx, scheme, n, n_jobs, first, count, pt, pt_limbs, ct):
+        self._check(self._lib.flashe_encrypt_range_dev(self._h, it, idx, scheme, n, n_jobs, first, count,
+                                                       self._ptr(pt), pt_limbs, self._ptr(ct)))
+
+    def decrypt_range_dev(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, out):
+        pa, _a = _u32_list(add_idx)
+        pm, _m = _u32_list(minus_idx)
+        self._check(self._lib.flashe_decrypt_range_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs,
+                                                       first, count, self._ptr(inp), self._ptr(out)))
+
+    def combine_dev(self, n, inp, in_limbs, add, minus, out):
+        self._check(self._lib.flashe_combine_dev(self._h, n, self._ptr(inp), in_limbs, self._ptr(add), self._ptr(minus), self._ptr(out)))
+
+    def _ptr_array(self, items):
+        arr = (c_vp * max(len(items), 1))(*[self._ptr(x) for x in items])
+        return ctypes.cast(arr, ctypes.POINTER(c_vp)), arr
+
+    def aggregate_elem_dev(self, cts, n, out):
+        p, _keep = self._ptr_array(cts)
+        self._check(self._lib.flashe_aggregate_elem_dev(self._h, len(cts), p, n, self._ptr(out)))
+
+    def aggregate_packed_dev(self, packed, n_limbs, total_bits, out):
+        p, _keep = self._ptr_array(packed)
+        self._check(self._lib.flashe_aggregate_packed_dev(self._h, len(packed), p, n_limbs, total_bits, self._ptr(out)))
+
+    def pack_dev(self, n, inp, out):
+        self._check(self._lib.flashe_pack_dev(self._h, n, self._ptr(inp), self._ptr(out)))
+
+    def unpack_dev(self, n, inp, out):
+        self._check(self._lib.flashe_unpack_dev(self._h, n, self._ptr(inp), self._ptr(out)))
+
+    def expand_to_dense_dev(self, total, k, loc, vals, zero_limbs, out):
+        z = (c_u64 * 2)(*([int(v) for v in zero_limbs] + [0])[:2])
+        self._check(self._lib.flashe_expand_to_dense_dev(self._h, total, k, self._ptr(loc), self._ptr(vals),
+                                                         ctypes.cast(z, c_u64p), self._ptr(out)))
+
+    def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out):
+        p, _keep = self._ptr_array(locs)
+        k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        self._check(self._lib.flashe_sparse_minus_mask_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs,
+                                                           self._ptr(out)))
+
+    def sparse_dense_mask_dev(self, it, sels, total, out):
+        p, _keep = self._ptr_array(sels)
+        self._check(self._lib.flashe_sparse_dense_mask_dev(self._h, it, len(sels), p, total, self._ptr(out)))
+
+    # -- host-array API (synchronous; numpy uint64 limb arrays in and out) -----------------------
+    def _vec(self, arr, allow_pt=False):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        if arr.ndim == 1:
+            arr = arr.reshape(-1, 1)
+        if arr.shape[1] != self.limbs and not (allow_pt and arr.shape[1] == 1):
+            raise ValueError(f"expected [n, {self.limbs}] uint64 limbs, got {arr.shape}")
+        return arr
+
+    def mask(self, it, idx_list, n, n_jobs):
+        out = np.zeros((n, self.limbs), dtype=np.uint64)
+        p, _keep = _u32_list(idx_list)
+        self._check(self._lib.flashe_mask(self._h, it, p, len(idx_list), n, n_jobs, out.ctypes.data))
+        return out
+
+    def encrypt(self, it, idx, scheme, n_jobs, pt):
+        pt = self._vec(pt, allow_pt=True)
+        n = pt.shape[0]
+        ct = np.zeros((n, self.limbs), dtype=np.uint64)
+        self._check(self._lib.flashe_encrypt(self._h, it, idx, scheme, n, n_jobs, pt.ctypes.data, pt.shape[1], ct.ctypes.data))
+        return ct
+
+    def decrypt(self, it, add_idx, minus_idx, n_jobs, ct):
+        ct = self._vec(ct)
+        n = ct.shape[0]
+        out = np.zeros_like(ct)
+        pa, _a = _u32_list(add_idx)
+        pm, _m = _u32_list(minus_idx)
+        self._check(self._lib.flashe_decrypt(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs,
+                                             ct.ctypes.data, out.ctypes.data))
+        return out
+
+    def combine(self, inp, add=None, minus=None):
+        inp = self._vec(inp, allow_pt=True)
+        n = inp.shape[0]
+        add = self._vec(add) if add is not None else None
+        minus = self._vec(minus) if minus is not None else None
+        out = np.zeros((n, self.limbs), dtype=np.uint64)
+        self._check(self._lib.flashe_combine(self._h, n, inp.ctypes.data, inp.shape[1],
+                                             add.ctypes.data if add is not None else None,
+                                             minus.ctypes.data if minus is not None else None, out.ctypes.data))
+        return out
+
+    def aggregate_elem(self, cts):
+        cts = [self._vec(c) for c in cts]
+        n = cts[0].shape[0]
+        if any(c.shape[0] != n for c in cts):
+            raise ValueError("operands differ in length")
+        out = np.zeros((n, self.limbs), dtype=np.uint64)
+        tab = (c_vp * len(cts))(*[c.ctypes.data for c in cts])
+        self._check(self._lib.flashe_aggregate_elem(self._h, len(cts), ctypes.cast(tab, ctypes.POINTER(c_vp)), n, out.ctypes.data))
+        return out
+
+    def aggregate_packed(self, packed, total_bits):
+        n_limbs = (total_bits + 63) // 64
+        packed = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1) for p in packed]
+        if any(p.shape[0] != n_limbs for p in packed):
+            raise ValueError("operands must have ceil(total_bits / 64) limbs")
+        out = np.zeros(n_limbs, dtype=np.uint64)
+        tab = (c_vp * len(packed))(*[p.ctypes.data for p in packed])
+        self._check(self._lib.flashe_aggregate_packed(self._h, len(packed), ctypes.cast(tab, ctypes.POINTER(c_vp)),
+                                                      n_limbs, total_bits, out.ctypes.data))
+        return out
+
+    def pack(self, x):
+        x = self._vec(x)
+        n = x.shape[0]
+        out = np.zeros((n * self.int_bits + 63) // 64, dtype=np.uint64)
+        self._check(self._lib.flashe_pack(self._h, n, x.ctypes.data, out.ctypes.data))
+        return out
+
+    def unpack(self, p, n):
+        p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1)
+        if p.shape[0] != (n * self.int_bits + 63) // 64:
+            raise ValueError("packed operand has the wrong number of limbs")
+        out = np.zeros((n, self.limbs), dtype=np.uint64)
+        self._check(self._lib.flashe_unpack(self._h, n, p.ctypes.data, out.ctypes.data))
+        return out
+
+    def expand_to_dense(self, total, loc, vals, zero_limbs):
+        loc = np.ascontiguousarray(loc, dtype=np.uint32)
+        vals = self._vec(vals) if len(loc) else np.zeros((0, self.limbs), dtype=np.uint64)
+        z = (c_u64 * 2)(*([int(v) for v in np.asarray(zero_limbs).reshape(-1)] + [0])[:2])
+        out = np.zeros((total, self.limbs), dtype=np.uint64)
+        self._check(self._lib.flashe_expand_to_dense(self._h, total, len(loc), loc.ctypes.data, vals.ctypes.data,
+                                                     ctypes.cast(z, c_u64p), out.ctypes.data))
+        return out
+
+    def sparse_minus_mask(self, it, locs, total, n_jobs):
+        locs = [np.ascontiguousarray(l, dtype=np.uint32) for l in locs]
+        tab = (c_vp * max(len(locs), 1))(*[l.ctypes.data for l in locs])
+        k = (c_u64 * max(len(locs), 1))(*[len(l) for l in locs])
+        out = np.zeros((total, self.limbs), dtype=np.uint64)
+        self._check(self._lib.flashe_sparse_minus_mask(self._h, it, len(locs), ctypes.cast(tab, ctypes.POINTER(c_vp)),
+                                                       ctypes.cast(k, c_u64p), total, n_jobs, out.ctypes.data))
+        return out
+
+    def sparse_dense_mask(self, it, sels, total):
+        sels = [np.ascontiguousarray(s, dtype=np.uint8) for s in sels]
+        if any(s.shape[0] != total for s in sels):
+            raise ValueError("selector length must equal total")
+        tab = (c_vp * max(len(sels), 1))(*[s.ctypes.data for s in sels])
+        out = np.zeros((total, self.limbs), dtype=np.uint64)
+        self._check(self._lib.flashe_sparse_dense_mask(self._h, it, len(sels), ctypes.cast(tab, ctypes.POINTER(c_vp)),
+                                                       total, out.ctypes.data))
+        return out

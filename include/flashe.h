@@ -1,0 +1,193 @@
+/*
+ * flashe.h -- C ABI of libflashe_hip.so, the MI355X (gfx950) FLASHE cipher engine.
+ *
+ * This is the drop-in boundary for ONE path of SamuelGong/FLASHE: the
+ * federatedml/secureprotol FLASHE cipher (AES-256 PRF mask generation, per-element
+ * modular encrypt / decrypt over big-integer vectors) plus the arbiter's ciphertext
+ * mod-add reduce and the bit-packing codec either side of it.  Reference citations are
+ * relative to the reference tree (federatedml/...).
+ *
+ * Conventions
+ *   - plain C, no exceptions, no ownership transfer: the caller allocates every buffer.
+ *   - every function returns 0 (FLASHE_OK) or a negative errno-style code;
+ *     flashe_last_error(ctx) gives the text of the last failure on that ctx.
+ *   - a ctx is bound to one HIP device and one HIP stream; it is not thread-safe, separate
+ *     ctxs are independent.  *_dev functions take DEVICE pointers and are asynchronous on
+ *     the ctx stream (flashe_sync to wait); the un-suffixed twins take HOST pointers and
+ *     are synchronous (H2D + kernels + D2H).
+ *   - element layout: an element of b = int_bits bits (1 <= b <= 128) is
+ *     L = flashe_limbs(b) = ceil(b/64) little-endian uint64 limbs; vectors are [n][L].
+ *     Inputs need not be reduced: everything is taken mod 2^b as the reference does
+ *     (jzf_flashe.py:480-481).
+ *   - there is NO CPU fallback: without a HIP device every ctx call fails with
+ *     FLASHE_ENODEV.
+ */
+#ifndef FLASHE_H
+#define FLASHE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLASHE_OK       0
+#define FLASHE_EIO     (-5)    /* a HIP runtime call failed; see flashe_last_error */
+#define FLASHE_ENOMEM  (-12)
+#define FLASHE_ENODEV  (-19)   /* no usable HIP device */
+#define FLASHE_EINVAL  (-22)
+
+#define FLASHE_SCHEME_SINGLE 0 /* FlasheCipher(int_bits, mask="single") */
+#define FLASHE_SCHEME_DOUBLE 1 /* FlasheCipher(int_bits)  (default "double") */
+
+typedef struct flashe_ctx flashe_ctx;
+
+/* ---- library / device ------------------------------------------------------------- */
+int flashe_abi_version(void);
+int flashe_device_count(int *count);
+int flashe_limbs(int int_bits);                 /* 1 or 2; 0 if int_bits is out of range */
+
+/* ---- context ---------------------------------------------------------------------- */
+/* Replaces FlasheCipher.__init__ + generate_prp_seed (jzf_flashe.py:230-260, :280-295):
+ * key is the 32-byte AES-256 key, i.e. the low 256 bits of the PRP seed, big-endian
+ * (jzf_aes.py:21-28).  stream: a hipStream_t to run on (e.g. the caller framework's
+ * current stream) or NULL to let the ctx create its own non-blocking stream. */
+int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int device, void *stream);
+int flashe_ctx_destroy(flashe_ctx *ctx);
+int flashe_ctx_set_key(flashe_ctx *ctx, const uint8_t key[32]);
+int flashe_ctx_int_bits(const flashe_ctx *ctx);
+/* Text of the last error on ctx (ctx == NULL: last flashe_ctx_create failure of this thread). */
+const char *flashe_last_error(const flashe_ctx *ctx);
+/* Known-answer self test on the device: FIPS-197 C.3 through the PRF kernel. */
+int flashe_selftest(flashe_ctx *ctx);
+
+/* ---- host-side logic of the path (no device needed) -------------------------------- */
+/* chunks_idx(range(n), n_jobs) -- jzf_flashe.py:12-16.  begins has n_jobs + 1 entries. */
+int flashe_chunks(uint64_t n, uint32_t n_jobs, uint64_t *begins);
+/* set_idx_list(mode="decrypt") telescoping -- jzf_flashe.py:356-367.  raw is sorted in
+ * place (as the reference sorts its argument); add_out / minus_out hold n_raw entries. */
+int flashe_telescope(uint32_t *raw, int n_raw, uint32_t *add_out, uint32_t *minus_out, int *n_runs);
+/* AES-256 of one 16-byte block on the HOST (key schedule check / small utilities) --
+ * PsuedoRandomPermutation.get_permutation, jzf_aes_prp.py:24-30. */
+int flashe_prp_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16]);
+
+/* ---- device memory, stream, events -------------------------------------------------- */
+int flashe_dev_alloc(flashe_ctx *ctx, size_t bytes, void **dptr);
+int flashe_dev_free(flashe_ctx *ctx, void *dptr);
+int flashe_memcpy_h2d(flashe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int flashe_memcpy_d2h(flashe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int flashe_memcpy_d2d(flashe_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
+int flashe_memset_dev(flashe_ctx *ctx, void *dst_dev, int byte, size_t bytes);
+int flashe_sync(flashe_ctx *ctx);
+int flashe_event_create(flashe_ctx *ctx, void **event);
+int flashe_event_destroy(flashe_ctx *ctx, void *event);
+int flashe_event_record(flashe_ctx *ctx, void *event);               /* on the ctx stream */
+int flashe_event_elapsed_ms(flashe_ctx *ctx, void *start, void *stop, float *ms); /* syncs on stop */
+
+/* ---- PRF mask streams -------------------------------------------------------------- */
+/* out[j] = sum_k term(iter, idx[k], j) mod 2^b, chunked like chunks_idx(range(n), n_jobs).
+ * n_idx == 1 is _static_prepare_encrypt_single (jzf_flashe.py:19-45), i.e. one stream of
+ * prepare_encrypt / prepare_decrypt (:599-666); n_idx > 1 is one half of
+ * _static_prepare_decrypt / _static_prepare_decrypt_single (:85-152). */
+int flashe_mask_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx,
+                    uint64_t n, uint32_t n_jobs, uint64_t *out_dev);
+int flashe_mask(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx,
+                uint64_t n, uint32_t n_jobs, uint64_t *out);
+
+/* ---- encrypt / decrypt -------------------------------------------------------------- */
+/* FlasheCipher.encrypt -- jzf_flashe.py:490-504 -> _multiprocessing_encrypt (:456-488,
+ * double: ct = pt + term(iter, idx) - term(iter, idx+1)) or _multiprocessing_encrypt_single
+ * (:431-454, single: ct = pt + term(iter, idx)), fused with the mask generation.
+ * pt has pt_limbs limbs per element (1 = uint64 plaintext, zero-extended; or L). */
+int flashe_encrypt_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
+                       uint64_t n, uint32_t n_jobs,
+                       const uint64_t *pt_dev, int pt_limbs, uint64_t *ct_dev);
+int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
+                   uint64_t n, uint32_t n_jobs,
+                   const uint64_t *pt, int pt_limbs, uint64_t *ct);
+
+/* FlasheCipher.decrypt -- jzf_flashe.py:584-594 -> _multiprocessing_decrypt (:537-582) /
+ * _multiprocessing_decrypt_single (:506-535) with the prefix lists set_idx_list derived
+ * (:356-386; single: :311-314 with n_add = 0):
+ * out = in + sum_k term(iter, add_idx[k]) - sum_k term(iter, minus_idx[k])  mod 2^b. */
+int flashe_decrypt_dev(flashe_ctx *ctx, uint32_t iter,
+                       const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                       uint64_t n, uint32_t n_jobs, const uint64_t *in_dev, uint64_t *out_dev);
+int flashe_decrypt(flashe_ctx *ctx, uint32_t iter,
+                   const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                   uint64_t n, uint32_t n_jobs, const uint64_t *in, uint64_t *out);
+
+/* Range twins for element-sharded execution (one vector split over several GPUs): the call
+ * covers global elements [first, first + count) of an n-element vector; the device pointers
+ * address element `first` (i.e. are indexed by element - first).  n and n_jobs still describe the
+ * WHOLE vector, because the PRF counters depend on chunks_idx(range(n), n_jobs)
+ * (jzf_flashe.py:12-16, :34). */
+int flashe_mask_range_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx,
+                          uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count, uint64_t *out_dev);
+int flashe_encrypt_range_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
+                             uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
+                             const uint64_t *pt_dev, int pt_limbs, uint64_t *ct_dev);
+int flashe_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter,
+                             const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                             uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
+                             const uint64_t *in_dev, uint64_t *out_dev);
+
+/* Pre-computed-mask arithmetic: out = in + add - minus mod 2^b (add / minus may be NULL).
+ * The online half of encrypt / decrypt when next_iter_{en,de}crypt_prepared is populated
+ * (jzf_flashe.py:457,480-481, :557-571) and the sparse single-mask decrypt (:531-532). */
+int flashe_combine_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, int in_limbs,
+                       const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);
+int flashe_combine(flashe_ctx *ctx, uint64_t n, const uint64_t *in, int in_limbs,
+                   const uint64_t *add, const uint64_t *minus, uint64_t *out);
+
+/* ---- arbiter reduce ----------------------------------------------------------------- */
+/* Element-wise: out[j] = sum_c cts[c][j] mod 2^b -- jzf_aggregator.py:424-430.
+ * cts is a HOST array of C pointers (device pointers for _dev). */
+int flashe_aggregate_elem_dev(flashe_ctx *ctx, int C, const uint64_t *const *cts_dev,
+                              uint64_t n, uint64_t *out_dev);
+int flashe_aggregate_elem(flashe_ctx *ctx, int C, const uint64_t *const *cts,
+                          uint64_t n, uint64_t *out);
+/* Packed: each operand is ONE integer of total_bits bits (n_limbs = ceil(total_bits/64)
+ * little-endian limbs); out = sum mod 2^total_bits -- jzf_aggregator.py:406-419. */
+int flashe_aggregate_packed_dev(flashe_ctx *ctx, int C, const uint64_t *const *packed_dev,
+                                uint64_t n_limbs, uint64_t total_bits, uint64_t *out_dev);
+int flashe_aggregate_packed(flashe_ctx *ctx, int C, const uint64_t *const *packed,
+                            uint64_t n_limbs, uint64_t total_bits, uint64_t *out);
+
+/* ---- bit-packing codec ---------------------------------------------------------------- */
+/* pack: P = sum_j x[j] << (b * (n-1-j)) as ceil(n*b/64) little-endian limbs --
+ * _to_bytes / _to_bytes_old + compress(), jzf_weights.py:36-84, :155-195.
+ * unpack: the inverse -- _from_bytes_old + reverse(), jzf_weights.py:87-95, :197-231. */
+int flashe_pack_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
+int flashe_pack(flashe_ctx *ctx, uint64_t n, const uint64_t *in, uint64_t *out);
+int flashe_unpack_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
+int flashe_unpack(flashe_ctx *ctx, uint64_t n, const uint64_t *in, uint64_t *out);
+
+/* ---- sparse path --------------------------------------------------------------------- */
+/* Arbiter.expand_to_dense -- jzf_aggregator.py:150-165: out[loc[q]] = vals[q], every other
+ * of the `total` positions = zero (L limbs, HOST pointer in both variants). */
+int flashe_expand_to_dense_dev(flashe_ctx *ctx, uint64_t total, uint64_t k, const uint32_t *loc_dev,
+                               const uint64_t *vals_dev, const uint64_t *zero, uint64_t *out_dev);
+int flashe_expand_to_dense(flashe_ctx *ctx, uint64_t total, uint64_t k, const uint32_t *loc,
+                           const uint64_t *vals, const uint64_t *zero, uint64_t *out);
+/* Sparse single-mask dense minus-mask -- set_idx_list_single sparse branch,
+ * jzf_flashe.py:316-343: for client c the stream over COMPACT positions 0..k[c]-1 (prefix
+ * iter|c, chunks_idx(range(k[c]), n_jobs)) scattered to loc[c][q] and summed over clients.
+ * loc is a HOST array of C pointers, k a HOST array. */
+int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev,
+                                 const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out_dev);
+int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc,
+                             const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out);
+/* Dense-position selected masks -- _static_prepare_decrypt_spar as ONE chunk
+ * (jzf_flashe.py:155-225, begin = 0): out[p] = sum_i sel[i][p] * term(iter, i, p) mod 2^b,
+ * sel[i] a 0/1 byte vector of length total.  sel is a HOST array of n_lists pointers. */
+int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel_dev,
+                                 uint64_t total, uint64_t *out_dev);
+int flashe_sparse_dense_mask(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel,
+                             uint64_t total, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLASHE_H */

@@ -1,0 +1,79 @@
+"""Worker for tests/test_dist_gloo.py: world_size ranks on CPU (gloo).  The exchange logic of
+flashe_amd.dist.ShardedRound is the code under test; local arithmetic is done by an ops double
+backed by the oracle (this file lives under tests/)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from flashe_amd.dist import ShardedRound  # noqa: E402
+from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE  # noqa: E402
+from oracle import flashe_oracle as orc  # noqa: E402
+
+KEY = bytes(range(32))
+
+
+class OracleOps:
+    def __init__(self, b):
+        self.b = b
+        self.L = 2 if b > 64 else 1
+
+    def _v(self, t, n=None):
+        a = t.numpy().view(np.uint64)
+        return a if n is None else a[: n * self.L].reshape(n, self.L)
+
+    def encrypt(self, it, idx, scheme, n, n_jobs, pt, pt_limbs, ct):
+        self._v(ct, n)[:] = orc.encrypt(KEY, it, idx, "double" if scheme == SCHEME_DOUBLE else "single", n_jobs, self.b,
+                                        pt.numpy().view(np.uint64).reshape(n, pt_limbs))
+
+    def aggregate(self, tensors, n, out):
+        self._v(out, n)[:] = orc.aggregate_elem([self._v(t, n) for t in tensors], self.b)
+
+    def aggregate_slices(self, buf, n_slices, slice_elems, out):
+        full = self._v(buf, n_slices * slice_elems)
+        parts = [full[g * slice_elems:(g + 1) * slice_elems] for g in range(n_slices)]
+        self._v(out, slice_elems)[:] = orc.aggregate_elem(parts, self.b)
+
+    def decrypt_range(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, out):
+        add = orc.mask_sum(KEY, it, add_idx, n, n_jobs, self.b)[first:first + count]
+        minus = orc.mask_sum(KEY, it, minus_idx, n, n_jobs, self.b)[first:first + count]
+        self._v(out, count)[:] = orc.combine(self.b, self._v(inp, count), add, minus)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    orc.set_num_threads(1)
+    for b, n, cpr, n_jobs, scheme in [(128, 1000, 2, 8, SCHEME_DOUBLE), (128, 77, 1, 1, SCHEME_DOUBLE),
+                                      (20, 999, 3, 16, SCHEME_DOUBLE), (64, 130, 2, 4, SCHEME_SINGLE)]:
+        L = 2 if b > 64 else 1
+        ops = OracleOps(b)
+        rnd = ShardedRound(ops, n, b, cpr, n_jobs, "cpu", rank=rank, world=world, scheme=scheme)
+        pt_bits = min(b, 64) - 8
+        all_pts = [np.random.Generator(np.random.PCG64(1000 + c)).integers(0, 2 ** pt_bits, n, dtype=np.uint64)
+                   for c in range(world * cpr)]
+        mine = [torch.from_numpy(all_pts[rank * cpr + c].view(np.int64).copy()) for c in range(cpr)]
+        res = rnd.run(5, mine, 1).numpy().view(np.uint64)[: n * L].reshape(n, L)
+        want = np.zeros(n, dtype=np.uint64)
+        for p in all_pts:
+            want += p
+        if b < 64:
+            want &= np.uint64((1 << b) - 1)
+        assert np.array_equal(res[:, 0], want), (rank, b, n)
+        if L == 2:
+            assert not res[:, 1].any()
+        # the same round through the oracle as one process: identical ciphertext aggregate
+    dist.barrier()
+    if rank == 0:
+        print("DIST_OK")
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

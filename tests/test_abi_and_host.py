@@ -1,0 +1,82 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/flashe.h declares, its
+host-side logic matches the golden vectors, and it refuses to work without a HIP device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load_golden
+
+from flashe_amd import _lib, engine
+
+KEY = bytes(range(32))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "flashe.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(flashe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/flashe.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+    assert lib.flashe_abi_version() == 1
+    assert [lib.flashe_limbs(b) for b in (0, 1, 64, 65, 128, 129)] == [0, 1, 1, 2, 2, 0]
+
+
+def test_chunks_match_reference():
+    for c in load_golden("mask_streams.json")["cases"]:
+        b = engine.chunks(c["n"], c["n_jobs"])
+        assert [[b[i], b[i + 1]] for i in range(c["n_jobs"])] == c["chunks"]
+    with pytest.raises(engine.FlasheError):
+        engine.chunks(5, 0)
+
+
+def test_telescope_matches_reference_prefixes():
+    for c in load_golden("cipher_rounds.json")["cases"]:
+        if c["scheme"] != "double":
+            continue
+        add, minus = engine.telescope(list(c["uploaded"]))
+        it = c["iter"]
+        assert [(it.to_bytes(4, "big") + i.to_bytes(4, "big")).hex() for i in add] == c["prefix_add"]
+        assert [(it.to_bytes(4, "big") + i.to_bytes(4, "big")).hex() for i in minus] == c["prefix_minus"]
+    assert engine.telescope([]) == ([], [])
+    assert engine.telescope([0, 1, 2, 4]) == ([3, 5], [0, 4])          # SURVEY.md 8c dropout anchor
+    assert engine.telescope([0] * 10) == ([1] * 10, [0] * 10)          # notebook cell 14
+
+
+def test_host_prp_block_matches_anchors():
+    g = load_golden("aes_anchors.json")
+    f = g["fips197_c3"]
+    assert engine.prp_block(bytes.fromhex(f["key"]), bytes.fromhex(f["pt"])).hex() == f["ct"]
+    for c in g["blocks"]:
+        assert engine.prp_block(KEY, bytes.fromhex(c["block"])).hex() == c["out"]
+
+
+def test_no_device_means_loud_failure():
+    lib = _lib.load()
+    cnt = ctypes.c_int(-1)
+    lib.flashe_device_count(ctypes.byref(cnt))
+    if cnt.value > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(engine.FlasheError) as e:
+        engine.Engine(KEY, 128)
+    assert e.value.code == -19 and "no CPU fallback" in str(e.value)
+    h = ctypes.c_void_p()
+    rc = lib.flashe_ctx_create(ctypes.byref(h), (ctypes.c_uint8 * 32)(), 300, 0, None)
+    assert rc == -22 and b"int_bits" in lib.flashe_last_error(None)
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "flashe_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), f"{f} mentions the oracle"

@@ -1,0 +1,89 @@
+"""CPU-only: the host logic of flashe_amd.cipher.FlasheCipher (state machine, prefix
+selection, precompute caches, int<->limb conversion, sparse bookkeeping), driven with the
+oracle-backed engine double from tests/fake_engine.py against the reference's golden vectors.
+The same scenarios run on the real HIP engine in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, unhex
+from fake_engine import OracleEngine
+
+from flashe_amd import cipher as cm
+from cipher_scenarios import (run_precompute_case, run_round_case, run_sparse_dense_double_case,
+                              run_sparse_single_case)
+
+
+@pytest.fixture()
+def cipher_cls(oracle, monkeypatch):
+    monkeypatch.setattr(cm.FlasheCipher, "_engine_cls", OracleEngine)
+    return cm.FlasheCipher
+
+
+def test_rounds(cipher_cls):
+    for c in load_golden("cipher_rounds.json")["cases"]:
+        run_round_case(cm, c)
+
+
+def test_precompute(cipher_cls):
+    for c in load_golden("precompute.json")["cases"]:
+        run_precompute_case(cm, c)
+
+
+def test_sparse_single(cipher_cls):
+    for c in load_golden("sparse.json")["single"]:
+        run_sparse_single_case(cm, c)
+
+
+def test_sparse_dense_double(cipher_cls):
+    for c in load_golden("sparse.json")["dense_double"]:
+        run_sparse_dense_double_case(cm, c)
+
+
+def test_reference_error_convention(cipher_cls):
+    c = cm.FlasheCipher(64)
+    assert c.encrypt(np.array([1, 2], dtype=object)) is None          # no seed (jzf_flashe.py:503-504)
+    assert c.decrypt(np.array([1, 2], dtype=object)) is None
+    c.generate_prp_seed(bytes(range(32)))
+    c.set_iter_index(0)
+    c.idx = 0
+    assert c.encrypt([1, 2, 3]) is None                                # not an ndarray (:496-497)
+    assert c.decrypt([1, 2, 3]) is None
+    with pytest.raises(ZeroDivisionError):
+        cm.FlasheCipher(129)                                           # merge_size = 128 // int_bits == 0
+    with pytest.raises(OverflowError):
+        c.set_iter_index(-1)
+    assert c.get_idx_list() == [0]
+    assert len(c.get_prp_seed()) == 256                                # the reference's 256-BYTE seed quirk
+
+
+def test_key_normalisation(cipher_cls):
+    for k in load_golden("aes_anchors.json")["key_norm"]:
+        c = cm.FlasheCipher(128)
+        c.generate_prp_seed(bytes.fromhex(k["seed"]) if "seed" in k else int(k["seed_int"], 16))
+        assert c._key.hex() == k["aes_key"] and len(c.get_prp_seed()) == k["prp_seed_len"]
+
+
+def test_exchanged_keys(cipher_cls):
+    c = cm.FlasheCipher(64)
+    c.set_self_uuid("me")
+    c.set_exchanged_keys({"g": (0, 1, "guest", 0), "me": (2, 5, "host", 1)})
+    assert c.idx == 2 and c.get_guest_uuid() == "g"
+
+
+def test_uint64_fast_path_equals_object_path(cipher_cls):
+    key = bytes(range(32))
+    cm.N_JOBS = 4
+    for b in (128, 64, 20):
+        vals = np.arange(1, 40, dtype=np.uint64) * np.uint64(977)
+        c = cm.FlasheCipher(b)
+        c.generate_prp_seed(key)
+        c.set_iter_index(3)
+        c.idx = 1
+        a = c.encrypt(vals.astype(object))
+        f = c.encrypt(vals)
+        ints = [int(v) for v in a]
+        if b > 64:
+            assert f.shape == (39, 2)
+            assert [int(lo) | (int(hi) << 64) for lo, hi in f] == ints
+        else:
+            assert f.shape == (39,) and [int(v) for v in f] == ints

@@ -1,0 +1,340 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of
+libflashe_hip.so and is compared bit-for-bit with (a) the golden vectors generated from the
+reference and (b) the CPU oracle on the same seeded inputs; full BASELINE sizes are covered by
+size-independent properties (round trip, linearity) plus one full-array oracle comparison."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, unhex
+
+pytestmark = pytest.mark.gpu
+
+KEY = bytes(range(32))
+
+
+@pytest.fixture(scope="module")
+def E():
+    from flashe_amd import engine
+    return engine
+
+
+def make(E, b, key=KEY):
+    return E.Engine(key, b, device=0)
+
+
+def L(b):
+    return 2 if b > 64 else 1
+
+
+def rand_limbs(rng, n, b):
+    out = rng.integers(0, 2 ** 64, size=(n, L(b)), dtype=np.uint64)
+    if b > 64 and b < 128:
+        out[:, 1] &= np.uint64((1 << (b - 64)) - 1)
+    elif b < 64:
+        out[:, 0] &= np.uint64((1 << b) - 1)
+    return out
+
+
+# ------------------------------------------------------------------ known answers
+def test_device_selftest(E):
+    for b in (128, 64, 20):
+        make(E, b).selftest()
+
+
+def test_mask_streams_golden(E, oracle):
+    g = load_golden("mask_streams.json")
+    engines = {}
+    for c in g["cases"]:
+        eng = engines.setdefault(c["b"], make(E, c["b"]))
+        got = oracle.limbs_to_ints(eng.mask(c["iter"], [c["idx"]], c["n"], c["n_jobs"]))
+        assert got == unhex(c["stream"]), (c["b"], c["n"], c["n_jobs"])
+    for c in g["sums"]:
+        eng = engines.setdefault(c["b"], make(E, c["b"]))
+        assert oracle.limbs_to_ints(eng.mask(c["iter"], c["add_idx"], c["n"], c["n_jobs"])) == unhex(c["add"])
+        assert oracle.limbs_to_ints(eng.mask(c["iter"], c["minus_idx"], c["n"], c["n_jobs"])) == unhex(c["minus"])
+
+
+def test_cipher_rounds_golden_engine(E, oracle):
+    for c in load_golden("cipher_rounds.json")["cases"]:
+        b, n, J, it = c["b"], c["n"], c["n_jobs"], c["iter"]
+        sch = E.SCHEME_DOUBLE if c["scheme"] == "double" else E.SCHEME_SINGLE
+        eng = make(E, b)
+        cts = {}
+        for i, pt in c["pt"].items():
+            ct = eng.encrypt(it, int(i), sch, J, oracle.ints_to_limbs(unhex(pt), b))
+            assert oracle.limbs_to_ints(ct) == unhex(c["ct"][i])
+            cts[int(i)] = ct
+        models = [cts[i] for i in c["uploaded"]]
+        if n == 0:
+            continue
+        agg = eng.aggregate_elem(models)
+        assert oracle.limbs_to_ints(agg) == unhex(c["agg_elem"])
+        packed = [eng.pack(m) for m in models]
+        aggp = eng.aggregate_packed(packed, n * b)
+        assert sum(int(v) << (64 * i) for i, v in enumerate(aggp)) == int(c["agg_packed_int"], 16)
+        aggp_el = eng.unpack(aggp, n)
+        assert oracle.limbs_to_ints(aggp_el) == unhex(c["agg_packed"])
+        if c["scheme"] == "double":
+            add_idx, minus_idx = E.telescope(list(c["uploaded"]))
+        else:
+            add_idx, minus_idx = [], list(c["uploaded"])
+        assert oracle.limbs_to_ints(eng.decrypt(it, add_idx, minus_idx, J, agg)) == unhex(c["dec_elem"])
+        assert oracle.limbs_to_ints(eng.decrypt(it, add_idx, minus_idx, J, aggp_el)) == unhex(c["dec_packed"])
+
+
+def test_flashe_cipher_class_golden(E):
+    """The same scenarios the CPU suite runs on the engine double, now on the HIP engine."""
+    from flashe_amd import cipher as cm
+    from cipher_scenarios import (run_precompute_case, run_round_case, run_sparse_dense_double_case,
+                                  run_sparse_single_case)
+    assert cm.FlasheCipher._engine_cls is E.Engine
+    for c in load_golden("cipher_rounds.json")["cases"]:
+        run_round_case(cm, c)
+    for c in load_golden("precompute.json")["cases"]:
+        run_precompute_case(cm, c)
+    g = load_golden("sparse.json")
+    for c in g["single"]:
+        run_sparse_single_case(cm, c)
+    for c in g["dense_double"]:
+        run_sparse_dense_double_case(cm, c)
+
+
+def test_pack_golden(E, oracle):
+    g = load_golden("pack.json")
+    for c in g["cases"] + g["merges"]:
+        eng = make(E, c["b"])
+        v = oracle.ints_to_limbs(unhex(c["vals"]), c["b"])
+        p = eng.pack(v)
+        assert sum(int(x) << (64 * i) for i, x in enumerate(p)) == int(c["packed_int"], 16)
+        assert oracle.limbs_to_ints(eng.unpack(p, c["n"])) == unhex(c["vals"])
+    ce = g["carry_example"]
+    eng = make(E, 8)
+    a, c2 = oracle.ints_to_limbs(unhex(ce["a"]), 8), oracle.ints_to_limbs(unhex(ce["c"]), 8)
+    s = eng.aggregate_packed([eng.pack(a), eng.pack(c2)], 24)
+    assert oracle.limbs_to_ints(eng.unpack(s, 3)) == unhex(ce["packed_sum"])
+    assert oracle.limbs_to_ints(eng.aggregate_elem([a, c2])) == unhex(ce["elem_sum"])
+
+
+def test_sparse_golden_engine(E, oracle):
+    g = load_golden("sparse.json")
+    for c in g["single"]:
+        b, total, J, it, C = c["b"], c["total"], c["n_jobs"], c["iter"], c["num_clients"]
+        eng = make(E, b)
+        dense = []
+        for i in range(C):
+            up = unhex(c["uploads"][i])
+            ct = eng.encrypt(it, i, E.SCHEME_SINGLE, J, oracle.ints_to_limbs(unhex(c["pt"][i]), b))
+            assert oracle.limbs_to_ints(ct) == up[:-1]
+            d = eng.expand_to_dense(total, c["locs"][i], ct, oracle.ints_to_limbs([up[-1]], b))
+            assert oracle.limbs_to_ints(d) == unhex(c["dense"][i])
+            dense.append(d)
+        agg = eng.aggregate_elem(dense)
+        assert oracle.limbs_to_ints(agg) == unhex(c["agg"])
+        mm = eng.sparse_minus_mask(it, c["locs"], total, J)
+        assert oracle.limbs_to_ints(mm) == unhex(c["minus_mask"])
+        assert oracle.limbs_to_ints(eng.combine(agg, None, mm)) == unhex(c["dec"])
+    for c in g["dense_double"]:
+        eng = make(E, c["b"])
+        assert oracle.limbs_to_ints(eng.sparse_dense_mask(c["iter"], c["add_sel"], c["total"])) == unhex(c["add"])
+        assert oracle.limbs_to_ints(eng.sparse_dense_mask(c["iter"], c["minus_sel"], c["total"])) == unhex(c["minus"])
+
+
+def test_config1_golden(E):
+    """BASELINE config 1 (1e4 fp32 -> 32-bit quantise -> 64-bit modulus, 2 clients, single mask)."""
+    z = np.load(os.path.join(GOLDEN, "config1.npz"))
+    n, b, J = 10000, 64, 8
+    eng = make(E, b)
+    cts = []
+    for c in range(2):
+        ct = eng.encrypt(0, c, E.SCHEME_SINGLE, J, z[f"q{c}"])
+        assert np.array_equal(ct[:, 0], z[f"ct{c}"])
+        cts.append(ct)
+    agg = eng.aggregate_elem(cts)
+    assert np.array_equal(agg[:, 0], z["agg_elem"])
+    aggp = eng.unpack(eng.aggregate_packed([eng.pack(c) for c in cts], n * b), n)
+    assert np.array_equal(aggp[:, 0], z["agg_packed"])
+    assert np.array_equal(eng.decrypt(0, [], [0, 1], J, agg)[:, 0], z["dec_elem"])
+    assert np.array_equal(eng.decrypt(0, [], [0, 1], J, aggp)[:, 0], z["dec_packed"])
+
+
+# ------------------------------------------------------------------ seeded oracle comparisons
+@pytest.mark.parametrize("b,n,J", [(128, 100003, 8), (127, 4099, 3), (100, 70001, 16), (65, 5000, 1),
+                                   (64, 100003, 8), (63, 20011, 16), (33, 50021, 5), (32, 65536, 16),
+                                   (23, 61706, 16), (20, 262144, 16), (16, 30011, 7), (8, 40009, 16),
+                                   (7, 10007, 3), (1, 12345, 16), (128, 1, 16), (20, 5, 16), (64, 1025, 1024)])
+def test_encrypt_decrypt_vs_oracle(E, oracle, b, n, J):
+    rng = np.random.Generator(np.random.PCG64(b * 1000 + J))
+    eng = make(E, b)
+    it = 123456
+    pt = rand_limbs(rng, n, b)
+    for sch, name in ((E.SCHEME_DOUBLE, "double"), (E.SCHEME_SINGLE, "single")):
+        ct = eng.encrypt(it, 5, sch, J, pt)
+        assert np.array_equal(ct, oracle.encrypt(KEY, it, 5, name, J, b, pt)), (b, n, J, name)
+    add_idx, minus_idx = [3, 11, 11, 2 ** 32 - 1], [0, 7, 9]
+    ct = rand_limbs(rng, n, b)
+    assert np.array_equal(eng.decrypt(it, add_idx, minus_idx, J, ct), oracle.decrypt(KEY, it, add_idx, minus_idx, J, b, ct))
+    assert np.array_equal(eng.decrypt(it, [], [4], J, ct), oracle.decrypt(KEY, it, [], [4], J, b, ct))
+    assert np.array_equal(eng.decrypt(it, [10], [0], J, ct), oracle.decrypt(KEY, it, [10], [0], J, b, ct))
+    assert np.array_equal(eng.decrypt(it, [], [], J, ct), oracle.combine(b, ct))
+    assert np.array_equal(eng.mask(it, [9], n, J), oracle.mask(KEY, it, 9, n, J, b))
+
+
+def test_u64_plaintext_zero_extension(E, oracle):
+    rng = np.random.Generator(np.random.PCG64(3))
+    eng = make(E, 128)
+    pt = rng.integers(0, 2 ** 64, 30000, dtype=np.uint64)
+    wide = np.stack([pt, np.zeros_like(pt)], axis=1)
+    a = eng.encrypt(1, 2, E.SCHEME_DOUBLE, 4, pt)
+    assert np.array_equal(a, eng.encrypt(1, 2, E.SCHEME_DOUBLE, 4, wide))
+    assert np.array_equal(a, oracle.encrypt(KEY, 1, 2, "double", 4, 128, pt))
+
+
+def test_counter_beyond_32_bits_and_extreme_prefixes(E, oracle):
+    """iter / idx at 2^32 - 1 (FIPS anchors hold the 2^64-1 counter block itself)."""
+    eng = make(E, 128)
+    it, idx = 2 ** 32 - 1, 2 ** 32 - 2
+    pt = np.arange(1000, dtype=np.uint64)
+    assert np.array_equal(eng.encrypt(it, idx, E.SCHEME_DOUBLE, 1, pt), oracle.encrypt(KEY, it, idx, "double", 1, 128, pt))
+    g = load_golden("aes_anchors.json")
+    for c in g["blocks"]:
+        assert E.prp_block(KEY, bytes.fromhex(c["block"])).hex() == c["out"]
+
+
+@pytest.mark.parametrize("b,C,n", [(128, 10, 100003), (128, 1, 17), (64, 3, 100001), (20, 100, 61706),
+                                   (128, 100, 61706), (100, 65, 1001), (7, 130, 999)])
+def test_aggregate_elem_vs_oracle(E, oracle, b, C, n):
+    rng = np.random.Generator(np.random.PCG64(C))
+    eng = make(E, b)
+    cts = [rand_limbs(rng, n, b) for _ in range(C)]
+    assert np.array_equal(eng.aggregate_elem(cts), oracle.aggregate_elem(cts, b))
+
+
+def test_aggregate_packed_carry_chains(E, oracle):
+    """Adversarial carries: all-ones limbs make one +1 ripple across wave, block and pass boundaries."""
+    eng = make(E, 64)
+    for n_limbs, C in [(1, 2), (2, 3), (511, 2), (512, 2), (513, 5), (1025, 2), (4099, 10), (20000, 66), (3000, 130)]:
+        total_bits = n_limbs * 64
+        ones = np.full(n_limbs, 2 ** 64 - 1, dtype=np.uint64)
+        one = np.zeros(n_limbs, dtype=np.uint64)
+        one[0] = 1
+        ops = [ones, one] + [np.zeros(n_limbs, dtype=np.uint64) for _ in range(C - 2)]
+        got = eng.aggregate_packed(ops, total_bits)
+        assert np.array_equal(got, oracle.aggregate_packed(ops, total_bits)), (n_limbs, C)
+        assert not got.any()                                            # 2^N - 1 + 1 = 0 mod 2^N
+        rng = np.random.Generator(np.random.PCG64(n_limbs))
+        ops = [rng.integers(0, 2 ** 64, n_limbs, dtype=np.uint64) for _ in range(C)]
+        ops[0][n_limbs // 3: 2 * n_limbs // 3 + 1] = 2 ** 64 - 1        # long propagate run
+        ops[1][n_limbs // 3: 2 * n_limbs // 3 + 1] = 0
+        for o in ops[2:]:
+            o[n_limbs // 3: 2 * n_limbs // 3 + 1] = 0
+        for top in (0, 1, 37):
+            tb = total_bits - top if n_limbs > 1 or top < 64 else total_bits
+            masked = [o.copy() for o in ops]
+            assert np.array_equal(eng.aggregate_packed(masked, tb), oracle.aggregate_packed(masked, tb)), (n_limbs, C, top)
+
+
+@pytest.mark.parametrize("b,n", [(128, 50001), (120, 40003), (65, 999), (64, 70001), (33, 12345), (23, 61706),
+                                 (20, 100000), (8, 4097), (7, 30000), (1, 10000)])
+def test_pack_unpack_vs_oracle(E, oracle, b, n):
+    rng = np.random.Generator(np.random.PCG64(b))
+    eng = make(E, b)
+    x = rand_limbs(rng, n, b)
+    p = eng.pack(x)
+    assert np.array_equal(p, oracle.pack(x, b))
+    assert np.array_equal(eng.unpack(p, n), x)
+    ys = [rand_limbs(rng, n, b) for _ in range(4)]
+    got = eng.unpack(eng.aggregate_packed([eng.pack(y) for y in ys], n * b), n)
+    want = oracle.unpack(oracle.aggregate_packed([oracle.pack(y, b) for y in ys], n * b), n, b)
+    assert np.array_equal(got, want)
+
+
+def test_sparse_config5_shape_small(E, oracle):
+    """BASELINE config 5 scaled down: total = 255 570, 1 % per client, C = 8, b = 128, single mask."""
+    total, C, b, J, it = 255570, 8, 128, 16, 2
+    rng = np.random.Generator(np.random.PCG64(2000))
+    eng = make(E, b)
+    locs = [np.sort(rng.choice(total, size=total // 100, replace=False)).astype(np.uint32) for _ in range(C)]
+    dense, zeros = [], []
+    for c in range(C):
+        pt = rng.integers(0, 2 ** 60, len(locs[c]), dtype=np.uint64)
+        ct = eng.encrypt(it, c, E.SCHEME_SINGLE, J, pt)
+        z = np.array([int(rng.integers(0, 2 ** 15)), 0], dtype=np.uint64)
+        zeros.append(z)
+        d = eng.expand_to_dense(total, locs[c], ct, z)
+        assert np.array_equal(d, oracle.expand_to_dense(total, locs[c], ct, z, b))
+        dense.append(d)
+    agg = eng.aggregate_elem(dense)
+    mm = eng.sparse_minus_mask(it, locs, total, J)
+    assert np.array_equal(mm, oracle.sparse_minus_mask(KEY, it, locs, total, J, b))
+    dec = eng.combine(agg, None, mm)
+    assert np.array_equal(dec, oracle.combine(b, oracle.aggregate_elem(dense, b), None, mm))
+
+
+# ------------------------------------------------------------------ BASELINE full sizes
+def _sum_u64(pts):
+    lo = np.zeros_like(pts[0])
+    hi = np.zeros_like(pts[0])
+    for p in pts:
+        new = lo + p
+        hi += (new < lo).astype(np.uint64)
+        lo = new
+    return lo, hi
+
+
+def test_config2_full_size_round(E, oracle):
+    """n = 1e7, b = 128, C = 10, double mask, data resident in HBM: the decrypted aggregate must equal
+    the plaintext sum (encrypt -> aggregate -> decrypt round trip), a dropout round must too, and one
+    client's full ciphertext plus the full aggregate are compared with the oracle."""
+    n, C, b, it = 10_000_000, 10, 128, 0
+    eng = make(E, b)
+    pts = [np.random.Generator(np.random.PCG64(1000 + c)).integers(0, 2 ** 64, n, dtype=np.uint64) for c in range(C)]
+    dpt = [eng.upload(p) for p in pts]
+    dct = [eng.alloc_vec(n) for _ in range(C)]
+    for c in range(C):
+        eng.encrypt_dev(it, c, E.SCHEME_DOUBLE, n, 16, dpt[c], 1, dct[c])
+    dagg, dout = eng.alloc_vec(n), eng.alloc_vec(n)
+    eng.aggregate_elem_dev(dct, n, dagg)
+    eng.decrypt_dev(it, [C], [0], n, 16, dagg, dout)
+    out = dout.download(np.uint64, 2 * n).reshape(n, 2)
+    lo, hi = _sum_u64(pts)
+    assert np.array_equal(out[:, 0], lo) and np.array_equal(out[:, 1], hi)
+    # one client in full against the oracle, and the aggregate against the oracle's reduce
+    ct3 = dct[3].download(np.uint64, 2 * n).reshape(n, 2)
+    assert np.array_equal(ct3, oracle.encrypt(KEY, it, 3, "double", 16, b, pts[3]))
+    # dropout: clients 4 and 7 missing -> telescoped prefixes
+    up = [0, 1, 2, 3, 5, 6, 8, 9]
+    eng.aggregate_elem_dev([dct[c] for c in up], n, dagg)
+    add_idx, minus_idx = E.telescope(list(up))
+    assert (add_idx, minus_idx) == ([4, 7, 10], [0, 5, 8])
+    eng.decrypt_dev(it, add_idx, minus_idx, n, 16, dagg, dout)
+    out = dout.download(np.uint64, 2 * n).reshape(n, 2)
+    lo, hi = _sum_u64([pts[c] for c in up])
+    assert np.array_equal(out[:, 0], lo) and np.array_equal(out[:, 1], hi)
+    # packed reduce at full size equals element-wise + carry-ins: check via oracle on the packed ints
+    dpk = [eng.alloc_vec(n) for _ in range(3)]
+    for k in range(3):
+        eng.pack_dev(n, dct[k], dpk[k])
+    dsum = eng.alloc_vec(n)
+    eng.aggregate_packed_dev(dpk, 2 * n, 128 * n, dsum)
+    got = dsum.download(np.uint64, 2 * n)
+    want = oracle.aggregate_packed([d.download(np.uint64, 2 * n) for d in dpk], 128 * n)
+    assert np.array_equal(got, want)
+
+
+def test_error_codes(E):
+    eng = make(E, 128)
+    with pytest.raises(E.FlasheError):
+        eng.mask(0, list(range(200)), 10, 1)            # prefix list too long
+    with pytest.raises(E.FlasheError):
+        eng.mask(0, [1], 10, 0)                         # n_jobs = 0
+    with pytest.raises(E.FlasheError):
+        E.Engine(KEY, 0)
+    with pytest.raises(E.FlasheError):
+        E.Engine(KEY, 128, device=99)
+    with pytest.raises(E.FlasheError):
+        eng.expand_to_dense(4, [9], np.zeros((1, 2), dtype=np.uint64), [0, 0])
+    d = eng.alloc_vec(8)
+    with pytest.raises(E.FlasheError):
+        eng.aggregate_packed_dev([d], 16, 1024, d)      # out aliases an operand
