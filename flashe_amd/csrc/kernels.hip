@@ -17,6 +17,7 @@ namespace flashe {
 
 typedef unsigned __int128 u128;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
 
 // ------------------------------------------------------------------------------------------
 // AES-256 core
@@ -59,25 +60,27 @@ __device__ __forceinline__ void fill_tables(uint32_t *tab, const uint32_t *te0)
     __syncthreads();
 }
 
-struct LaneRegs { uint32_t a, b; };   // a: tables 0/1 (low half), b: tables 2/3 (high half)
+// a: tables 0/1 (low 64 KiB half), b: tables 2/3 (high half); base: the table object in LDS, so
+// that every lookup is visibly a load from the array the prologue filled.
+struct LaneRegs { uint32_t a, b; const lds_u8 *base; };
 
-__device__ __forceinline__ LaneRegs lane_regs()
+__device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
 {
     const uint32_t lane4 = (threadIdx.x & 31u) * 4u;
-    return LaneRegs{lane4, lane4 | 0x00010000u};
+    return LaneRegs{lane4, lane4 | 0x00010000u, (const lds_u8 *)(lds_u32 *)tab};
 }
 
 template <int OFF>
-__device__ __forceinline__ uint32_t lut(uint32_t w, uint32_t lanereg, uint32_t sel)
+__device__ __forceinline__ uint32_t lut(const lds_u8 *base, uint32_t w, uint32_t lanereg, uint32_t sel)
 {
     const uint32_t addr = __builtin_amdgcn_perm(w, lanereg, sel);
-    return *reinterpret_cast<lds_u32 *>(static_cast<uintptr_t>(addr + OFF));
+    return *reinterpret_cast<const lds_u32 *>(base + addr + OFF);
 }
 
-#define T0(w, sel) lut<0>(w, lr.a, sel)
-#define T1(w, sel) lut<128>(w, lr.a, sel)
-#define T2(w, sel) lut<0>(w, lr.b, sel)
-#define T3(w, sel) lut<128>(w, lr.b, sel)
+#define T0(w, sel) lut<0>(lr.base, w, lr.a, sel)
+#define T1(w, sel) lut<128>(lr.base, w, lr.a, sel)
+#define T2(w, sel) lut<0>(lr.base, w, lr.b, sel)
+#define T3(w, sel) lut<128>(lr.base, w, lr.b, sel)
 
 __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)
 {
@@ -174,9 +177,8 @@ template <int MODE>
 __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys rk, const PrfParams p, const IdxLists lists)
 {
     __shared__ uint32_t tab[kTabWords];
-    if (lds_offset(tab) != 0u) __builtin_trap();   // lut() addresses LDS from offset 0
     fill_tables(tab, p.te0);
-    const LaneRegs lr = lane_regs();
+    const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(p.mask_hi) << 64) | p.mask_lo;
 
     for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kPrfThreads; base < p.count;
@@ -247,9 +249,8 @@ constexpr int kTch = 8;    // elements accumulated in registers per pass
 __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKeys rk, const PrfParams p, const IdxLists lists)
 {
     __shared__ uint32_t tab[kTabWords];
-    if (lds_offset(tab) != 0u) __builtin_trap();   // lut() addresses LDS from offset 0
     fill_tables(tab, p.te0);
-    const LaneRegs lr = lane_regs();
+    const LaneRegs lr = lane_regs(tab);
 
     // chunks_idx(range(n), n_jobs) in closed form: the first r chunks have d + 1 elements.
     const uint64_t J = p.n_jobs, d = p.n / J, r = p.n % J;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kPrfThreads) void aes_blocks_kernel(const RoundKeys
 {
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, te0);
-    const LaneRegs lr = lane_regs();
+    const LaneRegs lr = lane_regs(tab);
     for (uint32_t i = blockIdx.x * kPrfThreads + threadIdx.x; i < nblk; i += gridDim.x * kPrfThreads) {
         uint32_t s[1][4] = {{in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]}};
         aes256_encrypt<1>(rk, lr, s);

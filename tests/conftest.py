@@ -24,6 +24,8 @@ def oracle():
     """The CPU oracle (test infrastructure): oracle/flashe_oracle.{c,py}."""
     from oracle import flashe_oracle
     flashe_oracle.build()
+    # many-core cloud hosts gain nothing past a few threads for these sizes (and lose to barriers)
+    flashe_oracle.set_num_threads(min(os.cpu_count() or 1, 16))
     return flashe_oracle
 
 
