@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof/<tag>/ (tools/profile.sh output) into tracked files under profiles/:
+
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+  profiles/<tag>_pmc.json           per-kernel PMC averages + derived numbers
+  profiles/traffic.json             HBM bytes per launch of the dominant kernel (read by bench.py)
+
+HBM bytes follow MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are collected in
+separate passes and are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a
+coalesced streaming read, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+The doubling is checked here against a launch whose read volume is known (the aggregate kernel
+reads exactly C * n * 16 bytes)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rows(pattern):
+    files = glob.glob(pattern)
+    return list(csv.DictReader(open(files[0]))) if files else []
+
+
+def main(tag):
+    src = os.path.join(ROOT, "gpurun_out", "prof", tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        for r in rows(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+            k = r["Kernel_Name"]
+            per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            per[k]["_meta"] = [{"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
+                                "lds_bytes": int(r["LDS_Block_Size"]), "workgroup": int(r["Workgroup_Size"]),
+                                "grid": int(r["Grid_Size"])}]
+    for r in rows(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    out = {}
+    for k, d in per.items():
+        if not k.startswith("void flashe::") and not k.startswith("flashe::"):
+            continue
+        e = {"launch": d["_meta"][0]}
+        for c, v in d.items():
+            if c == "_meta":
+                continue
+            e[c] = {"avg": sum(v) / len(v), "min": min(v), "max": max(v), "launches": len(v)}
+        if k in dur:
+            e["avg_duration_us_unprofiled_pass"] = sum(dur[k]) / len(dur[k]) / 1e3
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_bytes_per_launch_avg"] = (2 * e["FETCH_SIZE"]["avg"] + e["WRITE_SIZE"]["avg"]) * 1024
+        if "GRBM_GUI_ACTIVE" in e and k in dur:
+            e["effective_clock_ghz"] = e["GRBM_GUI_ACTIVE"]["avg"] / 8 / (sum(dur[k]) / len(dur[k]))
+        out[k] = e
+    json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+    enc = next((k for k in out if "prf_wide_kernel<1>" in k), None)
+    if enc and "FETCH_SIZE" in out[enc]:
+        f, w = out[enc]["FETCH_SIZE"], out[enc]["WRITE_SIZE"]
+        # the encrypt launches are the ones with the smaller read volume (8-B plaintext in); the
+        # decrypt launch shares the kernel and reads 16 B per element
+        traffic = {"tag": tag, "kernel": enc,
+                   "encrypt_kernel_hbm_bytes_per_launch": (2 * f["min"] + w["min"]) * 1024,
+                   "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = "
+                          "(2 * FETCH_SIZE[KiB] + WRITE_SIZE[KiB]) * 1024 (gfx950 FETCH_SIZE counts 64 B per 128-B "
+                          "request, MI355X_MICROARCH.md HBM section); min over launches = the encrypt launches",
+                   "fetch_kib_min": f["min"], "write_kib": w["min"]}
+        agg = next((k for k in out if "aggregate_elem_kernel" in k), None)
+        if agg and "FETCH_SIZE" in out[agg]:
+            traffic["calibration"] = {"kernel": agg, "fetch_kib_avg": out[agg]["FETCH_SIZE"]["avg"],
+                                      "doubled_bytes": 2 * out[agg]["FETCH_SIZE"]["avg"] * 1024,
+                                      "known_read_bytes": "C * n * 16 (= 1.6e9 at C = 10, n = 1e7)"}
+        json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    print(json.dumps({k[:50]: {c: (round(v["avg"]) if isinstance(v, dict) and "avg" in v else v) for c, v in e.items()
+                               if c != "launch"} for k, e in out.items()}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
