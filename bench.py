@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--clients", type=int, default=10, help="clients per GPU")
     ap.add_argument("--bits", type=int, default=128)
     ap.add_argument("--n-jobs", type=int, default=16)
+    ap.add_argument("--prf-backend", choices=["auto", "table", "bitslice", "hybrid"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     return ap.parse_args()
@@ -110,6 +111,7 @@ def main():
     with torch.cuda.stream(stream):
         eng = Engine(key, b, device=local_rank, stream=stream.cuda_stream)
         eng.selftest()
+        eng.set_prf_backend({"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3}[args.prf_backend])
         ops = HipOps(eng)
         rnd = ShardedRound(ops, n, b, C, args.n_jobs, device, rank=rank, world=world)
         host_pts = [plaintext(rank * C + c) for c in range(C)]
@@ -194,7 +196,8 @@ def main():
                                    f"{C} clients per GPU, double mask, n_jobs={args.n_jobs}; round = {C} encrypts + "
                                    f"{C}-way aggregate + 1 decrypt" + (f"; {world} GPUs: all-to-all reduce-scatter + "
                                    "sliced decrypt + all-gather" if world > 1 else ""),
-                       "n": n, "int_bits": b, "clients_per_gpu": C, "mask": "double", "parity": "bit-exact (checked in-run)"},
+                       "n": n, "int_bits": b, "clients_per_gpu": C, "mask": "double", "prf_backend": args.prf_backend,
+                       "parity": "bit-exact (checked in-run)"},
             "roofline": {"kernel": "prf_wide_kernel<1> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -118,6 +119,7 @@ struct flashe_ctx {
     bool own_stream = false;
     LaunchEnv env{};
     uint32_t *te0_dev = nullptr;
+    uint32_t *rkw_dev = nullptr;
     std::string err;
     // scratch buffers owned by the ctx (grown on demand, reused across calls)
     struct Buf { void *p = nullptr; size_t cap = 0; };
@@ -160,6 +162,14 @@ int ensure(flashe_ctx *ctx, flashe_ctx::Buf &b, size_t bytes)
     size_t cap = std::max<size_t>(bytes, 4096);
     HIP_TRY(ctx, hipMalloc(&b.p, cap));
     b.cap = cap;
+    return FLASHE_OK;
+}
+
+// Device copy of the expanded key for the bit-sliced PRF (it scalar-loads 4 words per round).
+int upload_key_words(flashe_ctx *ctx)
+{
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->rkw_dev, ctx->env.rk.w, sizeof(ctx->env.rk.w), hipMemcpyHostToDevice, ctx->env.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
     return FLASHE_OK;
 }
 
@@ -227,7 +237,25 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
     if ((e = hipMemcpy(ctx->te0_dev, aes_tables().te0, 1024, hipMemcpyHostToDevice)) != hipSuccess)
         return bail(FLASHE_EIO, "hipMemcpy(te0)", e);
     ctx->env.te0_dev = ctx->te0_dev;
+    if ((e = hipMalloc(&ctx->rkw_dev, 256)) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(rkw)", e);
+    ctx->env.rkw_dev = ctx->rkw_dev;
     expand_key(key, &ctx->env.rk);
+    if (upload_key_words(ctx) != FLASHE_OK) {
+        g_create_error = ctx->err;
+        delete ctx;
+        return FLASHE_EIO;
+    }
+    ctx->env.prf_backend = PRF_AUTO;
+    ctx->env.hybrid_bs_permille = 300;
+    if ((e = hipStreamCreateWithFlags(&ctx->env.stream2, hipStreamNonBlocking)) != hipSuccess) return bail(FLASHE_EIO, "hipStreamCreate(2)", e);
+    if ((e = hipEventCreateWithFlags(&ctx->env.ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(FLASHE_EIO, "hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->env.ev_join, hipEventDisableTiming)) != hipSuccess) return bail(FLASHE_EIO, "hipEventCreate", e);
+    if (const char *be = getenv("FLASHE_PRF_BACKEND")) {
+        if (!strcmp(be, "table")) ctx->env.prf_backend = PRF_TABLE;
+        else if (!strcmp(be, "bitslice")) ctx->env.prf_backend = PRF_BITSLICE;
+        else if (!strcmp(be, "hybrid")) ctx->env.prf_backend = PRF_HYBRID;
+    }
+    if (const char *pm = getenv("FLASHE_HYBRID_BS_PERMILLE")) ctx->env.hybrid_bs_permille = atoi(pm);
     *out = ctx;
     return FLASHE_OK;
 }
@@ -240,6 +268,10 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1]})
         if (b->p) (void)hipFree(b->p);
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
+    if (ctx->rkw_dev) (void)hipFree(ctx->rkw_dev);
+    if (ctx->env.stream2) { (void)hipStreamSynchronize(ctx->env.stream2); (void)hipStreamDestroy(ctx->env.stream2); }
+    if (ctx->env.ev_fork) (void)hipEventDestroy(ctx->env.ev_fork);
+    if (ctx->env.ev_join) (void)hipEventDestroy(ctx->env.ev_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->env.stream);
     delete ctx;
     return FLASHE_OK;
@@ -248,7 +280,18 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
 int flashe_ctx_set_key(flashe_ctx *ctx, const uint8_t key[32])
 {
     if (!ctx || !key) return FLASHE_EINVAL;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
     expand_key(key, &ctx->env.rk);
+    return upload_key_words(ctx);
+}
+
+int flashe_ctx_set_prf_backend(flashe_ctx *ctx, int backend)
+{
+    if (!ctx) return FLASHE_EINVAL;
+    if (backend != PRF_AUTO && backend != PRF_TABLE && backend != PRF_BITSLICE && backend != PRF_HYBRID)
+        return fail(ctx, FLASHE_EINVAL, "unknown PRF backend %d", backend);
+    ctx->env.prf_backend = backend;
     return FLASHE_OK;
 }
 

@@ -13,9 +13,18 @@ struct LaunchEnv {
     hipStream_t stream;
     int num_cus;
     const uint32_t *te0_dev;   // 256-entry Te0 table in device memory (1 KiB)
+    const uint32_t *rkw_dev;   // the 60 expanded key words in device memory (scalar-loaded per round by the bit-sliced PRF)
     RoundKeys rk;
     int b;                     // int_bits
+    int prf_backend;           // PRF_AUTO / PRF_TABLE / PRF_BITSLICE / PRF_HYBRID
+    // PRF_HYBRID: the bit-sliced kernel takes `hybrid_bs_permille` / 1000 of the elements on a second
+    // stream while the LDS-table kernel runs the rest -- they saturate different pipes (VALU vs LDS)
+    hipStream_t stream2;
+    hipEvent_t ev_fork, ev_join;
+    int hybrid_bs_permille;
 };
+
+enum { PRF_AUTO = 0, PRF_TABLE = 1, PRF_BITSLICE = 2, PRF_HYBRID = 3 };
 
 // out = (in? + sum_{k<n_add} term(iter, add[k]) - sum_{k<n_minus} term(iter, minus[k])) mod 2^b.
 // add/minus are HOST arrays (copied into the kernel argument block; at most kMaxIdx each).

@@ -87,16 +87,13 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)
     return (a & mask) | (b & ~mask);   // v_bfi_b32
 }
 
-// NB independent blocks, state = 4 big-endian column words each; s already holds plaintext.
-template <int NB>
-__device__ __forceinline__ void aes256_encrypt(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4])
+// Rounds FIRST..13 and the final round on NB independent blocks (state = 4 big-endian column words,
+// already carrying everything up to round FIRST - 1).
+template <int NB, int FIRST>
+__device__ __forceinline__ void aes256_rounds(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4])
 {
 #pragma unroll
-    for (int q = 0; q < NB; q++) {
-        s[q][0] ^= rk.w[0]; s[q][1] ^= rk.w[1]; s[q][2] ^= rk.w[2]; s[q][3] ^= rk.w[3];
-    }
-#pragma unroll
-    for (int r = 1; r < 14; r++) {
+    for (int r = FIRST; r < 14; r++) {
 #pragma unroll
         for (int q = 0; q < NB; q++) {
             uint32_t t[4];
@@ -124,6 +121,44 @@ __device__ __forceinline__ void aes256_encrypt(const RoundKeys &rk, const LaneRe
         }
         s[q][0] = t[0]; s[q][1] = t[1]; s[q][2] = t[2]; s[q][3] = t[3];
     }
+}
+
+// NB independent blocks; s holds the plaintext blocks.
+template <int NB>
+__device__ __forceinline__ void aes256_encrypt(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4])
+{
+#pragma unroll
+    for (int q = 0; q < NB; q++) {
+        s[q][0] ^= rk.w[0]; s[q][1] ^= rk.w[1]; s[q][2] ^= rk.w[2]; s[q][3] ^= rk.w[3];
+    }
+    aes256_rounds<NB, 1>(rk, lr, s);
+}
+
+// PRF blocks are iter | idx | counter: within one launch only the low counter word varies between
+// lanes (when the launch does not straddle a 2^32 counter boundary), so 12 of the 16 first-round
+// lookups see lane-invariant bytes.  CtrPrefix folds them, the round-0 and the round-1 keys into four
+// words per prefix, computed once per kernel; round 1 then costs 4 lookups instead of 16.
+struct CtrPrefix { uint32_t u[4]; };
+
+__device__ __forceinline__ CtrPrefix ctr_prefix(const RoundKeys &rk, const LaneRegs lr, uint32_t iter, uint32_t idx, uint32_t ctr_hi)
+{
+    const uint32_t s0 = iter ^ rk.w[0], s1 = idx ^ rk.w[1], s2 = ctr_hi ^ rk.w[2];
+    CtrPrefix c;
+    c.u[0] = xor3(T0(s0, SEL_B3), T1(s1, SEL_B2), T2(s2, SEL_B1)) ^ rk.w[4];   // + T3[b0(s3)]
+    c.u[1] = xor3(T0(s1, SEL_B3), T1(s2, SEL_B2), T3(s0, SEL_B0)) ^ rk.w[5];   // + T2[b1(s3)]
+    c.u[2] = xor3(T0(s2, SEL_B3), T2(s0, SEL_B1), T3(s1, SEL_B0)) ^ rk.w[6];   // + T1[b2(s3)]
+    c.u[3] = xor3(T1(s0, SEL_B2), T2(s1, SEL_B1), T3(s2, SEL_B0)) ^ rk.w[7];   // + T0[b3(s3)]
+    return c;
+}
+
+// State after round 1 for the block with prefix c and low counter word ctr_lo.
+__device__ __forceinline__ void ctr_round1(const RoundKeys &rk, const LaneRegs lr, const CtrPrefix &c, uint32_t ctr_lo, uint32_t (&s)[4])
+{
+    const uint32_t s3 = ctr_lo ^ rk.w[3];
+    s[0] = c.u[0] ^ T3(s3, SEL_B0);
+    s[1] = c.u[1] ^ T2(s3, SEL_B1);
+    s[2] = c.u[2] ^ T1(s3, SEL_B2);
+    s[3] = c.u[3] ^ T0(s3, SEL_B3);
 }
 
 __device__ __forceinline__ u128 words_to_u128(const uint32_t (&s)[4])
@@ -178,8 +213,18 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
 {
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, p.te0);
+    // latency-critical (LDS round trips): win VALU issue arbitration over co-resident bit-sliced waves
+    __builtin_amdgcn_s_setprio(3);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(p.mask_hi) << 64) | p.mask_lo;
+    // lane-invariant part of round 1 (valid when the launch stays inside one 2^32 counter window)
+    const uint32_t ctr_hi = static_cast<uint32_t>(p.first >> 32);
+    const bool ctr_fast = MODE != 0 && ((p.first + p.count - 1) >> 32) == (p.first >> 32);
+    CtrPrefix pre_a{}, pre_b{};
+    if (ctr_fast) {
+        pre_a = ctr_prefix(rk, lr, p.iter, lists.add[0], ctr_hi);
+        if (MODE == 1) pre_b = ctr_prefix(rk, lr, p.iter, lists.minus[0], ctr_hi);
+    }
 
     for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kPrfThreads; base < p.count;
          base += static_cast<uint64_t>(gridDim.x) * kPrfThreads) {
@@ -190,15 +235,26 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
         if (p.in) acc = p.in_limbs == 2 ? ld128(p.in + 2 * e) : static_cast<u128>(p.in[e]);
         if (MODE == 1) {
             uint32_t s[2][4];
-            set_block(s[0], p.iter, lists.add[0], j);
-            set_block(s[1], p.iter, lists.minus[0], j);
-            aes256_encrypt<2>(rk, lr, s);
+            if (ctr_fast) {
+                ctr_round1(rk, lr, pre_a, static_cast<uint32_t>(j), s[0]);
+                ctr_round1(rk, lr, pre_b, static_cast<uint32_t>(j), s[1]);
+                aes256_rounds<2, 2>(rk, lr, s);
+            } else {
+                set_block(s[0], p.iter, lists.add[0], j);
+                set_block(s[1], p.iter, lists.minus[0], j);
+                aes256_encrypt<2>(rk, lr, s);
+            }
             acc += words_to_u128(s[0]);
             acc -= words_to_u128(s[1]);
         } else if (MODE == 2) {
             uint32_t s[1][4];
-            set_block(s[0], p.iter, lists.add[0], j);
-            aes256_encrypt<1>(rk, lr, s);
+            if (ctr_fast) {
+                ctr_round1(rk, lr, pre_a, static_cast<uint32_t>(j), s[0]);
+                aes256_rounds<1, 2>(rk, lr, s);
+            } else {
+                set_block(s[0], p.iter, lists.add[0], j);
+                aes256_encrypt<1>(rk, lr, s);
+            }
             acc += words_to_u128(s[0]);
         } else {
             int k = 0;
@@ -327,6 +383,62 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Bit-sliced AES-256 PRF (b > 64): pure VALU, no LDS.
+//
+// One lane holds 32 AES blocks as 128 bit planes (plane[8*B + k] = bit k of state byte B; bit p of
+// the 32-bit word = block p); a wave therefore runs 2048 blocks per pass through straight-line
+// v_bitop3_b32 code generated by tools/bitslice/gen_bitslice.py (S-box = Boyar-Peralta circuit
+// mapped to 3-input LUTs, MixColumns / AddRoundKey merged into the same netlist).  With two streams
+// (encrypt double: idx and idx + 1) blocks p < 16 carry the add stream and p >= 16 the minus
+// stream of the SAME 16 elements, so the subtraction stays inside the lane: a wave-pass covers
+// elements tile*1024 + q*64 + lane (q = 0..15) -- for fixed q the 64 lanes are contiguous, i.e.
+// every global access is a full coalesced wave burst.  Planes <-> per-block words go through
+// 32x32 bit transposes (v_perm_b32 for the byte-granular stages, v_bfi_b32 for the rest).
+// ------------------------------------------------------------------------------------------
+}  // namespace flashe
+#include "aes_bitslice_gen.h"
+#include "bitslice_core.h"
+namespace flashe {
+
+constexpr int kBsThreads = 256;
+
+// NSTREAM = 2: one add + one minus prefix (encrypt double / no-dropout decrypt), 16 elements per lane
+// per pass.  NSTREAM = 1: one add prefix only, 32 elements per lane per pass.
+template <int NSTREAM>
+__global__ __launch_bounds__(kBsThreads, 2) void prf_wide_bs_kernel(const uint32_t *__restrict__ rkw, const PrfParams p,
+                                                                    const uint32_t idx_a, const uint32_t idx_b)
+{
+    constexpr int EPL = 32 / NSTREAM;                   // elements per lane per pass
+    constexpr uint64_t TILE = 64ull * EPL;              // elements per wave-pass
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * (kBsThreads / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = static_cast<uint64_t>(gridDim.x) * (kBsThreads / 64);
+    const u128 mask = (static_cast<u128>(p.mask_hi) << 64) | p.mask_lo;
+    const uint64_t n_tiles = (p.count + TILE - 1) / TILE;
+
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        uint32_t s[128];
+        const uint64_t t_first = p.first + tile * TILE;
+        bs::load_planes<NSTREAM>(s, p.iter, idx_a, idx_b, t_first + lane, t_first, t_first + TILE - 1);
+        bs::encrypt_planes(s, rkw);
+        u128 S[32];
+        bs::planes_to_blocks(s, S);
+        // ---- out = in + S_a - S_b ----
+#pragma unroll
+        for (int q = 0; q < EPL; q++) {
+            const uint64_t e = tile * TILE + static_cast<uint64_t>(q) * 64 + lane;
+            if (e < p.count) {
+                u128 acc = 0;
+                if (p.in) acc = p.in_limbs == 2 ? ld128(p.in + 2 * e) : static_cast<u128>(p.in[e]);
+                acc += S[q];
+                if (NSTREAM == 2) acc -= S[q + 16];
+                st128(p.out + 2 * e, acc & mask);
+            }
+        }
+    }
+}
+
 // Known-answer helper: raw AES of nblk blocks given as big-endian words.
 __global__ __launch_bounds__(kPrfThreads) void aes_blocks_kernel(const RoundKeys rk, const uint32_t *te0, uint32_t nblk,
                                                                  const uint32_t *in, uint32_t *out)
@@ -373,6 +485,39 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
                       const uint64_t *in_dev, int in_limbs, uint64_t *out_dev)
 {
     if (count == 0) return hipSuccess;
+    if (env.prf_backend == PRF_HYBRID && env.b > 64 && n_add == 1 && n_minus <= 1 && env.stream2) {
+        // split [first, first + count): tail -> bit-sliced kernel on stream2, head -> table kernel here.
+        // The bit-sliced share is a whole number of passes of all its waves (1 wave per SIMD).
+        const uint64_t tile = n_minus ? 1024 : 2048;
+        const uint64_t wave_slots = static_cast<uint64_t>(env.num_cus) * 4;
+        uint64_t passes = (count * env.hybrid_bs_permille / 1000 + tile * wave_slots / 2) / (tile * wave_slots);
+        uint64_t bs_count = passes * tile * wave_slots;
+        if (bs_count == 0 && count * env.hybrid_bs_permille / 1000 >= tile) bs_count = (count * env.hybrid_bs_permille / 1000) / tile * tile;
+        if (bs_count > count) bs_count = count / tile * tile;
+        const uint64_t tt_count = count - bs_count;
+        LaunchEnv e_tt = env, e_bs = env;
+        e_tt.prf_backend = PRF_TABLE;
+        e_bs.prf_backend = PRF_BITSLICE;
+        e_bs.stream = env.stream2;
+        hipError_t err = hipSuccess;
+        if (bs_count) {
+            if ((err = hipEventRecord(env.ev_fork, env.stream)) != hipSuccess) return err;
+            if ((err = hipStreamWaitEvent(env.stream2, env.ev_fork, 0)) != hipSuccess) return err;
+            const int il = in_limbs ? in_limbs : 0;
+            err = launch_prf(e_bs, iter, add, n_add, minus, n_minus, n, n_jobs, first + tt_count, bs_count,
+                             in_dev ? in_dev + tt_count * il : nullptr, in_limbs, out_dev + tt_count * 2);
+            if (err != hipSuccess) return err;
+        }
+        if (tt_count) {
+            err = launch_prf(e_tt, iter, add, n_add, minus, n_minus, n, n_jobs, first, tt_count, in_dev, in_limbs, out_dev);
+            if (err != hipSuccess) return err;
+        }
+        if (bs_count) {
+            if ((err = hipEventRecord(env.ev_join, env.stream2)) != hipSuccess) return err;
+            if ((err = hipStreamWaitEvent(env.stream, env.ev_join, 0)) != hipSuccess) return err;
+        }
+        return hipSuccess;
+    }
     IdxLists lists;
     for (int k = 0; k < kMaxIdx; k++) { lists.add[k] = k < n_add ? add[k] : 0; lists.minus[k] = k < n_minus ? minus[k] : 0; }
     PrfParams p{};
@@ -381,7 +526,21 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
     p.in_limbs = in_limbs; p.n_add = n_add; p.n_minus = n_minus; p.n_jobs = n_jobs;
     p.b = env.b; p.m = 128 / env.b;
     masks_of(env.b, &p.mask_lo, &p.mask_hi);
-    if (env.b > 64) {
+    const bool bs_shape = env.b > 64 && n_add == 1 && n_minus <= 1;
+    if (bs_shape && env.prf_backend == PRF_BITSLICE) {
+        // 8 waves per CU (2 per SIMD at <= 256 VGPRs): two 256-thread blocks per CU
+        const uint64_t tile = n_minus ? 1024 : 2048;
+        uint64_t waves = (count + tile - 1) / tile;
+        uint64_t blocks = (waves + 3) / 4;
+        const uint64_t cap = static_cast<uint64_t>(env.num_cus) * 2;
+        if (blocks > cap) blocks = cap;
+        if (n_minus)
+            hipLaunchKernelGGL(prf_wide_bs_kernel<2>, dim3(static_cast<unsigned>(blocks)), dim3(kBsThreads), 0, env.stream,
+                               env.rkw_dev, p, lists.add[0], lists.minus[0]);
+        else
+            hipLaunchKernelGGL(prf_wide_bs_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kBsThreads), 0, env.stream,
+                               env.rkw_dev, p, lists.add[0], 0u);
+    } else if (env.b > 64) {
         const int grid = grid_for(env, count, kPrfThreads);
         if (n_add == 1 && n_minus == 1)
             hipLaunchKernelGGL(prf_wide_kernel<1>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);

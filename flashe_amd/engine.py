@@ -127,6 +127,10 @@ class Engine:
         assert len(key) == 32
         self._check(self._lib.flashe_ctx_set_key(self._h, (ctypes.c_uint8 * 32).from_buffer_copy(key)))
 
+    def set_prf_backend(self, backend):
+        """0 = auto, 1 = LDS T-table kernel, 2 = bit-sliced VALU kernel (identical results)."""
+        self._check(self._lib.flashe_ctx_set_prf_backend(self._h, int(backend)))
+
     def selftest(self):
         self._check(self._lib.flashe_selftest(self._h))
 

@@ -57,6 +57,14 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
 int flashe_ctx_destroy(flashe_ctx *ctx);
 int flashe_ctx_set_key(flashe_ctx *ctx, const uint8_t key[32]);
 int flashe_ctx_int_bits(const flashe_ctx *ctx);
+/* Which implementation of the AES-256 PRF the fused kernels use (results are identical):
+ * 0 = automatic, 1 = LDS T-table kernel, 2 = bit-sliced VALU kernel (b > 64, single add prefix with
+ * at most one minus prefix; other shapes always use the table kernel).  Also settable at ctx creation
+ * through the environment variable FLASHE_PRF_BACKEND=table|bitslice. */
+#define FLASHE_PRF_AUTO     0
+#define FLASHE_PRF_TABLE    1
+#define FLASHE_PRF_BITSLICE 2
+int flashe_ctx_set_prf_backend(flashe_ctx *ctx, int backend);
 /* Text of the last error on ctx (ctx == NULL: last flashe_ctx_create failure of this thread). */
 const char *flashe_last_error(const flashe_ctx *ctx);
 /* Known-answer self test on the device: FIPS-197 C.3 through the PRF kernel. */

@@ -181,6 +181,87 @@ def test_encrypt_decrypt_vs_oracle(E, oracle, b, n, J):
     assert np.array_equal(eng.mask(it, [9], n, J), oracle.mask(KEY, it, 9, n, J, b))
 
 
+@pytest.mark.parametrize("b,n", [(128, 100003), (128, 1024), (128, 1), (128, 2049), (127, 4099), (65, 70001), (100, 1000000)])
+def test_bitsliced_prf_backend_vs_oracle(E, oracle, b, n):
+    """The bit-sliced VALU PRF kernel must give the same bits as the LDS-table kernel and the oracle."""
+    rng = np.random.Generator(np.random.PCG64(b + n))
+    eng = make(E, b)
+    eng.set_prf_backend(2)
+    it = 77
+    pt = rand_limbs(rng, n, b)
+    ct = eng.encrypt(it, 5, E.SCHEME_DOUBLE, 16, pt)
+    assert np.array_equal(ct, oracle.encrypt(KEY, it, 5, "double", 16, b, pt))
+    ct1 = eng.encrypt(it, 2 ** 32 - 1, E.SCHEME_SINGLE, 16, pt)
+    assert np.array_equal(ct1, oracle.encrypt(KEY, it, 2 ** 32 - 1, "single", 16, b, pt))
+    u64 = pt[:, 0].copy()
+    assert np.array_equal(eng.encrypt(it, 0, E.SCHEME_DOUBLE, 16, u64), oracle.encrypt(KEY, it, 0, "double", 16, b, u64))
+    assert np.array_equal(eng.decrypt(it, [10], [0], 16, ct), oracle.decrypt(KEY, it, [10], [0], 16, b, ct))
+    assert np.array_equal(eng.mask(it, [9], n, 16), oracle.mask(KEY, it, 9, n, 16, b))
+    # range twin: a slice in the middle of the vector, unaligned to the 1024-element tiles
+    if n > 3000:
+        first, count = 1537, n - 2600
+        d_in, d_out = eng.upload(ct[first:first + count]), eng.alloc_vec(count)
+        eng.decrypt_range_dev(it, [10], [0], n, 16, first, count, d_in, d_out)
+        got = d_out.download(np.uint64, count * 2).reshape(count, 2)
+        assert np.array_equal(got, oracle.decrypt(KEY, it, [10], [0], 16, b, ct)[first:first + count])
+    eng.set_prf_backend(1)
+    assert np.array_equal(eng.encrypt(it, 5, E.SCHEME_DOUBLE, 16, pt), ct)
+
+
+@pytest.mark.parametrize("backend", [1, 2])
+def test_counter_window_across_2_32(E, backend):
+    """A launch whose counters straddle 2^32 (and one just below / above it) must take the generic
+    first-round path; expected values come from the host AES, element by element."""
+    eng = make(E, 128)
+    eng.set_prf_backend(backend)
+    it, idx, n_total = 9, 41, 2 ** 33
+    for first, count in [(2 ** 32 - 700, 1500), (2 ** 32 - 3000, 2048), (2 ** 32, 1100), (3 * 2 ** 31 + 5, 64)]:
+        rng = np.random.Generator(np.random.PCG64(first % 1000))
+        pt = rng.integers(0, 2 ** 64, count, dtype=np.uint64)
+        d_in, d_out = eng.upload(pt), eng.alloc_vec(count)
+        eng.encrypt_range_dev(it, idx, E.SCHEME_DOUBLE, n_total, 1, first, count, d_in, 1, d_out)
+        got = d_out.download(np.uint64, 2 * count).reshape(count, 2)
+        for e in list(range(0, count, 97)) + [count - 1, 699, 700, 701]:
+            if e >= count:
+                continue
+            ctr = first + e
+            blk = lambda i: int.from_bytes(E.prp_block(KEY, it.to_bytes(4, "big") + i.to_bytes(4, "big") + ctr.to_bytes(8, "big")), "big")
+            want = (int(pt[e]) + blk(idx) - blk(idx + 1)) % (1 << 128)
+            assert int(got[e, 0]) | (int(got[e, 1]) << 64) == want, (backend, first, e)
+        d_m = eng.alloc_vec(count)
+        eng.mask_range_dev(it, [idx], n_total, 1, first, count, d_m)          # single-stream mode
+        gm = d_m.download(np.uint64, 2 * count).reshape(count, 2)
+        for e in (0, count // 2, count - 1):
+            ctr = first + e
+            want = int.from_bytes(E.prp_block(KEY, it.to_bytes(4, "big") + idx.to_bytes(4, "big") + ctr.to_bytes(8, "big")), "big")
+            assert int(gm[e, 0]) | (int(gm[e, 1]) << 64) == want
+
+
+def test_range_twins_table_backend(E, oracle):
+    for b, n, J in [(128, 50000, 16), (64, 50001, 8), (20, 70001, 16), (7, 9999, 3)]:
+        rng = np.random.Generator(np.random.PCG64(n))
+        eng = make(E, b)
+        eng.set_prf_backend(1)
+        Lb = L(b)
+        ct = rand_limbs(rng, n, b)
+        want = oracle.decrypt(KEY, 3, [4, 9], [0, 5], J, b, ct)
+        for first, count in [(0, n), (1, n - 1), (1025, 4097), (n - 5, 5), (n // 2, 1), (777, 0)]:
+            d_in, d_out = eng.upload(ct[first:first + count] if count else np.zeros((1, Lb), dtype=np.uint64)), eng.alloc_vec(max(count, 1))
+            eng.decrypt_range_dev(3, [4, 9], [0, 5], n, J, first, count, d_in, d_out)
+            got = d_out.download(np.uint64, count * Lb).reshape(count, Lb)
+            assert np.array_equal(got, want[first:first + count]), (b, first, count)
+        pt = rand_limbs(rng, n, b)[:, :1].copy()
+        wantc = oracle.encrypt(KEY, 3, 6, "double", J, b, pt)
+        first, count = 333, n - 1000
+        d_in, d_out = eng.upload(pt[first:first + count]), eng.alloc_vec(count)
+        eng.encrypt_range_dev(3, 6, E.SCHEME_DOUBLE, n, J, first, count, d_in, 1, d_out)
+        assert np.array_equal(d_out.download(np.uint64, count * Lb).reshape(count, Lb), wantc[first:first + count])
+        d_out2 = eng.alloc_vec(count)
+        eng.mask_range_dev(3, [6, 8], n, J, first, count, d_out2)
+        assert np.array_equal(d_out2.download(np.uint64, count * Lb).reshape(count, Lb),
+                              oracle.mask_sum(KEY, 3, [6, 8], n, J, b)[first:first + count])
+
+
 def test_u64_plaintext_zero_extension(E, oracle):
     rng = np.random.Generator(np.random.PCG64(3))
     eng = make(E, 128)
