@@ -81,6 +81,14 @@ _SIGNATURES = {
     "flashe_sparse_minus_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
     "flashe_sparse_dense_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_sparse_dense_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
+    "flashe_quantize_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),
+    "flashe_quantize": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),
+    "flashe_unquantize_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_int, c_vp]),
+    "flashe_unquantize": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_int, c_vp]),
+    "flashe_batch_dev": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
+    "flashe_batch": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
+    "flashe_unbatch_dev": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
+    "flashe_unbatch": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

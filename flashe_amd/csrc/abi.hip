@@ -695,6 +695,68 @@ int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, co
     return FLASHE_OK;
 }
 
+// ---- quantise / batch codec ----
+static int check_codec_bits(flashe_ctx *ctx, int element_bits)
+{
+    if (element_bits < 1 || element_bits > 62) return fail(ctx, FLASHE_EINVAL, "element_bits must be in [1, 62], got %d", element_bits);
+    return FLASHE_OK;
+}
+
+int flashe_quantize_dev(flashe_ctx *ctx, uint64_t n, const void *x_dev, int x_is_f64, double alpha, int element_bits,
+                        const double *u_dev, uint64_t *q_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!x_dev || !u_dev || !q_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (!(alpha > 0)) return fail(ctx, FLASHE_EINVAL, "alpha must be positive");
+    int rc = check_codec_bits(ctx, element_bits);
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_quantize(ctx->env, n, x_dev, x_is_f64 != 0, alpha, element_bits, u_dev, q_dev));
+    return FLASHE_OK;
+}
+
+int flashe_unquantize_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *v_dev, int v_limbs, double alpha, int element_bits,
+                          int num_clients, double *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!v_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (v_limbs != 1 && v_limbs != 2) return fail(ctx, FLASHE_EINVAL, "v_limbs must be 1 or 2");
+    if (v_limbs == 2 && !aligned16(v_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    if (num_clients < 1) return fail(ctx, FLASHE_EINVAL, "num_clients must be >= 1");
+    int rc = check_codec_bits(ctx, element_bits);
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_unquantize(ctx->env, n, v_dev, v_limbs, alpha, element_bits, num_clients, out_dev));
+    return FLASHE_OK;
+}
+
+static int check_field_bits(flashe_ctx *ctx, int field_bits)
+{
+    if (field_bits < 1 || field_bits > 64 || field_bits > ctx->int_bits)
+        return fail(ctx, FLASHE_EINVAL, "field_bits must be in [1, min(64, int_bits)], got %d", field_bits);
+    return FLASHE_OK;
+}
+
+int flashe_batch_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *vals_dev, int field_bits, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!vals_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_field_bits(ctx, field_bits);
+    if (rc) return rc;
+    if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    HIP_TRY(ctx, launch_batch(ctx->env, n, vals_dev, field_bits, out_dev));
+    return FLASHE_OK;
+}
+
+int flashe_unbatch_dev(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in_dev, int field_bits, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n_batches && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_field_bits(ctx, field_bits);
+    if (rc) return rc;
+    if (ctx->limbs == 2 && !aligned16(in_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    HIP_TRY(ctx, launch_unbatch(ctx->env, n_batches, in_dev, field_bits, out_dev));
+    return FLASHE_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Host-pointer twins: H2D, the _dev call, D2H, synchronous.
 // ------------------------------------------------------------------------------------------
@@ -906,6 +968,78 @@ int flashe_sparse_dense_mask(flashe_ctx *ctx, uint32_t iter, int n_lists, const 
     int rc = flashe_sparse_dense_mask_dev(ctx, iter, n_lists, ptrs.data(), total, dout.as<uint64_t>());
     if (rc) return rc;
     D2H(out, dout.p, vec_bytes(ctx, total));
+    return FLASHE_OK;
+}
+
+int flashe_quantize(flashe_ctx *ctx, uint64_t n, const void *x, int x_is_f64, double alpha, int element_bits, const double *u,
+                    uint64_t *q)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!x || !u || !q) return fail(ctx, FLASHE_EINVAL, "null vector");
+    const size_t xb = static_cast<size_t>(n) * (x_is_f64 ? 8 : 4);
+    Tmp dx, du, dq;
+    HIP_TRY(ctx, dx.alloc(xb));
+    HIP_TRY(ctx, du.alloc(static_cast<size_t>(n) * 8));
+    HIP_TRY(ctx, dq.alloc(static_cast<size_t>(n) * 8));
+    H2D(dx.p, x, xb);
+    H2D(du.p, u, static_cast<size_t>(n) * 8);
+    int rc = flashe_quantize_dev(ctx, n, dx.p, x_is_f64, alpha, element_bits, du.as<double>(), dq.as<uint64_t>());
+    if (rc) return rc;
+    D2H(q, dq.p, static_cast<size_t>(n) * 8);
+    return FLASHE_OK;
+}
+
+int flashe_unquantize(flashe_ctx *ctx, uint64_t n, const uint64_t *v, int v_limbs, double alpha, int element_bits, int num_clients,
+                      double *out)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!v || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (v_limbs != 1 && v_limbs != 2) return fail(ctx, FLASHE_EINVAL, "v_limbs must be 1 or 2");
+    Tmp dv, dout;
+    HIP_TRY(ctx, dv.alloc(static_cast<size_t>(n) * v_limbs * 8));
+    HIP_TRY(ctx, dout.alloc(static_cast<size_t>(n) * 8));
+    H2D(dv.p, v, static_cast<size_t>(n) * v_limbs * 8);
+    int rc = flashe_unquantize_dev(ctx, n, dv.as<uint64_t>(), v_limbs, alpha, element_bits, num_clients, dout.as<double>());
+    if (rc) return rc;
+    D2H(out, dout.p, static_cast<size_t>(n) * 8);
+    return FLASHE_OK;
+}
+
+int flashe_batch(flashe_ctx *ctx, uint64_t n, const uint64_t *vals, int field_bits, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (n == 0) return FLASHE_OK;
+    if (!vals || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_field_bits(ctx, field_bits);
+    if (rc) return rc;
+    const uint64_t bs = ctx->int_bits / field_bits, nb = (n + bs - 1) / bs;
+    Tmp dv, dout;
+    HIP_TRY(ctx, dv.alloc(static_cast<size_t>(n) * 8));
+    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, nb)));
+    H2D(dv.p, vals, static_cast<size_t>(n) * 8);
+    rc = flashe_batch_dev(ctx, n, dv.as<uint64_t>(), field_bits, dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, nb));
+    return FLASHE_OK;
+}
+
+int flashe_unbatch(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in, int field_bits, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (n_batches == 0) return FLASHE_OK;
+    if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_field_bits(ctx, field_bits);
+    if (rc) return rc;
+    const uint64_t bs = ctx->int_bits / field_bits;
+    Tmp di, dout;
+    HIP_TRY(ctx, di.alloc(vec_bytes(ctx, n_batches)));
+    HIP_TRY(ctx, dout.alloc(static_cast<size_t>(n_batches * bs) * 8));
+    H2D(di.p, in, vec_bytes(ctx, n_batches));
+    rc = flashe_unbatch_dev(ctx, n_batches, di.as<uint64_t>(), field_bits, dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, static_cast<size_t>(n_batches * bs) * 8);
     return FLASHE_OK;
 }
 

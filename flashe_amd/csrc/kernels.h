@@ -64,6 +64,14 @@ hipError_t launch_scatter(const LaunchEnv &env, uint64_t k, const uint32_t *loc_
 hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uint8_t *sel_dev,
                                  const uint64_t *stream_dev, uint64_t *out_dev);
 
+// Quantise / batch codec
+hipError_t launch_quantize(const LaunchEnv &env, uint64_t n, const void *x_dev, bool is_f64, double alpha, int bits,
+                           const double *u_dev, uint64_t *q_dev);
+hipError_t launch_unquantize(const LaunchEnv &env, uint64_t n, const uint64_t *v_dev, int v_limbs, double alpha, int bits,
+                             int num_clients, double *out_dev);
+hipError_t launch_batch(const LaunchEnv &env, uint64_t n, const uint64_t *vals_dev, int field_bits, uint64_t *out_dev);
+hipError_t launch_unbatch(const LaunchEnv &env, uint64_t nb, const uint64_t *in_dev, int field_bits, uint64_t *out_dev);
+
 // Device KAT: encrypts `nblk` 16-byte blocks (big-endian words in) with the PRF core.
 hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t *in_words_dev,
                              uint32_t *out_words_dev);

@@ -949,4 +949,122 @@ hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uin
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// Quantise / batch codec either side of the cipher (streaming, HBM-bound)
+// ------------------------------------------------------------------------------------------
+// float arithmetic below must round exactly like numpy's: no contraction into FMAs
+template <typename T>
+__global__ __launch_bounds__(kStreamThreads) void quantize_kernel(uint64_t n, const T *x, T alpha, T scale, T den,
+                                                                  const double *u, uint64_t *q)
+{
+#pragma clang fp contract(off)
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        T v = x[j];
+        v = v < -alpha ? -alpha : (v > alpha ? alpha : v);
+        v = v + alpha;
+        v = v * scale;
+        v = v / den;
+        q[j] = static_cast<uint64_t>(static_cast<int64_t>(floor(static_cast<double>(v) + u[j])));
+    }
+}
+
+// correctly rounded (nearest-even) u128 -> double, as Python's int -> float
+__device__ __forceinline__ double u128_to_double(u128 v)
+{
+    const uint64_t hi = static_cast<uint64_t>(v >> 64), lo = static_cast<uint64_t>(v);
+    if (hi == 0) return static_cast<double>(lo);
+    const int sh = 64 - __clzll(static_cast<long long>(hi));       // 1..64 bits above the low limb
+    uint64_t m = static_cast<uint64_t>(v >> sh);                    // top 64 significant bits
+    const u128 dropped = v & ((static_cast<u128>(1) << sh) - 1);
+    if (dropped) m |= 1;                                            // sticky: 64 > 53 + 2 keeps rounding exact
+    return ldexp(static_cast<double>(m), sh);
+}
+
+__global__ __launch_bounds__(kStreamThreads) void unquantize_kernel(uint64_t n, const uint64_t *v, int v_limbs, double ac,
+                                                                    double two_a, double den, double *out)
+{
+#pragma clang fp contract(off)
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const u128 x = v_limbs == 2 ? ld128(v + 2 * j) : static_cast<u128>(v[j]);
+        const double d = u128_to_double(x);
+        out[j] = d * two_a / den - ac;
+    }
+}
+
+// one batch (bs consecutive values, first most significant) per lane
+__global__ __launch_bounds__(kStreamThreads) void batch_kernel(uint64_t n, uint64_t nb, const uint64_t *vals, int L, int bs,
+                                                               int field_bits, uint64_t *out)
+{
+    for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; b < nb;
+         b += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        u128 t = 0;
+        for (int i = 0; i < bs; i++) {
+            const uint64_t j = b * bs + i;
+            t = (field_bits >= 128 ? 0 : t << field_bits) + (j < n ? vals[j] : 0ull);
+        }
+        if (L == 2) st128(out + 2 * b, t);
+        else out[b] = static_cast<uint64_t>(t);
+    }
+}
+
+__global__ __launch_bounds__(kStreamThreads) void unbatch_kernel(uint64_t nb, const uint64_t *in, int L, int bs, int field_bits,
+                                                                 uint64_t *out)
+{
+    const u128 mk = field_bits >= 128 ? ~static_cast<u128>(0) : ((static_cast<u128>(1) << field_bits) - 1);
+    for (uint64_t b = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; b < nb;
+         b += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        u128 item = L == 2 ? ld128(in + 2 * b) : static_cast<u128>(in[b]);
+        for (int i = 0; i < bs; i++) {
+            out[b * bs + (bs - 1 - i)] = static_cast<uint64_t>(item & mk);
+            item = field_bits >= 128 ? 0 : item >> field_bits;
+        }
+    }
+}
+
+hipError_t launch_quantize(const LaunchEnv &env, uint64_t n, const void *x_dev, bool is_f64, double alpha, int bits,
+                           const double *u_dev, uint64_t *q_dev)
+{
+    if (n == 0) return hipSuccess;
+    const double scale = static_cast<double>((1ull << bits) - 1);
+    if (is_f64)
+        hipLaunchKernelGGL(quantize_kernel<double>, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n,
+                           static_cast<const double *>(x_dev), alpha, scale, 2 * alpha, u_dev, q_dev);
+    else
+        hipLaunchKernelGGL(quantize_kernel<float>, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n,
+                           static_cast<const float *>(x_dev), static_cast<float>(alpha), static_cast<float>(scale),
+                           static_cast<float>(2 * alpha), u_dev, q_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_unquantize(const LaunchEnv &env, uint64_t n, const uint64_t *v_dev, int v_limbs, double alpha, int bits,
+                             int num_clients, double *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    const double ac = alpha * static_cast<double>(num_clients);
+    const double den = static_cast<double>(((1ull << bits) - 1) * static_cast<uint64_t>(num_clients));
+    hipLaunchKernelGGL(unquantize_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, v_dev, v_limbs, ac,
+                       2 * ac, den, out_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_batch(const LaunchEnv &env, uint64_t n, const uint64_t *vals_dev, int field_bits, uint64_t *out_dev)
+{
+    const int bs = env.b / field_bits;
+    const uint64_t nb = (n + bs - 1) / bs;
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(batch_kernel, dim3(stream_grid(env, nb)), dim3(kStreamThreads), 0, env.stream, n, nb, vals_dev,
+                       env.b > 64 ? 2 : 1, bs, field_bits, out_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_unbatch(const LaunchEnv &env, uint64_t nb, const uint64_t *in_dev, int field_bits, uint64_t *out_dev)
+{
+    if (nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(unbatch_kernel, dim3(stream_grid(env, nb)), dim3(kStreamThreads), 0, env.stream, nb, in_dev,
+                       env.b > 64 ? 2 : 1, env.b / field_bits, field_bits, out_dev);
+    return hipGetLastError();
+}
+
 }  // namespace flashe

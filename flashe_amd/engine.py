@@ -339,3 +339,55 @@ class Engine:
         self._check(self._lib.flashe_sparse_dense_mask(self._h, it, len(sels), ctypes.cast(tab, ctypes.POINTER(c_vp)),
                                                        total, out.ctypes.data))
         return out
+
+    # -- quantise / batch codec (jzf_quantize.py *_padding_asymmetric) ----------------------------
+    def quantize_dev(self, n, x, x_is_f64, alpha, element_bits, u, q):
+        self._check(self._lib.flashe_quantize_dev(self._h, n, self._ptr(x), 1 if x_is_f64 else 0, float(alpha), element_bits,
+                                                  self._ptr(u), self._ptr(q)))
+
+    def unquantize_dev(self, n, v, v_limbs, alpha, element_bits, num_clients, out):
+        self._check(self._lib.flashe_unquantize_dev(self._h, n, self._ptr(v), v_limbs, float(alpha), element_bits, num_clients,
+                                                    self._ptr(out)))
+
+    def batch_dev(self, n, vals, field_bits, out):
+        self._check(self._lib.flashe_batch_dev(self._h, n, self._ptr(vals), field_bits, self._ptr(out)))
+
+    def unbatch_dev(self, n_batches, inp, field_bits, out):
+        self._check(self._lib.flashe_unbatch_dev(self._h, n_batches, self._ptr(inp), field_bits, self._ptr(out)))
+
+    def quantize(self, x, alpha, element_bits, u):
+        x = np.ascontiguousarray(x)
+        if x.dtype not in (np.float32, np.float64):
+            x = x.astype(np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1)
+        x = x.reshape(-1)
+        if u.shape[0] != x.shape[0]:
+            raise ValueError("need one uniform draw per element")
+        q = np.zeros(x.shape[0], dtype=np.uint64)
+        self._check(self._lib.flashe_quantize(self._h, x.shape[0], x.ctypes.data, 1 if x.dtype == np.float64 else 0,
+                                              float(alpha), element_bits, u.ctypes.data, q.ctypes.data))
+        return q
+
+    def unquantize(self, v, alpha, element_bits, num_clients):
+        v = np.ascontiguousarray(v, dtype=np.uint64)
+        if v.ndim == 1:
+            v = v.reshape(-1, 1)
+        out = np.zeros(v.shape[0], dtype=np.float64)
+        self._check(self._lib.flashe_unquantize(self._h, v.shape[0], v.ctypes.data, v.shape[1], float(alpha), element_bits,
+                                                num_clients, out.ctypes.data))
+        return out
+
+    def batch(self, vals, field_bits):
+        vals = np.ascontiguousarray(vals, dtype=np.uint64).reshape(-1)
+        bs = self.int_bits // field_bits
+        nb = (vals.shape[0] + bs - 1) // bs
+        out = np.zeros((nb, self.limbs), dtype=np.uint64)
+        self._check(self._lib.flashe_batch(self._h, vals.shape[0], vals.ctypes.data, field_bits, out.ctypes.data))
+        return out
+
+    def unbatch(self, batched, field_bits):
+        batched = self._vec(batched)
+        bs = self.int_bits // field_bits
+        out = np.zeros(batched.shape[0] * bs, dtype=np.uint64)
+        self._check(self._lib.flashe_unbatch(self._h, batched.shape[0], batched.ctypes.data, field_bits, out.ctypes.data))
+        return out

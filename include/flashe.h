@@ -195,6 +195,31 @@ int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, co
 int flashe_sparse_dense_mask(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel,
                              uint64_t total, uint64_t *out);
 
+/* ---- quantise / batch codec either side of the cipher ------------------ */
+/* _static_quantize_padding_asymmetric -- federatedml/secureprotol/jzf_quantize.py:55-67:
+ * q = floor(clip(x, -alpha, alpha) + alpha) * (2^element_bits - 1) / (2 alpha) + u), with numpy's
+ * dtype rules (x_is_f64 == 0: x is float32 and every step before "+ u" is a float32 operation).
+ * u holds the stochastic-rounding draws in [0, 1) (the reference uses np.random.random). */
+int flashe_quantize_dev(flashe_ctx *ctx, uint64_t n, const void *x_dev, int x_is_f64, double alpha,
+                        int element_bits, const double *u_dev, uint64_t *q_dev);
+int flashe_quantize(flashe_ctx *ctx, uint64_t n, const void *x, int x_is_f64, double alpha,
+                    int element_bits, const double *u, uint64_t *q);
+/* _static_unquantize_padding_asymmetric -- jzf_quantize.py:102-107:
+ * out = v * (2 alpha C) / ((2^element_bits - 1) C) - alpha C in float64, v converted like a Python int
+ * (correctly rounded).  v has v_limbs (1 or 2) limbs per element. */
+int flashe_unquantize_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *v_dev, int v_limbs, double alpha,
+                          int element_bits, int num_clients, double *out_dev);
+int flashe_unquantize(flashe_ctx *ctx, uint64_t n, const uint64_t *v, int v_limbs, double alpha,
+                      int element_bits, int num_clients, double *out);
+/* _static_batching_padding_asymmetric / _static_unbatching_padding_asymmetric -- jzf_quantize.py:162-185,
+ * :234-251: batch_size = int_bits // field_bits values (uint64, zero-padded to a multiple) <-> one
+ * int_bits-wide element, first value most significant; field_bits = element_bits + ceil(log2(num_clients)).
+ * batch: out holds ceil(n / batch_size) elements; unbatch: out holds n_batches * batch_size values. */
+int flashe_batch_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *vals_dev, int field_bits, uint64_t *out_dev);
+int flashe_batch(flashe_ctx *ctx, uint64_t n, const uint64_t *vals, int field_bits, uint64_t *out);
+int flashe_unbatch_dev(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in_dev, int field_bits, uint64_t *out_dev);
+int flashe_unbatch(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in, int field_bits, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -240,6 +240,60 @@ def sparse_dense_mask(key, it, sels, total, b):
     return out
 
 
+def quantize(x, alpha, bits, u):
+    x = np.ascontiguousarray(x)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    q = np.zeros(len(x), dtype=np.uint64)
+    if x.dtype == np.float32:
+        lib().fo_quantize_f32(ctypes.c_uint64(len(x)), x.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(alpha),
+                              ctypes.c_int(bits), u.ctypes.data_as(ctypes.c_void_p), _p64(q))
+    else:
+        x = x.astype(np.float64)
+        lib().fo_quantize_f64(ctypes.c_uint64(len(x)), x.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(alpha),
+                              ctypes.c_int(bits), u.ctypes.data_as(ctypes.c_void_p), _p64(q))
+    return q
+
+
+def unquantize(v, alpha, bits, num_clients):
+    v = np.ascontiguousarray(v, dtype=np.uint64)
+    if v.ndim == 1:
+        v = v.reshape(-1, 1)
+    out = np.zeros(v.shape[0], dtype=np.float64)
+    lib().fo_unquantize(ctypes.c_uint64(v.shape[0]), _p64(v), ctypes.c_int(v.shape[1]), ctypes.c_double(alpha),
+                        ctypes.c_int(bits), ctypes.c_int(num_clients), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def batch(vals, int_bits, field_bits):
+    vals = np.ascontiguousarray(vals, dtype=np.uint64)
+    bs = int_bits // field_bits
+    nb = (len(vals) + bs - 1) // bs
+    out = np.zeros((nb, limbs_of(int_bits)), dtype=np.uint64)
+    lib().fo_batch.restype = ctypes.c_uint64
+    r = lib().fo_batch(ctypes.c_uint64(len(vals)), _p64(vals), ctypes.c_int(int_bits), ctypes.c_int(field_bits), _p64(out))
+    assert r == nb
+    return out
+
+
+def unbatch(batched, int_bits, field_bits):
+    batched = np.ascontiguousarray(batched, dtype=np.uint64)
+    if batched.ndim == 1:
+        batched = batched.reshape(-1, 1)
+    bs = int_bits // field_bits
+    out = np.zeros(batched.shape[0] * bs, dtype=np.uint64)
+    lib().fo_unbatch(ctypes.c_uint64(batched.shape[0]), _p64(batched), ctypes.c_int(int_bits), ctypes.c_int(field_bits), _p64(out))
+    return out
+
+
+def aesni_available():
+    return bool(lib().fo_aesni_available())
+
+
+def set_aesni(on):
+    """Force the portable table AES (False) or allow AES-NI (True)."""
+    lib().fo_set_aesni(ctypes.c_int(1 if on else 0))
+
+
 def num_threads():
     return int(lib().fo_num_threads())
 

@@ -473,7 +473,46 @@ def gen_config1():
     print(f"wrote config1.npz: {os.path.getsize(p)} bytes; q0[:3] = {[int(v) for v in qs[0][:3]]}")
 
 
+# --------------------------------------------------------------------------- quantise codec (f-1)
+def gen_codec():
+    """_static_{quantize,unquantize,batching,unbatching}_padding_asymmetric (jzf_quantize.py:55-67,
+    :102-107, :162-185, :234-251) on seeded inputs.  The stochastic-rounding uniforms are numpy's
+    legacy global MT19937 stream (np.random.seed(s); np.random.random(n)); they are stored so that
+    a port can consume the same draws.  Float arrays are stored as raw little-endian bytes (hex)."""
+    out = {"quantize": [], "batch": [], "unquantize": []}
+    for dtype, eb, n, seed, scale in [("float32", 16, 257, 11, 1.0), ("float32", 32, 300, 12, 3.0), ("float32", 8, 100, 13, 0.2),
+                                      ("float64", 16, 200, 14, 1.0), ("float64", 32, 129, 15, 2.5), ("float32", 20, 64, 16, 10.0)]:
+        x = (np.random.RandomState(seed).standard_normal(n) * scale).astype(dtype)
+        x[:3] = [0.0, 1e9, -1e9]                                   # exact zero and both clip rails
+        alpha = ACIQ(eb).get_alpha_gaus_direct(1.0)
+        np.random.seed(1000 + seed)
+        u = np.random.random(n)
+        np.random.seed(1000 + seed)
+        q = RQ._static_quantize_padding_asymmetric(x, alpha, eb)
+        out["quantize"].append({"dtype": dtype, "element_bits": eb, "n": n, "alpha": float(alpha).hex(),
+                                "x": x.tobytes().hex(), "u": u.tobytes().hex(), "q": hxl(q)})
+    rng = np.random.RandomState(99)
+    for int_bits, eb, C, n in [(120, 16, 10, 37), (128, 16, 10, 50), (64, 16, 2, 10), (20, 16, 10, 7), (128, 32, 100, 33),
+                               (120, 16, 10, 6), (64, 8, 4, 100)]:
+        factor = int(np.ceil(np.log2(C)))
+        vals = [int(v) for v in rng.randint(0, 2 ** eb, size=n)]
+        b = RQ._static_batching_padding_asymmetric(np.array(vals, dtype=object), int_bits, eb, factor)
+        un = RQ._static_unbatching_padding_asymmetric(b, int_bits, eb, factor)
+        bs = int_bits // (eb + factor)
+        assert [int(v) for v in un[:n]] == vals and len(un) == len(b) * bs
+        out["batch"].append({"int_bits": int_bits, "element_bits": eb, "num_clients": C, "factor": factor, "n": n,
+                             "vals": hxl(vals), "batched": hxl(b), "unbatched": hxl(un)})
+    for eb, C, n, top_bits in [(32, 2, 100, 34), (16, 10, 64, 20), (32, 100, 50, 39), (16, 3, 40, 120), (8, 2, 30, 64)]:
+        alpha = ACIQ(eb).get_alpha_gaus_direct(1.0)
+        vals = rand_ints(rng, n, top_bits)
+        r = RQ._static_unquantize_padding_asymmetric(np.array(vals, dtype=object), alpha, eb, C)
+        out["unquantize"].append({"element_bits": eb, "num_clients": C, "n": n, "alpha": float(alpha).hex(),
+                                  "vals": hxl(vals), "out": np.array([float(v) for v in r], dtype=np.float64).tobytes().hex()})
+    dump("codec.json", out)
+
+
 if __name__ == "__main__":
+    gen_codec()
     gen_aes()
     gen_masks()
     gen_rounds()

@@ -353,6 +353,69 @@ def test_sparse_config5_shape_small(E, oracle):
     assert np.array_equal(dec, oracle.combine(b, oracle.aggregate_elem(dense, b), None, mm))
 
 
+# ------------------------------------------------------------------ quantise / batch codec (8f-1)
+def test_codec_golden(E, oracle):
+    g = load_golden("codec.json")
+    e64 = make(E, 64)
+    for c in g["quantize"]:
+        x = np.frombuffer(bytes.fromhex(c["x"]), dtype=c["dtype"])
+        u = np.frombuffer(bytes.fromhex(c["u"]), dtype=np.float64)
+        q = e64.quantize(x, float.fromhex(c["alpha"]), c["element_bits"], u)
+        assert [int(v) for v in q] == unhex(c["q"]), (c["dtype"], c["element_bits"])
+    for c in g["batch"]:
+        eng = make(E, c["int_bits"])
+        fb = c["element_bits"] + c["factor"]
+        b = eng.batch(np.array(unhex(c["vals"]), dtype=np.uint64), fb)
+        assert oracle.limbs_to_ints(b) == unhex(c["batched"])
+        assert [int(v) for v in eng.unbatch(b, fb)] == unhex(c["unbatched"])
+    e128 = make(E, 128)
+    for c in g["unquantize"]:
+        want = np.frombuffer(bytes.fromhex(c["out"]), dtype=np.float64)
+        got = e128.unquantize(oracle.ints_to_limbs(unhex(c["vals"]), 128), float.fromhex(c["alpha"]), c["element_bits"], c["num_clients"])
+        assert got.tobytes() == want.tobytes()
+
+
+def test_codec_vs_oracle_large(E, oracle):
+    rng = np.random.Generator(np.random.PCG64(5))
+    e64, e128 = make(E, 64), make(E, 128)
+    for dtype, bits in ((np.float32, 16), (np.float32, 32), (np.float64, 24)):
+        x = (rng.standard_normal(300001) * 4).astype(dtype)
+        u = rng.random(300001)
+        assert np.array_equal(e64.quantize(x, 8.17121, bits, u), oracle.quantize(x, 8.17121, bits, u))
+    v = rng.integers(0, 2 ** 64, size=(200001, 2), dtype=np.uint64)
+    v[::3, 1] = 0
+    v[1::7, 1] &= np.uint64(0xFF)
+    assert e128.unquantize(v, 6.5, 32, 10).tobytes() == oracle.unquantize(v, 6.5, 32, 10).tobytes()
+    for int_bits, fb in ((128, 20), (120, 20), (64, 17), (20, 20), (100, 33)):
+        eng = make(E, int_bits)
+        vals = rng.integers(0, 2 ** fb, 100003, dtype=np.uint64)
+        b = eng.batch(vals, fb)
+        assert np.array_equal(b, oracle.batch(vals, int_bits, fb))
+        assert np.array_equal(eng.unbatch(b, fb), oracle.unbatch(b, int_bits, fb))
+
+
+def test_config1_end_to_end_with_codec(E):
+    """BASELINE config 1 with the codec on the GPU too: fp32 -> quantise -> encrypt -> aggregate ->
+    decrypt -> unquantise, every stage equal to the reference's fixture (same MT19937 draws)."""
+    from flashe_amd import quantize as qz
+    z = np.load(os.path.join(GOLDEN, "config1.npz"))
+    n, b, J, alpha = 10000, 64, 8, float(z["alpha"])
+    eng = make(E, b)
+    cts = []
+    for c in range(2):
+        np.random.seed(7 + c)
+        q = qz._static_quantize_padding_asymmetric(z[f"x{c}"], alpha, 32, as_object=False)
+        assert np.array_equal(q, z[f"q{c}"])
+        ct = eng.encrypt(0, c, E.SCHEME_SINGLE, J, q)
+        assert np.array_equal(ct[:, 0], z[f"ct{c}"])
+        cts.append(ct)
+    dec = eng.decrypt(0, [], [0, 1], J, eng.aggregate_elem(cts))
+    unq = qz._static_unquantize_padding_asymmetric(dec[:, 0], alpha, 32, 2)
+    assert unq.tobytes() == z["unq_elem"].tobytes()
+    unq_obj = qz._static_unquantize_padding_asymmetric(dec[:, 0].astype(object), alpha, 32, 2)
+    assert unq_obj.tobytes() == z["unq_elem"].tobytes()
+
+
 # ------------------------------------------------------------------ BASELINE full sizes
 def _sum_u64(pts):
     lo = np.zeros_like(pts[0])

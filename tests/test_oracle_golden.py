@@ -190,6 +190,44 @@ def test_config1_plumbing(oracle):
     assert np.abs(z["unq_elem"] - true).max() < 1e-5 and np.abs(z["unq_packed"] - true).max() < 1e-5
 
 
+def test_quantise_codec(oracle):
+    """quantise / batch / unbatch / unquantise against the reference's outputs."""
+    g = load_golden("codec.json")
+    for c in g["quantize"]:
+        x = np.frombuffer(bytes.fromhex(c["x"]), dtype=c["dtype"])
+        u = np.frombuffer(bytes.fromhex(c["u"]), dtype=np.float64)
+        q = oracle.quantize(x, float.fromhex(c["alpha"]), c["element_bits"], u)
+        assert [int(v) for v in q] == unhex(c["q"]), (c["dtype"], c["element_bits"])
+    for c in g["batch"]:
+        fb = c["element_bits"] + c["factor"]
+        vals = np.array(unhex(c["vals"]), dtype=np.uint64)
+        b = oracle.batch(vals, c["int_bits"], fb)
+        assert oracle.limbs_to_ints(b) == unhex(c["batched"])
+        assert [int(v) for v in oracle.unbatch(b, c["int_bits"], fb)] == unhex(c["unbatched"])
+    for c in g["unquantize"]:
+        vals = oracle.ints_to_limbs(unhex(c["vals"]), 128)
+        want = np.frombuffer(bytes.fromhex(c["out"]), dtype=np.float64)
+        got = oracle.unquantize(vals, float.fromhex(c["alpha"]), c["element_bits"], c["num_clients"])
+        assert got.tobytes() == want.tobytes(), c["element_bits"]
+
+
+def test_aesni_and_table_paths_agree(oracle):
+    """The AES-NI fast path of the oracle (used for the CPU baseline) against its portable table path."""
+    if not oracle.aesni_available():
+        pytest.skip("no AES-NI on this CPU / compiler")
+    try:
+        for b, n, J in [(128, 4099, 3), (64, 5000, 8), (20, 7001, 16)]:
+            pt = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+            if b < 64:
+                pt &= np.uint64((1 << b) - 1)
+            oracle.set_aesni(False)
+            a = oracle.encrypt(KEY, 5, 7, "double", J, b, pt)
+            oracle.set_aesni(True)
+            assert np.array_equal(a, oracle.encrypt(KEY, 5, 7, "double", J, b, pt))
+    finally:
+        oracle.set_aesni(True)
+
+
 def test_telescope_examples(oracle):
     assert oracle.telescope([0, 1, 2, 4]) == ([3, 5], [0, 4])
     assert oracle.telescope([0] * 4) == ([1, 1, 1, 1], [0, 0, 0, 0])
