@@ -55,6 +55,7 @@ _SIGNATURES = {
     "flashe_event_create": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
     "flashe_event_destroy": (c_int, [c_vp, c_vp]),
     "flashe_event_record": (c_int, [c_vp, c_vp]),
+    "flashe_stream_wait_event": (c_int, [c_vp, c_vp]),
     "flashe_event_elapsed_ms": (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(ctypes.c_float)]),
     "flashe_mask_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_vp]),
     "flashe_mask": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_vp]),

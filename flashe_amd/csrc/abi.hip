@@ -441,6 +441,14 @@ int flashe_event_record(flashe_ctx *ctx, void *event)
     HIP_TRY(ctx, hipEventRecord(static_cast<hipEvent_t>(event), ctx->env.stream));
     return FLASHE_OK;
 }
+int flashe_stream_wait_event(flashe_ctx *ctx, void *event)
+{
+    CHECK_CTX(ctx);
+    if (!event) return fail(ctx, FLASHE_EINVAL, "null event");
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->env.stream, static_cast<hipEvent_t>(event), 0));
+    return FLASHE_OK;
+}
+
 int flashe_event_elapsed_ms(flashe_ctx *ctx, void *start, void *stop, float *ms)
 {
     CHECK_CTX(ctx);

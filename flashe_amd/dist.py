@@ -34,10 +34,40 @@ def slice_len(n, world):
 
 class HipOps:
     """torch CUDA tensors (int64 views of limb vectors) -> C-ABI `_dev` calls.  The engine must
-    have been created on torch's current stream so that RCCL and the kernels are ordered."""
+    have been created on torch's current stream so that RCCL and the kernels are ordered.
+    `side` is an optional second engine (same key / int_bits, its own stream) on which the
+    HBM-bound reduce of the pipelined round runs next to the AES-bound kernels."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, side=None):
         self.engine = engine
+        self.side = side
+        self._events = {}
+
+    # ---- two-stream plumbing for ShardedRound.run_pipelined (no-ops without a side engine) ----
+    def _ev(self, name):
+        if name not in self._events:
+            self._events[name] = self.engine.event()
+        return self._events[name]
+
+    def signal(self, name, on_side=False):
+        (self.side if on_side else self.engine).record(self._ev(name))
+
+    def wait(self, name, on_side=False):
+        (self.side if on_side else self.engine).wait_event(self._ev(name))
+
+    def encrypt_range(self, it, idx, scheme, n, n_jobs, first, count, pt, pt_limbs, ct):
+        L = self.engine.limbs
+        self.engine.encrypt_range_dev(it, idx, scheme, n, n_jobs, first, count, pt.data_ptr() + first * pt_limbs * 8,
+                                      pt_limbs, ct.data_ptr() + first * L * 8)
+
+    def aggregate_range(self, tensors, first, count, out, on_side=True):
+        eng = self.side if (on_side and self.side is not None) else self.engine
+        off = first * eng.limbs * 8
+        eng.aggregate_elem_dev([t.data_ptr() + off for t in tensors], count, out.data_ptr() + off)
+
+    def decrypt_range_at(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, out):
+        off = first * self.engine.limbs * 8
+        self.engine.decrypt_range_dev(it, add_idx, minus_idx, n, n_jobs, first, count, inp.data_ptr() + off, out.data_ptr() + off)
 
     @staticmethod
     def _p(t, elem_offset=0, limbs=1):
@@ -110,6 +140,31 @@ class ShardedRound:
             dist.all_gather_into_tensor(self.result, self.dec_slice, group=self.group)
         else:
             self.ops.decrypt_range(it, add_idx, minus_idx, self.n, self.n_jobs, 0, self.n, self.partial, self.result)
+        return self.result
+
+    def run_pipelined(self, it, pts, pt_limbs, chunks=4):
+        """Single-GPU round with the arbiter reduce hidden under the AES-bound kernels: the last
+        client's encrypt is issued chunk by chunk; as soon as chunk q of every ciphertext exists the
+        reduce of chunk q runs on the side stream, and the decrypt of chunk q follows it on the main
+        stream.  Same arithmetic, same buffers, only the schedule differs."""
+        assert self.world == 1
+        ops, n = self.ops, self.n
+        step = ((n + chunks - 1) // chunks + 1023) // 1024 * 1024
+        bounds = [(f, min(step, n - f)) for f in range(0, n, step)]
+        for c in range(self.cpr - 1):
+            ops.encrypt(it, c, self.scheme, n, self.n_jobs, pts[c], pt_limbs, self.ct[c])
+        last = self.cpr - 1
+        for q, (first, count) in enumerate(bounds):
+            ops.encrypt_range(it, last, self.scheme, n, self.n_jobs, first, count, pts[last], pt_limbs, self.ct[last])
+            ops.signal(f"enc{q}")
+            ops.wait(f"enc{q}", on_side=True)
+            ops.aggregate_range(self.ct, first, count, self.partial)
+            ops.signal(f"agg{q}", on_side=True)
+        uploaded = list(range(self.cpr))
+        add_idx, minus_idx = telescope(uploaded) if self.scheme == SCHEME_DOUBLE else ([], uploaded)
+        for q, (first, count) in enumerate(bounds):
+            ops.wait(f"agg{q}")
+            ops.decrypt_range_at(it, add_idx, minus_idx, n, self.n_jobs, first, count, self.partial, self.result)
         return self.result
 
     def run(self, it, pts, pt_limbs):

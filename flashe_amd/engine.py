@@ -155,6 +155,10 @@ class Engine:
     def record(self, ev):
         self._check(self._lib.flashe_event_record(self._h, ev))
 
+    def wait_event(self, ev):
+        """Device-side wait of this engine's stream on an event recorded by another engine."""
+        self._check(self._lib.flashe_stream_wait_event(self._h, ev))
+
     def elapsed_ms(self, start, stop):
         ms = ctypes.c_float(0)
         self._check(self._lib.flashe_event_elapsed_ms(self._h, start, stop, ctypes.byref(ms)))

@@ -92,6 +92,9 @@ int flashe_event_create(flashe_ctx *ctx, void **event);
 int flashe_event_destroy(flashe_ctx *ctx, void *event);
 int flashe_event_record(flashe_ctx *ctx, void *event);               /* on the ctx stream */
 int flashe_event_elapsed_ms(flashe_ctx *ctx, void *start, void *stop, float *ms); /* syncs on stop */
+/* Make ctx's stream wait (on the device, not the host) for an event recorded by ANOTHER ctx of the
+ * same device: the fork/join primitive for running e.g. the arbiter reduce on a second stream. */
+int flashe_stream_wait_event(flashe_ctx *ctx, void *event);
 
 /* ---- PRF mask streams -------------------------------------------------------------- */
 /* out[j] = sum_k term(iter, idx[k], j) mod 2^b, chunked like chunks_idx(range(n), n_jobs).

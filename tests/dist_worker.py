@@ -19,31 +19,7 @@ from oracle import flashe_oracle as orc  # noqa: E402
 KEY = bytes(range(32))
 
 
-class OracleOps:
-    def __init__(self, b):
-        self.b = b
-        self.L = 2 if b > 64 else 1
-
-    def _v(self, t, n=None):
-        a = t.numpy().view(np.uint64)
-        return a if n is None else a[: n * self.L].reshape(n, self.L)
-
-    def encrypt(self, it, idx, scheme, n, n_jobs, pt, pt_limbs, ct):
-        self._v(ct, n)[:] = orc.encrypt(KEY, it, idx, "double" if scheme == SCHEME_DOUBLE else "single", n_jobs, self.b,
-                                        pt.numpy().view(np.uint64).reshape(n, pt_limbs))
-
-    def aggregate(self, tensors, n, out):
-        self._v(out, n)[:] = orc.aggregate_elem([self._v(t, n) for t in tensors], self.b)
-
-    def aggregate_slices(self, buf, n_slices, slice_elems, out):
-        full = self._v(buf, n_slices * slice_elems)
-        parts = [full[g * slice_elems:(g + 1) * slice_elems] for g in range(n_slices)]
-        self._v(out, slice_elems)[:] = orc.aggregate_elem(parts, self.b)
-
-    def decrypt_range(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, out):
-        add = orc.mask_sum(KEY, it, add_idx, n, n_jobs, self.b)[first:first + count]
-        minus = orc.mask_sum(KEY, it, minus_idx, n, n_jobs, self.b)[first:first + count]
-        self._v(out, count)[:] = orc.combine(self.b, self._v(inp, count), add, minus)
+from oracle_ops import OracleOps  # noqa: E402
 
 
 def main():
