@@ -7,5 +7,6 @@ reference's `FlasheCipher` API.  See DESIGN.md / INTEGRATION.md.
 """
 from .cipher import FlasheCipher, aggregate          # noqa: F401
 from .engine import Engine, DeviceBuffer, FlasheError  # noqa: F401
+from .block import FlasheClient, dynamic_masking_choice  # noqa: F401
 
-__all__ = ["FlasheCipher", "aggregate", "Engine", "DeviceBuffer", "FlasheError"]
+__all__ = ["FlasheCipher", "aggregate", "Engine", "DeviceBuffer", "FlasheError", "FlasheClient", "dynamic_masking_choice"]

@@ -18,6 +18,7 @@ namespace flashe {
 typedef unsigned __int128 u128;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------------------------------
 // AES-256 core
@@ -635,12 +636,15 @@ __global__ __launch_bounds__(kStreamThreads) void aggregate_elem_kernel(int C, c
         u128 acc = 0;
 #pragma unroll 4
         for (int c = 0; c < C; c++) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(tab[c] + 2 * s);
-            if (WIDE) acc += (static_cast<u128>(v.y) << 64) | v.x;
-            else { a0 += v.x; a1 += v.y; }
+            // every operand byte is read exactly once: stream past the caches
+            const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(tab[c] + 2 * s));
+            if (WIDE) acc += (static_cast<u128>(v[1]) << 64) | v[0];
+            else { a0 += v[0]; a1 += v[1]; }
         }
         if (WIDE) { a0 = static_cast<uint64_t>(acc); a1 = static_cast<uint64_t>(acc >> 64); }
-        *reinterpret_cast<ulonglong2 *>(out + 2 * s) = make_ulonglong2(a0 & mask_lo, a1 & (WIDE ? mask_hi : mask_lo));
+        u64x2 r;
+        r[0] = a0 & mask_lo; r[1] = a1 & (WIDE ? mask_hi : mask_lo);
+        __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(out + 2 * s));
     }
     if (!WIDE && (n_limbs & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         uint64_t a = 0;

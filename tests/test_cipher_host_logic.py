@@ -87,3 +87,50 @@ def test_uint64_fast_path_equals_object_path(cipher_cls):
             assert [int(lo) | (int(hi) << 64) for lo, hi in f] == ints
         else:
             assert f.shape == (39,) and [int(v) for v in f] == ints
+
+
+def test_dynamic_masking_choice_matches_reference_model():
+    """jzf_flashe_block.py:92-112 restated literally (object one-hots, Python sum) vs the mirror."""
+    from flashe_amd.block import dynamic_masking_choice
+    rng = np.random.RandomState(4)
+    for total, C, k in [(100, 3, 10), (50, 4, 40), (64, 2, 64), (30, 5, 1), (200, 6, 150)]:
+        masks = [sorted(rng.choice(total, size=k, replace=False).tolist()) for _ in range(C)]
+        single_cost = 2 * sum([len(m) for m in masks])
+        double_cost = 2 * single_cost
+        one_hots = []
+        for i in range(C):
+            oh = np.zeros(total, dtype=object)
+            oh[masks[i]] = 1
+            one_hots.append(oh)
+        canceled = 0
+        for i in range(C - 1):
+            canceled += sum(one_hots[i] & one_hots[i + 1])
+        double_cost -= canceled * 2
+        want = "single" if single_cost <= double_cost else "double"
+        assert dynamic_masking_choice(masks, total) == want
+    # the survey's observation: single_cost <= double_cost always holds
+    assert dynamic_masking_choice([[0, 1, 2], [0, 1, 2]], 3) == "single"
+
+
+def test_flashe_client_adapter_round(cipher_cls):
+    """Two clients + precompute through the _Client-style adapter; the aggregate decrypts to the sum."""
+    from flashe_amd.block import FlasheClient
+    cm.N_JOBS = 4
+    args = {"quantize": {"int_bits": 64, "batch": False, "element_bits": 32, "padding": True, "secure": True},
+            "precompute": {"enable": True, "num_params": 50}}
+    clients = []
+    for i in range(2):
+        c = FlasheClient(args)
+        c.create_cipher(i, 2, bytes(range(32)))
+        assert 'add' in c.cipher.next_iter_encrypt_prepared          # iteration-0 masks precomputed (iter_index starts at -1)
+        c.set_iter_index(0)
+        clients.append(c)
+    vals = np.arange(50, dtype=np.uint64) * np.uint64(3)
+    cts = [c.encrypt(vals.astype(object)) for c in clients]
+    assert clients[0].cipher.next_iter_encrypt_prepared == {}
+    agg = clients[0].cipher.aggregate(cts)
+    clients[0].prepare_decrypt()
+    idx = clients[0].get_idx_list() + clients[1].get_idx_list()
+    clients[0].set_idx_list(idx)
+    out = clients[0].decrypt(agg)
+    assert [int(v) for v in out] == [int(2 * v) for v in vals]
