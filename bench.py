@@ -43,7 +43,10 @@ def parse():
     ap.add_argument("--n-jobs", type=int, default=16)
     ap.add_argument("--prf-backend", choices=["auto", "table", "bitslice", "hybrid"], default="auto")
     ap.add_argument("--pipeline-chunks", type=int, default=4,
-                    help="N = 1 only: > 0 runs the reduce on a second stream, chunk-pipelined under the AES kernels")
+                    help="> 0: everything after the last client's encrypt (reduce, exchange, decrypt) runs chunk by chunk on "
+                         "a side stream under it; 0: sequential phases")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with 1 GPU: still create the RCCL process group and run the N > 1 exchange path (world size 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="elements of the workload the CPU baseline round runs on (default: all of it; ~0.2-2 s)")
@@ -99,8 +102,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1 or args.force_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29300 + os.getpid() % 500))
+            dist.init_process_group("nccl", device_id=device, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     n, C, b, K, W = args.n, args.clients, args.bits, args.steps, args.warmup
@@ -117,12 +125,12 @@ def main():
         eng = Engine(key, b, device=local_rank, stream=stream.cuda_stream)
         eng.selftest()
         eng.set_prf_backend({"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3}[args.prf_backend])
-        side = None
-        if args.pipeline_chunks > 0 and world == 1:
+        side, side_stream = None, None
+        if args.pipeline_chunks > 0:
             side_stream = torch.cuda.Stream(device=device)
             side = Engine(key, b, device=local_rank, stream=side_stream.cuda_stream)
-        ops = HipOps(eng, side)
-        rnd = ShardedRound(ops, n, b, C, args.n_jobs, device, rank=rank, world=world)
+        ops = HipOps(eng, side, side_stream)
+        rnd = ShardedRound(ops, n, b, C, args.n_jobs, device, rank=rank, world=world, force_collectives=args.force_dist)
         host_pts = [plaintext(rank * C + c) for c in range(C)]
         pts = [torch.from_numpy(p.view(np.int64)).to(device) for p in host_pts]
 
@@ -131,7 +139,7 @@ def main():
         ph_ev = [[eng.event() for _ in range(4)] for _ in range(K)]
 
         def timed_round(it, k):
-            if side is not None:
+            if pipelined:
                 eng.record(ph_ev[k][0])
                 rnd.run_pipelined(it, pts, 1, chunks=args.pipeline_chunks)
                 for i in (1, 2, 3):
@@ -150,14 +158,6 @@ def main():
             rnd.decrypt_phase(it)
             eng.record(ph_ev[k][3])
 
-        run_once = (lambda it: rnd.run_pipelined(it, pts, 1, chunks=args.pipeline_chunks)) if side is not None \
-            else (lambda it: rnd.run(it, pts, 1))
-        for w in range(W):
-            run_once(w)
-        # parity gate before any timing counts: decrypted aggregate == plaintext sum (mod 2^b)
-        res = run_once(0)
-        torch.cuda.synchronize()
-        got = res[: n * L].cpu().numpy().view(np.uint64).reshape(n, L)
         lo = np.zeros(n, dtype=np.uint64)
         hi = np.zeros(n, dtype=np.uint64)
         for g in range(world * C):
@@ -167,9 +167,37 @@ def main():
             lo = new
         if b < 64:
             lo &= np.uint64((1 << b) - 1)
-        ok = np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi if b == 128 else hi & np.uint64((1 << (b - 64)) - 1)))
-        if not ok:
-            raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum")
+
+        def parity_ok(res):
+            torch.cuda.synchronize()
+            got = res[: n * L].cpu().numpy().view(np.uint64).reshape(n, L)
+            good = np.array_equal(got[:, 0], lo) and (
+                L == 1 or np.array_equal(got[:, 1], hi if b == 128 else hi & np.uint64((1 << (b - 64)) - 1)))
+            flag = torch.tensor([1 if good else 0], device=device)
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank must agree on the schedule used
+            return bool(flag.item())
+
+        # parity gate before any timing counts: decrypted aggregate == plaintext sum (mod 2^b).  The
+        # pipelined schedule is used only if it passes; otherwise fall back to sequential phases.
+        pipelined = side is not None
+        if pipelined:
+            try:
+                for w in range(W):
+                    rnd.run_pipelined(w, pts, 1, chunks=args.pipeline_chunks)
+                good = parity_ok(rnd.run_pipelined(0, pts, 1, chunks=args.pipeline_chunks))
+            except Exception as exc:          # never lose the measurement to the optional schedule
+                print(f"rank {rank}: pipelined schedule raised {exc!r}", file=sys.stderr)
+                good = False
+            if not good:
+                pipelined = False
+                if rank == 0:
+                    print("warning: pipelined schedule unusable; using sequential phases", file=sys.stderr)
+        if not pipelined:
+            for w in range(W):
+                rnd.run(w, pts, 1)
+            if not parity_ok(rnd.run(0, pts, 1)):
+                raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum")
 
         if world > 1:
             dist.barrier()
@@ -187,7 +215,7 @@ def main():
             dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         elapsed = float(elapsed.item())
 
-        if side is not None:
+        if pipelined:
             # per-launch events are not recorded in the pipelined schedule: time the kernel separately
             for e0, e1 in enc_ev[:C]:
                 eng.record(e0)
@@ -221,8 +249,8 @@ def main():
                                    f"{C}-way aggregate + 1 decrypt" + (f"; {world} GPUs: all-to-all reduce-scatter + "
                                    "sliced decrypt + all-gather" if world > 1 else ""),
                        "n": n, "int_bits": b, "clients_per_gpu": C, "mask": "double", "prf_backend": args.prf_backend,
-                       "schedule": (f"reduce chunk-pipelined on a side stream ({args.pipeline_chunks} chunks)" if args.pipeline_chunks > 0 and world == 1
-                                    else "sequential phases"),
+                       "schedule": (f"reduce / exchange / decrypt chunk-pipelined on a side stream ({args.pipeline_chunks} chunks)"
+                                    if pipelined else "sequential phases"),
                        "parity": "bit-exact (checked in-run)"},
             "roofline": {"kernel": "prf_wide_kernel<1> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt)",
                          "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -232,14 +260,14 @@ def main():
                          "aes_blocks_per_s": 2 * n / (enc_avg_ms * 1e-3),
                          "note": "integer path: the kernel is AES(LDS/VALU)-rate bound, HBM fraction reported as required"},
             "phases_ms": ({"round": float(ph.sum(axis=1).mean()), "note": "phases overlap in the pipelined schedule"}
-                          if side is not None else
+                          if pipelined else
                           {"encrypt_xC": float(ph[:, 0].mean()), "aggregate": float(ph[:, 1].mean()),
                            "decrypt": float(ph[:, 2].mean())}),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, host_pts)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -17,6 +17,8 @@ torch.distributed is plumbing only (process group, all_to_all_single / all_gathe
 RCCL, or gloo in the CPU tests); all arithmetic is done by the `ops` object -- `HipOps` over
 the C ABI in production.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -38,10 +40,17 @@ class HipOps:
     `side` is an optional second engine (same key / int_bits, its own stream) on which the
     HBM-bound reduce of the pipelined round runs next to the AES-bound kernels."""
 
-    def __init__(self, engine, side=None):
+    def __init__(self, engine, side=None, side_stream=None):
         self.engine = engine
         self.side = side
+        self.side_stream = side_stream      # the torch stream the side engine runs on (collectives follow it)
         self._events = {}
+
+    def on_side(self):
+        """Context under which torch.distributed collectives are enqueued on the side stream."""
+        if self.side_stream is None:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.side_stream)
 
     # ---- two-stream plumbing for ShardedRound.run_pipelined (no-ops without a side engine) ----
     def _ev(self, name):
@@ -69,6 +78,20 @@ class HipOps:
         off = first * self.engine.limbs * 8
         self.engine.decrypt_range_dev(it, add_idx, minus_idx, n, n_jobs, first, count, inp.data_ptr() + off, out.data_ptr() + off)
 
+    def aggregate_slices_side(self, buf, buf_elem_off, n_slices, slice_elems, out, out_elem_off):
+        """N-way mod-add of the equally sized pieces received by one chunk's all-to-all (side stream)."""
+        eng = self.side if self.side is not None else self.engine
+        L = eng.limbs
+        base = buf.data_ptr() + buf_elem_off * L * 8
+        eng.aggregate_elem_dev([base + g * slice_elems * L * 8 for g in range(n_slices)], slice_elems,
+                               out.data_ptr() + out_elem_off * L * 8)
+
+    def decrypt_range_side(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, in_elem_off, out, out_elem_off):
+        eng = self.side if self.side is not None else self.engine
+        L = eng.limbs
+        eng.decrypt_range_dev(it, add_idx, minus_idx, n, n_jobs, first, count, inp.data_ptr() + in_elem_off * L * 8,
+                              out.data_ptr() + out_elem_off * L * 8)
+
     @staticmethod
     def _p(t, elem_offset=0, limbs=1):
         return t.data_ptr() + elem_offset * limbs * 8
@@ -95,16 +118,19 @@ class ShardedRound:
     client number), so `world * clients_per_rank` ciphertext vectors are produced per round."""
 
     def __init__(self, ops, n, int_bits, clients_per_rank, n_jobs, device, rank=0, world=1, group=None,
-                 scheme=SCHEME_DOUBLE):
+                 scheme=SCHEME_DOUBLE, force_collectives=False):
         self.ops, self.n, self.b, self.cpr, self.n_jobs = ops, n, int_bits, clients_per_rank, n_jobs
         self.rank, self.world, self.group, self.scheme = rank, world, group, scheme
+        # world == 1 normally skips the exchange; force_collectives runs it anyway (a 1-rank all-to-all /
+        # all-gather), which lets a single-GPU box exercise the exact RCCL code path
+        self.exchange = world > 1 or force_collectives
         self.L = limbs_of(int_bits)
         self.slice = slice_len(n, world)
         self.padded = self.slice * world
         kw = dict(dtype=torch.int64, device=device)
         self.ct = [torch.zeros(n * self.L, **kw) for _ in range(clients_per_rank)]
         self.partial = torch.zeros(self.padded * self.L, **kw)       # local aggregate, padded to world slices
-        self.recv = torch.zeros(self.padded * self.L, **kw) if world > 1 else None
+        self.recv = torch.zeros(self.padded * self.L, **kw) if self.exchange else None
         self.agg_slice = torch.zeros(self.slice * self.L, **kw)
         self.dec_slice = torch.zeros(self.slice * self.L, **kw)
         self.result = torch.zeros(self.padded * self.L, **kw)        # plaintext aggregate on every rank
@@ -122,7 +148,7 @@ class ShardedRound:
     def aggregate_phase(self):
         """Local C-way mod-add, then (world > 1) the reduce-scatter: all-to-all of slices + local mod-add."""
         self.ops.aggregate(self.ct, self.n, self.partial)
-        if self.world > 1:
+        if self.exchange:
             dist.all_to_all_single(self.recv, self.partial, group=self.group)
             self.ops.aggregate_slices(self.recv, self.world, self.slice, self.agg_slice)
 
@@ -133,7 +159,7 @@ class ShardedRound:
             add_idx, minus_idx = telescope(uploaded)
         else:
             add_idx, minus_idx = [], uploaded
-        if self.world > 1:
+        if self.exchange:
             if self.count > 0:
                 self.ops.decrypt_range(it, add_idx, minus_idx, self.n, self.n_jobs, self.first, self.count,
                                        self.agg_slice, self.dec_slice)
@@ -142,30 +168,68 @@ class ShardedRound:
             self.ops.decrypt_range(it, add_idx, minus_idx, self.n, self.n_jobs, 0, self.n, self.partial, self.result)
         return self.result
 
+    def _pipe_buffers(self, chunks):
+        """Block-cyclic ownership for the pipelined schedule: the vector is cut into `chunks` contiguous
+        chunks of world * sub elements and rank g owns piece g of EVERY chunk, so each chunk's
+        all-to-all / all-gather works on one contiguous block."""
+        key = ("pipe", chunks)
+        if getattr(self, "_pipe_key", None) == key:
+            return
+        n, W, L = self.n, self.world, self.L
+        sub = ((n + chunks * W - 1) // (chunks * W) + ALIGN - 1) // ALIGN * ALIGN
+        self.p_sub, self.p_chunk = sub, sub * W
+        padded = self.p_chunk * chunks
+        kw = dict(dtype=torch.int64, device=self.partial.device)
+        self.p_partial = torch.zeros(padded * L, **kw)
+        self.p_result = torch.zeros(padded * L, **kw)
+        self.p_recv = torch.zeros(padded * L, **kw) if self.exchange else None
+        self.p_agg = torch.zeros(chunks * sub * L, **kw) if self.exchange else None
+        self.p_dec = torch.zeros(chunks * sub * L, **kw) if self.exchange else None
+        self._pipe_key = key
+
     def run_pipelined(self, it, pts, pt_limbs, chunks=4):
-        """Single-GPU round with the arbiter reduce hidden under the AES-bound kernels: the last
-        client's encrypt is issued chunk by chunk; as soon as chunk q of every ciphertext exists the
-        reduce of chunk q runs on the side stream, and the decrypt of chunk q follows it on the main
-        stream.  Same arithmetic, same buffers, only the schedule differs."""
-        assert self.world == 1
-        ops, n = self.ops, self.n
-        step = ((n + chunks - 1) // chunks + 1023) // 1024 * 1024
-        bounds = [(f, min(step, n - f)) for f in range(0, n, step)]
+        """The round with everything after the last client's encrypt hidden under it, chunk by chunk:
+        the last client encrypts chunk q on the main stream; on the side stream chunk q is reduced
+        locally, reduce-scattered (all-to-all + mod-add of the received pieces), the owned piece is
+        decrypted and all-gathered -- while the main stream already encrypts chunk q + 1.
+        Same arithmetic as run(); only the schedule and the (block-cyclic) ownership differ."""
+        ops, n, L, W = self.ops, self.n, self.L, self.world
+        self._pipe_buffers(chunks)
+        sub, chunk = self.p_sub, self.p_chunk
         for c in range(self.cpr - 1):
-            ops.encrypt(it, c, self.scheme, n, self.n_jobs, pts[c], pt_limbs, self.ct[c])
+            ops.encrypt(it, self.rank * self.cpr + c, self.scheme, n, self.n_jobs, pts[c], pt_limbs, self.ct[c])
         last = self.cpr - 1
-        for q, (first, count) in enumerate(bounds):
-            ops.encrypt_range(it, last, self.scheme, n, self.n_jobs, first, count, pts[last], pt_limbs, self.ct[last])
+        uploaded = list(range(self.total_clients()))
+        add_idx, minus_idx = telescope(uploaded) if self.scheme == SCHEME_DOUBLE else ([], uploaded)
+        for q in range(chunks):
+            first = q * chunk
+            cnt = max(0, min(chunk, n - first))
+            if cnt:
+                ops.encrypt_range(it, self.rank * self.cpr + last, self.scheme, n, self.n_jobs, first, cnt,
+                                  pts[last], pt_limbs, self.ct[last])
             ops.signal(f"enc{q}")
             ops.wait(f"enc{q}", on_side=True)
-            ops.aggregate_range(self.ct, first, count, self.partial)
-            ops.signal(f"agg{q}", on_side=True)
-        uploaded = list(range(self.cpr))
-        add_idx, minus_idx = telescope(uploaded) if self.scheme == SCHEME_DOUBLE else ([], uploaded)
-        for q, (first, count) in enumerate(bounds):
-            ops.wait(f"agg{q}")
-            ops.decrypt_range_at(it, add_idx, minus_idx, n, self.n_jobs, first, count, self.partial, self.result)
-        return self.result
+            if cnt:
+                ops.aggregate_range(self.ct, first, cnt, self.p_partial)
+            if self.exchange:
+                blk = slice(first * L, (first + chunk) * L)
+                with ops.on_side():
+                    dist.all_to_all_single(self.p_recv[blk], self.p_partial[blk], group=self.group)
+                ops.aggregate_slices_side(self.p_recv, first, W, sub, self.p_agg, q * sub)
+                gfirst = first + self.rank * sub
+                gcnt = max(0, min(sub, n - gfirst))
+                if gcnt:
+                    ops.decrypt_range_side(it, add_idx, minus_idx, n, self.n_jobs, gfirst, gcnt, self.p_agg, q * sub,
+                                           self.p_dec, q * sub)
+                with ops.on_side():
+                    dist.all_gather_into_tensor(self.p_result[blk], self.p_dec[q * sub * L:(q + 1) * sub * L], group=self.group)
+            elif cnt:
+                ops.decrypt_range_side(it, add_idx, minus_idx, n, self.n_jobs, first, cnt, self.p_partial, first,
+                                       self.p_result, first)
+            ops.signal(f"done{q}", on_side=True)
+        for q in range(chunks):
+            ops.wait(f"done{q}")
+        return self.p_result
 
     def run(self, it, pts, pt_limbs):
         """pts: this rank's plaintext tensors (one per local client).  Returns the tensor holding the

@@ -35,15 +35,17 @@ def main():
         all_pts = [np.random.Generator(np.random.PCG64(1000 + c)).integers(0, 2 ** pt_bits, n, dtype=np.uint64)
                    for c in range(world * cpr)]
         mine = [torch.from_numpy(all_pts[rank * cpr + c].view(np.int64).copy()) for c in range(cpr)]
-        res = rnd.run(5, mine, 1).numpy().view(np.uint64)[: n * L].reshape(n, L)
         want = np.zeros(n, dtype=np.uint64)
         for p in all_pts:
             want += p
         if b < 64:
             want &= np.uint64((1 << b) - 1)
-        assert np.array_equal(res[:, 0], want), (rank, b, n)
-        if L == 2:
-            assert not res[:, 1].any()
+        for mode, chunks in (("run", 0), ("pipe", 4), ("pipe", 3)):
+            out = rnd.run(5, mine, 1) if mode == "run" else rnd.run_pipelined(5, mine, 1, chunks=chunks)
+            res = out.numpy().view(np.uint64)[: n * L].reshape(n, L)
+            assert np.array_equal(res[:, 0], want), (rank, b, n, mode, chunks)
+            if L == 2:
+                assert not res[:, 1].any()
         # the same round through the oracle as one process: identical ciphertext aggregate
     dist.barrier()
     if rank == 0:

@@ -55,3 +55,18 @@ class OracleOps:
         minus = orc.mask_sum(KEY, it, minus_idx, n, n_jobs, self.b)[first:first + count]
         self._v(out, first + count)[first:first + count] = orc.combine(
             self.b, np.ascontiguousarray(self._v(inp, first + count)[first:first + count]), add, minus)
+
+    def on_side(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def aggregate_slices_side(self, buf, buf_elem_off, n_slices, slice_elems, out, out_elem_off):
+        full = self._v(buf, buf_elem_off + n_slices * slice_elems)
+        parts = [np.ascontiguousarray(full[buf_elem_off + g * slice_elems: buf_elem_off + (g + 1) * slice_elems]) for g in range(n_slices)]
+        self._v(out, out_elem_off + slice_elems)[out_elem_off:out_elem_off + slice_elems] = orc.aggregate_elem(parts, self.b)
+
+    def decrypt_range_side(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, in_elem_off, out, out_elem_off):
+        add = orc.mask_sum(KEY, it, add_idx, n, n_jobs, self.b)[first:first + count]
+        minus = orc.mask_sum(KEY, it, minus_idx, n, n_jobs, self.b)[first:first + count]
+        src = np.ascontiguousarray(self._v(inp, in_elem_off + count)[in_elem_off:in_elem_off + count])
+        self._v(out, out_elem_off + count)[out_elem_off:out_elem_off + count] = orc.combine(self.b, src, add, minus)

@@ -1,12 +1,9 @@
 #!/bin/bash
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/prof/bs
+OUT=$REPO/gpurun_out/prof/bs2
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L > $OUT/counters.txt 2>&1
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_VALU SQ_WAVES SQ_INSTS_FLAT SQ_INSTS_LDS" "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_LEVEL_SMEM SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/$tag -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --prf-backend bitslice > $OUT/$tag.log 2>&1
-  echo "$tag rc=$?"
+for be in bitslice table; do
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $OUT/$be -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --pipeline-chunks 0 --prf-backend $be > $OUT/$be.log 2>&1
 done
 find $OUT -type f ! -name '*.csv' ! -name '*.log' ! -name '*.txt' -delete
