@@ -223,12 +223,16 @@ class ShardedRound:
                                            self.p_dec, q * sub)
                 with ops.on_side():
                     dist.all_gather_into_tensor(self.p_result[blk], self.p_dec[q * sub * L:(q + 1) * sub * L], group=self.group)
-            elif cnt:
-                ops.decrypt_range_side(it, add_idx, minus_idx, n, self.n_jobs, first, cnt, self.p_partial, first,
-                                       self.p_result, first)
             ops.signal(f"done{q}", on_side=True)
         for q in range(chunks):
             ops.wait(f"done{q}")
+            if not self.exchange:
+                # single rank: the decrypt is as heavy as one encrypt, so it stays on the main stream (right
+                # behind the encrypts) and only the HBM-bound reduce is hidden on the side stream
+                first = q * chunk
+                cnt = max(0, min(chunk, n - first))
+                if cnt:
+                    ops.decrypt_range_at(it, add_idx, minus_idx, n, self.n_jobs, first, cnt, self.p_partial, self.p_result)
         return self.p_result
 
     def run(self, it, pts, pt_limbs):
