@@ -258,6 +258,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": enc_avg_ms,
                          "launches_timed": len(enc_ms),
                          "aes_blocks_per_s": 2 * n / (enc_avg_ms * 1e-3),
+                         "lds_lookup_bound": {"lookups_per_block": 212, "peak_lookups_per_s_at_2.4GHz": 32 * 256 * 2.4e9,
+                                              "achieved_lookups_per_s": 212 * 2 * n / (enc_avg_ms * 1e-3),
+                                              "frac_at_2.4GHz": 212 * 2 * n / (enc_avg_ms * 1e-3) / (32 * 256 * 2.4e9)},
                          "note": "integer path: the kernel is AES(LDS/VALU)-rate bound, HBM fraction reported as required"},
             "phases_ms": ({"round": float(ph.sum(axis=1).mean()), "note": "phases overlap in the pipelined schedule"}
                           if pipelined else

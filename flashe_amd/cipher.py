@@ -88,36 +88,21 @@ class FlasheCipher(object):
     _engine_cls = Engine      # the device context type (the HIP engine; tests may inject a double)
 
     def __init__(self, int_bits, mask="double", device=0):
-        # attribute set mirrors jzf_flashe.py:230-260
-        self.uuid = None
-        self.exchanged_keys = None
-        self.masking_scheme = mask
-        self.masks = None
-        self.total = None
-
-        self.prp_seed = None
-        self.prp_seed_len = 256
-        self.guest_uuid = None
-
-        self.idx = None
-        self.index_prefix_for_add = None
-        self.index_prefix_for_minus = None
-
-        self.iter_index = -1
-        self.iter_index_bytes = None
-
         if 128 // int_bits < 1:          # the reference divides by merge_size = 128 // int_bits
             raise ZeroDivisionError("integer division or modulo by zero")
         self.int_bits = int_bits
-
-        self.num_clients = None
+        self.masking_scheme = mask
+        # the same public attributes as jzf_flashe.py:230-260 (callers read and assign several of them)
+        for name in ("uuid", "exchanged_keys", "masks", "total", "prp_seed", "guest_uuid", "idx",
+                     "index_prefix_for_add", "index_prefix_for_minus", "iter_index_bytes", "num_clients", "num_params"):
+            setattr(self, name, None)
+        self.prp_seed_len = 256
+        self.iter_index = -1
+        self.encrypt_base = self.decrypt_base = 0
+        # mask caches: filled by prepare_*(), consumed (deleted) by the next encrypt / decrypt
         self.next_iter_encrypt_prepared = {}
         self.next_iter_decrypt_prepared = {}
         self.next_iter_decrypt_prepared_idx = {}
-        self.num_params = None
-
-        self.encrypt_base = 0
-        self.decrypt_base = 0
 
         self._device = device
         self._engine = None
@@ -143,13 +128,11 @@ class FlasheCipher(object):
 
     def generate_prp_seed(self, assigned_seed=None):  # jzf_flashe.py:280-295
         if assigned_seed is None:
-            seed = os.urandom(self.prp_seed_len // BITS_PER_BYTES)
+            seed = os.urandom(self.prp_seed_len // BITS_PER_BYTES)            # 32 random bytes
         else:
-            if isinstance(assigned_seed, int):
-                seed = int(assigned_seed & int(2 ** self.prp_seed_len - 1)).to_bytes(self.prp_seed_len, 'big')
-            else:
-                seed = int(int.from_bytes(assigned_seed, 'big') & int(2 ** self.prp_seed_len - 1)).to_bytes(
-                    self.prp_seed_len, 'big')
+            # the reference masks to prp_seed_len BITS but serialises to prp_seed_len BYTES (:286-292)
+            as_int = assigned_seed if isinstance(assigned_seed, int) else int.from_bytes(assigned_seed, 'big')
+            seed = (as_int & ((1 << self.prp_seed_len) - 1)).to_bytes(self.prp_seed_len, 'big')
         self.prp_seed = seed
         # AESCipher.generate_key (jzf_aes.py:21-28): the AES-256 key is the low 256 bits, big-endian
         self._key = (int.from_bytes(seed, 'big') & (256 ** 32 - 1)).to_bytes(32, 'big')
@@ -212,19 +195,13 @@ class FlasheCipher(object):
         else:
             if self.masks is None:
                 raw_idx_list.sort()                                   # in place, like the reference
-                temp_add, temp_minus = _engine.telescope(raw_idx_list)
-                self.index_prefix_for_add = []
-                self.index_prefix_for_minus = []
-                for idx in temp_add:
-                    if 'add' in self.next_iter_decrypt_prepared_idx and idx in self.next_iter_decrypt_prepared_idx['add']:
-                        pass
-                    else:
-                        self.index_prefix_for_add.append(self.iter_index_bytes + idx.to_bytes(4, 'big'))
-                for idx in temp_minus:
-                    if 'minus' in self.next_iter_decrypt_prepared_idx and idx in self.next_iter_decrypt_prepared_idx['minus']:
-                        pass
-                    else:
-                        self.index_prefix_for_minus.append(self.iter_index_bytes + idx.to_bytes(4, 'big'))
+                run_ends, run_starts = _engine.telescope(raw_idx_list)
+                # prefixes already covered by prepare_decrypt()'s masks are skipped (:372-386)
+                have_add = self.next_iter_decrypt_prepared_idx.get('add', ())
+                have_minus = self.next_iter_decrypt_prepared_idx.get('minus', ())
+                it = self.iter_index_bytes
+                self.index_prefix_for_add = [it + i.to_bytes(4, 'big') for i in run_ends if i not in have_add]
+                self.index_prefix_for_minus = [it + i.to_bytes(4, 'big') for i in run_starts if i not in have_minus]
             else:
                 # sparse + double: per-client run analysis on one-hot location vectors (:388-407),
                 # masks indexed by DENSE position (_static_prepare_decrypt_spar as one chunk; the

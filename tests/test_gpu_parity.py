@@ -467,6 +467,41 @@ def test_config2_full_size_round(E, oracle):
     assert np.array_equal(got, want)
 
 
+def test_config4_size_round(E, oracle):
+    """BASELINE config 4's vector (ResNet-50, n = 25 557 032, b = 128) on one GPU: round trip with a
+    dropout, and the range twins reproduce the full-vector decrypt slice by slice (what the sharded
+    multi-GPU round does)."""
+    n, C, b, it = 25_557_032, 4, 128, 3
+    eng = make(E, b)
+    pts = [np.random.Generator(np.random.PCG64(3000 + c)).integers(0, 2 ** 64, n, dtype=np.uint64) for c in range(C)]
+    dct = []
+    for c in range(C):
+        d_pt, d_ct = eng.upload(pts[c]), eng.alloc_vec(n)
+        eng.encrypt_dev(it, c, E.SCHEME_DOUBLE, n, 16, d_pt, 1, d_ct)
+        dct.append(d_ct)
+        eng.sync()
+        d_pt.free()
+    up = [0, 1, 3]
+    dagg, dout = eng.alloc_vec(n), eng.alloc_vec(n)
+    eng.aggregate_elem_dev([dct[c] for c in up], n, dagg)
+    add_idx, minus_idx = E.telescope(list(up))
+    eng.decrypt_dev(it, add_idx, minus_idx, n, 16, dagg, dout)
+    out = dout.download(np.uint64, 2 * n).reshape(n, 2)
+    lo, hi = _sum_u64([pts[c] for c in up])
+    assert np.array_equal(out[:, 0], lo) and np.array_equal(out[:, 1], hi)
+    # slice-wise (8 "ranks", unaligned cuts) == whole
+    dout2 = eng.alloc_vec(n)
+    cuts = [0] + [n * k // 8 + (k * 37) % 61 for k in range(1, 8)] + [n]
+    for k in range(8):
+        first, count = cuts[k], cuts[k + 1] - cuts[k]
+        eng.decrypt_range_dev(it, add_idx, minus_idx, n, 16, first, count, dagg.ptr + first * 16, dout2.ptr + first * 16)
+    assert np.array_equal(dout2.download(np.uint64, 2 * n).reshape(n, 2), out)
+    # the head of one ciphertext against the oracle
+    head = 2_000_000
+    ct1 = dct[1].download(np.uint64, 2 * head).reshape(head, 2)
+    assert np.array_equal(ct1, oracle.encrypt(KEY, it, 1, "double", 16, b, pts[1][:head]))
+
+
 def test_error_codes(E):
     eng = make(E, 128)
     with pytest.raises(E.FlasheError):
