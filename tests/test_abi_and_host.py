@@ -80,3 +80,14 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    """include/flashe.h is a plain-C interface: it must compile stand-alone as C11 and as C++17."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "flashe.h")
+    for comp, std, ext in (("gcc", "-std=c11", "c"), ("g++", "-std=c++17", "cpp")):
+        src = tmp_path / f"t.{ext}"
+        src.write_text('#include "flashe.h"\nint main(void) { return FLASHE_OK + (int)sizeof(flashe_ctx *) * 0; }\n')
+        subprocess.check_call([comp, std, "-Wall", "-Werror", "-pedantic", "-I", os.path.dirname(hdr), "-c", str(src),
+                               "-o", str(tmp_path / f"t_{ext}.o")])
