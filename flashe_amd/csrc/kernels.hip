@@ -152,14 +152,20 @@ __device__ __forceinline__ CtrPrefix ctr_prefix(const RoundKeys &rk, const LaneR
     return c;
 }
 
-// State after round 1 for the block with prefix c and low counter word ctr_lo.
-__device__ __forceinline__ void ctr_round1(const RoundKeys &rk, const LaneRegs lr, const CtrPrefix &c, uint32_t ctr_lo, uint32_t (&s)[4])
+// The lane-dependent quarter of round 1: the four lookups on the low counter word.  They do not
+// depend on the prefix, so the add and the minus block of one element share them.
+struct CtrVar { uint32_t v[4]; };
+
+__device__ __forceinline__ CtrVar ctr_var(const RoundKeys &rk, const LaneRegs lr, uint32_t ctr_lo)
 {
     const uint32_t s3 = ctr_lo ^ rk.w[3];
-    s[0] = c.u[0] ^ T3(s3, SEL_B0);
-    s[1] = c.u[1] ^ T2(s3, SEL_B1);
-    s[2] = c.u[2] ^ T1(s3, SEL_B2);
-    s[3] = c.u[3] ^ T0(s3, SEL_B3);
+    return CtrVar{{T3(s3, SEL_B0), T2(s3, SEL_B1), T1(s3, SEL_B2), T0(s3, SEL_B3)}};
+}
+
+// State after round 1 for the block with prefix c.
+__device__ __forceinline__ void ctr_round1(const CtrPrefix &c, const CtrVar &x, uint32_t (&s)[4])
+{
+    s[0] = c.u[0] ^ x.v[0]; s[1] = c.u[1] ^ x.v[1]; s[2] = c.u[2] ^ x.v[2]; s[3] = c.u[3] ^ x.v[3];
 }
 
 __device__ __forceinline__ u128 words_to_u128(const uint32_t (&s)[4])
@@ -237,8 +243,9 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
         if (MODE == 1) {
             uint32_t s[2][4];
             if (ctr_fast) {
-                ctr_round1(rk, lr, pre_a, static_cast<uint32_t>(j), s[0]);
-                ctr_round1(rk, lr, pre_b, static_cast<uint32_t>(j), s[1]);
+                const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(j));
+                ctr_round1(pre_a, x, s[0]);
+                ctr_round1(pre_b, x, s[1]);
                 aes256_rounds<2, 2>(rk, lr, s);
             } else {
                 set_block(s[0], p.iter, lists.add[0], j);
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
         } else if (MODE == 2) {
             uint32_t s[1][4];
             if (ctr_fast) {
-                ctr_round1(rk, lr, pre_a, static_cast<uint32_t>(j), s[0]);
+                ctr_round1(pre_a, ctr_var(rk, lr, static_cast<uint32_t>(j)), s[0]);
                 aes256_rounds<1, 2>(rk, lr, s);
             } else {
                 set_block(s[0], p.iter, lists.add[0], j);
