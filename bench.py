@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--clients", type=int, default=10, help="clients per GPU")
     ap.add_argument("--bits", type=int, default=128)
     ap.add_argument("--n-jobs", type=int, default=16)
-    ap.add_argument("--prf-backend", choices=["auto", "table", "bitslice", "hybrid"], default="auto")
+    ap.add_argument("--prf-backend", choices=["auto", "table", "bitslice", "hybrid", "bitslice16"], default="auto")
     ap.add_argument("--pipeline-chunks", type=int, default=4,
                     help="> 0: everything after the last client's encrypt (reduce, exchange, decrypt) runs chunk by chunk on "
                          "a side stream under it; 0: sequential phases")
@@ -124,7 +124,7 @@ def main():
     with torch.cuda.stream(stream):
         eng = Engine(key, b, device=local_rank, stream=stream.cuda_stream)
         eng.selftest()
-        eng.set_prf_backend({"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3}[args.prf_backend])
+        eng.set_prf_backend({"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend])
         side, side_stream = None, None
         if args.pipeline_chunks > 0:
             side_stream = torch.cuda.Stream(device=device)

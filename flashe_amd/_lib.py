@@ -61,6 +61,7 @@ _SIGNATURES = {
     "flashe_mask": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_vp]),
     "flashe_encrypt_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, c_vp]),
     "flashe_encrypt": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, c_vp]),
+    "flashe_encrypt_batch_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp)]),
     "flashe_decrypt_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
     "flashe_decrypt": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
     "flashe_mask_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_vp]),

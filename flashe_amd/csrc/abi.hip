@@ -120,6 +120,7 @@ struct flashe_ctx {
     LaunchEnv env{};
     uint32_t *te0_dev = nullptr;
     uint32_t *rkw_dev = nullptr;
+    uint32_t *rkp_dev = nullptr;
     std::string err;
     // scratch buffers owned by the ctx (grown on demand, reused across calls)
     struct Buf { void *p = nullptr; size_t cap = 0; };
@@ -169,6 +170,16 @@ int ensure(flashe_ctx *ctx, flashe_ctx::Buf &b, size_t bytes)
 int upload_key_words(flashe_ctx *ctx)
 {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->rkw_dev, ctx->env.rk.w, sizeof(ctx->env.rk.w), hipMemcpyHostToDevice, ctx->env.stream));
+    // packed key planes of the 16-blocks-per-lane bit-sliced PRF: word 64*r + 8*B + k holds bit k of round-key
+    // byte B in its low 16 bits and of byte B + 8 in its high 16 bits (byte b = byte b%4 of word 4r + b/4)
+    std::vector<uint32_t> planes(15 * 64);
+    for (int r = 0; r < 15; r++)
+        for (int B = 0; B < 8; B++)
+            for (int k = 0; k < 8; k++) {
+                auto bit = [&](int byte) { return (ctx->env.rk.w[4 * r + byte / 4] >> (24 - 8 * (byte % 4) + k)) & 1u; };
+                planes[64 * r + 8 * B + k] = (bit(B) ? 0xffffu : 0u) | (bit(B + 8) ? 0xffff0000u : 0u);
+            }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->rkp_dev, planes.data(), planes.size() * 4, hipMemcpyHostToDevice, ctx->env.stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
     return FLASHE_OK;
 }
@@ -239,6 +250,8 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
     ctx->env.te0_dev = ctx->te0_dev;
     if ((e = hipMalloc(&ctx->rkw_dev, 256)) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(rkw)", e);
     ctx->env.rkw_dev = ctx->rkw_dev;
+    if ((e = hipMalloc(&ctx->rkp_dev, 15 * 64 * 4)) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(rkp)", e);
+    ctx->env.rkp_dev = ctx->rkp_dev;
     expand_key(key, &ctx->env.rk);
     if (upload_key_words(ctx) != FLASHE_OK) {
         g_create_error = ctx->err;
@@ -254,6 +267,7 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
         if (!strcmp(be, "table")) ctx->env.prf_backend = PRF_TABLE;
         else if (!strcmp(be, "bitslice")) ctx->env.prf_backend = PRF_BITSLICE;
         else if (!strcmp(be, "hybrid")) ctx->env.prf_backend = PRF_HYBRID;
+        else if (!strcmp(be, "bitslice16")) ctx->env.prf_backend = PRF_BITSLICE16;
     }
     if (const char *pm = getenv("FLASHE_HYBRID_BS_PERMILLE")) ctx->env.hybrid_bs_permille = atoi(pm);
     *out = ctx;
@@ -269,6 +283,7 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
         if (b->p) (void)hipFree(b->p);
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
     if (ctx->rkw_dev) (void)hipFree(ctx->rkw_dev);
+    if (ctx->rkp_dev) (void)hipFree(ctx->rkp_dev);
     if (ctx->env.stream2) { (void)hipStreamSynchronize(ctx->env.stream2); (void)hipStreamDestroy(ctx->env.stream2); }
     if (ctx->env.ev_fork) (void)hipEventDestroy(ctx->env.ev_fork);
     if (ctx->env.ev_join) (void)hipEventDestroy(ctx->env.ev_join);
@@ -289,7 +304,7 @@ int flashe_ctx_set_key(flashe_ctx *ctx, const uint8_t key[32])
 int flashe_ctx_set_prf_backend(flashe_ctx *ctx, int backend)
 {
     if (!ctx) return FLASHE_EINVAL;
-    if (backend != PRF_AUTO && backend != PRF_TABLE && backend != PRF_BITSLICE && backend != PRF_HYBRID)
+    if (backend < PRF_AUTO || backend > PRF_BITSLICE16)
         return fail(ctx, FLASHE_EINVAL, "unknown PRF backend %d", backend);
     ctx->env.prf_backend = backend;
     return FLASHE_OK;
@@ -494,6 +509,32 @@ int flashe_encrypt_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
     if (rc) return rc;
     const uint32_t add = idx, minus = idx + 1;
     HIP_TRY(ctx, launch_prf(ctx->env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, 0, n, pt_dev, pt_limbs, ct_dev));
+    return FLASHE_OK;
+}
+
+int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec, const uint32_t *idx,
+                             const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev)
+{
+    CHECK_CTX(ctx);
+    if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    if (n_vec < 0 || (n_vec && (!idx || !pt_dev || !ct_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
+    for (int v = 0; v < n_vec; v++) {
+        if (n && (!pt_dev[v] || !ct_dev[v])) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
+        int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev[v], pt_dev[v], pt_limbs);
+        if (rc) return rc;
+    }
+    if (ctx->limbs == 1 || ctx->env.prf_backend != PRF_AUTO && ctx->env.prf_backend != PRF_TABLE) {
+        // chunk-dependent counters (b <= 64) and the alternative PRF backends go vector by vector
+        for (int v = 0; v < n_vec; v++) {
+            int rc = flashe_encrypt_dev(ctx, iter, idx[v], scheme, n, n_jobs, pt_dev[v], pt_limbs, ct_dev[v]);
+            if (rc) return rc;
+        }
+        return FLASHE_OK;
+    }
+    for (int v0 = 0; v0 < n_vec; v0 += kMaxBatch) {
+        const int nv = std::min(kMaxBatch, n_vec - v0);
+        HIP_TRY(ctx, launch_prf_batch(ctx->env, iter, scheme == FLASHE_SCHEME_DOUBLE, nv, idx + v0, pt_dev + v0, pt_limbs, ct_dev + v0, n));
+    }
     return FLASHE_OK;
 }
 

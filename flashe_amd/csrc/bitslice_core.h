@@ -127,5 +127,72 @@ __device__ __forceinline__ void planes_to_blocks(const uint32_t (&s)[128], u128 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Packed variant: 64 plane registers per lane, register 8*Bp + k = bit k of state byte Bp (low 16 bits)
+// and of state byte Bp + 8 (high 16 bits) for 16 blocks.  Same work per instruction, half the
+// registers, so 3-4 waves fit per SIMD.
+// ------------------------------------------------------------------------------------------
+// Planes of 16 PRF input blocks per lane.  With NSTREAM == 2 blocks 0..7 carry prefix idx_a and blocks
+// 8..15 prefix idx_b over the same 8 counters c0 + 64 * q.
+template <int NSTREAM>
+__device__ __forceinline__ void load_planes_p(uint32_t (&s)[64], uint32_t iter, uint32_t idx_a, uint32_t idx_b, uint64_t c0)
+{
+    constexpr int EPL = 16 / NSTREAM;
+    uint32_t t[32];
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        const uint64_t c = c0 + static_cast<uint64_t>(p & (EPL - 1)) * 64;
+        t[p] = static_cast<uint32_t>(c);
+        t[16 + p] = static_cast<uint32_t>(c >> 32);
+    }
+    transpose32(t);     // t[i]: low half = plane of counter bit i, high half = plane of counter bit 32 + i
+    constexpr uint32_t mask_a = NSTREAM == 2 ? 0x00ffu : 0xffffu, mask_b = NSTREAM == 2 ? 0xff00u : 0u;
+#pragma unroll
+    for (int B = 0; B < 8; B++) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            // low half: state byte B (bytes 0-3 = iter, 4-7 = idx, big-endian)
+            uint32_t low;
+            if (B < 4) low = (iter >> ((3 - B) * 8 + k)) & 1u ? 0xffffu : 0u;
+            else low = ((idx_a >> ((7 - B) * 8 + k)) & 1u ? mask_a : 0u) | ((idx_b >> ((7 - B) * 8 + k)) & 1u ? mask_b : 0u);
+            // high half: state byte B + 8 = counter byte, i.e. counter bit (7 - B) * 8 + k
+            const int cb = (7 - B) * 8 + k;
+            s[8 * B + k] = cb < 32 ? ((t[cb] << 16) | low) : ((t[cb - 32] & 0xffff0000u) | low);
+        }
+    }
+}
+
+// AES-256 on the packed planes in place.  rkp = 15 x 64 packed key planes.
+__device__ __forceinline__ void encrypt_planes_p(uint32_t (&s)[64], const uint32_t *__restrict__ rkp)
+{
+    uint32_t o[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) s[i] ^= rkp[i];
+#pragma unroll 1
+    for (int r = 1; r < 13; r += 2) {
+        round_main_p(s, rkp + 64 * r, o);
+        round_main_p(o, rkp + 64 * (r + 1), s);
+    }
+    round_main_p(s, rkp + 64 * 13, o);
+    round_final_p(o, rkp + 64 * 14, s);
+}
+
+// S[p] = AES output of block p (p = 0..15) as a big-endian 128-bit integer.
+__device__ __forceinline__ void planes_to_blocks_p(const uint32_t (&s)[64], u128 (&S)[16])
+{
+    uint32_t w1[32], w2[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        w1[i] = s[8 * (3 - i / 8) + (i & 7)];     // low halves: bytes 0..3 (word 3), high halves: bytes 8..11 (word 1)
+        w2[i] = s[8 * (7 - i / 8) + (i & 7)];     // low halves: bytes 4..7 (word 2), high halves: bytes 12..15 (word 0)
+    }
+    transpose32(w1);
+    transpose32(w2);
+#pragma unroll
+    for (int p = 0; p < 16; p++)
+        S[p] = (static_cast<u128>(w1[p]) << 96) | (static_cast<u128>(w2[p]) << 64) |
+               (static_cast<u128>(w1[p + 16]) << 32) | static_cast<u128>(w2[p + 16]);
+}
+
 }  // namespace bs
 }  // namespace flashe

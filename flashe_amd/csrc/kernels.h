@@ -14,6 +14,7 @@ struct LaunchEnv {
     int num_cus;
     const uint32_t *te0_dev;   // 256-entry Te0 table in device memory (1 KiB)
     const uint32_t *rkw_dev;   // the 60 expanded key words in device memory (scalar-loaded per round by the bit-sliced PRF)
+    const uint32_t *rkp_dev;   // packed key planes for the 16-blocks-per-lane bit-sliced PRF: 15 x 64 words
     RoundKeys rk;
     int b;                     // int_bits
     int prf_backend;           // PRF_AUTO / PRF_TABLE / PRF_BITSLICE / PRF_HYBRID
@@ -24,7 +25,7 @@ struct LaunchEnv {
     int hybrid_bs_permille;
 };
 
-enum { PRF_AUTO = 0, PRF_TABLE = 1, PRF_BITSLICE = 2, PRF_HYBRID = 3 };
+enum { PRF_AUTO = 0, PRF_TABLE = 1, PRF_BITSLICE = 2, PRF_HYBRID = 3, PRF_BITSLICE16 = 4 };
 
 // out = (in? + sum_{k<n_add} term(iter, add[k]) - sum_{k<n_minus} term(iter, minus[k])) mod 2^b.
 // add/minus are HOST arrays (copied into the kernel argument block; at most kMaxIdx each).
@@ -35,6 +36,12 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter,
                       const uint32_t *add, int n_add, const uint32_t *minus, int n_minus,
                       uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
                       const uint64_t *in_dev, int in_limbs, uint64_t *out_dev);
+
+// Several independent encrypts of equal length in ONE launch: vector v is encrypted with prefix idx[v]
+// (and idx[v] + 1 when `dbl`).  b > 64 only; at most kMaxBatch vectors.
+constexpr int kMaxBatch = 32;
+hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx,
+                            const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n);
 
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
                           const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);

@@ -13,6 +13,8 @@
 //     round-robin; there is no inter-workgroup reuse, so no XCD remap is needed.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace flashe {
 
 typedef unsigned __int128 u128;
@@ -300,6 +302,57 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
     }
 }
 
+// ---- batched form of prf_wide_kernel<1/2>: n_vec independent vectors in one launch ----
+struct BatchTable {
+    uint32_t idx[kMaxBatch];
+    const uint64_t *in[kMaxBatch];
+    uint64_t *out[kMaxBatch];
+};
+
+template <bool DBL>
+__global__ __launch_bounds__(kPrfThreads) void prf_wide_batch_kernel(const RoundKeys rk, const BatchTable tb, int n_vec, uint64_t n,
+                                                                     uint32_t iter, int in_limbs, uint64_t mask_lo, uint64_t mask_hi,
+                                                                     const uint32_t *te0)
+{
+    __shared__ uint32_t tab[kTabWords];
+    fill_tables(tab, te0);
+    __builtin_amdgcn_s_setprio(3);
+    const LaneRegs lr = lane_regs(tab);
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const uint64_t tiles_per_vec = (n + kPrfThreads - 1) / kPrfThreads;
+    const uint64_t total_tiles = tiles_per_vec * static_cast<uint64_t>(n_vec);
+    const bool ctr_fast = ((n - 1) >> 32) == 0;
+    int cur = -1;
+    CtrPrefix pre_a{}, pre_b{};
+    for (uint64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        const int v = static_cast<int>(t / tiles_per_vec);              // wave-uniform
+        const uint64_t j = (t - static_cast<uint64_t>(v) * tiles_per_vec) * kPrfThreads + threadIdx.x;
+        const uint32_t ia = tb.idx[v];
+        if (v != cur && ctr_fast) {
+            pre_a = ctr_prefix(rk, lr, iter, ia, 0u);
+            if (DBL) pre_b = ctr_prefix(rk, lr, iter, ia + 1u, 0u);
+            cur = v;
+        }
+        if (j >= n) continue;
+        const uint64_t *in = tb.in[v];
+        u128 acc = in_limbs == 2 ? ld128(in + 2 * j) : static_cast<u128>(in[j]);
+        uint32_t s[DBL ? 2 : 1][4];
+        if (ctr_fast) {
+            const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(j));
+            ctr_round1(pre_a, x, s[0]);
+            if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
+            aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
+        } else {
+            set_block(s[0], iter, ia, j);
+            if (DBL) set_block(s[DBL ? 1 : 0], iter, ia + 1u, j);
+            aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
+        }
+        acc += words_to_u128(s[0]);
+        if (DBL) acc -= words_to_u128(s[DBL ? 1 : 0]);
+        st128(tb.out[v] + 2 * j, acc & mask);
+    }
+}
+
 // ---- b <= 64: one AES block (m = 128 / b elements) per lane, chunk-dependent counters ----
 // Bits [sh, sh + 64) of S (caller masks to b bits).
 __device__ __forceinline__ uint64_t extract64(u128 S, int sh)
@@ -447,6 +500,41 @@ __global__ __launch_bounds__(kBsThreads, 2) void prf_wide_bs_kernel(const uint32
     }
 }
 
+// Packed bit-sliced PRF: 16 blocks per lane in 64 plane registers (two state bytes per register), so the
+// kernel needs ~half the VGPRs of prf_wide_bs_kernel and 3-4 waves fit per SIMD.  NSTREAM = 2: blocks
+// 0..7 / 8..15 are the add / minus stream of the same 8 elements (wave-pass = 512 elements).
+template <int NSTREAM, int WAVES>
+__global__ __launch_bounds__(kBsThreads, WAVES) void prf_wide_bsp_kernel(const uint32_t *__restrict__ rkp, const PrfParams p,
+                                                                         const uint32_t idx_a, const uint32_t idx_b)
+{
+    constexpr int EPL = 16 / NSTREAM;
+    constexpr uint64_t TILE = 64ull * EPL;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = static_cast<uint64_t>(blockIdx.x) * (kBsThreads / 64) + (threadIdx.x >> 6);
+    const uint64_t n_waves = static_cast<uint64_t>(gridDim.x) * (kBsThreads / 64);
+    const u128 mask = (static_cast<u128>(p.mask_hi) << 64) | p.mask_lo;
+    const uint64_t n_tiles = (p.count + TILE - 1) / TILE;
+
+    for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
+        uint32_t s[64];
+        bs::load_planes_p<NSTREAM>(s, p.iter, idx_a, idx_b, p.first + tile * TILE + lane);
+        bs::encrypt_planes_p(s, rkp);
+        u128 S[16];
+        bs::planes_to_blocks_p(s, S);
+#pragma unroll
+        for (int q = 0; q < EPL; q++) {
+            const uint64_t e = tile * TILE + static_cast<uint64_t>(q) * 64 + lane;
+            if (e < p.count) {
+                u128 acc = 0;
+                if (p.in) acc = p.in_limbs == 2 ? ld128(p.in + 2 * e) : static_cast<u128>(p.in[e]);
+                acc += S[q];
+                if (NSTREAM == 2) acc -= S[q + 8];
+                st128(p.out + 2 * e, acc & mask);
+            }
+        }
+    }
+}
+
 // Known-answer helper: raw AES of nblk blocks given as big-endian words.
 __global__ __launch_bounds__(kPrfThreads) void aes_blocks_kernel(const RoundKeys rk, const uint32_t *te0, uint32_t nblk,
                                                                  const uint32_t *in, uint32_t *out)
@@ -535,7 +623,20 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
     p.b = env.b; p.m = 128 / env.b;
     masks_of(env.b, &p.mask_lo, &p.mask_hi);
     const bool bs_shape = env.b > 64 && n_add == 1 && n_minus <= 1;
-    if (bs_shape && env.prf_backend == PRF_BITSLICE) {
+    if (bs_shape && env.prf_backend == PRF_BITSLICE16) {
+        // waves per SIMD the kernel variant is compiled for (register budget 256 / 168 / 128 VGPRs)
+        static const int kWaves = [] { const char *e = getenv("FLASHE_BS16_WAVES"); int w = e ? atoi(e) : 3; return w < 2 || w > 4 ? 3 : w; }();
+        const uint64_t tile = n_minus ? 512 : 1024;
+        uint64_t waves = (count + tile - 1) / tile;
+        uint64_t blocks = (waves + 3) / 4;
+        const uint64_t cap = static_cast<uint64_t>(env.num_cus) * kWaves;
+        if (blocks > cap) blocks = cap;
+        const dim3 g(static_cast<unsigned>(blocks)), t(kBsThreads);
+#define BSP_LAUNCH(NS, W) hipLaunchKernelGGL((prf_wide_bsp_kernel<NS, W>), g, t, 0, env.stream, env.rkp_dev, p, lists.add[0], lists.minus[0])
+        if (n_minus) { if (kWaves == 2) BSP_LAUNCH(2, 2); else if (kWaves == 3) BSP_LAUNCH(2, 3); else BSP_LAUNCH(2, 4); }
+        else { if (kWaves == 2) BSP_LAUNCH(1, 2); else if (kWaves == 3) BSP_LAUNCH(1, 3); else BSP_LAUNCH(1, 4); }
+#undef BSP_LAUNCH
+    } else if (bs_shape && env.prf_backend == PRF_BITSLICE) {
         // 8 waves per CU (2 per SIMD at <= 256 VGPRs): two 256-thread blocks per CU
         const uint64_t tile = n_minus ? 1024 : 2048;
         uint64_t waves = (count + tile - 1) / tile;
@@ -562,6 +663,26 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
         const int grid = grid_for(env, p.blk_count, kSmallThreads);
         hipLaunchKernelGGL(prf_small_kernel, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, p, lists);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx,
+                            const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n)
+{
+    if (n == 0 || n_vec == 0) return hipSuccess;
+    if (env.b <= 64 || n_vec > kMaxBatch) return hipErrorInvalidValue;
+    BatchTable tb{};
+    for (int v = 0; v < n_vec; v++) { tb.idx[v] = idx[v]; tb.in[v] = in_dev[v]; tb.out[v] = out_dev[v]; }
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t tiles = ((n + kPrfThreads - 1) / kPrfThreads) * static_cast<uint64_t>(n_vec);
+    const int grid = static_cast<int>(tiles < static_cast<uint64_t>(env.num_cus) ? tiles : env.num_cus);
+    if (dbl)
+        hipLaunchKernelGGL(prf_wide_batch_kernel<true>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, n_vec, n, iter,
+                           in_limbs, lo, hi, env.te0_dev);
+    else
+        hipLaunchKernelGGL(prf_wide_batch_kernel<false>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, n_vec, n, iter,
+                           in_limbs, lo, hi, env.te0_dev);
     return hipGetLastError();
 }
 

@@ -99,6 +99,10 @@ class HipOps:
     def encrypt(self, it, idx, scheme, n, n_jobs, pt, pt_limbs, ct):
         self.engine.encrypt_dev(it, idx, scheme, n, n_jobs, pt.data_ptr(), pt_limbs, ct.data_ptr())
 
+    def encrypt_batch(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts):
+        self.engine.encrypt_batch_dev(it, idx_list, scheme, n, n_jobs, [t.data_ptr() for t in pts], pt_limbs,
+                                      [t.data_ptr() for t in cts])
+
     def aggregate(self, ptrs_tensors, n, out):
         self.engine.aggregate_elem_dev([t.data_ptr() if torch.is_tensor(t) else t for t in ptrs_tensors], n, out.data_ptr())
 
@@ -142,8 +146,8 @@ class ShardedRound:
 
     def encrypt_phase(self, it, pts, pt_limbs):
         """Every local client encrypts its vector (cipher idx = global client number)."""
-        for c in range(self.cpr):
-            self.ops.encrypt(it, self.rank * self.cpr + c, self.scheme, self.n, self.n_jobs, pts[c], pt_limbs, self.ct[c])
+        idx = [self.rank * self.cpr + c for c in range(self.cpr)]
+        self.ops.encrypt_batch(it, idx, self.scheme, self.n, self.n_jobs, pts, pt_limbs, self.ct)
 
     def aggregate_phase(self):
         """Local C-way mod-add, then (world > 1) the reduce-scatter: all-to-all of slices + local mod-add."""
@@ -196,9 +200,10 @@ class ShardedRound:
         ops, n, L, W = self.ops, self.n, self.L, self.world
         self._pipe_buffers(chunks)
         sub, chunk = self.p_sub, self.p_chunk
-        for c in range(self.cpr - 1):
-            ops.encrypt(it, self.rank * self.cpr + c, self.scheme, n, self.n_jobs, pts[c], pt_limbs, self.ct[c])
         last = self.cpr - 1
+        if last:
+            ops.encrypt_batch(it, [self.rank * self.cpr + c for c in range(last)], self.scheme, n, self.n_jobs,
+                              pts[:last], pt_limbs, self.ct[:last])
         uploaded = list(range(self.total_clients()))
         add_idx, minus_idx = telescope(uploaded) if self.scheme == SCHEME_DOUBLE else ([], uploaded)
         for q in range(chunks):

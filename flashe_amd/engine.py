@@ -181,6 +181,13 @@ class Engine:
     def encrypt_dev(self, it, idx, scheme, n, n_jobs, pt, pt_limbs, ct):
         self._check(self._lib.flashe_encrypt_dev(self._h, it, idx, scheme, n, n_jobs, self._ptr(pt), pt_limbs, self._ptr(ct)))
 
+    def encrypt_batch_dev(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts):
+        """len(idx_list) independent encrypts of equal length in as few launches as possible."""
+        pi, _k = _u32_list(idx_list)
+        pp, _a = self._ptr_array(pts)
+        pc, _b = self._ptr_array(cts)
+        self._check(self._lib.flashe_encrypt_batch_dev(self._h, it, scheme, n, n_jobs, len(idx_list), pi, pp, pt_limbs, pc))
+
     def decrypt_dev(self, it, add_idx, minus_idx, n, n_jobs, inp, out):
         pa, _a = _u32_list(add_idx)
         pm, _m = _u32_list(minus_idx)

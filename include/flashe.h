@@ -118,6 +118,12 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
                    uint64_t n, uint32_t n_jobs,
                    const uint64_t *pt, int pt_limbs, uint64_t *ct);
 
+/* n_vec independent encrypts of equal length (e.g. the clients a simulation or a multi-tenant service hosts on one
+ * GPU, or the layers of one model) in as few launches as possible: ct[v] = FlasheCipher.encrypt with cipher index
+ * idx[v], exactly as n_vec calls of flashe_encrypt_dev.  pt / ct are HOST arrays of n_vec device pointers. */
+int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
+                             const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev);
+
 /* FlasheCipher.decrypt -- jzf_flashe.py:584-594 -> _multiprocessing_decrypt (:537-582) /
  * _multiprocessing_decrypt_single (:506-535) with the prefix lists set_idx_list derived
  * (:356-386; single: :311-314 with n_add = 0):

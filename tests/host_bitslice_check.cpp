@@ -32,6 +32,7 @@ static inline uint32_t emu_perm(uint32_t s0, uint32_t s1, uint32_t sel)
 #define __builtin_amdgcn_bitop3_b32(a, b, c, tt) emu_bitop3((a), (b), (c), (tt))
 #define __builtin_amdgcn_perm(a, b, s) emu_perm((a), (b), (s))
 #define __builtin_amdgcn_sched_barrier(x)
+#define __builtin_amdgcn_alignbit(a, b, s) static_cast<uint32_t>(((static_cast<uint64_t>(a) << 32) | (b)) >> (s))
 #include "aes_bitslice_gen.h"
 #include "bitslice_core.h"
 
@@ -89,6 +90,40 @@ static int check(EVP_CIPHER_CTX *ctx, const uint32_t *rkp, uint32_t iter, uint32
     return bad;
 }
 
+template <int NSTREAM>
+static int check_packed(EVP_CIPHER_CTX *ctx, const uint32_t *rkw, uint32_t iter, uint32_t idx_a, uint32_t idx_b, uint64_t t_first)
+{
+    constexpr int EPL = 16 / NSTREAM;
+    static uint32_t rkp[15 * 64];
+    for (int r = 0; r < 15; r++)
+        for (int B = 0; B < 8; B++)
+            for (int k = 0; k < 8; k++) {
+                auto bit = [&](int byte) { return (rkw[4 * r + byte / 4] >> (24 - 8 * (byte % 4) + k)) & 1u; };
+                rkp[64 * r + 8 * B + k] = (bit(B) ? 0xffffu : 0u) | (bit(B + 8) ? 0xffff0000u : 0u);
+            }
+    int bad = 0;
+    for (int lane = 0; lane < 64; lane += 21) {
+        uint32_t s[64];
+        flashe::bs::load_planes_p<NSTREAM>(s, iter, idx_a, idx_b, t_first + lane);
+        flashe::bs::encrypt_planes_p(s, rkp);
+        u128 S[16];
+        flashe::bs::planes_to_blocks_p(s, S);
+        for (int q = 0; q < 16; q++) {
+            const uint64_t ctr = t_first + lane + 64ull * (q & (EPL - 1));
+            const uint32_t idx = (NSTREAM == 2 && q >= 8) ? idx_b : idx_a;
+            uint8_t in[16], out[32];
+            for (int i = 0; i < 4; i++) { in[i] = iter >> (24 - 8 * i); in[4 + i] = idx >> (24 - 8 * i); }
+            for (int i = 0; i < 8; i++) in[8 + i] = ctr >> (56 - 8 * i);
+            int len = 0;
+            EVP_EncryptUpdate(ctx, out, &len, in, 16);
+            u128 want = 0;
+            for (int i = 0; i < 16; i++) want = (want << 8) | out[i];
+            if (want != S[q]) bad++;
+        }
+    }
+    return bad;
+}
+
 int main()
 {
     uint8_t key[32];
@@ -110,6 +145,10 @@ int main()
     bad += check<2>(ctx, rkp, 3, 0, 1, (1ull << 32) - 500);          // crosses the 2^32 counter boundary
     bad += check<1>(ctx, rkp, 1, 9, 0, 123456789012ull);
     bad += check<1>(ctx, rkp, 0, 0, 0, 0);
+    bad += check_packed<2>(ctx, rkp, 77, 5, 6, 0);
+    bad += check_packed<2>(ctx, rkp, 0xffffffffu, 0xfffffffeu, 0xffffffffu, 1537);
+    bad += check_packed<2>(ctx, rkp, 3, 0, 1, (1ull << 32) - 300);
+    bad += check_packed<1>(ctx, rkp, 1, 9, 0, 123456789012ull);
     printf(bad ? "bitslice host check FAILED: %d mismatching blocks\n" : "bitslice host check OK\n", bad);
     return bad ? 1 : 0;
 }

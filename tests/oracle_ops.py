@@ -21,6 +21,10 @@ class OracleOps:
         self._v(ct, n)[:] = orc.encrypt(KEY, it, idx, "double" if scheme == SCHEME_DOUBLE else "single", n_jobs, self.b,
                                         pt.numpy().view(np.uint64).reshape(n, pt_limbs))
 
+    def encrypt_batch(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts):
+        for i, pt, ct in zip(idx_list, pts, cts):
+            self.encrypt(it, i, scheme, n, n_jobs, pt, pt_limbs, ct)
+
     def aggregate(self, tensors, n, out):
         self._v(out, n)[:] = orc.aggregate_elem([self._v(t, n) for t in tensors], self.b)
 

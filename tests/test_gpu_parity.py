@@ -181,12 +181,14 @@ def test_encrypt_decrypt_vs_oracle(E, oracle, b, n, J):
     assert np.array_equal(eng.mask(it, [9], n, J), oracle.mask(KEY, it, 9, n, J, b))
 
 
+@pytest.mark.parametrize("backend", [2, 4])
 @pytest.mark.parametrize("b,n", [(128, 100003), (128, 1024), (128, 1), (128, 2049), (127, 4099), (65, 70001), (100, 1000000)])
-def test_bitsliced_prf_backend_vs_oracle(E, oracle, b, n):
-    """The bit-sliced VALU PRF kernel must give the same bits as the LDS-table kernel and the oracle."""
+def test_bitsliced_prf_backend_vs_oracle(E, oracle, b, n, backend):
+    """The bit-sliced VALU PRF kernels (2: 32 blocks per lane, 4: packed, 16 blocks per lane) must give the
+    same bits as the LDS-table kernel and the oracle."""
     rng = np.random.Generator(np.random.PCG64(b + n))
     eng = make(E, b)
-    eng.set_prf_backend(2)
+    eng.set_prf_backend(backend)
     it = 77
     pt = rand_limbs(rng, n, b)
     ct = eng.encrypt(it, 5, E.SCHEME_DOUBLE, 16, pt)
@@ -208,7 +210,7 @@ def test_bitsliced_prf_backend_vs_oracle(E, oracle, b, n):
     assert np.array_equal(eng.encrypt(it, 5, E.SCHEME_DOUBLE, 16, pt), ct)
 
 
-@pytest.mark.parametrize("backend", [1, 2])
+@pytest.mark.parametrize("backend", [1, 2, 4])
 def test_counter_window_across_2_32(E, backend):
     """A launch whose counters straddle 2^32 (and one just below / above it) must take the generic
     first-round path; expected values come from the host AES, element by element."""
@@ -260,6 +262,21 @@ def test_range_twins_table_backend(E, oracle):
         eng.mask_range_dev(3, [6, 8], n, J, first, count, d_out2)
         assert np.array_equal(d_out2.download(np.uint64, count * Lb).reshape(count, Lb),
                               oracle.mask_sum(KEY, 3, [6, 8], n, J, b)[first:first + count])
+
+
+def test_encrypt_batch_equals_single_calls(E, oracle):
+    rng = np.random.Generator(np.random.PCG64(77))
+    for b, n, nv, sch, name in [(128, 100003, 10, 1, "double"), (128, 1500, 40, 1, "double"), (100, 5000, 3, 0, "single"), (64, 3001, 4, 1, "double")]:
+        eng = make(E, b)
+        Lb = L(b)
+        pts = [rng.integers(0, 2 ** 60, n, dtype=np.uint64) for _ in range(nv)]
+        idx = [int(v) for v in rng.integers(0, 2 ** 32 - 2, nv)]
+        dpt = [eng.upload(p) for p in pts]
+        dct = [eng.alloc_vec(n) for _ in range(nv)]
+        eng.encrypt_batch_dev(9, idx, sch, n, 16, dpt, 1, dct)
+        for v in range(0, nv, max(1, nv // 5)):
+            got = dct[v].download(np.uint64, n * Lb).reshape(n, Lb)
+            assert np.array_equal(got, oracle.encrypt(KEY, 9, idx[v], name, 16, b, pts[v])), (b, n, v)
 
 
 def test_u64_plaintext_zero_extension(E, oracle):

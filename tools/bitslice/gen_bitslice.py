@@ -68,6 +68,121 @@ def build_round(final):
     return net, S, K, flat_out
 
 
+def build_round_packed(final):
+    """Packed variant: plane register 8*Bp + k (Bp = 0..7) holds bit k of state byte Bp in its LOW 16 bits
+    and of state byte Bp + 8 in its HIGH 16 bits (16 blocks per lane).  Bytes Bp and Bp + 8 sit in the same
+    row of columns c and c + 2, so SubBytes / MixColumns / AddRoundKey act on both halves at once and
+    ShiftRows becomes a re-wiring plus half-swaps (rot16)."""
+    net = Net()
+    S = [[net.inp(f"s[{8 * B + k}]") for k in range(8)] for B in range(8)]
+    K = [[net.inp(f"rk[{8 * B + k}]", scalar=True) for k in range(8)] for B in range(8)]
+    sb = [add_sbox(net, S[B]) for B in range(8)]
+    sr = [[None] * 8 for _ in range(8)]
+    for c in range(2):
+        for r in range(4):
+            t = (c + r) % 4                      # old column feeding the low half of new pair c, row r
+            src = sb[4 * (t % 2) + r]
+            sr[4 * c + r] = [net.rot16(x) for x in src] if t >= 2 else src
+    outs = [[None] * 8 for _ in range(8)]
+    for c in range(2):
+        a = [sr[4 * c + r] for r in range(4)]
+        if final:
+            for r in range(4):
+                for k in range(8):
+                    outs[4 * c + r][k] = net.xor(a[r][k], K[4 * c + r][k])
+            continue
+        u = [[net.xor(a[r][k], a[(r + 1) % 4][k]) for k in range(8)] for r in range(4)]
+        T = [net.xor(u[0][k], u[2][k]) for k in range(8)]
+        for r in range(4):
+            for k in range(8):
+                x = net.xor(a[r][k], T[k])
+                if k >= 1:
+                    x = net.xor(x, u[r][k - 1])
+                if k in (0, 1, 3, 4):
+                    x = net.xor(x, u[r][7])
+                outs[4 * c + r][k] = net.xor(x, K[4 * c + r][k])
+    flat_out = [outs[B][k] for B in range(8) for k in range(8)]
+    return net, S, K, flat_out
+
+
+def verify_packed(net, S, K, flat_out, luts, final, trials=3):
+    rnd = random.Random(4321 + final)
+    for _ in range(trials):
+        blocks = [[rnd.randrange(256) for _ in range(16)] for _ in range(16)]
+        rk = [rnd.randrange(256) for _ in range(16)]
+        vals = {}
+        for B in range(8):
+            for k in range(8):
+                lo = sum(((blocks[p][B] >> k) & 1) << p for p in range(16))
+                hi = sum(((blocks[p][B + 8] >> k) & 1) << p for p in range(16))
+                vals[S[B][k]] = lo | (hi << 16)
+                vals[K[B][k]] = (0xFFFF if (rk[B] >> k) & 1 else 0) | (0xFFFF0000 if (rk[B + 8] >> k) & 1 else 0)
+        res = simulate_luts(net, luts, vals)
+        for p in range(16):
+            want = ref_round(blocks[p], rk, final)
+            got = [0] * 16
+            for B in range(8):
+                for k in range(8):
+                    v = res[flat_out[8 * B + k]]
+                    got[B] |= ((v >> p) & 1) << k
+                    got[B + 8] |= ((v >> (16 + p)) & 1) << k
+            assert got == want, (final, p)
+
+
+def emit_packed(net, luts, flat_out, fname, S, K):
+    by_node = {n: (n, leaves, tt) for n, leaves, tt in luts}
+    done, order, marks = set(), [], []
+
+    def visit(n):
+        if n in done or n not in by_node:
+            return
+        for l in by_node[n][1]:
+            visit(l)
+        done.add(n)
+        order.append(by_node[n])
+
+    for c in range(2):
+        for r in range(4):
+            for k in range(8):
+                visit(flat_out[8 * (4 * c + r) + k])
+        marks.append(len(order))
+    assert len(order) == len(luts)
+    name = {}
+    for B in range(8):
+        for k in range(8):
+            name[S[B][k]] = f"s[{8 * B + k}]"
+            name[K[B][k]] = f"rk[{8 * B + k}]"
+    lines = []
+    n_lut = n_rot = 0
+    for pos, (n, leaves, tt) in enumerate(order):
+        if pos in marks:
+            lines.append("    __builtin_amdgcn_sched_barrier(0);")
+        name[n] = f"t{n}"
+        args = [name[l] for l in leaves]
+        if tt == "rot16":
+            expr = f"rot16({args[0]})"
+            n_rot += 1
+        elif len(leaves) == 3:
+            expr = f"lut3<0x{tt:02x}>({args[0]}, {args[1]}, {args[2]})"
+            n_lut += 1
+        elif len(leaves) == 2:
+            simple = {0x3c: f"({args[0]} ^ {args[1]})", 0xc0: f"({args[0]} & {args[1]})",
+                      0xc3: f"~({args[0]} ^ {args[1]})", 0xfc: f"({args[0]} | {args[1]})"}
+            expr = simple.get(tt, f"lut3<0x{tt:02x}>({args[0]}, {args[1]}, {args[1]})")
+            n_lut += 1
+        else:
+            assert tt in (0xf0, 0x0f), hex(tt)
+            expr = f"~{args[0]}" if tt == 0x0f else args[0]
+            n_lut += 1
+        lines.append(f"    const uint32_t {name[n]} = {expr};")
+    for i, n in enumerate(flat_out):
+        lines.append(f"    o[{i}] = {name[n]};")
+    body = "\n".join(lines)
+    return (f"// {n_lut} LUT ops + {n_rot} half-swaps\n"
+            f"__device__ __forceinline__ void {fname}(const uint32_t (&s)[64], const uint32_t *__restrict__ rk, uint32_t (&o)[64])\n"
+            "{\n" + body + "\n}\n"), n_lut, n_rot
+
+
 # ---------------------------------------------------------------- reference round on bytes
 def xtime(a):
     a <<= 1
@@ -187,6 +302,17 @@ def main():
         n_gates = sum(1 for n in range(len(net.ops)) if net.fanins(n))
         stats[fname] = (n_gates, len(luts))
         parts.append(emit(net, luts, flat_out, fname, S, K))
+        parts.append("\n")
+    parts.append("// ---- packed variant: 64 plane registers, two state bytes (B, B + 8) x 16 blocks per register;\n"
+                 "// rk points at the round's 64 packed key planes ----\n"
+                 "__device__ __forceinline__ uint32_t rot16(uint32_t x)\n{\n    return __builtin_amdgcn_alignbit(x, x, 16);\n}\n\n")
+    for final, fname in ((False, "round_main_p"), (True, "round_final_p")):
+        net, S, K, flat_out = build_round_packed(final)
+        luts = map_luts(net, flat_out)
+        verify_packed(net, S, K, flat_out, luts, final)
+        text, n_lut, n_rot = emit_packed(net, luts, flat_out, fname, S, K)
+        stats[fname] = (sum(1 for n in range(len(net.ops)) if net.fanins(n)), n_lut + n_rot)
+        parts.append(text)
         parts.append("\n")
     parts.append("}  // namespace bs\n}  // namespace flashe\n")
     with open(out_path, "w") as f:

@@ -44,13 +44,21 @@ class Net:
     def not_(self, a):
         return self.gate("not", a)
 
+    def rot16(self, a):
+        """Swap the two 16-bit halves of a plane register (a non-LUT op: one v_alignbit_b32).  For the
+        mapper it is a boundary: its output is a leaf for cuts, its input must be realised."""
+        return self.gate("rot16", a)
+
     def fanins(self, n):
         op, a, b = self.ops[n]
         if op == "in":
             return ()
-        if op == "not":
+        if op in ("not", "rot16"):
             return (a,)
         return (a, b)
+
+    def is_rot(self, n):
+        return self.ops[n][0] == "rot16"
 
 
 def eval_cone(net, node, leaves):
@@ -63,7 +71,7 @@ def eval_cone(net, node, leaves):
         if n in memo:
             return memo[n]
         op, a, b = net.ops[n]
-        if op == "in":
+        if op in ("in", "rot16"):
             raise ValueError("cone reaches an input that is not a leaf")
         if op == "not":
             v = ev(a) ^ 0xFF
@@ -105,6 +113,11 @@ def map_luts(net, outputs, max_cuts=16, rounds=4):
             cuts[n] = [frozenset([n])]
             af[n] = 0.0
             continue
+        if net.is_rot(n):
+            cuts[n] = [frozenset([n])]
+            best[n] = frozenset(fi)
+            af[n] = (1.0 + af[fi[0]]) / max(1, fanout[n])
+            continue
         cand = set()
         lists = [cuts[f] for f in fi]
         for combo in itertools.product(*lists):
@@ -143,7 +156,7 @@ def map_luts(net, outputs, max_cuts=16, rounds=4):
     for _ in range(rounds):
         changed = False
         for n in range(n_nodes):
-            if refs[n] == 0 or not net.fanins(n):
+            if refs[n] == 0 or not net.fanins(n) or net.is_rot(n):
                 continue
             cur = best[n]
             for l in cur:                      # take the current cut out
@@ -166,6 +179,9 @@ def map_luts(net, outputs, max_cuts=16, rounds=4):
     used = [n for n in range(n_nodes) if refs[n] > 0 and net.fanins(n)]
     luts = []
     for n in used:
+        if net.is_rot(n):
+            luts.append((n, tuple(best[n]), "rot16"))
+            continue
         leaves = tuple(sorted(best[n], key=lambda l: (net.scalar[l], l)))   # scalar leaf last
         luts.append((n, leaves, eval_cone(net, n, leaves)))
     return luts
@@ -176,6 +192,10 @@ def simulate_luts(net, luts, input_values, width=32):
     mask = (1 << width) - 1
     val = dict(input_values)
     for n, leaves, tt in luts:
+        if tt == "rot16":
+            x = val[leaves[0]]
+            val[n] = ((x >> 16) | (x << 16)) & mask
+            continue
         a = [val[l] for l in leaves] + [0] * (3 - len(leaves))
         out = 0
         for m in range(8):
