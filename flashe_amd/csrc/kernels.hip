@@ -222,8 +222,6 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
 {
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, p.te0);
-    // latency-critical (LDS round trips): win VALU issue arbitration over co-resident bit-sliced waves
-    __builtin_amdgcn_s_setprio(3);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(p.mask_hi) << 64) | p.mask_lo;
     // lane-invariant part of round 1 (valid when the launch stays inside one 2^32 counter window)
@@ -309,24 +307,24 @@ struct BatchTable {
     uint64_t *out[kMaxBatch];
 };
 
-template <bool DBL>
-__global__ __launch_bounds__(kPrfThreads) void prf_wide_batch_kernel(const RoundKeys rk, const BatchTable tb, int n_vec, uint64_t n,
+template <bool DBL, int THREADS, int PRIO>
+__global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const BatchTable tb, int n_vec, uint64_t n,
                                                                      uint32_t iter, int in_limbs, uint64_t mask_lo, uint64_t mask_hi,
                                                                      const uint32_t *te0)
 {
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, te0);
-    __builtin_amdgcn_s_setprio(3);
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
-    const uint64_t tiles_per_vec = (n + kPrfThreads - 1) / kPrfThreads;
+    const uint64_t tiles_per_vec = (n + THREADS - 1) / THREADS;
     const uint64_t total_tiles = tiles_per_vec * static_cast<uint64_t>(n_vec);
     const bool ctr_fast = ((n - 1) >> 32) == 0;
     int cur = -1;
     CtrPrefix pre_a{}, pre_b{};
     for (uint64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
         const int v = static_cast<int>(t / tiles_per_vec);              // wave-uniform
-        const uint64_t j = (t - static_cast<uint64_t>(v) * tiles_per_vec) * kPrfThreads + threadIdx.x;
+        const uint64_t j = (t - static_cast<uint64_t>(v) * tiles_per_vec) * THREADS + threadIdx.x;
         const uint32_t ia = tb.idx[v];
         if (v != cur && ctr_fast) {
             pre_a = ctr_prefix(rk, lr, iter, ia, 0u);
@@ -675,14 +673,16 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
     for (int v = 0; v < n_vec; v++) { tb.idx[v] = idx[v]; tb.in[v] = in_dev[v]; tb.out[v] = out_dev[v]; }
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
+    // measured on MI355X (tools/sweep_tt.py): 1024-thread workgroups beat 768 / 512 (2.71 vs 2.87 / 2.99 ms for ten
+    // 1e7-element vectors) and raising the wave priority costs ~1 %
     const uint64_t tiles = ((n + kPrfThreads - 1) / kPrfThreads) * static_cast<uint64_t>(n_vec);
     const int grid = static_cast<int>(tiles < static_cast<uint64_t>(env.num_cus) ? tiles : env.num_cus);
     if (dbl)
-        hipLaunchKernelGGL(prf_wide_batch_kernel<true>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, n_vec, n, iter,
-                           in_limbs, lo, hi, env.te0_dev);
+        hipLaunchKernelGGL((prf_wide_batch_kernel<true, kPrfThreads, 0>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb,
+                           n_vec, n, iter, in_limbs, lo, hi, env.te0_dev);
     else
-        hipLaunchKernelGGL(prf_wide_batch_kernel<false>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, n_vec, n, iter,
-                           in_limbs, lo, hi, env.te0_dev);
+        hipLaunchKernelGGL((prf_wide_batch_kernel<false, kPrfThreads, 0>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb,
+                           n_vec, n, iter, in_limbs, lo, hi, env.te0_dev);
     return hipGetLastError();
 }
 
