@@ -673,7 +673,7 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
     for (int v = 0; v < n_vec; v++) { tb.idx[v] = idx[v]; tb.in[v] = in_dev[v]; tb.out[v] = out_dev[v]; }
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
-    // measured on MI355X (tools/sweep_tt.py): 1024-thread workgroups beat 768 / 512 (2.71 vs 2.87 / 2.99 ms for ten
+    // measured on MI355X: 1024-thread workgroups beat 768 / 512 (2.71 vs 2.87 / 2.99 ms for ten
     // 1e7-element vectors) and raising the wave priority costs ~1 %
     const uint64_t tiles = ((n + kPrfThreads - 1) / kPrfThreads) * static_cast<uint64_t>(n_vec);
     const int grid = static_cast<int>(tiles < static_cast<uint64_t>(env.num_cus) ? tiles : env.num_cus);
