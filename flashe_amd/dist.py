@@ -191,7 +191,7 @@ class ShardedRound:
         self.p_dec = torch.zeros(chunks * sub * L, **kw) if self.exchange else None
         self._pipe_key = key
 
-    def run_pipelined(self, it, pts, pt_limbs, chunks=4):
+    def run_pipelined(self, it, pts, pt_limbs, chunks=4, batch_events=None):
         """The round with everything after the last client's encrypt hidden under it, chunk by chunk:
         the last client encrypts chunk q on the main stream; on the side stream chunk q is reduced
         locally, reduce-scattered (all-to-all + mod-add of the received pieces), the owned piece is
@@ -202,8 +202,12 @@ class ShardedRound:
         sub, chunk = self.p_sub, self.p_chunk
         last = self.cpr - 1
         if last:
+            if batch_events:                       # (start, stop) engine events bracketing the batched launch
+                ops.engine.record(batch_events[0])
             ops.encrypt_batch(it, [self.rank * self.cpr + c for c in range(last)], self.scheme, n, self.n_jobs,
                               pts[:last], pt_limbs, self.ct[:last])
+            if batch_events:
+                ops.engine.record(batch_events[1])
         uploaded = list(range(self.total_clients()))
         add_idx, minus_idx = telescope(uploaded) if self.scheme == SCHEME_DOUBLE else ([], uploaded)
         for q in range(chunks):

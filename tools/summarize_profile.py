@@ -61,22 +61,24 @@ def main(tag):
             e["effective_clock_ghz"] = e["GRBM_GUI_ACTIVE"]["avg"] / 8 / (sum(dur[k]) / len(dur[k]))
         out[k] = e
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
-    enc = next((k for k in out if "prf_wide_kernel<1>" in k), None)
-    if enc and "FETCH_SIZE" in out[enc]:
-        f, w = out[enc]["FETCH_SIZE"], out[enc]["WRITE_SIZE"]
-        # the encrypt launches are the ones with the smaller read volume (8-B plaintext in); the
-        # decrypt launch shares the kernel and reads 16 B per element
-        traffic = {"tag": tag, "kernel": enc,
-                   "encrypt_kernel_hbm_bytes_per_launch": (2 * f["min"] + w["min"]) * 1024,
-                   "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = "
-                          "(2 * FETCH_SIZE[KiB] + WRITE_SIZE[KiB]) * 1024 (gfx950 FETCH_SIZE counts 64 B per 128-B "
-                          "request, MI355X_MICROARCH.md HBM section); min over launches = the encrypt launches",
-                   "fetch_kib_min": f["min"], "write_kib": w["min"]}
+    # the dominant kernel of the default (pipelined) schedule is the batched encrypt; the same kernel body also
+    # runs as prf_wide_kernel<1> for the last client's chunks and the decrypt
+    dom = next((k for k in out if "prf_wide_batch_kernel" in k), None) or next((k for k in out if "prf_wide_kernel<1>" in k), None)
+    if dom and "FETCH_SIZE" in out[dom]:
+        f, w = out[dom]["FETCH_SIZE"], out[dom]["WRITE_SIZE"]
+        per_launch = (2 * f["avg"] + w["avg"]) * 1024
+        vectors = round(w["avg"] * 1024 / 160e6) or 1                     # each client vector writes n * 16 B = 160 MB
+        traffic = {"tag": tag, "kernel": dom, "dominant_kernel_hbm_bytes_per_launch": per_launch,
+                   "client_vectors_per_launch": vectors, "encrypt_hbm_bytes_per_vector": per_launch / vectors,
+                   "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the default bench command; "
+                          "bytes = (2 * FETCH_SIZE[KiB] + WRITE_SIZE[KiB]) * 1024 (gfx950 FETCH_SIZE counts 64 B per 128-B "
+                          "request, MI355X_MICROARCH.md HBM section), averaged over the kernel's launches",
+                   "fetch_kib_avg": f["avg"], "write_kib_avg": w["avg"]}
         agg = next((k for k in out if "aggregate_elem_kernel" in k), None)
         if agg and "FETCH_SIZE" in out[agg]:
             traffic["calibration"] = {"kernel": agg, "fetch_kib_avg": out[agg]["FETCH_SIZE"]["avg"],
-                                      "doubled_bytes": 2 * out[agg]["FETCH_SIZE"]["avg"] * 1024,
-                                      "known_read_bytes": "C * n * 16 (= 1.6e9 at C = 10, n = 1e7)"}
+                                      "write_kib_avg": out[agg]["WRITE_SIZE"]["avg"],
+                                      "note": "the reduce reads exactly 10 x what it writes: 2 * FETCH / WRITE must be 10"}
         json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps({k[:50]: {c: (round(v["avg"]) if isinstance(v, dict) and "avg" in v else v) for c, v in e.items()
                                if c != "launch"} for k, e in out.items()}, indent=1))
