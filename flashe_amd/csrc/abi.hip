@@ -523,8 +523,8 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
         int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev[v], pt_dev[v], pt_limbs);
         if (rc) return rc;
     }
-    if (ctx->limbs == 1 || ctx->env.prf_backend != PRF_AUTO && ctx->env.prf_backend != PRF_TABLE) {
-        // chunk-dependent counters (b <= 64) and the alternative PRF backends go vector by vector
+    if (ctx->env.prf_backend != PRF_AUTO && ctx->env.prf_backend != PRF_TABLE) {
+        // the alternative PRF backends go vector by vector
         for (int v = 0; v < n_vec; v++) {
             int rc = flashe_encrypt_dev(ctx, iter, idx[v], scheme, n, n_jobs, pt_dev[v], pt_limbs, ct_dev[v]);
             if (rc) return rc;
@@ -533,7 +533,8 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
     }
     for (int v0 = 0; v0 < n_vec; v0 += kMaxBatch) {
         const int nv = std::min(kMaxBatch, n_vec - v0);
-        HIP_TRY(ctx, launch_prf_batch(ctx->env, iter, scheme == FLASHE_SCHEME_DOUBLE, nv, idx + v0, pt_dev + v0, pt_limbs, ct_dev + v0, n));
+        HIP_TRY(ctx, launch_prf_batch(ctx->env, iter, scheme == FLASHE_SCHEME_DOUBLE, nv, idx + v0, pt_dev + v0, pt_limbs, ct_dev + v0, n,
+                                      n_jobs));
     }
     return FLASHE_OK;
 }

@@ -38,10 +38,11 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter,
                       const uint64_t *in_dev, int in_limbs, uint64_t *out_dev);
 
 // Several independent encrypts of equal length in ONE launch: vector v is encrypted with prefix idx[v]
-// (and idx[v] + 1 when `dbl`).  b > 64 only; at most kMaxBatch vectors.
+// (and idx[v] + 1 when `dbl`); at most kMaxBatch vectors per launch.
 constexpr int kMaxBatch = 32;
 hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx,
-                            const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n);
+                            const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n,
+                            uint32_t n_jobs);
 
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
                           const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);

@@ -533,6 +533,51 @@ __global__ __launch_bounds__(kBsThreads, WAVES) void prf_wide_bsp_kernel(const u
     }
 }
 
+// ---- batched form of prf_small_kernel for encrypts: n_vec vectors of equal length, one prefix pair each ----
+template <bool DBL>
+__global__ __launch_bounds__(kSmallThreads) void prf_small_batch_kernel(const RoundKeys rk, const BatchTable tb, int n_vec, const PrfParams p)
+{
+    __shared__ uint32_t tab[kTabWords];
+    fill_tables(tab, p.te0);
+    const LaneRegs lr = lane_regs(tab);
+    const uint64_t J = p.n_jobs, d = p.n / J, r = p.n % J;
+    const uint64_t m = static_cast<uint64_t>(p.m);
+    const uint64_t nb1 = (d + 1 + m - 1) / m;
+    const uint64_t nb0 = d ? (d + m - 1) / m : 0;
+    const uint64_t blocks_per_vec = r * nb1 + (J - r) * nb0;
+    const uint64_t total = blocks_per_vec * static_cast<uint64_t>(n_vec);
+
+    for (uint64_t G = static_cast<uint64_t>(blockIdx.x) * kSmallThreads + threadIdx.x; G < total;
+         G += static_cast<uint64_t>(gridDim.x) * kSmallThreads) {
+        const uint64_t v = G / blocks_per_vec, B = G - v * blocks_per_vec;
+        uint64_t begin, len, i;
+        if (B < r * nb1) {
+            const uint64_t c = B / nb1;
+            i = B - c * nb1; begin = c * (d + 1); len = d + 1;
+        } else {
+            const uint64_t B2 = B - r * nb1, c = B2 / nb0;
+            i = B2 - c * nb0; begin = r * (d + 1) + c * d; len = d;
+        }
+        const uint64_t j0 = begin + i * m;
+        const uint64_t rem = len - i * m;
+        const int cnt = rem < m ? static_cast<int>(rem) : static_cast<int>(m);
+        const uint64_t ctr = begin + i;
+        const uint32_t ia = tb.idx[v];
+        const uint64_t *in = tb.in[v];
+        uint64_t *out = tb.out[v];
+        uint32_t s[DBL ? 2 : 1][4];
+        set_block(s[0], p.iter, ia, ctr);
+        if (DBL) set_block(s[DBL ? 1 : 0], p.iter, ia + 1u, ctr);
+        aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
+        const u128 S0 = words_to_u128(s[0]);
+        const u128 S1 = DBL ? words_to_u128(s[DBL ? 1 : 0]) : static_cast<u128>(0);
+        for (int t = 0; t < cnt; t++) {
+            const uint64_t a = extract64(S0, p.b * t), bsub = DBL ? extract64(S1, p.b * t) : 0ull;
+            out[j0 + t] = (in[j0 + t] + a - bsub) & p.mask_lo;
+        }
+    }
+}
+
 // Known-answer helper: raw AES of nblk blocks given as big-endian words.
 __global__ __launch_bounds__(kPrfThreads) void aes_blocks_kernel(const RoundKeys rk, const uint32_t *te0, uint32_t nblk,
                                                                  const uint32_t *in, uint32_t *out)
@@ -665,14 +710,25 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
 }
 
 hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx,
-                            const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n)
+                            const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n, uint32_t n_jobs)
 {
     if (n == 0 || n_vec == 0) return hipSuccess;
-    if (env.b <= 64 || n_vec > kMaxBatch) return hipErrorInvalidValue;
+    if (n_vec > kMaxBatch) return hipErrorInvalidValue;
     BatchTable tb{};
     for (int v = 0; v < n_vec; v++) { tb.idx[v] = idx[v]; tb.in[v] = in_dev[v]; tb.out[v] = out_dev[v]; }
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
+    if (env.b <= 64) {
+        PrfParams p{};
+        p.te0 = env.te0_dev; p.n = n; p.iter = iter; p.n_jobs = n_jobs; p.b = env.b; p.m = 128 / env.b; p.mask_lo = lo;
+        const uint64_t m = p.m, J = n_jobs, d = n / J, r = n % J;
+        const uint64_t nb1 = (d + 1 + m - 1) / m, nb0 = d ? (d + m - 1) / m : 0;
+        const uint64_t total = (r * nb1 + (J - r) * nb0) * static_cast<uint64_t>(n_vec);
+        const int grid = grid_for(env, total, kSmallThreads);
+        if (dbl) hipLaunchKernelGGL(prf_small_batch_kernel<true>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, n_vec, p);
+        else hipLaunchKernelGGL(prf_small_batch_kernel<false>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, n_vec, p);
+        return hipGetLastError();
+    }
     // measured on MI355X: 1024-thread workgroups beat 768 / 512 (2.71 vs 2.87 / 2.99 ms for ten
     // 1e7-element vectors) and raising the wave priority costs ~1 %
     const uint64_t tiles = ((n + kPrfThreads - 1) / kPrfThreads) * static_cast<uint64_t>(n_vec);

@@ -266,10 +266,11 @@ def test_range_twins_table_backend(E, oracle):
 
 def test_encrypt_batch_equals_single_calls(E, oracle):
     rng = np.random.Generator(np.random.PCG64(77))
-    for b, n, nv, sch, name in [(128, 100003, 10, 1, "double"), (128, 1500, 40, 1, "double"), (100, 5000, 3, 0, "single"), (64, 3001, 4, 1, "double")]:
+    for b, n, nv, sch, name in [(128, 100003, 10, 1, "double"), (128, 1500, 40, 1, "double"), (100, 5000, 3, 0, "single"), (64, 3001, 4, 1, "double"),
+                                 (23, 61706, 33, 1, "double"), (20, 9999, 5, 0, "single"), (7, 1000, 2, 1, "double"), (64, 5, 3, 1, "double")]:
         eng = make(E, b)
         Lb = L(b)
-        pts = [rng.integers(0, 2 ** 60, n, dtype=np.uint64) for _ in range(nv)]
+        pts = [rng.integers(0, 2 ** min(60, b), n, dtype=np.uint64) for _ in range(nv)]
         idx = [int(v) for v in rng.integers(0, 2 ** 32 - 2, nv)]
         dpt = [eng.upload(p) for p in pts]
         dct = [eng.alloc_vec(n) for _ in range(nv)]
