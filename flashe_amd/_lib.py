@@ -91,6 +91,8 @@ _SIGNATURES = {
     "flashe_batch": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
     "flashe_unbatch_dev": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
     "flashe_unbatch": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
+    "flashe_sparsify_dev": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "flashe_sparsify": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -127,6 +127,7 @@ struct flashe_ctx {
     Buf summaries;    // packed-aggregate block summaries
     Buf stream_tmp;   // whole-vector mask stream for the sparse paths
     Buf acc_tmp[2];   // ping-pong partial sums when a packed reduce has more than kMaxOps operands
+    Buf sp_ws;        // sparsifier workspace (select state, histogram, per-block counts)
 };
 
 namespace {
@@ -279,7 +280,7 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     if (!ctx) return FLASHE_EINVAL;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->env.stream);
-    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1]})
+    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws})
         if (b->p) (void)hipFree(b->p);
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
     if (ctx->rkw_dev) (void)hipFree(ctx->rkw_dev);
@@ -807,6 +808,21 @@ int flashe_unbatch_dev(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in_d
     return FLASHE_OK;
 }
 
+// ---- sparsifier ----
+int flashe_sparsify_dev(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x_dev, int x_is_f64, void *residual_dev, uint32_t *loc_dev,
+                        void *vals_dev)
+{
+    CHECK_CTX(ctx);
+    if (n >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "sparsify: n must be < 2^32");
+    if (k > n) return fail(ctx, FLASHE_EINVAL, "sparsify: k (%llu) > n (%llu)", static_cast<unsigned long long>(k),
+                           static_cast<unsigned long long>(n));
+    if (n && k && (!x_dev || !loc_dev || !vals_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = ensure(ctx, ctx->sp_ws, sparsify_workspace_bytes(n));
+    if (rc) return rc;
+    HIP_TRY(ctx, launch_sparsify(ctx->env, n, k, x_dev, x_is_f64 != 0, residual_dev, loc_dev, vals_dev, ctx->sp_ws.p));
+    return FLASHE_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Host-pointer twins: H2D, the _dev call, D2H, synchronous.
 // ------------------------------------------------------------------------------------------
@@ -1090,6 +1106,26 @@ int flashe_unbatch(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in, int 
     rc = flashe_unbatch_dev(ctx, n_batches, di.as<uint64_t>(), field_bits, dout.as<uint64_t>());
     if (rc) return rc;
     D2H(out, dout.p, static_cast<size_t>(n_batches * bs) * 8);
+    return FLASHE_OK;
+}
+
+int flashe_sparsify(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x, int x_is_f64, void *residual, uint32_t *loc, void *vals)
+{
+    CHECK_CTX(ctx);
+    if (n == 0 || k == 0) return FLASHE_OK;
+    if (!x || !loc || !vals) return fail(ctx, FLASHE_EINVAL, "null vector");
+    const size_t es = x_is_f64 ? 8 : 4;
+    Tmp dx, dr, dl, dv;
+    HIP_TRY(ctx, dx.alloc(n * es));
+    HIP_TRY(ctx, dl.alloc(k * 4));
+    HIP_TRY(ctx, dv.alloc(k * es));
+    H2D(dx.p, x, n * es);
+    if (residual) { HIP_TRY(ctx, dr.alloc(n * es)); H2D(dr.p, residual, n * es); }
+    int rc = flashe_sparsify_dev(ctx, n, k, dx.p, x_is_f64, residual ? dr.p : nullptr, dl.as<uint32_t>(), dv.p);
+    if (rc) return rc;
+    if (residual) HIP_TRY(ctx, hipMemcpyAsync(residual, dr.p, n * es, hipMemcpyDeviceToHost, ctx->env.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(loc, dl.p, k * 4, hipMemcpyDeviceToHost, ctx->env.stream));
+    D2H(vals, dv.p, k * es);
     return FLASHE_OK;
 }
 

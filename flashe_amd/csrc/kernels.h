@@ -80,6 +80,11 @@ hipError_t launch_unquantize(const LaunchEnv &env, uint64_t n, const uint64_t *v
 hipError_t launch_batch(const LaunchEnv &env, uint64_t n, const uint64_t *vals_dev, int field_bits, uint64_t *out_dev);
 hipError_t launch_unbatch(const LaunchEnv &env, uint64_t nb, const uint64_t *in_dev, int field_bits, uint64_t *out_dev);
 
+// Top-k sparsifier; ws = device workspace of sparsify_workspace_bytes(n).
+size_t sparsify_workspace_bytes(uint64_t n);
+hipError_t launch_sparsify(const LaunchEnv &env, uint64_t n, uint64_t k, const void *x, bool is_f64, void *residual, uint32_t *loc,
+                           void *vals, void *ws);
+
 // Device KAT: encrypts `nblk` 16-byte blocks (big-endian words in) with the PRF core.
 hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t *in_words_dev,
                              uint32_t *out_words_dev);

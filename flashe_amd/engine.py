@@ -402,3 +402,20 @@ class Engine:
         out = np.zeros(batched.shape[0] * bs, dtype=np.uint64)
         self._check(self._lib.flashe_unbatch(self._h, batched.shape[0], batched.ctypes.data, field_bits, out.ctypes.data))
         return out
+
+    # -- top-k sparsifier (Client.sparsify, jzf_aggregator.py:578-623) ---------------------------------
+    def sparsify_dev(self, n, k, x, x_is_f64, residual, loc, vals):
+        self._check(self._lib.flashe_sparsify_dev(self._h, n, k, self._ptr(x), 1 if x_is_f64 else 0, self._ptr(residual),
+                                                  self._ptr(loc), self._ptr(vals)))
+
+    def sparsify(self, layer, k, residual=None):
+        """-> (loc uint32[k] ascending, vals[k] = layer + residual at loc, new residual or None)."""
+        layer = np.ascontiguousarray(layer).reshape(-1)
+        if layer.dtype not in (np.float32, np.float64):
+            layer = layer.astype(np.float64)
+        res = None if residual is None else np.ascontiguousarray(residual, dtype=layer.dtype).reshape(-1).copy()
+        loc = np.zeros(k, dtype=np.uint32)
+        vals = np.zeros(k, dtype=layer.dtype)
+        self._check(self._lib.flashe_sparsify(self._h, layer.shape[0], k, layer.ctypes.data, 1 if layer.dtype == np.float64 else 0,
+                                              res.ctypes.data if res is not None else None, loc.ctypes.data, vals.ctypes.data))
+        return loc, vals, res

@@ -229,6 +229,18 @@ int flashe_batch(flashe_ctx *ctx, uint64_t n, const uint64_t *vals, int field_bi
 int flashe_unbatch_dev(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in_dev, int field_bits, uint64_t *out_dev);
 int flashe_unbatch(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in, int field_bits, uint64_t *out);
 
+/* ---- top-s% sparsifier of the client ------------------------------------ */
+/* Client.sparsify for ONE layer -- federatedml/framework/homo/procedure/jzf_aggregator.py:578-623: the k entries
+ * of largest |x| (ranked BEFORE the residual is added, as the reference does; ties at the k-th magnitude go to the
+ * higher index) are emitted in ascending index order -- loc[k] and vals[k] = x + residual -- and the residual is
+ * updated in place (selected positions 0, the others x + residual).  residual may be NULL (treated as zeros, not
+ * written).  x / residual / vals are float32 (x_is_f64 == 0) or float64; n < 2^32; k <= n with
+ * k = max(1, floor(sparsity * n)) in the reference. */
+int flashe_sparsify_dev(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x_dev, int x_is_f64, void *residual_dev,
+                        uint32_t *loc_dev, void *vals_dev);
+int flashe_sparsify(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x, int x_is_f64, void *residual,
+                    uint32_t *loc, void *vals);
+
 #ifdef __cplusplus
 }
 #endif

@@ -285,6 +285,22 @@ def unbatch(batched, int_bits, field_bits):
     return out
 
 
+def sparsify(layer, k, remain):
+    """-> (loc uint32[k], vals[k], new remain).  remain is not modified in place."""
+    layer = np.ascontiguousarray(layer)
+    is64 = layer.dtype == np.float64
+    if not is64:
+        layer = layer.astype(np.float32)
+    rem = np.ascontiguousarray(remain, dtype=layer.dtype).copy()
+    loc = np.zeros(k, dtype=np.uint32)
+    vals = np.zeros(k, dtype=layer.dtype)
+    rc = lib().fo_sparsify(ctypes.c_uint64(len(layer)), ctypes.c_uint64(k), layer.ctypes.data_as(ctypes.c_void_p),
+                           ctypes.c_int(1 if is64 else 0), rem.ctypes.data_as(ctypes.c_void_p),
+                           loc.ctypes.data_as(_u32p), vals.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    return loc, vals, rem
+
+
 def aesni_available():
     return bool(lib().fo_aesni_available())
 

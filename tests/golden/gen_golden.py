@@ -511,7 +511,38 @@ def gen_codec():
     dump("codec.json", out)
 
 
+# --------------------------------------------------------------------------- sparsifier (f-3)
+def gen_sparsify():
+    """Client.sparsify (jzf_aggregator.py:578-623), one layer, restated literally (jzf_aggregator cannot be
+    imported): top-k by |layer| (taken BEFORE the residual is added), residual accumulation across two rounds.
+    Values are distinct in magnitude so numpy's unstable argsort has a unique answer."""
+    cases = []
+    for dtype, n, sparsity, seed in [("float32", 1000, 0.01, 1), ("float32", 4099, 0.1, 2), ("float64", 777, 0.05, 3),
+                                     ("float32", 50, 0.001, 4), ("float32", 300, 1.0, 5)]:
+        rng = np.random.RandomState(seed)
+        remain = None
+        rounds = []
+        for rd in range(2):
+            layer = rng.standard_normal(n).astype(dtype)
+            while len(np.unique(np.abs(layer))) != n:          # float32 magnitudes can collide: redraw
+                layer = rng.standard_normal(n).astype(dtype)
+            flatten = layer.flatten()
+            abs_flatten = np.abs(flatten)
+            if remain is not None:
+                flatten += remain
+            idx = max(1, int(np.floor(sparsity * n)))
+            location = sorted(abs_flatten.argsort()[-idx:][::-1])
+            masked_layer = flatten[location]
+            flatten[location] = 0.0
+            remain = flatten
+            rounds.append({"layer": layer.tobytes().hex(), "k": idx, "location": [int(v) for v in location],
+                           "masked": masked_layer.tobytes().hex(), "remain": remain.tobytes().hex()})
+        cases.append({"dtype": dtype, "n": n, "sparsity": sparsity, "rounds": rounds})
+    dump("sparsify.json", {"cases": cases})
+
+
 if __name__ == "__main__":
+    gen_sparsify()
     gen_codec()
     gen_aes()
     gen_masks()

@@ -434,6 +434,62 @@ def test_config1_end_to_end_with_codec(E):
     assert unq_obj.tobytes() == z["unq_elem"].tobytes()
 
 
+def test_wire_format_mirror(E):
+    """f-2: compress / decompress integers equal the reference's (_to_bytes_old fixtures, incl. the chunk-merge)."""
+    from flashe_amd import weights as wz
+    g = load_golden("pack.json")
+    for c in g["cases"] + g["merges"]:
+        vals = unhex(c["vals"])
+        big, n = wz.to_big_int(np.array(vals, dtype=object), c["b"])
+        assert n == c["n"] and big == int(c["packed_int"], 16)
+        assert [int(v) for v in wz.from_big_int(big, n, c["b"])] == vals
+    layer = np.array([[3, 1, 4], [1, 5, 9]], dtype=object)
+    tw = wz.TransferableWeights({"w": layer, "b": np.array([7], dtype=object)}, bits=20)
+    assert tw.unboxed["w"] == sum(int(v) << (20 * (5 - j)) for j, v in enumerate(layer.flatten()))
+    back = tw.decompress()
+    assert back["w"].shape == (2, 3) and [int(v) for v in back["w"].flatten()] == [3, 1, 4, 1, 5, 9] and int(back["b"][0]) == 7
+    # sparse location coding: _to_bytes(locations, total.bit_length())
+    total = 25_557_032
+    locs = np.sort(np.random.Generator(np.random.PCG64(1)).choice(total, size=5000, replace=False))
+    big, n = wz.to_big_int(locs.astype(object), total.bit_length())
+    assert [int(v) for v in wz.from_big_int(big, n, total.bit_length())] == [int(v) for v in locs]
+
+
+def test_sparsify_golden_and_oracle(E, oracle):
+    """f-3: top-k + residual, the reference's fixtures (two rounds) and a config-5-sized layer vs the oracle."""
+    eng = make(E, 128)
+    for c in load_golden("sparsify.json")["cases"]:
+        dt = np.dtype(c["dtype"])
+        remain = np.zeros(c["n"], dtype=dt)
+        for rd in c["rounds"]:
+            layer = np.frombuffer(bytes.fromhex(rd["layer"]), dtype=dt)
+            loc, vals, remain = eng.sparsify(layer, rd["k"], remain)
+            assert [int(v) for v in loc] == rd["location"]
+            assert vals.tobytes().hex() == rd["masked"] and remain.tobytes().hex() == rd["remain"]
+    rng = np.random.Generator(np.random.PCG64(8))
+    for dt, n, k in [(np.float32, 2_555_703, 25_557), (np.float64, 300_001, 1), (np.float32, 5000, 5000), (np.float32, 70_000, 69_999)]:
+        layer = rng.standard_normal(n).astype(dt)
+        layer[::97] = layer[5]                       # plenty of exact ties, some at the threshold for small k
+        res = rng.standard_normal(n).astype(dt)
+        loc, vals, new = eng.sparsify(layer, k, res)
+        wl, wv, wr = oracle.sparsify(layer, k, res)
+        assert np.array_equal(loc, wl) and vals.tobytes() == wv.tobytes() and new.tobytes() == wr.tobytes(), (dt, n, k)
+    loc, vals, none = eng.sparsify(np.array([1, -2, 2, 0.5, 2, -1], dtype=np.float32), 2)
+    assert [int(v) for v in loc] == [2, 4] and none is None
+    # the dict-level mirror: two layers, locations bit-packed with total.bit_length() bits
+    from flashe_amd import weights as wz
+    sp = wz.Sparsifier(0.1)
+    w = {"a": rng.standard_normal((30, 10)).astype(np.float32), "b": rng.standard_normal(50).astype(np.float32)}
+    ref = {k: v.copy() for k, v in w.items()}
+    enc, le, bits, total = sp.sparsify(w)
+    assert (le, bits, total) == (30 + 5, (350).bit_length(), 350) and w["a"].shape == (30,) and w["b"].shape == (5,)
+    locs = [int(v) for v in wz.from_big_int(enc, le, bits)]
+    want_a = sorted(np.abs(ref["a"].flatten()).argsort(kind="stable")[-30:].tolist())
+    want_b = sorted((np.abs(ref["b"]).argsort(kind="stable")[-5:] + 300).tolist())
+    assert locs == want_a + want_b
+    assert np.array_equal(w["a"], ref["a"].flatten()[want_a]) and sp.remain_weights["a"][want_a].sum() == 0
+
+
 # ------------------------------------------------------------------ BASELINE full sizes
 def _sum_u64(pts):
     lo = np.zeros_like(pts[0])

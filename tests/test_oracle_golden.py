@@ -211,6 +211,23 @@ def test_quantise_codec(oracle):
         assert got.tobytes() == want.tobytes(), c["element_bits"]
 
 
+def test_sparsify(oracle):
+    """per-layer top-k with residual accumulation, two consecutive rounds."""
+    for c in load_golden("sparsify.json")["cases"]:
+        dt = np.dtype(c["dtype"])
+        remain = np.zeros(c["n"], dtype=dt)
+        for rd in c["rounds"]:
+            layer = np.frombuffer(bytes.fromhex(rd["layer"]), dtype=dt)
+            loc, vals, remain = oracle.sparsify(layer, rd["k"], remain)
+            assert [int(v) for v in loc] == rd["location"]
+            assert vals.tobytes().hex() == rd["masked"] and remain.tobytes().hex() == rd["remain"]
+    # ties at the threshold go to the higher index (stable argsort semantics)
+    layer = np.array([1, -2, 2, 0.5, 2, -1], dtype=np.float32)
+    loc, vals, rem = oracle.sparsify(layer, 2, np.zeros(6, dtype=np.float32))
+    want = sorted(np.abs(layer).argsort(kind="stable")[-2:].tolist())
+    assert [int(v) for v in loc] == want == [2, 4]
+
+
 def test_aesni_and_table_paths_agree(oracle):
     """The AES-NI fast path of the oracle (used for the CPU baseline) against its portable table path."""
     if not oracle.aesni_available():
