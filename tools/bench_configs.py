@@ -135,6 +135,14 @@ def streaming(out):
     p20 = e20.alloc(8 * ((n * 20 + 63) // 64))
     t = timeit(e20, lambda: e20.pack_dev(n, v20, p20))
     res["pack_b20"] = {"ms": t, "TBps": (8 + 2.5) * n / (t * 1e-3) / 1e12}
+    # top-k sparsifier at config-5 size: 25 557 032 float32, k = 1 %
+    nt = 25_557_032
+    xs = eng.upload(rng.standard_normal(nt).astype(np.float32))
+    rs = eng.upload(np.zeros(nt, dtype=np.float32))
+    kk = nt // 100
+    dl, dv = eng.alloc(4 * kk), eng.alloc(4 * kk)
+    t = timeit(eng, lambda: eng.sparsify_dev(nt, kk, xs, False, rs, dl, dv), reps=10)
+    res["sparsify_f32_25M_top1pct"] = {"ms": t, "TBps_algorithmic": (4 * nt * 6 + 8 * nt) / (t * 1e-3) / 1e12}
     out["streaming_kernels_n1e7"] = res
 
 
