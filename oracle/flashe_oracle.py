@@ -131,13 +131,14 @@ def combine(b, inp, add=None, minus=None):
     return out
 
 
-def encrypt(key, it, idx, scheme, n_jobs, b, pt):
-    """scheme: 'single' | 'double'.  pt: uint64 [n] / [n,1] (zero-extended) or [n,L]."""
+def encrypt(key, it, idx, scheme, n_jobs, b, pt, out=None):
+    """scheme: 'single' | 'double'.  pt: uint64 [n] / [n,1] (zero-extended) or [n,L].  out: optional
+    preallocated [n, L] result buffer (the CPU baseline reuses pre-touched buffers)."""
     pt = np.ascontiguousarray(pt, dtype=np.uint64)
     if pt.ndim == 1:
         pt = pt.reshape(-1, 1)
     n = pt.shape[0]
-    ct = np.zeros((n, limbs_of(b)), dtype=np.uint64)
+    ct = np.zeros((n, limbs_of(b)), dtype=np.uint64) if out is None else out
     rc = lib().fo_encrypt(_key(key), ctypes.c_uint32(it), ctypes.c_uint32(idx),
                           ctypes.c_int(1 if scheme == "double" else 0), ctypes.c_uint64(n),
                           ctypes.c_uint32(n_jobs), ctypes.c_int(b), _p64(pt),
@@ -146,13 +147,13 @@ def encrypt(key, it, idx, scheme, n_jobs, b, pt):
     return ct
 
 
-def decrypt(key, it, add_idx, minus_idx, n_jobs, b, ct):
+def decrypt(key, it, add_idx, minus_idx, n_jobs, b, ct, out=None):
     ct = np.ascontiguousarray(ct, dtype=np.uint64)
     if ct.ndim == 1:
         ct = ct.reshape(-1, 1)
     n = ct.shape[0]
     assert ct.shape[1] == limbs_of(b)
-    out = np.zeros_like(ct)
+    out = np.zeros_like(ct) if out is None else out
     aa, pa, ka = _idx(add_idx)
     am, pm, km = _idx(minus_idx)
     rc = lib().fo_decrypt(_key(key), ctypes.c_uint32(it), pa, ctypes.c_int(ka), pm, ctypes.c_int(km),
@@ -176,10 +177,10 @@ def _ptr_table(arrs):
     return arrs, tab
 
 
-def aggregate_elem(cts, b):
+def aggregate_elem(cts, b, out=None):
     arrs, tab = _ptr_table(cts)
     n = arrs[0].shape[0]
-    out = np.zeros((n, limbs_of(b)), dtype=np.uint64)
+    out = np.zeros((n, limbs_of(b)), dtype=np.uint64) if out is None else out
     lib().fo_aggregate_elem(ctypes.c_int(len(arrs)), tab, ctypes.c_uint64(n), ctypes.c_int(b), _p64(out))
     return out
 
