@@ -192,6 +192,19 @@ __device__ __forceinline__ void st128(uint64_t *p, u128 v)
     *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(static_cast<uint64_t>(v), static_cast<uint64_t>(v >> 64));
 }
 
+// streaming (read-once / write-once) forms: keep such traffic out of the caches
+__device__ __forceinline__ u128 ld128_nt(const uint64_t *p)
+{
+    const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(p));
+    return (static_cast<u128>(v[1]) << 64) | v[0];
+}
+__device__ __forceinline__ void st128_nt(uint64_t *p, u128 v)
+{
+    u64x2 r;
+    r[0] = static_cast<uint64_t>(v); r[1] = static_cast<uint64_t>(v >> 64);
+    __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(p));
+}
+
 struct IdxLists {
     uint32_t add[kMaxIdx];
     uint32_t minus[kMaxIdx];
@@ -771,10 +784,10 @@ __global__ __launch_bounds__(kStreamThreads) void combine_wide_kernel(uint64_t n
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
     for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
          j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
-        u128 v = in_limbs == 2 ? ld128(in + 2 * j) : static_cast<u128>(in[j]);
-        if (add) v += ld128(add + 2 * j);
-        if (minus) v -= ld128(minus + 2 * j);
-        st128(out + 2 * j, v & mask);
+        u128 v = in_limbs == 2 ? ld128_nt(in + 2 * j) : static_cast<u128>(__builtin_nontemporal_load(in + j));
+        if (add) v += ld128_nt(add + 2 * j);
+        if (minus) v -= ld128_nt(minus + 2 * j);
+        st128_nt(out + 2 * j, v & mask);
     }
 }
 
