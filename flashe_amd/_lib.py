@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflashe_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("FLASHE_LIB_NAME", "libflashe_hip.so"))
 
 OK = 0
 SCHEME_SINGLE = 0
