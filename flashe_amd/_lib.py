@@ -73,6 +73,8 @@ _SIGNATURES = {
     "flashe_aggregate_elem": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_aggregate_packed_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_u64, c_vp]),
     "flashe_aggregate_packed": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_u64, c_vp]),
+    "flashe_packed_probe_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
+    "flashe_packed_add_carry_dev": (c_int, [c_vp, c_u64, c_u64, c_u64, c_vp]),
     "flashe_pack_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_pack": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_unpack_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),

@@ -676,6 +676,22 @@ int flashe_aggregate_packed_dev(flashe_ctx *ctx, int C, const uint64_t *const *p
     return FLASHE_OK;
 }
 
+int flashe_packed_probe_dev(flashe_ctx *ctx, uint64_t n_limbs, const uint64_t *x_dev, uint64_t *info_dev)
+{
+    CHECK_CTX(ctx);
+    if (!info_dev || n_limbs < 2 || !x_dev) return fail(ctx, FLASHE_EINVAL, "packed_probe: needs a body limb and a carry limb (n_limbs = %llu)", (unsigned long long)n_limbs);
+    HIP_TRY(ctx, launch_packed_probe(ctx->env, n_limbs, x_dev, info_dev));
+    return FLASHE_OK;
+}
+int flashe_packed_add_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t total_bits, uint64_t carry_in, uint64_t *x_dev)
+{
+    CHECK_CTX(ctx);
+    if (n_limbs != (total_bits + 63) / 64) return fail(ctx, FLASHE_EINVAL, "n_limbs must equal ceil(total_bits / 64)");
+    if (n_limbs && !x_dev) return fail(ctx, FLASHE_EINVAL, "null vector");
+    HIP_TRY(ctx, launch_packed_add_carry(ctx->env, n_limbs, total_bits, carry_in, x_dev));
+    return FLASHE_OK;
+}
+
 // ---- codec ----
 int flashe_pack_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
 {

@@ -62,6 +62,11 @@ hipError_t launch_aggregate_packed(const LaunchEnv &env, int C, const uint64_t *
                                    uint64_t n_limbs, uint64_t total_bits, uint64_t *out_dev,
                                    uint32_t *summaries_dev);
 
+// helpers for a packed reduce cut into limb slices across GPUs: (low limb, body-all-ones, carry limb) of a
+// slice sum, and the in-place carry-in ripple
+hipError_t launch_packed_probe(const LaunchEnv &env, uint64_t n_limbs, const uint64_t *x_dev, uint64_t *info_dev);
+hipError_t launch_packed_add_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, uint64_t cin, uint64_t *x_dev);
+
 hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
 hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
 

@@ -223,6 +223,14 @@ class Engine:
         p, _keep = self._ptr_array(packed)
         self._check(self._lib.flashe_aggregate_packed_dev(self._h, len(packed), p, n_limbs, total_bits, self._ptr(out)))
 
+    def packed_probe_dev(self, n_limbs, x, info):
+        """info (device, 3 words) <- (x[0], body limbs [1, n_limbs-1) all ones, x[n_limbs-1]); asynchronous."""
+        self._check(self._lib.flashe_packed_probe_dev(self._h, n_limbs, self._ptr(x), self._ptr(info)))
+
+    def packed_add_carry_dev(self, n_limbs, total_bits, carry_in, x):
+        """x <- (x + carry_in) mod 2^total_bits in place."""
+        self._check(self._lib.flashe_packed_add_carry_dev(self._h, n_limbs, total_bits, carry_in, self._ptr(x)))
+
     def pack_dev(self, n, inp, out):
         self._check(self._lib.flashe_pack_dev(self._h, n, self._ptr(inp), self._ptr(out)))
 

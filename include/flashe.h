@@ -172,6 +172,17 @@ int flashe_aggregate_packed_dev(flashe_ctx *ctx, int C, const uint64_t *const *p
 int flashe_aggregate_packed(flashe_ctx *ctx, int C, const uint64_t *const *packed,
                             uint64_t n_limbs, uint64_t total_bits, uint64_t *out);
 
+/* Slice helpers (new; no reference counterpart): the packed reduce above cut into limb slices
+ * over several GPUs ("packed variant") needs each slice's carry-out and
+ * the one way a carry-in can ripple through a whole slice.
+ * probe: x_dev holds n_limbs - 1 body limbs plus one carry limb (the slice was summed one limb
+ * wider than it is).  info_dev[0] = x[0]; info_dev[1] = 1 iff body limbs [1, n_limbs - 1) are
+ * all ones; info_dev[2] = x[n_limbs - 1].  Asynchronous; info_dev is device memory (24 bytes).
+ * add_carry: x = (x + carry_in) mod 2^total_bits in place, n_limbs = ceil(total_bits / 64). */
+int flashe_packed_probe_dev(flashe_ctx *ctx, uint64_t n_limbs, const uint64_t *x_dev, uint64_t *info_dev);
+int flashe_packed_add_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t total_bits,
+                                uint64_t carry_in, uint64_t *x_dev);
+
 /* ---- bit-packing codec ---------------------------------------------------------------- */
 /* pack: P = sum_j x[j] << (b * (n-1-j)) as ceil(n*b/64) little-endian limbs --
  * _to_bytes / _to_bytes_old + compress(), jzf_weights.py:36-84, :155-195.

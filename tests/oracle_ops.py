@@ -74,3 +74,26 @@ class OracleOps:
         minus = orc.mask_sum(KEY, it, minus_idx, n, n_jobs, self.b)[first:first + count]
         src = np.ascontiguousarray(self._v(inp, in_elem_off + count)[in_elem_off:in_elem_off + count])
         self._v(out, out_elem_off + count)[out_elem_off:out_elem_off + count] = orc.combine(self.b, src, add, minus)
+
+    # ---- packed reduce ----
+    def pack(self, n, src, dst):
+        p = orc.pack(self._v(src, n), self.b)
+        dst.numpy().view(np.uint64)[: len(p)] = p
+
+    def unpack(self, n, src, dst):
+        nl = (n * self.b + 63) // 64
+        self._v(dst, n)[:] = orc.unpack(src.numpy().view(np.uint64)[:nl], n, self.b)
+
+    def aggregate_packed(self, tensors, limb_offsets, n_limbs, total_bits, out):
+        parts = [np.ascontiguousarray(t.numpy().view(np.uint64)[o:o + n_limbs]) for t, o in zip(tensors, limb_offsets)]
+        out.numpy().view(np.uint64)[:n_limbs] = orc.aggregate_packed(parts, total_bits)
+
+    def packed_probe(self, x, n_limbs, info):
+        a = x.numpy().view(np.uint64)
+        i = info.numpy().view(np.uint64)
+        i[0], i[1], i[2] = a[0], int(bool((a[1:n_limbs - 1] == np.uint64(2 ** 64 - 1)).all())), a[n_limbs - 1]
+
+    def packed_add_carry(self, x, n_limbs, total_bits, carry_in):
+        a = x.numpy().view(np.uint64)
+        v = (int.from_bytes(a[:n_limbs].tobytes(), "little") + carry_in) % (1 << total_bits)
+        a[:n_limbs] = np.frombuffer(v.to_bytes(8 * n_limbs, "little"), dtype=np.uint64)

@@ -334,6 +334,56 @@ def test_aggregate_packed_carry_chains(E, oracle):
             assert np.array_equal(eng.aggregate_packed(masked, tb), oracle.aggregate_packed(masked, tb)), (n_limbs, C, top)
 
 
+def test_packed_slice_helpers(E):
+    """flashe_packed_probe_dev / flashe_packed_add_carry_dev (the cross-GPU packed reduce's carry plumbing)
+    against Python integers, including ripples through every limb."""
+    eng = make(E, 64)
+    rng = np.random.Generator(np.random.PCG64(77))
+    ones = np.uint64(2 ** 64 - 1)
+    for n_limbs in (1, 2, 3, 1023, 1024, 1025, 1026, 5000, 300_001):
+        cases = [rng.integers(0, 2 ** 64, n_limbs, dtype=np.uint64), np.full(n_limbs, ones)]
+        part = np.full(n_limbs, ones)
+        part[n_limbs * 2 // 3] = 5                                     # the ripple stops here
+        cases.append(part)
+        for x in cases:
+            for cin in (0, 1, 7, 2 ** 64 - 1):
+                for top in (0, 1, 63):
+                    total_bits = 64 * n_limbs - top
+                    x = x.copy()
+                    if top:
+                        x[-1] &= np.uint64((1 << (64 - top)) - 1)
+                    d = eng.upload(x)
+                    eng.packed_add_carry_dev(n_limbs, total_bits, cin, d)
+                    got = int.from_bytes(d.download(np.uint64, n_limbs).tobytes(), "little")
+                    want = (int.from_bytes(x.tobytes(), "little") + cin) % (1 << total_bits)
+                    assert got == want, (n_limbs, cin, top)
+        if n_limbs >= 2:
+            info = eng.alloc(24)
+            for x in cases:
+                for flip in (None, 1, n_limbs - 2, n_limbs - 1, 0):
+                    y = x.copy()
+                    if flip is not None:
+                        y[flip] = 12345
+                    d = eng.upload(y)
+                    eng.packed_probe_dev(n_limbs, d, info)
+                    low, body_ones, top_limb = (int(v) for v in info.download(np.uint64, 3))
+                    assert low == int(y[0]) and top_limb == int(y[-1])
+                    assert body_ones == int(bool((y[1:n_limbs - 1] == ones).all())), (n_limbs, flip)
+    with pytest.raises(Exception):
+        eng.packed_probe_dev(1, eng.alloc(16), eng.alloc(24))
+    with pytest.raises(Exception):
+        eng.packed_add_carry_dev(3, 64, 1, eng.alloc(32))
+
+
+def test_sharded_round_through_rccl_single_rank():
+    """flashe_amd.dist (element-wise, pipelined and packed rounds) with HipOps + a 1-rank RCCL group."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("b,n", [(128, 50001), (120, 40003), (65, 999), (64, 70001), (33, 12345), (23, 61706),
                                  (20, 100000), (8, 4097), (7, 30000), (1, 10000)])
 def test_pack_unpack_vs_oracle(E, oracle, b, n):
