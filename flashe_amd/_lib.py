@@ -24,6 +24,14 @@ c_u64 = ctypes.c_uint64
 c_size = ctypes.c_size_t
 
 
+class PrfJob(ctypes.Structure):
+    """flashe_prf_job of include/flashe.h."""
+    _fields_ = [("add_idx", ctypes.c_uint32), ("minus_idx", ctypes.c_uint32), ("has_minus", ctypes.c_int32),
+                ("in_limbs", ctypes.c_int32), ("first", ctypes.c_uint64), ("count", ctypes.c_uint64),
+                ("in_dev", ctypes.c_void_p), ("out_dev", ctypes.c_void_p)]
+
+
+
 class FlasheError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"flashe error {code}: {msg}")
@@ -61,6 +69,7 @@ _SIGNATURES = {
     "flashe_mask": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_vp]),
     "flashe_encrypt_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, c_vp]),
     "flashe_encrypt": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, c_vp]),
+    "flashe_prf_jobs_dev": (c_int, [c_vp, c_u32, c_u64, c_u32, c_int, ctypes.POINTER(PrfJob)]),
     "flashe_encrypt_batch_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp)]),
     "flashe_decrypt_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
     "flashe_decrypt": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),

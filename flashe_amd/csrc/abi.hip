@@ -540,6 +540,41 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
     return FLASHE_OK;
 }
 
+int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_jobs, int n_entries, const flashe_prf_job *entries)
+{
+    CHECK_CTX(ctx);
+    if (n_entries < 0 || (n_entries && !entries)) return fail(ctx, FLASHE_EINVAL, "bad job list");
+    if (n_entries == 0) return FLASHE_OK;
+    const int dbl = entries[0].has_minus;
+    for (int e = 0; e < n_entries; e++) {
+        const flashe_prf_job &j = entries[e];
+        if (j.has_minus != dbl || (dbl != 0 && dbl != 1)) return fail(ctx, FLASHE_EINVAL, "entry %d: has_minus must be 0 or 1 and equal across the call", e);
+        if (j.first > n || j.count > n - j.first) return fail(ctx, FLASHE_EINVAL, "entry %d: range exceeds n", e);
+        if (j.count && !j.out_dev) return fail(ctx, FLASHE_EINVAL, "entry %d: null output", e);
+        int rc = check_prf_args(ctx, 1, dbl, n_jobs, j.out_dev, j.in_dev, j.in_dev ? j.in_limbs : 0);
+        if (rc) return rc;
+    }
+    const bool one_launch = ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE);
+    if (!one_launch) {
+        for (int e = 0; e < n_entries; e++) {
+            const flashe_prf_job &j = entries[e];
+            HIP_TRY(ctx, launch_prf(ctx->env, iter, &j.add_idx, 1, &j.minus_idx, dbl, n, n_jobs, j.first, j.count, j.in_dev,
+                                    j.in_dev ? j.in_limbs : 0, j.out_dev));
+        }
+        return FLASHE_OK;
+    }
+    for (int e0 = 0; e0 < n_entries; e0 += kMaxBatch) {
+        PrfJob jobs[kMaxBatch];
+        const int ne = std::min(kMaxBatch, n_entries - e0);
+        for (int e = 0; e < ne; e++) {
+            const flashe_prf_job &j = entries[e0 + e];
+            jobs[e] = PrfJob{j.add_idx, j.minus_idx, j.first, j.count, j.in_dev, j.in_limbs, j.out_dev};
+        }
+        HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, dbl != 0, ne, jobs, n));
+    }
+    return FLASHE_OK;
+}
+
 int flashe_decrypt_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
                        uint64_t n, uint32_t n_jobs, const uint64_t *in_dev, uint64_t *out_dev)
 {

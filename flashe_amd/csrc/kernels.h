@@ -44,6 +44,17 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
                             const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n,
                             uint32_t n_jobs);
 
+// General form of the batched launch (b > 64 only): out[k] = in[k] + term(iter, add_idx, first + k)
+// - [dbl] term(iter, minus_idx, first + k) for k < count; in_dev may be null (zeros); pointers address element `first`.
+struct PrfJob {
+    uint32_t add_idx, minus_idx;
+    uint64_t first, count;
+    const uint64_t *in_dev;
+    int in_limbs;
+    uint64_t *out_dev;
+};
+hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n);
+
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
                           const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);
 

@@ -392,9 +392,20 @@ struct BatchTable {
     uint64_t *out[kMaxBatch];
 };
 
+// One launch = up to kMaxBatch jobs; job v covers global elements [first, first + count) of an n-element
+// vector: out[k] = in[k] + term(iter, add, first + k) - [DBL] term(iter, minus, first + k), in = 0 when null.
+// encrypt: (idx, idx + 1, pt); telescoped decrypt: (C, 0, aggregate); mask precompute: in = null.
+struct JobTable {
+    uint32_t add[kMaxBatch], minus[kMaxBatch];
+    uint64_t first[kMaxBatch], count[kMaxBatch], tile_end[kMaxBatch];   // tile_end: running total of tiles
+    const uint64_t *in[kMaxBatch];
+    uint64_t *out[kMaxBatch];
+    uint8_t in_limbs[kMaxBatch];
+};
+
 template <bool DBL, int THREADS, int PRIO>
-__global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const BatchTable tb, int n_vec, uint64_t n,
-                                                                     uint32_t iter, int in_limbs, uint64_t mask_lo, uint64_t mask_hi,
+__global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const JobTable tb, int n_vec, uint64_t n,
+                                                                     uint32_t iter, uint64_t mask_lo, uint64_t mask_hi,
                                                                      const uint32_t *te0)
 {
     __shared__ uint32_t tab[kTabWords];
@@ -402,23 +413,24 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
     if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
-    const uint64_t tiles_per_vec = (n + THREADS - 1) / THREADS;
-    const uint64_t total_tiles = tiles_per_vec * static_cast<uint64_t>(n_vec);
+    const uint64_t total_tiles = tb.tile_end[n_vec - 1];
     const bool ctr_fast = ((n - 1) >> 32) == 0;
-    int cur = -1;
+    int cur = -1, v = 0;
+    uint64_t tile0 = 0;                                                  // first tile of job v
     CtrPrefix pre_a{}, pre_b{};
     for (uint64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-        const int v = static_cast<int>(t / tiles_per_vec);              // wave-uniform
-        const uint64_t j = (t - static_cast<uint64_t>(v) * tiles_per_vec) * THREADS + threadIdx.x;
-        const uint32_t ia = tb.idx[v];
+        while (t >= tb.tile_end[v]) tile0 = tb.tile_end[v++];            // wave-uniform, t only grows
+        const uint64_t k = (t - tile0) * THREADS + threadIdx.x;
+        const uint32_t ia = tb.add[v], im = tb.minus[v];
         if (v != cur && ctr_fast) {
             pre_a = ctr_prefix(rk, lr, iter, ia, 0u);
-            if (DBL) pre_b = ctr_prefix(rk, lr, iter, ia + 1u, 0u);
+            if (DBL) pre_b = ctr_prefix(rk, lr, iter, im, 0u);
             cur = v;
         }
-        if (j >= n) continue;
+        if (k >= tb.count[v]) continue;
+        const uint64_t j = tb.first[v] + k;
         const uint64_t *in = tb.in[v];
-        u128 acc = in_limbs == 2 ? ld128(in + 2 * j) : static_cast<u128>(in[j]);
+        u128 acc = !in ? static_cast<u128>(0) : tb.in_limbs[v] == 2 ? ld128(in + 2 * k) : static_cast<u128>(in[k]);
         uint32_t s[DBL ? 2 : 1][4];
         if (ctr_fast) {
             const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(j));
@@ -427,12 +439,12 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
             aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
         } else {
             set_block(s[0], iter, ia, j);
-            if (DBL) set_block(s[DBL ? 1 : 0], iter, ia + 1u, j);
+            if (DBL) set_block(s[DBL ? 1 : 0], iter, im, j);
             aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
         }
         acc += words_to_u128(s[0]);
         if (DBL) acc -= words_to_u128(s[DBL ? 1 : 0]);
-        st128(tb.out[v] + 2 * j, acc & mask);
+        st128(tb.out[v] + 2 * k, acc & mask);
     }
 }
 
@@ -814,16 +826,38 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
         else hipLaunchKernelGGL(prf_small_batch_kernel<false>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, n_vec, p);
         return hipGetLastError();
     }
+    PrfJob jobs[kMaxBatch];
+    for (int v = 0; v < n_vec; v++)
+        jobs[v] = PrfJob{idx[v], idx[v] + 1u, 0, n, in_dev[v], in_limbs, out_dev[v]};
+    return launch_prf_jobs(env, iter, dbl, n_vec, jobs, n);
+}
+
+hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n)
+{
+    if (n_entries > kMaxBatch || env.b <= 64) return hipErrorInvalidValue;
+    JobTable tb{};
+    uint64_t tiles = 0;
+    int nv = 0;
+    for (int e = 0; e < n_entries; e++) {
+        if (jobs[e].count == 0) continue;
+        tb.add[nv] = jobs[e].add_idx; tb.minus[nv] = jobs[e].minus_idx;
+        tb.first[nv] = jobs[e].first; tb.count[nv] = jobs[e].count;
+        tb.in[nv] = jobs[e].in_dev; tb.out[nv] = jobs[e].out_dev; tb.in_limbs[nv] = static_cast<uint8_t>(jobs[e].in_limbs);
+        tiles += (jobs[e].count + kPrfThreads - 1) / kPrfThreads;
+        tb.tile_end[nv++] = tiles;
+    }
+    if (nv == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
     // measured on MI355X: 1024-thread workgroups beat 768 / 512 (2.71 vs 2.87 / 2.99 ms for ten
     // 1e7-element vectors) and raising the wave priority costs ~1 %
-    const uint64_t tiles = ((n + kPrfThreads - 1) / kPrfThreads) * static_cast<uint64_t>(n_vec);
     const int grid = static_cast<int>(tiles < static_cast<uint64_t>(env.num_cus) ? tiles : env.num_cus);
     if (dbl)
         hipLaunchKernelGGL((prf_wide_batch_kernel<true, kPrfThreads, 0>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb,
-                           n_vec, n, iter, in_limbs, lo, hi, env.te0_dev);
+                           nv, n, iter, lo, hi, env.te0_dev);
     else
         hipLaunchKernelGGL((prf_wide_batch_kernel<false, kPrfThreads, 0>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb,
-                           n_vec, n, iter, in_limbs, lo, hi, env.te0_dev);
+                           nv, n, iter, lo, hi, env.te0_dev);
     return hipGetLastError();
 }
 

@@ -82,13 +82,16 @@ class HipOps:
         off = first * self.engine.limbs * 8
         self.engine.decrypt_range_dev(it, add_idx, minus_idx, n, n_jobs, first, count, inp.data_ptr() + off, out.data_ptr() + off)
 
-    def aggregate_slices_side(self, buf, buf_elem_off, n_slices, slice_elems, out, out_elem_off):
-        """N-way mod-add of the equally sized pieces received by one chunk's all-to-all (side stream)."""
+    def aggregate_slices_side(self, buf, buf_elem_off, n_slices, slice_elems, out, out_elem_off, extra=None):
+        """N-way mod-add of the equally sized pieces received by one chunk's all-to-all (side stream);
+        extra = (tensor, elem_offset) is one more operand (the precomputed decrypt mask difference)."""
         eng = self.side if self.side is not None else self.engine
         L = eng.limbs
         base = buf.data_ptr() + buf_elem_off * L * 8
-        eng.aggregate_elem_dev([base + g * slice_elems * L * 8 for g in range(n_slices)], slice_elems,
-                               out.data_ptr() + out_elem_off * L * 8)
+        ptrs = [base + g * slice_elems * L * 8 for g in range(n_slices)]
+        if extra is not None:
+            ptrs.append(extra[0].data_ptr() + extra[1] * L * 8)
+        eng.aggregate_elem_dev(ptrs, slice_elems, out.data_ptr() + out_elem_off * L * 8)
 
     def decrypt_range_side(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, in_elem_off, out, out_elem_off):
         eng = self.side if self.side is not None else self.engine
@@ -117,6 +120,13 @@ class HipOps:
 
     def decrypt_range(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, out):
         self.engine.decrypt_range_dev(it, add_idx, minus_idx, n, n_jobs, first, count, inp.data_ptr(), out.data_ptr())
+
+    def prf_jobs(self, it, n, n_jobs, jobs):
+        """jobs: (add_idx, minus_idx, first, count, in_tensor or None, in_word_offset, in_limbs, out_tensor, out_word_offset);
+        one launch for all of them (flashe_prf_jobs_dev)."""
+        self.engine.prf_jobs_dev(it, n, n_jobs, [
+            (a, m, first, count, None if t_in is None else t_in.data_ptr() + 8 * o_in, in_limbs, t_out.data_ptr() + 8 * o_out)
+            for a, m, first, count, t_in, o_in, in_limbs, t_out, o_out in jobs])
 
     # ---- packed reduce (the arbiter's one-big-integer add, jzf_aggregator.py:406-419) ----
     def pack(self, n, src, dst):
@@ -263,6 +273,58 @@ class ShardedRound:
                 cnt = max(0, min(chunk, n - first))
                 if cnt:
                     ops.decrypt_range_at(it, add_idx, minus_idx, n, self.n_jobs, first, cnt, self.p_partial, self.p_result)
+        return self.p_result
+
+    def run_fused(self, it, pts, pt_limbs, chunks=4, launch_events=None):
+        """Double mask, nobody dropped.  Per chunk, ONE launch on the main stream does all the mask arithmetic:
+        the local clients' encrypts of the chunk plus D = term(iter, C) - term(iter, 0) on the piece of the
+        chunk this rank publishes -- the reference's prepare_decrypt (jzf_flashe.py:633-666), kept as the
+        fused difference.  The side stream then only runs HBM-bound adds and the exchange: the reduce takes D
+        as one more operand, so what it writes IS the plaintext aggregate (decrypt's `value + add - minus`,
+        :570-571).  Chunk q's reduce / exchange hides under chunk q + 1's launch.  Same results as run().
+        launch_events: optional list of `chunks` entries, each None or a (start, stop) engine event pair that
+        brackets that chunk's launch."""
+        assert self.scheme == SCHEME_DOUBLE, "run_fused needs the double mask (one add / one minus prefix)"
+        ops, n, L, W = self.ops, self.n, self.L, self.world
+        self._pipe_buffers(chunks)
+        sub, chunk = self.p_sub, self.p_chunk
+        if getattr(self, "p_dmask", None) is None or self.p_dmask.numel() != (chunks * sub * L if self.exchange else self.p_partial.numel()):
+            self.p_dmask = torch.zeros(chunks * sub * L if self.exchange else self.p_partial.numel(), dtype=torch.int64,
+                                       device=self.partial.device)
+        C, base = self.total_clients(), self.rank * self.cpr
+        for q in range(chunks):
+            first = q * chunk
+            cnt = max(0, min(chunk, n - first))
+            jobs = [(base + c, base + c + 1, first, cnt, pts[c], first * pt_limbs, pt_limbs, self.ct[c], first * L)
+                    for c in range(self.cpr)]
+            if self.exchange:
+                gfirst = min(first + self.rank * sub, n)
+                jobs.append((C, 0, gfirst, max(0, min(sub, n - gfirst)), None, 0, 0, self.p_dmask, q * sub * L))
+            else:
+                jobs.append((C, 0, first, cnt, None, 0, 0, self.p_dmask, first * L))
+            ev = launch_events[q] if launch_events else None
+            if ev:
+                ops.engine.record(ev[0])
+            ops.prf_jobs(it, n, self.n_jobs, jobs)
+            if ev:
+                ops.engine.record(ev[1])
+            ops.signal(f"enc{q}")
+            ops.wait(f"enc{q}", on_side=True)
+            if not self.exchange:
+                if cnt:
+                    ops.aggregate_range(self.ct + [self.p_dmask], first, cnt, self.p_result)
+            else:
+                if cnt:
+                    ops.aggregate_range(self.ct, first, cnt, self.p_partial)
+                blk = slice(first * L, (first + chunk) * L)
+                with ops.on_side():
+                    dist.all_to_all_single(self.p_recv[blk], self.p_partial[blk], group=self.group)
+                ops.aggregate_slices_side(self.p_recv, first, W, sub, self.p_dec, q * sub, extra=(self.p_dmask, q * sub))
+                with ops.on_side():
+                    dist.all_gather_into_tensor(self.p_result[blk], self.p_dec[q * sub * L:(q + 1) * sub * L], group=self.group)
+            ops.signal(f"done{q}", on_side=True)
+        for q in range(chunks):
+            ops.wait(f"done{q}")
         return self.p_result
 
     def _packed_buffers(self):

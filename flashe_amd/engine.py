@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import SCHEME_DOUBLE, SCHEME_SINGLE, FlasheError, c_int, c_u32, c_u32p, c_u64, c_u64p, c_vp
+from ._lib import SCHEME_DOUBLE, SCHEME_SINGLE, FlasheError, PrfJob, c_int, c_u32, c_u32p, c_u64, c_u64p, c_vp
 
 __all__ = ["Engine", "DeviceBuffer", "limbs_of", "SCHEME_SINGLE", "SCHEME_DOUBLE", "FlasheError",
            "chunks", "telescope", "prp_block"]
@@ -187,6 +187,17 @@ class Engine:
         pp, _a = self._ptr_array(pts)
         pc, _b = self._ptr_array(cts)
         self._check(self._lib.flashe_encrypt_batch_dev(self._h, it, scheme, n, n_jobs, len(idx_list), pi, pp, pt_limbs, pc))
+
+    def prf_jobs_dev(self, it, n, n_jobs, jobs):
+        """jobs: iterable of (add_idx, minus_idx or None, first, count, in_ptr or None, in_limbs, out_ptr); each writes
+        out[k] = in[k] + term(it, add_idx, first + k) - term(it, minus_idx, first + k) for k < count (one launch for
+        int_bits > 64).  Pointers address element `first`."""
+        jobs = list(jobs)
+        arr = (PrfJob * max(len(jobs), 1))()
+        for e, (a, m, first, count, inp, in_limbs, out) in enumerate(jobs):
+            arr[e] = PrfJob(a, 0 if m is None else m, 0 if m is None else 1, in_limbs, first, count,
+                            None if inp is None else self._ptr(inp), self._ptr(out))
+        self._check(self._lib.flashe_prf_jobs_dev(self._h, it, n, n_jobs, len(jobs), arr))
 
     def decrypt_dev(self, it, add_idx, minus_idx, n, n_jobs, inp, out):
         pa, _a = _u32_list(add_idx)

@@ -124,6 +124,28 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
 int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
                              const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev);
 
+/* General batched form (new): every entry is one piece of mask arithmetic on elements
+ * [first, first + count) of an n-element vector,
+ *     out[k] = in[k] + term(iter, add_idx, first + k) - [has_minus] term(iter, minus_idx, first + k)   mod 2^b,
+ * with in = 0 when in_dev is NULL; in_dev / out_dev address element `first`.  It covers, with one
+ * launch for many entries (b > 64; entry by entry otherwise):
+ *   FlasheCipher.encrypt (double)     add = idx, minus = idx + 1, in = plaintext   jzf_flashe.py:349-353, :480-481
+ *   FlasheCipher.encrypt (single)     add = idx, has_minus = 0                     :308-309, :450-451
+ *   decrypt, nobody dropped           add = num_clients, minus = 0, in = aggregate :633-666, :570-571
+ *   prepare_encrypt / prepare_decrypt the same with in_dev = NULL (the cached add - minus) :599-666
+ * All entries of one call must agree on has_minus. */
+typedef struct flashe_prf_job {
+    uint32_t add_idx;
+    uint32_t minus_idx;
+    int32_t has_minus;       /* 0 or 1 */
+    int32_t in_limbs;        /* limbs per input element: 1 (uint64, zero-extended) or L; ignored when in_dev is NULL */
+    uint64_t first, count;
+    const uint64_t *in_dev;
+    uint64_t *out_dev;
+} flashe_prf_job;
+int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_jobs,
+                        int n_entries, const flashe_prf_job *entries);
+
 /* FlasheCipher.decrypt -- jzf_flashe.py:584-594 -> _multiprocessing_decrypt (:537-582) /
  * _multiprocessing_decrypt_single (:506-535) with the prefix lists set_idx_list derived
  * (:356-386; single: :311-314 with n_add = 0):

@@ -44,11 +44,15 @@ def main():
             want_packed = orc.combine(b, orc.unpack(agg_packed, n, b), add, minus)
             for force in (True, False):
                 rnd = ShardedRound(HipOps(eng, side, side_stream), n, b, C, J, device, scheme=scheme, force_collectives=force)
-                for mode in ("run", "pipe", "packed"):
+                for mode in ("run", "pipe", "fused", "packed"):
+                    if mode == "fused" and scheme != SCHEME_DOUBLE:
+                        continue
                     if mode == "run":
                         out = rnd.run(4, pts, 1)
                     elif mode == "pipe":
                         out = rnd.run_pipelined(4, pts, 1, chunks=3)
+                    elif mode == "fused":
+                        out = rnd.run_fused(4, pts, 1, chunks=3)
                     else:
                         out = rnd.run_packed(4, pts, 1)
                     torch.cuda.synchronize()

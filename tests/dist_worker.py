@@ -93,8 +93,10 @@ def main():
             want += p
         if b < 64:
             want &= np.uint64((1 << b) - 1)
-        for mode, chunks in (("run", 0), ("pipe", 4), ("pipe", 3)):
-            out = rnd.run(5, mine, 1) if mode == "run" else rnd.run_pipelined(5, mine, 1, chunks=chunks)
+        for mode, chunks in (("run", 0), ("pipe", 4), ("pipe", 3), ("fused", 4), ("fused", 1), ("fused", 5)):
+            if mode == "fused" and scheme != SCHEME_DOUBLE:
+                continue
+            out = rnd.run(5, mine, 1) if mode == "run" else (rnd.run_pipelined if mode == "pipe" else rnd.run_fused)(5, mine, 1, chunks=chunks)
             res = out.numpy().view(np.uint64)[: n * L].reshape(n, L)
             assert np.array_equal(res[:, 0], want), (rank, b, n, mode, chunks)
             if L == 2:

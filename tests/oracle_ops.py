@@ -64,9 +64,11 @@ class OracleOps:
         import contextlib
         return contextlib.nullcontext()
 
-    def aggregate_slices_side(self, buf, buf_elem_off, n_slices, slice_elems, out, out_elem_off):
+    def aggregate_slices_side(self, buf, buf_elem_off, n_slices, slice_elems, out, out_elem_off, extra=None):
         full = self._v(buf, buf_elem_off + n_slices * slice_elems)
         parts = [np.ascontiguousarray(full[buf_elem_off + g * slice_elems: buf_elem_off + (g + 1) * slice_elems]) for g in range(n_slices)]
+        if extra is not None:
+            parts.append(np.ascontiguousarray(self._v(extra[0], extra[1] + slice_elems)[extra[1]:extra[1] + slice_elems]))
         self._v(out, out_elem_off + slice_elems)[out_elem_off:out_elem_off + slice_elems] = orc.aggregate_elem(parts, self.b)
 
     def decrypt_range_side(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, in_elem_off, out, out_elem_off):
@@ -97,3 +99,15 @@ class OracleOps:
         a = x.numpy().view(np.uint64)
         v = (int.from_bytes(a[:n_limbs].tobytes(), "little") + carry_in) % (1 << total_bits)
         a[:n_limbs] = np.frombuffer(v.to_bytes(8 * n_limbs, "little"), dtype=np.uint64)
+
+    def prf_jobs(self, it, n, n_jobs, jobs):
+        for a, m, first, count, t_in, o_in, in_limbs, t_out, o_out in jobs:
+            if count == 0:
+                continue
+            add = orc.mask(KEY, it, a, n, n_jobs, self.b)[first:first + count]
+            minus = orc.mask(KEY, it, m, n, n_jobs, self.b)[first:first + count] if m is not None else None
+            if t_in is None:
+                inp = np.zeros((count, self.L), dtype=np.uint64)
+            else:
+                inp = t_in.numpy().view(np.uint64)[o_in:o_in + count * in_limbs].reshape(count, in_limbs)
+            t_out.numpy().view(np.uint64)[o_out:o_out + count * self.L] = orc.combine(self.b, inp, add, minus).reshape(-1)

@@ -31,8 +31,8 @@ def test_pipelined_single_rank_schedule(oracle):
         want = np.zeros(n, dtype=np.uint64)
         for p in pts:
             want += p
-        for mode in ("run", "pipe"):
+        for mode in ("run", "pipe", "fused"):
             rnd = ShardedRound(OracleOps(b), n, b, cpr, 16, "cpu")
-            res = rnd.run(3, tens, 1) if mode == "run" else rnd.run_pipelined(3, tens, 1, chunks=chunks)
+            res = rnd.run(3, tens, 1) if mode == "run" else (rnd.run_pipelined if mode == "pipe" else rnd.run_fused)(3, tens, 1, chunks=chunks)
             got = res.numpy().view(np.uint64)[: n * L].reshape(n, L)
             assert np.array_equal(got[:, 0], want), (b, n, mode)

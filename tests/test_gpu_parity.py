@@ -280,6 +280,57 @@ def test_encrypt_batch_equals_single_calls(E, oracle):
             assert np.array_equal(got, oracle.encrypt(KEY, 9, idx[v], name, 16, b, pts[v])), (b, n, v)
 
 
+@pytest.mark.parametrize("b,n,J", [(128, 70_001, 16), (100, 5000, 3), (64, 30_000, 16), (20, 9999, 7)])
+def test_prf_jobs_vs_oracle(E, oracle, b, n, J):
+    """flashe_prf_jobs_dev: encrypt, telescoped decrypt and bare mask-difference entries with ragged ranges in one call."""
+    eng = make(E, b)
+    Lb = L(b)
+    rng = np.random.Generator(np.random.PCG64(b + n))
+    pt = rng.integers(0, 2 ** min(b, 64), n, dtype=np.uint64)
+    agg = rand_limbs(rng, n, b)
+    dpt, dagg = eng.upload(pt), eng.upload(agg)
+    masks = {i: oracle.mask(KEY, 6, i, n, J, b) for i in (0, 3, 4, 9, 10)}
+
+    def want(add, minus, first, count, inp):
+        z = np.zeros((count, Lb), dtype=np.uint64)
+        a = masks[add][first:first + count]
+        m = masks[minus][first:first + count] if minus is not None else z
+        return oracle.combine(b, inp[first:first + count] if inp is not None else z, a, m)
+
+    pt_l = np.zeros((n, Lb), dtype=np.uint64)
+    pt_l[:, 0] = pt
+    for has_minus in (True, False):
+        spec = [(3, 4, 0, n, "pt"), (10, 0, 0, n, "agg"), (10, 0, 0, n, None), (9, 10, 1025, n - 2000, "pt"), (3, 4, n - 1, 1, "agg"),
+                (3, 4, 17, 0, "pt"), (0, 3, 1, 1023, None)]
+        outs, jobs = [], []
+        for add, minus, first, count, src in spec:
+            minus = minus if has_minus else None
+            o = eng.alloc_vec(max(count, 1))
+            outs.append(o)
+            if src == "pt":
+                jobs.append((add, minus, first, count, dpt.ptr + 8 * first, 1, o))
+            elif src == "agg":
+                jobs.append((add, minus, first, count, dagg.ptr + 8 * Lb * first, Lb, o))
+            else:
+                jobs.append((add, minus, first, count, None, 0, o))
+        eng.prf_jobs_dev(6, n, J, jobs)
+        for (add, minus, first, count, src), o in zip(spec, outs):
+            if count == 0:
+                continue
+            got = o.download(np.uint64, count * Lb).reshape(count, Lb)
+            ref = want(add, minus if has_minus else None, first, count, {"pt": pt_l, "agg": agg, None: None}[src])
+            assert np.array_equal(got, ref), (b, has_minus, add, first, count, src)
+    # more entries than one launch holds
+    many = [(3, 4, 64 * e, 100 + e, None, 0, eng.alloc_vec(200)) for e in range(40)]
+    eng.prf_jobs_dev(6, n, J, many)
+    for e, job in enumerate(many):
+        assert np.array_equal(job[6].download(np.uint64, (100 + e) * Lb).reshape(-1, Lb), want(3, 4, 64 * e, 100 + e, None)), e
+    with pytest.raises(Exception):
+        eng.prf_jobs_dev(6, n, J, [(3, 4, 0, 10, None, 0, many[0][6]), (3, None, 0, 10, None, 0, many[1][6])])   # mixed has_minus
+    with pytest.raises(Exception):
+        eng.prf_jobs_dev(6, n, J, [(3, 4, n - 5, 10, None, 0, many[0][6])])                                        # range past n
+
+
 def test_u64_plaintext_zero_extension(E, oracle):
     rng = np.random.Generator(np.random.PCG64(3))
     eng = make(E, 128)

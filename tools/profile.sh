@@ -4,7 +4,7 @@
 # Raw output -> gpurun_out/prof/<tag>/ ; summarise with tools/summarize_profile.py.
 set -u
 TAG=${1:-r01}
-STEPS=${2:-5}
+STEPS=${2:-20}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"

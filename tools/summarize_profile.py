@@ -67,9 +67,19 @@ def main(tag):
     if dom and "FETCH_SIZE" in out[dom]:
         f, w = out[dom]["FETCH_SIZE"], out[dom]["WRITE_SIZE"]
         per_launch = (2 * f["avg"] + w["avg"]) * 1024
-        vectors = round(w["avg"] * 1024 / 160e6) or 1                     # each client vector writes n * 16 B = 160 MB
+        # algorithmic bytes per launch as the profiled bench run itself reported them
+        alg = None
+        for log in ("pmc_fetch.log", "trace.log"):
+            try:
+                for line in open(os.path.join(src, log)):
+                    if line.startswith('{"metric'):
+                        alg = json.loads(line)["roofline"]["algorithmic_bytes_per_launch"]
+            except OSError:
+                pass
+            if alg:
+                break
         traffic = {"tag": tag, "kernel": dom, "dominant_kernel_hbm_bytes_per_launch": per_launch,
-                   "client_vectors_per_launch": vectors, "encrypt_hbm_bytes_per_vector": per_launch / vectors,
+                   "algorithmic_bytes_per_launch": alg, "hbm_bytes_per_algorithmic_byte": per_launch / alg if alg else None,
                    "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the default bench command; "
                           "bytes = (2 * FETCH_SIZE[KiB] + WRITE_SIZE[KiB]) * 1024 (gfx950 FETCH_SIZE counts 64 B per 128-B "
                           "request, MI355X_MICROARCH.md HBM section), averaged over the kernel's launches",
