@@ -245,8 +245,13 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
     }
     ctx->env.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->env.b = int_bits;
-    if ((e = hipMalloc(&ctx->te0_dev, 1024)) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(te0)", e);
-    if ((e = hipMemcpy(ctx->te0_dev, aes_tables().te0, 1024, hipMemcpyHostToDevice)) != hipSuccess)
+    // Te0 followed by Te1..Te3 (byte rotations of Te0): 4 KiB; the kernels fill LDS from the first KiB and use the
+    // whole table for wave-uniform lookups through the scalar cache
+    uint32_t te4[1024];
+    for (int t = 0; t < 4; t++)
+        for (int x = 0; x < 256; x++) te4[256 * t + x] = t ? ror(aes_tables().te0[x], 8 * t) : aes_tables().te0[x];
+    if ((e = hipMalloc(&ctx->te0_dev, sizeof(te4))) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(te0)", e);
+    if ((e = hipMemcpy(ctx->te0_dev, te4, sizeof(te4), hipMemcpyHostToDevice)) != hipSuccess)
         return bail(FLASHE_EIO, "hipMemcpy(te0)", e);
     ctx->env.te0_dev = ctx->te0_dev;
     if ((e = hipMalloc(&ctx->rkw_dev, 256)) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(rkw)", e);

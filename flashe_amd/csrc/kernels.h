@@ -12,7 +12,7 @@ struct RoundKeys { uint32_t w[60]; };
 struct LaunchEnv {
     hipStream_t stream;
     int num_cus;
-    const uint32_t *te0_dev;   // 256-entry Te0 table in device memory (1 KiB)
+    const uint32_t *te0_dev;   // Te0 | Te1 | Te2 | Te3, 256 entries each, in device memory (4 KiB)
     const uint32_t *rkw_dev;   // the 60 expanded key words in device memory (scalar-loaded per round by the bit-sliced PRF)
     const uint32_t *rkp_dev;   // packed key planes for the 16-blocks-per-lane bit-sliced PRF: 15 x 64 words
     RoundKeys rk;

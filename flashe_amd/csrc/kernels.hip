@@ -73,6 +73,9 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
     return LaneRegs{lane4, lane4 | 0x00010000u, (const lds_u8 *)(lds_u32 *)tab};
 }
 
+#ifndef FLASHE_CTR2
+#define FLASHE_CTR2 1   // wave-uniform part of rounds 1-2 through the scalar cache
+#endif
 #ifndef FLASHE_SWP
 #define FLASHE_SWP 1   // two-block calls run software pipelined (measured 4.6 % faster than the compiler's own order)
 #endif
@@ -242,6 +245,44 @@ __device__ __forceinline__ void ctr_round1(const CtrPrefix &c, const CtrVar &x, 
     s[0] = c.u[0] ^ x.v[0]; s[1] = c.u[1] ^ x.v[1]; s[2] = c.u[2] ^ x.v[2]; s[3] = c.u[3] ^ x.v[3];
 }
 
+// Second step of the CTR shortcut.  With 64 consecutive counters per wave (and a wave base that is a
+// multiple of 64) bytes 1..3 of the low counter word are wave-uniform, so after round 1 only state
+// column 0 differs between lanes, and in round 2 every output column has ONE lane-dependent lookup (a
+// byte of column 0) and three wave-uniform ones.  The uniform part goes through the scalar cache (te4 =
+// Te0|Te1|Te2|Te3 in global memory, SGPR indices) instead of the LDS: per block 4.5 LDS lookups for
+// rounds 1-2 instead of 18.
+struct CtrUniform { uint32_t u[4]; };
+
+__device__ __forceinline__ CtrPrefix scalar_prefix(const CtrPrefix &c)
+{
+    return CtrPrefix{{static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(c.u[0])), static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(c.u[1])),
+                      static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(c.u[2])), static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(c.u[3]))}};
+}
+
+// x3 = (wave's counter base) ^ rk.w[3]; only its bytes 1..3 are used.
+__device__ __forceinline__ CtrUniform ctr_uniform(const RoundKeys &rk, const uint32_t *__restrict__ te4, const CtrPrefix &c, uint32_t x3)
+{
+    const uint32_t S1 = c.u[1] ^ te4[512 + ((x3 >> 8) & 0xffu)];
+    const uint32_t S2 = c.u[2] ^ te4[256 + ((x3 >> 16) & 0xffu)];
+    const uint32_t S3 = c.u[3] ^ te4[x3 >> 24];
+    CtrUniform r;
+    r.u[0] = te4[256 + ((S1 >> 16) & 0xffu)] ^ te4[512 + ((S2 >> 8) & 0xffu)] ^ te4[768 + (S3 & 0xffu)] ^ rk.w[8];
+    r.u[1] = te4[S1 >> 24] ^ te4[256 + ((S2 >> 16) & 0xffu)] ^ te4[512 + ((S3 >> 8) & 0xffu)] ^ rk.w[9];
+    r.u[2] = te4[S2 >> 24] ^ te4[256 + ((S3 >> 16) & 0xffu)] ^ te4[768 + (S1 & 0xffu)] ^ rk.w[10];
+    r.u[3] = te4[S3 >> 24] ^ te4[512 + ((S1 >> 8) & 0xffu)] ^ te4[768 + (S2 & 0xffu)] ^ rk.w[11];
+    return r;
+}
+
+// State after round 2: v0 = T3[b0(ctr_lo ^ rk.w[3])] (shared by the blocks of one element), c0 = c.u[0].
+__device__ __forceinline__ void ctr_round2(const LaneRegs lr, uint32_t c0, uint32_t v0, const CtrUniform &U, uint32_t (&s)[4])
+{
+    const uint32_t s0 = c0 ^ v0;
+    s[0] = U.u[0] ^ T0(s0, SEL_B3);
+    s[1] = U.u[1] ^ T3(s0, SEL_B0);
+    s[2] = U.u[2] ^ T2(s0, SEL_B1);
+    s[3] = U.u[3] ^ T1(s0, SEL_B2);
+}
+
 __device__ __forceinline__ u128 words_to_u128(const uint32_t (&s)[4])
 {
     const uint64_t hi = (static_cast<uint64_t>(s[0]) << 32) | s[1];
@@ -300,23 +341,14 @@ struct PrfParams {
 };
 
 // ---- b > 64: one element per lane, counter = element index (m = 1 makes chunks irrelevant) ----
-// MODE 0: generic prefix lists; 1: one add + one minus (encrypt double, no-dropout decrypt);
-// 2: one add, no minus (encrypt single, single mask stream).
-template <int MODE>
+// Generic prefix lists (dropout decrypts, single-mask decrypts).  One add and at most one minus prefix -- every
+// encrypt, the no-dropout decrypt, the mask streams -- go through prf_wide_batch_kernel below.
 __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys rk, const PrfParams p, const IdxLists lists)
 {
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, p.te0);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(p.mask_hi) << 64) | p.mask_lo;
-    // lane-invariant part of round 1 (valid when the launch stays inside one 2^32 counter window)
-    const uint32_t ctr_hi = static_cast<uint32_t>(p.first >> 32);
-    const bool ctr_fast = MODE != 0 && ((p.first + p.count - 1) >> 32) == (p.first >> 32);
-    CtrPrefix pre_a{}, pre_b{};
-    if (ctr_fast) {
-        pre_a = ctr_prefix(rk, lr, p.iter, lists.add[0], ctr_hi);
-        if (MODE == 1) pre_b = ctr_prefix(rk, lr, p.iter, lists.minus[0], ctr_hi);
-    }
 
     for (uint64_t base = static_cast<uint64_t>(blockIdx.x) * kPrfThreads; base < p.count;
          base += static_cast<uint64_t>(gridDim.x) * kPrfThreads) {
@@ -325,31 +357,7 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
         const uint64_t j = p.first + e;                 // global element = PRF counter (m = 1)
         u128 acc = 0;
         if (p.in) acc = p.in_limbs == 2 ? ld128(p.in + 2 * e) : static_cast<u128>(p.in[e]);
-        if (MODE == 1) {
-            uint32_t s[2][4];
-            if (ctr_fast) {
-                const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(j));
-                ctr_round1(pre_a, x, s[0]);
-                ctr_round1(pre_b, x, s[1]);
-                aes256_rounds<2, 2>(rk, lr, s);
-            } else {
-                set_block(s[0], p.iter, lists.add[0], j);
-                set_block(s[1], p.iter, lists.minus[0], j);
-                aes256_encrypt<2>(rk, lr, s);
-            }
-            acc += words_to_u128(s[0]);
-            acc -= words_to_u128(s[1]);
-        } else if (MODE == 2) {
-            uint32_t s[1][4];
-            if (ctr_fast) {
-                ctr_round1(pre_a, ctr_var(rk, lr, static_cast<uint32_t>(j)), s[0]);
-                aes256_rounds<1, 2>(rk, lr, s);
-            } else {
-                set_block(s[0], p.iter, lists.add[0], j);
-                aes256_encrypt<1>(rk, lr, s);
-            }
-            acc += words_to_u128(s[0]);
-        } else {
+        {
             int k = 0;
             for (; k + 1 < p.n_add; k += 2) {
                 uint32_t s[2][4];
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
     }
 }
 
-// ---- batched form of prf_wide_kernel<1/2>: n_vec independent vectors in one launch ----
+// ---- one add / at most one minus prefix: many independent jobs in one launch ----
 struct BatchTable {
     uint32_t idx[kMaxBatch];
     const uint64_t *in[kMaxBatch];
@@ -395,56 +403,100 @@ struct BatchTable {
 // One launch = up to kMaxBatch jobs; job v covers global elements [first, first + count) of an n-element
 // vector: out[k] = in[k] + term(iter, add, first + k) - [DBL] term(iter, minus, first + k), in = 0 when null.
 // encrypt: (idx, idx + 1, pt); telescoped decrypt: (C, 0, aggregate); mask precompute: in = null.
+// Tiling: job v starts with big[v] BIG tiles (THREADS * 4 elements; every wave walks 4 x 64 consecutive elements, so
+// its 256 counters share bytes 1..3 and the wave-uniform part of rounds 1-2 is computed once per 256 elements) and
+// finishes with SMALL tiles (THREADS elements).  Tile index space of the launch: all big tiles of all jobs, then all
+// small tiles; workgroup i takes tiles i, i + grid, ...  The host makes the number of big tiles a multiple of the
+// grid, so every workgroup gets the same number of them and the remainder is balanced in units of 1024 elements.
 struct JobTable {
     uint32_t add[kMaxBatch], minus[kMaxBatch];
-    uint64_t first[kMaxBatch], count[kMaxBatch], tile_end[kMaxBatch];   // tile_end: running total of tiles
+    uint64_t first[kMaxBatch], count[kMaxBatch];
+    uint64_t big_end[kMaxBatch], small_end[kMaxBatch];      // running totals of big / small tiles
     const uint64_t *in[kMaxBatch];
     uint64_t *out[kMaxBatch];
     uint8_t in_limbs[kMaxBatch];
 };
+constexpr int kBigEpl = 4;
 
 template <bool DBL, int THREADS, int PRIO>
 __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const JobTable tb, int n_vec, uint64_t n,
                                                                      uint32_t iter, uint64_t mask_lo, uint64_t mask_hi,
-                                                                     const uint32_t *te0)
+                                                                     const uint32_t *__restrict__ te0)
 {
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, te0);
     if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
-    const uint64_t total_tiles = tb.tile_end[n_vec - 1];
-    const bool ctr_fast = ((n - 1) >> 32) == 0;
+    const uint64_t n_big = tb.big_end[n_vec - 1], total_tiles = n_big + tb.small_end[n_vec - 1];
+    const uint32_t wave64 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
+    const uint32_t lane = threadIdx.x & 63u;
     int cur = -1, v = 0;
-    uint64_t tile0 = 0;                                                  // first tile of job v
+    bool in_small = false;
+    uint64_t tile0 = 0;                                                  // first tile (of the current kind) of job v
     CtrPrefix pre_a{}, pre_b{};
     for (uint64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-        while (t >= tb.tile_end[v]) tile0 = tb.tile_end[v++];            // wave-uniform, t only grows
-        const uint64_t k = (t - tile0) * THREADS + threadIdx.x;
+        // locate the tile: wave-uniform, and t only grows
+        uint64_t kw;                                                     // first element of this wave's share
+        int epl;
+        if (t < n_big) {
+            while (t >= tb.big_end[v]) tile0 = tb.big_end[v++];
+            epl = kBigEpl;
+            kw = (t - tile0) * (THREADS * kBigEpl) + wave64 * kBigEpl;
+        } else {
+            if (!in_small) { in_small = true; v = 0; tile0 = 0; }
+            const uint64_t ts = t - n_big;
+            while (ts >= tb.small_end[v]) tile0 = tb.small_end[v++];
+            const uint64_t big_v = tb.big_end[v] - (v ? tb.big_end[v - 1] : 0);
+            epl = 1;
+            kw = big_v * (THREADS * kBigEpl) + (ts - tile0) * THREADS + wave64;
+        }
         const uint32_t ia = tb.add[v], im = tb.minus[v];
+        const uint64_t count = tb.count[v], first = tb.first[v];
+        // the shortcuts need the job to stay inside one 2^32 counter window (only the low counter word varies)
+        const bool ctr_fast = ((first + count - 1) >> 32) == (first >> 32);
         if (v != cur && ctr_fast) {
-            pre_a = ctr_prefix(rk, lr, iter, ia, 0u);
-            if (DBL) pre_b = ctr_prefix(rk, lr, iter, im, 0u);
+            pre_a = scalar_prefix(ctr_prefix(rk, lr, iter, ia, static_cast<uint32_t>(first >> 32)));
+            if (DBL) pre_b = scalar_prefix(ctr_prefix(rk, lr, iter, im, static_cast<uint32_t>(first >> 32)));
             cur = v;
         }
-        if (k >= tb.count[v]) continue;
-        const uint64_t j = tb.first[v] + k;
+        if (kw >= count) continue;
         const uint64_t *in = tb.in[v];
-        u128 acc = !in ? static_cast<u128>(0) : tb.in_limbs[v] == 2 ? ld128(in + 2 * k) : static_cast<u128>(in[k]);
-        uint32_t s[DBL ? 2 : 1][4];
-        if (ctr_fast) {
-            const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(j));
-            ctr_round1(pre_a, x, s[0]);
-            if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
-            aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
-        } else {
-            set_block(s[0], iter, ia, j);
-            if (DBL) set_block(s[DBL ? 1 : 0], iter, im, j);
-            aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
+        uint64_t *out = tb.out[v];
+        const int in_limbs = tb.in_limbs[v];
+        // wave-uniform part of rounds 1-2: valid while the wave's 256 counters share bytes 1..3
+        const bool uni = FLASHE_CTR2 && epl == kBigEpl && ctr_fast && ((first + kw) & 255u) == 0;
+        CtrUniform Ua{}, Ub{};
+        if (uni) {
+            const uint32_t x3 = static_cast<uint32_t>(first + kw) ^ rk.w[3];
+            Ua = ctr_uniform(rk, te0, pre_a, x3);
+            if (DBL) Ub = ctr_uniform(rk, te0, pre_b, x3);
         }
-        acc += words_to_u128(s[0]);
-        if (DBL) acc -= words_to_u128(s[DBL ? 1 : 0]);
-        st128(tb.out[v] + 2 * k, acc & mask);
+        for (int e = 0; e < epl; e++) {
+            const uint64_t k = kw + static_cast<uint64_t>(e) * 64u + lane;
+            if (k >= count) break;
+            const uint64_t j = first + k;
+            u128 acc = !in ? static_cast<u128>(0) : in_limbs == 2 ? ld128(in + 2 * k) : static_cast<u128>(in[k]);
+            uint32_t s[DBL ? 2 : 1][4];
+            if (uni) {
+                const uint32_t v0 = T3(static_cast<uint32_t>(j) ^ rk.w[3], SEL_B0);
+                ctr_round2(lr, pre_a.u[0], v0, Ua, s[0]);
+                if (DBL) ctr_round2(lr, pre_b.u[0], v0, Ub, s[DBL ? 1 : 0]);
+                aes256_rounds<DBL ? 2 : 1, 3>(rk, lr, s);
+            } else if (ctr_fast) {
+                const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(j));
+                ctr_round1(pre_a, x, s[0]);
+                if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
+                aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
+            } else {
+                set_block(s[0], iter, ia, j);
+                if (DBL) set_block(s[DBL ? 1 : 0], iter, im, j);
+                aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
+            }
+            acc += words_to_u128(s[0]);
+            if (DBL) acc -= words_to_u128(s[DBL ? 1 : 0]);
+            st128(out + 2 * k, acc & mask);
+        }
     }
 }
 
@@ -789,14 +841,12 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
         else
             hipLaunchKernelGGL(prf_wide_bs_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kBsThreads), 0, env.stream,
                                env.rkw_dev, p, lists.add[0], 0u);
+    } else if (bs_shape) {
+        const PrfJob job{lists.add[0], lists.minus[0], first, count, in_dev, in_limbs, out_dev};
+        return launch_prf_jobs(env, iter, n_minus == 1, 1, &job, n);
     } else if (env.b > 64) {
         const int grid = grid_for(env, count, kPrfThreads);
-        if (n_add == 1 && n_minus == 1)
-            hipLaunchKernelGGL(prf_wide_kernel<1>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);
-        else if (n_add == 1 && n_minus == 0)
-            hipLaunchKernelGGL(prf_wide_kernel<2>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);
-        else
-            hipLaunchKernelGGL(prf_wide_kernel<0>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);
+        hipLaunchKernelGGL(prf_wide_kernel, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);
     } else {
         p.blk_first = block_of(first, n, n_jobs, p.m);
         p.blk_count = block_of(first + count - 1, n, n_jobs, p.m) - p.blk_first + 1;
@@ -836,22 +886,39 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
 {
     if (n_entries > kMaxBatch || env.b <= 64) return hipErrorInvalidValue;
     JobTable tb{};
-    uint64_t tiles = 0;
     int nv = 0;
+    uint64_t big[kMaxBatch];
+    uint64_t n_big = 0;
+    constexpr uint64_t kBigTile = static_cast<uint64_t>(kPrfThreads) * kBigEpl;
     for (int e = 0; e < n_entries; e++) {
         if (jobs[e].count == 0) continue;
         tb.add[nv] = jobs[e].add_idx; tb.minus[nv] = jobs[e].minus_idx;
         tb.first[nv] = jobs[e].first; tb.count[nv] = jobs[e].count;
         tb.in[nv] = jobs[e].in_dev; tb.out[nv] = jobs[e].out_dev; tb.in_limbs[nv] = static_cast<uint8_t>(jobs[e].in_limbs);
-        tiles += (jobs[e].count + kPrfThreads - 1) / kPrfThreads;
-        tb.tile_end[nv++] = tiles;
+        big[nv] = jobs[e].count / kBigTile;
+        n_big += big[nv++];
     }
     if (nv == 0) return hipSuccess;
+    // whole rounds of big tiles only: the big tiles beyond a multiple of the grid become small ones (taken from the
+    // last jobs), so that no workgroup is left with a 4096-element tile more than the others
+    const uint64_t cus = static_cast<uint64_t>(env.num_cus);
+    uint64_t excess = n_big % cus;
+    for (int v = nv - 1; v >= 0 && excess; v--) {
+        const uint64_t take = big[v] < excess ? big[v] : excess;
+        big[v] -= take; excess -= take;
+    }
+    uint64_t be = 0, se = 0;
+    for (int v = 0; v < nv; v++) {
+        be += big[v];
+        se += (tb.count[v] - big[v] * kBigTile + kPrfThreads - 1) / kPrfThreads;
+        tb.big_end[v] = be; tb.small_end[v] = se;
+    }
+    const uint64_t tiles = be + se;
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
     // measured on MI355X: 1024-thread workgroups beat 768 / 512 (2.71 vs 2.87 / 2.99 ms for ten
     // 1e7-element vectors) and raising the wave priority costs ~1 %
-    const int grid = static_cast<int>(tiles < static_cast<uint64_t>(env.num_cus) ? tiles : env.num_cus);
+    const int grid = static_cast<int>(tiles < cus ? tiles : cus);
     if (dbl)
         hipLaunchKernelGGL((prf_wide_batch_kernel<true, kPrfThreads, 0>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb,
                            nv, n, iter, lo, hi, env.te0_dev);

@@ -30,7 +30,7 @@ from .engine import SCHEME_DOUBLE, limbs_of, telescope
 
 __all__ = ["HipOps", "ShardedRound", "slice_len"]
 
-ALIGN = 64          # slice boundaries are multiples of this many elements
+ALIGN = 256         # slice and chunk boundaries are multiples of this many elements (256 consecutive PRF counters share 3 bytes)
 
 
 def slice_len(n, world):

@@ -28,7 +28,18 @@ for rep in range(5):
     for _ in range(5): eng.encrypt_batch_dev(0, list(range(C)), SCHEME_DOUBLE, n, 16, pts, 1, cts)
     eng.record(e1)
     best = min(best, eng.elapsed_ms(e0, e1) / 5)
-print("%%.4f" %% best)
+def timeit(fn, inner):
+    b = 1e9
+    for rep in range(5):
+        eng.record(e0)
+        for _ in range(inner): fn()
+        eng.record(e1)
+        b = min(b, eng.elapsed_ms(e0, e1) / inner)
+    return b
+one = timeit(lambda: eng.encrypt_dev(0, 3, SCHEME_DOUBLE, n, 16, pts[3], 1, cts[3]), 10)
+q = 2_500_032
+rng = timeit(lambda: eng.encrypt_range_dev(0, 3, SCHEME_DOUBLE, n, 16, q, q, pts[3].ptr + 8 * q, 1, cts[3].ptr + 16 * q), 20)
+print("%%.4f  one vector %%.4f  range of 2.5M %%.4f" %% (best, one, rng))
 ''' % ROOT
 
 
@@ -41,7 +52,7 @@ def main():
             env[var] = v
             out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
             res = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "ERR " + out.stderr[-300:]
-            print(f"round {rnd}  {var}={v}: {res} ms per 10-vector launch")
+            print(f"round {rnd}  {var}={v}: {res} (ms per 10-vector launch, per single-vector launch, per 2.5M-element range launch)")
 
 
 if __name__ == "__main__":

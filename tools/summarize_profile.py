@@ -61,9 +61,8 @@ def main(tag):
             e["effective_clock_ghz"] = e["GRBM_GUI_ACTIVE"]["avg"] / 8 / (sum(dur[k]) / len(dur[k]))
         out[k] = e
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
-    # the dominant kernel of the default (pipelined) schedule is the batched encrypt; the same kernel body also
-    # runs as prf_wide_kernel<1> for the last client's chunks and the decrypt
-    dom = next((k for k in out if "prf_wide_batch_kernel" in k), None) or next((k for k in out if "prf_wide_kernel<1>" in k), None)
+    # the dominant kernel is the job-list PRF kernel (batched encrypts, chunked encrypt / decrypt launches)
+    dom = next((k for k in out if "prf_wide_batch_kernel" in k), None)
     if dom and "FETCH_SIZE" in out[dom]:
         f, w = out[dom]["FETCH_SIZE"], out[dom]["WRITE_SIZE"]
         per_launch = (2 * f["avg"] + w["avg"]) * 1024
