@@ -45,8 +45,10 @@ def parse():
     ap.add_argument("--pipeline-chunks", type=int, default=4,
                     help="> 0: everything after the last client's encrypt (reduce, exchange, decrypt) runs chunk by chunk on "
                          "a side stream under it; 0: sequential phases")
-    ap.add_argument("--schedule", choices=["auto", "fused", "pipelined", "sequential"], default="auto",
-                    help="auto: fused or pipelined, whichever is faster in a short untimed calibration on this box; "
+    ap.add_argument("--schedule", choices=["default", "auto", "fused", "pipelined", "sequential"], default="default",
+                    help="default: pipelined on one GPU, fused when ranks exchange (what measurements favour; deterministic, so "
+                         "a profile of the run shows one launch shape per kernel); auto: fused or pipelined, whichever is "
+                         "faster in a short untimed calibration on this box; "
                          "fused: per chunk one launch does every local encrypt plus the decrypt mask difference, the reduce "
                          "(which then yields the plaintext aggregate) and the exchange hide under the next chunk's launch; "
                          "pipelined: last client's encrypt chunked, reduce / exchange / decrypt on a side stream; sequential: phases")
@@ -222,7 +224,11 @@ def main():
         # parity gate before any timing counts: decrypted aggregate == plaintext sum (mod 2^b).  A schedule is
         # used only if it passes; otherwise fall back to the next simpler one.
         order = ["fused", "pipelined", "sequential"]
-        start = "fused" if args.schedule == "auto" else args.schedule
+        start = args.schedule
+        if start == "auto":
+            start = "fused"
+        elif start == "default":
+            start = "fused" if rnd.exchange else "pipelined"
         if start == "fused" and b <= 64:
             start = "pipelined"              # the one-launch job list needs b > 64
         candidates = order[order.index(start):] if side is not None else ["sequential"]
@@ -314,13 +320,13 @@ def main():
             elems = n / Q
             alg_bytes = elems * (C * (pt_bytes + 8 * L) + 8 * L)
             blocks = 2 * (C + 1) * elems
-            kernel_name = (f"prf_wide_batch_kernel<true,1024,0> (fused AES-256 PRF x2 + 128-bit add/sub: {C} client encrypts + "
+            kernel_name = (f"prf_wide_batch_kernel<true,1024,1> (fused AES-256 PRF x2 + 128-bit add/sub: {C} client encrypts + "
                            f"decrypt mask difference on 1/{Q} of the vector per launch)")
         else:
             vec_per_launch = (C - 1) if (schedule == "pipelined" and C > 1) else 1
             alg_bytes = vec_per_launch * n * (pt_bytes + 8 * L)   # u64 plaintext in + L-limb ciphertext out, per vector
             blocks = 2 * n * vec_per_launch
-            kernel_name = ("prf_wide_batch_kernel<true,1024,0> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt, "
+            kernel_name = ("prf_wide_batch_kernel<true,1024,1> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt, "
                            f"{vec_per_launch} client vectors per launch)") if vec_per_launch > 1 else \
                 "prf_wide_batch_kernel<true,1024,0> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt, one client vector per launch)"
         achieved = alg_bytes / (enc_avg_ms * 1e-3) / 1e9

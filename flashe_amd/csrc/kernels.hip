@@ -418,14 +418,15 @@ struct JobTable {
 };
 constexpr int kBigEpl = 4;
 
-template <bool DBL, int THREADS, int PRIO>
+// MULTI only names the instantiation (1 = a launch with several jobs, 0 = one job), so that profiles list the
+// batched launches and the single-vector / chunk launches as separate kernels.
+template <bool DBL, int THREADS, int MULTI>
 __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const JobTable tb, int n_vec, uint64_t n,
                                                                      uint32_t iter, uint64_t mask_lo, uint64_t mask_hi,
                                                                      const uint32_t *__restrict__ te0)
 {
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, te0);
-    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
     const uint64_t n_big = tb.big_end[n_vec - 1], total_tiles = n_big + tb.small_end[n_vec - 1];
@@ -917,14 +918,14 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
     // measured on MI355X: 1024-thread workgroups beat 768 / 512 (2.71 vs 2.87 / 2.99 ms for ten
-    // 1e7-element vectors) and raising the wave priority costs ~1 %
+    // 1e7-element vectors) and raising the wave priority (s_setprio) costs ~1 %
     const int grid = static_cast<int>(tiles < cus ? tiles : cus);
-    if (dbl)
-        hipLaunchKernelGGL((prf_wide_batch_kernel<true, kPrfThreads, 0>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb,
-                           nv, n, iter, lo, hi, env.te0_dev);
-    else
-        hipLaunchKernelGGL((prf_wide_batch_kernel<false, kPrfThreads, 0>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb,
-                           nv, n, iter, lo, hi, env.te0_dev);
+#define JOBS_LAUNCH(DBL, MULTI)                                                                                              \
+    hipLaunchKernelGGL((prf_wide_batch_kernel<DBL, kPrfThreads, MULTI>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, \
+                       nv, n, iter, lo, hi, env.te0_dev)
+    if (dbl) { if (nv > 1) JOBS_LAUNCH(true, 1); else JOBS_LAUNCH(true, 0); }
+    else { if (nv > 1) JOBS_LAUNCH(false, 1); else JOBS_LAUNCH(false, 0); }
+#undef JOBS_LAUNCH
     return hipGetLastError();
 }
 
