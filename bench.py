@@ -46,12 +46,13 @@ def parse():
                     help="> 0: everything after the last client's encrypt (reduce, exchange, decrypt) runs chunk by chunk on "
                          "a side stream under it; 0: sequential phases")
     ap.add_argument("--schedule", choices=["default", "auto", "fused", "pipelined", "sequential"], default="default",
-                    help="default: pipelined on one GPU, fused when ranks exchange (what measurements favour; deterministic, so "
-                         "a profile of the run shows one launch shape per kernel); auto: fused or pipelined, whichever is "
-                         "faster in a short untimed calibration on this box; "
+                    help="default: sequential (two launches) on one GPU, fused when ranks exchange (the three schedules are within "
+                         "~1.5 %% of each other on one GPU; deterministic, so a profile of the run shows one launch shape per "
+                         "kernel); auto: fused or pipelined, whichever is faster in a short untimed calibration on this box; "
                          "fused: per chunk one launch does every local encrypt plus the decrypt mask difference, the reduce "
                          "(which then yields the plaintext aggregate) and the exchange hide under the next chunk's launch; "
-                         "pipelined: last client's encrypt chunked, reduce / exchange / decrypt on a side stream; sequential: phases")
+                         "pipelined: last client's encrypt chunked, reduce / exchange / decrypt on a side stream; "
+                         "sequential: all local encrypts in one launch, then reduce (+ exchange) fused with the decrypt")
     ap.add_argument("--force-dist", action="store_true",
                     help="with 1 GPU: still create the RCCL process group and run the N > 1 exchange path (world size 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -174,7 +175,7 @@ def main():
         # HIP events on the engine's stream: per dominant launch + per phase
         Q = max(args.pipeline_chunks, 1)
         enc_ev = [(eng.event(), eng.event()) for _ in range(K * max(C, Q))]
-        ph_ev = [[eng.event() for _ in range(4)] for _ in range(K)]
+        ph_ev = [[eng.event() for _ in range(3)] for _ in range(K)]
 
         def run_schedule(schedule, it, k=None):
             """One round.  k = index of the timed step (events recorded) or None (warmup / parity run)."""
@@ -189,16 +190,10 @@ def main():
                     return rnd.run(it, pts, 1)
                 # same sequence as ShardedRound.run, with event brackets around the launches
                 eng.record(ph_ev[k][0])
-                for c in range(C):
-                    e0, e1 = enc_ev[k * C + c]
-                    eng.record(e0)
-                    ops.encrypt(it, rank * C + c, SCHEME_DOUBLE, n, args.n_jobs, pts[c], 1, rnd.ct[c])
-                    eng.record(e1)
+                rnd.encrypt_phase(it, pts, 1)              # one launch: every local client's encrypt
                 eng.record(ph_ev[k][1])
-                rnd.aggregate_phase()
+                res = rnd.reduce_decrypt_phase(it)         # reduce (+ exchange) fused with the decrypt of its result
                 eng.record(ph_ev[k][2])
-                res = rnd.decrypt_phase(it)
-                eng.record(ph_ev[k][3])
                 return res
 
         lo = np.zeros(n, dtype=np.uint64)
@@ -228,7 +223,7 @@ def main():
         if start == "auto":
             start = "fused"
         elif start == "default":
-            start = "fused" if rnd.exchange else "pipelined"
+            start = "fused" if rnd.exchange else "sequential"
         if start == "fused" and b <= 64:
             start = "pipelined"              # the one-launch job list needs b > 64
         candidates = order[order.index(start):] if side is not None else ["sequential"]
@@ -305,9 +300,9 @@ def main():
             # pair per round around it
             enc_ev = enc_ev[:K] if C > 1 else []
         else:
-            enc_ev = enc_ev[:K * C]
+            enc_ev = [(p[0], p[1]) for p in ph_ev]      # the batched encrypt launch of every timed round
         enc_ms = [eng.elapsed_ms(e0, e1) for e0, e1 in enc_ev]
-        ph = np.array([[eng.elapsed_ms(p[i], p[i + 1]) for i in range(3)] for p in ph_ev]) if schedule == "sequential" else None
+        ph = np.array([[eng.elapsed_ms(p[i], p[i + 1]) for i in range(2)] for p in ph_ev]) if schedule == "sequential" else None
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / K
@@ -323,7 +318,7 @@ def main():
             kernel_name = (f"prf_wide_batch_kernel<true,1024,1> (fused AES-256 PRF x2 + 128-bit add/sub: {C} client encrypts + "
                            f"decrypt mask difference on 1/{Q} of the vector per launch)")
         else:
-            vec_per_launch = (C - 1) if (schedule == "pipelined" and C > 1) else 1
+            vec_per_launch = (C - 1) if (schedule == "pipelined" and C > 1) else C
             alg_bytes = vec_per_launch * n * (pt_bytes + 8 * L)   # u64 plaintext in + L-limb ciphertext out, per vector
             blocks = 2 * n * vec_per_launch
             kernel_name = ("prf_wide_batch_kernel<true,1024,1> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt, "
@@ -352,7 +347,7 @@ def main():
                        "schedule": {"fused": f"{Q} chunks; per chunk one launch = all local encrypts + decrypt mask difference; reduce "
                                              "(-> plaintext aggregate) and exchange hidden on a side stream",
                                     "pipelined": f"reduce / exchange / decrypt chunk-pipelined on a side stream ({Q} chunks)",
-                                    "sequential": "sequential phases"}[schedule],
+                                    "sequential": "two launches: all local encrypts, then reduce fused with decrypt"}[schedule],
                        "schedule_calibration_ms": calibration,
                        "parity": "bit-exact (checked in-run)"},
             "roofline": {"kernel": kernel_name,
@@ -369,8 +364,7 @@ def main():
                          "note": "integer path: the kernel is AES(LDS/VALU)-rate bound, HBM fraction reported as required"},
             "phases_ms": ({"round": ms_per_step, "note": "phases overlap in this schedule"}
                           if pipelined else
-                          {"encrypt_xC": float(ph[:, 0].mean()), "aggregate": float(ph[:, 1].mean()),
-                           "decrypt": float(ph[:, 2].mean())}),
+                          {"encrypt_xC": float(ph[:, 0].mean()), "reduce_plus_decrypt": float(ph[:, 1].mean())}),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, host_pts)

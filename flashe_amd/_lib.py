@@ -28,7 +28,8 @@ class PrfJob(ctypes.Structure):
     """flashe_prf_job of include/flashe.h."""
     _fields_ = [("add_idx", ctypes.c_uint32), ("minus_idx", ctypes.c_uint32), ("has_minus", ctypes.c_int32),
                 ("in_limbs", ctypes.c_int32), ("first", ctypes.c_uint64), ("count", ctypes.c_uint64),
-                ("in_dev", ctypes.c_void_p), ("out_dev", ctypes.c_void_p)]
+                ("in_dev", ctypes.c_void_p), ("out_dev", ctypes.c_void_p), ("n_in", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("in_stride", ctypes.c_uint64), ("sum_out_dev", ctypes.c_void_p)]
 
 
 
@@ -80,6 +81,8 @@ _SIGNATURES = {
     "flashe_combine": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
     "flashe_aggregate_elem_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_aggregate_elem": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
+    "flashe_aggregate_decrypt_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_int,
+                                                   ctypes.POINTER(c_vp), c_vp, c_vp]),
     "flashe_aggregate_packed_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_u64, c_vp]),
     "flashe_aggregate_packed": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_u64, c_vp]),
     "flashe_packed_probe_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),

@@ -556,6 +556,10 @@ int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_j
         if (j.has_minus != dbl || (dbl != 0 && dbl != 1)) return fail(ctx, FLASHE_EINVAL, "entry %d: has_minus must be 0 or 1 and equal across the call", e);
         if (j.first > n || j.count > n - j.first) return fail(ctx, FLASHE_EINVAL, "entry %d: range exceeds n", e);
         if (j.count && !j.out_dev) return fail(ctx, FLASHE_EINVAL, "entry %d: null output", e);
+        if (j.reserved) return fail(ctx, FLASHE_EINVAL, "entry %d: reserved field must be 0", e);
+        if (j.n_in > 1 && (ctx->limbs != 2 || !j.in_dev || j.in_limbs != 2 || j.n_in > 255 || !aligned16(j.in_dev + 2 * j.in_stride) ||
+                           (j.sum_out_dev && !aligned16(j.sum_out_dev))))
+            return fail(ctx, FLASHE_EINVAL, "entry %d: a summed input needs int_bits > 64, 2-limb 16-byte aligned vectors and n_in <= 255", e);
         int rc = check_prf_args(ctx, 1, dbl, n_jobs, j.out_dev, j.in_dev, j.in_dev ? j.in_limbs : 0);
         if (rc) return rc;
     }
@@ -563,6 +567,7 @@ int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_j
     if (!one_launch) {
         for (int e = 0; e < n_entries; e++) {
             const flashe_prf_job &j = entries[e];
+            if (j.n_in > 1) return fail(ctx, FLASHE_EINVAL, "entry %d: summed inputs need the table PRF backend", e);
             HIP_TRY(ctx, launch_prf(ctx->env, iter, &j.add_idx, 1, &j.minus_idx, dbl, n, n_jobs, j.first, j.count, j.in_dev,
                                     j.in_dev ? j.in_limbs : 0, j.out_dev));
         }
@@ -573,7 +578,8 @@ int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_j
         const int ne = std::min(kMaxBatch, n_entries - e0);
         for (int e = 0; e < ne; e++) {
             const flashe_prf_job &j = entries[e0 + e];
-            jobs[e] = PrfJob{j.add_idx, j.minus_idx, j.first, j.count, j.in_dev, j.in_limbs, j.out_dev};
+            jobs[e] = PrfJob{j.add_idx, j.minus_idx, j.first, j.count, j.in_dev, j.in_limbs, j.out_dev,
+                             j.n_in ? j.n_in : 1u, j.in_stride * 2, j.n_in > 1 ? j.sum_out_dev : nullptr};
         }
         HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, dbl != 0, ne, jobs, n));
     }
@@ -677,6 +683,47 @@ int flashe_aggregate_elem_dev(flashe_ctx *ctx, int C, const uint64_t *const *cts
         HIP_TRY(ctx, launch_aggregate_elem(ctx->env, static_cast<int>(ops.size()), ops.data(), n, out_dev));
     }
     return FLASHE_OK;
+}
+
+int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx,
+                                       int n_minus, uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count, int C,
+                                       const uint64_t *const *cts_dev, uint64_t *agg_out_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (C < 1 || !cts_dev || (count && !out_dev)) return fail(ctx, FLASHE_EINVAL, "aggregate_decrypt: bad arguments (C = %d)", C);
+    int rc = check_range(ctx, n, first, count);
+    if (rc) return rc;
+    if (count == 0) return FLASHE_OK;
+    for (int c = 0; c < C; c++)
+        if (!cts_dev[c]) return fail(ctx, FLASHE_EINVAL, "operand %d is null", c);
+    // one pass when the ciphertexts are equally spaced (ascending), one add and at most one minus prefix, b > 64
+    bool strided = ctx->limbs == 2 && n_add == 1 && n_minus <= 1 && C <= 255 &&
+                   (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE) && aligned16(cts_dev[0]) && aligned16(out_dev) &&
+                   aligned16(agg_out_dev);
+    uint64_t stride = 0;
+    if (strided && C > 1) {
+        if (cts_dev[1] <= cts_dev[0]) strided = false;
+        else {
+            stride = static_cast<uint64_t>(cts_dev[1] - cts_dev[0]);
+            for (int c = 2; c < C && strided; c++) strided = cts_dev[c] == cts_dev[0] + stride * c;
+            strided = strided && stride % 2 == 0;
+        }
+    }
+    if (strided) {
+        const PrfJob job{add_idx[0], n_minus ? minus_idx[0] : 0u, first, count, cts_dev[0], 2, out_dev,
+                         static_cast<uint32_t>(C), stride, agg_out_dev};
+        HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, n_minus == 1, 1, &job, n));
+        return FLASHE_OK;
+    }
+    uint64_t *agg = agg_out_dev;
+    if (!agg) {
+        rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, count));
+        if (rc) return rc;
+        agg = static_cast<uint64_t *>(ctx->stream_tmp.p);
+    }
+    rc = flashe_aggregate_elem_dev(ctx, C, cts_dev, count, agg);
+    if (rc) return rc;
+    return flashe_decrypt_range_dev(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, first, count, agg, out_dev);
 }
 
 int flashe_aggregate_packed_dev(flashe_ctx *ctx, int C, const uint64_t *const *packed_dev, uint64_t n_limbs, uint64_t total_bits,

@@ -73,6 +73,9 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
     return LaneRegs{lane4, lane4 | 0x00010000u, (const lds_u8 *)(lds_u32 *)tab};
 }
 
+#ifndef FLASHE_NT_SUM
+#define FLASHE_NT_SUM 1   // read-once operands of the fused reduce bypass the caches
+#endif
 #ifndef FLASHE_CTR2
 #define FLASHE_CTR2 1   // wave-uniform part of rounds 1-2 through the scalar cache
 #endif
@@ -414,7 +417,9 @@ struct JobTable {
     uint64_t big_end[kMaxBatch], small_end[kMaxBatch];      // running totals of big / small tiles
     const uint64_t *in[kMaxBatch];
     uint64_t *out[kMaxBatch];
-    uint8_t in_limbs[kMaxBatch];
+    uint64_t in_stride[kMaxBatch];      // limbs between the n_in input vectors of a summed input
+    uint64_t *sum_out[kMaxBatch];       // optional: where the summed input goes
+    uint8_t in_limbs[kMaxBatch], n_in[kMaxBatch];
 };
 constexpr int kBigEpl = 4;
 
@@ -465,6 +470,9 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
         const uint64_t *in = tb.in[v];
         uint64_t *out = tb.out[v];
         const int in_limbs = tb.in_limbs[v];
+        const int n_in = tb.n_in[v];
+        const uint64_t in_stride = tb.in_stride[v];
+        uint64_t *sum_out = tb.sum_out[v];
         // wave-uniform part of rounds 1-2: valid while the wave's 256 counters share bytes 1..3
         const bool uni = FLASHE_CTR2 && epl == kBigEpl && ctr_fast && ((first + kw) & 255u) == 0;
         CtrUniform Ua{}, Ub{};
@@ -478,6 +486,17 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
             if (k >= count) break;
             const uint64_t j = first + k;
             u128 acc = !in ? static_cast<u128>(0) : in_limbs == 2 ? ld128(in + 2 * k) : static_cast<u128>(in[k]);
+            if (n_in > 1) {                     // the reduce fused in: sum of n_in vectors (wave-uniform trip count)
+#if FLASHE_NT_SUM
+                for (int c = 1; c < n_in; c++) acc += ld128_nt(in + static_cast<uint64_t>(c) * in_stride + 2 * k);
+                acc &= mask;
+                if (sum_out) st128_nt(sum_out + 2 * k, acc);
+#else
+                for (int c = 1; c < n_in; c++) acc += ld128(in + static_cast<uint64_t>(c) * in_stride + 2 * k);
+                acc &= mask;
+                if (sum_out) st128(sum_out + 2 * k, acc);
+#endif
+            }
             uint32_t s[DBL ? 2 : 1][4];
             if (uni) {
                 const uint32_t v0 = T3(static_cast<uint32_t>(j) ^ rk.w[3], SEL_B0);
@@ -896,6 +915,9 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
         tb.add[nv] = jobs[e].add_idx; tb.minus[nv] = jobs[e].minus_idx;
         tb.first[nv] = jobs[e].first; tb.count[nv] = jobs[e].count;
         tb.in[nv] = jobs[e].in_dev; tb.out[nv] = jobs[e].out_dev; tb.in_limbs[nv] = static_cast<uint8_t>(jobs[e].in_limbs);
+        if (jobs[e].n_in > 255 || (jobs[e].n_in > 1 && (jobs[e].in_limbs != 2 || !jobs[e].in_dev))) return hipErrorInvalidValue;
+        tb.n_in[nv] = static_cast<uint8_t>(jobs[e].n_in ? jobs[e].n_in : 1); tb.in_stride[nv] = jobs[e].in_stride;
+        tb.sum_out[nv] = jobs[e].n_in > 1 ? jobs[e].sum_out_dev : nullptr;
         big[nv] = jobs[e].count / kBigTile;
         n_big += big[nv++];
     }

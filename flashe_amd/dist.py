@@ -121,6 +121,14 @@ class HipOps:
     def decrypt_range(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, out):
         self.engine.decrypt_range_dev(it, add_idx, minus_idx, n, n_jobs, first, count, inp.data_ptr(), out.data_ptr())
 
+    def aggregate_decrypt(self, it, add_idx, minus_idx, n, n_jobs, first, count, srcs, agg_out, out, on_side=False):
+        """The reduce fused with the decrypt of its result, on elements [first, first + count) of the vector:
+        srcs = [(tensor, elem_offset)] operands addressing element `first`; agg_out / out = (tensor, elem_offset) or None."""
+        eng = self.side if (on_side and self.side is not None) else self.engine
+        L = eng.limbs
+        at = lambda x: None if x is None else x[0].data_ptr() + x[1] * L * 8
+        eng.aggregate_decrypt_range_dev(it, add_idx, minus_idx, n, n_jobs, first, count, [at(x) for x in srcs], at(agg_out), at(out))
+
     def prf_jobs(self, it, n, n_jobs, jobs):
         """jobs: (add_idx, minus_idx, first, count, in_tensor or None, in_word_offset, in_limbs, out_tensor, out_word_offset);
         one launch for all of them (flashe_prf_jobs_dev)."""
@@ -163,7 +171,10 @@ class ShardedRound:
         self.slice = slice_len(n, world)
         self.padded = self.slice * world
         kw = dict(dtype=torch.int64, device=device)
-        self.ct = [torch.zeros(n * self.L, **kw) for _ in range(clients_per_rank)]
+        # the local ciphertexts are equally spaced in ONE allocation: the fused reduce + decrypt walks them by stride
+        stride = (n * self.L + 1) // 2 * 2                          # every vector 16-byte aligned
+        self.ct_all = torch.zeros(clients_per_rank * stride, **kw)
+        self.ct = [self.ct_all[c * stride:c * stride + n * self.L] for c in range(clients_per_rank)]
         self.partial = torch.zeros(self.padded * self.L, **kw)       # local aggregate, padded to world slices
         self.recv = torch.zeros(self.padded * self.L, **kw) if self.exchange else None
         self.agg_slice = torch.zeros(self.slice * self.L, **kw)
@@ -394,9 +405,27 @@ class ShardedRound:
         ops.decrypt_range(it, add_idx, minus_idx, n, self.n_jobs, 0, n, self.k_agg, self.result)
         return self.result
 
+    def reduce_decrypt_phase(self, it):
+        """aggregate_phase + decrypt_phase with the last reduce fused into the decrypt (one pass over its operands):
+        without an exchange the C local ciphertexts, with one the W received pieces of the owned slice."""
+        uploaded = list(range(self.total_clients()))
+        add_idx, minus_idx = telescope(uploaded) if self.scheme == SCHEME_DOUBLE else ([], uploaded)
+        n, W = self.n, self.world
+        if not self.exchange:
+            self.ops.aggregate_decrypt(it, add_idx, minus_idx, n, self.n_jobs, 0, n, [(t, 0) for t in self.ct],
+                                       (self.partial, 0), (self.result, 0))
+            return self.result
+        self.ops.aggregate(self.ct, n, self.partial)
+        dist.all_to_all_single(self.recv, self.partial, group=self.group)
+        if self.count > 0:
+            self.ops.aggregate_decrypt(it, add_idx, minus_idx, n, self.n_jobs, self.first, self.count,
+                                       [(self.recv, g * self.slice) for g in range(W)], (self.agg_slice, 0), (self.dec_slice, 0))
+        dist.all_gather_into_tensor(self.result, self.dec_slice, group=self.group)
+        return self.result
+
     def run(self, it, pts, pt_limbs):
         """pts: this rank's plaintext tensors (one per local client).  Returns the tensor holding the
-        decrypted aggregate (first n*L words valid)."""
+        decrypted aggregate (first n*L words valid).  Two PRF launches per round on one GPU: every local
+        encrypt, then reduce + decrypt."""
         self.encrypt_phase(it, pts, pt_limbs)
-        self.aggregate_phase()
-        return self.decrypt_phase(it)
+        return self.reduce_decrypt_phase(it)

@@ -194,9 +194,13 @@ class Engine:
         int_bits > 64).  Pointers address element `first`."""
         jobs = list(jobs)
         arr = (PrfJob * max(len(jobs), 1))()
-        for e, (a, m, first, count, inp, in_limbs, out) in enumerate(jobs):
+        for e, job in enumerate(jobs):
+            a, m, first, count, inp, in_limbs, out = job[:7]
+            # optional tail: (n_in, in_stride_elements, sum_out_ptr or None) = the reduce of n_in vectors fused in
+            n_in, in_stride, sum_out = job[7:10] if len(job) > 7 else (0, 0, None)
             arr[e] = PrfJob(a, 0 if m is None else m, 0 if m is None else 1, in_limbs, first, count,
-                            None if inp is None else self._ptr(inp), self._ptr(out))
+                            None if inp is None else self._ptr(inp), self._ptr(out), n_in, 0, in_stride,
+                            None if sum_out is None else self._ptr(sum_out))
         self._check(self._lib.flashe_prf_jobs_dev(self._h, it, n, n_jobs, len(jobs), arr))
 
     def decrypt_dev(self, it, add_idx, minus_idx, n, n_jobs, inp, out):
@@ -229,6 +233,15 @@ class Engine:
     def aggregate_elem_dev(self, cts, n, out):
         p, _keep = self._ptr_array(cts)
         self._check(self._lib.flashe_aggregate_elem_dev(self._h, len(cts), p, n, self._ptr(out)))
+
+    def aggregate_decrypt_range_dev(self, it, add_idx, minus_idx, n, n_jobs, first, count, cts, agg_out, out):
+        """agg = sum of cts mod 2^b (stored to agg_out unless None), out = decrypt of agg on elements [first, first + count);
+        one pass when the ciphertexts are equally spaced in memory.  Pointers address element `first`."""
+        pa, _a = _u32_list(add_idx)
+        pm, _m = _u32_list(minus_idx)
+        p, _keep = self._ptr_array(cts)
+        self._check(self._lib.flashe_aggregate_decrypt_range_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, first, count,
+                                                                 len(cts), p, self._ptr(agg_out), self._ptr(out)))
 
     def aggregate_packed_dev(self, packed, n_limbs, total_bits, out):
         p, _keep = self._ptr_array(packed)

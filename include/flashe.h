@@ -133,7 +133,10 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
  *   FlasheCipher.encrypt (single)     add = idx, has_minus = 0                     :308-309, :450-451
  *   decrypt, nobody dropped           add = num_clients, minus = 0, in = aggregate :633-666, :570-571
  *   prepare_encrypt / prepare_decrypt the same with in_dev = NULL (the cached add - minus) :599-666
- * All entries of one call must agree on has_minus. */
+ * All entries of one call must agree on has_minus.
+ * n_in > 1 fuses the arbiter's reduce (jzf_aggregator.py:424-430) into the entry: the input is
+ * sum_{c < n_in} of the vectors at in_dev + c * in_stride elements (in_limbs = L required), reduced
+ * mod 2^b; sum_out_dev, when not NULL, receives that sum (the ciphertext aggregate). n_in = 0 means 1. */
 typedef struct flashe_prf_job {
     uint32_t add_idx;
     uint32_t minus_idx;
@@ -142,6 +145,10 @@ typedef struct flashe_prf_job {
     uint64_t first, count;
     const uint64_t *in_dev;
     uint64_t *out_dev;
+    uint32_t n_in;           /* number of input vectors summed (0 or 1: plain input) */
+    uint32_t reserved;       /* must be 0 */
+    uint64_t in_stride;      /* elements between consecutive input vectors when n_in > 1 */
+    uint64_t *sum_out_dev;   /* optional, n_in > 1 only */
 } flashe_prf_job;
 int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_jobs,
                         int n_entries, const flashe_prf_job *entries);
@@ -187,6 +194,16 @@ int flashe_aggregate_elem_dev(flashe_ctx *ctx, int C, const uint64_t *const *cts
                               uint64_t n, uint64_t *out_dev);
 int flashe_aggregate_elem(flashe_ctx *ctx, int C, const uint64_t *const *cts,
                           uint64_t n, uint64_t *out);
+/* The element-wise reduce fused with the decrypt of its result (new): agg = sum_c cts[c] mod 2^b
+ * (stored to agg_out_dev unless NULL), out = agg + sum term(add) - sum term(minus) -- exactly
+ * flashe_aggregate_elem_dev followed by flashe_decrypt_range_dev on elements [first, first + count)
+ * of the n-element vector, in one pass over the ciphertexts when they are equally spaced in
+ * memory (one launch, the aggregate never re-read); any other shape runs the two calls.
+ * cts_dev / agg_out_dev / out_dev address element `first`. */
+int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter,
+                                       const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                                       uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
+                                       int C, const uint64_t *const *cts_dev, uint64_t *agg_out_dev, uint64_t *out_dev);
 /* Packed: each operand is ONE integer of total_bits bits (n_limbs = ceil(total_bits/64)
  * little-endian limbs); out = sum mod 2^total_bits -- jzf_aggregator.py:406-419. */
 int flashe_aggregate_packed_dev(flashe_ctx *ctx, int C, const uint64_t *const *packed_dev,

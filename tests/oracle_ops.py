@@ -111,3 +111,12 @@ class OracleOps:
             else:
                 inp = t_in.numpy().view(np.uint64)[o_in:o_in + count * in_limbs].reshape(count, in_limbs)
             t_out.numpy().view(np.uint64)[o_out:o_out + count * self.L] = orc.combine(self.b, inp, add, minus).reshape(-1)
+
+    def aggregate_decrypt(self, it, add_idx, minus_idx, n, n_jobs, first, count, srcs, agg_out, out, on_side=False):
+        parts = [np.ascontiguousarray(self._v(t, o + count)[o:o + count]) for t, o in srcs]
+        agg = orc.aggregate_elem(parts, self.b)
+        if agg_out is not None:
+            self._v(agg_out[0], agg_out[1] + count)[agg_out[1]:agg_out[1] + count] = agg
+        add = orc.mask_sum(KEY, it, add_idx, n, n_jobs, self.b)[first:first + count]
+        minus = orc.mask_sum(KEY, it, minus_idx, n, n_jobs, self.b)[first:first + count]
+        self._v(out[0], out[1] + count)[out[1]:out[1] + count] = orc.combine(self.b, agg, add, minus)

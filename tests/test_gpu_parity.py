@@ -331,6 +331,44 @@ def test_prf_jobs_vs_oracle(E, oracle, b, n, J):
         eng.prf_jobs_dev(6, n, J, [(3, 4, n - 5, 10, None, 0, many[0][6])])                                        # range past n
 
 
+@pytest.mark.parametrize("b,n,J,C", [(128, 70_001, 16, 10), (100, 5000, 3, 3), (128, 2_100_000, 1, 2), (64, 30_000, 16, 4), (20, 9999, 7, 70)])
+def test_aggregate_decrypt_fused_vs_oracle(E, oracle, b, n, J, C):
+    """flashe_aggregate_decrypt_range_dev == aggregate_elem followed by decrypt: equally spaced ciphertexts (one launch for
+    b > 64), scattered ones, prefix lists, sub-ranges; with and without storing the aggregate."""
+    eng = make(E, b)
+    Lb = L(b)
+    rng = np.random.Generator(np.random.PCG64(n + C))
+    cts = [rand_limbs(rng, n, b) for _ in range(C)]
+    agg = oracle.aggregate_elem(cts, b)
+    n_pad = n + (n & 1)                                                        # keeps every operand 16-byte aligned
+    slab = eng.upload(np.concatenate([np.concatenate([c.reshape(-1), np.zeros((n_pad - n) * Lb, dtype=np.uint64)]) for c in cts]))
+    scattered = [eng.upload(c) for c in cts]                                   # separate allocations
+    cases = [([C], [0]), ([3, 7], [0, 5]), ([], list(range(min(C, 6)))), ([4], [])]
+    for add, minus in cases:
+        # operands of the reduce must be 16-byte aligned: any element for 2-limb vectors, even ones for 1-limb vectors
+        odd = 1 if Lb == 2 else 2
+        for first, count in ((0, n), (256, n - 777), (odd, 1), ((n - 1) // odd * odd, 1), (78, 0)):
+            want = oracle.combine(b, agg[first:first + count], oracle.mask_sum(KEY, 2, add, n, J, b)[first:first + count],
+                                  oracle.mask_sum(KEY, 2, minus, n, J, b)[first:first + count]) if count else None
+            for layout in ("slab", "scattered"):
+                for keep in (True, False):
+                    ptrs = [(slab.ptr + 8 * Lb * (c * n_pad + first)) if layout == "slab" else (scattered[c].ptr + 8 * Lb * first) for c in range(C)]
+                    out, ao = eng.alloc_vec(max(count, 1)), eng.alloc_vec(max(count, 1))
+                    eng.aggregate_decrypt_range_dev(2, add, minus, n, J, first, count, ptrs, ao if keep else None, out)
+                    if count == 0:
+                        continue
+                    assert np.array_equal(out.download(np.uint64, count * Lb).reshape(count, Lb), want), (b, add, minus, first, count, layout, keep)
+                    if keep:
+                        assert np.array_equal(ao.download(np.uint64, count * Lb).reshape(count, Lb), agg[first:first + count]), (b, layout)
+    # the job-list form with a summed input
+    if b > 64:
+        out, ao = eng.alloc_vec(n), eng.alloc_vec(n)
+        eng.prf_jobs_dev(2, n, J, [(C, 0, 0, n, slab, Lb, out, C, n_pad, ao)])
+        want = oracle.combine(b, agg, oracle.mask(KEY, 2, C, n, J, b), oracle.mask(KEY, 2, 0, n, J, b))
+        assert np.array_equal(out.download(np.uint64, n * Lb).reshape(n, Lb), want)
+        assert np.array_equal(ao.download(np.uint64, n * Lb).reshape(n, Lb), agg)
+
+
 def test_u64_plaintext_zero_extension(E, oracle):
     rng = np.random.Generator(np.random.PCG64(3))
     eng = make(E, 128)

@@ -11,6 +11,11 @@ __device__ __forceinline__ uint32_t op(uint32_t a, uint32_t b, uint32_t c)
     if (OP == 1) return a ^ b;
     if (OP == 2) return __builtin_amdgcn_perm(a, b, 0x06020400u);
     if (OP == 3) return (a & b) | (c & ~b);   // v_bfi
+    if (OP == 5) {   // SDWA byte insert: byte 3 of b -> byte 1 of a, other bytes of a preserved
+        asm volatile("v_mov_b32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a) : "v"(b));
+        return a;
+    }
+    if (OP == 6) return (a & 0xff00u) | c;   // v_and_or_b32
     return a + b;
 }
 
@@ -65,6 +70,8 @@ int main()
         run<1, 4>("xor", w);
         run<2, 4>("perm", w);
         run<3, 4>("bfi", w);
+        run<5, 4>("sdwa_ins", w);
+        run<6, 4>("and_or", w);
         run<0, 256>("bitop3", w);
         run<1, 256>("xor", w);
         run<0, 1024>("bitop3", w);
