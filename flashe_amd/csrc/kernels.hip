@@ -73,9 +73,6 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
     return LaneRegs{lane4, lane4 | 0x00010000u, (const lds_u8 *)(lds_u32 *)tab};
 }
 
-#ifndef FLASHE_NT_SUM
-#define FLASHE_NT_SUM 1   // read-once operands of the fused reduce bypass the caches
-#endif
 #ifndef FLASHE_CTR2
 #define FLASHE_CTR2 1   // wave-uniform part of rounds 1-2 through the scalar cache
 #endif
@@ -423,9 +420,12 @@ struct JobTable {
 };
 constexpr int kBigEpl = 4;
 
-// MULTI only names the instantiation (1 = a launch with several jobs, 0 = one job), so that profiles list the
-// batched launches and the single-vector / chunk launches as separate kernels.
-template <bool DBL, int THREADS, int MULTI>
+// KIND 0 / 1 only name the instantiation (one job / several jobs per launch), so that profiles list the batched
+// launches and the single-vector / chunk launches as separate kernels; KIND 2 additionally compiles the summed
+// input (reduce fused in): its operands are loaded before the AES rounds and added after them, so their HBM
+// latency hides under the lookups of the same element.
+constexpr int kSumRegs = 10;            // operands held in registers across the rounds (more are added up front)
+template <bool DBL, int THREADS, int KIND>
 __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const JobTable tb, int n_vec, uint64_t n,
                                                                      uint32_t iter, uint64_t mask_lo, uint64_t mask_hi,
                                                                      const uint32_t *__restrict__ te0)
@@ -486,16 +486,14 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
             if (k >= count) break;
             const uint64_t j = first + k;
             u128 acc = !in ? static_cast<u128>(0) : in_limbs == 2 ? ld128(in + 2 * k) : static_cast<u128>(in[k]);
-            if (n_in > 1) {                     // the reduce fused in: sum of n_in vectors (wave-uniform trip count)
-#if FLASHE_NT_SUM
-                for (int c = 1; c < n_in; c++) acc += ld128_nt(in + static_cast<uint64_t>(c) * in_stride + 2 * k);
-                acc &= mask;
-                if (sum_out) st128_nt(sum_out + 2 * k, acc);
-#else
-                for (int c = 1; c < n_in; c++) acc += ld128(in + static_cast<uint64_t>(c) * in_stride + 2 * k);
-                acc &= mask;
-                if (sum_out) st128(sum_out + 2 * k, acc);
-#endif
+            u64x2 held[KIND == 2 ? kSumRegs : 1];
+            if (KIND == 2 && n_in > 1) {        // the reduce fused in: sum of n_in vectors (wave-uniform trip count)
+#pragma unroll
+                for (int c = 0; c < kSumRegs; c++) {
+                    const int cc = c + 1 < n_in ? c + 1 : 0;        // surplus slots re-read operand 0 and are not added
+                    held[c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + static_cast<uint64_t>(cc) * in_stride + 2 * k));
+                }
+                for (int c = kSumRegs + 1; c < n_in; c++) acc += ld128_nt(in + static_cast<uint64_t>(c) * in_stride + 2 * k);
             }
             uint32_t s[DBL ? 2 : 1][4];
             if (uni) {
@@ -512,6 +510,13 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
                 set_block(s[0], iter, ia, j);
                 if (DBL) set_block(s[DBL ? 1 : 0], iter, im, j);
                 aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
+            }
+            if (KIND == 2 && n_in > 1) {
+#pragma unroll
+                for (int c = 0; c < kSumRegs; c++)
+                    if (c + 1 < n_in) acc += (static_cast<u128>(held[c][1]) << 64) | held[c][0];
+                acc &= mask;
+                if (sum_out) st128_nt(sum_out + 2 * k, acc);
             }
             acc += words_to_u128(s[0]);
             if (DBL) acc -= words_to_u128(s[DBL ? 1 : 0]);
@@ -945,8 +950,10 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
 #define JOBS_LAUNCH(DBL, MULTI)                                                                                              \
     hipLaunchKernelGGL((prf_wide_batch_kernel<DBL, kPrfThreads, MULTI>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, \
                        nv, n, iter, lo, hi, env.te0_dev)
-    if (dbl) { if (nv > 1) JOBS_LAUNCH(true, 1); else JOBS_LAUNCH(true, 0); }
-    else { if (nv > 1) JOBS_LAUNCH(false, 1); else JOBS_LAUNCH(false, 0); }
+    bool summed = false;
+    for (int v = 0; v < nv; v++) summed |= tb.n_in[v] > 1;
+    if (dbl) { if (summed) JOBS_LAUNCH(true, 2); else if (nv > 1) JOBS_LAUNCH(true, 1); else JOBS_LAUNCH(true, 0); }
+    else { if (summed) JOBS_LAUNCH(false, 2); else if (nv > 1) JOBS_LAUNCH(false, 1); else JOBS_LAUNCH(false, 0); }
 #undef JOBS_LAUNCH
     return hipGetLastError();
 }
