@@ -520,7 +520,7 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
             }
             acc += words_to_u128(s[0]);
             if (DBL) acc -= words_to_u128(s[DBL ? 1 : 0]);
-            st128(out + 2 * k, acc & mask);
+            st128(out + 2 * k, acc & mask);   // plain store: measured, part of it is still in the Infinity Cache for the reduce
         }
     }
 }
