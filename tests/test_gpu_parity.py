@@ -239,6 +239,41 @@ def test_counter_window_across_2_32(E, backend):
             assert int(gm[e, 0]) | (int(gm[e, 1]) << 64) == want
 
 
+def test_counter_window_large_launches(E):
+    """Launches big enough for the 4096-element tiles (wave-uniform rounds 1-2 through the scalar cache): above 2^32
+    (non-zero high counter word folded into the prefix), straddling 2^32 (generic path on big tiles), and a start
+    that is not a multiple of 256 (one-step shortcut on big tiles).  Expected values from the host AES."""
+    eng = make(E, 128)
+    it, idx, n_total = 5, 1234, 2 ** 34
+    for first, count in [(2 ** 32 + 256 * 977, 1_300_000), (2 ** 32 - 600_000, 1_300_000), (3 * 2 ** 32 + 100, 1_100_000), (0, 1_050_000)]:
+        rng = np.random.Generator(np.random.PCG64(count))
+        pt = rng.integers(0, 2 ** 64, count, dtype=np.uint64)
+        d_in, d_out = eng.upload(pt), eng.alloc_vec(count)
+        eng.encrypt_range_dev(it, idx, E.SCHEME_DOUBLE, n_total, 1, first, count, d_in, 1, d_out)
+        got = d_out.download(np.uint64, 2 * count).reshape(count, 2)
+        picks = set(int(v) for v in rng.integers(0, count, 150)) | {0, 63, 64, 255, 256, 4095, 4096, count - 1, count - 1025, 600_000 - 1, 600_000, 600_001}
+        for e in sorted(picks):
+            if not 0 <= e < count:
+                continue
+            ctr = first + e
+            blk = lambda i: int.from_bytes(E.prp_block(KEY, it.to_bytes(4, "big") + i.to_bytes(4, "big") + ctr.to_bytes(8, "big")), "big")
+            want = (int(pt[e]) + blk(idx) - blk(idx + 1)) % (1 << 128)
+            assert int(got[e, 0]) | (int(got[e, 1]) << 64) == want, (first, e)
+        # linearity against the single-stream launch of the same range: ct - pt == mask(idx) - mask(idx + 1)
+        d_a, d_b = eng.alloc_vec(count), eng.alloc_vec(count)
+        eng.mask_range_dev(it, [idx], n_total, 1, first, count, d_a)
+        eng.mask_range_dev(it, [idx + 1], n_total, 1, first, count, d_b)
+        a = d_a.download(np.uint64, 2 * count).reshape(count, 2)
+        bb = d_b.download(np.uint64, 2 * count).reshape(count, 2)
+        lo = pt + a[:, 0]
+        c1 = (lo < pt).astype(np.uint64)
+        hi = a[:, 1] + c1
+        lo2 = lo - bb[:, 0]
+        br = (lo < bb[:, 0]).astype(np.uint64)
+        hi2 = hi - bb[:, 1] - br
+        assert np.array_equal(got[:, 0], lo2) and np.array_equal(got[:, 1], hi2), first
+
+
 def test_range_twins_table_backend(E, oracle):
     for b, n, J in [(128, 50000, 16), (64, 50001, 8), (20, 70001, 16), (7, 9999, 3)]:
         rng = np.random.Generator(np.random.PCG64(n))
