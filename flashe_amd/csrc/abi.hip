@@ -809,6 +809,31 @@ int flashe_expand_to_dense_dev(flashe_ctx *ctx, uint64_t total, uint64_t k, cons
     return FLASHE_OK;
 }
 
+int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                const uint64_t *const *vals_dev, const uint64_t *zeros, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (C < 0 || (C && (!loc_dev || !k || !vals_dev || !zeros)) || (total && !out_dev)) return fail(ctx, FLASHE_EINVAL, "bad arguments");
+    if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    const int L = ctx->limbs;
+    using u128 = unsigned __int128;
+    const u128 mask = ctx->int_bits == 128 ? ~static_cast<u128>(0) : ((static_cast<u128>(1) << ctx->int_bits) - 1);
+    u128 zsum = 0;
+    for (int c = 0; c < C; c++) {
+        const u128 z = (L == 2 ? static_cast<u128>(zeros[2 * c + 1]) << 64 : 0) | zeros[static_cast<size_t>(L) * c];
+        if (z & ~mask) return fail(ctx, FLASHE_EINVAL, "zero value of client %d exceeds int_bits", c);
+        if (k[c] && (!loc_dev[c] || !vals_dev[c] || (L == 2 && !aligned16(vals_dev[c])))) return fail(ctx, FLASHE_EINVAL, "client %d: null or misaligned vector", c);
+        zsum = (zsum + z) & mask;
+    }
+    // sum_c expand_to_dense(c) = (sum_c zero_c everywhere) + per client (vals_c[q] - zero_c) at loc_c[q]; the clients go one
+    // after the other because their location sets overlap
+    HIP_TRY(ctx, launch_fill(ctx->env, total, static_cast<uint64_t>(zsum), static_cast<uint64_t>(zsum >> 64), out_dev));
+    for (int c = 0; c < C; c++)
+        HIP_TRY(ctx, launch_scatter(ctx->env, k[c], loc_dev[c], vals_dev[c], out_dev, true, zeros[static_cast<size_t>(L) * c],
+                                    L == 2 ? zeros[2 * c + 1] : 0));
+    return FLASHE_OK;
+}
+
 int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                                  uint64_t total, uint32_t n_jobs, uint64_t *out_dev)
 {

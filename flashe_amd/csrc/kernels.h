@@ -88,7 +88,8 @@ hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_de
 
 hipError_t launch_fill(const LaunchEnv &env, uint64_t n, uint64_t lo, uint64_t hi, uint64_t *out_dev);
 hipError_t launch_scatter(const LaunchEnv &env, uint64_t k, const uint32_t *loc_dev,
-                          const uint64_t *vals_dev, uint64_t *out_dev, bool accumulate);
+                          const uint64_t *vals_dev, uint64_t *out_dev, bool accumulate,
+                          uint64_t sub_lo = 0, uint64_t sub_hi = 0);
 // out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
 hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uint8_t *sel_dev,
                                  const uint64_t *stream_dev, uint64_t *out_dev);

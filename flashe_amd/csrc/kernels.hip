@@ -1351,19 +1351,22 @@ __global__ __launch_bounds__(kStreamThreads) void fill_kernel(uint64_t n, int L,
 
 // out[loc[q]] = vals[q]  or  out[loc[q]] = (out[loc[q]] + vals[q]) mod 2^b.  loc must hold
 // distinct positions within one launch (the reference's location lists are sets).
+// sub (a constant, < 2^b) is subtracted from every value first: the sparse reduce adds vals[q] - zero.
 __global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t k, int L, const uint32_t *loc, const uint64_t *vals,
-                                                                 uint64_t *out, bool accumulate, uint64_t mask_lo, uint64_t mask_hi)
+                                                                 uint64_t *out, bool accumulate, uint64_t mask_lo, uint64_t mask_hi,
+                                                                 uint64_t sub_lo, uint64_t sub_hi)
 {
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const u128 sub = (static_cast<u128>(sub_hi) << 64) | sub_lo;
     for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; q < k;
          q += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
         const uint64_t p = loc[q];
         if (L == 2) {
-            u128 v = ld128(vals + 2 * q);
+            u128 v = ld128(vals + 2 * q) - sub;
             if (accumulate) v += ld128(out + 2 * p);
             st128(out + 2 * p, v & mask);
         } else {
-            uint64_t v = vals[q];
+            uint64_t v = vals[q] - sub_lo;
             if (accumulate) v += out[p];
             out[p] = v & mask_lo;
         }
@@ -1391,13 +1394,13 @@ hipError_t launch_fill(const LaunchEnv &env, uint64_t n, uint64_t lo, uint64_t h
 }
 
 hipError_t launch_scatter(const LaunchEnv &env, uint64_t k, const uint32_t *loc_dev, const uint64_t *vals_dev,
-                          uint64_t *out_dev, bool accumulate)
+                          uint64_t *out_dev, bool accumulate, uint64_t sub_lo, uint64_t sub_hi)
 {
     if (k == 0) return hipSuccess;
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
     hipLaunchKernelGGL(scatter_kernel, dim3(stream_grid(env, k)), dim3(kStreamThreads), 0, env.stream, k, env.b > 64 ? 2 : 1,
-                       loc_dev, vals_dev, out_dev, accumulate, lo, hi);
+                       loc_dev, vals_dev, out_dev, accumulate, lo, hi, sub_lo, sub_hi);
     return hipGetLastError();
 }
 

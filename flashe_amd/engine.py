@@ -266,6 +266,20 @@ class Engine:
         self._check(self._lib.flashe_expand_to_dense_dev(self._h, total, k, self._ptr(loc), self._ptr(vals),
                                                          ctypes.cast(z, c_u64p), self._ptr(out)))
 
+    def sparse_aggregate_dev(self, total, locs, ks, vals, zeros, out):
+        """out = sum over clients of expand_to_dense(total, locs[c], vals[c], zeros[c]) mod 2^b, without the dense
+        intermediates.  zeros: per client a sequence of L limbs (or an int)."""
+        pl, _kl = self._ptr_array(locs)
+        pv, _kv = self._ptr_array(vals)
+        k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        flat = []
+        for z in zeros:
+            z = [int(z) & (2 ** 64 - 1), int(z) >> 64] if isinstance(z, int) else [int(v) for v in z] + [0]
+            flat += z[:self.limbs]
+        zz = (c_u64 * max(len(flat), 1))(*flat)
+        self._check(self._lib.flashe_sparse_aggregate_dev(self._h, total, len(locs), pl, ctypes.cast(k, c_u64p), pv,
+                                                          ctypes.cast(zz, c_u64p), self._ptr(out)))
+
     def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out):
         p, _keep = self._ptr_array(locs)
         k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])

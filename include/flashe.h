@@ -238,6 +238,13 @@ int flashe_expand_to_dense_dev(flashe_ctx *ctx, uint64_t total, uint64_t k, cons
                                const uint64_t *vals_dev, const uint64_t *zero, uint64_t *out_dev);
 int flashe_expand_to_dense(flashe_ctx *ctx, uint64_t total, uint64_t k, const uint32_t *loc,
                            const uint64_t *vals, const uint64_t *zero, uint64_t *out);
+/* The sparse job's arbiter step as one operation (new): out = sum_c expand_to_dense(total, loc[c], vals[c], zero_c)
+ * mod 2^b -- Arbiter.expand_to_dense (jzf_aggregator.py:150-165, :382-384) for every client followed by the
+ * element-wise reduce (:424-430) -- without materialising the C dense vectors: the sum of the zero values is
+ * written everywhere, then each client's (vals[q] - zero_c) is added at loc[c][q].  loc / vals are HOST arrays of
+ * C device pointers, k a HOST array, zeros a HOST array of C x L limbs; locations are distinct within a client. */
+int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                const uint64_t *const *vals_dev, const uint64_t *zeros, uint64_t *out_dev);
 /* Sparse single-mask dense minus-mask -- set_idx_list_single sparse branch,
  * jzf_flashe.py:316-343: for client c the stream over COMPACT positions 0..k[c]-1 (prefix
  * iter|c, chunks_idx(range(k[c]), n_jobs)) scattered to loc[c][q] and summed over clients.

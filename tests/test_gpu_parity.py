@@ -545,6 +545,30 @@ def test_sparse_config5_shape_small(E, oracle):
     assert np.array_equal(dec, oracle.combine(b, oracle.aggregate_elem(dense, b), None, mm))
 
 
+@pytest.mark.parametrize("b,total,C", [(128, 50_000, 7), (100, 4099, 3), (64, 30_001, 5), (20, 9999, 9), (128, 64, 4)])
+def test_sparse_aggregate_fused_vs_dense_path(E, oracle, b, total, C):
+    """flashe_sparse_aggregate_dev == expand_to_dense per client + element-wise reduce (overlapping location sets,
+    full-range zero values, an empty client, a client that covers every position)."""
+    rng = np.random.Generator(np.random.PCG64(total + C))
+    eng = make(E, b)
+    Lb = L(b)
+    ks = [int(v) for v in rng.integers(1, max(2, total // 3), C)]
+    ks[0], ks[-1] = 0, total
+    locs = [np.sort(rng.choice(total, size=k, replace=False)).astype(np.uint32) for k in ks]
+    vals = [rand_limbs(rng, max(k, 1), b)[:k] for k in ks]
+    zeros = [rand_limbs(rng, 1, b)[0] for _ in range(C)]
+    dense = [oracle.expand_to_dense(total, locs[c], vals[c], zeros[c], b) for c in range(C)]
+    want = oracle.aggregate_elem(dense, b)
+    dl = [eng.upload(l if len(l) else np.zeros(1, dtype=np.uint32)) for l in locs]
+    dv = [eng.upload(v if len(v) else np.zeros((1, Lb), dtype=np.uint64)) for v in vals]
+    out = eng.alloc_vec(total)
+    eng.sparse_aggregate_dev(total, dl, ks, dv, zeros, out)
+    assert np.array_equal(out.download(np.uint64, total * Lb).reshape(total, Lb), want)
+    if b not in (64, 128):
+        with pytest.raises(Exception):                     # a zero value wider than int_bits
+            eng.sparse_aggregate_dev(total, dl[:1], ks[:1], dv[:1], [[2 ** 64 - 1, 2 ** 64 - 1]], out)
+
+
 # ------------------------------------------------------------------ quantise / batch codec (8f-1)
 def test_codec_golden(E, oracle):
     g = load_golden("codec.json")
