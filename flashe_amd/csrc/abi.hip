@@ -843,6 +843,25 @@ int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const ui
     if (total) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
     uint64_t kmax = 0;
     for (int c = 0; c < C; c++) kmax = std::max(kmax, k[c]);
+    if (ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE)) {
+        // m = 1: the compact streams do not depend on their length, so up to kMaxBatch clients' streams come from one
+        // job-list launch; the scatters stay one per client (location sets overlap between clients)
+        const uint64_t kpad = (kmax + 1) & ~1ull;
+        const int group = std::min(C, kMaxBatch);
+        int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kpad) * static_cast<size_t>(std::max(group, 1)));
+        if (rc) return rc;
+        uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
+        for (int c0 = 0; c0 < C; c0 += group) {
+            PrfJob jobs[kMaxBatch];
+            const int nc = std::min(group, C - c0);
+            for (int e = 0; e < nc; e++)
+                jobs[e] = PrfJob{static_cast<uint32_t>(c0 + e), 0u, 0, k[c0 + e], nullptr, 0, tmp + 2 * kpad * static_cast<uint64_t>(e)};
+            HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nc, jobs, kmax));
+            for (int e = 0; e < nc; e++)
+                HIP_TRY(ctx, launch_scatter(ctx->env, k[c0 + e], loc_dev[c0 + e], tmp + 2 * kpad * static_cast<uint64_t>(e), out_dev, true));
+        }
+        return FLASHE_OK;
+    }
     int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kmax));
     if (rc) return rc;
     uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
