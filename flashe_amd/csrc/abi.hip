@@ -697,7 +697,8 @@ int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uin
     for (int c = 0; c < C; c++)
         if (!cts_dev[c]) return fail(ctx, FLASHE_EINVAL, "operand %d is null", c);
     // one pass when the ciphertexts are equally spaced (ascending), one add and at most one minus prefix, b > 64
-    bool strided = ctx->limbs == 2 && n_add == 1 && n_minus <= 1 && C <= 255 &&
+    // (a short vector does not fill the chip with 1024-element tiles: the streaming reduce kernel + a decrypt win there)
+    bool strided = ctx->limbs == 2 && n_add == 1 && n_minus <= 1 && C <= 255 && count >= static_cast<uint64_t>(ctx->env.num_cus) * 1024 &&
                    (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE) && aligned16(cts_dev[0]) && aligned16(out_dev) &&
                    aligned16(agg_out_dev);
     uint64_t stride = 0;

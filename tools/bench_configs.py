@@ -39,7 +39,9 @@ def config3(out):
         rng = np.random.Generator(np.random.PCG64(3))
         pt = rng.integers(0, 2 ** 16, n, dtype=np.uint64)
         dpt = eng.upload(pt)
-        dct = [eng.alloc_vec(n) for _ in range(C)]
+        stride = (n * L + 1) // 2 * 2                       # ciphertexts equally spaced: the fused reduce + decrypt walks them by stride
+        slab = eng.alloc(8 * stride * C)
+        dct = [slab.ptr + 8 * stride * c for c in range(C)]
         dadd, dminus, dagg, dout = eng.alloc_vec(n), eng.alloc_vec(n), eng.alloc_vec(n), eng.alloc_vec(n)
         t_enc = timeit(eng, lambda: eng.encrypt_dev(1, 5, SCHEME_DOUBLE, n, 16, dpt, 1, dct[5]))
         t_prep = timeit(eng, lambda: (eng.mask_dev(1, [5], n, 16, dadd), eng.mask_dev(1, [6], n, 16, dminus)))
@@ -50,14 +52,19 @@ def config3(out):
         t_agg = timeit(eng, lambda: eng.aggregate_elem_dev(dct, n, dagg))
         t_dec = timeit(eng, lambda: eng.decrypt_dev(1, [C], [0], n, 16, dagg, dout))
         t_dec_pre = timeit(eng, lambda: eng.combine_dev(n, dagg, L, dadd, dminus, dout))
+        t_aggdec = timeit(eng, lambda: eng.aggregate_decrypt_range_dev(1, [C], [0], n, 16, 0, n, dct, dagg, dout))
         eng.decrypt_dev(1, [C], [0], n, 16, dagg, dout)
         got = dout.download(np.uint64, n * L).reshape(n, L)
         assert np.array_equal(got[:, 0], (pt * np.uint64(C)) & np.uint64((1 << min(b, 64)) - 1 if b < 64 else 2 ** 64 - 1))
-        ct5 = dct[5].download(np.uint64, n * L).reshape(n, L)
+        got2 = dout.download(np.uint64, n * L).reshape(n, L)
+        eng.aggregate_decrypt_range_dev(1, [C], [0], n, 16, 0, n, dct, dagg, dout)
+        assert np.array_equal(dout.download(np.uint64, n * L).reshape(n, L), got2)
+        ct5 = slab.download(np.uint64, stride * C)[5 * stride:5 * stride + n * L].reshape(n, L)
         assert np.array_equal(ct5, orc.encrypt(KEY, 1, 5, "double", 16, b, pt))
-        t_round = t_enc_batch + t_agg + t_dec
+        t_round = t_enc_batch + min(t_agg + t_dec, t_aggdec)
         res[f"b{b}"] = {"encrypt_us": t_enc * 1e3, "encrypt_all_clients_batched_us": t_enc_batch * 1e3, "prepare_encrypt_us": t_prep * 1e3, "encrypt_precomputed_us": t_enc_pre * 1e3,
                         "aggregate_C100_us": t_agg * 1e3, "decrypt_us": t_dec * 1e3, "decrypt_precomputed_us": t_dec_pre * 1e3,
+                        "aggregate_plus_decrypt_fused_us": t_aggdec * 1e3,
                         "round_ms": t_round, "ciphertexts_per_s": C * n / (t_round * 1e-3)}
     out["config3_lenet_C100"] = res
 
