@@ -366,7 +366,8 @@ def test_prf_jobs_vs_oracle(E, oracle, b, n, J):
         eng.prf_jobs_dev(6, n, J, [(3, 4, n - 5, 10, None, 0, many[0][6])])                                        # range past n
 
 
-@pytest.mark.parametrize("b,n,J,C", [(128, 70_001, 16, 10), (100, 5000, 3, 3), (128, 2_100_000, 1, 2), (64, 30_000, 16, 4), (20, 9999, 7, 70)])
+@pytest.mark.parametrize("b,n,J,C", [(128, 70_001, 16, 10), (100, 5000, 3, 3), (128, 2_100_000, 1, 2), (128, 300_000, 16, 13), (64, 30_000, 16, 4),
+                                     (20, 9999, 7, 70)])
 def test_aggregate_decrypt_fused_vs_oracle(E, oracle, b, n, J, C):
     """flashe_aggregate_decrypt_range_dev == aggregate_elem followed by decrypt: equally spaced ciphertexts (one launch for
     b > 64), scattered ones, prefix lists, sub-ranges; with and without storing the aggregate."""
