@@ -70,6 +70,10 @@ _SIGNATURES = {
     "flashe_mask": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_vp]),
     "flashe_encrypt_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, c_vp]),
     "flashe_encrypt": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, c_vp]),
+    "flashe_graph_begin": (c_int, [c_vp]),
+    "flashe_graph_end": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
+    "flashe_graph_launch": (c_int, [c_vp, c_vp]),
+    "flashe_graph_destroy": (c_int, [c_vp]),
     "flashe_prf_jobs_dev": (c_int, [c_vp, c_u32, c_u64, c_u32, c_int, ctypes.POINTER(PrfJob)]),
     "flashe_encrypt_batch_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp)]),
     "flashe_decrypt_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
@@ -93,7 +97,8 @@ _SIGNATURES = {
     "flashe_unpack": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_expand_to_dense_dev": (c_int, [c_vp, c_u64, c_u64, c_vp, c_vp, c_u64p, c_vp]),
     "flashe_expand_to_dense": (c_int, [c_vp, c_u64, c_u64, c_vp, c_vp, c_u64p, c_vp]),
-    "flashe_sparse_aggregate_dev": (c_int, [c_vp, c_u64, c_int, ctypes.POINTER(c_vp), c_u64p, ctypes.POINTER(c_vp), c_u64p, c_vp]),
+    "flashe_sparse_aggregate_dev": (c_int, [c_vp, c_u64, c_int, ctypes.POINTER(c_vp), c_u64p, ctypes.POINTER(c_vp), c_u64p, c_int, c_vp]),
+    "flashe_sparse_minus_mask_sorted_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
     "flashe_sparse_minus_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
     "flashe_sparse_minus_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
     "flashe_sparse_dense_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -128,6 +129,13 @@ struct flashe_ctx {
     Buf stream_tmp;   // whole-vector mask stream for the sparse paths
     Buf acc_tmp[2];   // ping-pong partial sums when a packed reduce has more than kMaxOps operands
     Buf sp_ws;        // sparsifier workspace (select state, histogram, per-block counts)
+    Buf bounds;       // span reduce: first entry of every client in every span
+    bool capturing = false;   // between flashe_graph_begin and flashe_graph_end
+};
+
+struct flashe_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 namespace {
@@ -160,6 +168,8 @@ int fail(flashe_ctx *ctx, int code, const char *fmt, ...)
 int ensure(flashe_ctx *ctx, flashe_ctx::Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return FLASHE_OK;
+    if (ctx->capturing)
+        return fail(ctx, FLASHE_EINVAL, "scratch memory cannot grow while a graph is being captured: run the sequence once before flashe_graph_begin");
     if (b.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); HIP_TRY(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t cap = std::max<size_t>(bytes, 4096);
     HIP_TRY(ctx, hipMalloc(&b.p, cap));
@@ -285,7 +295,7 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     if (!ctx) return FLASHE_EINVAL;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->env.stream);
-    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws})
+    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds})
         if (b->p) (void)hipFree(b->p);
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
     if (ctx->rkw_dev) (void)hipFree(ctx->rkw_dev);
@@ -470,6 +480,58 @@ int flashe_stream_wait_event(flashe_ctx *ctx, void *event)
     return FLASHE_OK;
 }
 
+int flashe_graph_begin(flashe_ctx *ctx)
+{
+    CHECK_CTX(ctx);
+    if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "a capture is already in progress on this context");
+    HIP_TRY(ctx, hipStreamBeginCapture(ctx->env.stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return FLASHE_OK;
+}
+
+int flashe_graph_end(flashe_ctx *ctx, flashe_graph **graph)
+{
+    CHECK_CTX(ctx);
+    if (!ctx->capturing) return fail(ctx, FLASHE_EINVAL, "no capture in progress");
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->env.stream, &g);
+    if (e != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        return fail(ctx, FLASHE_EIO, "hipStreamEndCapture: %s (a call made during the capture was not capturable)", hipGetErrorString(e));
+    }
+    if (!graph) { (void)hipGraphDestroy(g); return fail(ctx, FLASHE_EINVAL, "null graph pointer"); }
+    flashe_graph *out = new (std::nothrow) flashe_graph();
+    if (!out) { (void)hipGraphDestroy(g); return fail(ctx, FLASHE_ENOMEM, "out of host memory"); }
+    out->graph = g;
+    e = hipGraphInstantiate(&out->exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        delete out;
+        return fail(ctx, FLASHE_EIO, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    *graph = out;
+    return FLASHE_OK;
+}
+
+int flashe_graph_launch(flashe_ctx *ctx, flashe_graph *graph)
+{
+    CHECK_CTX(ctx);
+    if (!graph || !graph->exec) return fail(ctx, FLASHE_EINVAL, "null graph");
+    if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "cannot launch a graph while capturing");
+    HIP_TRY(ctx, hipGraphLaunch(graph->exec, ctx->env.stream));
+    return FLASHE_OK;
+}
+
+int flashe_graph_destroy(flashe_graph *graph)
+{
+    if (!graph) return FLASHE_OK;
+    if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+    if (graph->graph) (void)hipGraphDestroy(graph->graph);
+    delete graph;
+    return FLASHE_OK;
+}
+
 int flashe_event_elapsed_ms(flashe_ctx *ctx, void *start, void *stop, float *ms)
 {
     CHECK_CTX(ctx);
@@ -537,8 +599,10 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
         }
         return FLASHE_OK;
     }
-    for (int v0 = 0; v0 < n_vec; v0 += kMaxBatch) {
-        const int nv = std::min(kMaxBatch, n_vec - v0);
+    // equal shares when several launches are needed (100 vectors: 4 x 25, not 32 + 32 + 32 + 4)
+    const int per_launch = n_vec ? (n_vec + (n_vec + kMaxBatch - 1) / kMaxBatch - 1) / ((n_vec + kMaxBatch - 1) / kMaxBatch) : 1;
+    for (int v0 = 0; v0 < n_vec; v0 += per_launch) {
+        const int nv = std::min(per_launch, n_vec - v0);
         HIP_TRY(ctx, launch_prf_batch(ctx->env, iter, scheme == FLASHE_SCHEME_DOUBLE, nv, idx + v0, pt_dev + v0, pt_limbs, ct_dev + v0, n,
                                       n_jobs));
     }
@@ -573,9 +637,10 @@ int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_j
         }
         return FLASHE_OK;
     }
-    for (int e0 = 0; e0 < n_entries; e0 += kMaxBatch) {
+    const int launches = (n_entries + kMaxBatch - 1) / kMaxBatch, per_launch = (n_entries + launches - 1) / launches;
+    for (int e0 = 0; e0 < n_entries; e0 += per_launch) {
         PrfJob jobs[kMaxBatch];
-        const int ne = std::min(kMaxBatch, n_entries - e0);
+        const int ne = std::min(per_launch, n_entries - e0);
         for (int e = 0; e < ne; e++) {
             const flashe_prf_job &j = entries[e0 + e];
             jobs[e] = PrfJob{j.add_idx, j.minus_idx, j.first, j.count, j.in_dev, j.in_limbs, j.out_dev,
@@ -811,7 +876,7 @@ int flashe_expand_to_dense_dev(flashe_ctx *ctx, uint64_t total, uint64_t k, cons
 }
 
 int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
-                                const uint64_t *const *vals_dev, const uint64_t *zeros, uint64_t *out_dev)
+                                const uint64_t *const *vals_dev, const uint64_t *zeros, int sorted, uint64_t *out_dev)
 {
     CHECK_CTX(ctx);
     if (C < 0 || (C && (!loc_dev || !k || !vals_dev || !zeros)) || (total && !out_dev)) return fail(ctx, FLASHE_EINVAL, "bad arguments");
@@ -828,6 +893,18 @@ int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const ui
     }
     // sum_c expand_to_dense(c) = (sum_c zero_c everywhere) + per client (vals_c[q] - zero_c) at loc_c[q]; the clients go one
     // after the other because their location sets overlap
+    if (sorted && C > 0) {
+        // strictly increasing location lists: LDS-staged span reduce, the dense output is written exactly once
+        int rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(std::min(C, kMaxScatter)) * sizeof(uint32_t));
+        if (rc) return rc;
+        for (int c0 = 0; c0 < C; c0 += kMaxScatter) {
+            const int nc = std::min(kMaxScatter, C - c0);
+            HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, vals_dev + c0, k + c0, zeros + static_cast<size_t>(L) * c0,
+                                            c0 ? 0 : static_cast<uint64_t>(zsum), c0 ? 0 : static_cast<uint64_t>(zsum >> 64), total,
+                                            static_cast<uint32_t *>(ctx->bounds.p), c0 != 0, out_dev));
+        }
+        return FLASHE_OK;
+    }
     HIP_TRY(ctx, launch_fill(ctx->env, total, static_cast<uint64_t>(zsum), static_cast<uint64_t>(zsum >> 64), out_dev));
     for (int c = 0; c < C; c++)
         HIP_TRY(ctx, launch_scatter(ctx->env, k[c], loc_dev[c], vals_dev[c], out_dev, true, zeros[static_cast<size_t>(L) * c],
@@ -835,31 +912,43 @@ int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const ui
     return FLASHE_OK;
 }
 
-int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
-                                 uint64_t total, uint32_t n_jobs, uint64_t *out_dev)
+static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                  uint64_t total, uint32_t n_jobs, bool sorted, uint64_t *out_dev)
 {
     CHECK_CTX(ctx);
     if (C < 0 || (C && (!loc_dev || !k)) || (total && !out_dev) || n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "bad arguments");
     if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
-    if (total) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
     uint64_t kmax = 0;
     for (int c = 0; c < C; c++) kmax = std::max(kmax, k[c]);
+    const bool jobs_path = ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE);
+    if (!(sorted && jobs_path && C > 0) && total) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
     if (ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE)) {
         // m = 1: the compact streams do not depend on their length, so up to kMaxBatch clients' streams come from one
         // job-list launch; the scatters stay one per client (location sets overlap between clients)
         const uint64_t kpad = (kmax + 1) & ~1ull;
-        const int group = std::min(C, kMaxBatch);
+        const int group = std::min(C, sorted ? kMaxScatter : kMaxBatch);     // clients whose streams are held at once
         int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kpad) * static_cast<size_t>(std::max(group, 1)));
         if (rc) return rc;
+        if (sorted && C > 0 && (rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(group) * sizeof(uint32_t)))) return rc;
         uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
         for (int c0 = 0; c0 < C; c0 += group) {
-            PrfJob jobs[kMaxBatch];
             const int nc = std::min(group, C - c0);
-            for (int e = 0; e < nc; e++)
-                jobs[e] = PrfJob{static_cast<uint32_t>(c0 + e), 0u, 0, k[c0 + e], nullptr, 0, tmp + 2 * kpad * static_cast<uint64_t>(e)};
-            HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nc, jobs, kmax));
-            for (int e = 0; e < nc; e++)
-                HIP_TRY(ctx, launch_scatter(ctx->env, k[c0 + e], loc_dev[c0 + e], tmp + 2 * kpad * static_cast<uint64_t>(e), out_dev, true));
+            const uint64_t *streams[kMaxScatter];
+            for (int e = 0; e < nc; e++) streams[e] = tmp + 2 * kpad * static_cast<uint64_t>(e);
+            for (int j0 = 0; j0 < nc; j0 += kMaxBatch) {
+                PrfJob jobs[kMaxBatch];
+                const int nj = std::min(kMaxBatch, nc - j0);
+                for (int e = 0; e < nj; e++)
+                    jobs[e] = PrfJob{static_cast<uint32_t>(c0 + j0 + e), 0u, 0, k[c0 + j0 + e], nullptr, 0, tmp + 2 * kpad * static_cast<uint64_t>(j0 + e)};
+                HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nj, jobs, kmax));
+            }
+            if (sorted) {
+                HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, streams, k + c0, nullptr, 0, 0, total,
+                                                static_cast<uint32_t *>(ctx->bounds.p), c0 != 0, out_dev));
+            } else {
+                for (int e = 0; e < nc; e++)
+                    HIP_TRY(ctx, launch_scatter(ctx->env, k[c0 + e], loc_dev[c0 + e], streams[e], out_dev, true));
+            }
         }
         return FLASHE_OK;
     }
@@ -873,6 +962,18 @@ int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const ui
         HIP_TRY(ctx, launch_scatter(ctx->env, k[c], loc_dev[c], tmp, out_dev, true));
     }
     return FLASHE_OK;
+}
+
+int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                 uint64_t total, uint32_t n_jobs, uint64_t *out_dev)
+{
+    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, false, out_dev);
+}
+
+int flashe_sparse_minus_mask_sorted_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                        uint64_t total, uint32_t n_jobs, uint64_t *out_dev)
+{
+    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, true, out_dev);
 }
 
 int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel_dev, uint64_t total,
@@ -1150,16 +1251,19 @@ int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32
     if (C < 0 || (C && (!loc || !k)) || !out) return fail(ctx, FLASHE_EINVAL, "bad arguments");
     std::vector<Tmp> dl(C);
     std::vector<const uint32_t *> ptrs(C);
+    bool sorted = true;            // the reference's lists are (jzf_aggregator.py:598); then the one-pass span reduce applies
     for (int c = 0; c < C; c++) {
-        for (uint64_t q = 0; q < k[c]; q++)
+        for (uint64_t q = 0; q < k[c]; q++) {
             if (loc[c][q] >= total) return fail(ctx, FLASHE_EINVAL, "client %d location out of range", c);
+            if (q && loc[c][q] <= loc[c][q - 1]) sorted = false;
+        }
         HIP_TRY(ctx, dl[c].alloc(static_cast<size_t>(k[c]) * 4));
         if (k[c]) H2D(dl[c].p, loc[c], static_cast<size_t>(k[c]) * 4);
         ptrs[c] = dl[c].as<uint32_t>();
     }
     Tmp dout;
     HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, total)));
-    int rc = flashe_sparse_minus_mask_dev(ctx, iter, C, ptrs.data(), k, total, n_jobs, dout.as<uint64_t>());
+    int rc = sparse_minus_mask_impl(ctx, iter, C, ptrs.data(), k, total, n_jobs, sorted, dout.as<uint64_t>());
     if (rc) return rc;
     D2H(out, dout.p, vec_bytes(ctx, total));
     return FLASHE_OK;

@@ -1373,6 +1373,126 @@ __global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t k, int
     }
 }
 
+// Sparse reduce over SORTED location lists, two launches for any number of clients.
+// The dense vector is cut into spans of kSpan positions, one workgroup each.  Kernel A: start[s][c] = first entry of
+// client c at or beyond position s * kSpan (one binary search per (span, client)).  Kernel B: the workgroup clears a
+// span-sized accumulator in LDS, adds every client's entries that fall into its span (128-bit add = two LDS atomics;
+// the low one returns the old value, which tells the lane exactly whether ITS add wrapped -- integer adds commute,
+// so the sum does not depend on the order), then writes base + accumulator for the WHOLE span: the dense output is
+// written exactly once, coalesced, and never read.
+constexpr int kSpan = 2048;
+struct ScatterTable {
+    const uint32_t *loc[kMaxScatter];
+    const uint64_t *vals[kMaxScatter];
+    uint64_t k[kMaxScatter], sub_lo[kMaxScatter], sub_hi[kMaxScatter];
+};
+
+__global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const ScatterTable tb, int C, uint64_t n_spans, uint32_t *start)
+{
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x;
+    if (i >= (n_spans + 1) * static_cast<uint64_t>(C)) return;
+    const int c = static_cast<int>(i % C);
+    const uint64_t pos = (i / C) * kSpan;
+    const uint32_t *loc = tb.loc[c];
+    uint64_t lo = 0, hi = tb.k[c];
+    while (lo < hi) {                                   // lower_bound(loc, pos)
+        const uint64_t mid = (lo + hi) >> 1;
+        if (loc[mid] < pos) lo = mid + 1; else hi = mid;
+    }
+    start[i] = static_cast<uint32_t>(lo);
+}
+
+__global__ __launch_bounds__(kStreamThreads) void span_reduce_kernel(const ScatterTable tb, int C, int L, uint64_t total, const uint32_t *start,
+                                                                     uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo, uint64_t mask_hi,
+                                                                     bool accumulate_into_out, uint64_t *out)
+{
+    __shared__ unsigned long long acc[2 * kSpan];
+    __shared__ uint32_t s_begin[kMaxScatter], s_prefix[kMaxScatter + 1];
+    __shared__ const uint32_t *s_loc[kMaxScatter];
+    __shared__ const uint64_t *s_vals[kMaxScatter];
+    __shared__ uint64_t s_sub[2 * kMaxScatter];
+    const uint64_t span = blockIdx.x, p0 = span * kSpan;
+    const uint64_t span_len = total - p0 < kSpan ? total - p0 : kSpan;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * kSpan; i += kStreamThreads) acc[i] = 0;
+    // this span's slice [begin, begin + count) of every client's list, and the running total of the counts: the entries
+    // of ALL clients are then walked as one flat index space, so every load of the span is independent of the others
+    if (tid < C) {
+        const uint32_t b0 = start[span * C + tid], b1 = start[(span + 1) * C + tid];
+        s_begin[tid] = b0;
+        s_prefix[tid + 1] = b1 - b0;
+        s_loc[tid] = tb.loc[tid]; s_vals[tid] = tb.vals[tid];
+        s_sub[2 * tid] = tb.sub_lo[tid]; s_sub[2 * tid + 1] = tb.sub_hi[tid];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        s_prefix[0] = 0;
+        for (int c = 0; c < C; c++) { run += s_prefix[c + 1]; s_prefix[c + 1] = run; }
+    }
+    __syncthreads();
+    const uint32_t n_entries = s_prefix[C];
+    for (uint32_t f = tid; f < n_entries; f += kStreamThreads) {
+        int lo = 0, hi = C;                             // client c with s_prefix[c] <= f < s_prefix[c + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_prefix[mid] <= f) lo = mid; else hi = mid;
+        }
+        const int c = lo;
+        const uint64_t q = static_cast<uint64_t>(s_begin[c]) + (f - s_prefix[c]);
+        const uint32_t r = s_loc[c][q] - static_cast<uint32_t>(p0);
+        if (L == 2) {
+            const u128 v = ld128(s_vals[c] + 2 * q) - ((static_cast<u128>(s_sub[2 * c + 1]) << 64) | s_sub[2 * c]);
+            const unsigned long long vlo = static_cast<unsigned long long>(v), vhi = static_cast<unsigned long long>(v >> 64);
+            const unsigned long long old = atomicAdd(&acc[2 * r], vlo);
+            atomicAdd(&acc[2 * r + 1], vhi + (old + vlo < old ? 1ull : 0ull));
+        } else {
+            atomicAdd(&acc[r], static_cast<unsigned long long>(s_vals[c][q] - s_sub[2 * c]));
+        }
+    }
+    __syncthreads();
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const u128 base = (static_cast<u128>(base_hi) << 64) | base_lo;
+    for (uint64_t r = tid; r < span_len; r += kStreamThreads) {
+        if (L == 2) {
+            u128 v = base + ((static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r]);
+            if (accumulate_into_out) v += ld128(out + 2 * (p0 + r));
+            st128_nt(out + 2 * (p0 + r), v & mask);
+        } else {
+            uint64_t v = base_lo + acc[r];
+            if (accumulate_into_out) v += out[p0 + r];
+            __builtin_nontemporal_store(v & mask_lo, out + p0 + r);
+        }
+    }
+}
+
+uint64_t span_count(uint64_t total) { return (total + kSpan - 1) / kSpan; }
+
+// out[p] = base + sum over clients c and entries q with loc[c][q] == p of (vals[c][q] - sub[c])   (mod 2^b), every p < total;
+// loc[c] strictly increasing.  start_dev: (span_count(total) + 1) * C words of scratch.
+hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
+                              const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
+                              uint32_t *start_dev, bool accumulate_into_out, uint64_t *out_dev)
+{
+    if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    const int L = env.b > 64 ? 2 : 1;
+    ScatterTable tb{};
+    for (int c = 0; c < C; c++) {
+        tb.loc[c] = loc_dev[c]; tb.vals[c] = vals_dev[c]; tb.k[c] = k[c];
+        tb.sub_lo[c] = sub ? sub[static_cast<size_t>(L) * c] : 0;
+        tb.sub_hi[c] = sub && L == 2 ? sub[2 * c + 1] : 0;
+    }
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_spans = span_count(total), n_bounds = (n_spans + 1) * static_cast<uint64_t>(C);
+    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>((n_bounds + kStreamThreads - 1) / kStreamThreads)), dim3(kStreamThreads), 0,
+                       env.stream, tb, C, n_spans, start_dev);
+    hipLaunchKernelGGL(span_reduce_kernel, dim3(static_cast<unsigned>(n_spans)), dim3(kStreamThreads), 0, env.stream, tb, C, L, total, start_dev,
+                       base_lo, base_hi, lo, hi, accumulate_into_out, out_dev);
+    return hipGetLastError();
+}
+
 // out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
 __global__ __launch_bounds__(kStreamThreads) void sel_accumulate_kernel(uint64_t n, int L, const uint8_t *sel, const uint64_t *stream,
                                                                         uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)

@@ -87,6 +87,24 @@ class DeviceBuffer:
         return out
 
 
+class Graph:
+    """A captured sequence of device calls (flashe_graph); launch() replays it on the engine's stream."""
+
+    def __init__(self, engine, handle):
+        self.engine, self._g = engine, handle
+
+    def launch(self):
+        self.engine._check(self.engine._lib.flashe_graph_launch(self.engine._h, self._g))
+
+    def __del__(self):
+        try:
+            if self._g:
+                self.engine._lib.flashe_graph_destroy(self._g)
+                self._g = None
+        except Exception:
+            pass
+
+
 class Engine:
     """One device context of the cipher engine (wraps flashe_ctx)."""
 
@@ -146,6 +164,15 @@ class Engine:
 
     def sync(self):
         self._check(self._lib.flashe_sync(self._h))
+
+    # -- HIP graph capture / replay of a sequence of *_dev calls ---------------------------------
+    def graph_begin(self):
+        self._check(self._lib.flashe_graph_begin(self._h))
+
+    def graph_end(self):
+        g = c_vp()
+        self._check(self._lib.flashe_graph_end(self._h, ctypes.byref(g)))
+        return Graph(self, g)
 
     def event(self):
         ev = c_vp()
@@ -266,9 +293,10 @@ class Engine:
         self._check(self._lib.flashe_expand_to_dense_dev(self._h, total, k, self._ptr(loc), self._ptr(vals),
                                                          ctypes.cast(z, c_u64p), self._ptr(out)))
 
-    def sparse_aggregate_dev(self, total, locs, ks, vals, zeros, out):
+    def sparse_aggregate_dev(self, total, locs, ks, vals, zeros, out, sorted_lists=False):
         """out = sum over clients of expand_to_dense(total, locs[c], vals[c], zeros[c]) mod 2^b, without the dense
-        intermediates.  zeros: per client a sequence of L limbs (or an int)."""
+        intermediates.  zeros: per client a sequence of L limbs (or an int).  sorted_lists: every location list is
+        strictly increasing (one-pass LDS-staged form)."""
         pl, _kl = self._ptr_array(locs)
         pv, _kv = self._ptr_array(vals)
         k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
@@ -278,13 +306,13 @@ class Engine:
             flat += z[:self.limbs]
         zz = (c_u64 * max(len(flat), 1))(*flat)
         self._check(self._lib.flashe_sparse_aggregate_dev(self._h, total, len(locs), pl, ctypes.cast(k, c_u64p), pv,
-                                                          ctypes.cast(zz, c_u64p), self._ptr(out)))
+                                                          ctypes.cast(zz, c_u64p), 1 if sorted_lists else 0, self._ptr(out)))
 
-    def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out):
+    def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out, sorted_lists=False):
         p, _keep = self._ptr_array(locs)
         k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
-        self._check(self._lib.flashe_sparse_minus_mask_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs,
-                                                           self._ptr(out)))
+        fn = self._lib.flashe_sparse_minus_mask_sorted_dev if sorted_lists else self._lib.flashe_sparse_minus_mask_dev
+        self._check(fn(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, self._ptr(out)))
 
     def sparse_dense_mask_dev(self, it, sels, total, out):
         p, _keep = self._ptr_array(sels)

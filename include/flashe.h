@@ -96,6 +96,17 @@ int flashe_event_elapsed_ms(flashe_ctx *ctx, void *start, void *stop, float *ms)
  * same device: the fork/join primitive for running e.g. the arbiter reduce on a second stream. */
 int flashe_stream_wait_event(flashe_ctx *ctx, void *event);
 
+/* Capture and replay (HIP graphs): the *_dev calls made on ctx between begin and end are recorded instead of
+ * run; launch replays the whole sequence with one submission -- for launch-bound work such as a round over a
+ * LeNet-sized model (six kernels of 10-60 us).  Pointers and scalar arguments are frozen into the graph: replay
+ * with new DATA in the same buffers.  Host-pointer twins, syncs and event timing are not capturable, and
+ * ctx-owned scratch must already have its size: run the sequence once normally before capturing it. */
+typedef struct flashe_graph flashe_graph;
+int flashe_graph_begin(flashe_ctx *ctx);
+int flashe_graph_end(flashe_ctx *ctx, flashe_graph **graph);
+int flashe_graph_launch(flashe_ctx *ctx, flashe_graph *graph);
+int flashe_graph_destroy(flashe_graph *graph);
+
 /* ---- PRF mask streams -------------------------------------------------------------- */
 /* out[j] = sum_k term(iter, idx[k], j) mod 2^b, chunked like chunks_idx(range(n), n_jobs).
  * n_idx == 1 is _static_prepare_encrypt_single (jzf_flashe.py:19-45), i.e. one stream of
@@ -242,15 +253,21 @@ int flashe_expand_to_dense(flashe_ctx *ctx, uint64_t total, uint64_t k, const ui
  * mod 2^b -- Arbiter.expand_to_dense (jzf_aggregator.py:150-165, :382-384) for every client followed by the
  * element-wise reduce (:424-430) -- without materialising the C dense vectors: the sum of the zero values is
  * written everywhere, then each client's (vals[q] - zero_c) is added at loc[c][q].  loc / vals are HOST arrays of
- * C device pointers, k a HOST array, zeros a HOST array of C x L limbs; locations are distinct within a client. */
+ * C device pointers, k a HOST array, zeros a HOST array of C x L limbs; locations are distinct within a client.
+ * sorted != 0 promises that every loc[c] is strictly increasing -- what Client.sparsify emits (jzf_aggregator.py:598,
+ * :604) -- and selects the one-pass form: spans of the dense vector are accumulated in LDS and written once. */
 int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
-                                const uint64_t *const *vals_dev, const uint64_t *zeros, uint64_t *out_dev);
+                                const uint64_t *const *vals_dev, const uint64_t *zeros, int sorted, uint64_t *out_dev);
 /* Sparse single-mask dense minus-mask -- set_idx_list_single sparse branch,
  * jzf_flashe.py:316-343: for client c the stream over COMPACT positions 0..k[c]-1 (prefix
  * iter|c, chunks_idx(range(k[c]), n_jobs)) scattered to loc[c][q] and summed over clients.
  * loc is a HOST array of C pointers, k a HOST array. */
 int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev,
                                  const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out_dev);
+/* The same for strictly increasing location lists (see flashe_sparse_aggregate_dev); the host-pointer twin picks it by
+ * itself when the lists qualify. */
+int flashe_sparse_minus_mask_sorted_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev,
+                                        const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out_dev);
 int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc,
                              const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out);
 /* Dense-position selected masks -- _static_prepare_decrypt_spar as ONE chunk

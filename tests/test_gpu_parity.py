@@ -405,6 +405,55 @@ def test_aggregate_decrypt_fused_vs_oracle(E, oracle, b, n, J, C):
         assert np.array_equal(ao.download(np.uint64, n * Lb).reshape(n, Lb), agg)
 
 
+@pytest.mark.parametrize("b,n,C", [(128, 61_706, 12), (23, 61_706, 6)])
+def test_graph_capture_replays_a_round(E, oracle, b, n, C):
+    """flashe_graph_*: a whole round (batched encrypt, reduce, decrypt) captured once and replayed on NEW data in the same
+    buffers; growth of ctx scratch during a capture is refused."""
+    eng = make(E, b)
+    Lb = L(b)
+    rng = np.random.Generator(np.random.PCG64(b))
+    dpt = [eng.alloc(8 * n) for _ in range(C)]
+    dct = [eng.alloc_vec(n) for _ in range(C)]
+    dagg, dout = eng.alloc_vec(n), eng.alloc_vec(n)
+
+    def round_calls():
+        eng.encrypt_batch_dev(7, list(range(C)), E.SCHEME_DOUBLE, n, 16, dpt, 1, dct)
+        eng.aggregate_elem_dev(dct, n, dagg)
+        eng.decrypt_dev(7, [C], [0], n, 16, dagg, dout)
+
+    round_calls()                                   # sizes every scratch buffer
+    eng.graph_begin()
+    round_calls()
+    g = eng.graph_end()
+    for rep in range(3):
+        pts = [rng.integers(0, 2 ** min(b - 8, 60), n, dtype=np.uint64) for _ in range(C)]
+        for d, p in zip(dpt, pts):
+            d.upload(p)
+        g.launch()
+        got = dout.download(np.uint64, n * Lb).reshape(n, Lb)
+        want = np.zeros(n, dtype=np.uint64)
+        for p in pts:
+            want += p
+        assert np.array_equal(got[:, 0], want & np.uint64((1 << min(b, 64)) - 1 if b < 64 else 2 ** 64 - 1)), rep
+        ct3 = dct[3].download(np.uint64, n * Lb).reshape(n, Lb)
+        assert np.array_equal(ct3, oracle.encrypt(KEY, 7, 3, "double", 16, b, pts[3])), rep
+    # scratch growth inside a capture is refused, the capture still ends cleanly
+    big = make(E, 64)
+    ops = [big.upload(rng.integers(0, 2 ** 64, 50_000, dtype=np.uint64)) for _ in range(3)]
+    o = big.alloc(8 * 50_000)
+    big.graph_begin()
+    with pytest.raises(Exception):
+        big.aggregate_packed_dev(ops, 50_000, 64 * 50_000, o)          # needs the block-summary scratch
+    with pytest.raises(Exception):
+        big.graph_begin()                                               # already capturing
+    try:
+        big.graph_end()
+    except Exception:
+        pass
+    big.aggregate_packed_dev(ops, 50_000, 64 * 50_000, o)              # works outside a capture
+    big.sync()
+
+
 def test_u64_plaintext_zero_extension(E, oracle):
     rng = np.random.Generator(np.random.PCG64(3))
     eng = make(E, 128)
@@ -546,7 +595,8 @@ def test_sparse_config5_shape_small(E, oracle):
     assert np.array_equal(dec, oracle.combine(b, oracle.aggregate_elem(dense, b), None, mm))
 
 
-@pytest.mark.parametrize("b,total,C", [(128, 50_000, 7), (100, 4099, 3), (64, 30_001, 5), (20, 9999, 9), (128, 64, 4)])
+@pytest.mark.parametrize("b,total,C", [(128, 50_000, 7), (100, 4099, 3), (64, 30_001, 5), (20, 9999, 9), (128, 64, 4), (128, 300_000, 70), (128, 2048, 2),
+                                       (128, 2049, 2)])
 def test_sparse_aggregate_fused_vs_dense_path(E, oracle, b, total, C):
     """flashe_sparse_aggregate_dev == expand_to_dense per client + element-wise reduce (overlapping location sets,
     full-range zero values, an empty client, a client that covers every position)."""
@@ -563,8 +613,21 @@ def test_sparse_aggregate_fused_vs_dense_path(E, oracle, b, total, C):
     dl = [eng.upload(l if len(l) else np.zeros(1, dtype=np.uint32)) for l in locs]
     dv = [eng.upload(v if len(v) else np.zeros((1, Lb), dtype=np.uint64)) for v in vals]
     out = eng.alloc_vec(total)
-    eng.sparse_aggregate_dev(total, dl, ks, dv, zeros, out)
+    for sorted_lists in (False, True):
+        out.upload(np.full(total * Lb, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64))      # stale contents must not matter
+        eng.sparse_aggregate_dev(total, dl, ks, dv, zeros, out, sorted_lists=sorted_lists)
+        assert np.array_equal(out.download(np.uint64, total * Lb).reshape(total, Lb), want), sorted_lists
+    # unsorted (shuffled) lists through the general form
+    perm = [rng.permutation(k) for k in ks]
+    dl2 = [eng.upload(l[p] if len(l) else np.zeros(1, dtype=np.uint32)) for l, p in zip(locs, perm)]
+    dv2 = [eng.upload(v[p] if len(v) else np.zeros((1, Lb), dtype=np.uint64)) for v, p in zip(vals, perm)]
+    eng.sparse_aggregate_dev(total, dl2, ks, dv2, zeros, out, sorted_lists=False)
     assert np.array_equal(out.download(np.uint64, total * Lb).reshape(total, Lb), want)
+    # the clients' dense minus-mask: sorted one-pass form == general form == oracle
+    mm = oracle.sparse_minus_mask(KEY, 4, locs, total, 16, b)
+    for sorted_lists in (False, True):
+        eng.sparse_minus_mask_dev(4, dl, ks, total, 16, out, sorted_lists=sorted_lists)
+        assert np.array_equal(out.download(np.uint64, total * Lb).reshape(total, Lb), mm), sorted_lists
     if b not in (64, 128):
         with pytest.raises(Exception):                     # a zero value wider than int_bits
             eng.sparse_aggregate_dev(total, dl[:1], ks[:1], dv[:1], [[2 ** 64 - 1, 2 ** 64 - 1]], out)

@@ -61,10 +61,24 @@ def config3(out):
         assert np.array_equal(dout.download(np.uint64, n * L).reshape(n, L), got2)
         ct5 = slab.download(np.uint64, stride * C)[5 * stride:5 * stride + n * L].reshape(n, L)
         assert np.array_equal(ct5, orc.encrypt(KEY, 1, 5, "double", 16, b, pt))
-        t_round = t_enc_batch + min(t_agg + t_dec, t_aggdec)
+        # the whole round as ONE graph launch (6 kernels captured once)
+        def round_calls():
+            eng.encrypt_batch_dev(1, list(range(C)), SCHEME_DOUBLE, n, 16, [dpt] * C, 1, dct)
+            eng.aggregate_elem_dev(dct, n, dagg)
+            eng.decrypt_dev(1, [C], [0], n, 16, dagg, dout)
+        round_calls()
+        eng.graph_begin()
+        round_calls()
+        graph = eng.graph_end()
+        t_graph = timeit(eng, graph.launch)
+        t_calls = timeit(eng, round_calls)
+        graph.launch()
+        assert np.array_equal(dout.download(np.uint64, n * L).reshape(n, L), got2)
+        t_round = min(t_enc_batch + min(t_agg + t_dec, t_aggdec), t_graph)
         res[f"b{b}"] = {"encrypt_us": t_enc * 1e3, "encrypt_all_clients_batched_us": t_enc_batch * 1e3, "prepare_encrypt_us": t_prep * 1e3, "encrypt_precomputed_us": t_enc_pre * 1e3,
                         "aggregate_C100_us": t_agg * 1e3, "decrypt_us": t_dec * 1e3, "decrypt_precomputed_us": t_dec_pre * 1e3,
                         "aggregate_plus_decrypt_fused_us": t_aggdec * 1e3,
+                        "round_as_separate_calls_us": t_calls * 1e3, "round_as_one_graph_launch_us": t_graph * 1e3,
                         "round_ms": t_round, "ciphertexts_per_s": C * n / (t_round * 1e-3)}
     out["config3_lenet_C100"] = res
 
@@ -95,24 +109,27 @@ def config5(out):
     for c in range(C):
         eng.expand_to_dense_dev(total, k, dloc[c], dct[c], zero, ddense[c])
     t_agg = timeit(eng, lambda: eng.aggregate_elem_dev(ddense, total, dagg), reps=5)
-    t_mask = timeit(eng, lambda: eng.sparse_minus_mask_dev(it, dloc, [k] * C, total, J, dmask), reps=5)
+    t_mask_general = timeit(eng, lambda: eng.sparse_minus_mask_dev(it, dloc, [k] * C, total, J, dmask), reps=5)
+    t_mask = timeit(eng, lambda: eng.sparse_minus_mask_dev(it, dloc, [k] * C, total, J, dmask, sorted_lists=True), reps=5)
     t_dec = timeit(eng, lambda: eng.combine_dev(total, dagg, 2, None, dmask, dout), reps=5)
     # spot check against the oracle on client 7's ciphertext
     ct7 = dct[7].download(np.uint64, 2 * k).reshape(k, 2)
     assert np.array_equal(ct7, orc.encrypt(KEY, it, 7, "single", J, b, dpt.download(np.uint64, k)))
     dvals_zero = [zero] * C
-    t_sagg = timeit(eng, lambda: eng.sparse_aggregate_dev(total, dloc, [k] * C, dct, dvals_zero, dout), reps=5)
-    eng.sparse_aggregate_dev(total, dloc, [k] * C, dct, dvals_zero, dout)
+    t_sagg_general = timeit(eng, lambda: eng.sparse_aggregate_dev(total, dloc, [k] * C, dct, dvals_zero, dout), reps=5)
+    t_sagg = timeit(eng, lambda: eng.sparse_aggregate_dev(total, dloc, [k] * C, dct, dvals_zero, dout, sorted_lists=True), reps=5)
+    eng.sparse_aggregate_dev(total, dloc, [k] * C, dct, dvals_zero, dout, sorted_lists=True)
     eng.aggregate_elem_dev(ddense, total, dagg)
     assert np.array_equal(dout.download(np.uint64, 400000), dagg.download(np.uint64, 400000))     # fused == dense path
     idxs = list(range(C))
     t_enc_batch = timeit(eng, lambda: eng.encrypt_batch_dev(it, idxs, SCHEME_SINGLE, k, J, [dpt] * C, 1, dct), reps=5)
-    t_round_dense = C * (t_enc + t_expand) + t_agg + t_mask + t_dec
+    t_round_dense = C * (t_enc + t_expand) + t_agg + t_mask_general + t_dec
     t_round = t_enc_batch + t_sagg + t_mask + t_dec
     out["config5_sparse_top1pct_C50"] = {
         "k": k, "total": total, "encrypt_compact_us": t_enc * 1e3, "expand_to_dense_ms": t_expand, "aggregate_dense_C50_ms": t_agg,
         "aggregate_dense_TBps": 16 * (C + 1) * total / (t_agg * 1e-3) / 1e12, "sparse_minus_mask_ms": t_mask, "decrypt_ms": t_dec,
-        "encrypt_all_clients_batched_ms": t_enc_batch, "sparse_aggregate_fused_ms": t_sagg,
+        "encrypt_all_clients_batched_ms": t_enc_batch, "sparse_aggregate_fused_ms": t_sagg, "sparse_aggregate_unsorted_lists_ms": t_sagg_general,
+        "sparse_minus_mask_unsorted_lists_ms": t_mask_general,
         "round_dense_path_ms": t_round_dense, "round_ms": t_round, "sparse_ciphertexts_per_s": C * k / (t_round * 1e-3),
         "host_index_generation_s": gen_s}
 
