@@ -115,7 +115,8 @@ def cpu_baseline(args, host_pts):
     return {"value": C * ns / best[0], "unit": "ciphertexts/s", "cores": cores, "kind": "port",
             "sample": f"best of 5 full rounds (C={C} encrypts + aggregate + decrypt, b={b}, double mask) on the first {ns} of "
                       f"{args.n} elements of the workload; oracle/flashe_oracle.c, "
-                      f"{'AES-NI' if orc.aesni_available() else 'table'} AES-256, OpenMP x{cores}",
+                      f"{'AVX-512 VAES x16' if orc.vaes_available() else 'AES-NI x8' if orc.aesni_available() else 'table'} AES-256, "
+                      f"OpenMP x{cores}",
             "phases_s": {"encrypt_xC": best[1], "aggregate": best[2], "decrypt": best[3]},
             "round_s_all": [r[0] for r in rounds]}
 

@@ -311,6 +311,15 @@ def set_aesni(on):
     lib().fo_set_aesni(ctypes.c_int(1 if on else 0))
 
 
+def vaes_available():
+    return bool(lib().fo_vaes_available())
+
+
+def set_vaes(on):
+    """Allow (True) or forbid (False) the AVX-512 VAES form of the AES-NI path."""
+    lib().fo_set_vaes(ctypes.c_int(1 if on else 0))
+
+
 def num_threads():
     return int(lib().fo_num_threads())
 

@@ -239,10 +239,15 @@ def test_aesni_and_table_paths_agree(oracle):
                 pt &= np.uint64((1 << b) - 1)
             oracle.set_aesni(False)
             a = oracle.encrypt(KEY, 5, 7, "double", J, b, pt)
+            m = oracle.mask(KEY, 5, 9, n, J, b)
             oracle.set_aesni(True)
-            assert np.array_equal(a, oracle.encrypt(KEY, 5, 7, "double", J, b, pt))
+            for vaes in (False, True):                 # 8-way AES-NI, then (when the CPU has it) 16-way VAES
+                oracle.set_vaes(vaes)
+                assert np.array_equal(a, oracle.encrypt(KEY, 5, 7, "double", J, b, pt)), (b, vaes)
+                assert np.array_equal(m, oracle.mask(KEY, 5, 9, n, J, b)), (b, vaes)
     finally:
         oracle.set_aesni(True)
+        oracle.set_vaes(True)
 
 
 def test_telescope_examples(oracle):
