@@ -627,7 +627,7 @@ int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_j
         int rc = check_prf_args(ctx, 1, dbl, n_jobs, j.out_dev, j.in_dev, j.in_dev ? j.in_limbs : 0);
         if (rc) return rc;
     }
-    const bool one_launch = ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE);
+    const bool one_launch = ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE || ctx->limbs == 1;
     if (!one_launch) {
         for (int e = 0; e < n_entries; e++) {
             const flashe_prf_job &j = entries[e];
@@ -646,7 +646,7 @@ int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_j
             jobs[e] = PrfJob{j.add_idx, j.minus_idx, j.first, j.count, j.in_dev, j.in_limbs, j.out_dev,
                              j.n_in ? j.n_in : 1u, j.in_stride * 2, j.n_in > 1 ? j.sum_out_dev : nullptr};
         }
-        HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, dbl != 0, ne, jobs, n));
+        HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, dbl != 0, ne, jobs, n, n_jobs));
     }
     return FLASHE_OK;
 }
@@ -778,7 +778,7 @@ int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uin
     if (strided) {
         const PrfJob job{add_idx[0], n_minus ? minus_idx[0] : 0u, first, count, cts_dev[0], 2, out_dev,
                          static_cast<uint32_t>(C), stride, agg_out_dev};
-        HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, n_minus == 1, 1, &job, n));
+        HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, n_minus == 1, 1, &job, n, n_jobs));
         return FLASHE_OK;
     }
     uint64_t *agg = agg_out_dev;
@@ -940,7 +940,7 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
                 const int nj = std::min(kMaxBatch, nc - j0);
                 for (int e = 0; e < nj; e++)
                     jobs[e] = PrfJob{static_cast<uint32_t>(c0 + j0 + e), 0u, 0, k[c0 + j0 + e], nullptr, 0, tmp + 2 * kpad * static_cast<uint64_t>(j0 + e)};
-                HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nj, jobs, kmax));
+                HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nj, jobs, kmax, n_jobs));
             }
             if (sorted) {
                 HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, streams, k + c0, nullptr, 0, 0, total,

@@ -44,7 +44,7 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
                             const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n,
                             uint32_t n_jobs);
 
-// General form of the batched launch (b > 64 only): out[k] = in[k] + term(iter, add_idx, first + k)
+// General form of the batched launch: out[k] = in[k] + term(iter, add_idx, first + k)
 // - [dbl] term(iter, minus_idx, first + k) for k < count; in_dev may be null (zeros); pointers address element `first`.
 // n_in > 1 (in_limbs == 2 only): the input is the mod-2^b sum of n_in vectors, vector c at in_dev + c * in_stride
 // limbs -- the arbiter's reduce fused into the decrypt of its result; sum_out_dev (optional) receives that sum.
@@ -58,7 +58,8 @@ struct PrfJob {
     uint64_t in_stride = 0;
     uint64_t *sum_out_dev = nullptr;
 };
-hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n);
+hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n,
+                           uint32_t n_jobs);
 
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
                           const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);

@@ -394,12 +394,6 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
 }
 
 // ---- one add / at most one minus prefix: many independent jobs in one launch ----
-struct BatchTable {
-    uint32_t idx[kMaxBatch];
-    const uint64_t *in[kMaxBatch];
-    uint64_t *out[kMaxBatch];
-};
-
 // One launch = up to kMaxBatch jobs; job v covers global elements [first, first + count) of an n-element
 // vector: out[k] = in[k] + term(iter, add, first + k) - [DBL] term(iter, minus, first + k), in = 0 when null.
 // encrypt: (idx, idx + 1, pt); telescoped decrypt: (C, 0, aggregate); mask precompute: in = null.
@@ -707,25 +701,95 @@ __global__ __launch_bounds__(kBsThreads, WAVES) void prf_wide_bsp_kernel(const u
     }
 }
 
-// ---- batched form of prf_small_kernel for encrypts: n_vec vectors of equal length, one prefix pair each ----
+// ---- b <= 64, one add / at most one minus prefix: many jobs per launch, coalesced element traffic ----
+// A lane still encrypts one AES block (m = 128 / b elements, counter = chunk begin + block index), but the m
+// elements are no longer loaded / stored by that lane (lane-strided 8-byte accesses, m * 8 bytes apart).  A wave
+// owns 64 consecutive blocks = 64 * m consecutive elements: every lane packs its block's per-slot result
+//     D = slot-wise (S_add - S_minus) mod 2^b        (one SWAR subtraction on the 128-bit word)
+// into a 16-byte row of a per-wave LDS scratch, and the wave then walks its elements 64 at a time, lane-contiguous:
+// element x of the tile reads the b-bit window of row x / m at bit b * (x % m), adds the plaintext and stores --
+// full coalesced bursts.  Tiles that contain a partial block (chunk ends) or run past the job take the per-lane path.
+struct SmallJobTable {
+    uint32_t add[kMaxBatch], minus[kMaxBatch];
+    uint64_t first[kMaxBatch], count[kMaxBatch];            // element range of the job (global indices)
+    uint64_t blk_first[kMaxBatch], blk_count[kMaxBatch];    // AES blocks intersecting it (global block numbering)
+    uint64_t tile_end[kMaxBatch];                           // running total of 1024-block workgroup tiles
+    const uint64_t *in[kMaxBatch];                          // may be null; indexed by (element - first)
+    uint64_t *out[kMaxBatch];
+};
+
+struct SmallParams {
+    uint64_t n;               // length of the whole vector (defines the chunking)
+    uint32_t n_jobs, iter;
+    int b, m;
+    uint32_t m_magic;         // ceil(2^32 / m): x / m == (x * m_magic) >> 32 for x < 2^13
+    uint64_t mask_lo;
+    uint64_t top_lo, top_hi;  // the top bit of every b-bit slot of the 128-bit word (SWAR subtraction)
+    uint32_t nb1_magic, nb0_magic;   // floor(2^32 / nb1), floor(2^32 / nb0): 32-bit block -> chunk division without a divide
+    const uint32_t *te0;
+};
+
+// x / dsr for 32-bit operands with magic = floor(2^32 / dsr) (dsr >= 2; dsr == 1 is handled by the caller): the estimate is at most
+// two short, fixed up by comparisons -- ~8 instructions instead of the ~100 of a 64-bit division per AES block.
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t dsr, uint32_t magic)
+{
+    uint32_t q = __umulhi(x, magic);
+    uint32_t rem = x - q * dsr;
+    if (rem >= dsr) { q++; rem -= dsr; }
+    if (rem >= dsr) { q++; }
+    return q;
+}
+
 template <bool DBL>
-__global__ __launch_bounds__(kSmallThreads) void prf_small_batch_kernel(const RoundKeys rk, const BatchTable tb, int n_vec, const PrfParams p)
+__global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const RoundKeys rk, const SmallJobTable tb, int n_vec, const SmallParams p)
 {
     __shared__ uint32_t tab[kTabWords];
+    __shared__ uint32_t scratch[(kSmallThreads / 64) * 256 + 8];
     fill_tables(tab, p.te0);
     const LaneRegs lr = lane_regs(tab);
     const uint64_t J = p.n_jobs, d = p.n / J, r = p.n % J;
     const uint64_t m = static_cast<uint64_t>(p.m);
     const uint64_t nb1 = (d + 1 + m - 1) / m;
     const uint64_t nb0 = d ? (d + m - 1) / m : 0;
-    const uint64_t blocks_per_vec = r * nb1 + (J - r) * nb0;
-    const uint64_t total = blocks_per_vec * static_cast<uint64_t>(n_vec);
-
-    for (uint64_t G = static_cast<uint64_t>(blockIdx.x) * kSmallThreads + threadIdx.x; G < total;
-         G += static_cast<uint64_t>(gridDim.x) * kSmallThreads) {
-        const uint64_t v = G / blocks_per_vec, B = G - v * blocks_per_vec;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    uint32_t *row0 = scratch + wave * 256;
+    const bool ctr_fast = ((p.n - 1) >> 32) == 0;           // every counter (chunk begin + block index) is below n
+    const u128 top = (static_cast<u128>(p.top_hi) << 64) | p.top_lo;
+    const uint64_t total_tiles = tb.tile_end[n_vec - 1];
+    int cur = -1, v = 0;
+    uint64_t tile0 = 0;
+    CtrPrefix pre_a{}, pre_b{};
+    for (uint64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+        while (t >= tb.tile_end[v]) tile0 = tb.tile_end[v++];
+        const uint32_t ia = tb.add[v], im = tb.minus[v];
+        if (v != cur && ctr_fast) {
+            pre_a = ctr_prefix(rk, lr, p.iter, ia, 0u);
+            if (DBL) pre_b = ctr_prefix(rk, lr, p.iter, im, 0u);
+            cur = v;
+        }
+        const uint64_t Bw = (t - tile0) * kSmallThreads + wave * 64u;      // this wave's first block (job-local)
+        const uint64_t blk_count = tb.blk_count[v];
+        if (Bw >= blk_count) continue;
+        const uint64_t first = tb.first[v], range_end = first + tb.count[v];
+        const uint64_t *in = tb.in[v];
+        uint64_t *out = tb.out[v];
+        const uint64_t Bl = Bw + lane;
+        const bool valid = Bl < blk_count;
+        const uint64_t B = tb.blk_first[v] + (valid ? Bl : 0);
         uint64_t begin, len, i;
-        if (B < r * nb1) {
+        if (ctr_fast) {
+            // n < 2^32: block, chunk and element indices fit 32 bits
+            const uint32_t B32 = static_cast<uint32_t>(B), nb1_32 = static_cast<uint32_t>(nb1), nb0_32 = static_cast<uint32_t>(nb0);
+            const uint32_t d32 = static_cast<uint32_t>(d), r32 = static_cast<uint32_t>(r);
+            if (B32 < r32 * nb1_32) {
+                const uint32_t c = nb1_32 == 1 ? B32 : udiv_magic(B32, nb1_32, p.nb1_magic);
+                i = B32 - c * nb1_32; begin = static_cast<uint64_t>(c) * (d32 + 1u); len = d + 1;
+            } else {
+                const uint32_t B2 = B32 - r32 * nb1_32, c = nb0_32 == 1 ? B2 : udiv_magic(B2, nb0_32, p.nb0_magic);
+                i = B2 - c * nb0_32; begin = static_cast<uint64_t>(r32) * (d32 + 1u) + static_cast<uint64_t>(c) * d32; len = d;
+            }
+        } else if (B < r * nb1) {
             const uint64_t c = B / nb1;
             i = B - c * nb1; begin = c * (d + 1); len = d + 1;
         } else {
@@ -736,18 +800,52 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_batch_kernel(const Ro
         const uint64_t rem = len - i * m;
         const int cnt = rem < m ? static_cast<int>(rem) : static_cast<int>(m);
         const uint64_t ctr = begin + i;
-        const uint32_t ia = tb.idx[v];
-        const uint64_t *in = tb.in[v];
-        uint64_t *out = tb.out[v];
         uint32_t s[DBL ? 2 : 1][4];
-        set_block(s[0], p.iter, ia, ctr);
-        if (DBL) set_block(s[DBL ? 1 : 0], p.iter, ia + 1u, ctr);
-        aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
+        if (ctr_fast) {
+            const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(ctr));
+            ctr_round1(pre_a, x, s[0]);
+            if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
+            aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
+        } else {
+            set_block(s[0], p.iter, ia, ctr);
+            if (DBL) set_block(s[DBL ? 1 : 0], p.iter, im, ctr);
+            aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
+        }
         const u128 S0 = words_to_u128(s[0]);
-        const u128 S1 = DBL ? words_to_u128(s[DBL ? 1 : 0]) : static_cast<u128>(0);
-        for (int t = 0; t < cnt; t++) {
-            const uint64_t a = extract64(S0, p.b * t), bsub = DBL ? extract64(S1, p.b * t) : 0ull;
-            out[j0 + t] = (in[j0 + t] + a - bsub) & p.mask_lo;
+        u128 D = S0;
+        if (DBL) {
+            const u128 S1 = words_to_u128(s[DBL ? 1 : 0]);
+            D = ((S0 | top) - (S1 & ~top)) ^ ((S0 ^ ~S1) & top);            // per slot: (a - b) mod 2^b
+        }
+        if (__all(valid && cnt == p.m)) {
+            // 64 full blocks: elements j0(lane 0) .. + 64 m - 1 are consecutive
+            *reinterpret_cast<uint4 *>(row0 + 4 * lane) = make_uint4(static_cast<uint32_t>(D), static_cast<uint32_t>(D >> 32),
+                                                                     static_cast<uint32_t>(D >> 64), static_cast<uint32_t>(D >> 96));
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t e0 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(j0)) |
+                                (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(j0 >> 32))) << 32);
+            for (int q = 0; q < p.m; q++) {
+                const uint32_t x = static_cast<uint32_t>(q) * 64u + lane;
+                const uint32_t src = static_cast<uint32_t>((static_cast<uint64_t>(x) * p.m_magic) >> 32);
+                const uint32_t o = static_cast<uint32_t>(p.b) * (x - src * static_cast<uint32_t>(p.m));
+                const uint32_t *w = row0 + 4 * src + (o >> 5);
+                const uint32_t sh = o & 31u;
+                uint64_t val = ((static_cast<uint64_t>(w[1]) << 32) | w[0]) >> sh;
+                if (sh) val |= static_cast<uint64_t>(w[2]) << (64u - sh);
+                const uint64_t j = e0 + x;
+                if (j >= first && j < range_end) {
+                    const uint64_t pt = in ? __builtin_nontemporal_load(in + (j - first)) : 0ull;
+                    __builtin_nontemporal_store((pt + val) & p.mask_lo, out + (j - first));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else if (valid) {
+            for (int tt = 0; tt < cnt; tt++) {
+                const uint64_t j = j0 + tt;
+                if (j < first || j >= range_end) continue;
+                const uint64_t val = extract64(D, p.b * tt);
+                out[j - first] = ((in ? in[j - first] : 0ull) + val) & p.mask_lo;
+            }
         }
     }
 }
@@ -868,10 +966,13 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
                                env.rkw_dev, p, lists.add[0], 0u);
     } else if (bs_shape) {
         const PrfJob job{lists.add[0], lists.minus[0], first, count, in_dev, in_limbs, out_dev};
-        return launch_prf_jobs(env, iter, n_minus == 1, 1, &job, n);
+        return launch_prf_jobs(env, iter, n_minus == 1, 1, &job, n, n_jobs);
     } else if (env.b > 64) {
         const int grid = grid_for(env, count, kPrfThreads);
         hipLaunchKernelGGL(prf_wide_kernel, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, p, lists);
+    } else if (n_add == 1 && n_minus <= 1) {
+        const PrfJob job{lists.add[0], lists.minus[0], first, count, in_dev, in_limbs, out_dev};
+        return launch_prf_jobs(env, iter, n_minus == 1, 1, &job, n, n_jobs);
     } else {
         p.blk_first = block_of(first, n, n_jobs, p.m);
         p.blk_count = block_of(first + count - 1, n, n_jobs, p.m) - p.blk_first + 1;
@@ -886,30 +987,55 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
 {
     if (n == 0 || n_vec == 0) return hipSuccess;
     if (n_vec > kMaxBatch) return hipErrorInvalidValue;
-    BatchTable tb{};
-    for (int v = 0; v < n_vec; v++) { tb.idx[v] = idx[v]; tb.in[v] = in_dev[v]; tb.out[v] = out_dev[v]; }
-    uint64_t lo, hi;
-    masks_of(env.b, &lo, &hi);
-    if (env.b <= 64) {
-        PrfParams p{};
-        p.te0 = env.te0_dev; p.n = n; p.iter = iter; p.n_jobs = n_jobs; p.b = env.b; p.m = 128 / env.b; p.mask_lo = lo;
-        const uint64_t m = p.m, J = n_jobs, d = n / J, r = n % J;
-        const uint64_t nb1 = (d + 1 + m - 1) / m, nb0 = d ? (d + m - 1) / m : 0;
-        const uint64_t total = (r * nb1 + (J - r) * nb0) * static_cast<uint64_t>(n_vec);
-        const int grid = grid_for(env, total, kSmallThreads);
-        if (dbl) hipLaunchKernelGGL(prf_small_batch_kernel<true>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, n_vec, p);
-        else hipLaunchKernelGGL(prf_small_batch_kernel<false>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, n_vec, p);
-        return hipGetLastError();
-    }
     PrfJob jobs[kMaxBatch];
     for (int v = 0; v < n_vec; v++)
         jobs[v] = PrfJob{idx[v], idx[v] + 1u, 0, n, in_dev[v], in_limbs, out_dev[v]};
-    return launch_prf_jobs(env, iter, dbl, n_vec, jobs, n);
+    return launch_prf_jobs(env, iter, dbl, n_vec, jobs, n, n_jobs);
 }
 
-hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n)
+// b <= 64 form of launch_prf_jobs
+static hipError_t launch_prf_jobs_small(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n,
+                                        uint32_t n_jobs)
 {
-    if (n_entries > kMaxBatch || env.b <= 64) return hipErrorInvalidValue;
+    SmallJobTable tb{};
+    SmallParams p{};
+    p.n = n; p.n_jobs = n_jobs; p.iter = iter; p.b = env.b; p.m = 128 / env.b; p.te0 = env.te0_dev;
+    p.m_magic = static_cast<uint32_t>(((1ull << 32) + p.m - 1) / p.m);
+    uint64_t hi;
+    masks_of(env.b, &p.mask_lo, &hi);
+    unsigned __int128 top = 0;
+    for (int t = 0; t < p.m; t++) top |= static_cast<unsigned __int128>(1) << (env.b * t + env.b - 1);
+    p.top_lo = static_cast<uint64_t>(top); p.top_hi = static_cast<uint64_t>(top >> 64);
+    {
+        const uint64_t mm = p.m, d = n / n_jobs, nb1 = (d + 1 + mm - 1) / mm, nb0 = d ? (d + mm - 1) / mm : 0;
+        p.nb1_magic = nb1 > 1 && nb1 < (1ull << 32) ? static_cast<uint32_t>((1ull << 32) / nb1) : 0;
+        p.nb0_magic = nb0 > 1 && nb0 < (1ull << 32) ? static_cast<uint32_t>((1ull << 32) / nb0) : 0;
+    }
+    uint64_t tiles = 0;
+    int nv = 0;
+    for (int e = 0; e < n_entries; e++) {
+        if (jobs[e].count == 0) continue;
+        if (jobs[e].n_in > 1 || (jobs[e].in_dev && jobs[e].in_limbs != 1)) return hipErrorInvalidValue;
+        tb.add[nv] = jobs[e].add_idx; tb.minus[nv] = jobs[e].minus_idx;
+        tb.first[nv] = jobs[e].first; tb.count[nv] = jobs[e].count;
+        tb.in[nv] = jobs[e].in_dev; tb.out[nv] = jobs[e].out_dev;
+        tb.blk_first[nv] = block_of(jobs[e].first, n, n_jobs, p.m);
+        tb.blk_count[nv] = block_of(jobs[e].first + jobs[e].count - 1, n, n_jobs, p.m) - tb.blk_first[nv] + 1;
+        tiles += (tb.blk_count[nv] + kSmallThreads - 1) / kSmallThreads;
+        tb.tile_end[nv++] = tiles;
+    }
+    if (nv == 0) return hipSuccess;
+    const uint64_t cus = static_cast<uint64_t>(env.num_cus);
+    const int grid = static_cast<int>(tiles < cus ? tiles : cus);
+    if (dbl) hipLaunchKernelGGL(prf_small_jobs_kernel<true>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nv, p);
+    else hipLaunchKernelGGL(prf_small_jobs_kernel<false>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nv, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n, uint32_t n_jobs)
+{
+    if (n_entries > kMaxBatch) return hipErrorInvalidValue;
+    if (env.b <= 64) return launch_prf_jobs_small(env, iter, dbl, n_entries, jobs, n, n_jobs);
     JobTable tb{};
     int nv = 0;
     uint64_t big[kMaxBatch];
