@@ -713,7 +713,7 @@ struct SmallJobTable {
     uint32_t add[kMaxBatch], minus[kMaxBatch];
     uint64_t first[kMaxBatch], count[kMaxBatch];            // element range of the job (global indices)
     uint64_t blk_first[kMaxBatch], blk_count[kMaxBatch];    // AES blocks intersecting it (global block numbering)
-    uint64_t tile_end[kMaxBatch];                           // running total of 1024-block workgroup tiles
+    uint64_t tile_end[kMaxBatch];                           // running total of 64-block wave tiles
     const uint64_t *in[kMaxBatch];                          // may be null; indexed by (element - first)
     uint64_t *out[kMaxBatch];
 };
@@ -756,11 +756,14 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
     uint32_t *row0 = scratch + wave * 256;
     const bool ctr_fast = ((p.n - 1) >> 32) == 0;           // every counter (chunk begin + block index) is below n
     const u128 top = (static_cast<u128>(p.top_hi) << 64) | p.top_lo;
+    // the unit of distribution is a WAVE tile of 64 blocks (all jobs in one index space): short vectors, e.g. a hundred
+    // LeNet-sized models, still spread evenly over the 16 x 256 waves of the chip
     const uint64_t total_tiles = tb.tile_end[n_vec - 1];
+    const uint64_t n_waves = static_cast<uint64_t>(gridDim.x) * (kSmallThreads / 64);
     int cur = -1, v = 0;
     uint64_t tile0 = 0;
     CtrPrefix pre_a{}, pre_b{};
-    for (uint64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * (kSmallThreads / 64) + wave; t < total_tiles; t += n_waves) {
         while (t >= tb.tile_end[v]) tile0 = tb.tile_end[v++];
         const uint32_t ia = tb.add[v], im = tb.minus[v];
         if (v != cur && ctr_fast) {
@@ -768,9 +771,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
             if (DBL) pre_b = ctr_prefix(rk, lr, p.iter, im, 0u);
             cur = v;
         }
-        const uint64_t Bw = (t - tile0) * kSmallThreads + wave * 64u;      // this wave's first block (job-local)
+        const uint64_t Bw = (t - tile0) * 64u;                              // this wave's first block (job-local)
         const uint64_t blk_count = tb.blk_count[v];
-        if (Bw >= blk_count) continue;
         const uint64_t first = tb.first[v], range_end = first + tb.count[v];
         const uint64_t *in = tb.in[v];
         uint64_t *out = tb.out[v];
@@ -817,25 +819,37 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
             const u128 S1 = words_to_u128(s[DBL ? 1 : 0]);
             D = ((S0 | top) - (S1 & ~top)) ^ ((S0 ^ ~S1) & top);            // per slot: (a - b) mod 2^b
         }
-        if (__all(valid && cnt == p.m)) {
-            // 64 full blocks: elements j0(lane 0) .. + 64 m - 1 are consecutive
+        // Runs of consecutive elements inside the wave tile: blocks are full except the last one of a chunk, so with at most
+        // one partial block (lane P) the tile is run A = lanes 0..P and run B = the lanes after it (next chunk).
+        const uint64_t valid_mask = __ballot(valid), partial_mask = __ballot(valid && cnt < p.m);
+        if (__popcll(partial_mask) <= 1) {
             *reinterpret_cast<uint4 *>(row0 + 4 * lane) = make_uint4(static_cast<uint32_t>(D), static_cast<uint32_t>(D >> 32),
                                                                      static_cast<uint32_t>(D >> 64), static_cast<uint32_t>(D >> 96));
             __builtin_amdgcn_wave_barrier();
-            const uint64_t e0 = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(j0)) |
-                                (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(j0 >> 32))) << 32);
-            for (int q = 0; q < p.m; q++) {
-                const uint32_t x = static_cast<uint32_t>(q) * 64u + lane;
-                const uint32_t src = static_cast<uint32_t>((static_cast<uint64_t>(x) * p.m_magic) >> 32);
-                const uint32_t o = static_cast<uint32_t>(p.b) * (x - src * static_cast<uint32_t>(p.m));
-                const uint32_t *w = row0 + 4 * src + (o >> 5);
-                const uint32_t sh = o & 31u;
-                uint64_t val = ((static_cast<uint64_t>(w[1]) << 32) | w[0]) >> sh;
-                if (sh) val |= static_cast<uint64_t>(w[2]) << (64u - sh);
-                const uint64_t j = e0 + x;
-                if (j >= first && j < range_end) {
-                    const uint64_t pt = in ? __builtin_nontemporal_load(in + (j - first)) : 0ull;
-                    __builtin_nontemporal_store((pt + val) & p.mask_lo, out + (j - first));
+            const int n_valid = __popcll(valid_mask);
+            const int P = partial_mask ? static_cast<int>(__ffsll(static_cast<unsigned long long>(partial_mask))) - 1 : -1;
+            const uint32_t j0_lo = static_cast<uint32_t>(j0), j0_hi = static_cast<uint32_t>(j0 >> 32);
+#pragma unroll 1
+            for (int run = 0; run < 2; run++) {
+                const int lane_base = run == 0 ? 0 : P + 1;
+                if (run == 1 && (P < 0 || lane_base >= n_valid)) break;
+                const uint64_t e0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_lo, lane_base)) |
+                                    (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_hi, lane_base))) << 32);
+                const uint32_t n_elems = run == 0 ? (P >= 0 ? static_cast<uint32_t>(P) * p.m + static_cast<uint32_t>(__builtin_amdgcn_readlane(cnt, P))
+                                                            : static_cast<uint32_t>(n_valid) * p.m)
+                                                  : static_cast<uint32_t>(n_valid - lane_base) * p.m;
+                for (uint32_t x = lane; x < n_elems; x += 64u) {
+                    const uint32_t blk = static_cast<uint32_t>((static_cast<uint64_t>(x) * p.m_magic) >> 32);
+                    const uint32_t o = static_cast<uint32_t>(p.b) * (x - blk * static_cast<uint32_t>(p.m));
+                    const uint32_t *w = row0 + 4 * (lane_base + blk) + (o >> 5);
+                    const uint32_t sh = o & 31u;
+                    uint64_t val = ((static_cast<uint64_t>(w[1]) << 32) | w[0]) >> sh;
+                    if (sh) val |= static_cast<uint64_t>(w[2]) << (64u - sh);
+                    const uint64_t j = e0 + x;
+                    if (j >= first && j < range_end) {
+                        const uint64_t pt = in ? __builtin_nontemporal_load(in + (j - first)) : 0ull;
+                        __builtin_nontemporal_store((pt + val) & p.mask_lo, out + (j - first));
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1021,12 +1035,12 @@ static hipError_t launch_prf_jobs_small(const LaunchEnv &env, uint32_t iter, boo
         tb.in[nv] = jobs[e].in_dev; tb.out[nv] = jobs[e].out_dev;
         tb.blk_first[nv] = block_of(jobs[e].first, n, n_jobs, p.m);
         tb.blk_count[nv] = block_of(jobs[e].first + jobs[e].count - 1, n, n_jobs, p.m) - tb.blk_first[nv] + 1;
-        tiles += (tb.blk_count[nv] + kSmallThreads - 1) / kSmallThreads;
+        tiles += (tb.blk_count[nv] + 63) / 64;
         tb.tile_end[nv++] = tiles;
     }
     if (nv == 0) return hipSuccess;
-    const uint64_t cus = static_cast<uint64_t>(env.num_cus);
-    const int grid = static_cast<int>(tiles < cus ? tiles : cus);
+    const uint64_t cus = static_cast<uint64_t>(env.num_cus), wg_tiles = (tiles + kSmallThreads / 64 - 1) / (kSmallThreads / 64);
+    const int grid = static_cast<int>(wg_tiles < cus ? wg_tiles : cus);
     if (dbl) hipLaunchKernelGGL(prf_small_jobs_kernel<true>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nv, p);
     else hipLaunchKernelGGL(prf_small_jobs_kernel<false>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nv, p);
     return hipGetLastError();
