@@ -454,6 +454,52 @@ def test_graph_capture_replays_a_round(E, oracle, b, n, C):
     big.sync()
 
 
+def test_prf_jobs_randomised(E, oracle):
+    """Seeded sweep of flashe_prf_jobs_dev over bit widths, vector lengths (incl. > 2^20 elements: the 4096-element tiles and
+    their scalar-cache shortcut), chunkings and ragged job lists (aligned and unaligned ranges, with and without input)."""
+    rng = np.random.Generator(np.random.PCG64(20260))
+    cases = [(128, 1_300_000, 16), (128, 300_001, 1), (100, 70_000, 5), (64, 200_000, 16), (33, 10_000, 3), (23, 61_706, 16), (20, 150_001, 7),
+             (8, 100_000, 16), (3, 5000, 2), (64, 63, 16), (20, 7, 3)]
+    for b, n, J in cases:
+        eng = make(E, b)
+        Lb = L(b)
+        pt = rng.integers(0, 2 ** min(b, 64), n, dtype=np.uint64)
+        dpt = eng.upload(pt)
+        pt_l = np.zeros((n, Lb), dtype=np.uint64)
+        pt_l[:, 0] = pt
+        idxs = [int(v) for v in rng.integers(0, 2 ** 32 - 1, 3)]
+        masks = {i: oracle.mask(KEY, 11, i, n, J, b) for i in idxs}
+        for has_minus in (True, False):
+            spec, jobs, outs = [], [], []
+            for _ in range(int(rng.integers(1, 9))):
+                kind = int(rng.integers(0, 4))
+                if kind == 0:
+                    first, count = 0, n
+                elif kind == 1:
+                    first = int(rng.integers(0, n))
+                    count = int(rng.integers(0, n - first + 1))
+                elif kind == 2:
+                    first = min(n, int(rng.integers(0, max(1, n // 256 + 1))) * 256)
+                    count = n - first
+                else:
+                    first, count = int(rng.integers(0, n)), 1
+                add, minus = idxs[int(rng.integers(0, 3))], idxs[int(rng.integers(0, 3))]
+                with_in = bool(rng.integers(0, 2))
+                o = eng.alloc_vec(max(count, 1))
+                outs.append(o)
+                spec.append((add, minus, first, count, with_in))
+                jobs.append((add, minus if has_minus else None, first, count, dpt.ptr + 8 * first if with_in else None, 1, o))
+            eng.prf_jobs_dev(11, n, J, jobs)
+            for (add, minus, first, count, with_in), o in zip(spec, outs):
+                if count == 0:
+                    continue
+                z = np.zeros((count, Lb), dtype=np.uint64)
+                want = oracle.combine(b, pt_l[first:first + count] if with_in else z, masks[add][first:first + count],
+                                      masks[minus][first:first + count] if has_minus else z)
+                got = o.download(np.uint64, count * Lb).reshape(count, Lb)
+                assert np.array_equal(got, want), (b, n, J, has_minus, add, minus, first, count, with_in)
+
+
 def test_u64_plaintext_zero_extension(E, oracle):
     rng = np.random.Generator(np.random.PCG64(3))
     eng = make(E, 128)
