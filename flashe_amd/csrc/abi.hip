@@ -599,8 +599,10 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
         }
         return FLASHE_OK;
     }
-    // equal shares when several launches are needed (100 vectors: 4 x 25, not 32 + 32 + 32 + 4)
-    const int per_launch = n_vec ? (n_vec + (n_vec + kMaxBatch - 1) / kMaxBatch - 1) / ((n_vec + kMaxBatch - 1) / kMaxBatch) : 1;
+    // equal shares when several launches are needed (b <= 64, 100 vectors: 4 x 25, not 32 + 32 + 32 + 4); 2-limb vectors
+    // travel in the compact table, up to 128 per launch
+    const int cap = ctx->limbs == 2 ? kMaxUniformBatch : kMaxBatch;
+    const int per_launch = n_vec ? (n_vec + (n_vec + cap - 1) / cap - 1) / ((n_vec + cap - 1) / cap) : 1;
     for (int v0 = 0; v0 < n_vec; v0 += per_launch) {
         const int nv = std::min(per_launch, n_vec - v0);
         HIP_TRY(ctx, launch_prf_batch(ctx->env, iter, scheme == FLASHE_SCHEME_DOUBLE, nv, idx + v0, pt_dev + v0, pt_limbs, ct_dev + v0, n,

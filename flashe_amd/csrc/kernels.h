@@ -39,7 +39,8 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter,
 
 // Several independent encrypts of equal length in ONE launch: vector v is encrypted with prefix idx[v]
 // (and idx[v] + 1 when `dbl`); at most kMaxBatch vectors per launch.
-constexpr int kMaxBatch = 32;
+constexpr int kMaxBatch = 32;      // jobs per launch (general table)
+constexpr int kMaxUniformBatch = 128;   // equal-length whole vectors per launch (compact table, b > 64)
 hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx,
                             const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n,
                             uint32_t n_jobs);

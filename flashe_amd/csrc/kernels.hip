@@ -411,6 +411,42 @@ struct JobTable {
     uint64_t in_stride[kMaxBatch];      // limbs between the n_in input vectors of a summed input
     uint64_t *sum_out[kMaxBatch];       // optional: where the summed input goes
     uint8_t in_limbs[kMaxBatch], n_in[kMaxBatch];
+    __device__ uint32_t add_of(int v) const { return add[v]; }
+    __device__ uint32_t minus_of(int v) const { return minus[v]; }
+    __device__ uint64_t first_of(int v) const { return first[v]; }
+    __device__ uint64_t count_of(int v) const { return count[v]; }
+    __device__ uint64_t big_end_of(int v) const { return big_end[v]; }
+    __device__ uint64_t small_end_of(int v) const { return small_end[v]; }
+    __device__ const uint64_t *in_of(int v) const { return in[v]; }
+    __device__ uint64_t *out_of(int v) const { return out[v]; }
+    __device__ int in_limbs_of(int v) const { return in_limbs[v]; }
+    __device__ int n_in_of(int v) const { return n_in[v]; }
+    __device__ uint64_t in_stride_of(int v) const { return in_stride[v]; }
+    __device__ uint64_t *sum_out_of(int v) const { return sum_out[v]; }
+};
+
+// Compact table for the common batch: up to kMaxUniform whole vectors of EQUAL length (the clients a simulation hosts, the
+// layers of a model) -- four words per job instead of eleven, so 128 of them fit the kernel-argument block and a hundred
+// LeNet-sized encrypts are one launch.
+constexpr int kMaxUniform = kMaxUniformBatch;
+struct UniformJobTable {
+    uint32_t add[kMaxUniform], minus[kMaxUniform];
+    const uint64_t *in[kMaxUniform];
+    uint64_t *out[kMaxUniform];
+    uint64_t count, big_per, small_per;   // elements, big tiles and small tiles of every job
+    int in_limbs;
+    __device__ uint32_t add_of(int v) const { return add[v]; }
+    __device__ uint32_t minus_of(int v) const { return minus[v]; }
+    __device__ uint64_t first_of(int) const { return 0; }
+    __device__ uint64_t count_of(int) const { return count; }
+    __device__ uint64_t big_end_of(int v) const { return static_cast<uint64_t>(v + 1) * big_per; }
+    __device__ uint64_t small_end_of(int v) const { return static_cast<uint64_t>(v + 1) * small_per; }
+    __device__ const uint64_t *in_of(int v) const { return in[v]; }
+    __device__ uint64_t *out_of(int v) const { return out[v]; }
+    __device__ int in_limbs_of(int) const { return in_limbs; }
+    __device__ int n_in_of(int) const { return 1; }
+    __device__ uint64_t in_stride_of(int) const { return 0; }
+    __device__ uint64_t *sum_out_of(int) const { return nullptr; }
 };
 constexpr int kBigEpl = 4;
 
@@ -419,8 +455,8 @@ constexpr int kBigEpl = 4;
 // input (reduce fused in): its operands are loaded before the AES rounds and added after them, so their HBM
 // latency hides under the lookups of the same element.
 constexpr int kSumRegs = 10;            // operands held in registers across the rounds (more are added up front)
-template <bool DBL, int THREADS, int KIND>
-__global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const JobTable tb, int n_vec, uint64_t n,
+template <bool DBL, int THREADS, int KIND, class Table>
+__global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const Table tb, int n_vec, uint64_t n,
                                                                      uint32_t iter, uint64_t mask_lo, uint64_t mask_hi,
                                                                      const uint32_t *__restrict__ te0)
 {
@@ -428,31 +464,38 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
     fill_tables(tab, te0);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
-    const uint64_t n_big = tb.big_end[n_vec - 1], total_tiles = n_big + tb.small_end[n_vec - 1];
+    const uint64_t n_big = tb.big_end_of(n_vec - 1), total_tiles = n_big + tb.small_end_of(n_vec - 1);
     const uint32_t wave64 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
     const uint32_t lane = threadIdx.x & 63u;
     int cur = -1, v = 0;
     bool in_small = false;
     uint64_t tile0 = 0;                                                  // first tile (of the current kind) of job v
     CtrPrefix pre_a{}, pre_b{};
-    for (uint64_t t = blockIdx.x; t < total_tiles; t += gridDim.x) {
-        // locate the tile: wave-uniform, and t only grows
+    // workgroup g takes a CONTIGUOUS share of the big tiles and a contiguous share of the small ones (equal counts: the
+    // host made the big tiles a multiple of the grid): consecutive tiles mostly belong to the same job, so the prefix
+    // words are rebuilt at job boundaries only, and a workgroup streams through adjacent memory
+    const uint64_t G = gridDim.x, g = blockIdx.x, n_small = total_tiles - n_big;
+    const uint64_t big_lo = n_big / G * g + (g < n_big % G ? g : n_big % G), big_cnt = n_big / G + (g < n_big % G ? 1 : 0);
+    const uint64_t small_lo = n_small / G * g + (g < n_small % G ? g : n_small % G), small_cnt = n_small / G + (g < n_small % G ? 1 : 0);
+    for (uint64_t kk = 0; kk < big_cnt + small_cnt; kk++) {
+        const uint64_t t = kk < big_cnt ? big_lo + kk : n_big + small_lo + (kk - big_cnt);
+        // locate the tile: wave-uniform, and t only grows within a kind
         uint64_t kw;                                                     // first element of this wave's share
         int epl;
         if (t < n_big) {
-            while (t >= tb.big_end[v]) tile0 = tb.big_end[v++];
+            while (t >= tb.big_end_of(v)) tile0 = tb.big_end_of(v++);
             epl = kBigEpl;
             kw = (t - tile0) * (THREADS * kBigEpl) + wave64 * kBigEpl;
         } else {
             if (!in_small) { in_small = true; v = 0; tile0 = 0; }
             const uint64_t ts = t - n_big;
-            while (ts >= tb.small_end[v]) tile0 = tb.small_end[v++];
-            const uint64_t big_v = tb.big_end[v] - (v ? tb.big_end[v - 1] : 0);
+            while (ts >= tb.small_end_of(v)) tile0 = tb.small_end_of(v++);
+            const uint64_t big_v = tb.big_end_of(v) - (v ? tb.big_end_of(v - 1) : 0);
             epl = 1;
             kw = big_v * (THREADS * kBigEpl) + (ts - tile0) * THREADS + wave64;
         }
-        const uint32_t ia = tb.add[v], im = tb.minus[v];
-        const uint64_t count = tb.count[v], first = tb.first[v];
+        const uint32_t ia = tb.add_of(v), im = tb.minus_of(v);
+        const uint64_t count = tb.count_of(v), first = tb.first_of(v);
         // the shortcuts need the job to stay inside one 2^32 counter window (only the low counter word varies)
         const bool ctr_fast = ((first + count - 1) >> 32) == (first >> 32);
         if (v != cur && ctr_fast) {
@@ -461,12 +504,12 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
             cur = v;
         }
         if (kw >= count) continue;
-        const uint64_t *in = tb.in[v];
-        uint64_t *out = tb.out[v];
-        const int in_limbs = tb.in_limbs[v];
-        const int n_in = tb.n_in[v];
-        const uint64_t in_stride = tb.in_stride[v];
-        uint64_t *sum_out = tb.sum_out[v];
+        const uint64_t *in = tb.in_of(v);
+        uint64_t *out = tb.out_of(v);
+        const int in_limbs = tb.in_limbs_of(v);
+        const int n_in = tb.n_in_of(v);
+        const uint64_t in_stride = tb.in_stride_of(v);
+        uint64_t *sum_out = tb.sum_out_of(v);
         // wave-uniform part of rounds 1-2: valid while the wave's 256 counters share bytes 1..3
         const bool uni = FLASHE_CTR2 && epl == kBigEpl && ctr_fast && ((first + kw) & 255u) == 0;
         CtrUniform Ua{}, Ub{};
@@ -1000,7 +1043,32 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
                             const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n, uint32_t n_jobs)
 {
     if (n == 0 || n_vec == 0) return hipSuccess;
-    if (n_vec > kMaxBatch) return hipErrorInvalidValue;
+    if (n_vec > (env.b > 64 ? kMaxUniform : kMaxBatch)) return hipErrorInvalidValue;
+    if (env.b > 64 && n_vec > kMaxBatch) {
+        // many equal vectors: compact table, one launch
+        if (n_vec > kMaxUniform) return hipErrorInvalidValue;
+        UniformJobTable tb{};
+        for (int v = 0; v < n_vec; v++) { tb.add[v] = idx[v]; tb.minus[v] = idx[v] + 1u; tb.in[v] = in_dev[v]; tb.out[v] = out_dev[v]; }
+        tb.count = n; tb.in_limbs = in_limbs;
+        constexpr uint64_t kBigTile = static_cast<uint64_t>(kPrfThreads) * kBigEpl;
+        const uint64_t cus = static_cast<uint64_t>(env.num_cus);
+        // big tiles only if they come in whole rounds of the grid (else everything in 1024-element tiles)
+        uint64_t big_per = n / kBigTile;
+        while (big_per && (big_per * n_vec) % cus) big_per--;
+        tb.big_per = big_per;
+        tb.small_per = (n - big_per * kBigTile + kPrfThreads - 1) / kPrfThreads;
+        const uint64_t tiles = (tb.big_per + tb.small_per) * n_vec;
+        uint64_t lo, hi;
+        masks_of(env.b, &lo, &hi);
+        const int grid = static_cast<int>(tiles < cus ? tiles : cus);
+        if (dbl)
+            hipLaunchKernelGGL((prf_wide_batch_kernel<true, kPrfThreads, 1, UniformJobTable>), dim3(grid), dim3(kPrfThreads), 0, env.stream,
+                               env.rk, tb, n_vec, n, iter, lo, hi, env.te0_dev);
+        else
+            hipLaunchKernelGGL((prf_wide_batch_kernel<false, kPrfThreads, 1, UniformJobTable>), dim3(grid), dim3(kPrfThreads), 0, env.stream,
+                               env.rk, tb, n_vec, n, iter, lo, hi, env.te0_dev);
+        return hipGetLastError();
+    }
     PrfJob jobs[kMaxBatch];
     for (int v = 0; v < n_vec; v++)
         jobs[v] = PrfJob{idx[v], idx[v] + 1u, 0, n, in_dev[v], in_limbs, out_dev[v]};
@@ -1088,7 +1156,7 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
     // 1e7-element vectors) and raising the wave priority (s_setprio) costs ~1 %
     const int grid = static_cast<int>(tiles < cus ? tiles : cus);
 #define JOBS_LAUNCH(DBL, MULTI)                                                                                              \
-    hipLaunchKernelGGL((prf_wide_batch_kernel<DBL, kPrfThreads, MULTI>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, \
+    hipLaunchKernelGGL((prf_wide_batch_kernel<DBL, kPrfThreads, MULTI, JobTable>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, \
                        nv, n, iter, lo, hi, env.te0_dev)
     bool summed = false;
     for (int v = 0; v < nv; v++) summed |= tb.n_in[v] > 1;

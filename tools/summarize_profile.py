@@ -62,7 +62,7 @@ def main(tag):
         out[k] = e
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
     # the dominant kernel is the job-list PRF kernel (batched encrypts, chunked encrypt / decrypt launches)
-    dom = next((k for k in out if "prf_wide_batch_kernel<true, 1024, 1>" in k), None) or next((k for k in out if "prf_wide_batch_kernel" in k), None)
+    dom = next((k for k in out if "prf_wide_batch_kernel<true, 1024, 1" in k), None) or next((k for k in out if "prf_wide_batch_kernel" in k), None)
     if dom and "FETCH_SIZE" in out[dom]:
         f, w = out[dom]["FETCH_SIZE"], out[dom]["WRITE_SIZE"]
         per_launch = (2 * f["avg"] + w["avg"]) * 1024
