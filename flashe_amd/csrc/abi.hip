@@ -853,6 +853,7 @@ int flashe_pack_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint64_
     CHECK_CTX(ctx);
     if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
     if (ctx->limbs == 2 && !aligned16(in_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    if (ctx->int_bits == 128 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "int_bits = 128: the packed buffer must be 16-byte aligned");
     HIP_TRY(ctx, launch_pack(ctx->env, n, in_dev, out_dev));
     return FLASHE_OK;
 }
@@ -861,6 +862,7 @@ int flashe_unpack_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint6
     CHECK_CTX(ctx);
     if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
     if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    if (ctx->int_bits == 128 && !aligned16(in_dev)) return fail(ctx, FLASHE_EINVAL, "int_bits = 128: the packed buffer must be 16-byte aligned");
     HIP_TRY(ctx, launch_unpack(ctx->env, n, in_dev, out_dev));
     return FLASHE_OK;
 }

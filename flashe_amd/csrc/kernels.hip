@@ -1529,9 +1529,22 @@ __global__ __launch_bounds__(kStreamThreads) void unpack_kernel(uint64_t n, int 
     }
 }
 
+// b = 128: the packed integer is the element order reversed (element 0 most significant) -- one 16-byte move per lane,
+// the same kernel packs and unpacks.
+__global__ __launch_bounds__(kStreamThreads) void reverse128_kernel(uint64_t n, const uint64_t *in, uint64_t *out)
+{
+    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; e < n;
+         e += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        st128_nt(out + 2 * e, ld128_nt(in + 2 * (n - 1 - e)));
+}
+
 hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
 {
     if (n == 0) return hipSuccess;
+    if (env.b == 128) {
+        hipLaunchKernelGGL(reverse128_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, in_dev, out_dev);
+        return hipGetLastError();
+    }
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
     const uint64_t n_limbs = (n * static_cast<uint64_t>(env.b) + 63) / 64;
@@ -1543,6 +1556,10 @@ hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev,
 hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
 {
     if (n == 0) return hipSuccess;
+    if (env.b == 128) {
+        hipLaunchKernelGGL(reverse128_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, in_dev, out_dev);
+        return hipGetLastError();
+    }
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
     const uint64_t n_limbs = (n * static_cast<uint64_t>(env.b) + 63) / 64;
