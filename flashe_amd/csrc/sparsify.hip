@@ -96,17 +96,17 @@ __global__ __launch_bounds__(kSpThreads) void sp_scan_kernel(uint32_t n_blocks, 
     for (uint32_t b = b0; b < b1; b++) { g += blk_gt[b]; e += blk_eq[b]; }
     sums[0][threadIdx.x] = g; sums[1][threadIdx.x] = e;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // inclusive Hillis-Steele scan over the 1024 per-thread totals (10 steps), then shift to exclusive
+    for (int off = 1; off < kSpThreads; off <<= 1) {
         unsigned long long ag = 0, ae = 0;
-        for (int t = 0; t < kSpThreads; t++) {
-            const unsigned long long tg = sums[0][t], te = sums[1][t];
-            sums[0][t] = ag; sums[1][t] = ae;
-            ag += tg; ae += te;
-        }
-        st->total_eq = ae;
+        if (static_cast<int>(threadIdx.x) >= off) { ag = sums[0][threadIdx.x - off]; ae = sums[1][threadIdx.x - off]; }
+        __syncthreads();
+        sums[0][threadIdx.x] += ag; sums[1][threadIdx.x] += ae;
+        __syncthreads();
     }
-    __syncthreads();
-    g = sums[0][threadIdx.x]; e = sums[1][threadIdx.x];
+    if (threadIdx.x == kSpThreads - 1) st->total_eq = sums[1][threadIdx.x];
+    const unsigned long long own_g = g, own_e = e;
+    g = sums[0][threadIdx.x] - own_g; e = sums[1][threadIdx.x] - own_e;
     for (uint32_t b = b0; b < b1; b++) {
         const uint32_t tg = blk_gt[b], te = blk_eq[b];
         blk_gt[b] = static_cast<uint32_t>(g); blk_eq[b] = static_cast<uint32_t>(e);     // offsets fit: n < 2^32
