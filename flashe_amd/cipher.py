@@ -42,9 +42,15 @@ def _to_limbs(value, limbs):
         n = value.shape[0]
         out = np.empty((n, limbs), dtype=np.uint64)
         if n:
-            out[:, 0] = (value & _M64).astype(np.uint64)
-            if limbs == 2:
-                out[:, 1] = ((value >> 64) & _M64).astype(np.uint64)
+            try:
+                # the usual case -- non-negative values below 2**64 -- converts in one C loop
+                out[:, 0] = value.astype(np.uint64)
+                if limbs == 2:
+                    out[:, 1] = 0
+            except (OverflowError, TypeError):
+                out[:, 0] = (value & _M64).astype(np.uint64)
+                if limbs == 2:
+                    out[:, 1] = ((value >> 64) & _M64).astype(np.uint64)
         return out, "object"
     if value.dtype == np.uint64:
         if value.ndim == 1:
