@@ -134,3 +134,21 @@ def test_flashe_client_adapter_round(cipher_cls):
     clients[0].set_idx_list(idx)
     out = clients[0].decrypt(agg)
     assert [int(v) for v in out] == [int(2 * v) for v in vals]
+
+
+def test_object_array_conversion_fast_and_fallback_paths():
+    """_to_limbs: the one-pass conversion (values in [0, 2**64)) and the masked fallback (negative or wider Python ints)
+    give the limbs the reference's `& (2**b - 1)` arithmetic implies."""
+    import numpy as np
+    from flashe_amd.cipher import _from_limbs, _to_limbs
+    vals = [0, 1, 2 ** 64 - 1, 12345678901234567890]
+    for limbs in (1, 2):
+        got, kind = _to_limbs(np.array(vals, dtype=object), limbs)
+        assert kind == "object" and [int(v) for v in got[:, 0]] == vals and (limbs == 1 or not got[:, 1].any())
+        wide = vals + [-3, 2 ** 70 + 5, 2 ** 128 - 1]
+        got, _ = _to_limbs(np.array(wide, dtype=object), limbs)
+        assert [int(v) for v in got[:, 0]] == [v & (2 ** 64 - 1) for v in wide]
+        if limbs == 2:
+            assert [int(v) for v in got[:, 1]] == [(v >> 64) & (2 ** 64 - 1) for v in wide]
+            back = _from_limbs(got, "object")
+            assert [int(v) for v in back] == [v & (2 ** 128 - 1) for v in wide]
