@@ -55,6 +55,8 @@ def parse():
                          "sequential: all local encrypts in one launch, then reduce (+ exchange) fused with the decrypt")
     ap.add_argument("--force-dist", action="store_true",
                     help="with 1 GPU: still create the RCCL process group and run the N > 1 exchange path (world size 1)")
+    ap.add_argument("--settle-rounds", type=int, default=32,
+                    help="untimed rounds (~0.1 s) run after the in-run parity check, before the warmup steps (GPU clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="elements of the workload the CPU baseline round runs on (default: all of it; ~0.2-2 s)")
@@ -274,7 +276,13 @@ def main():
         if schedule is None:
             raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum")
         pipelined = schedule != "sequential"
-        # warmup right before the timed region (the parity check above leaves the GPU idle while the host compares)
+        # The parity check above leaves the GPU idle while the host compares 1e7 elements, and its clocks drop: run rounds
+        # for ~0.1 s (32 of them) so that the timed region does not start on a cold device even when --warmup is small, then the W
+        # warmup steps proper, right before the timed region.
+        for it in range(args.settle_rounds):          # a fixed count: every rank must issue the same collectives
+            run_schedule(schedule, it)
+            if it % 8 == 7:
+                torch.cuda.synchronize()
         for w in range(W):
             run_schedule(schedule, w)
 
