@@ -46,9 +46,9 @@ def parse():
                     help="> 0: everything after the last client's encrypt (reduce, exchange, decrypt) runs chunk by chunk on "
                          "a side stream under it; 0: sequential phases")
     ap.add_argument("--schedule", choices=["default", "auto", "fused", "pipelined", "sequential"], default="default",
-                    help="default: sequential (two launches) on one GPU, fused when ranks exchange (the three schedules are within "
-                         "~1.5 %% of each other on one GPU; deterministic, so a profile of the run shows one launch shape per "
-                         "kernel); auto: fused or pipelined, whichever is faster in a short untimed calibration on this box; "
+                    help="default: sequential (two launches) on one GPU (the three schedules are within ~1.5 %% of each other there; "
+                         "deterministic, so a profile of the run shows one launch shape per kernel), and 'auto' when ranks exchange; "
+                         "auto: whichever schedule is fastest in a short untimed calibration on this box / node; "
                          "fused: per chunk one launch does every local encrypt plus the decrypt mask difference, the reduce "
                          "(which then yields the plaintext aggregate) and the exchange hide under the next chunk's launch; "
                          "pipelined: last client's encrypt chunked, reduce / exchange / decrypt on a side stream; "
@@ -223,10 +223,13 @@ def main():
         # used only if it passes; otherwise fall back to the next simpler one.
         order = ["fused", "pipelined", "sequential"]
         start = args.schedule
-        if start == "auto":
+        # several ranks: which schedule hides the exchange best depends on how RCCL behaves on the node, so the default
+        # there is to time all of them briefly (untimed region) and keep the fastest; one GPU: the two-launch round
+        calibrate = start == "auto" or (start == "default" and rnd.exchange)
+        if calibrate:
             start = "fused"
         elif start == "default":
-            start = "fused" if rnd.exchange else "sequential"
+            start = "sequential"
         if start == "fused" and b <= 64:
             start = "pipelined"              # the one-launch job list needs b > 64
         candidates = order[order.index(start):] if side is not None else ["sequential"]
@@ -257,16 +260,16 @@ def main():
             return float(t.item()) * 1e3 / rounds
 
         schedule, calibration = None, None
-        if args.schedule == "auto" and len(candidates) == 3:
-            # the two overlapped schedules are within a few percent of each other and which one wins depends on the
-            # box (and on whether ranks exchange): keep whichever is faster here, among those that pass the gate
-            usable = [c for c in candidates[:2] if passes(c)]
-            if len(usable) == 2:
+        if calibrate and len(candidates) > 1:
+            # the schedules are within a few percent of each other and which one wins depends on the box and on the
+            # exchange: keep whichever is fastest here, among those that pass the gate
+            usable = [c for c in candidates if passes(c)]
+            if len(usable) > 1:
                 calibration = {c: quick_ms(c) for c in usable}
                 schedule = min(calibration, key=calibration.get)
             elif usable:
                 schedule = usable[0]
-            candidates = candidates[2:]
+            candidates = []
         for cand in ([] if schedule else candidates):
             if passes(cand):
                 schedule = cand
