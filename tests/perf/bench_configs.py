@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine, telescope  # noqa: E402
 from oracle import flashe_oracle as orc  # noqa: E402

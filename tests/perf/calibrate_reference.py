@@ -9,7 +9,7 @@ from functools import reduce
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(ROOT, "tests", "golden", "gen_golden.py"))
 gg = importlib.util.module_from_spec(spec)
