@@ -286,6 +286,8 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
         else if (!strcmp(be, "bitslice16")) ctx->env.prf_backend = PRF_BITSLICE16;
     }
     if (const char *pm = getenv("FLASHE_HYBRID_BS_PERMILLE")) ctx->env.hybrid_bs_permille = atoi(pm);
+    ctx->env.use_chain = 1;
+    if (const char *ch = getenv("FLASHE_CHAIN")) ctx->env.use_chain = atoi(ch) != 0;   // 0: every job computes both of its streams (A/B runs)
     *out = ctx;
     return FLASHE_OK;
 }

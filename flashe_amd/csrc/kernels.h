@@ -23,6 +23,7 @@ struct LaunchEnv {
     hipStream_t stream2;
     hipEvent_t ev_fork, ev_join;
     int hybrid_bs_permille;
+    int use_chain;             // 1 (default): jobs over the same range that share a prefix share the PRF stream (prf_chain_kernel)
 };
 
 enum { PRF_AUTO = 0, PRF_TABLE = 1, PRF_BITSLICE = 2, PRF_HYBRID = 3, PRF_BITSLICE16 = 4 };
@@ -61,6 +62,23 @@ struct PrfJob {
 };
 hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n,
                            uint32_t n_jobs);
+
+// Chained jobs (int_bits > 64): `n_out` outputs over elements [first, first + count) that share their PRF streams.
+// Double mask (single == false): n_out + 1 prefixes, out[c] = in[c] + term(idx[c]) - term(idx[c + 1]) -- consecutive clients
+// (idx[c + 1] = idx[c] + 1, jzf_flashe.py:349-353) cost n_out + 1 streams instead of 2 n_out; a plain (add, minus) job is a chain
+// of one output.  single == true: n_out prefixes, out[c] = in[c] + term(idx[c]).  idx, in_dev, out_dev are HOST arrays; in_dev (or
+// an entry of it) may be null = zeros; device pointers address element `first`.  Returns hipErrorNotSupported when a chain cannot
+// take this path (int_bits <= 64, a range that straddles a 2^32 counter boundary): the caller then uses launch_prf_jobs.
+struct PrfChain {
+    const uint32_t *idx;
+    int n_out;
+    bool single;
+    uint64_t first, count;
+    const uint64_t *const *in_dev;
+    int in_limbs;
+    uint64_t *const *out_dev;
+};
+hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains);
 
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
                           const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);

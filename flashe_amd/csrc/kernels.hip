@@ -13,7 +13,9 @@
 //     round-robin; there is no inter-workgroup reuse, so no XCD remap is needed.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace flashe {
 
@@ -562,6 +564,193 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
     }
 }
 
+// ---- chained jobs (b > 64): C consecutive clients share their PRF streams -------------------------------------
+// Client c of the double-mask scheme encrypts with term(idx_c) - term(idx_c + 1) (jzf_flashe.py:349-353,480-481):
+// the minus stream of client c IS the add stream of client c + 1.  A CHAIN of `len` outputs over one element range
+// has len + 1 streams s_0 .. s_len and out_c = in_c + S(s_c) - S(s_{c+1}); every stream is computed ONCE per
+// element (11 AES blocks per element-position for ten clients instead of 20).  A plain (add, minus) job is a chain
+// of length 1; a SINGLE chain has one stream per output and no subtraction (single-mask encrypts, mask precompute).
+//
+// Work unit = a wave tile: 256 consecutive counters aligned to 256, so bytes 1..3 of the low counter word are
+// wave-uniform (the scalar-cache step of the CTR shortcut), walked as two PAIRS of elements per lane; a pair runs
+// through the software-pipelined two-block rounds, both blocks on the SAME prefix.  The stream loop is the outer
+// loop: per (tile, stream) one wave-uniform prefix fetch + 15 scalar-cache lookups, then 4 blocks per lane; the
+// previous stream's blocks of the lane's 4 elements stay in registers (16 VGPRs) for the subtraction.
+// Dealing: tiles are weighted by their stream count; workgroup g owns the tiles whose weight offset falls into
+// [W g / G, W (g + 1) / G) -- contiguous memory per workgroup -- and its 16 waves take them round-robin; what is
+// left of a workgroup's share after whole rounds is cut into HALF tiles (one pair per lane, one-step shortcut) so
+// that no wave ends up with a whole 256 x (len + 1)-block tile more than its neighbours.  Short launches
+// (all_half) run entirely in half tiles.
+constexpr int kMaxChains = 16;       // chains per launch
+constexpr int kMaxLinks = 128;       // outputs per launch, all chains together
+struct ChainTable {
+    uint64_t first[kMaxChains], count[kMaxChains];     // element range (global indices = PRF counters)
+    uint64_t wend[kMaxChains];                         // running total of tiles x streams
+    uint16_t link0[kMaxChains], sbase[kMaxChains];     // first output / first stream of the chain in the flat arrays
+    uint8_t len[kMaxChains];                           // outputs of the chain
+    uint8_t flags[kMaxChains];                         // bit 0: SINGLE, bit 1: two-limb inputs
+    uint32_t idx[kMaxLinks + kMaxChains];              // prefix index of every stream
+    const uint64_t *in[kMaxLinks];                     // may be null (zeros); addresses element first[chain]
+    uint64_t *out[kMaxLinks];
+};
+
+__device__ __forceinline__ CtrPrefix load_prefix(const uint32_t *pre_lds, int s)
+{
+    const uint4 v = *reinterpret_cast<const uint4 *>(pre_lds + 4 * s);       // wave-uniform address: a broadcast read
+    return CtrPrefix{{static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v.x)), static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v.y)),
+                      static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v.z)), static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v.w))}};
+}
+
+// An unconditional use of two loaded values: the compiler places the wait for their loads HERE, on the straight-line path,
+// instead of inside the exec-masked store branches (where a skipped branch leaves the loads "possibly in flight" in its
+// path-insensitive bookkeeping and every later wait becomes vmcnt(0), which also waits for the stores just issued).
+__device__ __forceinline__ void loads_landed(const u128 &a, const u128 &b)
+{
+    asm volatile("" ::"v"(static_cast<uint64_t>(a)), "v"(static_cast<uint64_t>(a >> 64)), "v"(static_cast<uint64_t>(b)),
+                 "v"(static_cast<uint64_t>(b >> 64)));
+}
+
+template <class T> __device__ __forceinline__ void swap_regs(T &a, T &b) { const T t = a; a = b; b = t; }
+
+// a wave-uniform 64-bit value read from LDS, moved to SGPRs so that what is derived from it stays scalar
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v))) |
+           (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32)))) << 32);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, const ChainTable tb, int n_chains, int all_half,
+                                                              uint32_t iter, uint64_t mask_lo, uint64_t mask_hi,
+                                                              const uint32_t *__restrict__ te0)
+{
+    constexpr uint32_t WAVES = THREADS / 64;
+    __shared__ uint32_t tab[kTabWords];
+    __shared__ __attribute__((aligned(16))) uint32_t pre_lds[(kMaxLinks + kMaxChains) * 4];
+    __shared__ uint64_t d_tlo[kMaxChains], d_cend[kMaxChains];
+    fill_tables(tab, te0);
+    const LaneRegs lr = lane_regs(tab);
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    {
+        // round-1 prefix words of every stream (chains never straddle a 2^32 counter window: host-checked)
+        const int last = n_chains - 1;
+        const int n_streams = tb.sbase[last] + tb.len[last] + ((tb.flags[last] & 1) ? 0 : 1);
+        for (int s = threadIdx.x; s < n_streams; s += THREADS) {
+            int i = 0;
+            while (i < last && s >= tb.sbase[i + 1]) i++;
+            const CtrPrefix c = ctr_prefix(rk, lr, iter, tb.idx[s], static_cast<uint32_t>(tb.first[i] >> 32));
+            *reinterpret_cast<uint4 *>(pre_lds + 4 * s) = make_uint4(c.u[0], c.u[1], c.u[2], c.u[3]);
+        }
+        // this workgroup's tiles of every chain
+        if (threadIdx.x == 0) {
+            const uint64_t Wt = tb.wend[last], G = gridDim.x, g = blockIdx.x;
+            const uint64_t lo = Wt / G * g + (Wt % G) * g / G, hi = Wt / G * (g + 1) + (Wt % G) * (g + 1) / G;
+            uint64_t cw = 0, acc = 0;
+            for (int i = 0; i < n_chains; i++) {
+                const uint64_t w = tb.len[i] + ((tb.flags[i] & 1) ? 0 : 1), T = (tb.wend[i] - cw) / w;
+                uint64_t a = lo > cw ? (lo - cw + w - 1) / w : 0, b = hi > cw ? (hi - cw + w - 1) / w : 0;
+                if (a > T) a = T;
+                if (b > T) b = T;
+                d_tlo[i] = a; acc += b - a; d_cend[i] = acc; cw = tb.wend[i];
+            }
+        }
+        __syncthreads();
+    }
+    const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t Ng = uniform64(d_cend[n_chains - 1]);
+    const uint64_t n_full = all_half ? 0 : Ng - Ng % WAVES;
+    const uint64_t n_items = n_full + 2 * (Ng - n_full);
+    int cur = 0;
+    uint64_t cbeg = 0;                                                     // local index of chain cur's first tile
+    for (uint64_t q = wave; q < n_items; q += WAVES) {
+        const bool whole = q < n_full;
+        const uint64_t L = whole ? q : n_full + ((q - n_full) >> 1);
+        const uint32_t half = whole ? 0u : static_cast<uint32_t>((q - n_full) & 1u);
+        while (L >= uniform64(d_cend[cur])) cbeg = uniform64(d_cend[cur++]);
+        const uint64_t first = tb.first[cur], end = first + tb.count[cur];
+        const uint64_t tj = (first & ~255ull) + 256u * (uniform64(d_tlo[cur]) + (L - cbeg)) + 128u * half;   // first counter of the item
+        const int link0 = tb.link0[cur], sbase = tb.sbase[cur];
+        const bool single = tb.flags[cur] & 1, in2 = tb.flags[cur] & 2;
+        const int n_streams = tb.len[cur] + (single ? 0 : 1);
+        if (whole) {
+            // ---- 256 elements: two pairs per lane, wave-uniform part of rounds 1-2 through the scalar cache ----
+            const uint32_t x3 = static_cast<uint32_t>(tj) ^ rk.w[3];
+            const uint32_t jl = static_cast<uint32_t>(tj) + lane;
+            uint32_t vA0 = T3(jl ^ rk.w[3], SEL_B0), vA1 = T3((jl + 64u) ^ rk.w[3], SEL_B0);
+            uint32_t vB0 = T3((jl + 128u) ^ rk.w[3], SEL_B0), vB1 = T3((jl + 192u) ^ rk.w[3], SEL_B0);
+            u128 pA0 = 0, pA1 = 0, pB0 = 0, pB1 = 0;
+            for (int c = 0; c < n_streams; c++) {
+                const CtrPrefix pre = load_prefix(pre_lds, sbase + c);
+                const CtrUniform U = ctr_uniform(rk, te0, pre, x3);
+                const int link = single ? c : c - 1;                   // the output this stream completes
+                const uint64_t *in = link >= 0 ? tb.in[link0 + link] : nullptr;
+                uint64_t *out = link >= 0 ? tb.out[link0 + link] : nullptr;
+#pragma unroll 1
+                for (int p = 0; p < 2; p++) {
+                    const uint64_t jb = tj + 128u * p;
+                    if (jb < end && jb + 128u > first) {
+                        const uint64_t j0 = jb + lane, j1 = j0 + 64u, k0 = j0 - first, k1 = j1 - first;
+                        const bool a0 = j0 >= first && j0 < end, a1 = j1 >= first && j1 < end;
+                        // every load is consumed on every path (the adds below are unconditional, only the stores are
+                        // predicated): otherwise the compiler must assume a load may still be in flight at the loop's back
+                        // edge and drains the memory queue -- stores included -- every iteration
+                        u128 x0 = 0, x1 = 0;
+                        if (in != nullptr && in2) {
+                            if (a0) x0 = ld128(in + 2 * k0);
+                            if (a1) x1 = ld128(in + 2 * k1);
+                        } else if (in != nullptr) {
+                            if (a0) x0 = static_cast<u128>(in[k0]);
+                            if (a1) x1 = static_cast<u128>(in[k1]);
+                        }
+                        uint32_t s[2][4];
+                        ctr_round2(lr, pre.u[0], vA0, U, s[0]);
+                        ctr_round2(lr, pre.u[0], vA1, U, s[1]);
+                        aes256_rounds<2, 3>(rk, lr, s);
+                        loads_landed(x0, x1);
+                        const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
+                        const u128 r0 = x0 + (single ? c0 : pA0 - c0), r1 = x1 + (single ? c1 : pA1 - c1);
+                        if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
+                        if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
+                        pA0 = c0; pA1 = c1;
+                    }
+                    swap_regs(pA0, pB0); swap_regs(pA1, pB1); swap_regs(vA0, vB0); swap_regs(vA1, vB1);
+                }
+            }
+        } else if (tj < end && tj + 128u > first) {
+            // ---- 128 elements: one pair per lane; the four counter-dependent lookups of round 1 are shared by all streams ----
+            const uint64_t j0 = tj + lane, j1 = j0 + 64u, k0 = j0 - first, k1 = j1 - first;
+            const bool a0 = j0 >= first && j0 < end, a1 = j1 >= first && j1 < end;
+            const CtrVar xv0 = ctr_var(rk, lr, static_cast<uint32_t>(j0)), xv1 = ctr_var(rk, lr, static_cast<uint32_t>(j1));
+            u128 p0 = 0, p1 = 0;
+            for (int c = 0; c < n_streams; c++) {
+                const CtrPrefix pre = load_prefix(pre_lds, sbase + c);
+                const int link = single ? c : c - 1;
+                const uint64_t *in = link >= 0 ? tb.in[link0 + link] : nullptr;
+                uint64_t *out = link >= 0 ? tb.out[link0 + link] : nullptr;
+                u128 x0 = 0, x1 = 0;
+                if (in != nullptr && in2) {
+                    if (a0) x0 = ld128(in + 2 * k0);
+                    if (a1) x1 = ld128(in + 2 * k1);
+                } else if (in != nullptr) {
+                    if (a0) x0 = static_cast<u128>(in[k0]);
+                    if (a1) x1 = static_cast<u128>(in[k1]);
+                }
+                uint32_t s[2][4];
+                ctr_round1(pre, xv0, s[0]);
+                ctr_round1(pre, xv1, s[1]);
+                aes256_rounds<2, 2>(rk, lr, s);
+                loads_landed(x0, x1);
+                const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
+                const u128 r0 = x0 + (single ? c0 : p0 - c0), r1 = x1 + (single ? c1 : p1 - c1);
+                if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
+                if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
+                p0 = c0; p1 = c1;
+            }
+        }
+    }
+}
+
 // ---- b <= 64: one AES block (m = 128 / b elements) per lane, chunk-dependent counters ----
 // Bits [sh, sh + 64) of S (caller masks to b bits).
 __device__ __forceinline__ uint64_t extract64(u128 S, int sh)
@@ -1044,6 +1233,24 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
 {
     if (n == 0 || n_vec == 0) return hipSuccess;
     if (n_vec > (env.b > 64 ? kMaxUniform : kMaxBatch)) return hipErrorInvalidValue;
+    if (env.b > 64 && env.use_chain) {
+        // runs of consecutive clients share their streams (double mask); single mask: one stream per vector
+        std::vector<uint32_t> sidx;
+        std::vector<PrfChain> chains;
+        std::vector<int> starts;
+        for (int v = 0; v < n_vec;) {
+            int w = v + 1;
+            while (w < n_vec && (!dbl || idx[w] == idx[w - 1] + 1u)) w++;
+            starts.push_back(static_cast<int>(sidx.size()));
+            for (int k = v; k < w; k++) sidx.push_back(idx[k]);
+            if (dbl) sidx.push_back(idx[w - 1] + 1u);
+            chains.push_back(PrfChain{nullptr, w - v, !dbl, 0, n, in_dev + v, in_limbs, out_dev + v});
+            v = w;
+        }
+        for (size_t c = 0; c < chains.size(); c++) chains[c].idx = sidx.data() + starts[c];
+        const hipError_t e = launch_prf_chains(env, iter, static_cast<int>(chains.size()), chains.data());
+        if (e != hipErrorNotSupported) return e;
+    }
     if (env.b > 64 && n_vec > kMaxBatch) {
         // many equal vectors: compact table, one launch
         if (n_vec > kMaxUniform) return hipErrorInvalidValue;
@@ -1114,10 +1321,46 @@ static hipError_t launch_prf_jobs_small(const LaunchEnv &env, uint32_t iter, boo
     return hipGetLastError();
 }
 
+// Jobs -> chains: neighbours over the same element range are linked when the minus prefix of one is the add prefix of the
+// next (double mask), or simply collected (single mask).  hipErrorNotSupported = use the job-table kernel.
+static hipError_t launch_jobs_as_chains(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs)
+{
+    if (!env.use_chain || env.b <= 64) return hipErrorNotSupported;
+    struct Build { std::vector<uint32_t> idx; std::vector<const uint64_t *> in; std::vector<uint64_t *> out; uint64_t first, count; int in_limbs; };
+    std::vector<Build> bs;
+    for (int e = 0; e < n_entries; e++) {
+        const PrfJob &j = jobs[e];
+        if (j.n_in > 1) return hipErrorNotSupported;
+        if (j.count == 0) continue;
+        const int il = j.in_dev ? j.in_limbs : 0;
+        Build *b = bs.empty() ? nullptr : &bs.back();
+        const bool link = b && b->first == j.first && b->count == j.count && (il == 0 || b->in_limbs == 0 || b->in_limbs == il) &&
+                          (!dbl || b->idx.back() == j.add_idx);
+        if (!link) {
+            bs.push_back(Build{{}, {}, {}, j.first, j.count, 0});
+            b = &bs.back();
+            b->idx.push_back(j.add_idx);
+        } else if (!dbl) {
+            b->idx.push_back(j.add_idx);
+        }
+        if (dbl) b->idx.push_back(j.minus_idx);
+        if (il) b->in_limbs = il;
+        b->in.push_back(j.in_dev); b->out.push_back(j.out_dev);
+    }
+    std::vector<PrfChain> chains;
+    for (const Build &b : bs)
+        chains.push_back(PrfChain{b.idx.data(), static_cast<int>(b.out.size()), !dbl, b.first, b.count, b.in.data(), b.in_limbs ? b.in_limbs : 1, b.out.data()});
+    return launch_prf_chains(env, iter, static_cast<int>(chains.size()), chains.data());
+}
+
 hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n, uint32_t n_jobs)
 {
     if (n_entries > kMaxBatch) return hipErrorInvalidValue;
     if (env.b <= 64) return launch_prf_jobs_small(env, iter, dbl, n_entries, jobs, n, n_jobs);
+    {
+        const hipError_t e = launch_jobs_as_chains(env, iter, dbl, n_entries, jobs);
+        if (e != hipErrorNotSupported) return e;
+    }
     JobTable tb{};
     int nv = 0;
     uint64_t big[kMaxBatch];
@@ -1164,6 +1407,76 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
     else { if (summed) JOBS_LAUNCH(false, 2); else if (nv > 1) JOBS_LAUNCH(false, 1); else JOBS_LAUNCH(false, 0); }
 #undef JOBS_LAUNCH
     return hipGetLastError();
+}
+
+// Chained launch (b > 64): see prf_chain_kernel.  Long chains are cut where the per-launch tables end (the stream at a
+// cut is computed by both pieces); short launches are cut further so that every wave of the chip gets an item.
+hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains)
+{
+    if (env.b <= 64) return hipErrorNotSupported;
+    struct Piece { const PrfChain *ch; int l0, l1; uint64_t tiles; };
+    std::vector<Piece> pieces;
+    uint64_t total_tiles = 0;
+    for (int i = 0; i < n_chains; i++) {
+        const PrfChain &c = chains[i];
+        if (c.count == 0 || c.n_out == 0) continue;
+        if (((c.first + c.count - 1) >> 32) != (c.first >> 32)) return hipErrorNotSupported;     // the CTR shortcuts need one counter window
+        const uint64_t tiles = (c.first + c.count - (c.first & ~255ull) + 255) / 256;
+        pieces.push_back(Piece{&c, 0, c.n_out, tiles});
+        total_tiles += tiles;
+    }
+    if (pieces.empty()) return hipSuccess;
+    const uint64_t waves = static_cast<uint64_t>(env.num_cus) * (kPrfThreads / 64);
+    const bool all_half = total_tiles < 2 * waves;
+    // cut: (1) table limits, (2) parallelism of short launches (never below 4 outputs per piece: a cut costs one stream)
+    std::vector<Piece> cut;
+    for (const Piece &pc : pieces) {
+        int parts = (pc.l1 + kMaxLinks - 1) / kMaxLinks;
+        if (all_half && 2 * total_tiles < waves) {
+            const uint64_t want = waves / (2 * total_tiles);
+            const int cap = std::max(1, pc.l1 / 4);
+            parts = std::max<int>(parts, static_cast<int>(std::min<uint64_t>(want, static_cast<uint64_t>(cap))));
+            parts = std::min(parts, std::max(1, kMaxChains / static_cast<int>(pieces.size())));
+            parts = std::max(parts, (pc.l1 + kMaxLinks - 1) / kMaxLinks);
+        }
+        for (int k = 0; k < parts; k++) {
+            const int a = static_cast<int>(static_cast<int64_t>(pc.l1) * k / parts), b = static_cast<int>(static_cast<int64_t>(pc.l1) * (k + 1) / parts);
+            if (b > a) cut.push_back(Piece{pc.ch, a, b, pc.tiles});
+        }
+    }
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    size_t at = 0;
+    while (at < cut.size()) {
+        ChainTable tb{};
+        int nc = 0, links = 0, streams = 0;
+        uint64_t wend = 0, tiles = 0;
+        while (at < cut.size() && nc < kMaxChains && links + (cut[at].l1 - cut[at].l0) <= kMaxLinks) {
+            const Piece &pc = cut[at++];
+            const PrfChain &c = *pc.ch;
+            const int len = pc.l1 - pc.l0, ns = len + (c.single ? 0 : 1);
+            tb.first[nc] = c.first; tb.count[nc] = c.count;
+            tb.link0[nc] = static_cast<uint16_t>(links); tb.sbase[nc] = static_cast<uint16_t>(streams);
+            tb.len[nc] = static_cast<uint8_t>(len);
+            tb.flags[nc] = static_cast<uint8_t>((c.single ? 1 : 0) | (c.in_limbs == 2 ? 2 : 0));
+            for (int s = 0; s < ns; s++) tb.idx[streams + s] = c.idx[pc.l0 + s];
+            for (int l = 0; l < len; l++) {
+                tb.in[links + l] = c.in_dev ? c.in_dev[pc.l0 + l] : nullptr;
+                tb.out[links + l] = c.out_dev[pc.l0 + l];
+            }
+            wend += pc.tiles * static_cast<uint64_t>(ns);
+            tb.wend[nc] = wend;
+            tiles += pc.tiles;
+            links += len; streams += ns; nc++;
+        }
+        const uint64_t items = all_half ? 2 * tiles : tiles, cus = static_cast<uint64_t>(env.num_cus);
+        const int grid = static_cast<int>(items < cus ? items : cus);
+        hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc, all_half ? 1 : 0,
+                           iter, lo, hi, env.te0_dev);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t *in_words_dev, uint32_t *out_words_dev)
