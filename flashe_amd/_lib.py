@@ -73,6 +73,7 @@ _SIGNATURES = {
     "flashe_graph_begin": (c_int, [c_vp]),
     "flashe_graph_end": (c_int, [c_vp, ctypes.POINTER(c_vp)]),
     "flashe_graph_launch": (c_int, [c_vp, c_vp]),
+    "flashe_graph_launch_shifted": (c_int, [c_vp, c_vp, c_u32]),
     "flashe_graph_destroy": (c_int, [c_vp]),
     "flashe_prf_jobs_dev": (c_int, [c_vp, c_u32, c_u64, c_u32, c_int, ctypes.POINTER(PrfJob)]),
     "flashe_encrypt_batch_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp)]),

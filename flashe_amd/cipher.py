@@ -43,11 +43,24 @@ def _to_limbs(value, limbs):
         out = np.empty((n, limbs), dtype=np.uint64)
         if n:
             try:
-                # the usual case -- non-negative values below 2**64 -- converts in one C loop
-                out[:, 0] = value.astype(np.uint64)
+                # the usual case -- non-negative values below 2**64 -- converts in C loops.  A negative value must NOT take
+                # this path: the reference reduces it mod 2**int_bits (sign-extended high limb), and astype(uint64) would wrap
+                # a negative NumPy scalar held in the object array without raising.
+                try:
+                    low = value.astype(np.int64)                 # raises beyond int64
+                    if (low < 0).any():
+                        raise OverflowError("negative value")
+                    out[:, 0] = low.view(np.uint64)
+                except OverflowError:
+                    low = value.astype(np.uint64)                # values in [2**63, 2**64); raises beyond
+                    if (value.astype(np.float64) < 0).any():
+                        raise OverflowError("negative value")
+                    out[:, 0] = low
                 if limbs == 2:
                     out[:, 1] = 0
             except (OverflowError, TypeError):
+                # the general path works on Python ints (NumPy scalars held in the object array would overflow in `&`)
+                value = np.fromiter((int(v) for v in value), dtype=object, count=n)
                 out[:, 0] = (value & _M64).astype(np.uint64)
                 if limbs == 2:
                     out[:, 1] = ((value >> 64) & _M64).astype(np.uint64)

@@ -131,11 +131,14 @@ struct flashe_ctx {
     Buf sp_ws;        // sparsifier workspace (select state, histogram, per-block counts)
     Buf bounds;       // span reduce: first entry of every client in every span
     bool capturing = false;   // between flashe_graph_begin and flashe_graph_end
+    uint32_t key_epoch = 0;   // bumped by flashe_ctx_set_key: a graph replays the key it was captured with
+    uint32_t *err_flag_host = nullptr;   // host-mapped word the sparse kernels set when they skip an out-of-range location
 };
 
 struct flashe_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    uint32_t key_epoch = 0;
 };
 
 namespace {
@@ -177,6 +180,13 @@ int ensure(flashe_ctx *ctx, flashe_ctx::Buf &b, size_t bytes)
     return FLASHE_OK;
 }
 
+// Zero memory that held key material in a way the optimiser may not drop.
+void wipe(void *p, size_t bytes)
+{
+    volatile uint8_t *q = static_cast<volatile uint8_t *>(p);
+    for (size_t i = 0; i < bytes; i++) q[i] = 0;
+}
+
 // Device copy of the expanded key for the bit-sliced PRF (it scalar-loads 4 words per round).
 int upload_key_words(flashe_ctx *ctx)
 {
@@ -190,8 +200,21 @@ int upload_key_words(flashe_ctx *ctx)
                 auto bit = [&](int byte) { return (ctx->env.rk.w[4 * r + byte / 4] >> (24 - 8 * (byte % 4) + k)) & 1u; };
                 planes[64 * r + 8 * B + k] = (bit(B) ? 0xffffu : 0u) | (bit(B + 8) ? 0xffff0000u : 0u);
             }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->rkp_dev, planes.data(), planes.size() * 4, hipMemcpyHostToDevice, ctx->env.stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
+    hipError_t e = hipMemcpyAsync(ctx->rkp_dev, planes.data(), planes.size() * 4, hipMemcpyHostToDevice, ctx->env.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->env.stream);
+    wipe(planes.data(), planes.size() * 4);
+    HIP_TRY(ctx, e);
+    return FLASHE_OK;
+}
+
+// After a synchronisation point: did a sparse kernel meet (and skip) a location >= total since the last check?
+int check_device_flag(flashe_ctx *ctx)
+{
+    if (ctx->err_flag_host && *static_cast<volatile uint32_t *>(ctx->err_flag_host)) {
+        *static_cast<volatile uint32_t *>(ctx->err_flag_host) = 0;
+        return fail(ctx, FLASHE_EINVAL, "a sparse location list held a position >= total, or a list passed as sorted was not "
+                                        "strictly increasing (the offending entries were skipped, nothing was written out of bounds)");
+    }
     return FLASHE_OK;
 }
 
@@ -238,9 +261,10 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
     ctx->device = device;
     ctx->int_bits = int_bits;
     ctx->limbs = int_bits > 64 ? 2 : 1;
+    // every failure path releases what was created so far (and wipes the key) through flashe_ctx_destroy
     auto bail = [&](int code, const char *what, hipError_t e) {
         fail(nullptr, code, "%s: %s", what, hipGetErrorString(e));
-        delete ctx;
+        (void)flashe_ctx_destroy(ctx);
         return code;
     };
     hipError_t e;
@@ -256,8 +280,8 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
     ctx->env.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->env.b = int_bits;
     // Te0 followed by Te1..Te3 (byte rotations of Te0): 4 KiB; the kernels fill LDS from the first KiB and use the
-    // whole table for wave-uniform lookups through the scalar cache
-    uint32_t te4[1024];
+    // whole table for wave-uniform lookups through the scalar cache.  Word 1024 = the iter shift (kernels.hip), 0 by default.
+    uint32_t te4[1024 + 4] = {};
     for (int t = 0; t < 4; t++)
         for (int x = 0; x < 256; x++) te4[256 * t + x] = t ? ror(aes_tables().te0[x], 8 * t) : aes_tables().te0[x];
     if ((e = hipMalloc(&ctx->te0_dev, sizeof(te4))) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(te0)", e);
@@ -268,10 +292,15 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
     ctx->env.rkw_dev = ctx->rkw_dev;
     if ((e = hipMalloc(&ctx->rkp_dev, 15 * 64 * 4)) != hipSuccess) return bail(FLASHE_ENOMEM, "hipMalloc(rkp)", e);
     ctx->env.rkp_dev = ctx->rkp_dev;
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&ctx->err_flag_host), 64, hipHostMallocMapped)) != hipSuccess)
+        return bail(FLASHE_ENOMEM, "hipHostMalloc(error flag)", e);
+    *ctx->err_flag_host = 0;
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void **>(&ctx->env.err_flag), ctx->err_flag_host, 0)) != hipSuccess)
+        return bail(FLASHE_EIO, "hipHostGetDevicePointer", e);
     expand_key(key, &ctx->env.rk);
     if (upload_key_words(ctx) != FLASHE_OK) {
         g_create_error = ctx->err;
-        delete ctx;
+        (void)flashe_ctx_destroy(ctx);
         return FLASHE_EIO;
     }
     ctx->env.prf_backend = PRF_AUTO;
@@ -296,16 +325,19 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
 {
     if (!ctx) return FLASHE_EINVAL;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->env.stream);
+    if (ctx->env.stream) (void)hipStreamSynchronize(ctx->env.stream);
     for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds})
         if (b->p) (void)hipFree(b->p);
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
-    if (ctx->rkw_dev) (void)hipFree(ctx->rkw_dev);
-    if (ctx->rkp_dev) (void)hipFree(ctx->rkp_dev);
+    // the expanded AES-256 key leaves neither HBM nor host memory behind
+    if (ctx->rkw_dev) { (void)hipMemset(ctx->rkw_dev, 0, 256); (void)hipFree(ctx->rkw_dev); }
+    if (ctx->rkp_dev) { (void)hipMemset(ctx->rkp_dev, 0, 15 * 64 * 4); (void)hipFree(ctx->rkp_dev); }
+    wipe(&ctx->env.rk, sizeof(ctx->env.rk));
+    if (ctx->err_flag_host) (void)hipHostFree(ctx->err_flag_host);
     if (ctx->env.stream2) { (void)hipStreamSynchronize(ctx->env.stream2); (void)hipStreamDestroy(ctx->env.stream2); }
     if (ctx->env.ev_fork) (void)hipEventDestroy(ctx->env.ev_fork);
     if (ctx->env.ev_join) (void)hipEventDestroy(ctx->env.ev_join);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->env.stream);
+    if (ctx->own_stream && ctx->env.stream) (void)hipStreamDestroy(ctx->env.stream);
     delete ctx;
     return FLASHE_OK;
 }
@@ -315,7 +347,9 @@ int flashe_ctx_set_key(flashe_ctx *ctx, const uint8_t key[32])
     if (!ctx || !key) return FLASHE_EINVAL;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
+    wipe(&ctx->env.rk, sizeof(ctx->env.rk));
     expand_key(key, &ctx->env.rk);
+    ctx->key_epoch++;             // graphs captured under the previous key refuse to replay
     return upload_key_words(ctx);
 }
 
@@ -433,7 +467,7 @@ int flashe_memcpy_d2h(flashe_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
     CHECK_CTX(ctx);
     if (bytes) { HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->env.stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); }
-    return FLASHE_OK;
+    return check_device_flag(ctx);
 }
 int flashe_memcpy_d2d(flashe_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
@@ -451,7 +485,7 @@ int flashe_sync(flashe_ctx *ctx)
 {
     CHECK_CTX(ctx);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
-    return FLASHE_OK;
+    return check_device_flag(ctx);
 }
 int flashe_event_create(flashe_ctx *ctx, void **event)
 {
@@ -506,6 +540,7 @@ int flashe_graph_end(flashe_ctx *ctx, flashe_graph **graph)
     flashe_graph *out = new (std::nothrow) flashe_graph();
     if (!out) { (void)hipGraphDestroy(g); return fail(ctx, FLASHE_ENOMEM, "out of host memory"); }
     out->graph = g;
+    out->key_epoch = ctx->key_epoch;
     e = hipGraphInstantiate(&out->exec, g, nullptr, nullptr, 0);
     if (e != hipSuccess) {
         (void)hipGraphDestroy(g);
@@ -516,14 +551,24 @@ int flashe_graph_end(flashe_ctx *ctx, flashe_graph **graph)
     return FLASHE_OK;
 }
 
-int flashe_graph_launch(flashe_ctx *ctx, flashe_graph *graph)
+int flashe_graph_launch_shifted(flashe_ctx *ctx, flashe_graph *graph, uint32_t iter_shift)
 {
     CHECK_CTX(ctx);
     if (!graph || !graph->exec) return fail(ctx, FLASHE_EINVAL, "null graph");
     if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "cannot launch a graph while capturing");
+    if (graph->key_epoch != ctx->key_epoch)
+        return fail(ctx, FLASHE_EINVAL, "the graph was captured under a different key (flashe_ctx_set_key since): its kernels carry the old "
+                                        "key schedule in their argument blocks -- capture it again");
+    // kernel arguments (iter included) are frozen into the graph; the shift is a device word every PRF kernel adds to its
+    // iter at run time, set and reset in stream order around the replay
+    uint32_t *shift = ctx->te0_dev + 1024;
+    if (iter_shift) HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(shift), static_cast<int>(iter_shift), 1, ctx->env.stream));
     HIP_TRY(ctx, hipGraphLaunch(graph->exec, ctx->env.stream));
+    if (iter_shift) HIP_TRY(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(shift), 0, 1, ctx->env.stream));
     return FLASHE_OK;
 }
+
+int flashe_graph_launch(flashe_ctx *ctx, flashe_graph *graph) { return flashe_graph_launch_shifted(ctx, graph, 0); }
 
 int flashe_graph_destroy(flashe_graph *graph)
 {
@@ -546,8 +591,7 @@ int flashe_event_elapsed_ms(flashe_ctx *ctx, void *start, void *stop, float *ms)
 // ---- PRF / encrypt / decrypt ----
 static int check_prf_args(flashe_ctx *ctx, int n_add, int n_minus, uint32_t n_jobs, const void *out, const void *in, int in_limbs)
 {
-    if (n_add < 0 || n_minus < 0 || n_add > kMaxIdx || n_minus > kMaxIdx)
-        return fail(ctx, FLASHE_EINVAL, "prefix list length out of range (max %d): add %d minus %d", kMaxIdx, n_add, n_minus);
+    if (n_add < 0 || n_minus < 0) return fail(ctx, FLASHE_EINVAL, "negative prefix list length: add %d minus %d", n_add, n_minus);
     if (n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "n_jobs must be >= 1");
     if (in && in_limbs != 1 && in_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 or %d, got %d", ctx->limbs, in_limbs);
     if (in && ctx->limbs == 1 && in_limbs != 1) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 for int_bits <= 64");
@@ -558,6 +602,28 @@ static int check_prf_args(flashe_ctx *ctx, int n_add, int n_minus, uint32_t n_jo
     return FLASHE_OK;
 }
 
+// out = in + sum term(add[k]) - sum term(minus[k]) over prefix lists of ANY length (the reference sums whatever set_idx_list
+// produced: one minus prefix per uploaded client in single-mask mode, one pair per run of a dropout pattern,
+// jzf_flashe.py:126-150,311-314).  One launch holds kMaxIdx prefixes per list in its argument block; longer lists go in
+// several launches that accumulate in place (first pass in -> out, later passes out -> out: the sums are additive mod 2^b and
+// every lane reads its element before it writes it).
+static hipError_t prf_lists(flashe_ctx *ctx, uint32_t iter, const uint32_t *add, int n_add, const uint32_t *minus, int n_minus,
+                            uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count, const uint64_t *in_dev, int in_limbs,
+                            uint64_t *out_dev)
+{
+    int a = 0, m = 0;
+    bool first_pass = true;
+    while (first_pass || a < n_add || m < n_minus) {
+        const int na = std::min(kMaxIdx, n_add - a), nm = std::min(kMaxIdx, n_minus - m);
+        const hipError_t e = launch_prf(ctx->env, iter, add + a, na, minus + m, nm, n, n_jobs, first, count,
+                                        first_pass ? in_dev : out_dev, first_pass ? in_limbs : ctx->limbs, out_dev);
+        if (e != hipSuccess) return e;
+        a += na; m += nm;
+        first_pass = false;
+    }
+    return hipSuccess;
+}
+
 int flashe_mask_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx, uint64_t n, uint32_t n_jobs, uint64_t *out_dev)
 {
     CHECK_CTX(ctx);
@@ -565,7 +631,7 @@ int flashe_mask_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_i
     int rc = check_prf_args(ctx, n_idx, 0, n_jobs, out_dev, nullptr, 0);
     if (rc) return rc;
     if (n_idx == 0) { if (n) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, n), ctx->env.stream)); return FLASHE_OK; }
-    HIP_TRY(ctx, launch_prf(ctx->env, iter, idx, n_idx, nullptr, 0, n, n_jobs, 0, n, nullptr, 0, out_dev));
+    HIP_TRY(ctx, prf_lists(ctx, iter, idx, n_idx, nullptr, 0, n, n_jobs, 0, n, nullptr, 0, out_dev));
     return FLASHE_OK;
 }
 
@@ -666,7 +732,7 @@ int flashe_decrypt_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, 
         HIP_TRY(ctx, launch_combine(ctx->env, n, in_dev, ctx->limbs, nullptr, nullptr, out_dev));
         return FLASHE_OK;
     }
-    HIP_TRY(ctx, launch_prf(ctx->env, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, 0, n, in_dev, ctx->limbs, out_dev));
+    HIP_TRY(ctx, prf_lists(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, 0, n, in_dev, ctx->limbs, out_dev));
     return FLASHE_OK;
 }
 
@@ -687,7 +753,7 @@ int flashe_mask_range_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, i
     int rc = check_prf_args(ctx, n_idx, 0, n_jobs, out_dev, nullptr, 0);
     if (rc || (rc = check_range(ctx, n, first, count))) return rc;
     if (n_idx == 0) { if (count) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, count), ctx->env.stream)); return FLASHE_OK; }
-    HIP_TRY(ctx, launch_prf(ctx->env, iter, idx, n_idx, nullptr, 0, n, n_jobs, first, count, nullptr, 0, out_dev));
+    HIP_TRY(ctx, prf_lists(ctx, iter, idx, n_idx, nullptr, 0, n, n_jobs, first, count, nullptr, 0, out_dev));
     return FLASHE_OK;
 }
 
@@ -717,7 +783,7 @@ int flashe_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add
         HIP_TRY(ctx, launch_combine(ctx->env, count, in_dev, ctx->limbs, nullptr, nullptr, out_dev));
         return FLASHE_OK;
     }
-    HIP_TRY(ctx, launch_prf(ctx->env, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, first, count, in_dev, ctx->limbs, out_dev));
+    HIP_TRY(ctx, prf_lists(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, first, count, in_dev, ctx->limbs, out_dev));
     return FLASHE_OK;
 }
 
@@ -877,7 +943,7 @@ int flashe_expand_to_dense_dev(flashe_ctx *ctx, uint64_t total, uint64_t k, cons
     if (!zero || (total && !out_dev) || (k && (!loc_dev || !vals_dev))) return fail(ctx, FLASHE_EINVAL, "null argument");
     if (ctx->limbs == 2 && (!aligned16(out_dev) || !aligned16(vals_dev))) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
     HIP_TRY(ctx, launch_fill(ctx->env, total, zero[0], ctx->limbs == 2 ? zero[1] : 0, out_dev));
-    HIP_TRY(ctx, launch_scatter(ctx->env, k, loc_dev, vals_dev, out_dev, false));
+    HIP_TRY(ctx, launch_scatter(ctx->env, total, k, loc_dev, vals_dev, out_dev, false));
     return FLASHE_OK;
 }
 
@@ -913,7 +979,7 @@ int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const ui
     }
     HIP_TRY(ctx, launch_fill(ctx->env, total, static_cast<uint64_t>(zsum), static_cast<uint64_t>(zsum >> 64), out_dev));
     for (int c = 0; c < C; c++)
-        HIP_TRY(ctx, launch_scatter(ctx->env, k[c], loc_dev[c], vals_dev[c], out_dev, true, zeros[static_cast<size_t>(L) * c],
+        HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c], loc_dev[c], vals_dev[c], out_dev, true, zeros[static_cast<size_t>(L) * c],
                                     L == 2 ? zeros[2 * c + 1] : 0));
     return FLASHE_OK;
 }
@@ -953,7 +1019,7 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
                                                 static_cast<uint32_t *>(ctx->bounds.p), c0 != 0, out_dev));
             } else {
                 for (int e = 0; e < nc; e++)
-                    HIP_TRY(ctx, launch_scatter(ctx->env, k[c0 + e], loc_dev[c0 + e], streams[e], out_dev, true));
+                    HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c0 + e], loc_dev[c0 + e], streams[e], out_dev, true));
             }
         }
         return FLASHE_OK;
@@ -965,7 +1031,7 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
         if (!k[c]) continue;
         const uint32_t idx = static_cast<uint32_t>(c);
         HIP_TRY(ctx, launch_prf(ctx->env, iter, &idx, 1, nullptr, 0, k[c], n_jobs, 0, k[c], nullptr, 0, tmp));
-        HIP_TRY(ctx, launch_scatter(ctx->env, k[c], loc_dev[c], tmp, out_dev, true));
+        HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c], loc_dev[c], tmp, out_dev, true));
     }
     return FLASHE_OK;
 }

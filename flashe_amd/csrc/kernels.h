@@ -23,6 +23,7 @@ struct LaunchEnv {
     hipStream_t stream2;
     hipEvent_t ev_fork, ev_join;
     int hybrid_bs_permille;
+    uint32_t *err_flag;        // host-mapped word: set to 1 when a sparse kernel skips an out-of-range / out-of-order location
     int use_chain;             // 1 (default): jobs over the same range that share a prefix share the PRF stream (prf_chain_kernel)
 };
 
@@ -107,7 +108,8 @@ hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev,
 hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
 
 hipError_t launch_fill(const LaunchEnv &env, uint64_t n, uint64_t lo, uint64_t hi, uint64_t *out_dev);
-hipError_t launch_scatter(const LaunchEnv &env, uint64_t k, const uint32_t *loc_dev,
+// locations >= total are skipped and reported through env.err_flag (the reference raises IndexError, jzf_aggregator.py:150-165)
+hipError_t launch_scatter(const LaunchEnv &env, uint64_t total, uint64_t k, const uint32_t *loc_dev,
                           const uint64_t *vals_dev, uint64_t *out_dev, bool accumulate,
                           uint64_t sub_lo = 0, uint64_t sub_hi = 0);
 // Sparse reduce over strictly increasing location lists (LDS-staged, the dense output is written once):

@@ -28,6 +28,10 @@ typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
 // AES-256 core
 // ------------------------------------------------------------------------------------------
 constexpr int kTabWords = 32768;                 // 128 KiB: 4 tables x 256 entries x 32 copies
+// Word 1024 of the device table buffer (right behind Te0..Te3) is the ITER SHIFT of the ctx: every PRF kernel adds it to the iter
+// it was launched with.  It is 0 except while a captured graph is replayed for a later round (flashe_graph_launch_shifted): kernel
+// arguments are frozen into a graph, the shift is read from memory at run time, so a replay never reuses a mask stream.
+constexpr int kIterShiftWord = 1024;
 constexpr int kPrfThreads = 1024;
 
 // v_perm_b32 selectors: D = {0x00, lanereg.byte2, state.byte_k, lanereg.byte0}
@@ -347,6 +351,7 @@ struct PrfParams {
 // encrypt, the no-dropout decrypt, the mask streams -- go through prf_wide_batch_kernel below.
 __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys rk, const PrfParams p, const IdxLists lists)
 {
+    const uint32_t iter = p.iter + p.te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, p.te0);
     const LaneRegs lr = lane_regs(tab);
@@ -363,30 +368,30 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
             int k = 0;
             for (; k + 1 < p.n_add; k += 2) {
                 uint32_t s[2][4];
-                set_block(s[0], p.iter, lists.add[k], j);
-                set_block(s[1], p.iter, lists.add[k + 1], j);
+                set_block(s[0], iter, lists.add[k], j);
+                set_block(s[1], iter, lists.add[k + 1], j);
                 aes256_encrypt<2>(rk, lr, s);
                 acc += words_to_u128(s[0]);
                 acc += words_to_u128(s[1]);
             }
             if (k < p.n_add) {
                 uint32_t s[1][4];
-                set_block(s[0], p.iter, lists.add[k], j);
+                set_block(s[0], iter, lists.add[k], j);
                 aes256_encrypt<1>(rk, lr, s);
                 acc += words_to_u128(s[0]);
             }
             k = 0;
             for (; k + 1 < p.n_minus; k += 2) {
                 uint32_t s[2][4];
-                set_block(s[0], p.iter, lists.minus[k], j);
-                set_block(s[1], p.iter, lists.minus[k + 1], j);
+                set_block(s[0], iter, lists.minus[k], j);
+                set_block(s[1], iter, lists.minus[k + 1], j);
                 aes256_encrypt<2>(rk, lr, s);
                 acc -= words_to_u128(s[0]);
                 acc -= words_to_u128(s[1]);
             }
             if (k < p.n_minus) {
                 uint32_t s[1][4];
-                set_block(s[0], p.iter, lists.minus[k], j);
+                set_block(s[0], iter, lists.minus[k], j);
                 aes256_encrypt<1>(rk, lr, s);
                 acc -= words_to_u128(s[0]);
             }
@@ -459,9 +464,10 @@ constexpr int kBigEpl = 4;
 constexpr int kSumRegs = 10;            // operands held in registers across the rounds (more are added up front)
 template <bool DBL, int THREADS, int KIND, class Table>
 __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys rk, const Table tb, int n_vec, uint64_t n,
-                                                                     uint32_t iter, uint64_t mask_lo, uint64_t mask_hi,
+                                                                     uint32_t iter0, uint64_t mask_lo, uint64_t mask_hi,
                                                                      const uint32_t *__restrict__ te0)
 {
+    const uint32_t iter = iter0 + te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, te0);
     const LaneRegs lr = lane_regs(tab);
@@ -621,9 +627,10 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, const ChainTable tb, int n_chains, int all_half,
-                                                              uint32_t iter, uint64_t mask_lo, uint64_t mask_hi,
+                                                              uint32_t iter0, uint64_t mask_lo, uint64_t mask_hi,
                                                               const uint32_t *__restrict__ te0)
 {
+    const uint32_t iter = iter0 + te0[kIterShiftWord];
     constexpr uint32_t WAVES = THREADS / 64;
     __shared__ uint32_t tab[kTabWords];
     __shared__ __attribute__((aligned(16))) uint32_t pre_lds[(kMaxLinks + kMaxChains) * 4];
@@ -763,6 +770,7 @@ constexpr int kTch = 8;    // elements accumulated in registers per pass
 
 __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKeys rk, const PrfParams p, const IdxLists lists)
 {
+    const uint32_t iter = p.iter + p.te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
     fill_tables(tab, p.te0);
     const LaneRegs lr = lane_regs(tab);
@@ -800,8 +808,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
             int k = 0;
             for (; k + 1 < p.n_add; k += 2) {
                 uint32_t s[2][4];
-                set_block(s[0], p.iter, lists.add[k], ctr);
-                set_block(s[1], p.iter, lists.add[k + 1], ctr);
+                set_block(s[0], iter, lists.add[k], ctr);
+                set_block(s[1], iter, lists.add[k + 1], ctr);
                 aes256_encrypt<2>(rk, lr, s);
                 const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
 #pragma unroll
@@ -809,7 +817,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
             }
             if (k < p.n_add) {
                 uint32_t s[1][4];
-                set_block(s[0], p.iter, lists.add[k], ctr);
+                set_block(s[0], iter, lists.add[k], ctr);
                 aes256_encrypt<1>(rk, lr, s);
                 const u128 S0 = words_to_u128(s[0]);
 #pragma unroll
@@ -818,8 +826,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
             k = 0;
             for (; k + 1 < p.n_minus; k += 2) {
                 uint32_t s[2][4];
-                set_block(s[0], p.iter, lists.minus[k], ctr);
-                set_block(s[1], p.iter, lists.minus[k + 1], ctr);
+                set_block(s[0], iter, lists.minus[k], ctr);
+                set_block(s[1], iter, lists.minus[k + 1], ctr);
                 aes256_encrypt<2>(rk, lr, s);
                 const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
 #pragma unroll
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
             }
             if (k < p.n_minus) {
                 uint32_t s[1][4];
-                set_block(s[0], p.iter, lists.minus[k], ctr);
+                set_block(s[0], iter, lists.minus[k], ctr);
                 aes256_encrypt<1>(rk, lr, s);
                 const u128 S0 = words_to_u128(s[0]);
 #pragma unroll
@@ -868,6 +876,7 @@ template <int NSTREAM>
 __global__ __launch_bounds__(kBsThreads, 2) void prf_wide_bs_kernel(const uint32_t *__restrict__ rkw, const PrfParams p,
                                                                     const uint32_t idx_a, const uint32_t idx_b)
 {
+    const uint32_t iter = p.iter + p.te0[kIterShiftWord];
     constexpr int EPL = 32 / NSTREAM;                   // elements per lane per pass
     constexpr uint64_t TILE = 64ull * EPL;              // elements per wave-pass
     const int lane = threadIdx.x & 63;
@@ -879,7 +888,7 @@ __global__ __launch_bounds__(kBsThreads, 2) void prf_wide_bs_kernel(const uint32
     for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
         uint32_t s[128];
         const uint64_t t_first = p.first + tile * TILE;
-        bs::load_planes<NSTREAM>(s, p.iter, idx_a, idx_b, t_first + lane, t_first, t_first + TILE - 1);
+        bs::load_planes<NSTREAM>(s, iter, idx_a, idx_b, t_first + lane, t_first, t_first + TILE - 1);
         bs::encrypt_planes(s, rkw);
         u128 S[32];
         bs::planes_to_blocks(s, S);
@@ -905,6 +914,7 @@ template <int NSTREAM, int WAVES>
 __global__ __launch_bounds__(kBsThreads, WAVES) void prf_wide_bsp_kernel(const uint32_t *__restrict__ rkp, const PrfParams p,
                                                                          const uint32_t idx_a, const uint32_t idx_b)
 {
+    const uint32_t iter = p.iter + p.te0[kIterShiftWord];
     constexpr int EPL = 16 / NSTREAM;
     constexpr uint64_t TILE = 64ull * EPL;
     const int lane = threadIdx.x & 63;
@@ -915,7 +925,7 @@ __global__ __launch_bounds__(kBsThreads, WAVES) void prf_wide_bsp_kernel(const u
 
     for (uint64_t tile = wave; tile < n_tiles; tile += n_waves) {
         uint32_t s[64];
-        bs::load_planes_p<NSTREAM>(s, p.iter, idx_a, idx_b, p.first + tile * TILE + lane);
+        bs::load_planes_p<NSTREAM>(s, iter, idx_a, idx_b, p.first + tile * TILE + lane);
         bs::encrypt_planes_p(s, rkp);
         u128 S[16];
         bs::planes_to_blocks_p(s, S);
@@ -975,6 +985,7 @@ __device__ __forceinline__ uint32_t udiv_magic(uint32_t x, uint32_t dsr, uint32_
 template <bool DBL>
 __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const RoundKeys rk, const SmallJobTable tb, int n_vec, const SmallParams p)
 {
+    const uint32_t iter = p.iter + p.te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
     __shared__ uint32_t scratch[(kSmallThreads / 64) * 256 + 8];
     fill_tables(tab, p.te0);
@@ -999,8 +1010,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
         while (t >= tb.tile_end[v]) tile0 = tb.tile_end[v++];
         const uint32_t ia = tb.add[v], im = tb.minus[v];
         if (v != cur && ctr_fast) {
-            pre_a = ctr_prefix(rk, lr, p.iter, ia, 0u);
-            if (DBL) pre_b = ctr_prefix(rk, lr, p.iter, im, 0u);
+            pre_a = ctr_prefix(rk, lr, iter, ia, 0u);
+            if (DBL) pre_b = ctr_prefix(rk, lr, iter, im, 0u);
             cur = v;
         }
         const uint64_t Bw = (t - tile0) * 64u;                              // this wave's first block (job-local)
@@ -1041,8 +1052,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
             if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
             aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
         } else {
-            set_block(s[0], p.iter, ia, ctr);
-            if (DBL) set_block(s[DBL ? 1 : 0], p.iter, im, ctr);
+            set_block(s[0], iter, ia, ctr);
+            if (DBL) set_block(s[DBL ? 1 : 0], iter, im, ctr);
             aes256_encrypt<DBL ? 2 : 1>(rk, lr, s);
         }
         const u128 S0 = words_to_u128(s[0]);
@@ -1894,15 +1905,16 @@ __global__ __launch_bounds__(kStreamThreads) void fill_kernel(uint64_t n, int L,
 // out[loc[q]] = vals[q]  or  out[loc[q]] = (out[loc[q]] + vals[q]) mod 2^b.  loc must hold
 // distinct positions within one launch (the reference's location lists are sets).
 // sub (a constant, < 2^b) is subtracted from every value first: the sparse reduce adds vals[q] - zero.
-__global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t k, int L, const uint32_t *loc, const uint64_t *vals,
+__global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t total, uint64_t k, int L, const uint32_t *loc, const uint64_t *vals,
                                                                  uint64_t *out, bool accumulate, uint64_t mask_lo, uint64_t mask_hi,
-                                                                 uint64_t sub_lo, uint64_t sub_hi)
+                                                                 uint64_t sub_lo, uint64_t sub_hi, uint32_t *err_flag)
 {
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
     const u128 sub = (static_cast<u128>(sub_hi) << 64) | sub_lo;
     for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; q < k;
          q += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
         const uint64_t p = loc[q];
+        if (p >= total) { *err_flag = 1; continue; }       // never write outside the dense vector: skip and report
         if (L == 2) {
             u128 v = ld128(vals + 2 * q) - sub;
             if (accumulate) v += ld128(out + 2 * p);
@@ -1946,7 +1958,7 @@ __global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const Scatt
 
 __global__ __launch_bounds__(kStreamThreads) void span_reduce_kernel(const ScatterTable tb, int C, int L, uint64_t total, const uint32_t *start,
                                                                      uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo, uint64_t mask_hi,
-                                                                     bool accumulate_into_out, uint64_t *out)
+                                                                     bool accumulate_into_out, uint64_t *out, uint32_t *err_flag)
 {
     __shared__ unsigned long long acc[2 * kSpan];
     __shared__ uint32_t s_begin[kMaxScatter], s_prefix[kMaxScatter + 1];
@@ -1966,6 +1978,8 @@ __global__ __launch_bounds__(kStreamThreads) void span_reduce_kernel(const Scatt
         s_loc[tid] = tb.loc[tid]; s_vals[tid] = tb.vals[tid];
         s_sub[2 * tid] = tb.sub_lo[tid]; s_sub[2 * tid + 1] = tb.sub_hi[tid];
     }
+    // entries at or beyond the end of the last span belong to no span at all
+    if (span + 1 == gridDim.x && tid < C && start[(span + 1) * C + tid] < tb.k[tid]) *err_flag = 1;
     __syncthreads();
     if (tid == 0) {
         uint32_t run = 0;
@@ -1983,6 +1997,7 @@ __global__ __launch_bounds__(kStreamThreads) void span_reduce_kernel(const Scatt
         const int c = lo;
         const uint64_t q = static_cast<uint64_t>(s_begin[c]) + (f - s_prefix[c]);
         const uint32_t r = s_loc[c][q] - static_cast<uint32_t>(p0);
+        if (r >= span_len) { *err_flag = 1; continue; }    // position >= total, or a list that is not strictly increasing
         if (L == 2) {
             const u128 v = ld128(s_vals[c] + 2 * q) - ((static_cast<u128>(s_sub[2 * c + 1]) << 64) | s_sub[2 * c]);
             const unsigned long long vlo = static_cast<unsigned long long>(v), vhi = static_cast<unsigned long long>(v >> 64);
@@ -2031,7 +2046,7 @@ hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const
     hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>((n_bounds + kStreamThreads - 1) / kStreamThreads)), dim3(kStreamThreads), 0,
                        env.stream, tb, C, n_spans, start_dev);
     hipLaunchKernelGGL(span_reduce_kernel, dim3(static_cast<unsigned>(n_spans)), dim3(kStreamThreads), 0, env.stream, tb, C, L, total, start_dev,
-                       base_lo, base_hi, lo, hi, accumulate_into_out, out_dev);
+                       base_lo, base_hi, lo, hi, accumulate_into_out, out_dev, env.err_flag);
     return hipGetLastError();
 }
 
@@ -2055,14 +2070,14 @@ hipError_t launch_fill(const LaunchEnv &env, uint64_t n, uint64_t lo, uint64_t h
     return hipGetLastError();
 }
 
-hipError_t launch_scatter(const LaunchEnv &env, uint64_t k, const uint32_t *loc_dev, const uint64_t *vals_dev,
+hipError_t launch_scatter(const LaunchEnv &env, uint64_t total, uint64_t k, const uint32_t *loc_dev, const uint64_t *vals_dev,
                           uint64_t *out_dev, bool accumulate, uint64_t sub_lo, uint64_t sub_hi)
 {
     if (k == 0) return hipSuccess;
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
-    hipLaunchKernelGGL(scatter_kernel, dim3(stream_grid(env, k)), dim3(kStreamThreads), 0, env.stream, k, env.b > 64 ? 2 : 1,
-                       loc_dev, vals_dev, out_dev, accumulate, lo, hi, sub_lo, sub_hi);
+    hipLaunchKernelGGL(scatter_kernel, dim3(stream_grid(env, k)), dim3(kStreamThreads), 0, env.stream, total, k, env.b > 64 ? 2 : 1,
+                       loc_dev, vals_dev, out_dev, accumulate, lo, hi, sub_lo, sub_hi, env.err_flag);
     return hipGetLastError();
 }
 

@@ -93,8 +93,10 @@ class Graph:
     def __init__(self, engine, handle):
         self.engine, self._g = engine, handle
 
-    def launch(self):
-        self.engine._check(self.engine._lib.flashe_graph_launch(self.engine._h, self._g))
+    def launch(self, iter_shift=0):
+        """Replay.  iter_shift = r runs the captured calls as if each had been made with iter + r (round r after the
+        captured one); 0 repeats the captured round, mask streams included."""
+        self.engine._check(self.engine._lib.flashe_graph_launch_shifted(self.engine._h, self._g, int(iter_shift) & 0xFFFFFFFF))
 
     def __del__(self):
         try:

@@ -100,11 +100,19 @@ int flashe_stream_wait_event(flashe_ctx *ctx, void *event);
  * run; launch replays the whole sequence with one submission -- for launch-bound work such as a round over a
  * LeNet-sized model (six kernels of 10-60 us).  Pointers and scalar arguments are frozen into the graph: replay
  * with new DATA in the same buffers.  Host-pointer twins, syncs and event timing are not capturable, and
- * ctx-owned scratch must already have its size: run the sequence once normally before capturing it. */
+ * ctx-owned scratch must already have its size: run the sequence once normally before capturing it.
+ * What a frozen argument block means for the cipher:
+ *   - `iter` is frozen, so flashe_graph_launch REPEATS the captured round's mask streams: never feed it new plaintexts
+ *     (ct1 - ct2 would equal pt1 - pt2).  For the NEXT rounds use flashe_graph_launch_shifted: every PRF kernel adds a
+ *     device-resident iter shift to its frozen iter at run time, so replaying with iter_shift = r runs the captured
+ *     sequence exactly as if every call in it had been made with iter + r (what round r after the captured one needs,
+ *     prepare_encrypt's iter + 1 included).
+ *   - the expanded key is frozen too: after flashe_ctx_set_key a graph captured earlier refuses to launch (FLASHE_EINVAL). */
 typedef struct flashe_graph flashe_graph;
 int flashe_graph_begin(flashe_ctx *ctx);
 int flashe_graph_end(flashe_ctx *ctx, flashe_graph **graph);
 int flashe_graph_launch(flashe_ctx *ctx, flashe_graph *graph);
+int flashe_graph_launch_shifted(flashe_ctx *ctx, flashe_graph *graph, uint32_t iter_shift);    /* new */
 int flashe_graph_destroy(flashe_graph *graph);
 
 /* ---- PRF mask streams -------------------------------------------------------------- */
@@ -131,7 +139,10 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
 
 /* n_vec independent encrypts of equal length (e.g. the clients a simulation or a multi-tenant service hosts on one
  * GPU, or the layers of one model) in as few launches as possible: ct[v] = FlasheCipher.encrypt with cipher index
- * idx[v], exactly as n_vec calls of flashe_encrypt_dev.  pt / ct are HOST arrays of n_vec device pointers. */
+ * idx[v], exactly as n_vec calls of flashe_encrypt_dev.  pt / ct are HOST arrays of n_vec device pointers.
+ * int_bits > 64, double mask: runs of CONSECUTIVE cipher indices (idx[v + 1] == idx[v] + 1) share their PRF streams --
+ * client c's minus stream term(iter, c + 1) is client c + 1's add stream (jzf_flashe.py:349-353) -- so a run of C clients
+ * costs C + 1 AES blocks per element instead of 2 C; the ciphertexts are bit-identical to C separate calls. */
 int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
                              const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev);
 
@@ -167,7 +178,10 @@ int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_j
 /* FlasheCipher.decrypt -- jzf_flashe.py:584-594 -> _multiprocessing_decrypt (:537-582) /
  * _multiprocessing_decrypt_single (:506-535) with the prefix lists set_idx_list derived
  * (:356-386; single: :311-314 with n_add = 0):
- * out = in + sum_k term(iter, add_idx[k]) - sum_k term(iter, minus_idx[k])  mod 2^b. */
+ * out = in + sum_k term(iter, add_idx[k]) - sum_k term(iter, minus_idx[k])  mod 2^b.
+ * The lists may have ANY length, as in the reference (single mask: one minus prefix per uploaded client; scattered
+ * dropouts: one pair per run); beyond 96 entries per list the call chains launches that accumulate in place.
+ * in_dev == out_dev is allowed.  The same holds for flashe_mask* and the range twins. */
 int flashe_decrypt_dev(flashe_ctx *ctx, uint32_t iter,
                        const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
                        uint64_t n, uint32_t n_jobs, const uint64_t *in_dev, uint64_t *out_dev);
@@ -243,6 +257,10 @@ int flashe_unpack_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint6
 int flashe_unpack(flashe_ctx *ctx, uint64_t n, const uint64_t *in, uint64_t *out);
 
 /* ---- sparse path --------------------------------------------------------------------- */
+/* Location lists live in device memory in the *_dev variants, so they cannot be validated before launch: a location
+ * >= total (the reference raises IndexError there) -- or, in the "sorted" variants, an entry that is not strictly
+ * increasing -- is SKIPPED by the kernels, nothing is written outside the dense vector, and the next synchronising call
+ * on the ctx (flashe_sync, flashe_memcpy_d2h) returns FLASHE_EINVAL once.  The host-pointer twins validate up front. */
 /* Arbiter.expand_to_dense -- jzf_aggregator.py:150-165: out[loc[q]] = vals[q], every other
  * of the `total` positions = zero (L limbs, HOST pointer in both variants). */
 int flashe_expand_to_dense_dev(flashe_ctx *ctx, uint64_t total, uint64_t k, const uint32_t *loc_dev,

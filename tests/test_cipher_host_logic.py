@@ -152,3 +152,23 @@ def test_object_array_conversion_fast_and_fallback_paths():
             assert [int(v) for v in got[:, 1]] == [(v >> 64) & (2 ** 64 - 1) for v in wide]
             back = _from_limbs(got, "object")
             assert [int(v) for v in back] == [v & (2 ** 128 - 1) for v in wide]
+
+
+def test_object_array_conversion_handles_negative_and_numpy_scalars():
+    """_to_limbs must reduce values mod 2**(64 * limbs) exactly as Python's `&` does in the reference
+    ((value + add - minus) & mask, jzf_flashe.py:480-481): negative Python ints, negative NumPy scalars held in an
+    object array (astype(uint64) wraps those silently) and values at the int64 / uint64 edges."""
+    import numpy as np
+    from flashe_amd.cipher import _from_limbs, _to_limbs
+    M = (1 << 64) - 1
+    cases = [[1, 2, 3], [np.int64(-3), 5], [-3, 5], [2 ** 63, 1], [2 ** 64 - 1, 0], [2 ** 64, 1], [2 ** 100, -2 ** 90],
+             [np.int64(-1), 2 ** 63 + 5], [np.uint64(2 ** 64 - 1), 3], []]
+    for vals in cases:
+        for limbs in (1, 2):
+            got, kind = _to_limbs(np.array(vals, dtype=object), limbs)
+            assert kind == "object" and got.shape == (len(vals), limbs)
+            for i, v in enumerate(vals):
+                want = int(v) & ((1 << (64 * limbs)) - 1)
+                assert int(got[i, 0]) == want & M and (limbs == 1 or int(got[i, 1]) == want >> 64), (vals, limbs, i)
+            back = _from_limbs(got, kind)
+            assert [int(x) for x in back] == [int(v) & ((1 << (64 * limbs)) - 1) for v in vals]

@@ -429,14 +429,24 @@ def test_graph_capture_replays_a_round(E, oracle, b, n, C):
         pts = [rng.integers(0, 2 ** min(b - 8, 60), n, dtype=np.uint64) for _ in range(C)]
         for d, p in zip(dpt, pts):
             d.upload(p)
-        g.launch()
+        # round `rep` after the captured one: the replay runs with iter 7 + rep (kernel arguments are frozen into the graph, the
+        # iter shift is read from device memory), so no round reuses another round's mask streams
+        g.launch(iter_shift=rep)
         got = dout.download(np.uint64, n * Lb).reshape(n, Lb)
         want = np.zeros(n, dtype=np.uint64)
         for p in pts:
             want += p
         assert np.array_equal(got[:, 0], want & np.uint64((1 << min(b, 64)) - 1 if b < 64 else 2 ** 64 - 1)), rep
         ct3 = dct[3].download(np.uint64, n * Lb).reshape(n, Lb)
-        assert np.array_equal(ct3, oracle.encrypt(KEY, 7, 3, "double", 16, b, pts[3])), rep
+        assert np.array_equal(ct3, oracle.encrypt(KEY, 7 + rep, 3, "double", 16, b, pts[3])), rep
+    # the shift is reset after a replay: ordinary calls use the iter they are given
+    eng.encrypt_dev(7, 3, E.SCHEME_DOUBLE, n, 16, dpt[3], 1, dct[3])
+    assert np.array_equal(dct[3].download(np.uint64, n * Lb).reshape(n, Lb), oracle.encrypt(KEY, 7, 3, "double", 16, b, pts[3]))
+    # a graph carries the key schedule it was captured with: after a key change it refuses to replay
+    eng.set_key(bytes(range(1, 33)))
+    with pytest.raises(E.FlasheError):
+        g.launch()
+    eng.set_key(KEY)
     # scratch growth inside a capture is refused, the capture still ends cleanly
     big = make(E, 64)
     ops = [big.upload(rng.integers(0, 2 ** 64, 50_000, dtype=np.uint64)) for _ in range(3)]
@@ -884,10 +894,82 @@ def test_config4_size_round(E, oracle):
     assert np.array_equal(ct1, oracle.encrypt(KEY, it, 1, "double", 16, b, pts[1][:head]))
 
 
+@pytest.mark.parametrize("b,n,J", [(128, 20_003, 16), (100, 5000, 3), (64, 9999, 16), (23, 61_706, 16), (8, 3000, 5)])
+def test_prefix_lists_of_any_length(E, oracle, b, n, J):
+    """The reference sums over prefix lists of any length (jzf_flashe.py:126-150): single-mask decrypt passes one minus prefix per
+    uploaded client (:311-314; BASELINE config 3 has 100 clients), and a scattered dropout pattern leaves one (add, minus) pair per
+    run.  Lists longer than one launch's argument block are chained over launches that accumulate in place."""
+    eng = make(E, b)
+    rng = np.random.Generator(np.random.PCG64(b * 7 + n))
+    ct = rand_limbs(rng, n, b)
+    # single mask: 100 and 300 uploaded clients
+    for C in (100, 300):
+        up = list(range(C))
+        got = eng.decrypt(5, [], up, J, ct)
+        assert np.array_equal(got, oracle.decrypt(KEY, 5, [], up, J, b, ct)), (b, C, "single")
+    # double mask: every other client of 260 dropped -> 130 runs, 130 add and 130 minus prefixes
+    up = list(range(0, 260, 2))
+    add_idx, minus_idx = E.telescope(list(up))
+    assert len(add_idx) == 130 and len(minus_idx) == 130
+    got = eng.decrypt(5, add_idx, minus_idx, J, ct)
+    assert np.array_equal(got, oracle.decrypt(KEY, 5, add_idx, minus_idx, J, b, ct)), (b, "130 runs")
+    # unequal list lengths, in place on the device, on a ragged range; and a long mask sum
+    d = eng.upload(ct)
+    first, count = 33, n - 70
+    Lb = L(b)
+    a_list, m_list = list(range(7, 7 + 205)), list(range(1000, 1000 + 97))
+    eng.decrypt_range_dev(5, a_list, m_list, n, J, first, count, d.ptr + first * Lb * 8, d.ptr + first * Lb * 8)
+    got = d.download(np.uint64, n * Lb).reshape(n, Lb)
+    want = ct.copy()
+    want[first:first + count] = oracle.decrypt(KEY, 5, a_list, m_list, J, b, ct)[first:first + count]
+    assert np.array_equal(got, want), (b, "in place, ragged")
+    assert np.array_equal(eng.mask(5, a_list, n, J), oracle.mask_sum(KEY, 5, a_list, n, J, b)), (b, "mask sum")
+
+
+def test_sparse_locations_out_of_range_are_skipped_and_reported(E, oracle):
+    """Device-resident location lists cannot be checked before launch: a position >= total must neither be written (the
+    arbiter would corrupt HBM next to the dense vector) nor go unnoticed -- the next synchronising call fails once."""
+    for b in (128, 64):
+        eng = make(E, b)
+        Lb = L(b)
+        total, k = 5000, 40
+        rng = np.random.Generator(np.random.PCG64(b))
+        loc = np.sort(rng.choice(total, k, replace=False)).astype(np.uint32)
+        vals = rand_limbs(rng, k, b)
+        bad = loc.copy()
+        bad[-1] = total + 3                                    # one entry beyond the vector
+        guard = eng.alloc_vec(total + 64)                      # the dense vector plus a canary zone behind it
+        canary = np.full(((total + 64), Lb), np.uint64(0x5A5A5A5A5A5A5A5A), dtype=np.uint64)
+        zero = [7] + [0] * (Lb - 1)
+        for sorted_lists in (False, True):
+            guard.upload(canary)
+            d_loc, d_vals = eng.upload(bad), eng.upload(vals)
+            eng.sparse_aggregate_dev(total, [d_loc], [k], [d_vals], [zero], guard, sorted_lists=sorted_lists)
+            with pytest.raises(E.FlasheError):
+                eng.sync()
+            eng.sync()                                         # reported once
+            got = guard.download(np.uint64, (total + 64) * Lb).reshape(total + 64, Lb)
+            assert np.array_equal(got[total:], canary[total:]), (b, sorted_lists, "wrote past the dense vector")
+            want = oracle.expand_to_dense(total, loc[:-1], vals[:-1], np.array(zero, dtype=np.uint64), b)
+            assert np.array_equal(got[:total], want), (b, sorted_lists)
+        # expand_to_dense and the minus-mask scatter take the same guard
+        guard.upload(canary)
+        eng.expand_to_dense_dev(total, k, eng.upload(bad), eng.upload(vals), zero, guard)
+        with pytest.raises(E.FlasheError):
+            eng.sync()
+        assert np.array_equal(guard.download(np.uint64, (total + 64) * Lb).reshape(total + 64, Lb)[total:], canary[total:])
+        guard.upload(canary)
+        eng.sparse_minus_mask_dev(3, [eng.upload(bad)], [k], total, 16, guard)
+        with pytest.raises(E.FlasheError):
+            eng.sync()
+        assert np.array_equal(guard.download(np.uint64, (total + 64) * Lb).reshape(total + 64, Lb)[total:], canary[total:])
+        # a good list afterwards: no stale error
+        eng.sparse_minus_mask_dev(3, [eng.upload(loc)], [k], total, 16, guard)
+        eng.sync()
+
+
 def test_error_codes(E):
     eng = make(E, 128)
-    with pytest.raises(E.FlasheError):
-        eng.mask(0, list(range(200)), 10, 1)            # prefix list too long
     with pytest.raises(E.FlasheError):
         eng.mask(0, [1], 10, 0)                         # n_jobs = 0
     with pytest.raises(E.FlasheError):
