@@ -5,31 +5,41 @@ mask -- BASELINE.json config 2 -- with every buffer resident in HBM when the clo
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W        (or simply: python bench.py --gpus N)
 
-A "step" is one round.  With N > 1 every rank plays C clients (weak scaling: N*C ciphertext
-vectors per round), partial aggregates are reduce-scattered over RCCL (all-to-all + local
-mod-add), every rank decrypts its slice and an all-gather returns the plaintext aggregate to
-all ranks (flashe_amd/dist.py).  Rank 0 prints ONE JSON line.
+A "step" is one round.  With N > 1 (config 2) every rank plays C clients (weak scaling: N*C ciphertext
+vectors per round), partial aggregates are reduce-scattered over RCCL (grouped send/recv all-to-all +
+local mod-add), every rank decrypts its slice and an all-gather returns the plaintext aggregate to all
+ranks (flashe_amd/dist.py).  Rank 0 prints ONE JSON line.  Nothing here imports PyTorch: kernels,
+device memory and the collectives all go through the C ABI of libflashe_hip.so; under torchrun only
+its RANK / WORLD_SIZE / MASTER_PORT environment is used.
 
-The JSON carries `roofline` for the dominant kernel (the fused PRF+encrypt kernel, timed live
-with HIP events on the stream it runs on) and, at N = 1, `cpu_baseline`: the CPU oracle (a port
-of the reference algorithm, oracle/flashe_oracle.c) timed on this host's cores on a bounded
-sample of the same workload.  The oracle is only the baseline / checker here, never the thing
-measured.
+--config selects the other BASELINE configurations (same JSON shape): 3 = LeNet-sized model, 100 clients,
+mask precompute; 4 = ResNet-50-sized vector, 10 clients dealt (2,2,1,...,1) over the GPUs (strong scaling);
+5 = top-1% sparse uploads of that vector, 50 clients.
+
+The JSON carries `roofline` for the dominant kernel (timed live with HIP events on the stream it runs
+on) and, at N = 1, `cpu_baseline`: the CPU oracle (a port of the reference algorithm,
+oracle/flashe_oracle.c) timed on this host's cores on a bounded sample of the same workload.  The
+oracle is only the baseline / checker here, never the thing measured.
 """
 import argparse
 import json
 import os
-import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The oracle's OpenMP team (parity gates, CPU baseline) must SLEEP between its parallel regions: spinning workers burn the
+# container's CPU quota and the throttling hits the thread that submits GPU work (measured: 100 launches 0.3 ms -> 4.9 ms).
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+KEY = bytes(range(32))
+RESNET50 = 25_557_032
+LENET = 61_706
 
 
 def parse():
@@ -37,29 +47,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000)
-    ap.add_argument("--clients", type=int, default=10, help="clients per GPU")
+    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=2, help="BASELINE.json configuration (default 2 = the headline)")
+    ap.add_argument("--n", type=int, default=None, help="vector length (default: the configuration's)")
+    ap.add_argument("--clients", type=int, default=None, help="config 2: clients per GPU; configs 3-5: clients in all")
     ap.add_argument("--bits", type=int, default=128)
     ap.add_argument("--n-jobs", type=int, default=16)
     ap.add_argument("--prf-backend", choices=["auto", "table", "bitslice", "hybrid", "bitslice16"], default="auto")
     ap.add_argument("--pipeline-chunks", type=int, default=4,
-                    help="> 0: everything after the last client's encrypt (reduce, exchange, decrypt) runs chunk by chunk on "
-                         "a side stream under it; 0: sequential phases")
+                    help="> 0: chunks of the pipelined / fused schedules (reduce, exchange, decrypt of chunk q run on a side stream "
+                         "under the launch of chunk q + 1); 0: sequential phases only")
     ap.add_argument("--schedule", choices=["default", "auto", "fused", "pipelined", "sequential"], default="default",
-                    help="default: sequential (two launches) on one GPU (the three schedules are within ~1.5 %% of each other there; "
-                         "deterministic, so a profile of the run shows one launch shape per kernel), and 'auto' when ranks exchange; "
-                         "auto: whichever schedule is fastest in a short untimed calibration on this box / node; "
-                         "fused: per chunk one launch does every local encrypt plus the decrypt mask difference, the reduce "
-                         "(which then yields the plaintext aggregate) and the exchange hide under the next chunk's launch; "
-                         "pipelined: last client's encrypt chunked, reduce / exchange / decrypt on a side stream; "
-                         "sequential: all local encrypts in one launch, then reduce (+ exchange) fused with the decrypt")
+                    help="default: sequential (two launches) on one GPU, 'auto' when ranks exchange; auto: whichever schedule is "
+                         "fastest in a short untimed calibration on this box / node; fused: per chunk one launch does every local "
+                         "encrypt plus the decrypt mask difference, the reduce (which then yields the plaintext aggregate) and the "
+                         "exchange hide under the next chunk's launch; pipelined: last client's encrypt chunked, reduce / exchange / "
+                         "decrypt on a side stream; sequential: all local encrypts in one launch, then reduce (+ exchange) fused with "
+                         "the decrypt")
     ap.add_argument("--force-dist", action="store_true",
-                    help="with 1 GPU: still create the RCCL process group and run the N > 1 exchange path (world size 1)")
+                    help="with 1 GPU: still create the RCCL communicator and run the N > 1 exchange path (world size 1)")
     ap.add_argument("--settle-rounds", type=int, default=32,
-                    help="untimed rounds (~0.1 s) run after the in-run parity check, before the warmup steps (GPU clock ramp)")
+                    help="untimed rounds run after the in-run parity check, before the warmup steps (GPU clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
-                    help="elements of the workload the CPU baseline round runs on (default: all of it; ~0.2-2 s)")
+                    help="elements of the workload the CPU baseline round runs on (default: all of config 2; ~0.2-2 s)")
+    ap.add_argument("--no-python-baseline", action="store_true", help="skip the structure-faithful Python baseline (~10-20 s)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the one PCIe-inclusive round through the host-pointer API")
     return ap.parse_args()
 
 
@@ -82,308 +94,548 @@ def usable_cpus():
     return cpus
 
 
-def cpu_baseline(args, host_pts):
-    """Oracle (port of the reference arithmetic) on the host cores: one full round on a bounded sample of
-    the SAME plaintext vectors the GPU just processed."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (the only place bench.py touches oracle/): reported beside the GPU number, never the thing measured
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(n_jobs, b, C, host_pts, sample):
+    """Oracle (port of the reference arithmetic) on the host cores: full rounds on a bounded sample of the SAME plaintext
+    vectors the GPU just processed."""
     import numpy as np
     from oracle import flashe_oracle as orc
     orc.build()
-    key = bytes(range(32))
-    ns, C, b = min(args.cpu_sample, args.n), args.clients, args.bits
-    pts = [np.ascontiguousarray(p[:ns]) for p in host_pts]
+    ns = min(sample, len(host_pts[0]))
+    pts = [np.ascontiguousarray(p[:ns]) for p in host_pts[:C]]
     cores = min(orc.num_threads(), usable_cpus())
     orc.set_num_threads(cores)
-    orc.mask(key, 0, 0, 1000, 1, b)          # table init outside the clock
+    orc.mask(KEY, 0, 0, 1000, 1, b)          # table init outside the clock
     Lb = 2 if b > 64 else 1
     # result buffers are allocated and touched before the clock starts, like the GPU's resident buffers
     cts = [np.ones((ns, Lb), dtype=np.uint64) for _ in range(C)]
     agg, dec = np.ones((ns, Lb), dtype=np.uint64), np.ones((ns, Lb), dtype=np.uint64)
     rounds = []
-    for rep in range(5):                     # the best of five rounds: host noise (page placement, other tenants) is large
+    for rep in range(5):                     # host noise (page placement, other tenants) is large: best AND median reported
         t0 = time.perf_counter()
         for c in range(C):
-            orc.encrypt(key, 0, c, "double", args.n_jobs, b, pts[c], out=cts[c])
+            orc.encrypt(KEY, 0, c, "double", n_jobs, b, pts[c], out=cts[c])
         t1 = time.perf_counter()
         orc.aggregate_elem(cts, b, out=agg)
         t2 = time.perf_counter()
-        orc.decrypt(key, 0, [C], [0], args.n_jobs, b, agg, out=dec)
+        orc.decrypt(KEY, 0, [C], [0], n_jobs, b, agg, out=dec)
         t3 = time.perf_counter()
         rounds.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
     best = min(rounds)
+    med = sorted(r[0] for r in rounds)[len(rounds) // 2]
     want = np.zeros(ns, dtype=np.uint64)
     for p in pts:
         want += p
+    if b < 64:
+        want &= np.uint64((1 << b) - 1)
     assert np.array_equal(dec[:, 0], want), "cpu baseline round trip failed"
-    return {"value": C * ns / best[0], "unit": "ciphertexts/s", "cores": cores, "kind": "port",
-            "sample": f"best of 5 full rounds (C={C} encrypts + aggregate + decrypt, b={b}, double mask) on the first {ns} of "
-                      f"{args.n} elements of the workload; oracle/flashe_oracle.c, "
+    return {"value": C * ns / best[0], "value_median": C * ns / med, "unit": "ciphertexts/s", "cores": cores, "kind": "port",
+            "sample": f"best (value) and median (value_median) of 5 full rounds (C={C} encrypts + aggregate + decrypt, b={b}, double mask) "
+                      f"on the first {ns} elements of every client vector; oracle/flashe_oracle.c, "
                       f"{'AVX-512 VAES x16' if orc.vaes_available() else 'AES-NI x8' if orc.aesni_available() else 'table'} AES-256, "
                       f"OpenMP x{cores}",
             "phases_s": {"encrypt_xC": best[1], "aggregate": best[2], "decrypt": best[3]},
             "round_s_all": [r[0] for r in rounds]}
 
 
+def _py_chunk(args):
+    """One Pool task of the structure-faithful baseline: the mask stream of one chunk, one AES call per block, Python ints
+    (what _static_prepare_encrypt does, jzf_flashe.py:48-82; the AES call goes to the oracle's C block function via ctypes
+    where the reference calls pycryptodome)."""
+    from oracle import flashe_oracle as orc
+    begin, end, it, idx_add, idx_minus, b = args
+    m = 128 // b
+    mask = (1 << b) - 1
+    add, minus = [], []
+    for blk in range((end - begin - 1) // m + 1):
+        ctr = (begin + blk).to_bytes(8, "big")
+        sa = int.from_bytes(orc.aes256_encrypt_block(KEY, it.to_bytes(4, "big") + idx_add.to_bytes(4, "big") + ctr), "big")
+        sm = int.from_bytes(orc.aes256_encrypt_block(KEY, it.to_bytes(4, "big") + idx_minus.to_bytes(4, "big") + ctr), "big")
+        for t in range(min(m, end - begin - blk * m)):
+            add.append((sa >> (b * t)) & mask)
+            minus.append((sm >> (b * t)) & mask)
+    return add, minus
+
+
+def python_structure_baseline(b, C, host_pts, sample_n, budget_s=25.0):
+    """The reference's own structure on this host: numpy object arrays of Python ints, multiprocessing.Pool(cpu_count), one AES call
+    per block from Python, `(value + add - minus) & mask` as an object-array expression, reduce(lambda x, y: (x + y) % mod).
+    It runs ~1e5 elements/s, so it is measured on `sample_n` elements of each vector and reported per element."""
+    import functools
+    import multiprocessing as mp
+    import numpy as np
+    from oracle import flashe_oracle as orc
+    orc.build()
+    cores = usable_cpus()
+    ns = min(sample_n, len(host_pts[0]))
+    mod = 1 << b
+    d, r = divmod(ns, cores)
+    bounds = [(i * (d + 1) if i < r else r * (d + 1) + (i - r) * d) for i in range(cores + 1)]
+    t_start = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        def stream(idx_add, idx_minus):
+            parts = pool.map(_py_chunk, [(bounds[i], bounds[i + 1], 0, idx_add, idx_minus, b) for i in range(cores) if bounds[i + 1] > bounds[i]])
+            return (np.array([v for a, _ in parts for v in a], dtype=object), np.array([v for _, m in parts for v in m], dtype=object))
+        t0 = time.perf_counter()
+        cts, done = [], 0
+        for c in range(C):
+            add, minus = stream(c, c + 1)
+            cts.append((np.array([int(v) for v in host_pts[c][:ns]], dtype=object) + add - minus) & (mod - 1))
+            done += 1
+            if time.perf_counter() - t_start > budget_s * 0.6:
+                break
+        t1 = time.perf_counter()
+        agg = functools.reduce(lambda x, y: (x + y) % mod, cts)
+        t2 = time.perf_counter()
+        add, minus = stream(C, 0)
+        dec = (agg + add - minus) & (mod - 1)
+        t3 = time.perf_counter()
+    if done == C:
+        want = [sum(int(p[j]) for p in host_pts[:C]) % mod for j in range(min(ns, 50))]
+        assert [int(v) for v in dec[:50]] == want, "python baseline round trip failed"
+    enc_per_client = (t1 - t0) / done
+    round_s = enc_per_client * C + (t2 - t1) * (C / done) + (t3 - t2)
+    return {"value": C * ns / round_s, "unit": "ciphertexts/s", "cores": cores, "kind": "port",
+            "sample": f"structure-faithful Python restatement (object arrays, Pool({cores}), one AES call per block, reduce with % mod) on the "
+                      f"first {ns} elements of every client vector; {done} of {C} client encrypts measured"
+                      + ("" if done == C else ", the rest extrapolated per client") + "; per-element cost is size-independent, so the "
+                      "figure extrapolates linearly to the full vector",
+            "phases_s": {"encrypt_per_client": enc_per_client, "aggregate": t2 - t1, "decrypt": t3 - t2}, "measured_n": ns}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+def plaintext(global_client, count, b):
+    # SURVEY.md 8(d) config 2: Generator(PCG64(1000 + c)).integers(0, 2**64, n, uint64)
+    import numpy as np
+    hi = 2 ** 64 if b >= 64 else 2 ** max(b - 8, 1)
+    return np.random.Generator(np.random.PCG64(1000 + global_client)).integers(0, hi, count, dtype=np.uint64)
+
+
+def sum_mod(vectors, n, b):
+    """(lo, hi) limbs of the mod-2^b sum of uint64 vectors."""
+    import numpy as np
+    lo = np.zeros(n, dtype=np.uint64)
+    hi = np.zeros(n, dtype=np.uint64)
+    for p in vectors:
+        new = lo + p
+        hi += (new < lo).astype(np.uint64)
+        lo = new
+    if b < 64:
+        lo &= np.uint64((1 << b) - 1)
+    if b < 128:
+        hi &= np.uint64((1 << max(b - 64, 0)) - 1) if b > 64 else np.uint64(0)
+    return lo, hi
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
-        # launched bare: start the per-GPU processes as a child BEFORE anything touches the GPU
-        port = 29400 + os.getpid() % 500
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
+        # launched bare: start the per-GPU processes BEFORE anything touches the GPU (flashe_amd.dist.spawn, no torchrun needed)
+        from flashe_amd.dist import spawn
+        sys.exit(spawn(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import numpy as np
-    import torch
-    import torch.distributed as dist
-    from flashe_amd.dist import HipOps, ShardedRound
-    from flashe_amd.engine import SCHEME_DOUBLE, Engine
+    from flashe_amd.dist import HipOps, RcclComm, ShardedRound, deal_clients
+    from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1 or args.force_dist:
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(29300 + os.getpid() % 500))
-            dist.init_process_group("nccl", device_id=device, rank=0, world_size=1)
-        else:
-            dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
-    n, C, b, K, W = args.n, args.clients, args.bits, args.steps, args.warmup
+    b, K, W, J = args.bits, args.steps, args.warmup, args.n_jobs
     L = 2 if b > 64 else 1
-    key = bytes(range(32))
-    stream = torch.cuda.Stream(device=device)
+    cfg = args.config
+    n = args.n or {2: 10_000_000, 3: LENET, 4: RESNET50, 5: RESNET50}[cfg]
 
-    def plaintext(global_client, count=n):
-        # SURVEY.md 8(d) config 2: Generator(PCG64(1000 + c)).integers(0, 2**64, n, uint64)
-        hi = 2 ** 64 if b >= 64 else 2 ** max(b - 8, 1)
-        return np.random.Generator(np.random.PCG64(1000 + global_client)).integers(0, hi, count, dtype=np.uint64)
+    eng = Engine(KEY, b, device=local_rank)
+    eng.selftest()
+    backend = {"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend]
+    eng.set_prf_backend(backend)
+    two_streams = args.pipeline_chunks > 0 and args.schedule != "sequential" and cfg in (2, 4)
+    side = Engine(KEY, b, device=local_rank) if two_streams else None
+    comm = RcclComm.from_env(eng) if (world > 1 or args.force_dist) else None
+    ops = HipOps(eng, side, comm)
 
-    with torch.cuda.stream(stream):
-        eng = Engine(key, b, device=local_rank, stream=stream.cuda_stream)
-        eng.selftest()
-        eng.set_prf_backend({"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend])
-        side, side_stream = None, None
-        if args.pipeline_chunks > 0 and args.schedule != "sequential":
-            side_stream = torch.cuda.Stream(device=device)
-            side = Engine(key, b, device=local_rank, stream=side_stream.cuda_stream)
-        ops = HipOps(eng, side, side_stream)
-        rnd = ShardedRound(ops, n, b, C, args.n_jobs, device, rank=rank, world=world, force_collectives=args.force_dist)
-        host_pts = [plaintext(rank * C + c) for c in range(C)]
-        pts = [torch.from_numpy(p.view(np.int64)).to(device) for p in host_pts]
+    out = {"metric": "ciphertexts/sec (enc+agg+dec), 1e7-elem vector; achieved HBM GB/s fraction", "unit": "ciphertexts/s",
+           "n_gpus": world, "steps": K, "warmup": W, "higher_is_better": True, "vs_baseline": None,
+           "dtype": "u128" if L == 2 else "u64", "data": "synthetic"}
 
-        # HIP events on the engine's stream: per dominant launch + per phase
-        Q = max(args.pipeline_chunks, 1)
-        enc_ev = [(eng.event(), eng.event()) for _ in range(K * max(C, Q))]
-        ph_ev = [[eng.event() for _ in range(3)] for _ in range(K)]
-
-        def run_schedule(schedule, it, k=None):
-            """One round.  k = index of the timed step (events recorded) or None (warmup / parity run)."""
-            if schedule == "fused":
-                # one bracketed launch per round (chunk k mod Q): event records are not free on a stream
-                evs = [enc_ev[k] if (k is not None and q == k % Q) else None for q in range(Q)]
-                return rnd.run_fused(it, pts, 1, chunks=Q, launch_events=evs)
-            elif schedule == "pipelined":
-                return rnd.run_pipelined(it, pts, 1, chunks=Q, batch_events=enc_ev[k] if (k is not None and C > 1) else None)
-            else:
-                if k is None:
-                    return rnd.run(it, pts, 1)
-                # same sequence as ShardedRound.run, with event brackets around the launches
-                eng.record(ph_ev[k][0])
-                rnd.encrypt_phase(it, pts, 1)              # one launch: every local client's encrypt
-                eng.record(ph_ev[k][1])
-                res = rnd.reduce_decrypt_phase(it)         # reduce (+ exchange) fused with the decrypt of its result
-                eng.record(ph_ev[k][2])
-                return res
-
-        lo = np.zeros(n, dtype=np.uint64)
-        hi = np.zeros(n, dtype=np.uint64)
-        for g in range(world * C):
-            p = host_pts[g - rank * C] if rank * C <= g < (rank + 1) * C else plaintext(g)
-            new = lo + p
-            hi += (new < lo).astype(np.uint64)
-            lo = new
-        if b < 64:
-            lo &= np.uint64((1 << b) - 1)
-
-        def parity_ok(res):
-            torch.cuda.synchronize()
-            got = res[: n * L].cpu().numpy().view(np.uint64).reshape(n, L)
-            good = np.array_equal(got[:, 0], lo) and (
-                L == 1 or np.array_equal(got[:, 1], hi if b == 128 else hi & np.uint64((1 << (b - 64)) - 1)))
-            flag = torch.tensor([1 if good else 0], device=device)
-            if world > 1:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank must agree on the schedule used
-            return bool(flag.item())
-
-        # parity gate before any timing counts: decrypted aggregate == plaintext sum (mod 2^b).  A schedule is
-        # used only if it passes; otherwise fall back to the next simpler one.
-        order = ["fused", "pipelined", "sequential"]
-        start = args.schedule
-        # several ranks: which schedule hides the exchange best depends on how RCCL behaves on the node, so the default
-        # there is to time all of them briefly (untimed region) and keep the fastest; one GPU: the two-launch round
-        calibrate = start == "auto" or (start == "default" and rnd.exchange)
-        if calibrate:
-            start = "fused"
-        elif start == "default":
-            start = "sequential"
-        if start == "fused" and b <= 64:
-            start = "pipelined"              # the one-launch job list needs b > 64
-        candidates = order[order.index(start):] if side is not None else ["sequential"]
-
-        def passes(cand):
-            try:
-                return parity_ok(run_schedule(cand, 0))
-            except Exception as exc:          # never lose the measurement to an optional schedule
-                print(f"rank {rank}: schedule {cand} raised {exc!r}", file=sys.stderr)
-                if world > 1:
-                    raise
-                return False
-
-        def quick_ms(cand, rounds=8):
-            """Untimed-region calibration: ms per round of a schedule, MAX over ranks."""
-            for it in range(2):
-                run_schedule(cand, it)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            c0 = time.perf_counter()
-            for it in range(rounds):
-                run_schedule(cand, it)
-            torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - c0], dtype=torch.float64, device=device)
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t.item()) * 1e3 / rounds
-
-        schedule, calibration = None, None
-        if calibrate and len(candidates) > 1:
-            # the schedules are within a few percent of each other and which one wins depends on the box and on the
-            # exchange: keep whichever is fastest here, among those that pass the gate
-            usable = [c for c in candidates if passes(c)]
-            if len(usable) > 1:
-                calibration = {c: quick_ms(c) for c in usable}
-                schedule = min(calibration, key=calibration.get)
-            elif usable:
-                schedule = usable[0]
-            candidates = []
-        for cand in ([] if schedule else candidates):
-            if passes(cand):
-                schedule = cand
-                break
-            if rank == 0:
-                print(f"warning: schedule {cand} unusable; falling back", file=sys.stderr)
-        if schedule is None:
-            raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum")
-        pipelined = schedule != "sequential"
-        # The parity check above leaves the GPU idle while the host compares 1e7 elements, and its clocks drop: run rounds
-        # for ~0.1 s (32 of them) so that the timed region does not start on a cold device even when --warmup is small, then the W
-        # warmup steps proper, right before the timed region.
-        for it in range(args.settle_rounds):          # a fixed count: every rank must issue the same collectives
-            run_schedule(schedule, it)
-            if it % 8 == 7:
-                torch.cuda.synchronize()
-        for w in range(W):
-            run_schedule(schedule, w)
-
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(K):
-            run_schedule(schedule, k, k)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-
-        elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=device)
-        if world > 1:
-            dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        elapsed = float(elapsed.item())
-
-        if schedule == "fused":
-            enc_ev = enc_ev[:K]              # one bracketed chunk launch per round, recorded inside the timed region
-        elif schedule == "pipelined":
-            # the dominant launch of this schedule is the batched encrypt of the first C - 1 clients: one event
-            # pair per round around it
-            enc_ev = enc_ev[:K] if C > 1 else []
-        else:
-            enc_ev = [(p[0], p[1]) for p in ph_ev]      # the batched encrypt launch of every timed round
-        enc_ms = [eng.elapsed_ms(e0, e1) for e0, e1 in enc_ev]
-        ph = np.array([[eng.elapsed_ms(p[i], p[i + 1]) for i in range(2)] for p in ph_ev]) if schedule == "sequential" else None
-
+    if cfg in (2, 4):
+        result = bench_dense(args, cfg, n, ops, rank, world, out)
+    elif cfg == 3:
+        result = bench_precompute(args, n, ops, rank, world, out)
+    else:
+        result = bench_sparse(args, n, ops, rank, world, out)
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / K
-        value = world * C * n / (elapsed / K)
-        pt_bytes = 8
-        enc_avg_ms = float(np.mean(enc_ms))
+        print(json.dumps(result), flush=True)
+    if comm is not None:
+        ops.barrier()
+        comm.close()
+
+
+def timed_region(ops, K, step):
+    """EXACTLY K steps between barrier + device sync on both sides; returns the MAX over ranks of the elapsed seconds."""
+    ops.barrier()
+    ops.sync()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(k)
+    ops.sync()
+    ops.barrier()
+    return ops.allreduce(time.perf_counter() - t0, 0)
+
+
+def traffic_ratio(kernel_key):
+    """Measured HBM bytes per algorithmic byte of a kernel, from the committed rocprofv3 PMC passes (profiles/traffic.json)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return tj.get("kernels", {}).get(kernel_key, {}).get("hbm_bytes_per_algorithmic_byte"), tj.get("source")
+    except Exception:
+        return None, None
+
+
+# ---- configs 2 and 4: dense double-mask round, clients sharded over ranks ------------------------------------------------
+def bench_dense(args, cfg, n, ops, rank, world, out):
+    import numpy as np
+    from flashe_amd.dist import ShardedRound, deal_clients
+    from flashe_amd.engine import SCHEME_DOUBLE
+    eng = ops.engine
+    b, K, W, J = args.bits, args.steps, args.warmup, args.n_jobs
+    L = 2 if b > 64 else 1
+    if cfg == 2:
+        cpr = args.clients or 10                          # weak scaling: every GPU plays `cpr` clients
+        total = world * cpr
+        mine = list(range(rank * cpr, (rank + 1) * cpr))
+        scaling = "weak"
+    else:
+        total = args.clients or 10                        # strong scaling: the 10 clients are dealt over the GPUs
+        mine = deal_clients(total, world)[rank]
+        scaling = "strong"
+    C = len(mine)
+    rnd = ShardedRound(ops, n, b, mine, J, rank=rank, world=world, total_clients=total, force_collectives=args.force_dist)
+    host_pts = {c: plaintext(c, n, b) for c in mine}
+    pts = [(ops.upload(host_pts[c]), 0) for c in mine]
+    Q = max(args.pipeline_chunks, 1)
+    enc_ev = [(eng.event(), eng.event()) for _ in range(K)]
+    ph_ev = [[eng.event() for _ in range(3)] for _ in range(K)]
+
+    def run_schedule(schedule, it, k=None):
+        """One round.  k = index of the timed step (events recorded) or None (warmup / parity run)."""
         if schedule == "fused":
-            # per launch: C encrypt jobs (u64 plaintext in, L-limb ciphertext out) + the mask-difference job (L limbs out)
-            # over one chunk of the vector; two AES blocks per element and job
-            elems = n / Q
-            alg_bytes = elems * (C * (pt_bytes + 8 * L) + 8 * L)
-            blocks = 2 * (C + 1) * elems
-            kernel_name = (f"prf_wide_batch_kernel<true,1024,1> (fused AES-256 PRF x2 + 128-bit add/sub: {C} client encrypts + "
-                           f"decrypt mask difference on 1/{Q} of the vector per launch)")
-        else:
-            vec_per_launch = (C - 1) if (schedule == "pipelined" and C > 1) else C
-            alg_bytes = vec_per_launch * n * (pt_bytes + 8 * L)   # u64 plaintext in + L-limb ciphertext out, per vector
-            blocks = 2 * n * vec_per_launch
-            kernel_name = ("prf_wide_batch_kernel<true,1024,1> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt, "
-                           f"{vec_per_launch} client vectors per launch)") if vec_per_launch > 1 else \
-                "prf_wide_batch_kernel<true,1024,0> (fused AES-256 PRF x2 + 128-bit add/sub = encrypt, one client vector per launch)"
-        achieved = alg_bytes / (enc_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                # measured HBM bytes per algorithmic byte of this kernel (rocprofv3 PMC passes of the default bench)
-                traffic = tj["hbm_bytes_per_algorithmic_byte"] * alg_bytes
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "ciphertexts/sec (enc+agg+dec), 1e7-elem vector; achieved HBM GB/s fraction",
-            "value": value, "unit": "ciphertexts/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u128" if L == 2 else "u64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 2: n={n}-element vector, 64-bit plaintext / {b}-bit modulus, "
-                                   f"{C} clients per GPU, double mask, n_jobs={args.n_jobs}; round = {C} encrypts + "
-                                   f"{C}-way aggregate + 1 decrypt" + (f"; {world} GPUs: all-to-all reduce-scatter + "
-                                   "sliced decrypt + all-gather" if world > 1 else ""),
-                       "n": n, "int_bits": b, "clients_per_gpu": C, "mask": "double", "prf_backend": args.prf_backend,
-                       "schedule": {"fused": f"{Q} chunks; per chunk one launch = all local encrypts + decrypt mask difference; reduce "
-                                             "(-> plaintext aggregate) and exchange hidden on a side stream",
-                                    "pipelined": f"reduce / exchange / decrypt chunk-pipelined on a side stream ({Q} chunks)",
-                                    "sequential": "two launches: all local encrypts, then reduce fused with decrypt"}[schedule],
-                       "schedule_calibration_ms": calibration,
-                       "parity": "bit-exact (checked in-run)"},
-            "roofline": {"kernel": kernel_name,
-                         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": enc_avg_ms,
-                         "launches_timed": len(enc_ms),
-                         "aes_blocks_per_s": blocks / (enc_avg_ms * 1e-3),
-                         # LDS lookups per AES block: 12 full rounds x 16 + 4 (round 2) + 0.5 (round 1) on the 4096-element
-                         # tiles; the < 6 % of elements in the 1024-element remainder tiles take 210
-                         "lds_lookup_bound": {"lookups_per_block": 196.5, "peak_lookups_per_s_at_2.4GHz": 32 * 256 * 2.4e9,
-                                              "achieved_lookups_per_s": 196.5 * blocks / (enc_avg_ms * 1e-3),
-                                              "frac_at_2.4GHz": 196.5 * blocks / (enc_avg_ms * 1e-3) / (32 * 256 * 2.4e9)},
-                         "note": "integer path: the kernel is AES(LDS/VALU)-rate bound, HBM fraction reported as required"},
-            "phases_ms": ({"round": ms_per_step, "note": "phases overlap in this schedule"}
-                          if pipelined else
-                          {"encrypt_xC": float(ph[:, 0].mean()), "reduce_plus_decrypt": float(ph[:, 1].mean())}),
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, host_pts)
-        print(json.dumps(out), flush=True)
-    if world > 1 or args.force_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+            # one bracketed launch per round (chunk k mod Q): event records are not free on a stream
+            evs = [enc_ev[k] if (k is not None and q == k % Q) else None for q in range(Q)]
+            return rnd.run_fused(it, pts, 1, chunks=Q, launch_events=evs)
+        if schedule == "pipelined":
+            return rnd.run_pipelined(it, pts, 1, chunks=Q, batch_events=enc_ev[k] if (k is not None and C > 1) else None)
+        if k is None:
+            return rnd.run(it, pts, 1)
+        eng.record(ph_ev[k][0])
+        rnd.encrypt_phase(it, pts, 1)              # one launch: every local client's encrypt (one chain of C + 1 streams)
+        eng.record(ph_ev[k][1])
+        res = rnd.reduce_decrypt_phase(it)         # reduce (+ exchange) fused with the decrypt of its result
+        eng.record(ph_ev[k][2])
+        return res
+
+    lo, hi = sum_mod([host_pts[c] if c in host_pts else plaintext(c, n, b) for c in range(total)], n, b)
+
+    def parity_ok(res):
+        got = ops.read((res, 0), n * L).reshape(n, L)
+        good = np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi))
+        return ops.allreduce(1.0 if good else 0.0, 1) > 0.5          # every rank must agree on the schedule used
+
+    # parity gate before any timing counts: decrypted aggregate == plaintext sum (mod 2^b).  A schedule is
+    # used only if it passes; otherwise fall back to the next simpler one.
+    order = ["fused", "pipelined", "sequential"]
+    start = args.schedule
+    calibrate = start == "auto" or (start == "default" and rnd.exchange)
+    if calibrate:
+        start = "fused"
+    elif start == "default":
+        start = "sequential"
+    if start == "fused" and b <= 64:
+        start = "pipelined"              # the one-launch job list needs b > 64
+    candidates = order[order.index(start):] if ops.side is not None else ["sequential"]
+
+    def passes(cand):
+        try:
+            return parity_ok(run_schedule(cand, 0))
+        except Exception as exc:          # never lose the measurement to an optional schedule
+            print(f"rank {rank}: schedule {cand} raised {exc!r}", file=sys.stderr)
+            if world > 1:
+                raise
+            return False
+
+    def quick_ms(cand, rounds=8):
+        """Untimed-region calibration: ms per round of a schedule, MAX over ranks."""
+        for it in range(2):
+            run_schedule(cand, it)
+        return timed_region(ops, rounds, lambda k: run_schedule(cand, k)) * 1e3 / rounds
+
+    schedule, calibration = None, None
+    if calibrate and len(candidates) > 1:
+        usable = [c for c in candidates if passes(c)]
+        if len(usable) > 1:
+            calibration = {c: quick_ms(c) for c in usable}
+            schedule = min(calibration, key=calibration.get)
+        elif usable:
+            schedule = usable[0]
+        candidates = []
+    for cand in ([] if schedule else candidates):
+        if passes(cand):
+            schedule = cand
+            break
+        if rank == 0:
+            print(f"warning: schedule {cand} unusable; falling back", file=sys.stderr)
+    if schedule is None:
+        raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum")
+    # The parity check above leaves the GPU idle while the host compares 1e7 elements, and its clocks drop: run rounds
+    # for ~0.1 s so that the timed region does not start on a cold device even when --warmup is small, then the W
+    # warmup steps proper, right before the timed region.
+    for it in range(args.settle_rounds):          # a fixed count: every rank must issue the same collectives
+        run_schedule(schedule, it)
+        if it % 8 == 7:
+            ops.sync()
+    for w in range(W):
+        run_schedule(schedule, w)
+    elapsed = timed_region(ops, K, lambda k: run_schedule(schedule, k, k))
+
+    if schedule == "sequential":
+        enc_pairs = [(p[0], p[1]) for p in ph_ev]      # the batched encrypt launch of every timed round
+    else:
+        enc_pairs = enc_ev if (schedule == "fused" or C > 1) else []
+    enc_ms = [eng.elapsed_ms(e0, e1) for e0, e1 in enc_pairs]
+    ph = np.array([[eng.elapsed_ms(p[i], p[i + 1]) for i in range(2)] for p in ph_ev]) if schedule == "sequential" else None
+    if rank != 0:
+        return None
+
+    ms_per_step = elapsed * 1e3 / K
+    pt_bytes = 8
+    enc_avg_ms = float(np.mean(enc_ms)) if enc_ms else float("nan")
+    chained = os.environ.get("FLASHE_CHAIN", "1") != "0" and L == 2
+    if schedule == "fused":
+        # per launch: C encrypt links (u64 plaintext in, L-limb ciphertext out) + the mask-difference job (L limbs out) over one
+        # chunk of the vector; a chain of C clients is C + 1 AES streams, the mask difference two more
+        elems = n / Q
+        alg_bytes = elems * (C * (pt_bytes + 8 * L)) + (elems / world) * 8 * L
+        blocks = (C + 1 if chained else 2 * C) * elems + 2 * elems / world
+        kernel_key = "prf_chain_kernel"
+        kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub: {C} client encrypts sharing {C + 1} streams + "
+                       f"decrypt mask difference, 1/{Q} of the vector per launch)")
+    else:
+        vec = (C - 1) if (schedule == "pipelined" and C > 1) else C
+        alg_bytes = vec * n * (pt_bytes + 8 * L)          # u64 plaintext in + L-limb ciphertext out, per client vector
+        blocks = (vec + 1 if chained else 2 * vec) * n / (1 if L == 2 else 128 // b)
+        kernel_key = "prf_chain_kernel" if L == 2 else "prf_small_jobs_kernel"
+        kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub = encrypt: {vec} consecutive clients per launch share "
+                       f"{vec + 1} PRF streams, ct_c = pt_c + S_c - S_(c+1))") if L == 2 else \
+            f"prf_small_jobs_kernel<true> (b <= 64: one AES block = {128 // b} elements per lane; {vec} client vectors per launch)"
+    achieved = alg_bytes / (enc_avg_ms * 1e-3) / 1e9
+    ratio, tsrc = traffic_ratio(kernel_key)
+    lookups = 196.1 if chained else 196.5
+    out.update({
+        "value": total * n / (elapsed / K), "ms_per_step": ms_per_step, "scaling": scaling,
+        "config": {"workload": f"BASELINE config {cfg}: n={n}-element vector, 64-bit plaintext / {b}-bit modulus, "
+                               + (f"{C} clients per GPU" if cfg == 2 else f"{total} clients dealt {[len(x) for x in deal_clients(total, world)]} over the GPUs")
+                               + f", double mask, n_jobs={J}; round = {total} encrypts + {total}-way aggregate + 1 decrypt"
+                               + (f"; {world} GPUs: all-to-all reduce-scatter (grouped ncclSend/ncclRecv) + sliced decrypt + all-gather" if world > 1 else ""),
+                   "n": n, "int_bits": b, "clients_total": total, "clients_this_gpu": C, "mask": "double", "prf_backend": args.prf_backend,
+                   "schedule": {"fused": f"{Q} chunks; per chunk one launch = all local encrypts + decrypt mask difference; reduce "
+                                         "(-> plaintext aggregate) and exchange hidden on a side stream",
+                                "pipelined": f"reduce / exchange / decrypt chunk-pipelined on a side stream ({Q} chunks)",
+                                "sequential": "two launches: all local encrypts, then reduce fused with decrypt"}[schedule],
+                   "schedule_calibration_ms": calibration, "collectives": "RCCL through libflashe_hip.so (no PyTorch)" if ops.comm else None,
+                   "parity": "bit-exact (decrypted aggregate == plaintext sum on every rank, checked in-run)"},
+        "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": ratio * alg_bytes if ratio else None,
+                     "traffic_source": (f"{tsrc}: HBM bytes per algorithmic byte measured once with rocprofv3 PMC passes on this kernel "
+                                        "(FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) x this run's algorithmic bytes; not re-measured in-run")
+                     if ratio else None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": enc_avg_ms, "launches_timed": len(enc_ms),
+                     "aes_blocks_per_launch": blocks, "aes_blocks_per_s": blocks / (enc_avg_ms * 1e-3),
+                     # LDS lookups per AES block: 11 full rounds x 16 + the final round's 16 + 4 (round 2) + the element's one
+                     # counter-dependent lookup of round 1 shared by its C + 1 blocks; half-tile tails take 208
+                     "lds_lookup_bound": {"lookups_per_block": lookups, "peak_lookups_per_s_at_2.4GHz": 32 * 256 * 2.4e9,
+                                          "achieved_lookups_per_s": lookups * blocks / (enc_avg_ms * 1e-3),
+                                          "frac_at_2.4GHz": lookups * blocks / (enc_avg_ms * 1e-3) / (32 * 256 * 2.4e9)},
+                     "note": "integer path: the kernel is AES(LDS lookup)-rate bound, HBM fraction reported as required"},
+        "phases_ms": ({"round": ms_per_step, "note": "phases overlap in this schedule"} if schedule != "sequential" else
+                      {"encrypt_xC": float(ph[:, 0].mean()), "reduce_plus_decrypt": float(ph[:, 1].mean())}),
+    })
+    if world == 1:
+        hp = [host_pts[c] for c in mine]
+        if not args.no_e2e:
+            out["e2e_ms_incl_pcie"] = e2e_round_ms(eng, hp, n, b, J)
+            out["e2e_note"] = ("one round through the host-pointer twins (flashe_encrypt x C, flashe_aggregate_elem, flashe_decrypt): pageable "
+                               "host buffers, H2D + kernels + D2H per call; never `value`")
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(J, b, C, hp, args.cpu_sample)
+            if not args.no_python_baseline:
+                out["cpu_baseline_python"] = python_structure_baseline(b, C, hp, 20_000)
+    return out
+
+
+def e2e_round_ms(eng, host_pts, n, b, J):
+    """The same round with every operand starting and ending in HOST memory (what a caller that keeps its vectors on the
+    host pays): PCIe Gen5 transfers included."""
+    import numpy as np
+    from flashe_amd.engine import SCHEME_DOUBLE
+    C = len(host_pts)
+    t0 = time.perf_counter()
+    cts = [eng.encrypt(0, c, SCHEME_DOUBLE, J, host_pts[c]) for c in range(C)]
+    agg = eng.aggregate_elem(cts)
+    dec = eng.decrypt(0, [C], [0], J, agg)
+    ms = (time.perf_counter() - t0) * 1e3
+    lo, _ = sum_mod(host_pts, n, b)
+    assert np.array_equal(dec[:, 0], lo), "host-pointer round trip failed"
+    return ms
+
+
+# ---- config 3: LeNet-sized model, 100 clients, double mask + mask precompute ---------------------------------------------
+def bench_precompute(args, n, ops, rank, world, out):
+    """Per round: every client's prepare_encrypt (the fused mask difference term(c) - term(c + 1), one chained launch for all
+    clients), prepare_decrypt (term(C) - term(0)); then the ONLINE part with no AES at all: 100 x combine (ct = pt + mask),
+    100-way reduce, combine (decrypt).  Both parts are inside the timed step; `phases_ms` splits them."""
+    import numpy as np
+    from oracle import flashe_oracle as orc          # parity gate only (rank 0, before the timed region)
+    eng = ops.engine
+    b, K, W, J = args.bits, args.steps, args.warmup, args.n_jobs
+    L = 2 if b > 64 else 1
+    C = args.clients or 100
+    host_pts = [plaintext(c, n, b) for c in range(C)]
+    pts = [ops.upload(p) for p in host_pts]
+    masks = [eng.alloc_vec(n) for _ in range(C)]
+    cts = [eng.alloc_vec(n) for _ in range(C)]
+    dmask, agg, dec = eng.alloc_vec(n), eng.alloc_vec(n), eng.alloc_vec(n)
+    ev = [[eng.event() for _ in range(4)] for _ in range(K)]
+
+    def step(it, k=None):
+        if k is not None:
+            eng.record(ev[k][0])
+        # precompute: masks of every client (the chain shares the streams: C + 1 instead of 2 C) + the decrypt mask difference
+        eng.prf_jobs_dev(it, n, J, [(c, c + 1, 0, n, None, 0, masks[c]) for c in range(C)] + [(C, 0, 0, n, None, 0, dmask)])
+        if k is not None:
+            eng.record(ev[k][1])
+        eng.combine_batch_dev(n, pts, 1, masks, None, cts)                 # online encrypts: ct = pt + (add - minus), one launch
+        if k is not None:
+            eng.record(ev[k][2])
+        eng.aggregate_elem_dev(cts, n, agg)
+        eng.combine_dev(n, agg, L, dmask, None, dec)                      # online decrypt
+        if k is not None:
+            eng.record(ev[k][3])
+
+    step(0)
+    got = dec.download(np.uint64, n * L).reshape(n, L)
+    lo, hi = sum_mod(host_pts, n, b)
+    assert np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi)), "PARITY FAILURE (round trip)"
+    orc.build()
+    for c in (0, C // 2, C - 1):                       # ciphertexts against the oracle's own encrypt
+        assert np.array_equal(cts[c].download(np.uint64, n * L).reshape(n, L), orc.encrypt(KEY, 0, c, "double", J, b, host_pts[c])), f"PARITY FAILURE client {c}"
+    for it in range(max(W, 3)):
+        step(it)
+    elapsed = timed_region(ops, K, lambda k: step(k, k))
+    if rank != 0:
+        return None
+    ph = np.array([[eng.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in ev])
+    pre_ms = float(ph[:, 0].mean())
+    m = 1 if L == 2 else 128 // b
+    blocks = (C + 1 + 2) * ((n + m - 1) // m) if L == 2 else 2 * (C + 1) * ((n + m - 1) // m)
+    alg_bytes = (C + 1) * n * 8 * L
+    achieved = alg_bytes / (pre_ms * 1e-3) / 1e9
+    out.update({
+        "value": world * C * n / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
+        "config": {"workload": f"BASELINE config 3: LeNet-sized gradient (n={n}), {C} clients, double mask + mask precompute, {b}-bit modulus, "
+                               f"n_jobs={J}; step = prepare_encrypt x {C} + prepare_decrypt (one launch) + online {C} encrypts + {C}-way "
+                               "aggregate + decrypt (no AES online)" + ("; independent replicas per GPU" if world > 1 else ""),
+                   "n": n, "int_bits": b, "clients_total": C, "mask": "double+precompute",
+                   "parity": "bit-exact (round trip + three clients' ciphertexts vs the oracle, checked in-run)"},
+        "roofline": {"kernel": "prf_chain_kernel<1024> (mask precompute: chain of %d clients + decrypt mask difference, in = NULL)" % C if L == 2
+                     else "prf_small_jobs_kernel<true> (mask precompute)",
+                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pre_ms, "launches_timed": K,
+                     "aes_blocks_per_launch": blocks, "aes_blocks_per_s": blocks / (pre_ms * 1e-3),
+                     "note": "launch- and latency-bound at this size (61,706 elements per vector)"},
+        "phases_ms": {"precompute_all_masks": pre_ms, "online_encrypt_xC": float(ph[:, 1].mean()),
+                      "online_aggregate_plus_decrypt": float(ph[:, 2].mean())},
+    })
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(J, b, C, host_pts, n)
+    return out
+
+
+# ---- config 5: top-1 % sparse uploads, 50 clients, single mask (the sparse path the reference can run) --------------------
+def bench_sparse(args, total, ops, rank, world, out):
+    """Per round (SURVEY.md 8 a-13, a-15, a-10): every client encrypts its compact k-vector (single mask, compact positions);
+    the arbiter adds the 50 expanded uploads (fused: sum of zero values everywhere + (value - zero) at the locations); the
+    clients' dense minus-mask is rebuilt from the location lists and subtracted."""
+    import numpy as np
+    from oracle import flashe_oracle as orc          # parity gate only
+    from flashe_amd.engine import SCHEME_SINGLE
+    eng = ops.engine
+    b, K, W, J = args.bits, args.steps, args.warmup, args.n_jobs
+    L = 2 if b > 64 else 1
+    C = args.clients or 50
+    k = total // 100
+    rng = [np.random.Generator(np.random.PCG64(2000 + c)) for c in range(C)]
+    locs = [np.sort(r.choice(total, k, replace=False)).astype(np.uint32) for r in rng]
+    vals = [r.integers(0, 2 ** 64 if b >= 64 else 2 ** (b - 8), k, dtype=np.uint64) for r in rng]
+    zero = 1 << 31                                   # the un-encrypted quantised zero that closes every upload
+    d_loc = [ops.upload(l) for l in locs]
+    d_val = [ops.upload(v) for v in vals]
+    d_ct = [eng.alloc_vec(k) for _ in range(C)]
+    d_agg, d_mask, d_dec = eng.alloc_vec(total), eng.alloc_vec(total), eng.alloc_vec(total)
+    ev = [[eng.event() for _ in range(4)] for _ in range(K)]
+
+    def step(it, kk=None):
+        if kk is not None:
+            eng.record(ev[kk][0])
+        eng.encrypt_batch_dev(it, list(range(C)), SCHEME_SINGLE, k, J, d_val, 1, d_ct)
+        if kk is not None:
+            eng.record(ev[kk][1])
+        eng.sparse_aggregate_dev(total, d_loc, [k] * C, d_ct, [zero] * C, d_agg, sorted_lists=True)
+        if kk is not None:
+            eng.record(ev[kk][2])
+        eng.sparse_minus_mask_dev(it, d_loc, [k] * C, total, J, d_mask, sorted_lists=True)
+        eng.combine_dev(total, d_agg, L, None, d_mask, d_dec)
+        if kk is not None:
+            eng.record(ev[kk][3])
+
+    step(0)
+    # parity: the decrypted dense vector == sum over clients of (value at its locations, zero elsewhere)
+    got = d_dec.download(np.uint64, total * L).reshape(total, L)
+    want = np.full(total, np.uint64((C * zero) & (2 ** 64 - 1)), dtype=np.uint64)
+    for c in range(C):
+        want[locs[c]] += vals[c] - np.uint64(zero)
+    assert np.array_equal(got[:, 0], want if b >= 64 else want & np.uint64((1 << b) - 1)), "PARITY FAILURE (sparse round trip)"
+    orc.build()
+    assert np.array_equal(d_ct[3].download(np.uint64, k * L).reshape(k, L), orc.encrypt(KEY, 0, 3, "single", J, b, vals[3])), "PARITY FAILURE client 3"
+    for it in range(max(W, 2)):
+        step(it)
+    elapsed = timed_region(ops, K, lambda kk: step(kk, kk))
+    if rank != 0:
+        return None
+    ph = np.array([[eng.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in ev])
+    agg_ms = float(ph[:, 1].mean())
+    alg_bytes = C * k * (4 + 8 * L) + total * 8 * L
+    achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
+    out.update({
+        "value": world * C * k / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
+        "config": {"workload": f"BASELINE config 5: top-1 % sparsified gradient (k={k} of {total} positions, u32 index + {8 * L}-byte value), {C} clients, "
+                               f"{b}-bit modulus, single mask over compact positions (the sparse path the reference runs; dynamic masking picks it), "
+                               f"n_jobs={J}; step = {C} compact encrypts + fused sparse aggregate + dense minus-mask + decrypt"
+                               + ("; independent replicas per GPU" if world > 1 else ""),
+                   "n": total, "k": k, "int_bits": b, "clients_total": C, "mask": "single (sparse)",
+                   "parity": "bit-exact (dense round trip + one client's ciphertext vs the oracle, checked in-run)"},
+        "roofline": {"kernel": "span_reduce_kernel (fused sparse aggregate: LDS-staged spans, dense vector written once)",
+                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms, "launches_timed": K},
+        "phases_ms": {"encrypt_xC": float(ph[:, 0].mean()), "sparse_aggregate": agg_ms, "minus_mask_plus_decrypt": float(ph[:, 2].mean())},
+    })
+    return out
 
 
 if __name__ == "__main__":

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "flashe_decrypt_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_vp, c_vp]),
     "flashe_combine_dev": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
     "flashe_combine": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "flashe_combine_batch_dev": (c_int, [c_vp, c_u64, c_int, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                         ctypes.POINTER(c_vp)]),
     "flashe_aggregate_elem_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_aggregate_elem": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_aggregate_decrypt_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_int,
@@ -92,6 +94,7 @@ _SIGNATURES = {
     "flashe_aggregate_packed": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_u64, c_vp]),
     "flashe_packed_probe_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_packed_add_carry_dev": (c_int, [c_vp, c_u64, c_u64, c_u64, c_vp]),
+    "flashe_packed_resolve_carry_dev": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_vp]),
     "flashe_pack_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_pack": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_unpack_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
@@ -114,6 +117,16 @@ _SIGNATURES = {
     "flashe_unbatch": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
     "flashe_sparsify_dev": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
     "flashe_sparsify": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "flashe_rccl_unique_id": (c_int, [c_u8p]),
+    "flashe_rccl_init": (c_int, [c_vp, c_u8p, c_int, c_int, ctypes.POINTER(c_vp)]),
+    "flashe_rccl_destroy": (c_int, [c_vp]),
+    "flashe_rccl_rank": (c_int, [c_vp]),
+    "flashe_rccl_world": (c_int, [c_vp]),
+    "flashe_rccl_all_to_all": (c_int, [c_vp, c_vp, c_vp, c_size, c_vp, c_size, c_size]),
+    "flashe_rccl_all_gather": (c_int, [c_vp, c_vp, c_vp, c_vp, c_size]),
+    "flashe_rccl_reduce_scatter_modadd": (c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp, c_vp]),
+    "flashe_rccl_allreduce_f64": (c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_double), c_int]),
+    "flashe_rccl_barrier": (c_int, [c_vp, c_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,7 +1,6 @@
 // C ABI of libflashe_hip.so (see include/flashe.h).  Host-side glue only: context, key
 // schedule, device buffers, argument checks, and the host-pointer convenience wrappers.
-#include "flashe.h"
-#include "kernels.h"
+#include "ctx.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -111,37 +110,15 @@ thread_local std::string g_create_error;
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
-// Context
+// Context (struct flashe_ctx: ctx.h)
 // ------------------------------------------------------------------------------------------
-struct flashe_ctx {
-    int device = 0;
-    int int_bits = 0;
-    int limbs = 0;
-    bool own_stream = false;
-    LaunchEnv env{};
-    uint32_t *te0_dev = nullptr;
-    uint32_t *rkw_dev = nullptr;
-    uint32_t *rkp_dev = nullptr;
-    std::string err;
-    // scratch buffers owned by the ctx (grown on demand, reused across calls)
-    struct Buf { void *p = nullptr; size_t cap = 0; };
-    Buf summaries;    // packed-aggregate block summaries
-    Buf stream_tmp;   // whole-vector mask stream for the sparse paths
-    Buf acc_tmp[2];   // ping-pong partial sums when a packed reduce has more than kMaxOps operands
-    Buf sp_ws;        // sparsifier workspace (select state, histogram, per-block counts)
-    Buf bounds;       // span reduce: first entry of every client in every span
-    bool capturing = false;   // between flashe_graph_begin and flashe_graph_end
-    uint32_t key_epoch = 0;   // bumped by flashe_ctx_set_key: a graph replays the key it was captured with
-    uint32_t *err_flag_host = nullptr;   // host-mapped word the sparse kernels set when they skip an out-of-range location
-};
-
 struct flashe_graph {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint32_t key_epoch = 0;
 };
 
-namespace {
+namespace flashe_host {
 
 int fail(flashe_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -154,19 +131,11 @@ int fail(flashe_ctx *ctx, int code, const char *fmt, ...)
     return code;
 }
 
-#define HIP_TRY(ctx, expr)                                                                           \
-    do {                                                                                             \
-        hipError_t e_ = (expr);                                                                      \
-        if (e_ != hipSuccess)                                                                        \
-            return fail(ctx, e_ == hipErrorOutOfMemory ? FLASHE_ENOMEM : FLASHE_EIO, "%s failed: %s", #expr, \
-                        hipGetErrorString(e_));                                                      \
-    } while (0)
+}  // namespace flashe_host
 
-#define CHECK_CTX(ctx)                                                        \
-    do {                                                                      \
-        if (!(ctx)) return FLASHE_EINVAL;                                     \
-        HIP_TRY(ctx, hipSetDevice((ctx)->device));                            \
-    } while (0)
+using flashe_host::fail;
+
+namespace {
 
 int ensure(flashe_ctx *ctx, flashe_ctx::Buf &b, size_t bytes)
 {
@@ -707,17 +676,13 @@ int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_j
         }
         return FLASHE_OK;
     }
-    const int launches = (n_entries + kMaxBatch - 1) / kMaxBatch, per_launch = (n_entries + launches - 1) / launches;
-    for (int e0 = 0; e0 < n_entries; e0 += per_launch) {
-        PrfJob jobs[kMaxBatch];
-        const int ne = std::min(per_launch, n_entries - e0);
-        for (int e = 0; e < ne; e++) {
-            const flashe_prf_job &j = entries[e0 + e];
-            jobs[e] = PrfJob{j.add_idx, j.minus_idx, j.first, j.count, j.in_dev, j.in_limbs, j.out_dev,
-                             j.n_in ? j.n_in : 1u, j.in_stride * 2, j.n_in > 1 ? j.sum_out_dev : nullptr};
-        }
-        HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, dbl != 0, ne, jobs, n, n_jobs));
+    std::vector<PrfJob> jobs(n_entries);
+    for (int e = 0; e < n_entries; e++) {
+        const flashe_prf_job &j = entries[e];
+        jobs[e] = PrfJob{j.add_idx, j.minus_idx, j.first, j.count, j.in_dev, j.in_limbs, j.out_dev,
+                         j.n_in ? j.n_in : 1u, j.in_stride * 2, j.n_in > 1 ? j.sum_out_dev : nullptr};
     }
+    HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, dbl != 0, n_entries, jobs.data(), n, n_jobs));
     return FLASHE_OK;
 }
 
@@ -796,6 +761,22 @@ int flashe_combine_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, int 
     if (ctx->limbs == 2 && (!aligned16(out_dev) || !aligned16(add_dev) || !aligned16(minus_dev) || (in_limbs == 2 && !aligned16(in_dev))))
         return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
     HIP_TRY(ctx, launch_combine(ctx->env, n, in_dev, in_limbs, add_dev, minus_dev, out_dev));
+    return FLASHE_OK;
+}
+
+int flashe_combine_batch_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                             const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n_vec < 0 || (n_vec && (!in_dev || !out_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
+    if (in_limbs != 1 && in_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 or %d", ctx->limbs);
+    for (int v = 0; v < n_vec; v++) {
+        if (n && (!in_dev[v] || !out_dev[v])) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
+        const uint64_t *a = add_dev ? add_dev[v] : nullptr, *m = minus_dev ? minus_dev[v] : nullptr;
+        if (ctx->limbs == 2 && (!aligned16(out_dev[v]) || !aligned16(a) || !aligned16(m) || (in_limbs == 2 && !aligned16(in_dev[v]))))
+            return fail(ctx, FLASHE_EINVAL, "vector %d: device vectors must be 16-byte aligned", v);
+    }
+    HIP_TRY(ctx, launch_combine_batch(ctx->env, n, n_vec, in_dev, in_limbs, add_dev, minus_dev, out_dev));
     return FLASHE_OK;
 }
 
@@ -912,6 +893,16 @@ int flashe_packed_add_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t tota
     if (n_limbs != (total_bits + 63) / 64) return fail(ctx, FLASHE_EINVAL, "n_limbs must equal ceil(total_bits / 64)");
     if (n_limbs && !x_dev) return fail(ctx, FLASHE_EINVAL, "null vector");
     HIP_TRY(ctx, launch_packed_add_carry(ctx->env, n_limbs, total_bits, carry_in, x_dev));
+    return FLASHE_OK;
+}
+
+int flashe_packed_resolve_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t total_bits, const uint64_t *infos_dev, int n_below,
+                                    uint64_t *x_dev)
+{
+    CHECK_CTX(ctx);
+    if (n_limbs != (total_bits + 63) / 64) return fail(ctx, FLASHE_EINVAL, "n_limbs must equal ceil(total_bits / 64)");
+    if ((n_limbs && !x_dev) || n_below < 0 || (n_below && !infos_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    HIP_TRY(ctx, launch_packed_resolve_carry(ctx->env, n_limbs, total_bits, infos_dev, n_below, x_dev));
     return FLASHE_OK;
 }
 

@@ -84,6 +84,11 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
                           const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);
 
+// n_vec combines of equal length in as few launches as possible (host arrays of device pointers; add_dev / minus_dev or single
+// entries of them may be null)
+hipError_t launch_combine_batch(const LaunchEnv &env, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev);
+
 // Operand pointers of one reduce pass travel in the kernel argument block (scalar loads).
 constexpr int kMaxOps = 64;
 struct PtrTable { const uint64_t *p[kMaxOps]; };
@@ -103,6 +108,9 @@ hipError_t launch_aggregate_packed(const LaunchEnv &env, int C, const uint64_t *
 // slice sum, and the in-place carry-in ripple
 hipError_t launch_packed_probe(const LaunchEnv &env, uint64_t n_limbs, const uint64_t *x_dev, uint64_t *info_dev);
 hipError_t launch_packed_add_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, uint64_t cin, uint64_t *x_dev);
+// the same with the carry-in derived on the device from the probe triples of the n_below slices underneath (infos_dev: 3 words each)
+hipError_t launch_packed_resolve_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, const uint64_t *infos_dev, int n_below,
+                                       uint64_t *x_dev);
 
 hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
 hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);

@@ -648,18 +648,34 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
             const CtrPrefix c = ctr_prefix(rk, lr, iter, tb.idx[s], static_cast<uint32_t>(tb.first[i] >> 32));
             *reinterpret_cast<uint4 *>(pre_lds + 4 * s) = make_uint4(c.u[0], c.u[1], c.u[2], c.u[3]);
         }
-        // this workgroup's tiles of every chain
-        if (threadIdx.x == 0) {
-            const uint64_t Wt = tb.wend[last], G = gridDim.x, g = blockIdx.x;
-            const uint64_t lo = Wt / G * g + (Wt % G) * g / G, hi = Wt / G * (g + 1) + (Wt % G) * (g + 1) / G;
-            uint64_t cw = 0, acc = 0;
-            for (int i = 0; i < n_chains; i++) {
-                const uint64_t w = tb.len[i] + ((tb.flags[i] & 1) ? 0 : 1), T = (tb.wend[i] - cw) / w;
-                uint64_t a = lo > cw ? (lo - cw + w - 1) / w : 0, b = hi > cw ? (hi - cw + w - 1) / w : 0;
-                if (a > T) a = T;
-                if (b > T) b = T;
-                d_tlo[i] = a; acc += b - a; d_cend[i] = acc; cw = tb.wend[i];
+        // this workgroup's tiles of every chain: lane i works out chain i (32-bit arithmetic whenever the launch's total
+        // weight fits -- a 64-bit division is ~150 dependent instructions, and a short launch is all prologue)
+        if (threadIdx.x < static_cast<unsigned>(n_chains)) {
+            const int i = threadIdx.x;
+            const uint64_t Wt = tb.wend[last], cw = i ? tb.wend[i - 1] : 0;
+            const uint32_t w = tb.len[i] + ((tb.flags[i] & 1) ? 0u : 1u);
+            uint64_t a, b, T;
+            if (Wt <= 0xffffffffull && gridDim.x <= 0xffffu) {
+                const uint32_t W32 = static_cast<uint32_t>(Wt), G = gridDim.x, g = blockIdx.x, c32 = static_cast<uint32_t>(cw);
+                const uint32_t q = W32 / G, r = W32 % G;
+                const uint32_t lo = q * g + r * g / G, hi = q * (g + 1) + r * (g + 1) / G;
+                const uint32_t T32 = (static_cast<uint32_t>(tb.wend[i]) - c32) / w;
+                const uint32_t a32 = lo > c32 ? (lo - c32 + w - 1) / w : 0, b32 = hi > c32 ? (hi - c32 + w - 1) / w : 0;
+                T = T32; a = a32; b = b32;
+            } else {
+                const uint64_t G = gridDim.x, g = blockIdx.x;
+                const uint64_t lo = Wt / G * g + (Wt % G) * g / G, hi = Wt / G * (g + 1) + (Wt % G) * (g + 1) / G;
+                T = (tb.wend[i] - cw) / w;
+                a = lo > cw ? (lo - cw + w - 1) / w : 0; b = hi > cw ? (hi - cw + w - 1) / w : 0;
             }
+            if (a > T) a = T;
+            if (b > T) b = T;
+            d_tlo[i] = a; d_cend[i] = b - a;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t acc = 0;
+            for (int i = 0; i < n_chains; i++) { acc += d_cend[i]; d_cend[i] = acc; }
         }
         __syncthreads();
     }
@@ -1366,12 +1382,21 @@ static hipError_t launch_jobs_as_chains(const LaunchEnv &env, uint32_t iter, boo
 
 hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n, uint32_t n_jobs)
 {
-    if (n_entries > kMaxBatch) return hipErrorInvalidValue;
-    if (env.b <= 64) return launch_prf_jobs_small(env, iter, dbl, n_entries, jobs, n, n_jobs);
-    {
+    if (env.b > 64) {
+        // any number of entries: neighbours that share a prefix are linked across the whole list
         const hipError_t e = launch_jobs_as_chains(env, iter, dbl, n_entries, jobs);
         if (e != hipErrorNotSupported) return e;
     }
+    if (n_entries > kMaxBatch) {
+        // the job-table kernels hold kMaxBatch entries per launch: equal shares
+        const int launches = (n_entries + kMaxBatch - 1) / kMaxBatch, per = (n_entries + launches - 1) / launches;
+        for (int e0 = 0; e0 < n_entries; e0 += per) {
+            const hipError_t e = launch_prf_jobs(env, iter, dbl, std::min(per, n_entries - e0), jobs + e0, n, n_jobs);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    if (env.b <= 64) return launch_prf_jobs_small(env, iter, dbl, n_entries, jobs, n, n_jobs);
     JobTable tb{};
     int nv = 0;
     uint64_t big[kMaxBatch];
@@ -1438,7 +1463,15 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
     }
     if (pieces.empty()) return hipSuccess;
     const uint64_t waves = static_cast<uint64_t>(env.num_cus) * (kPrfThreads / 64);
-    const bool all_half = total_tiles < 2 * waves;
+    bool all_half = total_tiles < 2 * waves;
+    // experiment knobs (tests/perf/sweep_chain.py), read per launch only when FLASHE_CHAIN_TUNE is set
+    static const bool tune = getenv("FLASHE_CHAIN_TUNE") != nullptr;
+    int force_parts = 0, force_grid = 0;
+    if (tune) {
+        if (const char *e = getenv("FLASHE_CHAIN_HALF")) all_half = atoi(e) != 0;
+        if (const char *e = getenv("FLASHE_CHAIN_PARTS")) force_parts = atoi(e);
+        if (const char *e = getenv("FLASHE_CHAIN_GRID")) force_grid = atoi(e);
+    }
     // cut: (1) table limits, (2) parallelism of short launches (never below 4 outputs per piece: a cut costs one stream)
     std::vector<Piece> cut;
     for (const Piece &pc : pieces) {
@@ -1450,6 +1483,7 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
             parts = std::min(parts, std::max(1, kMaxChains / static_cast<int>(pieces.size())));
             parts = std::max(parts, (pc.l1 + kMaxLinks - 1) / kMaxLinks);
         }
+        if (force_parts > 0) parts = std::max(std::min(force_parts, pc.l1), (pc.l1 + kMaxLinks - 1) / kMaxLinks);
         for (int k = 0; k < parts; k++) {
             const int a = static_cast<int>(static_cast<int64_t>(pc.l1) * k / parts), b = static_cast<int>(static_cast<int64_t>(pc.l1) * (k + 1) / parts);
             if (b > a) cut.push_back(Piece{pc.ch, a, b, pc.tiles});
@@ -1481,7 +1515,8 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
             links += len; streams += ns; nc++;
         }
         const uint64_t items = all_half ? 2 * tiles : tiles, cus = static_cast<uint64_t>(env.num_cus);
-        const int grid = static_cast<int>(items < cus ? items : cus);
+        int grid = static_cast<int>(items < cus ? items : cus);
+        if (force_grid > 0) grid = force_grid;
         hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc, all_half ? 1 : 0,
                            iter, lo, hi, env.te0_dev);
         const hipError_t e = hipGetLastError();
@@ -1536,6 +1571,63 @@ __global__ __launch_bounds__(kStreamThreads) void combine_small_kernel(uint64_t 
         if (minus) v -= minus[j];
         out[j] = v & mask;
     }
+}
+
+// Several combines of equal length in one launch (the online encrypts of the clients a process hosts when their masks were
+// precomputed: a hundred LeNet-sized vectors are launch-bound one by one).  blockIdx.y = vector.
+constexpr int kMaxCombine = 64;
+struct CombineTable {
+    const uint64_t *in[kMaxCombine], *add[kMaxCombine], *minus[kMaxCombine];
+    uint64_t *out[kMaxCombine];
+};
+
+template <bool WIDE>
+__global__ __launch_bounds__(kStreamThreads) void combine_batch_kernel(uint64_t n, const CombineTable tb, int in_limbs, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const int v = blockIdx.y;
+    const uint64_t *in = tb.in[v], *add = tb.add[v], *minus = tb.minus[v];
+    uint64_t *out = tb.out[v];
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        if (WIDE) {
+            u128 x = in_limbs == 2 ? ld128_nt(in + 2 * j) : static_cast<u128>(__builtin_nontemporal_load(in + j));
+            if (add) x += ld128_nt(add + 2 * j);
+            if (minus) x -= ld128_nt(minus + 2 * j);
+            st128_nt(out + 2 * j, x & mask);
+        } else {
+            uint64_t x = in[j];
+            if (add) x += add[j];
+            if (minus) x -= minus[j];
+            out[j] = x & mask_lo;
+        }
+    }
+}
+
+hipError_t launch_combine_batch(const LaunchEnv &env, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev)
+{
+    if (n == 0 || n_vec == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    for (int v0 = 0; v0 < n_vec; v0 += kMaxCombine) {
+        const int nv = std::min(kMaxCombine, n_vec - v0);
+        CombineTable tb{};
+        for (int v = 0; v < nv; v++) {
+            tb.in[v] = in_dev[v0 + v]; tb.add[v] = add_dev ? add_dev[v0 + v] : nullptr;
+            tb.minus[v] = minus_dev ? minus_dev[v0 + v] : nullptr; tb.out[v] = out_dev[v0 + v];
+        }
+        // enough blocks per vector to fill the chip together, at most 8 x 256 threads per CU in all
+        uint64_t bx = (n + kStreamThreads - 1) / kStreamThreads;
+        const uint64_t cap = std::max<uint64_t>(1, static_cast<uint64_t>(env.num_cus) * 8 / nv);
+        if (bx > cap) bx = cap;
+        const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(nv));
+        if (env.b > 64) hipLaunchKernelGGL(combine_batch_kernel<true>, grid, dim3(kStreamThreads), 0, env.stream, n, tb, in_limbs, lo, hi);
+        else hipLaunchKernelGGL(combine_batch_kernel<false>, grid, dim3(kStreamThreads), 0, env.stream, n, tb, in_limbs, lo, hi);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
@@ -1764,10 +1856,22 @@ __global__ void packed_probe_init_kernel(uint64_t *info) { info[0] = 0; info[1] 
 // x = (x + cin) mod 2^total_bits in place, one workgroup: the ripple stops at the first limb that is
 // not all ones, which is limb 0 or 1 for anything but adversarial data.
 constexpr int kRippleThreads = 1024;
-__global__ __launch_bounds__(kRippleThreads) void packed_add_carry_kernel(uint64_t n_limbs, uint64_t top_mask, uint64_t cin, uint64_t *x)
+// infos != null: the carry-in is derived on the device from the (low limb, body-all-ones, carry-out) triples of the limb
+// slices below this one (ranks 0 .. n_below - 1 of a packed reduce cut across GPUs): a slice passes its carry-in on when all its
+// body limbs are ones and the low limb overflows, on top of its own carry-out.
+__global__ __launch_bounds__(kRippleThreads) void packed_add_carry_kernel(uint64_t n_limbs, uint64_t top_mask, uint64_t cin, uint64_t *x,
+                                                                          const uint64_t *__restrict__ infos, int n_below)
 {
     __shared__ int first_stop;
     const int tid = threadIdx.x;
+    if (infos) {
+        uint64_t carry = 0;
+        for (int g = 0; g < n_below; g++) {
+            const uint64_t low = infos[3 * g], ones = infos[3 * g + 1], cout = infos[3 * g + 2];
+            carry = cout + ((ones && low + carry < low) ? 1ull : 0ull);
+        }
+        cin = carry;
+    }
     const uint64_t x0 = x[0];
     __syncthreads();
     const uint64_t s0 = x0 + cin;
@@ -1804,7 +1908,18 @@ hipError_t launch_packed_add_carry(const LaunchEnv &env, uint64_t n_limbs, uint6
     if (n_limbs == 0) return hipSuccess;
     const unsigned top = static_cast<unsigned>(total_bits % 64);
     const uint64_t top_mask = top ? ((1ull << top) - 1) : ~0ull;
-    hipLaunchKernelGGL(packed_add_carry_kernel, dim3(1), dim3(kRippleThreads), 0, env.stream, n_limbs, top_mask, cin, x_dev);
+    hipLaunchKernelGGL(packed_add_carry_kernel, dim3(1), dim3(kRippleThreads), 0, env.stream, n_limbs, top_mask, cin, x_dev,
+                       static_cast<const uint64_t *>(nullptr), 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_packed_resolve_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, const uint64_t *infos_dev, int n_below,
+                                       uint64_t *x_dev)
+{
+    if (n_limbs == 0) return hipSuccess;
+    const unsigned top = static_cast<unsigned>(total_bits % 64);
+    const uint64_t top_mask = top ? ((1ull << top) - 1) : ~0ull;
+    hipLaunchKernelGGL(packed_add_carry_kernel, dim3(1), dim3(kRippleThreads), 0, env.stream, n_limbs, top_mask, 0ull, x_dev, infos_dev, n_below);
     return hipGetLastError();
 }
 

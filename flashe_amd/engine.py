@@ -255,6 +255,14 @@ class Engine:
     def combine_dev(self, n, inp, in_limbs, add, minus, out):
         self._check(self._lib.flashe_combine_dev(self._h, n, self._ptr(inp), in_limbs, self._ptr(add), self._ptr(minus), self._ptr(out)))
 
+    def combine_batch_dev(self, n, inps, in_limbs, adds, minuses, outs):
+        """out[v] = inps[v] + adds[v] - minuses[v] for every v in one launch; adds / minuses: lists (entries may be None) or None."""
+        pi, _a = self._ptr_array(inps)
+        po, _b = self._ptr_array(outs)
+        pa, _c = self._ptr_array(adds) if adds is not None else (None, None)
+        pm, _d = self._ptr_array(minuses) if minuses is not None else (None, None)
+        self._check(self._lib.flashe_combine_batch_dev(self._h, n, len(inps), pi, in_limbs, pa, pm, po))
+
     def _ptr_array(self, items):
         arr = (c_vp * max(len(items), 1))(*[self._ptr(x) for x in items])
         return ctypes.cast(arr, ctypes.POINTER(c_vp)), arr
@@ -283,6 +291,10 @@ class Engine:
     def packed_add_carry_dev(self, n_limbs, total_bits, carry_in, x):
         """x <- (x + carry_in) mod 2^total_bits in place."""
         self._check(self._lib.flashe_packed_add_carry_dev(self._h, n_limbs, total_bits, carry_in, self._ptr(x)))
+
+    def packed_resolve_carry_dev(self, n_limbs, total_bits, infos, n_below, x):
+        """x <- (x + carry_in) mod 2^total_bits, carry_in derived on the device from the probe triples of the n_below slices below."""
+        self._check(self._lib.flashe_packed_resolve_carry_dev(self._h, n_limbs, total_bits, self._ptr(infos), n_below, self._ptr(x)))
 
     def pack_dev(self, n, inp, out):
         self._check(self._lib.flashe_pack_dev(self._h, n, self._ptr(inp), self._ptr(out)))

@@ -211,6 +211,11 @@ int flashe_combine_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, int 
                        const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);
 int flashe_combine(flashe_ctx *ctx, uint64_t n, const uint64_t *in, int in_limbs,
                    const uint64_t *add, const uint64_t *minus, uint64_t *out);
+/* n_vec combines of equal length in as few launches as possible (new): the online encrypts of the clients one process hosts --
+ * vector v is out[v] = in[v] + add[v] - minus[v].  in / add / minus / out are HOST arrays of n_vec device pointers; add_dev,
+ * minus_dev or single entries of them may be NULL. */
+int flashe_combine_batch_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                             const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev);
 
 /* ---- arbiter reduce ----------------------------------------------------------------- */
 /* Element-wise: out[j] = sum_c cts[c][j] mod 2^b -- jzf_aggregator.py:424-430.
@@ -246,6 +251,10 @@ int flashe_aggregate_packed(flashe_ctx *ctx, int C, const uint64_t *const *packe
 int flashe_packed_probe_dev(flashe_ctx *ctx, uint64_t n_limbs, const uint64_t *x_dev, uint64_t *info_dev);
 int flashe_packed_add_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t total_bits,
                                 uint64_t carry_in, uint64_t *x_dev);
+/* add_carry with the carry-in derived ON THE DEVICE from the probe triples of the n_below slices underneath (infos_dev =
+ * the all-gathered 3-word infos, slice 0 first): no host round trip between the exchange of the infos and the ripple. */
+int flashe_packed_resolve_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t total_bits,
+                                    const uint64_t *infos_dev, int n_below, uint64_t *x_dev);              /* new */
 
 /* ---- bit-packing codec ---------------------------------------------------------------- */
 /* pack: P = sum_j x[j] << (b * (n-1-j)) as ceil(n*b/64) little-endian limbs --
@@ -332,6 +341,36 @@ int flashe_sparsify_dev(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x_d
                         uint32_t *loc_dev, void *vals_dev);
 int flashe_sparsify(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x, int x_is_f64, void *residual,
                     uint32_t *loc, void *vals);
+
+/* ---- multi-GPU exchange (RCCL over xGMI; one process per GPU) ----------------------------------------------- */
+/* Replaces, inside one node, the arbiter's gather of client models + reduce in Python + broadcast of the aggregate
+ * (jzf_aggregator.py:292-308, :404-430, :502-508): every GPU encrypts and locally reduces the clients it hosts, ONE
+ * reduce-scatter mod 2^b combines the partial aggregates, every GPU decrypts the slice it owns (the *_range_dev twins)
+ * and an all-gather returns the plaintext aggregate to all.  librccl.so is loaded on first use (dlopen), so programs
+ * that never call these functions do not depend on it.  All transfers are enqueued on the ctx stream; a flashe_comm may
+ * be used with any ctx of the device it was created on (e.g. a side ctx whose stream overlaps the exchange with the
+ * AES-bound kernels).  Every rank must issue the same sequence of collective calls.  All "new". */
+#define FLASHE_RCCL_ID_BYTES 128                      /* sizeof(ncclUniqueId) */
+typedef struct flashe_comm flashe_comm;
+int flashe_rccl_unique_id(uint8_t id[FLASHE_RCCL_ID_BYTES]);       /* rank 0 makes it, the launcher hands it to every rank */
+int flashe_rccl_init(flashe_ctx *ctx, const uint8_t id[FLASHE_RCCL_ID_BYTES], int rank, int world, flashe_comm **out);
+int flashe_rccl_destroy(flashe_comm *comm);
+int flashe_rccl_rank(const flashe_comm *comm);
+int flashe_rccl_world(const flashe_comm *comm);
+/* Piece p (bytes long, at send_dev + p * send_stride) goes to rank p; the piece from rank p lands at recv_dev + p * recv_stride.
+ * Grouped ncclSend / ncclRecv: on xGMI every GPU pair has its own link, so the W - 1 transfers run concurrently. */
+int flashe_rccl_all_to_all(flashe_ctx *ctx, flashe_comm *comm, const void *send_dev, size_t send_stride,
+                           void *recv_dev, size_t recv_stride, size_t bytes);
+int flashe_rccl_all_gather(flashe_ctx *ctx, flashe_comm *comm, const void *send_dev, void *recv_dev, size_t bytes);
+/* The reduce-scatter mod 2^int_bits that RCCL cannot express (no 128-bit type; ncclSum does not wrap at 2^b):
+ * partial_dev = world slices of slice_elems elements; after the call out_slice_dev = sum over ranks of slice [rank]
+ * (+ extra_dev when given: one more local operand, e.g. the decrypt mask difference).  recv_dev = world x slice_elems
+ * elements of scratch. */
+int flashe_rccl_reduce_scatter_modadd(flashe_ctx *ctx, flashe_comm *comm, const uint64_t *partial_dev, uint64_t slice_elems,
+                                      uint64_t *recv_dev, const uint64_t *extra_dev, uint64_t *out_slice_dev);
+/* Host-value all-reduce, synchronous (timing: max over ranks; agreement: min): op 0 = max, 1 = min, 2 = sum. */
+int flashe_rccl_allreduce_f64(flashe_ctx *ctx, flashe_comm *comm, double *value, int op);
+int flashe_rccl_barrier(flashe_ctx *ctx, flashe_comm *comm);
 
 #ifdef __cplusplus
 }

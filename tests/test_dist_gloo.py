@@ -8,6 +8,8 @@ import pytest
 
 from conftest import ROOT
 
+KEY = bytes(range(32))
+
 
 @pytest.mark.parametrize("world,port", [(2, 29541), (3, 29542)])
 def test_sharded_round_gloo(world, port, oracle):
@@ -18,21 +20,57 @@ def test_sharded_round_gloo(world, port, oracle):
     assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_pipelined_single_rank_schedule(oracle):
-    """ShardedRound.run_pipelined (chunked reduce on a side stream) computes the same round as run()."""
+def test_single_rank_schedules(oracle):
+    """ShardedRound.run_pipelined / run_fused / run_packed compute the same round as run() on one rank, with and without the
+    (identity) exchange step forced."""
     import numpy as np
-    import torch
-    from flashe_amd.dist import ShardedRound
+    from flashe_amd.dist import ShardedRound, deal_clients
     from oracle_ops import OracleOps
+    assert [len(x) for x in deal_clients(10, 8)] == [2, 2, 1, 1, 1, 1, 1, 1]
+    assert deal_clients(10, 8)[1] == [2, 3] and deal_clients(3, 1) == [[0, 1, 2]] and deal_clients(2, 4) == [[0], [1], [], []]
     for b, n, cpr, chunks in [(128, 5000, 3, 4), (128, 1000, 2, 8), (64, 3000, 2, 2), (20, 2500, 4, 3)]:
         L = 2 if b > 64 else 1
         pts = [np.random.Generator(np.random.PCG64(50 + c)).integers(0, 2 ** (min(b, 64) - 8), n, dtype=np.uint64) for c in range(cpr)]
-        tens = [torch.from_numpy(p.view(np.int64).copy()) for p in pts]
         want = np.zeros(n, dtype=np.uint64)
         for p in pts:
             want += p
-        for mode in ("run", "pipe", "fused"):
-            rnd = ShardedRound(OracleOps(b), n, b, cpr, 16, "cpu")
-            res = rnd.run(3, tens, 1) if mode == "run" else (rnd.run_pipelined if mode == "pipe" else rnd.run_fused)(3, tens, 1, chunks=chunks)
-            got = res.numpy().view(np.uint64)[: n * L].reshape(n, L)
-            assert np.array_equal(got[:, 0], want), (b, n, mode)
+        for force in (False, True):
+            for mode in ("run", "pipe", "fused", "packed"):
+                ops = OracleOps(b)
+                refs = [(ops.upload(p), 0) for p in pts]
+                rnd = ShardedRound(ops, n, b, cpr, 16, force_collectives=force)
+                if mode == "run":
+                    res = rnd.run(3, refs, 1)
+                elif mode == "packed":
+                    res = rnd.run_packed(3, refs, 1)
+                else:
+                    res = (rnd.run_pipelined if mode == "pipe" else rnd.run_fused)(3, refs, 1, chunks=chunks)
+                got = ops.read((res, 0), n * L).reshape(n, L)
+                if mode != "packed":
+                    assert np.array_equal(got[:, 0], want), (b, n, mode, force)
+                else:
+                    # the packed reduce lets carries cross element boundaries: compare with the oracle's packed round
+                    cts = [oracle.encrypt(KEY, 3, c, "double", 16, b, pts[c]) for c in range(cpr)]
+                    agg = oracle.aggregate_packed([oracle.pack(ct, b) for ct in cts], n * b)
+                    ref = oracle.combine(b, oracle.unpack(agg, n, b), oracle.mask_sum(KEY, 3, [cpr], n, 16, b), oracle.mask_sum(KEY, 3, [0], n, 16, b))
+                    assert np.array_equal(got, ref), (b, n, mode, force)
+
+
+def test_rendezvous_file_hands_the_id_to_every_rank(tmp_path, monkeypatch):
+    """The torch-free rendezvous of flashe_amd.dist: rank 0 publishes 128 bytes atomically, the others poll for them."""
+    import threading
+    from flashe_amd.dist import rendezvous_unique_id
+    monkeypatch.setenv("FLASHE_RDZV_DIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "12345")
+    ident = bytes(range(128))
+    got = {}
+
+    def reader(r):
+        got[r] = rendezvous_unique_id(r, 3, None, timeout=20)[0]
+    ts = [threading.Thread(target=reader, args=(r,)) for r in (1, 2)]
+    for t in ts:
+        t.start()
+    got[0] = rendezvous_unique_id(0, 3, lambda: ident)[0]
+    for t in ts:
+        t.join()
+    assert got == {0: ident, 1: ident, 2: ident}

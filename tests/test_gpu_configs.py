@@ -1,0 +1,180 @@
+"""BASELINE.json configurations 3, 4 and 5 at FULL size on one MI355X, through the same code paths bench.py --config runs, every
+ciphertext (or, where the dense oracle form would not fit the host, an equivalent sparse restatement) compared with the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEY = bytes(range(32))
+LENET, RESNET50 = 61_706, 25_557_032
+
+
+@pytest.fixture(scope="module")
+def E():
+    from flashe_amd import engine
+    return engine
+
+
+def _sum_limbs(vectors, b):
+    lo = np.zeros_like(vectors[0])
+    hi = np.zeros_like(vectors[0])
+    for p in vectors:
+        new = lo + p
+        hi += (new < lo).astype(np.uint64)
+        lo = new
+    if b < 64:
+        lo &= np.uint64((1 << b) - 1)
+    if b <= 64:
+        hi[:] = 0
+    elif b < 128:
+        hi &= np.uint64((1 << (b - 64)) - 1)
+    return lo, hi
+
+
+@pytest.mark.parametrize("b,n_jobs", [(128, 16), (23, 16)])
+def test_config3_lenet_100_clients_with_mask_precompute(E, oracle, b, n_jobs):
+    """Config 3: n = 61,706 (LeNet-5), C = 100, double mask + mask precompute, at b = 128 and at the reference-style
+    int_bits = 16 + ceil(log2 100) = 23 (m = 5, chunk-dependent counters).  Round r: every client runs prepare_encrypt for the
+    next iteration (jzf_flashe.py:599-631); round r + 1: encrypt consumes the cached masks (no AES online, :457,483-486), the
+    arbiter reduces, prepare_decrypt + decrypt (:633-666, :537-582).  EVERY ciphertext is compared with the oracle's own encrypt;
+    the same round through the device-level batch calls bench.py --config 3 uses must give identical ciphertexts."""
+    from flashe_amd import FlasheCipher
+    from flashe_amd import cipher as cipher_mod
+    cipher_mod.N_JOBS = n_jobs
+    n, C, it = LENET, 100, 4
+    L = 2 if b > 64 else 1
+    rng = np.random.Generator(np.random.PCG64(3))
+    pts = [rng.integers(0, 2 ** (16 if b < 64 else 64), n, dtype=np.uint64) for _ in range(C)]
+    clients = []
+    for c in range(C):
+        ci = FlasheCipher(b)
+        ci.set_num_clients(C)
+        ci.generate_prp_seed(KEY)
+        ci.set_iter_index(it - 1)
+        ci.idx = c
+        ci.set_num_params(n)
+        ci.prepare_encrypt()                      # masks for iteration `it`
+        clients.append(ci)
+    cts = []
+    for c, ci in enumerate(clients):
+        ci.set_iter_index(it)
+        assert "add" in ci.next_iter_encrypt_prepared
+        ct = ci.encrypt(pts[c] if L == 1 else pts[c])
+        assert not ci.next_iter_encrypt_prepared            # consumed
+        want = oracle.encrypt(KEY, it, c, "double", n_jobs, b, pts[c])
+        got = ct.reshape(n, -1) if ct.dtype == np.uint64 else None
+        assert got is not None and np.array_equal(got, want), (b, c)
+        cts.append(got)
+    agg = clients[0].aggregate([c if L == 2 else c[:, 0] for c in cts])
+    agg = agg.reshape(n, -1)
+    assert np.array_equal(agg, oracle.aggregate_elem(cts, b))
+    ci = clients[7]
+    ci.prepare_decrypt()
+    ci.set_idx_list(raw_idx_list=list(range(C)), mode="decrypt")
+    assert ci.index_prefix_for_add == [] and ci.index_prefix_for_minus == []     # all covered by the precomputed masks
+    dec = ci.decrypt(agg if L == 2 else agg[:, 0]).reshape(n, -1)
+    lo, hi = _sum_limbs(pts, b)
+    assert np.array_equal(dec[:, 0], lo) and (L == 1 or np.array_equal(dec[:, 1], hi))
+    # device-level form (bench.py --config 3): one chained launch for every mask difference, one batched combine
+    eng = E.Engine(KEY, b, device=0)
+    dpt = [eng.upload(p) for p in pts]
+    masks = [eng.alloc_vec(n) for _ in range(C)]
+    dct = [eng.alloc_vec(n) for _ in range(C)]
+    dmask, dagg, ddec = eng.alloc_vec(n), eng.alloc_vec(n), eng.alloc_vec(n)
+    eng.prf_jobs_dev(it, n, n_jobs, [(c, c + 1, 0, n, None, 0, masks[c]) for c in range(C)] + [(C, 0, 0, n, None, 0, dmask)])
+    eng.combine_batch_dev(n, dpt, 1, masks, None, dct)
+    eng.aggregate_elem_dev(dct, n, dagg)
+    eng.combine_dev(n, dagg, L, dmask, None, ddec)
+    for c in range(C):
+        assert np.array_equal(dct[c].download(np.uint64, n * L).reshape(n, L), cts[c]), (b, c, "batched")
+    assert np.array_equal(ddec.download(np.uint64, n * L).reshape(n, L), dec)
+
+
+def test_config4_resnet50_ten_clients_one_gpu(E, oracle):
+    """Config 4 at N = 1: n = 25,557,032 (ResNet-50), C = 10, b = 128, all ten clients on one GPU through ShardedRound (what
+    bench.py --config 4 runs; with more GPUs the clients are dealt 2,2,1,1,1,1,1,1 -- tests/test_dist_gloo.py covers that
+    exchange).  Round trip == plaintext sum; two clients' FULL ciphertexts and the full aggregate against the oracle."""
+    from flashe_amd.dist import HipOps, ShardedRound, deal_clients
+    n, C, b, it = RESNET50, 10, 128, 2
+    assert [len(x) for x in deal_clients(C, 8)] == [2, 2, 1, 1, 1, 1, 1, 1]
+    eng = E.Engine(KEY, b, device=0)
+    ops = HipOps(eng)
+    pts = [np.random.Generator(np.random.PCG64(3000 + c)).integers(0, 2 ** 64, n, dtype=np.uint64) for c in range(C)]
+    refs = [(ops.upload(p), 0) for p in pts]
+    rnd = ShardedRound(ops, n, b, deal_clients(C, 1)[0], 16, total_clients=C)
+    out = rnd.run(it, refs, 1)
+    got = ops.read((out, 0), 2 * n).reshape(n, 2)
+    lo, hi = _sum_limbs(pts, b)
+    assert np.array_equal(got[:, 0], lo) and np.array_equal(got[:, 1], hi)
+    want_agg = None
+    for c in (0, 9):
+        ct = ops.read(rnd.ct[c], 2 * n).reshape(n, 2)
+        assert np.array_equal(ct, oracle.encrypt(KEY, it, c, "double", 16, b, pts[c])), c
+    cts = [ops.read(rnd.ct[c], 2 * n).reshape(n, 2) for c in range(C)]
+    want_agg = oracle.aggregate_elem(cts, b)
+    del cts
+    assert np.array_equal(ops.read((rnd.partial, 0), 2 * n).reshape(n, 2), want_agg)
+    # the fused schedule (chunked chain launches + mask difference) gives the same plaintext aggregate
+    side = E.Engine(KEY, b, device=0)
+    rnd2 = ShardedRound(HipOps(eng, side), n, b, list(range(C)), 16, total_clients=C)
+    out2 = rnd2.run_fused(it, refs, 1, chunks=4)
+    assert np.array_equal(rnd2.ops.read((out2, 0), 2 * n).reshape(n, 2), got)
+
+
+def test_config5_sparse_top1pct_50_clients(E, oracle):
+    """Config 5: total = 25,557,032 positions, k = 255,570 (top 1 %) sorted unique locations per client, C = 50, b = 128, the
+    single-mask sparse path.  Every client's compact ciphertext vs the oracle; the fused sparse
+    aggregate vs a sparse restatement of expand_to_dense + element-wise reduce (jzf_aggregator.py:150-165, :424-430) -- the 50
+    dense intermediates (20 GB) are exactly what the kernel avoids; the dense minus-mask vs the oracle; the decrypted vector vs the
+    plaintext sums."""
+    total, C, b, it, J = RESNET50, 50, 128, 6, 16
+    k = total // 100
+    eng = E.Engine(KEY, b, device=0)
+    rngs = [np.random.Generator(np.random.PCG64(2000 + c)) for c in range(C)]
+    locs = [np.sort(r.choice(total, k, replace=False)).astype(np.uint32) for r in rngs]
+    vals = [r.integers(0, 2 ** 64, k, dtype=np.uint64) for r in rngs]
+    zero = (1 << 31) + 5
+    d_loc = [eng.upload(l) for l in locs]
+    d_val = [eng.upload(v) for v in vals]
+    d_ct = [eng.alloc_vec(k) for _ in range(C)]
+    d_agg, d_mask, d_dec = eng.alloc_vec(total), eng.alloc_vec(total), eng.alloc_vec(total)
+    eng.encrypt_batch_dev(it, list(range(C)), E.SCHEME_SINGLE, k, J, d_val, 1, d_ct)
+    cts = []
+    for c in range(C):
+        ct = d_ct[c].download(np.uint64, 2 * k).reshape(k, 2)
+        assert np.array_equal(ct, oracle.encrypt(KEY, it, c, "single", J, b, vals[c])), c
+        cts.append(ct)
+    eng.sparse_aggregate_dev(total, d_loc, [k] * C, d_ct, [zero] * C, d_agg, sorted_lists=True)
+    # sum_c expand_to_dense(c) restated sparsely: C * zero everywhere, (ct - zero) added at every client's locations
+    lo = np.full(total, np.uint64((C * zero) & (2 ** 64 - 1)), dtype=np.uint64)
+    hi = np.full(total, np.uint64((C * zero) >> 64), dtype=np.uint64)
+    for c in range(C):
+        d_lo = cts[c][:, 0] - np.uint64(zero)
+        d_hi = cts[c][:, 1] - (cts[c][:, 0] < np.uint64(zero)).astype(np.uint64)
+        new = lo[locs[c]] + d_lo
+        hi[locs[c]] += d_hi + (new < d_lo).astype(np.uint64)
+        lo[locs[c]] = new
+    agg = d_agg.download(np.uint64, 2 * total).reshape(total, 2)
+    assert np.array_equal(agg[:, 0], lo) and np.array_equal(agg[:, 1], hi)
+    # a handful of positions through the oracle's own expand_to_dense (the literal form), on a cut of the vector
+    cut = 200_000
+    dense = []
+    for c in range(C):
+        sel = locs[c] < cut
+        dense.append(oracle.expand_to_dense(cut, locs[c][sel], cts[c][sel], np.array([zero, 0], dtype=np.uint64), b))
+    assert np.array_equal(agg[:cut], oracle.aggregate_elem(dense, b))
+    del dense
+    eng.sparse_minus_mask_dev(it, d_loc, [k] * C, total, J, d_mask, sorted_lists=True)
+    mask = d_mask.download(np.uint64, 2 * total).reshape(total, 2)
+    assert np.array_equal(mask, oracle.sparse_minus_mask(KEY, it, locs, total, J, b))
+    eng.combine_dev(total, d_agg, 2, None, d_mask, d_dec)
+    dec = d_dec.download(np.uint64, 2 * total).reshape(total, 2)
+    want = np.full(total, np.uint64((C * zero) & (2 ** 64 - 1)), dtype=np.uint64)
+    whi = np.zeros(total, dtype=np.uint64)
+    for c in range(C):
+        d = vals[c] - np.uint64(zero)
+        borrow = (vals[c] < np.uint64(zero)).astype(np.uint64)
+        new = want[locs[c]] + d
+        whi[locs[c]] += (new < d).astype(np.uint64) - borrow
+        want[locs[c]] = new
+    assert np.array_equal(dec[:, 0], want) and np.array_equal(dec[:, 1], whi)

@@ -606,12 +606,15 @@ def test_packed_slice_helpers(E):
 
 
 def test_sharded_round_through_rccl_single_rank():
-    """flashe_amd.dist (element-wise, pipelined and packed rounds) with HipOps + a 1-rank RCCL group."""
+    """flashe_amd.dist (element-wise, pipelined, fused and packed rounds) with HipOps + a 1-rank RCCL communicator created through
+    flashe_rccl_* (no PyTorch in the process); once with the own piece copied locally, once sent through grouped ncclSend / ncclRecv."""
     import subprocess
     import sys
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    for self_sendrecv in ("0", "1"):
+        env = dict(os.environ, FLASHE_RCCL_SELF_SENDRECV=self_sendrecv)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py")], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("b,n", [(128, 50001), (120, 40003), (65, 999), (64, 70001), (33, 12345), (23, 61706),

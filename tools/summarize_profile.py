@@ -61,37 +61,42 @@ def main(tag):
             e["effective_clock_ghz"] = e["GRBM_GUI_ACTIVE"]["avg"] / 8 / (sum(dur[k]) / len(dur[k]))
         out[k] = e
     json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
-    # the dominant kernel is the job-list PRF kernel (batched encrypts, chunked encrypt / decrypt launches)
-    dom = next((k for k in out if "prf_wide_batch_kernel<true, 1024, 1" in k), None) or next((k for k in out if "prf_wide_batch_kernel" in k), None)
-    if dom and "FETCH_SIZE" in out[dom]:
-        f, w = out[dom]["FETCH_SIZE"], out[dom]["WRITE_SIZE"]
-        per_launch = (2 * f["avg"] + w["avg"]) * 1024
-        # algorithmic bytes per launch as the profiled bench run itself reported them
-        alg = None
-        for log in ("pmc_fetch.log", "trace.log"):
-            try:
-                for line in open(os.path.join(src, log)):
-                    if line.startswith('{"metric'):
-                        alg = json.loads(line)["roofline"]["algorithmic_bytes_per_launch"]
-            except OSError:
-                pass
-            if alg:
-                break
-        traffic = {"tag": tag, "kernel": dom, "dominant_kernel_hbm_bytes_per_launch": per_launch,
-                   "algorithmic_bytes_per_launch": alg, "hbm_bytes_per_algorithmic_byte": per_launch / alg if alg else None,
-                   "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the default bench command; "
-                          "bytes = (2 * FETCH_SIZE[KiB] + WRITE_SIZE[KiB]) * 1024 (gfx950 FETCH_SIZE counts 64 B per 128-B "
-                          "request, MI355X_MICROARCH.md HBM section), averaged over the kernel's launches",
-                   "fetch_kib_avg": f["avg"], "write_kib_avg": w["avg"]}
-        agg = next((k for k in out if "aggregate_elem_kernel" in k), None)
-        if agg and "FETCH_SIZE" in out[agg]:
-            traffic["calibration"] = {"kernel": agg, "fetch_kib_avg": out[agg]["FETCH_SIZE"]["avg"],
-                                      "write_kib_avg": out[agg]["WRITE_SIZE"]["avg"],
-                                      "note": "the reduce reads exactly 10 x what it writes: 2 * FETCH / WRITE must be 10"}
-        json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    # HBM traffic per launch of every kernel of the round, and -- for the dominant one -- its ratio to the algorithmic bytes
+    # the profiled bench run itself reported (bench.py multiplies that ratio by its own algorithmic bytes: roofline.traffic)
+    alg, dom_name = None, None
+    for log in ("pmc_fetch.log", "trace.log"):
+        try:
+            for line in open(os.path.join(src, log)):
+                if line.startswith('{"metric'):
+                    rl = json.loads(line)["roofline"]
+                    alg, dom_name = rl["algorithmic_bytes_per_launch"], rl["kernel"].split("<")[0].split(" ")[0]
+        except OSError:
+            pass
+        if alg:
+            break
+    traffic = {"tag": tag, "source": f"profiles/{tag}_pmc.json",
+               "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of the default bench command; "
+                      "bytes = (2 * FETCH_SIZE[KiB] + WRITE_SIZE[KiB]) * 1024 (gfx950 FETCH_SIZE counts 64 B per 128-B "
+                      "request, MI355X_MICROARCH.md HBM section), averaged over the kernel's launches",
+               "kernels": {}}
+    for k, e in out.items():
+        if "FETCH_SIZE" not in e or "WRITE_SIZE" not in e:
+            continue
+        short = k.replace("void ", "").replace("flashe::", "").split("<")[0].split("(")[0]
+        ent = {"full_name": k, "hbm_bytes_per_launch": e["hbm_bytes_per_launch_avg"], "fetch_kib_avg": e["FETCH_SIZE"]["avg"],
+               "write_kib_avg": e["WRITE_SIZE"]["avg"], "launches": e["FETCH_SIZE"]["launches"]}
+        if dom_name and short == dom_name and alg:
+            ent["algorithmic_bytes_per_launch"] = alg
+            ent["hbm_bytes_per_algorithmic_byte"] = e["hbm_bytes_per_launch_avg"] / alg
+        if short == "aggregate_elem_kernel":
+            ent["note"] = "calibration: this reduce reads exactly C x what it writes, so 2 * FETCH / WRITE must equal C"
+        prev = traffic["kernels"].get(short)
+        if prev is None or ent["launches"] > prev["launches"]:
+            traffic["kernels"][short] = ent
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps({k[:50]: {c: (round(v["avg"]) if isinstance(v, dict) and "avg" in v else v) for c, v in e.items()
                                if c != "launch"} for k, e in out.items()}, indent=1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
