@@ -107,6 +107,10 @@ _SIGNATURES = {
     "flashe_sparse_minus_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
     "flashe_sparse_dense_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_sparse_dense_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
+    "flashe_quantize_encrypt_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),
+    "flashe_decrypt_unquantize_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, ctypes.c_double, c_int, c_int, c_vp]),
+    "flashe_shift_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int]),
+    "flashe_mean_std_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "flashe_quantize_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),
     "flashe_quantize": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),
     "flashe_unquantize_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_int, c_vp]),

@@ -7,6 +7,7 @@ is handed in directly.
 import numpy as np
 
 from .cipher import FlasheCipher
+from .quantize import QuantizingClient
 
 __all__ = ["dynamic_masking_choice", "FlasheClient"]
 
@@ -46,6 +47,7 @@ class FlasheClient(object):
             self.num_params = args['precompute']['num_params']
         self.mask = args.get('mask', 'double')
         self.cipher = None
+        self.quantizer = None
         self._device = device
 
     def create_cipher(self, idx, num_clients, prp_seed):
@@ -58,6 +60,10 @@ class FlasheClient(object):
         if self.precompute:
             self.cipher.set_num_params(self.num_params)
             self.cipher.prepare_encrypt()
+        # the quantiser the reference creates right after the cipher (:229-238, :311-320); num_clients arrives over the wire there
+        self.quantizer = QuantizingClient(self.int_bits, None, None, self.batch, self.element_bits, self.padding, self.secure,
+                                          device=self._device)
+        self.quantizer.num_clients = num_clients
         return self.cipher
 
     def dynamic_masking(self, choice, masks):
@@ -81,6 +87,24 @@ class FlasheClient(object):
 
     def set_iter_index(self, iter_index):
         self.cipher.set_iter_index(iter_index)
+        self.quantizer.set_iter(iter_index)
+
+    # the quantiser forwarders of _Client / Guest / Host (:159-163, :254-264)
+    def quantize(self, weights):
+        if self.quantizer.layer_size_list is None:
+            self.quantizer.set_layer_size_list(weights)
+        return self.quantizer.quantize(weights)
+
+    def normalize(self, weights):
+        if self.quantizer.layer_size_list is None:
+            self.quantizer.set_layer_size_list(weights)
+        return self.quantizer.normalize(weights)
+
+    def unquantize(self, weights):
+        return self.quantizer.unquantize(weights)
+
+    def unnormalize(self, weights):
+        return self.quantizer.unnormalize(weights)
 
     def prepare_encrypt(self):
         if self.precompute:

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -698,6 +699,107 @@ int flashe_decrypt_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, 
         return FLASHE_OK;
     }
     HIP_TRY(ctx, prf_lists(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, 0, n, in_dev, ctx->limbs, out_dev));
+    return FLASHE_OK;
+}
+
+// ---- fused codec: quantise -> encrypt and decrypt -> unquantise in ONE launch each ----
+static int check_codec_bits(flashe_ctx *ctx, int element_bits);
+int flashe_quantize_encrypt_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uint64_t n, uint32_t n_jobs, const void *x_dev,
+                                int x_is_f64, double alpha, int element_bits, const double *u_dev, uint64_t *ct_dev)
+{
+    CHECK_CTX(ctx);
+    if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    if (n && (!x_dev || !u_dev || !ct_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (!(alpha > 0)) return fail(ctx, FLASHE_EINVAL, "alpha must be positive");
+    if (element_bits < 1 || element_bits > 62 || element_bits > ctx->int_bits)
+        return fail(ctx, FLASHE_EINVAL, "element_bits must be in [1, min(62, int_bits)], got %d", element_bits);
+    int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev, nullptr, 0);
+    if (rc) return rc;
+    const Codec cq = codec_quantize_front(x_dev, x_is_f64 != 0, alpha, element_bits, u_dev);
+    LaunchEnv env = ctx->env;
+    env.codec = &cq;
+    const uint32_t add = idx, minus = idx + 1;
+    HIP_TRY(ctx, launch_prf(env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, 0, n, nullptr, 0, ct_dev));
+    return FLASHE_OK;
+}
+
+int flashe_decrypt_unquantize_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                                  uint64_t n, uint32_t n_jobs, const uint64_t *in_dev, double alpha, int element_bits, int num_clients,
+                                  double *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (!(alpha > 0) || num_clients < 1) return fail(ctx, FLASHE_EINVAL, "alpha must be positive and num_clients >= 1");
+    int rc = check_codec_bits(ctx, element_bits);
+    if (rc) return rc;
+    rc = check_prf_args(ctx, n_add, n_minus, n_jobs, in_dev, in_dev, ctx->limbs);
+    if (rc) return rc;
+    if (n == 0) return FLASHE_OK;
+    Codec cq{};
+    codec_unquantize_back(&cq, alpha, element_bits, num_clients, out_dev);
+    if (n_add == 0 && n_minus == 0) {
+        // nothing to unmask: reduce mod 2^b like every decrypt does, then unquantise (two launches; not a shape a round produces)
+        rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, n));
+        if (rc) return rc;
+        uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
+        HIP_TRY(ctx, launch_combine(ctx->env, n, in_dev, ctx->limbs, nullptr, nullptr, tmp));
+        HIP_TRY(ctx, launch_unquantize(ctx->env, n, tmp, ctx->limbs, alpha, element_bits, num_clients, out_dev));
+        return FLASHE_OK;
+    }
+    // lists longer than one launch holds: all but the last group accumulate into ctx scratch, the last launch writes the floats
+    const uint64_t *src = in_dev;
+    int a = 0, m = 0;
+    if (n_add > kMaxIdx || n_minus > kMaxIdx) {
+        rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, n));
+        if (rc) return rc;
+        uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
+        while (n_add - a > kMaxIdx || n_minus - m > kMaxIdx) {
+            const int na = std::min(kMaxIdx, n_add - a), nm = std::min(kMaxIdx, n_minus - m);
+            HIP_TRY(ctx, launch_prf(ctx->env, iter, add_idx + a, na, minus_idx + m, nm, n, n_jobs, 0, n, src, ctx->limbs, tmp));
+            a += na; m += nm; src = tmp;
+        }
+    }
+    LaunchEnv env = ctx->env;
+    env.codec = &cq;
+    HIP_TRY(ctx, launch_prf(env, iter, add_idx + a, n_add - a, minus_idx + m, n_minus - m, n, n_jobs, 0, n, src, ctx->limbs,
+                            const_cast<uint64_t *>(src)));
+    return FLASHE_OK;
+}
+
+// ---- normalise / unnormalise (QuantizingClient.normalize / unnormalize, jzf_quantize.py:542-564) ----
+int flashe_shift_dev(flashe_ctx *ctx, uint64_t n, void *x_dev, int x_is_f64, double shift, int wide)
+{
+    CHECK_CTX(ctx);
+    if (n && !x_dev) return fail(ctx, FLASHE_EINVAL, "null vector");
+    HIP_TRY(ctx, launch_shift(ctx->env, n, x_dev, x_is_f64 != 0, shift, wide != 0));
+    return FLASHE_OK;
+}
+
+int flashe_mean_std_dev(flashe_ctx *ctx, uint64_t n, const void *x_dev, int x_is_f64, double *mean, double *stddev)
+{
+    CHECK_CTX(ctx);
+    if (!mean || !stddev || (n && !x_dev)) return fail(ctx, FLASHE_EINVAL, "null argument");
+    if (n == 0) return fail(ctx, FLASHE_EINVAL, "mean of an empty vector");
+    const int grid = moments_grid(ctx->env, n);
+    int rc = ensure(ctx, ctx->sp_ws, static_cast<size_t>(grid) * sizeof(double));
+    if (rc) return rc;
+    double *part = static_cast<double *>(ctx->sp_ws.p);
+    std::vector<double> host(grid);
+    auto total = [&](double center, int pow, double *out) -> int {
+        HIP_TRY(ctx, launch_moment(ctx->env, n, x_dev, x_is_f64 != 0, center, pow, part));
+        HIP_TRY(ctx, hipMemcpyAsync(host.data(), part, static_cast<size_t>(grid) * sizeof(double), hipMemcpyDeviceToHost, ctx->env.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
+        long double t = 0;
+        for (double v : host) t += v;
+        *out = static_cast<double>(t);
+        return FLASHE_OK;
+    };
+    double s1 = 0, s2 = 0;
+    if ((rc = total(0.0, 1, &s1))) return rc;
+    const double mu = s1 / static_cast<double>(n);
+    if ((rc = total(mu, 2, &s2))) return rc;
+    *mean = mu;
+    *stddev = sqrt(s2 / static_cast<double>(n));
     return FLASHE_OK;
 }
 

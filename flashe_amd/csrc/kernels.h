@@ -8,6 +8,19 @@ namespace flashe {
 // AES-256 expanded key, 60 big-endian words; passed to kernels by value (lands in SGPRs).
 struct RoundKeys { uint32_t w[60]; };
 
+// Optional fused codec of a SINGLE-job PRF launch (the quantiser is the step right before encrypt / after
+// decrypt, jzf_quantize.py:55-67,102-107): front end = the plaintext of element k is the stochastic-rounded quantisation of a
+// float instead of a stored integer; back end = the result is written as the unquantised float64 instead of the integer.
+// Saves the 8-byte integer round trip through HBM on either side.  All-zero = off.
+struct Codec {
+    const void *x;             // front end: float32 / float64 values (null = off)
+    const double *u;           //            one uniform draw in [0, 1) per value
+    double alpha, scale, den;  //            q = floor((clip(x, -alpha, alpha) + alpha) * scale / den + u), computed in x's type
+    int x_is_f64, pad_;
+    double *fout;              // back end: float64 output (null = off)
+    double ac, two_a, uden;    //           out = float(value) * two_a / uden - ac
+};
+
 // Everything a launch needs that is not a per-call argument.
 struct LaunchEnv {
     hipStream_t stream;
@@ -23,6 +36,7 @@ struct LaunchEnv {
     hipStream_t stream2;
     hipEvent_t ev_fork, ev_join;
     int hybrid_bs_permille;
+    const Codec *codec;        // host pointer, null except inside the fused quantise / unquantise entry points (single-job launches)
     uint32_t *err_flag;        // host-mapped word: set to 1 when a sparse kernel skips an out-of-range / out-of-order location
     int use_chain;             // 1 (default): jobs over the same range that share a prefix share the PRF stream (prf_chain_kernel)
 };
@@ -133,6 +147,15 @@ hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uin
                                  const uint64_t *stream_dev, uint64_t *out_dev);
 
 // Quantise / batch codec
+// descriptors for LaunchEnv::codec
+Codec codec_quantize_front(const void *x_dev, bool is_f64, double alpha, int bits, const double *u_dev);
+void codec_unquantize_back(Codec *c, double alpha, int bits, int num_clients, double *out_dev);
+// x <- x + shift in place (normalize / unnormalize, jzf_quantize.py:542-564).  f32 arrays: wide = the add runs in float64 and is
+// rounded once (NumPy's loop for a float64 scalar operand), otherwise in float32
+hipError_t launch_shift(const LaunchEnv &env, uint64_t n, void *x_dev, bool is_f64, double shift, bool wide);
+// partial sums for mean / std: part[g] = sum over block g's elements of (x - center)^pow, pow = 1 or 2, float64; returns the grid size
+int moments_grid(const LaunchEnv &env, uint64_t n);
+hipError_t launch_moment(const LaunchEnv &env, uint64_t n, const void *x_dev, bool is_f64, double center, int pow, double *part_dev);
 hipError_t launch_quantize(const LaunchEnv &env, uint64_t n, const void *x_dev, bool is_f64, double alpha, int bits,
                            const double *u_dev, uint64_t *q_dev);
 hipError_t launch_unquantize(const LaunchEnv &env, uint64_t n, const uint64_t *v_dev, int v_limbs, double alpha, int bits,

@@ -324,6 +324,46 @@ __device__ __forceinline__ void st128_nt(uint64_t *p, u128 v)
     __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(p));
 }
 
+
+// correctly rounded (nearest-even) u128 -> double, as Python's int -> float
+__device__ __forceinline__ double u128_to_double(u128 v)
+{
+    const uint64_t hi = static_cast<uint64_t>(v >> 64), lo = static_cast<uint64_t>(v);
+    if (hi == 0) return static_cast<double>(lo);
+    const int sh = 64 - __clzll(static_cast<long long>(hi));       // 1..64 bits above the low limb
+    uint64_t m = static_cast<uint64_t>(v >> sh);                    // top 64 significant bits
+    const u128 dropped = v & ((static_cast<u128>(1) << sh) - 1);
+    if (dropped) m |= 1;                                            // sticky: 64 > 53 + 2 keeps rounding exact
+    return ldexp(static_cast<double>(m), sh);
+}
+
+// _static_quantize_padding_asymmetric (jzf_quantize.py:55-67) on one value, in the array's own float type; the arithmetic must
+// round exactly like numpy's: no contraction into FMAs
+template <typename T>
+__device__ __forceinline__ uint64_t quantize_one(T v, T alpha, T scale, T den, double u)
+{
+#pragma clang fp contract(off)
+    v = v < -alpha ? -alpha : (v > alpha ? alpha : v);
+    v = v + alpha;
+    v = v * scale;
+    v = v / den;
+    return static_cast<uint64_t>(static_cast<int64_t>(floor(static_cast<double>(v) + u)));
+}
+
+__device__ __forceinline__ uint64_t codec_quantize(const Codec &c, uint64_t k)
+{
+    return c.x_is_f64 ? quantize_one<double>(static_cast<const double *>(c.x)[k], c.alpha, c.scale, c.den, c.u[k])
+                      : quantize_one<float>(static_cast<const float *>(c.x)[k], static_cast<float>(c.alpha), static_cast<float>(c.scale),
+                                            static_cast<float>(c.den), c.u[k]);
+}
+
+// _static_unquantize_padding_asymmetric (jzf_quantize.py:102-107)
+__device__ __forceinline__ double codec_unquantize(const Codec &c, u128 v)
+{
+#pragma clang fp contract(off)
+    return u128_to_double(v) * c.two_a / c.uden - c.ac;
+}
+
 struct IdxLists {
     uint32_t add[kMaxIdx];
     uint32_t minus[kMaxIdx];
@@ -344,6 +384,7 @@ struct PrfParams {
     // b <= 64 only:
     uint32_t n_jobs;
     int b, m;
+    Codec cq;              // optional fused quantise front end / unquantise back end
 };
 
 // ---- b > 64: one element per lane, counter = element index (m = 1 makes chunks irrelevant) ----
@@ -363,7 +404,8 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
         if (e >= p.count) continue;
         const uint64_t j = p.first + e;                 // global element = PRF counter (m = 1)
         u128 acc = 0;
-        if (p.in) acc = p.in_limbs == 2 ? ld128(p.in + 2 * e) : static_cast<u128>(p.in[e]);
+        if (p.cq.x) acc = codec_quantize(p.cq, e);
+        else if (p.in) acc = p.in_limbs == 2 ? ld128(p.in + 2 * e) : static_cast<u128>(p.in[e]);
         {
             int k = 0;
             for (; k + 1 < p.n_add; k += 2) {
@@ -396,7 +438,8 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
                 acc -= words_to_u128(s[0]);
             }
         }
-        st128(p.out + 2 * e, acc & mask);
+        if (p.cq.fout) p.cq.fout[e] = codec_unquantize(p.cq, acc & mask);
+        else st128(p.out + 2 * e, acc & mask);
     }
 }
 
@@ -628,7 +671,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, const ChainTable tb, int n_chains, int all_half,
                                                               uint32_t iter0, uint64_t mask_lo, uint64_t mask_hi,
-                                                              const uint32_t *__restrict__ te0)
+                                                              const uint32_t *__restrict__ te0, const Codec cq)
 {
     const uint32_t iter = iter0 + te0[kIterShiftWord];
     constexpr uint32_t WAVES = THREADS / 64;
@@ -719,7 +762,10 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                         // predicated): otherwise the compiler must assume a load may still be in flight at the loop's back
                         // edge and drains the memory queue -- stores included -- every iteration
                         u128 x0 = 0, x1 = 0;
-                        if (in != nullptr && in2) {
+                        if (cq.x != nullptr && link >= 0) {
+                            if (a0) x0 = codec_quantize(cq, k0);
+                            if (a1) x1 = codec_quantize(cq, k1);
+                        } else if (in != nullptr && in2) {
                             if (a0) x0 = ld128(in + 2 * k0);
                             if (a1) x1 = ld128(in + 2 * k1);
                         } else if (in != nullptr) {
@@ -733,8 +779,13 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                         loads_landed(x0, x1);
                         const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
                         const u128 r0 = x0 + (single ? c0 : pA0 - c0), r1 = x1 + (single ? c1 : pA1 - c1);
-                        if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
-                        if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
+                        if (cq.fout != nullptr) {
+                            if (a0 && link >= 0) cq.fout[k0] = codec_unquantize(cq, r0 & mask);
+                            if (a1 && link >= 0) cq.fout[k1] = codec_unquantize(cq, r1 & mask);
+                        } else {
+                            if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
+                            if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
+                        }
                         pA0 = c0; pA1 = c1;
                     }
                     swap_regs(pA0, pB0); swap_regs(pA1, pB1); swap_regs(vA0, vB0); swap_regs(vA1, vB1);
@@ -752,7 +803,10 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                 const uint64_t *in = link >= 0 ? tb.in[link0 + link] : nullptr;
                 uint64_t *out = link >= 0 ? tb.out[link0 + link] : nullptr;
                 u128 x0 = 0, x1 = 0;
-                if (in != nullptr && in2) {
+                if (cq.x != nullptr && link >= 0) {
+                    if (a0) x0 = codec_quantize(cq, k0);
+                    if (a1) x1 = codec_quantize(cq, k1);
+                } else if (in != nullptr && in2) {
                     if (a0) x0 = ld128(in + 2 * k0);
                     if (a1) x1 = ld128(in + 2 * k1);
                 } else if (in != nullptr) {
@@ -766,8 +820,13 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                 loads_landed(x0, x1);
                 const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
                 const u128 r0 = x0 + (single ? c0 : p0 - c0), r1 = x1 + (single ? c1 : p1 - c1);
-                if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
-                if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
+                if (cq.fout != nullptr) {
+                    if (a0 && link >= 0) cq.fout[k0] = codec_unquantize(cq, r0 & mask);
+                    if (a1 && link >= 0) cq.fout[k1] = codec_unquantize(cq, r1 & mask);
+                } else {
+                    if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
+                    if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
+                }
                 p0 = c0; p1 = c1;
             }
         }
@@ -819,7 +878,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
 #pragma unroll
             for (int u = 0; u < kTch; u++) {
                 const uint64_t j = j0 + t0 + u;
-                acc[u] = (p.in && t0 + u < cnt && j >= p.first && j < range_end) ? p.in[j - p.first] : 0ull;
+                const bool on = t0 + u < cnt && j >= p.first && j < range_end;
+                acc[u] = !on ? 0ull : p.cq.x ? codec_quantize(p.cq, j - p.first) : p.in ? p.in[j - p.first] : 0ull;
             }
             int k = 0;
             for (; k + 1 < p.n_add; k += 2) {
@@ -860,7 +920,10 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
 #pragma unroll
             for (int u = 0; u < kTch; u++) {
                 const uint64_t j = j0 + t0 + u;
-                if (t0 + u < cnt && j >= p.first && j < range_end) p.out[j - p.first] = acc[u] & p.mask_lo;
+                if (t0 + u < cnt && j >= p.first && j < range_end) {
+                    if (p.cq.fout) p.cq.fout[j - p.first] = codec_unquantize(p.cq, acc[u] & p.mask_lo);
+                    else p.out[j - p.first] = acc[u] & p.mask_lo;
+                }
             }
         }
     }
@@ -985,6 +1048,7 @@ struct SmallParams {
     uint64_t top_lo, top_hi;  // the top bit of every b-bit slot of the 128-bit word (SWAR subtraction)
     uint32_t nb1_magic, nb0_magic;   // floor(2^32 / nb1), floor(2^32 / nb0): 32-bit block -> chunk division without a divide
     const uint32_t *te0;
+    Codec cq;                 // optional fused quantise front end / unquantise back end (single-job launches)
 };
 
 // x / dsr for 32-bit operands with magic = floor(2^32 / dsr) (dsr >= 2; dsr == 1 is handled by the caller): the estimate is at most
@@ -1106,8 +1170,9 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
                     if (sh) val |= static_cast<uint64_t>(w[2]) << (64u - sh);
                     const uint64_t j = e0 + x;
                     if (j >= first && j < range_end) {
-                        const uint64_t pt = in ? __builtin_nontemporal_load(in + (j - first)) : 0ull;
-                        __builtin_nontemporal_store((pt + val) & p.mask_lo, out + (j - first));
+                        const uint64_t pt = p.cq.x ? codec_quantize(p.cq, j - first) : in ? __builtin_nontemporal_load(in + (j - first)) : 0ull;
+                        if (p.cq.fout) p.cq.fout[j - first] = codec_unquantize(p.cq, (pt + val) & p.mask_lo);
+                        else __builtin_nontemporal_store((pt + val) & p.mask_lo, out + (j - first));
                     }
                 }
             }
@@ -1117,7 +1182,9 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
                 const uint64_t j = j0 + tt;
                 if (j < first || j >= range_end) continue;
                 const uint64_t val = extract64(D, p.b * tt);
-                out[j - first] = ((in ? in[j - first] : 0ull) + val) & p.mask_lo;
+                const uint64_t pt = p.cq.x ? codec_quantize(p.cq, j - first) : in ? in[j - first] : 0ull;
+                if (p.cq.fout) p.cq.fout[j - first] = codec_unquantize(p.cq, (pt + val) & p.mask_lo);
+                else out[j - first] = (pt + val) & p.mask_lo;
             }
         }
     }
@@ -1169,6 +1236,11 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
                       const uint64_t *in_dev, int in_limbs, uint64_t *out_dev)
 {
     if (count == 0) return hipSuccess;
+    if (env.codec && env.prf_backend != PRF_AUTO && env.prf_backend != PRF_TABLE) {
+        LaunchEnv e2 = env;                  // the fused codec lives in the table kernels
+        e2.prf_backend = PRF_TABLE;
+        return launch_prf(e2, iter, add, n_add, minus, n_minus, n, n_jobs, first, count, in_dev, in_limbs, out_dev);
+    }
     if (env.prf_backend == PRF_HYBRID && env.b > 64 && n_add == 1 && n_minus <= 1 && env.stream2) {
         // split [first, first + count): tail -> bit-sliced kernel on stream2, head -> table kernel here.
         // The bit-sliced share is a whole number of passes of all its waves (1 wave per SIMD).
@@ -1209,6 +1281,7 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
     p.first = first; p.count = count;
     p.in_limbs = in_limbs; p.n_add = n_add; p.n_minus = n_minus; p.n_jobs = n_jobs;
     p.b = env.b; p.m = 128 / env.b;
+    if (env.codec) p.cq = *env.codec;
     masks_of(env.b, &p.mask_lo, &p.mask_hi);
     const bool bs_shape = env.b > 64 && n_add == 1 && n_minus <= 1;
     if (bs_shape && env.prf_backend == PRF_BITSLICE16) {
@@ -1237,7 +1310,7 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
         else
             hipLaunchKernelGGL(prf_wide_bs_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kBsThreads), 0, env.stream,
                                env.rkw_dev, p, lists.add[0], 0u);
-    } else if (bs_shape) {
+    } else if (bs_shape && !(env.codec && (!env.use_chain || ((first + count - 1) >> 32) != (first >> 32)))) {
         const PrfJob job{lists.add[0], lists.minus[0], first, count, in_dev, in_limbs, out_dev};
         return launch_prf_jobs(env, iter, n_minus == 1, 1, &job, n, n_jobs);
     } else if (env.b > 64) {
@@ -1316,6 +1389,10 @@ static hipError_t launch_prf_jobs_small(const LaunchEnv &env, uint32_t iter, boo
     SmallJobTable tb{};
     SmallParams p{};
     p.n = n; p.n_jobs = n_jobs; p.iter = iter; p.b = env.b; p.m = 128 / env.b; p.te0 = env.te0_dev;
+    if (env.codec) {
+        if (n_entries != 1) return hipErrorInvalidValue;
+        p.cq = *env.codec;
+    }
     p.m_magic = static_cast<uint32_t>(((1ull << 32) + p.m - 1) / p.m);
     uint64_t hi;
     masks_of(env.b, &p.mask_lo, &hi);
@@ -1387,6 +1464,7 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
         const hipError_t e = launch_jobs_as_chains(env, iter, dbl, n_entries, jobs);
         if (e != hipErrorNotSupported) return e;
     }
+    if (env.codec && env.b > 64) return hipErrorNotSupported;          // (only the chained kernel and the list kernels carry the codec)
     if (n_entries > kMaxBatch) {
         // the job-table kernels hold kMaxBatch entries per launch: equal shares
         const int launches = (n_entries + kMaxBatch - 1) / kMaxBatch, per = (n_entries + launches - 1) / launches;
@@ -1517,8 +1595,13 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
         const uint64_t items = all_half ? 2 * tiles : tiles, cus = static_cast<uint64_t>(env.num_cus);
         int grid = static_cast<int>(items < cus ? items : cus);
         if (force_grid > 0) grid = force_grid;
+        Codec cq{};
+        if (env.codec) {
+            if (cut.size() != 1 || cut[0].l1 - cut[0].l0 != 1) return hipErrorInvalidValue;      // one job, one output
+            cq = *env.codec;
+        }
         hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc, all_half ? 1 : 0,
-                           iter, lo, hi, env.te0_dev);
+                           iter, lo, hi, env.te0_dev, cq);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -2217,28 +2300,9 @@ template <typename T>
 __global__ __launch_bounds__(kStreamThreads) void quantize_kernel(uint64_t n, const T *x, T alpha, T scale, T den,
                                                                   const double *u, uint64_t *q)
 {
-#pragma clang fp contract(off)
     for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
-         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
-        T v = x[j];
-        v = v < -alpha ? -alpha : (v > alpha ? alpha : v);
-        v = v + alpha;
-        v = v * scale;
-        v = v / den;
-        q[j] = static_cast<uint64_t>(static_cast<int64_t>(floor(static_cast<double>(v) + u[j])));
-    }
-}
-
-// correctly rounded (nearest-even) u128 -> double, as Python's int -> float
-__device__ __forceinline__ double u128_to_double(u128 v)
-{
-    const uint64_t hi = static_cast<uint64_t>(v >> 64), lo = static_cast<uint64_t>(v);
-    if (hi == 0) return static_cast<double>(lo);
-    const int sh = 64 - __clzll(static_cast<long long>(hi));       // 1..64 bits above the low limb
-    uint64_t m = static_cast<uint64_t>(v >> sh);                    // top 64 significant bits
-    const u128 dropped = v & ((static_cast<u128>(1) << sh) - 1);
-    if (dropped) m |= 1;                                            // sticky: 64 > 53 + 2 keeps rounding exact
-    return ldexp(static_cast<double>(m), sh);
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        q[j] = quantize_one<T>(x[j], alpha, scale, den, u[j]);
 }
 
 __global__ __launch_bounds__(kStreamThreads) void unquantize_kernel(uint64_t n, const uint64_t *v, int v_limbs, double ac,
@@ -2281,6 +2345,75 @@ __global__ __launch_bounds__(kStreamThreads) void unbatch_kernel(uint64_t nb, co
             item = field_bits >= 128 ? 0 : item >> field_bits;
         }
     }
+}
+
+Codec codec_quantize_front(const void *x_dev, bool is_f64, double alpha, int bits, const double *u_dev)
+{
+    Codec c{};
+    c.x = x_dev; c.u = u_dev; c.alpha = alpha; c.scale = static_cast<double>((1ull << bits) - 1); c.den = 2 * alpha; c.x_is_f64 = is_f64 ? 1 : 0;
+    return c;
+}
+
+void codec_unquantize_back(Codec *c, double alpha, int bits, int num_clients, double *out_dev)
+{
+    c->fout = out_dev;
+    c->ac = alpha * static_cast<double>(num_clients);
+    c->two_a = 2 * c->ac;
+    c->uden = static_cast<double>(((1ull << bits) - 1) * static_cast<uint64_t>(num_clients));
+}
+
+// x <- x + shift (normalize: shift = -mean, unnormalize: shift = +mean; a - b and a + (-b) round identically)
+template <typename T, bool WIDE>
+__global__ __launch_bounds__(kStreamThreads) void shift_kernel(uint64_t n, T *x, double shift)
+{
+#pragma clang fp contract(off)
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        x[j] = WIDE ? static_cast<T>(static_cast<double>(x[j]) + shift) : x[j] + static_cast<T>(shift);
+}
+
+hipError_t launch_shift(const LaunchEnv &env, uint64_t n, void *x_dev, bool is_f64, double shift, bool wide)
+{
+    if (n == 0) return hipSuccess;
+    const dim3 g(stream_grid(env, n)), t(kStreamThreads);
+    if (is_f64) hipLaunchKernelGGL((shift_kernel<double, false>), g, t, 0, env.stream, n, static_cast<double *>(x_dev), shift);
+    else if (wide) hipLaunchKernelGGL((shift_kernel<float, true>), g, t, 0, env.stream, n, static_cast<float *>(x_dev), shift);
+    else hipLaunchKernelGGL((shift_kernel<float, false>), g, t, 0, env.stream, n, static_cast<float *>(x_dev), shift);
+    return hipGetLastError();
+}
+
+// part[block] = sum over the block's elements of (x - center)^POW in float64: per-thread partial, wave shuffle tree, one LDS hop
+template <typename T, int POW>
+__global__ __launch_bounds__(kStreamThreads) void moment_kernel(uint64_t n, const T *x, double center, double *part)
+{
+    __shared__ double ws[kStreamThreads / 64];
+    double acc = 0;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const double d = static_cast<double>(x[j]) - center;
+        acc += POW == 1 ? d : d * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < kStreamThreads / 64; w++) t += ws[w];
+        part[blockIdx.x] = t;
+    }
+}
+
+int moments_grid(const LaunchEnv &env, uint64_t n) { return stream_grid(env, n); }
+
+hipError_t launch_moment(const LaunchEnv &env, uint64_t n, const void *x_dev, bool is_f64, double center, int pow, double *part_dev)
+{
+    if (n == 0) return hipSuccess;
+    const dim3 g(stream_grid(env, n)), t(kStreamThreads);
+    if (is_f64 && pow == 1) hipLaunchKernelGGL((moment_kernel<double, 1>), g, t, 0, env.stream, n, static_cast<const double *>(x_dev), center, part_dev);
+    else if (is_f64) hipLaunchKernelGGL((moment_kernel<double, 2>), g, t, 0, env.stream, n, static_cast<const double *>(x_dev), center, part_dev);
+    else if (pow == 1) hipLaunchKernelGGL((moment_kernel<float, 1>), g, t, 0, env.stream, n, static_cast<const float *>(x_dev), center, part_dev);
+    else hipLaunchKernelGGL((moment_kernel<float, 2>), g, t, 0, env.stream, n, static_cast<const float *>(x_dev), center, part_dev);
+    return hipGetLastError();
 }
 
 hipError_t launch_quantize(const LaunchEnv &env, uint64_t n, const void *x_dev, bool is_f64, double alpha, int bits,

@@ -454,6 +454,28 @@ class Engine:
     def unbatch_dev(self, n_batches, inp, field_bits, out):
         self._check(self._lib.flashe_unbatch_dev(self._h, n_batches, self._ptr(inp), field_bits, self._ptr(out)))
 
+    def quantize_encrypt_dev(self, it, idx, scheme, n, n_jobs, x, x_is_f64, alpha, element_bits, u, ct):
+        """ct = encrypt(quantize(x)) in one launch (un-batched values); x float32 / float64, u float64 uniforms, all device-resident."""
+        self._check(self._lib.flashe_quantize_encrypt_dev(self._h, it, idx, scheme, n, n_jobs, self._ptr(x), 1 if x_is_f64 else 0,
+                                                          float(alpha), element_bits, self._ptr(u), self._ptr(ct)))
+
+    def decrypt_unquantize_dev(self, it, add_idx, minus_idx, n, n_jobs, inp, alpha, element_bits, num_clients, out):
+        """out (float64) = unquantize(decrypt(inp)) in one launch."""
+        pa, _a = _u32_list(add_idx)
+        pm, _m = _u32_list(minus_idx)
+        self._check(self._lib.flashe_decrypt_unquantize_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, self._ptr(inp),
+                                                            float(alpha), element_bits, num_clients, self._ptr(out)))
+
+    def shift_dev(self, n, x, x_is_f64, shift, wide=False):
+        """x <- x + shift in place (normalize: shift = -mean)."""
+        self._check(self._lib.flashe_shift_dev(self._h, n, self._ptr(x), 1 if x_is_f64 else 0, float(shift), 1 if wide else 0))
+
+    def mean_std_dev(self, n, x, x_is_f64):
+        """(mean, std) of a device vector, float64 two-pass reduction (synchronous)."""
+        m, s = ctypes.c_double(0), ctypes.c_double(0)
+        self._check(self._lib.flashe_mean_std_dev(self._h, n, self._ptr(x), 1 if x_is_f64 else 0, ctypes.byref(m), ctypes.byref(s)))
+        return float(m.value), float(s.value)
+
     def quantize(self, x, alpha, element_bits, u):
         x = np.ascontiguousarray(x)
         if x.dtype not in (np.float32, np.float64):

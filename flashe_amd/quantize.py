@@ -1,6 +1,8 @@
-"""Quantise / batch codec either side of the cipher, on the GPU -- mirrors the four functions the
-FLASHE path uses from federatedml/secureprotol/jzf_quantize.py (QuantizingClient.quantize /
-unquantize, :394-564): same names, arguments and results.
+"""Quantise / batch codec either side of the cipher, on the GPU -- mirrors what the FLASHE path uses from
+federatedml/secureprotol/jzf_quantize.py and jzf_aciq.py: the four static codec functions (:55-67, :102-107,
+:162-185, :234-251), the ACIQ clipping threshold (jzf_aciq.py:10-27) and the transport-free part of
+QuantizingClient (quantize / unquantize / normalize / unnormalize, jzf_quantize.py:394-564): same names,
+arguments and results.
 
 Stochastic rounding: the reference draws its uniforms with ``np.random.random(size)`` (numpy's
 global legacy generator).  The mirror makes the *same* host-side draw and ships the numbers to the
@@ -78,3 +80,152 @@ def _static_unbatching_padding_asymmetric(array, int_bits, element_bits, factor,
             limbs[:, 1] = ((flat >> 64) & m64).astype(np.uint64)
         arr = limbs
     return eng.unbatch(arr, element_bits + factor)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ACIQ clipping threshold and the client-side orchestration
+# ------------------------------------------------------------------------------------------------------------------
+class ACIQ(object):
+    """jzf_aciq.py:4-27: alpha = (optimal clipping multiple for `num_bits`-bit quantisation of a Gaussian) x sigma.  The table is the
+    published ACIQ one as the reference carries it (indices 2..31; more than 31 bits use the last entry)."""
+
+    _ALPHA_GAUS = [None, None, 1.710635, 2.151593, 2.559136, 2.936201, 3.286914, 3.615114,
+                   3.924035, 4.216331, 4.494167, 4.759313, 5.013188, 5.257151, 5.491852, 5.719160,
+                   5.938345, 6.150141, 6.356593, 6.560495, 6.752936, 6.931921, 7.106395, 7.350340,
+                   7.482915, 7.691728, 7.668494, 7.583591, 7.583591, 8.326501, 8.171210, 8.171210]
+
+    def __init__(self, num_bits):
+        self.num_bits = num_bits
+
+    def _alpha_opt(self):
+        return self._ALPHA_GAUS[31] if self.num_bits > 31 else self._ALPHA_GAUS[self.num_bits]
+
+    def get_alpha_gaus(self, min, max, size):                       # jzf_aciq.py:10-19
+        gaussian_const = (0.5 * 0.35) * (1 + (np.pi * np.log(4)) ** 0.5)
+        sigma = ((max - min) * gaussian_const) / ((2 * np.log(size)) ** 0.5)
+        return self._alpha_opt() * sigma
+
+    def get_alpha_gaus_direct(self, sigma):                         # jzf_aciq.py:21-27
+        return self._alpha_opt() * sigma
+
+
+def _loop_dtype(arr_dtype, scalar):
+    """The dtype NumPy computes `array <op> scalar` in -- asked of the running NumPy itself, so a Python float stays weak
+    and a np.float64 scalar promotes a float32 array exactly as it does for the reference on this installation."""
+    return (np.zeros(1, dtype=arr_dtype) + scalar).dtype
+
+
+class QuantizingClient(object):
+    """jzf_quantize.py:336-564 without the federation transport (secure + padding path, which is what every shipped FLASHE job
+    configures): per-layer alpha from the previous global model's std, asymmetric stochastic quantisation (+ batching), and the
+    normalise / unnormalise bookkeeping around it.  `weights` is anything with `.walking_order` and `._weights` (JZFOrderDictWeights'
+    surface).  The arithmetic runs in the HIP kernels; uniforms come from NumPy's global generator exactly as in the reference."""
+
+    def __init__(self, int_bits, from_arbiter=None, to_arbiter=None, batch=False, element_bits=16, padding=True, secure=True, device=0):
+        self.int_bits, self.batch, self.element_bits, self.padding, self.secure = int_bits, batch, element_bits, padding, secure
+        self.from_arbiter, self.to_arbiter = from_arbiter, to_arbiter
+        self.num_clients = None
+        self.iter = 0
+        self.r_max_list = self.alpha_list = self.shape_list = self.layer_size_list = None
+        self.expected_mean_for_first_round = 0.0
+        self.expected_std_for_first_round = 1.0
+        self.past_layer_mean_list, self.past_layer_std_list = [], []
+        self._device = device
+
+    def set_iter(self, iter):
+        self.iter = iter
+
+    def receive_num_clients(self):
+        if self.from_arbiter is not None:
+            self.num_clients = self.from_arbiter.get(idx=0, suffix=(self.iter, 'num_clients'))
+        return self.num_clients
+
+    def set_layer_size_list(self, weights):                          # host, :380-392 (the guest's send_* does the same when secure)
+        self.layer_size_list = [weights._weights[k].size for k in weights.walking_order]
+        for _ in self.layer_size_list:
+            self.past_layer_mean_list.append(self.expected_mean_for_first_round)
+            self.past_layer_std_list.append(self.expected_std_for_first_round)
+
+    send_layer_size_list = set_layer_size_list
+
+    def quantize(self, weights):                                     # :394-491
+        aciq = ACIQ(self.element_bits)
+        alpha_list = []
+        for i, _size in enumerate(self.layer_size_list):
+            alpha = aciq.get_alpha_gaus_direct(self.past_layer_std_list[i])
+            if alpha == 0:
+                alpha = 0.1
+            alpha_list.append(alpha)
+        self.r_max_list, self.alpha_list = [], []
+        if self.batch:
+            self.shape_list = []
+        factor = int(np.ceil(np.log2(self.num_clients)))
+        layer_cnt = 0
+        for k in weights.walking_order:
+            if k == 'zzz':                                           # the sparsifier's trailing layer (:433-435)
+                alpha = 1.0
+            else:
+                alpha = alpha_list[layer_cnt]
+                self.r_max_list.append(alpha * self.num_clients)
+                self.alpha_list.append(alpha)
+            layer = np.asarray(weights._weights[k])
+            shape = layer.shape
+            flat = layer.flatten()
+            if self.batch:
+                self.shape_list.append(shape)
+            want = _loop_dtype(flat.dtype, alpha)                    # the dtype `np.clip(value, -alpha, alpha) + alpha` runs in
+            if flat.dtype != want:
+                flat = flat.astype(want)                             # exact (float32 -> float64)
+            elements = _static_quantize_padding_asymmetric(flat, float(alpha), self.element_bits, device=self._device, as_object=False)
+            if self.batch:
+                weights._weights[k] = _static_batching_padding_asymmetric(elements, self.int_bits, self.element_bits, factor, device=self._device)
+            else:
+                weights._weights[k] = _as_object(elements).reshape(shape)
+            layer_cnt += 1
+        return weights
+
+    def unquantize(self, weights):                                   # :493-540
+        factor = int(np.ceil(np.log2(self.num_clients)))
+        for layer_cnt, k in enumerate(weights.walking_order):
+            alpha = self.alpha_list[layer_cnt]
+            layer = np.asarray(weights._weights[k])
+            flat = layer.flatten()
+            if self.batch:
+                shape = self.shape_list[layer_cnt]
+                size = int(np.prod(shape))
+                flat = _static_unbatching_padding_asymmetric(flat, self.int_bits, self.element_bits, factor, device=self._device)[:size]
+            else:
+                shape = layer.shape
+            ret = _static_unquantize_padding_asymmetric(flat, float(alpha), self.element_bits, self.num_clients, device=self._device)
+            weights._weights[k] = np.asarray(ret, dtype=np.float64).reshape(shape)
+        return weights
+
+    def _shift(self, arr, shift):
+        """arr <- arr + shift with NumPy's in-place semantics (loop dtype from the scalar, result cast back), on the device."""
+        a = np.ascontiguousarray(arr)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        eng = _engine(64, self._device)
+        wide = a.dtype == np.float32 and _loop_dtype(a.dtype, shift) == np.float64
+        d = eng.upload(a.reshape(-1))
+        eng.shift_dev(a.size, d, a.dtype == np.float64, float(shift), wide)
+        return d, a
+
+    def normalize(self, weights):                                    # :542-547
+        for layer_cnt, k in enumerate(weights.walking_order):
+            mean = self.past_layer_mean_list[layer_cnt]
+            d, a = self._shift(weights._weights[k], -mean)
+            weights._weights[k] = d.download(a.dtype, a.size).reshape(a.shape)
+        return weights
+
+    def unnormalize(self, weights):                                  # :549-564
+        eng = _engine(64, self._device)
+        for layer_cnt, k in enumerate(weights.walking_order):
+            d, a = self._shift(weights._weights[k], self.past_layer_mean_list[layer_cnt])
+            mean, std = eng.mean_std_dev(a.size, d, a.dtype == np.float64)
+            weights._weights[k] = d.download(a.dtype, a.size).reshape(a.shape)
+            # np.float64 scalars, as np.mean / np.std leave them in the reference: the scalar's type decides the dtype the next
+            # round's `-=` and clip / scale arithmetic run in (_loop_dtype)
+            self.past_layer_mean_list[layer_cnt] = np.float64(mean)
+            self.past_layer_std_list[layer_cnt] = np.float64(std)
+        return weights

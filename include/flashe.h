@@ -306,6 +306,26 @@ int flashe_sparse_dense_mask(flashe_ctx *ctx, uint32_t iter, int n_lists, const 
                              uint64_t total, uint64_t *out);
 
 /* ---- quantise / batch codec either side of the cipher ------------------ */
+/* Fused forms (new): the quantiser is the step immediately before encrypt and after decrypt (QuantizingClient.quantize ->
+ * JZFWeights.encrypted, decrypted -> unquantize; jzf_quantize.py:394-491, jzf_weights.py:334-338), so one launch does both and the
+ * 8-byte integer never makes a round trip through HBM:
+ *   quantize_encrypt: ct[j] = encrypt(_static_quantize_padding_asymmetric(x, alpha, element_bits)[j]), u_dev = the uniform draws;
+ *   decrypt_unquantize: out[j] = _static_unquantize_padding_asymmetric(decrypt(in)[j], alpha, element_bits, num_clients) as float64.
+ * Bit-identical to the two-call sequences.  Un-batched values only (one quantised value per ciphertext element). */
+int flashe_quantize_encrypt_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uint64_t n, uint32_t n_jobs,
+                                const void *x_dev, int x_is_f64, double alpha, int element_bits, const double *u_dev,
+                                uint64_t *ct_dev);
+int flashe_decrypt_unquantize_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add,
+                                  const uint32_t *minus_idx, int n_minus, uint64_t n, uint32_t n_jobs,
+                                  const uint64_t *in_dev, double alpha, int element_bits, int num_clients, double *out_dev);
+/* QuantizingClient.normalize / unnormalize (jzf_quantize.py:542-564): x <- x + shift in place (normalize passes -mean).  wide: for
+ * float32 arrays the addition runs in float64 and is rounded once -- NumPy's loop when the scalar is a float64 (np.mean / np.std
+ * results), as opposed to a Python float; bit-exact either way.  mean_std: the per-layer statistics unnormalize records for the next
+ * round's alpha, accumulated in float64 by a two-pass parallel reduction; NOT bit-identical to NumPy's summation order (the
+ * reference sums a Python-float object array left to right): agreement is to ~1e-12 relative, tests use 1e-10.  Synchronous. */
+int flashe_shift_dev(flashe_ctx *ctx, uint64_t n, void *x_dev, int x_is_f64, double shift, int wide);
+int flashe_mean_std_dev(flashe_ctx *ctx, uint64_t n, const void *x_dev, int x_is_f64, double *mean, double *stddev);
+
 /* _static_quantize_padding_asymmetric -- federatedml/secureprotol/jzf_quantize.py:55-67:
  * q = floor(clip(x, -alpha, alpha) + alpha) * (2^element_bits - 1) / (2 alpha) + u), with numpy's
  * dtype rules (x_is_f64 == 0: x is float32 and every step before "+ u" is a float32 operation).

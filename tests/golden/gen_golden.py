@@ -541,7 +541,209 @@ def gen_sparsify():
     dump("sparsify.json", {"cases": cases})
 
 
+
+# --------------------------------------------------------------------------- quantiser orchestration (f-1)
+class _Weights:
+    """What QuantizingClient walks (JZFOrderDictWeights surface it touches: walking_order, _weights)."""
+
+    def __init__(self, layers):
+        self.walking_order = sorted(layers)
+        self._weights = dict(layers)
+
+
+def _fhex(a, dtype=None):
+    a = np.asarray(a if dtype is None else np.asarray(a).astype(dtype))
+    return a.tobytes().hex()
+
+
+def gen_quantclient():
+    """ACIQ alpha (jzf_aciq.py:10-27) and QuantizingClient.normalize / quantize / unquantize / unnormalize
+    (jzf_quantize.py:394-564, secure + padding path) driven on a stub weights object, two rounds, so that the per-layer
+    mean / std carried from round to round (-> next round's alpha) is pinned too.  Batched and un-batched."""
+    out = {"aciq": [], "clients": []}
+    for bits in (2, 4, 8, 16, 20, 31, 32, 40):
+        for sigma in (1.0, 0.037, 12.5):
+            a = ACIQ(bits)
+            out["aciq"].append({"bits": bits, "sigma": float(sigma).hex(), "alpha_direct": float(a.get_alpha_gaus_direct(sigma)).hex(),
+                                "min": float(-3.2 * sigma).hex(), "max": float(2.9 * sigma).hex(), "size": 61706,
+                                "alpha_gaus": float(a.get_alpha_gaus(-3.2 * sigma, 2.9 * sigma, 61706)).hex()})
+    for int_bits, eb, C, batch, dtype, sizes, seed in [(64, 32, 2, False, "float32", [(5, 7), (11,)], 1), (128, 16, 10, True, "float32", [(33,), (4, 6), (2,)], 2),
+                                                       (120, 16, 10, True, "float64", [(29,), (40,)], 3), (64, 16, 3, False, "float64", [(50,)], 4)]:
+        rng = np.random.RandomState(seed)
+        qc = RQ.QuantizingClient(int_bits, None, None, batch, eb, True, True)
+        qc.num_clients = C
+        rounds = []
+        for rd in range(2):
+            layers = {f"l{i}": (rng.standard_normal(sh) * (0.5 + i) + 0.1 * rd).astype(dtype) for i, sh in enumerate(sizes)}
+            w = _Weights({k: v.copy() for k, v in layers.items()})
+            if rd == 0:
+                qc.set_layer_size_list(w)
+            past_mean, past_std = list(qc.past_layer_mean_list), list(qc.past_layer_std_list)
+            w = qc.normalize(w)
+            normalized = {k: w._weights[k].copy() for k in w.walking_order}
+            np.random.seed(500 + seed + rd)
+            uniforms = {}
+            st = np.random.get_state()
+            for k in w.walking_order:                                  # the draws quantize() is about to make, layer by layer
+                uniforms[k] = np.random.random(normalized[k].size)
+            np.random.set_state(st)
+            w = qc.quantize(w)
+            quant = {k: [int(v) for v in np.asarray(w._weights[k]).flatten()] for k in w.walking_order}
+            # the arbiter's sum of C uploads: this client's values plus C - 1 deterministic companions in the same range
+            agg = {}
+            for k in w.walking_order:
+                top = (1 << eb) - 1
+                if not batch:
+                    other = [sum(int(rng.randint(0, top + 1)) for _ in range(C - 1)) for _ in quant[k]]
+                    agg[k] = np.array([a + o for a, o in zip(quant[k], other)], dtype=object).reshape(layers[k].shape)
+                else:
+                    factor = int(np.ceil(np.log2(C)))
+                    bs = int_bits // (eb + factor)
+                    other = []
+                    for _ in quant[k]:
+                        t = 0
+                        for _i in range(bs):
+                            t = (t << (eb + factor)) + sum(int(rng.randint(0, top + 1)) for _ in range(C - 1))
+                        other.append(t)
+                    agg[k] = np.array([a + o for a, o in zip(quant[k], other)], dtype=object)
+            w2 = _Weights({k: v.copy() for k, v in agg.items()})
+            w2 = qc.unquantize(w2)
+            unq = {k: np.array([float(v) for v in np.asarray(w2._weights[k]).flatten()], dtype=np.float64) for k in w2.walking_order}
+            w2 = qc.unnormalize(w2)
+            unn = {k: np.array([float(v) for v in np.asarray(w2._weights[k]).flatten()], dtype=np.float64) for k in w2.walking_order}
+            rounds.append({"layers": {k: _fhex(v) for k, v in layers.items()}, "past_mean": [float(v).hex() for v in past_mean],
+                           "past_std": [float(v).hex() for v in past_std], "normalized": {k: _fhex(v) for k, v in normalized.items()},
+                           "uniforms": {k: _fhex(v) for k, v in uniforms.items()}, "alpha": [float(a).hex() for a in qc.alpha_list],
+                           "quantized": {k: hxl(v) for k, v in quant.items()}, "aggregate": {k: hxl(np.asarray(v).flatten()) for k, v in agg.items()},
+                           "unquantized": {k: _fhex(v) for k, v in unq.items()}, "unnormalized": {k: _fhex(v) for k, v in unn.items()},
+                           "new_mean": [float(v).hex() for v in qc.past_layer_mean_list], "new_std": [float(v).hex() for v in qc.past_layer_std_list]})
+        out["clients"].append({"int_bits": int_bits, "element_bits": eb, "num_clients": C, "batch": batch, "dtype": dtype,
+                               "shapes": {f"l{i}": list(sh) for i, sh in enumerate(sizes)}, "rounds": rounds})
+    dump("quantclient.json", out)
+
+
+# --------------------------------------------------------------------------- adapter (a-16, f-4)
+def _import_block():
+    """jzf_flashe_block imports the Diffie-Hellman key exchange, which imports gmpy2 (absent here).  None of the code
+    this generator runs touches it, so the module gets a stub whose names resolve."""
+    gm = types.ModuleType("gmpy2")
+    for nm in ("mpz", "powmod", "invert", "is_prime", "mpz_random", "random_state", "mpz_urandomb", "gcd", "lcm", "bit_length",
+               "next_prime", "iroot", "c_mod", "t_mod", "f_mod", "divm", "isqrt", "mul", "add", "sub"):
+        setattr(gm, nm, lambda *a, **k: None)
+    sys.modules.setdefault("gmpy2", gm)
+    from federatedml.framework.homo.procedure import jzf_flashe_block as RB
+    return RB
+
+
+class _Wire:
+    """Stand-in for a federation transfer variable: records what is sent, replays it on get()."""
+
+    def __init__(self):
+        self.sent = []
+
+    def remote(self, obj=None, **kw):
+        self.sent.append(obj)
+
+    def get(self, **kw):
+        return self.sent[-1]
+
+
+def gen_block():
+    """Arbiter.dynamic_masking's decision (jzf_flashe_block.py:89-117) and the _Client / Host forwarders (:120-174, :278-285)
+    executed from the reference module on stub objects (the transport is a recorder): (1) cost-model cases; (2) a dense
+    double-mask job with precompute over two rounds, the second with a dropout; (3) a sparse job with mask = "dynamic",
+    where the arbiter's hint switches the clients to single masks over compact positions."""
+    RB = _import_block()
+    rng = np.random.RandomState(321)
+    dm = []
+    for total, sets in [(40, [[1, 2, 3], [1, 2, 3], [1, 2, 3]]), (40, [[0, 5], [7, 9], [11]]), (30, [list(range(30))] * 4), (25, [[3, 4, 5, 6]]),
+                        (50, [sorted(rng.choice(50, 20, replace=False).tolist()) for _ in range(5)]), (10, [[], []]),
+                        (64, [sorted(rng.choice(64, 60, replace=False).tolist()) for _ in range(3)])]:
+        g, h = _Wire(), _Wire()
+        stub = types.SimpleNamespace(mask="dynamic", arbiter_to_guest=g, arbiter_to_host=h)
+        RB.Arbiter.dynamic_masking(stub, [list(m) for m in sets], total, (0,))
+        assert g.sent[0]["choice"] == h.sent[0]["choice"] and g.sent[0]["masks"] == [list(m) for m in sets]
+        dm.append({"total": total, "masks": [list(m) for m in sets], "choice": g.sent[0]["choice"]})
+    g = _Wire()
+    assert RB.Arbiter.dynamic_masking(types.SimpleNamespace(mask="double", arbiter_to_guest=g, arbiter_to_host=g), [[1]], 5, (0,)) is None and not g.sent
+
+    def client(b, idx, C, n, mask="double", precompute=True):
+        """What Host.create_cipher leaves behind (:287-326), minus uuid sync and key exchange."""
+        ci = RF.FlasheCipher(b)
+        ci.idx = idx
+        ci.generate_prp_seed(KEY)
+        st = types.SimpleNamespace(cipher=ci, precompute=precompute, mask=mask, num_params=n,
+                                   quantizer=types.SimpleNamespace(set_iter=lambda it: None), arbiter_to_host=None)
+        if precompute:
+            ci.set_num_params(n)
+            ci.prepare_encrypt()
+        ci.set_num_clients(C)
+        return st
+
+    dense = []
+    for b, n, n_jobs, C in [(128, 37, 4, 3), (23, 50, 16, 4)]:
+        RF.N_JOBS = n_jobs
+        mod = 1 << b
+        cls = [client(b, c, C, n) for c in range(C)]
+        rounds = []
+        for it, up in [(0, list(range(C))), (1, [c for c in range(C) if c != 1])]:
+            pts, cts = {}, {}
+            for c in up:
+                RB._Client.set_iter_index(cls[c], it)
+                pts[c] = rand_ints(rng, n, min(b, 64) - 4)
+                had_masks = "add" in cls[c].cipher.next_iter_encrypt_prepared
+                cts[c] = [int(v) for v in RB._Client.encrypt(cls[c], np.array(pts[c], dtype=object))]
+                assert had_masks == (it == 0 or c in rounds[-1]["uploaded"])
+            agg = reduce(lambda x, y: (x + y) % mod, [np.array(cts[c], dtype=object) for c in up])
+            dec = {}
+            for c in up:
+                RB._Client.prepare_decrypt(cls[c])
+                RB._Client.set_idx_list(cls[c], list(up))
+                dec[c] = [int(v) for v in RB._Client.decrypt(cls[c], agg)]
+                RB._Client.prepare_encrypt(cls[c])                    # idle-time precompute for the next round
+            rounds.append({"iter": it, "uploaded": up, "pt": {str(c): hxl(pts[c]) for c in up}, "ct": {str(c): hxl(cts[c]) for c in up},
+                           "agg": hxl(agg), "dec": {str(c): hxl(dec[c]) for c in up},
+                           "roundtrip": dec[up[0]] == [sum(pts[c][j] for c in up) % mod for j in range(n)]})
+        dense.append({"b": b, "n": n, "n_jobs": n_jobs, "num_clients": C, "rounds": rounds})
+    sparse = []
+    for b, total, n_jobs, C, k in [(128, 90, 4, 3, 12), (64, 70, 8, 4, 9)]:
+        RF.N_JOBS = n_jobs
+        mod = 1 << b
+        it = 3
+        masks = [sorted(rng.choice(total, k, replace=False).tolist()) for _ in range(C)]
+        g, h = _Wire(), _Wire()
+        RB.Arbiter.dynamic_masking(types.SimpleNamespace(mask="dynamic", arbiter_to_guest=g, arbiter_to_host=h), masks, total, (it,))
+        cls = [client(b, c, C, k, mask="dynamic", precompute=False) for c in range(C)]
+        pts, ups, zeros = [], [], []
+        for c in range(C):
+            cls[c].arbiter_to_host = h
+            RB._Client.set_iter_index(cls[c], it)
+            RB.Host.dynamic_masking(cls[c], (it,))                  # cipher.masking_scheme / cipher.masks from the hint
+            cls[c].cipher.total = total                              # jzf_aggregator.py:707
+            pt = rand_ints(rng, k, min(b, 64) - 4)
+            pts.append(pt)
+            zero = int(rng.randint(0, 1 << 15))
+            zeros.append(zero)
+            ups.append([int(v) for v in RB._Client.encrypt(cls[c], np.array(pt, dtype=object))] + [zero])
+        dense_vecs = []
+        for c in range(C):                                           # Arbiter.expand_to_dense (jzf_aggregator.py:150-165)
+            e = np.zeros(total, dtype=object)
+            e[masks[c]] = np.array(ups[c][:-1], dtype=object)
+            e[list(set(range(total)) - set(masks[c]))] = ups[c][-1]
+            dense_vecs.append(e)
+        agg = reduce(lambda x, y: (x + y) % mod, dense_vecs)
+        RB._Client.set_idx_list(cls[0], list(range(C)))
+        dec = [int(v) for v in RB._Client.decrypt(cls[0], agg)]
+        sparse.append({"b": b, "total": total, "n_jobs": n_jobs, "num_clients": C, "iter": it, "masks": masks, "choice": h.sent[0]["choice"],
+                       "scheme_after_hint": cls[0].cipher.masking_scheme, "pt": [hxl(p) for p in pts], "zeros": zeros,
+                       "uploads": [hxl(u) for u in ups], "agg": hxl(agg), "dec": hxl(dec)})
+    dump("block.json", {"key": KEY.hex(), "dynamic_masking": dm, "dense_precompute": dense, "sparse_dynamic": sparse})
+
+
+
 if __name__ == "__main__":
+    gen_quantclient()
+    gen_block()
     gen_sparsify()
     gen_codec()
     gen_aes()

@@ -172,3 +172,52 @@ def test_object_array_conversion_handles_negative_and_numpy_scalars():
                 assert int(got[i, 0]) == want & M and (limbs == 1 or int(got[i, 1]) == want >> 64), (vals, limbs, i)
             back = _from_limbs(got, kind)
             assert [int(x) for x in back] == [int(v) & ((1 << (64 * limbs)) - 1) for v in vals]
+
+
+def test_dynamic_masking_and_aciq_against_reference_fixtures():
+    """a-16 / f-1 host logic pinned by the reference itself: tests/golden/block.json holds the decisions of the unmodified
+    Arbiter.dynamic_masking (jzf_flashe_block.py:89-117) run on stub objects, quantclient.json the ACIQ alphas (jzf_aciq.py:10-27)."""
+    from conftest import load_golden
+    from flashe_amd.block import dynamic_masking_choice
+    from flashe_amd.quantize import ACIQ
+    g = load_golden("block.json")
+    assert len(g["dynamic_masking"]) >= 7
+    for c in g["dynamic_masking"]:
+        assert dynamic_masking_choice(c["masks"], c["total"]) == c["choice"], c["total"]
+    for c in g["sparse_dynamic"]:
+        assert dynamic_masking_choice(c["masks"], c["total"]) == c["choice"] == c["scheme_after_hint"]
+    for c in load_golden("quantclient.json")["aciq"]:
+        a = ACIQ(c["bits"])
+        assert float(a.get_alpha_gaus_direct(float.fromhex(c["sigma"]))).hex() == c["alpha_direct"], c
+        assert float(a.get_alpha_gaus(float.fromhex(c["min"]), float.fromhex(c["max"]), c["size"])).hex() == c["alpha_gaus"], c
+
+
+def test_flashe_client_flows_from_reference_fixture(cipher_cls):
+    """f-4: the dense double-mask + precompute job (two rounds, the second with a dropout) recorded from the reference's own
+    _Client forwarders, replayed through FlasheClient on the engine double: same ciphertexts, same decrypts (including the
+    rounds where the reference's unconditional precomputed masks make the result differ from the plaintext sum)."""
+    from conftest import load_golden, unhex
+    from flashe_amd.block import FlasheClient
+    for case in load_golden("block.json")["dense_precompute"]:
+        b, n, C = case["b"], case["n"], case["num_clients"]
+        cm.N_JOBS = case["n_jobs"]
+        args = {"quantize": {"int_bits": b, "batch": False, "element_bits": 16, "padding": True, "secure": True},
+                "precompute": {"enable": True, "num_params": n}}
+        clients = []
+        for c in range(C):
+            cl = FlasheClient(args)
+            cl.create_cipher(c, C, bytes(range(32)))
+            clients.append(cl)
+        for rd in case["rounds"]:
+            up = rd["uploaded"]
+            for c in up:
+                clients[c].set_iter_index(rd["iter"])
+                ct = clients[c].encrypt(np.array(unhex(rd["pt"][str(c)]), dtype=object))
+                assert [int(v) for v in ct] == unhex(rd["ct"][str(c)]), (b, rd["iter"], c)
+            agg = np.array(unhex(rd["agg"]), dtype=object)
+            for c in up:
+                clients[c].prepare_decrypt()
+                clients[c].set_idx_list(list(up))
+                dec = clients[c].decrypt(agg)
+                assert [int(v) for v in dec] == unhex(rd["dec"][str(c)]), (b, rd["iter"], c, "decrypt")
+                clients[c].prepare_encrypt()

@@ -1,0 +1,221 @@
+"""GPU parity tests of the rows either side of the cipher: the quantiser orchestration and its fusion into encrypt / decrypt
+(SURVEY.md 8 f-1), and the adapter that drives the cipher (a-16, f-4).  Expected values: fixtures recorded from the unmodified
+reference (tests/golden/quantclient.json, block.json, config1.npz) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden, unhex
+
+pytestmark = pytest.mark.gpu
+
+KEY = bytes(range(32))
+
+
+@pytest.fixture(scope="module")
+def E():
+    from flashe_amd import engine
+    return engine
+
+
+class _Weights:
+    def __init__(self, layers):
+        self.walking_order = sorted(layers)
+        self._weights = dict(layers)
+
+
+def _arr(hexstr, dtype, shape=None):
+    a = np.frombuffer(bytes.fromhex(hexstr), dtype=dtype).copy()
+    return a if shape is None else a.reshape(shape)
+
+
+# ------------------------------------------------------------------------------------------------ f-1: orchestration
+def test_quantizing_client_against_reference_fixture():
+    """QuantizingClient.normalize -> quantize -> (arbiter) -> unquantize -> unnormalize, two rounds, every intermediate equal to
+    what the reference produced with the same NumPy draws: bit-exact for everything element-wise (floats compared as bytes), and
+    the per-layer mean / std -- a float64 reduction whose summation order differs from NumPy's -- to 1e-10 relative."""
+    from flashe_amd.quantize import QuantizingClient
+    g = load_golden("quantclient.json")
+    assert len(g["clients"]) == 4
+    for case in g["clients"]:
+        dt = np.dtype(case["dtype"])
+        qc = QuantizingClient(case["int_bits"], None, None, case["batch"], case["element_bits"], True, True)
+        qc.num_clients = case["num_clients"]
+        for rd_i, rd in enumerate(case["rounds"]):
+            layers = {k: _arr(v, dt, case["shapes"][k]) for k, v in rd["layers"].items()}
+            w = _Weights({k: v.copy() for k, v in layers.items()})
+            if rd_i == 0:
+                qc.set_layer_size_list(w)
+            # every stage is checked from the reference's own state of the previous stage (the statistics carried between
+            # rounds agree only to rounding, and one ulp of alpha may move a value across a rounding boundary)
+            # (types as the reference leaves them: Python floats before the first round, np.float64 scalars -- np.mean / np.std
+            # results -- afterwards; the type decides the dtype NumPy's next `-=` and clip arithmetic run in)
+            cast = np.float64 if rd_i else float
+            qc.past_layer_mean_list = [cast(float.fromhex(v)) for v in rd["past_mean"]]
+            qc.past_layer_std_list = [cast(float.fromhex(v)) for v in rd["past_std"]]
+            w = qc.normalize(w)
+            for k in w.walking_order:
+                assert np.asarray(w._weights[k]).tobytes() == bytes.fromhex(rd["normalized"][k]), (case["int_bits"], rd_i, k, "normalize")
+            seed_state = None
+            # the reference drew np.random.random(size) layer by layer inside quantize(): feed the same stream
+            draws = np.concatenate([_arr(rd["uniforms"][k], np.float64) for k in w.walking_order])
+            pos = [0]
+
+            def fake_random(shape):
+                size = int(np.prod(shape))
+                out = draws[pos[0]:pos[0] + size].reshape(shape)
+                pos[0] += size
+                return out
+            orig = np.random.random
+            np.random.random = fake_random
+            try:
+                w = qc.quantize(w)
+            finally:
+                np.random.random = orig
+            assert [float(a).hex() for a in qc.alpha_list] == rd["alpha"]
+            for k in w.walking_order:
+                assert [int(v) for v in np.asarray(w._weights[k]).flatten()] == unhex(rd["quantized"][k]), (case["int_bits"], rd_i, k, "quantize")
+            shapes = case["shapes"]
+            agg = {k: np.array(unhex(rd["aggregate"][k]), dtype=object) for k in w.walking_order}
+            if not case["batch"]:
+                agg = {k: v.reshape(shapes[k]) for k, v in agg.items()}
+            w2 = qc.unquantize(_Weights(agg))
+            for k in w2.walking_order:
+                assert np.asarray(w2._weights[k], dtype=np.float64).tobytes() == bytes.fromhex(rd["unquantized"][k]), (rd_i, k, "unquantize")
+            w2 = qc.unnormalize(w2)
+            for k in w2.walking_order:
+                assert np.asarray(w2._weights[k], dtype=np.float64).tobytes() == bytes.fromhex(rd["unnormalized"][k]), (rd_i, k, "unnormalize")
+            for got, want in zip(qc.past_layer_mean_list, rd["new_mean"]):
+                assert got == pytest.approx(float.fromhex(want), rel=1e-10, abs=1e-13)
+            for got, want in zip(qc.past_layer_std_list, rd["new_std"]):
+                assert got == pytest.approx(float.fromhex(want), rel=1e-10, abs=1e-13)
+            del seed_state
+
+
+def test_mean_std_large_vector_vs_numpy(E):
+    """flashe_mean_std_dev at ResNet-50 size, float32 and float64, against NumPy's float64 statistics (tolerance 1e-10 relative)."""
+    eng = E.Engine(KEY, 64, device=0)
+    for dt in (np.float32, np.float64):
+        x = (np.random.RandomState(3).standard_normal(25_557_032) * 0.37 + 0.011).astype(dt)
+        d = eng.upload(x)
+        mean, std = eng.mean_std_dev(x.size, d, dt == np.float64)
+        x64 = x.astype(np.float64)
+        assert mean == pytest.approx(float(np.mean(x64)), rel=1e-10, abs=1e-14)
+        assert std == pytest.approx(float(np.std(x64)), rel=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------ f-1: fusion
+@pytest.mark.parametrize("b,scheme,n,J,dtype,eb", [(64, "single", 10_000, 8, np.float32, 32), (128, "double", 70_001, 16, np.float32, 16),
+                                                    (128, "double", 1_300_003, 16, np.float64, 32), (20, "double", 9_999, 7, np.float32, 16),
+                                                    (100, "single", 4_099, 3, np.float64, 20), (64, "double", 250_000, 16, np.float32, 8)])
+def test_fused_quantize_encrypt_and_decrypt_unquantize(E, oracle, b, scheme, n, J, dtype, eb):
+    """quantise -> encrypt in ONE launch and decrypt -> unquantise in ONE launch, bit-identical to the separate calls and to
+    the oracle's quantise + encrypt; prefix lists of every shape on the decrypt side (none, one pair, dropouts, > 96 entries)."""
+    from flashe_amd.quantize import ACIQ
+    eng = E.Engine(KEY, b, device=0)
+    L = 2 if b > 64 else 1
+    rng = np.random.RandomState(n)
+    x = (rng.standard_normal(n) * 1.3).astype(dtype)
+    x[:3] = [0.0, 1e9, -1e9]
+    u = rng.random_sample(n)
+    alpha = ACIQ(eb).get_alpha_gaus_direct(1.0)
+    sch = E.SCHEME_DOUBLE if scheme == "double" else E.SCHEME_SINGLE
+    dx, du, dct = eng.upload(x), eng.upload(u), eng.alloc_vec(n)
+    eng.quantize_encrypt_dev(5, 3, sch, n, J, dx, dtype == np.float64, alpha, eb, du, dct)
+    ct = dct.download(np.uint64, n * L).reshape(n, L)
+    q = oracle.quantize(x, alpha, eb, u)
+    assert np.array_equal(q, eng.quantize(x, alpha, eb, u))
+    assert np.array_equal(ct, oracle.encrypt(KEY, 5, 3, scheme, J, b, q)), "fused quantise + encrypt"
+    # decrypt side: an aggregate of C such uploads, every list shape
+    C = 4
+    agg = np.zeros((n, L), dtype=np.uint64)
+    agg[:, 0] = rng.randint(0, 2 ** 31, n).astype(np.uint64) * np.uint64(C)
+    dagg, dout = eng.upload(agg), eng.alloc(8 * n)
+    for add_idx, minus_idx in [([C], [0]), ([], list(range(C))), ([2, 4], [0, 3]), ([], []), (list(range(200, 330)), list(range(5, 105)))]:
+        eng.decrypt_unquantize_dev(5, add_idx, minus_idx, n, J, dagg, alpha, eb, C, dout)
+        got = dout.download(np.float64, n)
+        dec = oracle.decrypt(KEY, 5, add_idx, minus_idx, J, b, agg)
+        want = oracle.unquantize(dec, alpha, eb, C)
+        assert got.tobytes() == want.tobytes(), (b, len(add_idx), len(minus_idx))
+        assert np.array_equal(dagg.download(np.uint64, n * L).reshape(n, L), agg), "the fused decrypt must not modify its input"
+
+
+def test_config1_one_launch_per_side(E):
+    """BASELINE config 1 end to end with ONE launch on each side of the arbiter: fp32 -> [quantise + encrypt] -> aggregate ->
+    [decrypt + unquantise], every stage equal to the fixture recorded from the reference (same MT19937 draws)."""
+    z = np.load(os.path.join(GOLDEN, "config1.npz"))
+    n, b, J, alpha = 10000, 64, 8, float(z["alpha"])
+    eng = E.Engine(KEY, b, device=0)
+    dcts = []
+    for c in range(2):
+        np.random.seed(7 + c)
+        u = np.random.random(n)                                   # the draw _static_quantize_padding_asymmetric makes
+        dct = eng.alloc_vec(n)
+        eng.quantize_encrypt_dev(0, c, E.SCHEME_SINGLE, n, J, eng.upload(z[f"x{c}"]), False, alpha, 32, eng.upload(u), dct)
+        assert np.array_equal(dct.download(np.uint64, n), z[f"ct{c}"]), c
+        dcts.append(dct)
+    dagg, dout = eng.alloc_vec(n), eng.alloc(8 * n)
+    eng.aggregate_elem_dev(dcts, n, dagg)
+    assert np.array_equal(dagg.download(np.uint64, n), z["agg_elem"])
+    eng.decrypt_unquantize_dev(0, [], [0, 1], n, J, dagg, alpha, 32, 2, dout)
+    assert dout.download(np.float64, n).tobytes() == z["unq_elem"].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------ a-16 / f-4: the adapter
+def test_flashe_client_on_the_device_against_reference_fixture():
+    """FlasheClient (the transport-free _Client mirror) on the HIP engine, replaying the jobs recorded from the reference's own
+    forwarders: dense double mask + precompute over two rounds (the second with a dropout), and a sparse job where the arbiter's
+    dynamic-masking hint switches the clients to single masks over compact positions."""
+    from flashe_amd import cipher as cm
+    from flashe_amd.block import FlasheClient, dynamic_masking_choice
+    g = load_golden("block.json")
+    for case in g["dense_precompute"]:
+        b, n, C = case["b"], case["n"], case["num_clients"]
+        cm.N_JOBS = case["n_jobs"]
+        args = {"quantize": {"int_bits": b, "batch": False, "element_bits": 16, "padding": True, "secure": True},
+                "precompute": {"enable": True, "num_params": n}}
+        clients = []
+        for c in range(C):
+            cl = FlasheClient(args)
+            cl.create_cipher(c, C, KEY)
+            assert "add" in cl.cipher.next_iter_encrypt_prepared
+            clients.append(cl)
+        for rd in case["rounds"]:
+            up = rd["uploaded"]
+            for c in up:
+                clients[c].set_iter_index(rd["iter"])
+                ct = clients[c].encrypt(np.array(unhex(rd["pt"][str(c)]), dtype=object))
+                assert [int(v) for v in ct] == unhex(rd["ct"][str(c)]), (b, rd["iter"], c)
+            agg = clients[up[0]].cipher.aggregate([np.array(unhex(rd["ct"][str(c)]), dtype=object) for c in up])
+            assert [int(v) for v in agg] == unhex(rd["agg"])
+            for c in up:
+                clients[c].prepare_decrypt()
+                clients[c].set_idx_list(list(up))
+                dec = clients[c].decrypt(agg)
+                assert [int(v) for v in dec] == unhex(rd["dec"][str(c)]), (b, rd["iter"], c, "decrypt")
+                clients[c].prepare_encrypt()
+    for case in g["sparse_dynamic"]:
+        b, total, C, it = case["b"], case["total"], case["num_clients"], case["iter"]
+        cm.N_JOBS = case["n_jobs"]
+        args = {"quantize": {"int_bits": b, "batch": False, "element_bits": 16, "padding": True, "secure": True},
+                "precompute": {"enable": False}, "mask": "dynamic"}
+        choice = dynamic_masking_choice(case["masks"], total)
+        assert choice == case["choice"]
+        uploads = []
+        clients = []
+        for c in range(C):
+            cl = FlasheClient(args)
+            cl.create_cipher(c, C, KEY)
+            cl.set_iter_index(it)
+            cl.dynamic_masking(choice, case["masks"])
+            assert cl.cipher.masking_scheme == case["scheme_after_hint"]
+            cl.cipher.total = total
+            ct = cl.encrypt(np.array(unhex(case["pt"][c]), dtype=object))
+            assert [int(v) for v in ct] + [case["zeros"][c]] == unhex(case["uploads"][c]), (b, c)
+            uploads.append(ct)
+            clients.append(cl)
+        agg = np.array(unhex(case["agg"]), dtype=object)
+        clients[0].set_idx_list(list(range(C)))
+        dec = clients[0].decrypt(agg)
+        assert [int(v) for v in dec] == unhex(case["dec"]), b
