@@ -34,6 +34,26 @@ __all__ = ["FlasheCipher", "aggregate", "N_JOBS"]
 
 
 # ------------------------------------------------------------------------------ conversions
+def _load_pyconv():
+    """flashe_amd/_pyconv.so (csrc/pyconv.c): object array <-> limbs through the CPython API, 4-6x NumPy's astype().  Host-side
+    format conversion only; when it is not built the NumPy path below gives the same arrays."""
+    import ctypes
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pyconv.so")
+    if not os.path.exists(path) or os.environ.get("FLASHE_NO_PYCONV"):
+        return None
+    try:
+        lib = ctypes.PyDLL(path)
+        for fn in (lib.flashe_pyconv_ints_to_limbs, lib.flashe_pyconv_limbs_to_ints):
+            fn.restype = ctypes.c_int
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_ssize_t, ctypes.c_int, ctypes.c_void_p]
+        return lib
+    except (OSError, AttributeError):
+        return None
+
+
+_PYCONV = _load_pyconv()
+
+
 def _to_limbs(value, limbs):
     """ndarray (object ints | uint64) -> (uint64 [n, k] array, kind) with k in {1, limbs}."""
     if value.dtype == object:
@@ -41,6 +61,11 @@ def _to_limbs(value, limbs):
             value = value.reshape(-1)
         n = value.shape[0]
         out = np.empty((n, limbs), dtype=np.uint64)
+        if n and _PYCONV is not None:
+            src = np.ascontiguousarray(value)
+            # raises the Python error the conversion hit (TypeError for a non-integer element, as int() would)
+            _PYCONV.flashe_pyconv_ints_to_limbs(src.ctypes.data, n, limbs, out.ctypes.data)
+            return out, "object"
         if n:
             try:
                 # the usual case -- non-negative values below 2**64 -- converts in C loops.  A negative value must NOT take
@@ -77,6 +102,12 @@ def _to_limbs(value, limbs):
 
 
 def _from_limbs(arr, kind):
+    if kind == "object" and _PYCONV is not None:
+        src = np.ascontiguousarray(arr, dtype=np.uint64)
+        out = np.empty(src.shape[0], dtype=object)
+        if src.shape[0]:
+            _PYCONV.flashe_pyconv_limbs_to_ints(src.ctypes.data, src.shape[0], src.shape[1], out.ctypes.data)
+        return out
     if kind == "object":
         out = arr[:, 0].astype(object)
         if arr.shape[1] == 2:
@@ -396,22 +427,32 @@ def aggregate(ciphertexts, int_bits, packed=False, device=0, _engine=None):
     if len(ciphertexts) == 0:
         raise TypeError("reduce() of empty sequence with no initial value")
     eng = _engine or Engine(bytes(32), int_bits, device=device)
-    conv = [_to_limbs(np.asarray(c) if not isinstance(c, np.ndarray) else c, eng.limbs) for c in ciphertexts]
+    # an operand passed several times (the notebook's `[ct] * num_clients`) is converted and uploaded once
+    seen, conv = {}, []
+    for c in ciphertexts:
+        if id(c) not in seen:
+            a, k = _to_limbs(np.asarray(c) if not isinstance(c, np.ndarray) else c, eng.limbs)
+            if a.shape[1] != eng.limbs:
+                a = np.concatenate([a, np.zeros((a.shape[0], eng.limbs - a.shape[1]), dtype=np.uint64)], axis=1)
+            seen[id(c)] = (a, k)
+        conv.append(seen[id(c)])
     kind = conv[0][1]
-    arrs = []
-    for a, _k in conv:
-        if a.shape[1] != eng.limbs:
-            a = np.concatenate([a, np.zeros((a.shape[0], eng.limbs - a.shape[1]), dtype=np.uint64)], axis=1)
-        arrs.append(a)
+    arrs = [a for a, _k in conv]
     n = arrs[0].shape[0]
     if any(a.shape[0] != n for a in arrs):
         raise ValueError("operands could not be broadcast together")
+    dev = {}
+    for a in arrs:
+        if id(a) not in dev:
+            dev[id(a)] = eng.upload(a)
+    dsrc = [dev[id(a)] for a in arrs]
     if not packed:
-        out = eng.aggregate_elem(arrs)
+        dsum = eng.alloc_vec(n)
+        eng.aggregate_elem_dev(dsrc, n, dsum)
+        out = dsum.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
     else:
         total_bits = n * int_bits
         n_limbs = (total_bits + 63) // 64
-        dsrc = [eng.upload(a) for a in arrs]
         dpk = [eng.alloc(max(n_limbs * 8, 16)) for _ in arrs]
         for s, p in zip(dsrc, dpk):
             eng.pack_dev(n, s, p)

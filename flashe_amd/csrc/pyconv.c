@@ -1,0 +1,96 @@
+/* Host-side converter between the reference's data convention -- 1-D numpy object arrays of Python ints
+ * (jzf_flashe.py:480-481 computes on those) -- and the engine's little-endian uint64 limb arrays.  NumPy's own
+ * astype() goes through the generic number protocol (~65 ns per element); reading the ints directly is 4-6x faster,
+ * which is what the class-level API (FlasheCipher.encrypt / decrypt / aggregate on object arrays) is bound by.
+ *
+ * Built as flashe_amd/_pyconv.so and loaded with ctypes.PyDLL (the GIL is held during the calls); it links nothing:
+ * the CPython symbols come from the running interpreter.  No arithmetic of the cipher happens here. */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include <string.h>
+
+/* value mod 2^(64 * limbs) of any Python int (negative values wrap like Python's `&`), two's complement */
+static int int_to_limbs(PyObject *o, int limbs, uint64_t *out)
+{
+    if (!PyLong_Check(o)) {                       /* numpy integer scalars held in the object array, bools, ... */
+        PyObject *idx = PyNumber_Index(o);
+        if (!idx) return -1;
+        int rc = int_to_limbs(idx, limbs, out);
+        Py_DECREF(idx);
+        return rc;
+    }
+    int overflow = 0;
+    long long v = PyLong_AsLongLongAndOverflow(o, &overflow);
+    if (!overflow) {
+        if (v == -1 && PyErr_Occurred()) return -1;
+        out[0] = (uint64_t)v;
+        if (limbs == 2) out[1] = v < 0 ? ~0ull : 0ull;
+        return 0;
+    }
+    /* beyond int64: the low 64 * limbs bits of the two's complement representation */
+    unsigned char buf[17];
+    size_t nbits = _PyLong_NumBits(o);
+    if (nbits == (size_t)-1 && PyErr_Occurred()) return -1;
+    if (nbits < 128) {
+        if (_PyLong_AsByteArray((PyLongObject *)o, buf, 17, 1, 1) < 0) return -1;
+        memcpy(&out[0], buf, 8);
+        if (limbs == 2) memcpy(&out[1], buf + 8, 8);
+        return 0;
+    }
+    /* wider than the modulus: mask in Python, then convert */
+    PyObject *mask = PyLong_FromString(limbs == 2 ? "ffffffffffffffffffffffffffffffff" : "ffffffffffffffff", NULL, 16);
+    if (!mask) return -1;
+    PyObject *low = PyNumber_And(o, mask);
+    Py_DECREF(mask);
+    if (!low) return -1;
+    int rc = _PyLong_AsByteArray((PyLongObject *)low, buf, 17, 1, 0);
+    Py_DECREF(low);
+    if (rc < 0) return -1;
+    memcpy(&out[0], buf, 8);
+    if (limbs == 2) memcpy(&out[1], buf + 8, 8);
+    return 0;
+}
+
+/* objs: the data of a 1-D numpy object array (n borrowed references); out: [n][limbs].  0 = ok, -1 = Python error set. */
+int flashe_pyconv_ints_to_limbs(PyObject **objs, Py_ssize_t n, int limbs, uint64_t *out)
+{
+    if (limbs != 1 && limbs != 2) { PyErr_SetString(PyExc_ValueError, "limbs must be 1 or 2"); return -1; }
+    for (Py_ssize_t i = 0; i < n; i++) {
+        /* the ints live wherever the allocator put them: the pointer array tells us where the NEXT ones are, so fetch ahead
+         * (this loop is otherwise one cache miss per element) */
+        if (i + 16 < n) __builtin_prefetch(objs[i + 16], 0, 0);
+        PyObject *o = objs[i];
+        uint64_t *dst = out + (size_t)i * limbs;
+        if (PyLong_CheckExact(o)) {
+            /* one- and two-digit non-negative ints (< 2^60): read the digits in place */
+            const Py_ssize_t sz = Py_SIZE(o);
+            const digit *d = ((PyLongObject *)o)->ob_digit;
+            if (sz == 1 || sz == 0 || sz == 2) {
+                dst[0] = sz == 0 ? 0 : sz == 1 ? (uint64_t)d[0] : ((uint64_t)d[0] | ((uint64_t)d[1] << PyLong_SHIFT));
+                if (limbs == 2) dst[1] = 0;
+                continue;
+            }
+        }
+        if (int_to_limbs(o, limbs, dst) < 0) return -1;
+    }
+    return 0;
+}
+
+/* in: [n][limbs]; objs: the data of a 1-D numpy object array whose n slots hold owned references (np.empty(n, object) holds None):
+ * each slot is replaced by a new int. */
+int flashe_pyconv_limbs_to_ints(const uint64_t *in, Py_ssize_t n, int limbs, PyObject **objs)
+{
+    if (limbs != 1 && limbs != 2) { PyErr_SetString(PyExc_ValueError, "limbs must be 1 or 2"); return -1; }
+    for (Py_ssize_t i = 0; i < n; i++) {
+        const uint64_t *p = in + (size_t)i * limbs;
+        PyObject *v;
+        if (limbs == 1 || p[1] == 0) v = PyLong_FromUnsignedLongLong(p[0]);
+        else v = _PyLong_FromByteArray((const unsigned char *)p, 16, 1, 0);
+        if (!v) return -1;
+        PyObject *old = objs[i];
+        objs[i] = v;
+        Py_XDECREF(old);
+    }
+    return 0;
+}

@@ -60,6 +60,9 @@ class OracleEngine:
         return orc.aggregate_elem(cts, self.int_bits)
 
     # device API on FakeBufs
+    def aggregate_elem_dev(self, cts, n, out):
+        out.arr = orc.aggregate_elem([np.ascontiguousarray(c.arr).reshape(n, self.limbs) for c in cts], self.int_bits)
+
     def mask_dev(self, it, idx_list, n, n_jobs, out):
         out.arr = orc.mask_sum(self.key, it, idx_list, n, n_jobs, self.int_bits)
 
