@@ -70,7 +70,14 @@ def config3(out):
         eng.graph_begin()
         round_calls()
         graph = eng.graph_end()
-        t_graph = timeit(eng, graph.launch)
+        # every replay is a NEW round: iter shift r makes the captured calls run with iter + r (kernel arguments are frozen into
+        # a graph, the shift is read from device memory), so the replayed rounds never reuse a mask stream
+        shift = [0]
+
+        def replay():
+            shift[0] += 1
+            graph.launch(iter_shift=shift[0])
+        t_graph = timeit(eng, replay)
         t_calls = timeit(eng, round_calls)
         graph.launch()
         assert np.array_equal(dout.download(np.uint64, n * L).reshape(n, L), got2)
