@@ -639,7 +639,8 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
     }
     // equal shares when several launches are needed (b <= 64, 100 vectors: 4 x 25, not 32 + 32 + 32 + 4); 2-limb vectors
     // travel in the compact table, up to 128 per launch
-    const int cap = ctx->limbs == 2 ? kMaxUniformBatch : kMaxBatch;
+    // (the chained launch holds 128 outputs for every int_bits; without it the b <= 64 job table holds kMaxBatch)
+    const int cap = (ctx->limbs == 2 || ctx->env.use_chain) ? kMaxUniformBatch : kMaxBatch;
     const int per_launch = n_vec ? (n_vec + (n_vec + cap - 1) / cap - 1) / ((n_vec + cap - 1) / cap) : 1;
     for (int v0 = 0; v0 < n_vec; v0 += per_launch) {
         const int nv = std::min(per_launch, n_vec - v0);

@@ -83,7 +83,8 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
 // (idx[c + 1] = idx[c] + 1, jzf_flashe.py:349-353) cost n_out + 1 streams instead of 2 n_out; a plain (add, minus) job is a chain
 // of one output.  single == true: n_out prefixes, out[c] = in[c] + term(idx[c]).  idx, in_dev, out_dev are HOST arrays; in_dev (or
 // an entry of it) may be null = zeros; device pointers address element `first`.  Returns hipErrorNotSupported when a chain cannot
-// take this path (int_bits <= 64, a range that straddles a 2^32 counter boundary): the caller then uses launch_prf_jobs.
+// take this path (a range that straddles a 2^32 counter boundary; int_bits <= 64: a vector of 2^32 elements or more, a fused codec):
+// the caller then uses the job-table kernels.  n, n_jobs: the whole vector's length and chunking (int_bits <= 64 counters).
 struct PrfChain {
     const uint32_t *idx;
     int n_out;
@@ -93,7 +94,7 @@ struct PrfChain {
     int in_limbs;
     uint64_t *const *out_dev;
 };
-hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains);
+hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs);
 
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
                           const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev);

@@ -669,7 +669,7 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 }
 
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, const ChainTable tb, int n_chains, int all_half,
+__global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, const ChainTable tb, int n_chains, int all_half_arg,
                                                               uint32_t iter0, uint64_t mask_lo, uint64_t mask_hi,
                                                               const uint32_t *__restrict__ te0, const Codec cq)
 {
@@ -678,7 +678,9 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
     __shared__ uint32_t tab[kTabWords];
     __shared__ __attribute__((aligned(16))) uint32_t pre_lds[(kMaxLinks + kMaxChains) * 4];
     __shared__ uint64_t d_tlo[kMaxChains], d_cend[kMaxChains];
+    int all_half = all_half_arg;
     fill_tables(tab, te0);
+    if (all_half & 0x100) return;                  // timing probes of the prologue (FLASHE_CHAIN_TUNE / FLASHE_CHAIN_PROBE only)
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
     {
@@ -722,6 +724,8 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
         }
         __syncthreads();
     }
+    if (all_half & 0x200) return;
+    all_half &= 1;
     const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t Ng = uniform64(d_cend[n_chains - 1]);
@@ -1190,6 +1194,209 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
     }
 }
 
+// ---- b <= 64, chained: consecutive clients share their streams (see prf_chain_kernel) ----
+// A lane owns AES block(s) of the vector for ALL streams of its chain: the chunk arithmetic is done once per tile, the four
+// counter-dependent lookups of round 1 once per block (they do not depend on the prefix), and per stream the lane runs one
+// block (PAIR = false) or two blocks software pipelined on the same prefix (PAIR = true: blocks L and L + 64 of a 128-block
+// tile).  Per output the slot-wise difference of the previous and the current stream goes through the per-wave LDS rows and
+// the wave walks its 64 * m consecutive elements lane-contiguously, exactly like prf_small_jobs_kernel.
+struct SmallChainTable {
+    uint64_t first[kMaxChains], count[kMaxChains];           // element range of the chain (global indices)
+    uint64_t blk_first[kMaxChains], blk_count[kMaxChains];   // AES blocks intersecting it (global block numbering)
+    uint64_t wend[kMaxChains];                               // running total of tiles x streams
+    uint16_t link0[kMaxChains], sbase[kMaxChains];
+    uint8_t len[kMaxChains], flags[kMaxChains];              // bit 0: SINGLE
+    uint32_t idx[kMaxLinks + kMaxChains];
+    const uint64_t *in[kMaxLinks];
+    uint64_t *out[kMaxLinks];
+};
+
+// block B of the vector (global block numbering) -> first element j0, elements in the block cnt, PRF counter (n < 2^32)
+__device__ __forceinline__ void small_block_params(uint32_t B32, uint32_t nb1_32, uint32_t nb0_32, uint32_t d32, uint32_t r32, uint32_t m,
+                                                   const SmallParams &p, uint64_t *j0, int *cnt, uint32_t *ctr)
+{
+    uint32_t begin, len, i;
+    if (B32 < r32 * nb1_32) {
+        const uint32_t c = nb1_32 == 1 ? B32 : udiv_magic(B32, nb1_32, p.nb1_magic);
+        i = B32 - c * nb1_32; begin = c * (d32 + 1u); len = d32 + 1u;
+    } else {
+        const uint32_t B2 = B32 - r32 * nb1_32, c = nb0_32 == 1 ? B2 : udiv_magic(B2, nb0_32, p.nb0_magic);
+        i = B2 - c * nb0_32; begin = r32 * (d32 + 1u) + c * d32; len = d32;
+    }
+    const uint32_t rem = len - i * m;
+    *j0 = static_cast<uint64_t>(begin) + static_cast<uint64_t>(i) * m;
+    *cnt = static_cast<int>(rem < m ? rem : m);
+    *ctr = begin + i;
+}
+
+// The wave's 64 blocks hold D (16 bytes per lane, b-bit slots): out[j] = (in[j] + slot) mod 2^b for every element of the tile
+// that lies in [first, range_end), coalesced whenever the tile has at most one partial block (a chunk end).
+__device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool valid, int cnt, uint64_t j0, u128 D, const uint64_t *in,
+                                           uint64_t *out, uint64_t first, uint64_t range_end, const SmallParams &p)
+{
+    const uint64_t valid_mask = __ballot(valid), partial_mask = __ballot(valid && cnt < p.m);
+    if (__popcll(partial_mask) <= 1) {
+        *reinterpret_cast<uint4 *>(row0 + 4 * lane) = make_uint4(static_cast<uint32_t>(D), static_cast<uint32_t>(D >> 32),
+                                                                 static_cast<uint32_t>(D >> 64), static_cast<uint32_t>(D >> 96));
+        __builtin_amdgcn_wave_barrier();
+        const int n_valid = __popcll(valid_mask);
+        const int P = partial_mask ? static_cast<int>(__ffsll(static_cast<unsigned long long>(partial_mask))) - 1 : -1;
+        const uint32_t j0_lo = static_cast<uint32_t>(j0), j0_hi = static_cast<uint32_t>(j0 >> 32);
+#pragma unroll 1
+        for (int run = 0; run < 2; run++) {
+            const int lane_base = run == 0 ? 0 : P + 1;
+            if (run == 1 && (P < 0 || lane_base >= n_valid)) break;
+            const uint64_t e0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_lo, lane_base)) |
+                                (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_hi, lane_base))) << 32);
+            const uint32_t n_elems = run == 0 ? (P >= 0 ? static_cast<uint32_t>(P) * p.m + static_cast<uint32_t>(__builtin_amdgcn_readlane(cnt, P))
+                                                        : static_cast<uint32_t>(n_valid) * p.m)
+                                              : static_cast<uint32_t>(n_valid - lane_base) * p.m;
+            for (uint32_t x = lane; x < n_elems; x += 64u) {
+                const uint32_t blk = static_cast<uint32_t>((static_cast<uint64_t>(x) * p.m_magic) >> 32);
+                const uint32_t o = static_cast<uint32_t>(p.b) * (x - blk * static_cast<uint32_t>(p.m));
+                const uint32_t *w = row0 + 4 * (lane_base + blk) + (o >> 5);
+                const uint32_t sh = o & 31u;
+                uint64_t val = ((static_cast<uint64_t>(w[1]) << 32) | w[0]) >> sh;
+                if (sh) val |= static_cast<uint64_t>(w[2]) << (64u - sh);
+                const uint64_t j = e0 + x;
+                if (j >= first && j < range_end) {
+                    const uint64_t pt = in ? __builtin_nontemporal_load(in + (j - first)) : 0ull;
+                    __builtin_nontemporal_store((pt + val) & p.mask_lo, out + (j - first));
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (valid) {
+        for (int tt = 0; tt < cnt; tt++) {
+            const uint64_t j = j0 + tt;
+            if (j < first || j >= range_end) continue;
+            const uint64_t val = extract64(D, p.b * tt);
+            out[j - first] = ((in ? in[j - first] : 0ull) + val) & p.mask_lo;
+        }
+    }
+}
+
+template <bool PAIR>
+__global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const RoundKeys rk, const SmallChainTable tb, int n_chains, const SmallParams p)
+{
+    constexpr uint32_t WAVES = kSmallThreads / 64, TILE = PAIR ? 128u : 64u;
+    __shared__ uint32_t tab[kTabWords];
+    __shared__ uint32_t scratch[(kSmallThreads / 64) * 256 + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t pre_lds[(kMaxLinks + kMaxChains) * 4];
+    __shared__ uint64_t d_tlo[kMaxChains], d_cend[kMaxChains];
+    const uint32_t iter = p.iter + p.te0[kIterShiftWord];
+    fill_tables(tab, p.te0);
+    const LaneRegs lr = lane_regs(tab);
+    {
+        const int last = n_chains - 1;
+        const int n_streams = tb.sbase[last] + tb.len[last] + ((tb.flags[last] & 1) ? 0 : 1);
+        for (int s = threadIdx.x; s < n_streams; s += kSmallThreads) {
+            const CtrPrefix c = ctr_prefix(rk, lr, iter, tb.idx[s], 0u);          // n < 2^32 (host-checked): the high counter word is 0
+            *reinterpret_cast<uint4 *>(pre_lds + 4 * s) = make_uint4(c.u[0], c.u[1], c.u[2], c.u[3]);
+        }
+        if (threadIdx.x < static_cast<unsigned>(n_chains)) {                          // this workgroup's tiles of every chain (see prf_chain_kernel)
+            const int i = threadIdx.x;
+            const uint64_t Wt = tb.wend[last], cw = i ? tb.wend[i - 1] : 0;
+            const uint32_t w = tb.len[i] + ((tb.flags[i] & 1) ? 0u : 1u);
+            uint64_t a, b, T;
+            if (Wt <= 0xffffffffull && gridDim.x <= 0xffffu) {
+                const uint32_t W32 = static_cast<uint32_t>(Wt), G = gridDim.x, g = blockIdx.x, c32 = static_cast<uint32_t>(cw);
+                const uint32_t q = W32 / G, r = W32 % G;
+                const uint32_t lo = q * g + r * g / G, hi = q * (g + 1) + r * (g + 1) / G;
+                T = (static_cast<uint32_t>(tb.wend[i]) - c32) / w;
+                a = lo > c32 ? (lo - c32 + w - 1) / w : 0; b = hi > c32 ? (hi - c32 + w - 1) / w : 0;
+            } else {
+                const uint64_t G = gridDim.x, g = blockIdx.x;
+                const uint64_t lo = Wt / G * g + (Wt % G) * g / G, hi = Wt / G * (g + 1) + (Wt % G) * (g + 1) / G;
+                T = (tb.wend[i] - cw) / w;
+                a = lo > cw ? (lo - cw + w - 1) / w : 0; b = hi > cw ? (hi - cw + w - 1) / w : 0;
+            }
+            if (a > T) a = T;
+            if (b > T) b = T;
+            d_tlo[i] = a; d_cend[i] = b - a;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t acc = 0;
+            for (int i = 0; i < n_chains; i++) { acc += d_cend[i]; d_cend[i] = acc; }
+        }
+        __syncthreads();
+    }
+    const uint64_t J = p.n_jobs, d = p.n / J, r = p.n % J, m64 = static_cast<uint64_t>(p.m);
+    const uint32_t nb1_32 = static_cast<uint32_t>((d + 1 + m64 - 1) / m64), nb0_32 = static_cast<uint32_t>(d ? (d + m64 - 1) / m64 : 0);
+    const uint32_t d32 = static_cast<uint32_t>(d), r32 = static_cast<uint32_t>(r), m32 = static_cast<uint32_t>(p.m);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    uint32_t *row0 = scratch + wave * 256;
+    const u128 top = (static_cast<u128>(p.top_hi) << 64) | p.top_lo;
+    const uint64_t Ng = uniform64(d_cend[n_chains - 1]);
+    int cur = 0;
+    uint64_t cbeg = 0;
+    for (uint64_t q = wave; q < Ng; q += WAVES) {
+        while (q >= uniform64(d_cend[cur])) cbeg = uniform64(d_cend[cur++]);
+        const uint64_t first = tb.first[cur], range_end = first + tb.count[cur], blk_count = tb.blk_count[cur];
+        const uint64_t Bw = (uniform64(d_tlo[cur]) + (q - cbeg)) * TILE;             // the tile's first block (chain-local)
+        const int link0 = tb.link0[cur], sbase = tb.sbase[cur];
+        const bool single = tb.flags[cur] & 1;
+        const int n_streams = tb.len[cur] + (single ? 0 : 1);
+        // per-lane block(s): chunk arithmetic and the counter-dependent quarter of round 1, once for all streams
+        const bool vA = Bw + lane < blk_count, vB = PAIR && Bw + 64u + lane < blk_count;
+        uint64_t j0A = 0, j0B = 0;
+        int cntA = 0, cntB = 0;
+        uint32_t ctrA = 0, ctrB = 0;
+        small_block_params(static_cast<uint32_t>(tb.blk_first[cur] + (vA ? Bw + lane : 0)), nb1_32, nb0_32, d32, r32, m32, p, &j0A, &cntA, &ctrA);
+        if (PAIR) small_block_params(static_cast<uint32_t>(tb.blk_first[cur] + (vB ? Bw + 64u + lane : 0)), nb1_32, nb0_32, d32, r32, m32, p, &j0B, &cntB, &ctrB);
+        const CtrVar xA = ctr_var(rk, lr, ctrA);
+        CtrVar xB{};
+        if (PAIR) xB = ctr_var(rk, lr, ctrB);
+        u128 prevA = 0, prevB = 0;
+        if (PAIR) {
+            // two blocks per lane on the same prefix, one stream per step
+            for (int c = 0; c < n_streams; c++) {
+                const CtrPrefix pre = load_prefix(pre_lds, sbase + c);
+                uint32_t s[2][4];
+                ctr_round1(pre, xA, s[0]);
+                ctr_round1(pre, xB, s[1]);
+                aes256_rounds<2, 2>(rk, lr, s);
+                const u128 SA = words_to_u128(s[0]), SB = words_to_u128(s[1]);
+                const int link = single ? c : c - 1;
+                if (link >= 0) {
+                    const uint64_t *in = tb.in[link0 + link];
+                    uint64_t *out = tb.out[link0 + link];
+                    // per slot (previous - current) mod 2^b: the previous stream is this client's add stream, the current its minus stream
+                    const u128 DA = single ? SA : ((prevA | top) - (SA & ~top)) ^ ((prevA ^ ~SA) & top);
+                    const u128 DB = single ? SB : ((prevB | top) - (SB & ~top)) ^ ((prevB ^ ~SB) & top);
+                    small_walk(row0, lane, vA, cntA, j0A, DA, in, out, first, range_end, p);
+                    small_walk(row0, lane, vB, cntB, j0B, DB, in, out, first, range_end, p);
+                }
+                prevA = SA; prevB = SB;
+            }
+        } else {
+            // one block per lane, TWO STREAMS per step (short launches: half the dependent AES depth per wave; an odd stream count
+            // computes its last stream twice)
+            for (int c = 0; c < n_streams; c += 2) {
+                const bool has1 = c + 1 < n_streams;
+                const CtrPrefix pre0 = load_prefix(pre_lds, sbase + c), pre1 = load_prefix(pre_lds, sbase + (has1 ? c + 1 : c));
+                uint32_t s[2][4];
+                ctr_round1(pre0, xA, s[0]);
+                ctr_round1(pre1, xA, s[1]);
+                aes256_rounds<2, 2>(rk, lr, s);
+                const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
+                const int l0 = single ? c : c - 1;
+                if (l0 >= 0) {
+                    const u128 D = single ? S0 : ((prevA | top) - (S0 & ~top)) ^ ((prevA ^ ~S0) & top);
+                    small_walk(row0, lane, vA, cntA, j0A, D, tb.in[link0 + l0], tb.out[link0 + l0], first, range_end, p);
+                }
+                if (has1) {
+                    const u128 D = single ? S1 : ((S0 | top) - (S1 & ~top)) ^ ((S0 ^ ~S1) & top);
+                    small_walk(row0, lane, vA, cntA, j0A, D, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, range_end, p);
+                }
+                prevA = has1 ? S1 : S0;
+            }
+        }
+    }
+}
+
 // Known-answer helper: raw AES of nblk blocks given as big-endian words.
 __global__ __launch_bounds__(kPrfThreads) void aes_blocks_kernel(const RoundKeys rk, const uint32_t *te0, uint32_t nblk,
                                                                  const uint32_t *in, uint32_t *out)
@@ -1332,8 +1539,8 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
                             const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n, uint32_t n_jobs)
 {
     if (n == 0 || n_vec == 0) return hipSuccess;
-    if (n_vec > (env.b > 64 ? kMaxUniform : kMaxBatch)) return hipErrorInvalidValue;
-    if (env.b > 64 && env.use_chain) {
+    if (n_vec > ((env.b > 64 || env.use_chain) ? kMaxUniform : kMaxBatch)) return hipErrorInvalidValue;
+    if (env.use_chain) {
         // runs of consecutive clients share their streams (double mask); single mask: one stream per vector
         std::vector<uint32_t> sidx;
         std::vector<PrfChain> chains;
@@ -1348,7 +1555,7 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
             v = w;
         }
         for (size_t c = 0; c < chains.size(); c++) chains[c].idx = sidx.data() + starts[c];
-        const hipError_t e = launch_prf_chains(env, iter, static_cast<int>(chains.size()), chains.data());
+        const hipError_t e = launch_prf_chains(env, iter, static_cast<int>(chains.size()), chains.data(), n, n_jobs);
         if (e != hipErrorNotSupported) return e;
     }
     if (env.b > 64 && n_vec > kMaxBatch) {
@@ -1376,10 +1583,12 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
                                env.rk, tb, n_vec, n, iter, lo, hi, env.te0_dev);
         return hipGetLastError();
     }
-    PrfJob jobs[kMaxBatch];
+    std::vector<PrfJob> jobs(n_vec);
     for (int v = 0; v < n_vec; v++)
         jobs[v] = PrfJob{idx[v], idx[v] + 1u, 0, n, in_dev[v], in_limbs, out_dev[v]};
-    return launch_prf_jobs(env, iter, dbl, n_vec, jobs, n, n_jobs);
+    LaunchEnv e2 = env;
+    e2.use_chain = 0;                        // the chained form was tried above
+    return launch_prf_jobs(e2, iter, dbl, n_vec, jobs.data(), n, n_jobs);
 }
 
 // b <= 64 form of launch_prf_jobs
@@ -1427,9 +1636,9 @@ static hipError_t launch_prf_jobs_small(const LaunchEnv &env, uint32_t iter, boo
 
 // Jobs -> chains: neighbours over the same element range are linked when the minus prefix of one is the add prefix of the
 // next (double mask), or simply collected (single mask).  hipErrorNotSupported = use the job-table kernel.
-static hipError_t launch_jobs_as_chains(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs)
+static hipError_t launch_jobs_as_chains(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n, uint32_t n_jobs)
 {
-    if (!env.use_chain || env.b <= 64) return hipErrorNotSupported;
+    if (!env.use_chain) return hipErrorNotSupported;
     struct Build { std::vector<uint32_t> idx; std::vector<const uint64_t *> in; std::vector<uint64_t *> out; uint64_t first, count; int in_limbs; };
     std::vector<Build> bs;
     for (int e = 0; e < n_entries; e++) {
@@ -1454,14 +1663,14 @@ static hipError_t launch_jobs_as_chains(const LaunchEnv &env, uint32_t iter, boo
     std::vector<PrfChain> chains;
     for (const Build &b : bs)
         chains.push_back(PrfChain{b.idx.data(), static_cast<int>(b.out.size()), !dbl, b.first, b.count, b.in.data(), b.in_limbs ? b.in_limbs : 1, b.out.data()});
-    return launch_prf_chains(env, iter, static_cast<int>(chains.size()), chains.data());
+    return launch_prf_chains(env, iter, static_cast<int>(chains.size()), chains.data(), n, n_jobs);
 }
 
 hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n, uint32_t n_jobs)
 {
-    if (env.b > 64) {
+    {
         // any number of entries: neighbours that share a prefix are linked across the whole list
-        const hipError_t e = launch_jobs_as_chains(env, iter, dbl, n_entries, jobs);
+        const hipError_t e = launch_jobs_as_chains(env, iter, dbl, n_entries, jobs, n, n_jobs);
         if (e != hipErrorNotSupported) return e;
     }
     if (env.codec && env.b > 64) return hipErrorNotSupported;          // (only the chained kernel and the list kernels carry the codec)
@@ -1525,9 +1734,11 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
 
 // Chained launch (b > 64): see prf_chain_kernel.  Long chains are cut where the per-launch tables end (the stream at a
 // cut is computed by both pieces); short launches are cut further so that every wave of the chip gets an item.
-hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains)
+static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs);
+
+hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs)
 {
-    if (env.b <= 64) return hipErrorNotSupported;
+    if (env.b <= 64) return launch_small_chains(env, iter, n_chains, chains, n, n_jobs);
     struct Piece { const PrfChain *ch; int l0, l1; uint64_t tiles; };
     std::vector<Piece> pieces;
     uint64_t total_tiles = 0;
@@ -1544,11 +1755,12 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
     bool all_half = total_tiles < 2 * waves;
     // experiment knobs (tests/perf/sweep_chain.py), read per launch only when FLASHE_CHAIN_TUNE is set
     static const bool tune = getenv("FLASHE_CHAIN_TUNE") != nullptr;
-    int force_parts = 0, force_grid = 0;
+    int force_parts = 0, force_grid = 0, probe = 0;
     if (tune) {
         if (const char *e = getenv("FLASHE_CHAIN_HALF")) all_half = atoi(e) != 0;
         if (const char *e = getenv("FLASHE_CHAIN_PARTS")) force_parts = atoi(e);
         if (const char *e = getenv("FLASHE_CHAIN_GRID")) force_grid = atoi(e);
+        if (const char *e = getenv("FLASHE_CHAIN_PROBE")) probe = atoi(e) == 1 ? 0x100 : atoi(e) == 2 ? 0x200 : 0;
     }
     // cut: (1) table limits, (2) parallelism of short launches (never below 4 outputs per piece: a cut costs one stream)
     std::vector<Piece> cut;
@@ -1600,8 +1812,93 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
             if (cut.size() != 1 || cut[0].l1 - cut[0].l0 != 1) return hipErrorInvalidValue;      // one job, one output
             cq = *env.codec;
         }
-        hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc, all_half ? 1 : 0,
+        hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc, (all_half ? 1 : 0) | probe,
                            iter, lo, hi, env.te0_dev, cq);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// b <= 64 form of launch_prf_chains.  hipErrorNotSupported (-> job-table kernel) for what this kernel does not carry: a fused
+// codec, vectors of 2^32 elements or more.
+static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs)
+{
+    if (env.codec || n >= (1ull << 32) || n == 0) return hipErrorNotSupported;
+    SmallParams p{};
+    p.n = n; p.n_jobs = n_jobs; p.iter = iter; p.b = env.b; p.m = 128 / env.b; p.te0 = env.te0_dev;
+    p.m_magic = static_cast<uint32_t>(((1ull << 32) + p.m - 1) / p.m);
+    uint64_t hi;
+    masks_of(env.b, &p.mask_lo, &hi);
+    unsigned __int128 top = 0;
+    for (int t = 0; t < p.m; t++) top |= static_cast<unsigned __int128>(1) << (env.b * t + env.b - 1);
+    p.top_lo = static_cast<uint64_t>(top); p.top_hi = static_cast<uint64_t>(top >> 64);
+    {
+        const uint64_t mm = p.m, d = n / n_jobs, nb1 = (d + 1 + mm - 1) / mm, nb0 = d ? (d + mm - 1) / mm : 0;
+        p.nb1_magic = nb1 > 1 && nb1 < (1ull << 32) ? static_cast<uint32_t>((1ull << 32) / nb1) : 0;
+        p.nb0_magic = nb0 > 1 && nb0 < (1ull << 32) ? static_cast<uint32_t>((1ull << 32) / nb0) : 0;
+    }
+    struct Piece { const PrfChain *ch; int l0, l1; uint64_t blk_first, blk_count; };
+    std::vector<Piece> pieces;
+    uint64_t total_blocks = 0;
+    for (int i = 0; i < n_chains; i++) {
+        const PrfChain &c = chains[i];
+        if (c.count == 0 || c.n_out == 0) continue;
+        if (c.in_dev && c.in_limbs != 1) return hipErrorInvalidValue;
+        const uint64_t bf = block_of(c.first, n, n_jobs, p.m), bc = block_of(c.first + c.count - 1, n, n_jobs, p.m) - bf + 1;
+        pieces.push_back(Piece{&c, 0, c.n_out, bf, bc});
+        total_blocks += bc;
+    }
+    if (pieces.empty()) return hipSuccess;
+    const uint64_t waves = static_cast<uint64_t>(env.num_cus) * (kSmallThreads / 64);
+    // two blocks per lane (software pipelined) once every wave has work for several such tiles; short launches run one block per
+    // lane and cut long chains so that more waves take part (a cut costs one stream)
+    const bool pair = total_blocks >= 2 * 128 * waves;
+    const uint64_t tile = pair ? 128 : 64;
+    uint64_t total_tiles = 0;
+    for (const Piece &pc : pieces) total_tiles += (pc.blk_count + tile - 1) / tile;
+    std::vector<Piece> cut;
+    for (const Piece &pc : pieces) {
+        int parts = (pc.l1 + kMaxLinks - 1) / kMaxLinks;
+        if (total_tiles < waves) {
+            // an underfilled chip is latency bound: parallelism first, down to one output (= one stream pair) per piece
+            const uint64_t want = waves / total_tiles;
+            parts = std::max<int>(parts, static_cast<int>(std::min<uint64_t>(want, static_cast<uint64_t>(pc.l1))));
+            parts = std::min(parts, std::max(1, kMaxChains / static_cast<int>(pieces.size())));
+            parts = std::max(parts, (pc.l1 + kMaxLinks - 1) / kMaxLinks);
+        }
+        for (int k = 0; k < parts; k++) {
+            const int a = static_cast<int>(static_cast<int64_t>(pc.l1) * k / parts), b = static_cast<int>(static_cast<int64_t>(pc.l1) * (k + 1) / parts);
+            if (b > a) cut.push_back(Piece{pc.ch, a, b, pc.blk_first, pc.blk_count});
+        }
+    }
+    size_t at = 0;
+    while (at < cut.size()) {
+        SmallChainTable tb{};
+        int nc = 0, links = 0, streams = 0;
+        uint64_t wend = 0, tiles = 0;
+        while (at < cut.size() && nc < kMaxChains && links + (cut[at].l1 - cut[at].l0) <= kMaxLinks) {
+            const Piece &pc = cut[at++];
+            const PrfChain &c = *pc.ch;
+            const int len = pc.l1 - pc.l0, ns = len + (c.single ? 0 : 1);
+            tb.first[nc] = c.first; tb.count[nc] = c.count; tb.blk_first[nc] = pc.blk_first; tb.blk_count[nc] = pc.blk_count;
+            tb.link0[nc] = static_cast<uint16_t>(links); tb.sbase[nc] = static_cast<uint16_t>(streams);
+            tb.len[nc] = static_cast<uint8_t>(len); tb.flags[nc] = static_cast<uint8_t>(c.single ? 1 : 0);
+            for (int q = 0; q < ns; q++) tb.idx[streams + q] = c.idx[pc.l0 + q];
+            for (int l = 0; l < len; l++) {
+                tb.in[links + l] = c.in_dev ? c.in_dev[pc.l0 + l] : nullptr;
+                tb.out[links + l] = c.out_dev[pc.l0 + l];
+            }
+            const uint64_t t = (pc.blk_count + tile - 1) / tile;
+            wend += t * static_cast<uint64_t>(ns);
+            tb.wend[nc] = wend;
+            tiles += t;
+            links += len; streams += ns; nc++;
+        }
+        const uint64_t cus = static_cast<uint64_t>(env.num_cus);
+        const int grid = static_cast<int>(tiles < cus ? tiles : cus);
+        if (pair) hipLaunchKernelGGL(prf_small_chain_kernel<true>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+        else hipLaunchKernelGGL(prf_small_chain_kernel<false>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

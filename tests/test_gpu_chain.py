@@ -42,6 +42,56 @@ def test_chain_batch_vs_oracle(E, oracle, b, n, idx):
             assert np.array_equal(got, oracle.encrypt(KEY, 13, idx[v], name, 16, b, pts[v])), (b, n, name, v)
 
 
+@pytest.mark.parametrize("b,n,J,idx", [
+    (64, 100_003, 16, list(range(10))),                    # one block per lane, chain of ten
+    (64, 2_300_017, 16, list(range(7, 12))),               # two blocks per lane (software pipelined pairs)
+    (23, 61_706, 16, list(range(100))),                    # BASELINE config 3 at the reference-style int_bits: chain of 100, cut for parallelism
+    (20, 7_000_001, 7, [3, 4, 5]),                         # m = 6, ragged chunks, pair mode
+    (8, 300_000, 16, [5, 6, 7, 20, 21, 9]),                # m = 16; runs broken by non-consecutive prefixes
+    (33, 4099, 3, list(range(130))),                       # more outputs than one launch table holds
+    (1, 5000, 5, [0, 1]), (64, 1, 1, [0, 1, 2]), (7, 41, 16, [2 ** 32 - 3, 2 ** 32 - 2]),      # n < n_jobs: empty chunks
+])
+def test_small_chain_batch_vs_oracle(E, oracle, b, n, J, idx):
+    """int_bits <= 64 (m = 128 // b elements per AES block, chunk-dependent counters): the chained launch against the oracle's
+    per-client encrypts, double and single mask."""
+    eng = E.Engine(KEY, b, device=0)
+    rng = np.random.Generator(np.random.PCG64(n + b))
+    pts = [rng.integers(0, 2 ** min(b, 63), n, dtype=np.uint64) for _ in idx]
+    dpt = [eng.upload(p) for p in pts]
+    dct = [eng.alloc_vec(n) for _ in idx]
+    for scheme, name in ((E.SCHEME_DOUBLE, "double"), (E.SCHEME_SINGLE, "single")):
+        eng.encrypt_batch_dev(13, idx, scheme, n, J, dpt, 1, dct)
+        step = 1 if len(idx) <= 12 else 9
+        for v in list(range(0, len(idx), step)) + [len(idx) - 1]:
+            got = dct[v].download(np.uint64, n).reshape(n, 1)
+            assert np.array_equal(got, oracle.encrypt(KEY, 13, idx[v], name, J, b, pts[v])), (b, n, name, v)
+
+
+def test_small_chain_ranges_and_mask_precompute(E, oracle):
+    """Chained job lists over ragged element ranges of a chunked vector (block-misaligned first / last elements), with and
+    without input, b = 23 and b = 64."""
+    for b, n, J in [(23, 61_706, 16), (64, 50_001, 8)]:
+        eng = E.Engine(KEY, b, device=0)
+        rng = np.random.Generator(np.random.PCG64(b))
+        pt = rng.integers(0, 2 ** 20, n, dtype=np.uint64)
+        dpt = eng.upload(pt)
+        masks = {i: oracle.mask(KEY, 9, i, n, J, b) for i in range(6)}
+        first, count = 1237, n - 3001
+        outs = [eng.alloc_vec(n) for _ in range(6)]
+        jobs = [(c, c + 1, first, count, dpt.ptr + 8 * first, 1, outs[c]) for c in range(3)]         # a chain 0-1-2-3 on a ragged range
+        jobs += [(c, c + 1, 0, n, None, 0, outs[c]) for c in range(3, 5)]                            # mask precompute chain 3-4-5
+        jobs.append((5, 0, 17, 1000, dpt.ptr + 8 * 17, 1, outs[5]))                                  # an unrelated job
+        eng.prf_jobs_dev(9, n, J, jobs)
+        ptl = pt.reshape(n, 1)
+        z = np.zeros((n, 1), dtype=np.uint64)
+        for c in range(3):
+            want = oracle.combine(b, ptl[first:first + count], masks[c][first:first + count], masks[c + 1][first:first + count])
+            assert np.array_equal(outs[c].download(np.uint64, count).reshape(count, 1), want), (b, c)
+        for c in range(3, 5):
+            assert np.array_equal(outs[c].download(np.uint64, n).reshape(n, 1), oracle.combine(b, z, masks[c], masks[c + 1])), (b, c)
+        assert np.array_equal(outs[5].download(np.uint64, 1000).reshape(1000, 1), oracle.combine(b, ptl[17:1017], masks[5][17:1017], masks[0][17:1017])), b
+
+
 def test_chain_two_limb_inputs_and_no_input(E, oracle):
     """16-byte plaintext containers (in_limbs = 2) and bare mask differences (in = NULL) through chained job lists."""
     b, n, it = 128, 70_001, 4
