@@ -831,17 +831,22 @@ def test_config2_full_size_round(E, oracle):
     pts = [np.random.Generator(np.random.PCG64(1000 + c)).integers(0, 2 ** 64, n, dtype=np.uint64) for c in range(C)]
     dpt = [eng.upload(p) for p in pts]
     dct = [eng.alloc_vec(n) for _ in range(C)]
-    for c in range(C):
-        eng.encrypt_dev(it, c, E.SCHEME_DOUBLE, n, 16, dpt[c], 1, dct[c])
+    # what bench.py runs: ONE chained launch for the ten clients (11 shared PRF streams instead of 20)
+    eng.encrypt_batch_dev(it, list(range(C)), E.SCHEME_DOUBLE, n, 16, dpt, 1, dct)
     dagg, dout = eng.alloc_vec(n), eng.alloc_vec(n)
     eng.aggregate_elem_dev(dct, n, dagg)
     eng.decrypt_dev(it, [C], [0], n, 16, dagg, dout)
     out = dout.download(np.uint64, 2 * n).reshape(n, 2)
     lo, hi = _sum_u64(pts)
     assert np.array_equal(out[:, 0], lo) and np.array_equal(out[:, 1], hi)
-    # one client in full against the oracle, and the aggregate against the oracle's reduce
-    ct3 = dct[3].download(np.uint64, 2 * n).reshape(n, 2)
-    assert np.array_equal(ct3, oracle.encrypt(KEY, it, 3, "double", 16, b, pts[3]))
+    # EVERY client's full 1e7-element ciphertext against the oracle, which encrypts each client on its own
+    for c in range(C):
+        ct = dct[c].download(np.uint64, 2 * n).reshape(n, 2)
+        assert np.array_equal(ct, oracle.encrypt(KEY, it, c, "double", 16, b, pts[c])), c
+    # and the same ciphertexts from ten separate launches
+    d_one = eng.alloc_vec(n)
+    eng.encrypt_dev(it, 3, E.SCHEME_DOUBLE, n, 16, dpt[3], 1, d_one)
+    assert np.array_equal(d_one.download(np.uint64, 2 * n), dct[3].download(np.uint64, 2 * n))
     # dropout: clients 4 and 7 missing -> telescoped prefixes
     up = [0, 1, 2, 3, 5, 6, 8, 9]
     eng.aggregate_elem_dev([dct[c] for c in up], n, dagg)
