@@ -159,6 +159,22 @@ def _py_chunk(args):
     return add, minus
 
 
+def python_structure_baseline_child(b, C, sample_n):
+    """Runs python_structure_baseline in a fresh interpreter (it forks a Pool: never from a process that has initialised the GPU)
+    with a hard time limit; None when it fails -- a baseline must not be able to take the benchmark down."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--py-baseline-child", f"{b},{C},{sample_n}"],
+                           capture_output=True, text=True, timeout=120, env=dict(os.environ, OMP_NUM_THREADS="1"))
+        for line in r.stdout.splitlines():
+            if line.startswith('{"value"'):
+                return json.loads(line)
+        print(f"python baseline child failed (rc {r.returncode}): {r.stderr[-300:]}", file=sys.stderr)
+    except Exception as exc:                    # timeout, spawn failure
+        print(f"python baseline child: {exc!r}", file=sys.stderr)
+    return None
+
+
 def python_structure_baseline(b, C, host_pts, sample_n, budget_s=25.0):
     """The reference's own structure on this host: numpy object arrays of Python ints, multiprocessing.Pool(cpu_count), one AES call
     per block from Python, `(value + add - minus) & mask` as an object-array expression, reduce(lambda x, y: (x + y) % mod).
@@ -232,6 +248,10 @@ def sum_mod(vectors, n, b):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--py-baseline-child":
+        b, C, ns = (int(v) for v in sys.argv[2].split(","))
+        print(json.dumps(python_structure_baseline(b, C, [plaintext(c, ns, b) for c in range(C)], ns)), flush=True)
+        return
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
@@ -340,7 +360,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
         eng.record(ph_ev[k][2])
         return res
 
-    lo, hi = sum_mod([host_pts[c] if c in host_pts else plaintext(c, n, b) for c in range(total)], n, b)
+    lo, hi = sum_mod((host_pts[c] if c in host_pts else plaintext(c, n, b) for c in range(total)), n, b)   # one vector at a time
 
     def parity_ok(res):
         got = ops.read((res, 0), n * L).reshape(n, L)
@@ -475,7 +495,9 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(J, b, C, hp, args.cpu_sample)
             if not args.no_python_baseline:
-                out["cpu_baseline_python"] = python_structure_baseline(b, C, hp, 20_000)
+                pyb = python_structure_baseline_child(b, C, 20_000)     # regenerates the same plaintext prefix from the seeds
+                if pyb:
+                    out["cpu_baseline_python"] = pyb
     return out
 
 
