@@ -26,7 +26,14 @@ import numpy as np
 from . import engine as _engine
 from .engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine
 
+import logging
+import time
+
 N_JOBS = cpu_count()
+# Phase markers: the reference brackets its phases with LOGGER.info("start encoding") / ("end encoding")
+# lines that its log post-processing turns into per-phase times.  The mirror logs one line per phase on this logger
+# (DEBUG level: silent unless enabled) -- name, vector length and wall time.
+LOGGER = logging.getLogger("flashe_amd.cipher")
 BITS_PER_BYTES = 8
 _M64 = (1 << 64) - 1
 
@@ -311,6 +318,10 @@ class FlasheCipher(object):
             del self.next_iter_encrypt_prepared['minus']
         return _from_limbs(ct, kind)
 
+    def _phase(self, name, n, t0):
+        if LOGGER.isEnabledFor(logging.DEBUG):
+            LOGGER.debug("phase=%s scheme=%s iter=%s n=%d seconds=%.6f", name, self.masking_scheme, self.iter_index, n, time.perf_counter() - t0)
+
     def encrypt(self, plaintext):                                        # jzf_flashe.py:490-504
         if self.prp_seed is not None:
             if self.masking_scheme == "double":
@@ -319,9 +330,10 @@ class FlasheCipher(object):
                 self.set_idx_list_single(mode="encrypt")
             if not isinstance(plaintext, np.ndarray):
                 return None
-            if self.masking_scheme == "double":
-                return self._encrypt_double(plaintext)
-            return self._encrypt_single(plaintext)
+            t0 = time.perf_counter()
+            out = self._encrypt_double(plaintext) if self.masking_scheme == "double" else self._encrypt_single(plaintext)
+            self._phase("encrypt", len(plaintext), t0)
+            return out
         return None
 
     # ------------------------------------------------------------------ decrypt
@@ -380,9 +392,10 @@ class FlasheCipher(object):
         if self.prp_seed is not None:
             if not isinstance(ciphertext, np.ndarray):
                 return None
-            if self.masking_scheme == "double":
-                return self._decrypt_double(ciphertext)
-            return self._decrypt_single(ciphertext)
+            t0 = time.perf_counter()
+            out = self._decrypt_double(ciphertext) if self.masking_scheme == "double" else self._decrypt_single(ciphertext)
+            self._phase("decrypt", len(ciphertext), t0)
+            return out
         return None
 
     # ------------------------------------------------------------------ mask precompute

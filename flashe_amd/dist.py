@@ -91,8 +91,8 @@ def rendezvous_unique_id(rank, world, make_id, timeout=300.0):
     path = os.path.join(d, f"flashe_rccl_id_{os.getuid()}_{tag}")
     if rank == 0:
         ident = bytes(make_id())
-        tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
+        fd, tmp = tempfile.mkstemp(prefix="flashe_rccl_id_", dir=d)          # 0600, a name nobody else can have prepared
+        with os.fdopen(fd, "wb") as f:
             f.write(ident)
         os.replace(tmp, path)                                   # atomic: readers see nothing or all 128 bytes
         return ident, path
@@ -101,7 +101,8 @@ def rendezvous_unique_id(rank, world, make_id, timeout=300.0):
         try:
             with open(path, "rb") as f:
                 ident = f.read()
-            if len(ident) == 128:
+                mine = os.fstat(f.fileno()).st_uid == os.getuid()          # only a file this user wrote is trusted
+            if len(ident) == 128 and mine:
                 return ident, path
         except FileNotFoundError:
             pass
