@@ -482,12 +482,13 @@ class ShardedRound:
         for q in range(chunks):
             first = q * chunk
             cnt = max(0, min(chunk, n - first))
+            # (a chunk may lie entirely beyond the end of the vector: the chunks are padded to world * sub elements)
             jobs = [(cl, cl + 1, first, cnt, self._at(pts[c], first * pt_limbs), pt_limbs, self._at(self.ct[c], first * L))
-                    for c, cl in enumerate(self.clients)]
+                    for c, cl in enumerate(self.clients)] if cnt else []
             if self.exchange:
                 gfirst = min(first + self.rank * sub, n)
                 jobs.append((C, 0, gfirst, max(0, min(sub, n - gfirst)), None, 0, (self.p_dmask, q * sub * L)))
-            else:
+            elif cnt:
                 jobs.append((C, 0, first, cnt, None, 0, (self.p_dmask, first * L)))
             ev = launch_events[q] if launch_events else None
             if ev:

@@ -1,0 +1,94 @@
+"""Worker for the -m gpu test of the N > 1 path with REAL kernels and several ranks on one GPU: flashe_amd.dist.ShardedRound +
+HipOps exactly as production runs them, the exchange through tests/shm_comm.py instead of RCCL (one-GPU boxes cannot host an RCCL
+group of several ranks).  Every schedule, equal and unequal dealing, results against the oracle.  No PyTorch."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from flashe_amd.dist import HipOps, ShardedRound, deal_clients  # noqa: E402
+from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine  # noqa: E402
+from oracle import flashe_oracle as orc  # noqa: E402
+from shm_comm import ShmComm  # noqa: E402
+
+KEY = bytes(range(32))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    comm = ShmComm(rank, world, os.environ["FLASHE_TEST_SHM_DIR"])
+    orc.set_num_threads(2)
+    cases = [(128, 300_007, "equal2", 16, SCHEME_DOUBLE), (128, 70_001, "uneven", 16, SCHEME_DOUBLE), (20, 50_001, "equal2", 16, SCHEME_DOUBLE),
+             (64, 7777, "uneven", 4, SCHEME_SINGLE), (128, 999, "sparse", 1, SCHEME_DOUBLE)]
+    for b, n, dealing, J, scheme in cases:
+        L = 2 if b > 64 else 1
+        if dealing == "equal2":
+            C, mine = 2 * world, list(range(2 * rank, 2 * rank + 2))
+        elif dealing == "uneven":
+            C = world + 2
+            mine = deal_clients(C, world)[rank]
+        else:
+            C = world - 1
+            mine = deal_clients(C, world)[rank]
+        eng, side = Engine(KEY, b, device=0), Engine(KEY, b, device=0)
+        ops = HipOps(eng, side, comm)
+        host = [np.random.Generator(np.random.PCG64(70 + c)).integers(0, 2 ** min(b, 64), n, dtype=np.uint64) for c in range(C)]
+        name = "double" if scheme == SCHEME_DOUBLE else "single"
+        cts = [orc.encrypt(KEY, 4, c, name, J, b, host[c]) for c in range(C)]
+        if scheme == SCHEME_DOUBLE:
+            add, minus = orc.mask_sum(KEY, 4, [C], n, J, b), orc.mask_sum(KEY, 4, [0], n, J, b)
+        else:
+            add, minus = np.zeros((n, L), dtype=np.uint64), orc.mask_sum(KEY, 4, list(range(C)), n, J, b)
+        want_elem = orc.combine(b, orc.aggregate_elem(cts, b), add, minus)
+        agg_packed = orc.aggregate_packed([orc.pack(ct, b) for ct in cts], n * b)
+        want_packed = orc.combine(b, orc.unpack(agg_packed, n, b), add, minus)
+        pts = [(ops.upload(host[c]), 0) for c in mine]
+        rnd = ShardedRound(ops, n, b, mine, J, rank=rank, world=world, total_clients=C, scheme=scheme)
+        for mode in ("run", "pipe", "fused", "packed"):
+            if mode == "fused" and scheme != SCHEME_DOUBLE:
+                continue
+            if mode == "run":
+                out = rnd.run(4, pts, 1)
+            elif mode == "pipe":
+                out = rnd.run_pipelined(4, pts, 1, chunks=3)
+            elif mode == "fused":
+                out = rnd.run_fused(4, pts, 1, chunks=3)
+            else:
+                out = rnd.run_packed(4, pts, 1)
+            got = ops.read((out, 0), n * L).reshape(n, L)
+            assert np.array_equal(got, want_packed if mode == "packed" else want_elem), (rank, b, n, dealing, mode)
+            if mode == "packed":
+                assert np.array_equal(ops.read((rnd.k_full, 0), len(agg_packed)), agg_packed), (rank, b, n, dealing)
+        for c, ref in zip(mine, rnd.ct):                                   # this rank's own ciphertexts (chained launch) vs the oracle
+            assert np.array_equal(ops.read(ref, n * L).reshape(n, L), cts[c]), (rank, b, c)
+    # adversarial carries through whole limb slices, resolved by the device-side rule
+    for b, n in [(128, 64), (64, 37), (20, 500)]:
+        L = 2 if b > 64 else 1
+        ones = np.full((n, L), np.uint64(2 ** 64 - 1) if b >= 64 else np.uint64(2 ** b - 1), dtype=np.uint64)
+        one = np.zeros((n, L), dtype=np.uint64)
+        one[n - 1, 0] = 1
+        pats = ([ones, one] + [np.zeros_like(one)] * world)[:world]
+        eng = Engine(KEY, b, device=0)
+        ops = HipOps(eng, None, comm)
+        rnd = ShardedRound(ops, n, b, [rank], 1, rank=rank, world=world, total_clients=world)
+        rnd._packed_buffers()
+        # plant this rank's "ciphertext" and run only the packed reduce part of the round
+        eng._check(eng._lib.flashe_memcpy_h2d(eng._h, ops._a(rnd.ct[0]), np.ascontiguousarray(pats[rank]).ctypes.data, pats[rank].nbytes))
+        rnd.encrypt_phase = lambda *a, **k: None
+        rnd.run_packed(0, [(ops.alloc(n), 0)], 1)
+        want = sum(int.from_bytes(orc.pack(p, b).tobytes(), "little") for p in pats) % (1 << (n * b))
+        nl = (n * b + 63) // 64
+        got = int.from_bytes(ops.read((rnd.k_full, 0), nl).tobytes(), "little")
+        assert got == want, (rank, b, n, hex(got)[:40], hex(want)[:40])
+    comm.barrier(eng)
+    assert "torch" not in sys.modules
+    if rank == 0:
+        print("DIST_GPU_MULTI_OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -122,6 +122,7 @@ class OracleOps:
 
     def prf_jobs(self, it, n, n_jobs, jobs):
         for a, m, first, count, inp, in_limbs, out in jobs:
+            assert first <= n and count <= n - first, "the C ABI rejects a range beyond the vector, empty or not"
             if count == 0:
                 continue
             add = orc.mask(KEY, it, a, n, n_jobs, self.b)[first:first + count]

@@ -617,6 +617,26 @@ def test_sharded_round_through_rccl_single_rank():
         assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_round_several_ranks_real_kernels(world, tmp_path):
+    """The N > 1 round with REAL kernels and `world` ranks: processes share device 0 and run flashe_amd.dist.ShardedRound through
+    HipOps exactly as on a multi-GPU node (slices, block-cyclic chunks, sliced decrypts at non-zero `first`, chained job lists,
+    device-side packed carry resolution); only the transport is swapped for a file-based double of RcclComm (tests/shm_comm.py),
+    because an RCCL group cannot have two ranks on one GPU.  Every schedule, equal / unequal / sparse dealing, vs the oracle."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), FLASHE_TEST_SHM_DIR=str(tmp_path), OMP_WAIT_POLICY="passive")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_multi_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: {so[-1500:]}{se[-3000:]}"
+    assert "DIST_GPU_MULTI_OK" in outs[0][0]
+
+
 @pytest.mark.parametrize("b,n", [(128, 50001), (120, 40003), (65, 999), (64, 70001), (33, 12345), (23, 61706),
                                  (20, 100000), (8, 4097), (7, 30000), (1, 10000)])
 def test_pack_unpack_vs_oracle(E, oracle, b, n):
