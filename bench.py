@@ -72,6 +72,10 @@ def parse():
                     help="elements of the workload the CPU baseline round runs on (default: all of config 2; ~0.2-2 s)")
     ap.add_argument("--no-python-baseline", action="store_true", help="skip the structure-faithful Python baseline (~10-20 s)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the one PCIe-inclusive round through the host-pointer API")
+    ap.add_argument("--test-comm-dir", default=None,
+                    help="TEST HOOK (tests/test_gpu_parity.py): every rank uses device 0 and the exchange goes through files in this "
+                         "directory (tests/shm_comm.py) instead of RCCL, so that the N > 1 flow of this script can run on a one-GPU box; "
+                         "the JSON line says so and the figure means nothing")
     return ap.parse_args()
 
 
@@ -271,13 +275,20 @@ def main():
     cfg = args.config
     n = args.n or {2: 10_000_000, 3: LENET, 4: RESNET50, 5: RESNET50}[cfg]
 
+    if args.test_comm_dir:
+        local_rank = 0
     eng = Engine(KEY, b, device=local_rank)
     eng.selftest()
     backend = {"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend]
     eng.set_prf_backend(backend)
     two_streams = args.pipeline_chunks > 0 and args.schedule != "sequential" and cfg in (2, 4)
     side = Engine(KEY, b, device=local_rank) if two_streams else None
-    comm = RcclComm.from_env(eng) if (world > 1 or args.force_dist) else None
+    if args.test_comm_dir:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from shm_comm import ShmComm
+        comm = ShmComm(rank, world, args.test_comm_dir)
+    else:
+        comm = RcclComm.from_env(eng) if (world > 1 or args.force_dist) else None
     ops = HipOps(eng, side, comm)
 
     out = {"metric": "ciphertexts/sec (enc+agg+dec), 1e7-elem vector; achieved HBM GB/s fraction", "unit": "ciphertexts/s",
@@ -467,7 +478,8 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
                                          "(-> plaintext aggregate) and exchange hidden on a side stream",
                                 "pipelined": f"reduce / exchange / decrypt chunk-pipelined on a side stream ({Q} chunks)",
                                 "sequential": "two launches: all local encrypts, then reduce fused with decrypt"}[schedule],
-                   "schedule_calibration_ms": calibration, "collectives": "RCCL through libflashe_hip.so (no PyTorch)" if ops.comm else None,
+                   "schedule_calibration_ms": calibration, "collectives": ("TEST DOUBLE: files, all ranks on one GPU (figures meaningless)" if args.test_comm_dir else
+                                   "RCCL through libflashe_hip.so (no PyTorch)") if ops.comm else None,
                    "parity": "bit-exact (decrypted aggregate == plaintext sum on every rank, checked in-run)"},
         "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS,

@@ -617,12 +617,13 @@ def test_sharded_round_through_rccl_single_rank():
         assert r.returncode == 0 and "DIST_GPU_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_round_several_ranks_real_kernels(world, tmp_path):
     """The N > 1 round with REAL kernels and `world` ranks: processes share device 0 and run flashe_amd.dist.ShardedRound through
     HipOps exactly as on a multi-GPU node (slices, block-cyclic chunks, sliced decrypts at non-zero `first`, chained job lists,
     device-side packed carry resolution); only the transport is swapped for a file-based double of RcclComm (tests/shm_comm.py),
-    because an RCCL group cannot have two ranks on one GPU.  Every schedule, equal / unequal / sparse dealing, vs the oracle."""
+    because an RCCL group cannot have two ranks on one GPU.  Every schedule, equal / unequal / sparse dealing, vs the oracle.  With
+    world = 8 the "uneven" case IS BASELINE config 4's dealing: 10 clients as 2, 2, 1, 1, 1, 1, 1, 1."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -635,6 +636,28 @@ def test_sharded_round_several_ranks_real_kernels(world, tmp_path):
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}: {so[-1500:]}{se[-3000:]}"
     assert "DIST_GPU_MULTI_OK" in outs[0][0]
+
+
+@pytest.mark.parametrize("extra", [["--config", "2", "--clients", "3"], ["--config", "4", "--clients", "5"]])
+def test_bench_multi_rank_flow(extra, tmp_path):
+    """bench.py's own N > 1 glue -- process spawn, per-rank parity gate with agreement between ranks, schedule calibration, barriers and
+    MAX-over-ranks timing, the one JSON line from rank 0 -- run with 3 ranks on this one GPU through the file-based comm double (the
+    printed figure is meaningless and labelled so).  Weak scaling (config 2) and the strong-scaling deal of config 4."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--n", "300007", "--steps", "3", "--warmup", "1", "--settle-rounds", "2",
+           "--no-cpu-baseline", "--no-e2e", "--test-comm-dir", str(tmp_path)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and d["steps"] == 3 and d["value"] > 0 and "bit-exact" in d["config"]["parity"]
+    assert d["scaling"] == ("weak" if extra[1] == "2" else "strong")
+    assert set(d["config"]["schedule_calibration_ms"]) == {"fused", "pipelined", "sequential"}
+    assert d["config"]["clients_total"] == (9 if extra[1] == "2" else 5)
 
 
 @pytest.mark.parametrize("b,n", [(128, 50001), (120, 40003), (65, 999), (64, 70001), (33, 12345), (23, 61706),
