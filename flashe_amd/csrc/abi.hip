@@ -193,10 +193,43 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 size_t vec_bytes(const flashe_ctx *ctx, uint64_t n) { return static_cast<size_t>(n) * ctx->limbs * 8; }
 
 // RAII temp device buffer for the host-pointer wrappers
+constexpr size_t kPoolBlockMax = 64u << 20;        // larger staging buffers are not kept: at that size the transfer dominates
+constexpr size_t kPoolBlocks = 24;
+
 struct Tmp {
     void *p = nullptr;
-    ~Tmp() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    flashe_ctx *owner = nullptr;
+    int slot = -1;
+    ~Tmp()
+    {
+        if (!p) return;
+        if (slot >= 0) owner->pool[slot].used = false;
+        else (void)hipFree(p);
+    }
+    hipError_t alloc(flashe_ctx *ctx, size_t bytes)
+    {
+        if (bytes == 0) bytes = 16;
+        if (bytes <= kPoolBlockMax) {
+            int best = -1;
+            for (size_t i = 0; i < ctx->pool.size(); i++)
+                if (!ctx->pool[i].used && ctx->pool[i].cap >= bytes && (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap)) best = static_cast<int>(i);
+            if (best < 0 && ctx->pool.size() < kPoolBlocks) {
+                size_t cap = 4096;
+                while (cap < bytes) cap <<= 1;
+                void *q = nullptr;
+                const hipError_t e = hipMalloc(&q, cap);
+                if (e != hipSuccess) return e;
+                ctx->pool.push_back(flashe_ctx::PoolBlock{q, cap, false});
+                best = static_cast<int>(ctx->pool.size()) - 1;
+            }
+            if (best >= 0) {
+                ctx->pool[best].used = true;
+                p = ctx->pool[best].p; owner = ctx; slot = best;
+                return hipSuccess;
+            }
+        }
+        return hipMalloc(&p, bytes);
+    }
     template <class T> T *as() { return static_cast<T *>(p); }
 };
 
@@ -298,6 +331,8 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     if (ctx->env.stream) (void)hipStreamSynchronize(ctx->env.stream);
     for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds})
         if (b->p) (void)hipFree(b->p);
+    for (flashe_ctx::PoolBlock &pb : ctx->pool)
+        if (pb.p) (void)hipFree(pb.p);
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
     // the expanded AES-256 key leaves neither HBM nor host memory behind
     if (ctx->rkw_dev) { (void)hipMemset(ctx->rkw_dev, 0, 256); (void)hipFree(ctx->rkw_dev); }
@@ -354,8 +389,8 @@ int flashe_selftest(flashe_ctx *ctx)
                                    : static_cast<uint32_t>(0x9e3779b9u * (4 * i + j + 1) ^ (i << 7));
     }
     Tmp din, dout;
-    HIP_TRY(ctx, din.alloc(in.size() * 4));
-    HIP_TRY(ctx, dout.alloc(out.size() * 4));
+    HIP_TRY(ctx, din.alloc(ctx, in.size() * 4));
+    HIP_TRY(ctx, dout.alloc(ctx, out.size() * 4));
     LaunchEnv env = ctx->env;
     expand_key(fips_key, &env.rk);
     HIP_TRY(ctx, hipMemcpyAsync(din.p, in.data(), in.size() * 4, hipMemcpyHostToDevice, env.stream));
@@ -1254,7 +1289,7 @@ int flashe_mask(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx, 
     if (n == 0) return FLASHE_OK;
     if (!out) return fail(ctx, FLASHE_EINVAL, "null output");
     Tmp d;
-    HIP_TRY(ctx, d.alloc(vec_bytes(ctx, n)));
+    HIP_TRY(ctx, d.alloc(ctx, vec_bytes(ctx, n)));
     int rc = flashe_mask_dev(ctx, iter, idx, n_idx, n, n_jobs, d.as<uint64_t>());
     if (rc) return rc;
     D2H(out, d.p, vec_bytes(ctx, n));
@@ -1269,8 +1304,8 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uin
     if (!pt || !ct) return fail(ctx, FLASHE_EINVAL, "null vector");
     if (pt_limbs != 1 && pt_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "pt_limbs must be 1 or %d", ctx->limbs);
     Tmp dp, dc;
-    HIP_TRY(ctx, dp.alloc(static_cast<size_t>(n) * pt_limbs * 8));
-    HIP_TRY(ctx, dc.alloc(vec_bytes(ctx, n)));
+    HIP_TRY(ctx, dp.alloc(ctx, static_cast<size_t>(n) * pt_limbs * 8));
+    HIP_TRY(ctx, dc.alloc(ctx, vec_bytes(ctx, n)));
     H2D(dp.p, pt, static_cast<size_t>(n) * pt_limbs * 8);
     int rc = flashe_encrypt_dev(ctx, iter, idx, scheme, n, n_jobs, dp.as<uint64_t>(), pt_limbs, dc.as<uint64_t>());
     if (rc) return rc;
@@ -1285,8 +1320,8 @@ int flashe_decrypt(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int 
     if (n == 0) return FLASHE_OK;
     if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
     Tmp di, dout;
-    HIP_TRY(ctx, di.alloc(vec_bytes(ctx, n)));
-    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, n)));
+    HIP_TRY(ctx, di.alloc(ctx, vec_bytes(ctx, n)));
+    HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, n)));
     H2D(di.p, in, vec_bytes(ctx, n));
     int rc = flashe_decrypt_dev(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, di.as<uint64_t>(), dout.as<uint64_t>());
     if (rc) return rc;
@@ -1301,11 +1336,11 @@ int flashe_combine(flashe_ctx *ctx, uint64_t n, const uint64_t *in, int in_limbs
     if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
     if (in_limbs != 1 && in_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 or %d", ctx->limbs);
     Tmp di, da, dm, dout;
-    HIP_TRY(ctx, di.alloc(static_cast<size_t>(n) * in_limbs * 8));
-    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, n)));
+    HIP_TRY(ctx, di.alloc(ctx, static_cast<size_t>(n) * in_limbs * 8));
+    HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, n)));
     H2D(di.p, in, static_cast<size_t>(n) * in_limbs * 8);
-    if (add) { HIP_TRY(ctx, da.alloc(vec_bytes(ctx, n))); H2D(da.p, add, vec_bytes(ctx, n)); }
-    if (minus) { HIP_TRY(ctx, dm.alloc(vec_bytes(ctx, n))); H2D(dm.p, minus, vec_bytes(ctx, n)); }
+    if (add) { HIP_TRY(ctx, da.alloc(ctx, vec_bytes(ctx, n))); H2D(da.p, add, vec_bytes(ctx, n)); }
+    if (minus) { HIP_TRY(ctx, dm.alloc(ctx, vec_bytes(ctx, n))); H2D(dm.p, minus, vec_bytes(ctx, n)); }
     int rc = flashe_combine_dev(ctx, n, di.as<uint64_t>(), in_limbs, add ? da.as<uint64_t>() : nullptr,
                                 minus ? dm.as<uint64_t>() : nullptr, dout.as<uint64_t>());
     if (rc) return rc;
@@ -1321,8 +1356,8 @@ int flashe_aggregate_elem(flashe_ctx *ctx, int C, const uint64_t *const *cts, ui
     if (!out) return fail(ctx, FLASHE_EINVAL, "null output");
     const size_t vb = (vec_bytes(ctx, n) + 15) & ~static_cast<size_t>(15);
     Tmp all, dout;
-    HIP_TRY(ctx, all.alloc(vb * C));
-    HIP_TRY(ctx, dout.alloc(vb));
+    HIP_TRY(ctx, all.alloc(ctx, vb * C));
+    HIP_TRY(ctx, dout.alloc(ctx, vb));
     std::vector<const uint64_t *> ptrs(C);
     for (int c = 0; c < C; c++) {
         if (!cts[c]) return fail(ctx, FLASHE_EINVAL, "operand %d is null", c);
@@ -1344,8 +1379,8 @@ int flashe_aggregate_packed(flashe_ctx *ctx, int C, const uint64_t *const *packe
     if (!out) return fail(ctx, FLASHE_EINVAL, "null output");
     const size_t vb = (static_cast<size_t>(n_limbs) * 8 + 15) & ~static_cast<size_t>(15);
     Tmp all, dout;
-    HIP_TRY(ctx, all.alloc(vb * C));
-    HIP_TRY(ctx, dout.alloc(vb));
+    HIP_TRY(ctx, all.alloc(ctx, vb * C));
+    HIP_TRY(ctx, dout.alloc(ctx, vb));
     std::vector<const uint64_t *> ptrs(C);
     for (int c = 0; c < C; c++) {
         if (!packed[c]) return fail(ctx, FLASHE_EINVAL, "operand %d is null", c);
@@ -1365,8 +1400,8 @@ int flashe_pack(flashe_ctx *ctx, uint64_t n, const uint64_t *in, uint64_t *out)
     if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
     const size_t ob = static_cast<size_t>((n * ctx->int_bits + 63) / 64) * 8;
     Tmp di, dout;
-    HIP_TRY(ctx, di.alloc(vec_bytes(ctx, n)));
-    HIP_TRY(ctx, dout.alloc(ob));
+    HIP_TRY(ctx, di.alloc(ctx, vec_bytes(ctx, n)));
+    HIP_TRY(ctx, dout.alloc(ctx, ob));
     H2D(di.p, in, vec_bytes(ctx, n));
     int rc = flashe_pack_dev(ctx, n, di.as<uint64_t>(), dout.as<uint64_t>());
     if (rc) return rc;
@@ -1381,8 +1416,8 @@ int flashe_unpack(flashe_ctx *ctx, uint64_t n, const uint64_t *in, uint64_t *out
     if (!in || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
     const size_t ib = static_cast<size_t>((n * ctx->int_bits + 63) / 64) * 8;
     Tmp di, dout;
-    HIP_TRY(ctx, di.alloc(ib));
-    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, n)));
+    HIP_TRY(ctx, di.alloc(ctx, ib));
+    HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, n)));
     H2D(di.p, in, ib);
     int rc = flashe_unpack_dev(ctx, n, di.as<uint64_t>(), dout.as<uint64_t>());
     if (rc) return rc;
@@ -1399,9 +1434,9 @@ int flashe_expand_to_dense(flashe_ctx *ctx, uint64_t total, uint64_t k, const ui
     for (uint64_t q = 0; q < k; q++)
         if (loc[q] >= total) return fail(ctx, FLASHE_EINVAL, "location %llu out of range", static_cast<unsigned long long>(loc[q]));
     Tmp dl, dv, dout;
-    HIP_TRY(ctx, dl.alloc(static_cast<size_t>(k) * 4));
-    HIP_TRY(ctx, dv.alloc(vec_bytes(ctx, k)));
-    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, total)));
+    HIP_TRY(ctx, dl.alloc(ctx, static_cast<size_t>(k) * 4));
+    HIP_TRY(ctx, dv.alloc(ctx, vec_bytes(ctx, k)));
+    HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, total)));
     if (k) { H2D(dl.p, loc, static_cast<size_t>(k) * 4); H2D(dv.p, vals, vec_bytes(ctx, k)); }
     int rc = flashe_expand_to_dense_dev(ctx, total, k, dl.as<uint32_t>(), dv.as<uint64_t>(), zero, dout.as<uint64_t>());
     if (rc) return rc;
@@ -1423,12 +1458,12 @@ int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32
             if (loc[c][q] >= total) return fail(ctx, FLASHE_EINVAL, "client %d location out of range", c);
             if (q && loc[c][q] <= loc[c][q - 1]) sorted = false;
         }
-        HIP_TRY(ctx, dl[c].alloc(static_cast<size_t>(k[c]) * 4));
+        HIP_TRY(ctx, dl[c].alloc(ctx, static_cast<size_t>(k[c]) * 4));
         if (k[c]) H2D(dl[c].p, loc[c], static_cast<size_t>(k[c]) * 4);
         ptrs[c] = dl[c].as<uint32_t>();
     }
     Tmp dout;
-    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, total)));
+    HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, total)));
     int rc = sparse_minus_mask_impl(ctx, iter, C, ptrs.data(), k, total, n_jobs, sorted, dout.as<uint64_t>());
     if (rc) return rc;
     D2H(out, dout.p, vec_bytes(ctx, total));
@@ -1443,12 +1478,12 @@ int flashe_sparse_dense_mask(flashe_ctx *ctx, uint32_t iter, int n_lists, const 
     std::vector<Tmp> ds(n_lists);
     std::vector<const uint8_t *> ptrs(n_lists);
     for (int i = 0; i < n_lists; i++) {
-        HIP_TRY(ctx, ds[i].alloc(static_cast<size_t>(total)));
+        HIP_TRY(ctx, ds[i].alloc(ctx, static_cast<size_t>(total)));
         H2D(ds[i].p, sel[i], static_cast<size_t>(total));
         ptrs[i] = ds[i].as<uint8_t>();
     }
     Tmp dout;
-    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, total)));
+    HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, total)));
     int rc = flashe_sparse_dense_mask_dev(ctx, iter, n_lists, ptrs.data(), total, dout.as<uint64_t>());
     if (rc) return rc;
     D2H(out, dout.p, vec_bytes(ctx, total));
@@ -1463,9 +1498,9 @@ int flashe_quantize(flashe_ctx *ctx, uint64_t n, const void *x, int x_is_f64, do
     if (!x || !u || !q) return fail(ctx, FLASHE_EINVAL, "null vector");
     const size_t xb = static_cast<size_t>(n) * (x_is_f64 ? 8 : 4);
     Tmp dx, du, dq;
-    HIP_TRY(ctx, dx.alloc(xb));
-    HIP_TRY(ctx, du.alloc(static_cast<size_t>(n) * 8));
-    HIP_TRY(ctx, dq.alloc(static_cast<size_t>(n) * 8));
+    HIP_TRY(ctx, dx.alloc(ctx, xb));
+    HIP_TRY(ctx, du.alloc(ctx, static_cast<size_t>(n) * 8));
+    HIP_TRY(ctx, dq.alloc(ctx, static_cast<size_t>(n) * 8));
     H2D(dx.p, x, xb);
     H2D(du.p, u, static_cast<size_t>(n) * 8);
     int rc = flashe_quantize_dev(ctx, n, dx.p, x_is_f64, alpha, element_bits, du.as<double>(), dq.as<uint64_t>());
@@ -1482,8 +1517,8 @@ int flashe_unquantize(flashe_ctx *ctx, uint64_t n, const uint64_t *v, int v_limb
     if (!v || !out) return fail(ctx, FLASHE_EINVAL, "null vector");
     if (v_limbs != 1 && v_limbs != 2) return fail(ctx, FLASHE_EINVAL, "v_limbs must be 1 or 2");
     Tmp dv, dout;
-    HIP_TRY(ctx, dv.alloc(static_cast<size_t>(n) * v_limbs * 8));
-    HIP_TRY(ctx, dout.alloc(static_cast<size_t>(n) * 8));
+    HIP_TRY(ctx, dv.alloc(ctx, static_cast<size_t>(n) * v_limbs * 8));
+    HIP_TRY(ctx, dout.alloc(ctx, static_cast<size_t>(n) * 8));
     H2D(dv.p, v, static_cast<size_t>(n) * v_limbs * 8);
     int rc = flashe_unquantize_dev(ctx, n, dv.as<uint64_t>(), v_limbs, alpha, element_bits, num_clients, dout.as<double>());
     if (rc) return rc;
@@ -1500,8 +1535,8 @@ int flashe_batch(flashe_ctx *ctx, uint64_t n, const uint64_t *vals, int field_bi
     if (rc) return rc;
     const uint64_t bs = ctx->int_bits / field_bits, nb = (n + bs - 1) / bs;
     Tmp dv, dout;
-    HIP_TRY(ctx, dv.alloc(static_cast<size_t>(n) * 8));
-    HIP_TRY(ctx, dout.alloc(vec_bytes(ctx, nb)));
+    HIP_TRY(ctx, dv.alloc(ctx, static_cast<size_t>(n) * 8));
+    HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, nb)));
     H2D(dv.p, vals, static_cast<size_t>(n) * 8);
     rc = flashe_batch_dev(ctx, n, dv.as<uint64_t>(), field_bits, dout.as<uint64_t>());
     if (rc) return rc;
@@ -1518,8 +1553,8 @@ int flashe_unbatch(flashe_ctx *ctx, uint64_t n_batches, const uint64_t *in, int 
     if (rc) return rc;
     const uint64_t bs = ctx->int_bits / field_bits;
     Tmp di, dout;
-    HIP_TRY(ctx, di.alloc(vec_bytes(ctx, n_batches)));
-    HIP_TRY(ctx, dout.alloc(static_cast<size_t>(n_batches * bs) * 8));
+    HIP_TRY(ctx, di.alloc(ctx, vec_bytes(ctx, n_batches)));
+    HIP_TRY(ctx, dout.alloc(ctx, static_cast<size_t>(n_batches * bs) * 8));
     H2D(di.p, in, vec_bytes(ctx, n_batches));
     rc = flashe_unbatch_dev(ctx, n_batches, di.as<uint64_t>(), field_bits, dout.as<uint64_t>());
     if (rc) return rc;
@@ -1534,11 +1569,11 @@ int flashe_sparsify(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x, int 
     if (!x || !loc || !vals) return fail(ctx, FLASHE_EINVAL, "null vector");
     const size_t es = x_is_f64 ? 8 : 4;
     Tmp dx, dr, dl, dv;
-    HIP_TRY(ctx, dx.alloc(n * es));
-    HIP_TRY(ctx, dl.alloc(k * 4));
-    HIP_TRY(ctx, dv.alloc(k * es));
+    HIP_TRY(ctx, dx.alloc(ctx, n * es));
+    HIP_TRY(ctx, dl.alloc(ctx, k * 4));
+    HIP_TRY(ctx, dv.alloc(ctx, k * es));
     H2D(dx.p, x, n * es);
-    if (residual) { HIP_TRY(ctx, dr.alloc(n * es)); H2D(dr.p, residual, n * es); }
+    if (residual) { HIP_TRY(ctx, dr.alloc(ctx, n * es)); H2D(dr.p, residual, n * es); }
     int rc = flashe_sparsify_dev(ctx, n, k, dx.p, x_is_f64, residual ? dr.p : nullptr, dl.as<uint32_t>(), dv.p);
     if (rc) return rc;
     if (residual) HIP_TRY(ctx, hipMemcpyAsync(residual, dr.p, n * es, hipMemcpyDeviceToHost, ctx->env.stream));

@@ -5,6 +5,7 @@
 #include "kernels.h"
 
 #include <string>
+#include <vector>
 
 struct flashe_ctx {
     int device = 0;
@@ -23,6 +24,10 @@ struct flashe_ctx {
     Buf acc_tmp[2];   // ping-pong partial sums when a packed reduce has more than kMaxOps operands
     Buf sp_ws;        // sparsifier workspace (select state, histogram, per-block counts)
     Buf bounds;       // span reduce: first entry of every client in every span
+    // staging blocks of the host-pointer twins: hipMalloc / hipFree cost more than the kernels on LeNet-sized vectors, so blocks
+    // up to kPoolBlockMax bytes are kept and reused (the twins are synchronous: a block is free again when its call returns)
+    struct PoolBlock { void *p; size_t cap; bool used; };
+    std::vector<PoolBlock> pool;
     bool capturing = false;   // between flashe_graph_begin and flashe_graph_end
     uint32_t key_epoch = 0;   // bumped by flashe_ctx_set_key: a graph replays the key it was captured with
     uint32_t *err_flag_host = nullptr;   // host-mapped word the sparse kernels set when they skip an out-of-range location
