@@ -21,18 +21,24 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(pattern):
+    """gpurun merges every call's output into the same directory: take the most recent run's file."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1] if files else None
+
+
 def rows(pattern):
-    files = glob.glob(pattern)
-    return list(csv.DictReader(open(files[0]))) if files else []
+    f = newest(pattern)
+    return list(csv.DictReader(open(f))) if f else []
 
 
 def main(tag):
     src = os.path.join(ROOT, "gpurun_out", "prof", tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+        shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
