@@ -100,6 +100,25 @@ def main(tag):
         if prev is None or ent["launches"] > prev["launches"]:
             traffic["kernels"][short] = ent
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    # The --stats average of the dominant kernel covers every launch of the process -- parity run, settle rounds, warmup (the first
+    # ones after the host-side parity check run on a cold clock) and the K timed ones.  bench.py's roofline.avg_launch_ms covers the K
+    # timed launches only, which are the LAST K of the trace: put both averages side by side.
+    if dom_name:
+        steps, bench_ms = None, None
+        try:
+            for line in open(os.path.join(src, "trace.log")):
+                if line.startswith('{"metric'):
+                    j = json.loads(line)
+                    steps, bench_ms = j["steps"], j["roofline"]["avg_launch_ms"]
+        except OSError:
+            pass
+        d_all = [v for k, vs in dur.items() if dom_name in k for v in vs]
+        if steps and len(d_all) >= steps:
+            json.dump({"kernel": dom_name, "launches_in_trace": len(d_all), "avg_us_all_launches": sum(d_all) / len(d_all) / 1e3,
+                       "timed_launches": steps, "avg_us_last_timed_launches": sum(d_all[-steps:]) / steps / 1e3,
+                       "bench_roofline_avg_launch_us_same_run": bench_ms * 1e3,
+                       "first_five_us": [v / 1e3 for v in d_all[:5]]},
+                      open(os.path.join(dst, f"{tag}_timed_launches.json"), "w"), indent=1)
     print(json.dumps({k[:50]: {c: (round(v["avg"]) if isinstance(v, dict) and "avg" in v else v) for c, v in e.items()
                                if c != "launch"} for k, e in out.items()}, indent=1))
 
