@@ -507,7 +507,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(J, b, C, hp, args.cpu_sample)
             if not args.no_python_baseline:
-                pyb = python_structure_baseline_child(b, C, 20_000)     # regenerates the same plaintext prefix from the seeds
+                pyb = python_structure_baseline_child(b, C, 1_000_000)  # n = 1e6 per phase; regenerates the plaintext prefix from the seeds
                 if pyb:
                     out["cpu_baseline_python"] = pyb
     return out
