@@ -460,10 +460,11 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
         vec = (C - 1) if (schedule == "pipelined" and C > 1) else C
         alg_bytes = vec * n * (pt_bytes + 8 * L)          # u64 plaintext in + L-limb ciphertext out, per client vector
         blocks = (vec + 1 if chained else 2 * vec) * n / (1 if L == 2 else 128 // b)
-        kernel_key = "prf_chain_kernel" if L == 2 else "prf_small_jobs_kernel"
+        kernel_key = "prf_chain_kernel" if L == 2 else "prf_small_chain_kernel"
         kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub = encrypt: {vec} consecutive clients per launch share "
                        f"{vec + 1} PRF streams, ct_c = pt_c + S_c - S_(c+1))") if L == 2 else \
-            f"prf_small_jobs_kernel<true> (b <= 64: one AES block = {128 // b} elements per lane; {vec} client vectors per launch)"
+            (f"prf_small_chain_kernel (b <= 64: one AES block = {128 // b} elements, a lane owns its block(s) for all {vec + 1} streams of the "
+             f"{vec}-client chain)")
     achieved = alg_bytes / (enc_avg_ms * 1e-3) / 1e9
     ratio, tsrc = traffic_ratio(kernel_key)
     lookups = 196.1 if chained else 196.5
@@ -607,7 +608,7 @@ def bench_precompute(args, n, ops, rank, world, out):
                    "n": n, "int_bits": b, "clients_total": C, "mask": "double+precompute",
                    "parity": "bit-exact (round trip + three clients' ciphertexts vs the oracle, checked in-run)"},
         "roofline": {"kernel": "prf_chain_kernel<1024> (mask precompute: chain of %d clients + decrypt mask difference, in = NULL)" % C if L == 2
-                     else "prf_small_jobs_kernel<true> (mask precompute)",
+                     else "prf_small_chain_kernel<false> (mask precompute: chained streams, two streams per step)",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pre_ms, "launches_timed": K,
                      "aes_blocks_per_launch": blocks, "aes_blocks_per_s": blocks / (pre_ms * 1e-3),
@@ -643,7 +644,7 @@ def bench_sparse(args, total, ops, rank, world, out):
     d_loc = [ops.upload(l) for l in locs]
     d_val = [ops.upload(v) for v in vals]
     d_ct = [eng.alloc_vec(k) for _ in range(C)]
-    d_agg, d_mask, d_dec = eng.alloc_vec(total), eng.alloc_vec(total), eng.alloc_vec(total)
+    d_agg, d_dec = eng.alloc_vec(total), eng.alloc_vec(total)
     ev = [[eng.event() for _ in range(4)] for _ in range(K)]
 
     def step(it, kk=None):
@@ -655,8 +656,7 @@ def bench_sparse(args, total, ops, rank, world, out):
         eng.sparse_aggregate_dev(total, d_loc, [k] * C, d_ct, [zero] * C, d_agg, sorted_lists=True)
         if kk is not None:
             eng.record(ev[kk][2])
-        eng.sparse_minus_mask_dev(it, d_loc, [k] * C, total, J, d_mask, sorted_lists=True)
-        eng.combine_dev(total, d_agg, L, None, d_mask, d_dec)
+        eng.sparse_decrypt_dev(it, d_loc, [k] * C, total, J, d_agg, d_dec, sorted_lists=True)    # dense minus-mask built and subtracted in one pass
         if kk is not None:
             eng.record(ev[kk][3])
 
@@ -682,7 +682,7 @@ def bench_sparse(args, total, ops, rank, world, out):
         "value": world * C * k / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
         "config": {"workload": f"BASELINE config 5: top-1 % sparsified gradient (k={k} of {total} positions, u32 index + {8 * L}-byte value), {C} clients, "
                                f"{b}-bit modulus, single mask over compact positions (the sparse path the reference runs; dynamic masking picks it), "
-                               f"n_jobs={J}; step = {C} compact encrypts + fused sparse aggregate + dense minus-mask + decrypt"
+                               f"n_jobs={J}; step = {C} compact encrypts + fused sparse aggregate + decrypt (dense minus-mask built and subtracted in one pass)"
                                + ("; independent replicas per GPU" if world > 1 else ""),
                    "n": total, "k": k, "int_bits": b, "clients_total": C, "mask": "single (sparse)",
                    "parity": "bit-exact (dense round trip + one client's ciphertext vs the oracle, checked in-run)"},

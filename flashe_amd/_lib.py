@@ -103,6 +103,7 @@ _SIGNATURES = {
     "flashe_expand_to_dense": (c_int, [c_vp, c_u64, c_u64, c_vp, c_vp, c_u64p, c_vp]),
     "flashe_sparse_aggregate_dev": (c_int, [c_vp, c_u64, c_int, ctypes.POINTER(c_vp), c_u64p, ctypes.POINTER(c_vp), c_u64p, c_int, c_vp]),
     "flashe_sparse_minus_mask_sorted_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
+    "flashe_sparse_decrypt_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_int, c_vp, c_vp]),
     "flashe_sparse_minus_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
     "flashe_sparse_minus_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
     "flashe_sparse_dense_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),

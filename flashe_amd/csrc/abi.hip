@@ -1102,7 +1102,7 @@ int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const ui
             const int nc = std::min(kMaxScatter, C - c0);
             HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, vals_dev + c0, k + c0, zeros + static_cast<size_t>(L) * c0,
                                             c0 ? 0 : static_cast<uint64_t>(zsum), c0 ? 0 : static_cast<uint64_t>(zsum >> 64), total,
-                                            static_cast<uint32_t *>(ctx->bounds.p), c0 != 0, out_dev));
+                                            static_cast<uint32_t *>(ctx->bounds.p), c0 != 0 ? out_dev : nullptr, false, out_dev));
         }
         return FLASHE_OK;
     }
@@ -1113,21 +1113,28 @@ int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const ui
     return FLASHE_OK;
 }
 
+// agg_dev == nullptr: out = the dense minus-mask.  agg_dev given: out = (agg - minus-mask) mod 2^b, the single-mask decrypt
+// (jzf_flashe.py:531-532) in the pass that builds the mask.
 static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
-                                  uint64_t total, uint32_t n_jobs, bool sorted, uint64_t *out_dev)
+                                  uint64_t total, uint32_t n_jobs, bool sorted, const uint64_t *agg_dev, uint64_t *out_dev)
 {
     CHECK_CTX(ctx);
     if (C < 0 || (C && (!loc_dev || !k)) || (total && !out_dev) || n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "bad arguments");
-    if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    if (ctx->limbs == 2 && (!aligned16(out_dev) || !aligned16(agg_dev))) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
     uint64_t kmax = 0;
-    for (int c = 0; c < C; c++) kmax = std::max(kmax, k[c]);
+    for (int c = 0; c < C; c++) {
+        if (k[c] > total) return fail(ctx, FLASHE_EINVAL, "client %d: more locations (%llu) than positions (%llu)", c,
+                                      static_cast<unsigned long long>(k[c]), static_cast<unsigned long long>(total));
+        kmax = std::max(kmax, k[c]);
+    }
     const bool jobs_path = ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE);
-    if (!(sorted && jobs_path && C > 0) && total) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
-    if (ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE)) {
-        // m = 1: the compact streams do not depend on their length, so up to kMaxBatch clients' streams come from one
-        // job-list launch; the scatters stay one per client (location sets overlap between clients)
+    const bool fused = sorted && jobs_path && C > 0;      // the span reduce writes (or subtracts from agg) the whole vector itself
+    if (!fused && total) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
+    if (jobs_path) {
+        // m = 1: the compact streams do not depend on their length, so every client's stream comes from one job-list
+        // launch per group; unsorted lists are scattered one client at a time (location sets overlap between clients)
         const uint64_t kpad = (kmax + 1) & ~1ull;
-        const int group = std::min(C, sorted ? kMaxScatter : kMaxBatch);     // clients whose streams are held at once
+        const int group = std::min(C, kMaxScatter);          // clients whose streams are held at once
         int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kpad) * static_cast<size_t>(std::max(group, 1)));
         if (rc) return rc;
         if (sorted && C > 0 && (rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(group) * sizeof(uint32_t)))) return rc;
@@ -1135,46 +1142,54 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
         for (int c0 = 0; c0 < C; c0 += group) {
             const int nc = std::min(group, C - c0);
             const uint64_t *streams[kMaxScatter];
-            for (int e = 0; e < nc; e++) streams[e] = tmp + 2 * kpad * static_cast<uint64_t>(e);
-            for (int j0 = 0; j0 < nc; j0 += kMaxBatch) {
-                PrfJob jobs[kMaxBatch];
-                const int nj = std::min(kMaxBatch, nc - j0);
-                for (int e = 0; e < nj; e++)
-                    jobs[e] = PrfJob{static_cast<uint32_t>(c0 + j0 + e), 0u, 0, k[c0 + j0 + e], nullptr, 0, tmp + 2 * kpad * static_cast<uint64_t>(j0 + e)};
-                HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nj, jobs, kmax, n_jobs));
+            PrfJob jobs[kMaxScatter];
+            for (int e = 0; e < nc; e++) {
+                streams[e] = tmp + 2 * kpad * static_cast<uint64_t>(e);
+                jobs[e] = PrfJob{static_cast<uint32_t>(c0 + e), 0u, 0, k[c0 + e], nullptr, 0, tmp + 2 * kpad * static_cast<uint64_t>(e)};
             }
+            HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nc, jobs, kmax, n_jobs));
             if (sorted) {
                 HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, streams, k + c0, nullptr, 0, 0, total,
-                                                static_cast<uint32_t *>(ctx->bounds.p), c0 != 0, out_dev));
+                                                static_cast<uint32_t *>(ctx->bounds.p), c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev));
             } else {
                 for (int e = 0; e < nc; e++)
                     HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c0 + e], loc_dev[c0 + e], streams[e], out_dev, true));
             }
         }
-        return FLASHE_OK;
+    } else {
+        int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kmax));
+        if (rc) return rc;
+        uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
+        for (int c = 0; c < C; c++) {
+            if (!k[c]) continue;
+            const uint32_t idx = static_cast<uint32_t>(c);
+            HIP_TRY(ctx, launch_prf(ctx->env, iter, &idx, 1, nullptr, 0, k[c], n_jobs, 0, k[c], nullptr, 0, tmp));
+            HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c], loc_dev[c], tmp, out_dev, true));
+        }
     }
-    int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kmax));
-    if (rc) return rc;
-    uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
-    for (int c = 0; c < C; c++) {
-        if (!k[c]) continue;
-        const uint32_t idx = static_cast<uint32_t>(c);
-        HIP_TRY(ctx, launch_prf(ctx->env, iter, &idx, 1, nullptr, 0, k[c], n_jobs, 0, k[c], nullptr, 0, tmp));
-        HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c], loc_dev[c], tmp, out_dev, true));
-    }
+    // the paths that built the mask itself: subtract it from the aggregate in place
+    if (agg_dev && !fused && total) HIP_TRY(ctx, launch_combine(ctx->env, total, agg_dev, ctx->limbs, nullptr, out_dev, out_dev));
     return FLASHE_OK;
 }
 
 int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                                  uint64_t total, uint32_t n_jobs, uint64_t *out_dev)
 {
-    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, false, out_dev);
+    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, false, nullptr, out_dev);
 }
 
 int flashe_sparse_minus_mask_sorted_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                                         uint64_t total, uint32_t n_jobs, uint64_t *out_dev)
 {
-    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, true, out_dev);
+    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, true, nullptr, out_dev);
+}
+
+int flashe_sparse_decrypt_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total,
+                              uint32_t n_jobs, int sorted, const uint64_t *agg_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (total && (!agg_dev || agg_dev == out_dev)) return fail(ctx, FLASHE_EINVAL, "the aggregate must be given and must not be the output vector");
+    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, sorted != 0, agg_dev, out_dev);
 }
 
 int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel_dev, uint64_t total,
@@ -1464,7 +1479,7 @@ int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32
     }
     Tmp dout;
     HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, total)));
-    int rc = sparse_minus_mask_impl(ctx, iter, C, ptrs.data(), k, total, n_jobs, sorted, dout.as<uint64_t>());
+    int rc = sparse_minus_mask_impl(ctx, iter, C, ptrs.data(), k, total, n_jobs, sorted, nullptr, dout.as<uint64_t>());
     if (rc) return rc;
     D2H(out, dout.p, vec_bytes(ctx, total));
     return FLASHE_OK;

@@ -136,13 +136,15 @@ hipError_t launch_scatter(const LaunchEnv &env, uint64_t total, uint64_t k, cons
                           const uint64_t *vals_dev, uint64_t *out_dev, bool accumulate,
                           uint64_t sub_lo = 0, uint64_t sub_hi = 0);
 // Sparse reduce over strictly increasing location lists (LDS-staged, the dense output is written once):
-// out[p] = base + sum_{c, q: loc[c][q] == p} (vals[c][q] - sub[c]) mod 2^b for every p < total (+ the old out[p] when
-// accumulate_into_out).  At most kMaxScatter clients per call; start_dev = (span_count(total) + 1) * C words of scratch.
+// out[p] = from[p] +/- sum_{c, q: loc[c][q] == p} (vals[c][q] - sub[c]) mod 2^b for every p < total, where from = src_dev when it
+// is given (it may be out_dev: accumulate in place) and the constant base otherwise; negate subtracts the sum (a decrypt:
+// aggregate - minus-mask in the pass that builds the mask).  At most kMaxScatter clients per call;
+// start_dev = (span_count(total) + 1) * C words of scratch.
 constexpr int kMaxScatter = 64;
 uint64_t span_count(uint64_t total);
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
-                              uint32_t *start_dev, bool accumulate_into_out, uint64_t *out_dev);
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev);
 // out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
 hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uint8_t *sel_dev,
                                  const uint64_t *stream_dev, uint64_t *out_dev);

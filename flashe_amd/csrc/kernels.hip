@@ -2424,124 +2424,170 @@ __global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t total,
 
 // Sparse reduce over SORTED location lists, two launches for any number of clients.
 // The dense vector is cut into spans of kSpan positions, one workgroup each.  Kernel A: start[s][c] = first entry of
-// client c at or beyond position s * kSpan (one binary search per (span, client)).  Kernel B: the workgroup clears a
-// span-sized accumulator in LDS, adds every client's entries that fall into its span (128-bit add = two LDS atomics;
-// the low one returns the old value, which tells the lane exactly whether ITS add wrapped -- integer adds commute,
-// so the sum does not depend on the order), then writes base + accumulator for the WHOLE span: the dense output is
-// written exactly once, coalesced, and never read.
-constexpr int kSpan = 2048;
+// client c at or beyond position s * kSpan -- one thread per ENTRY: entry q opens every span between the span of entry
+// q - 1 and its own (most entries open none), one coalesced pass over the location lists instead of a binary search per
+// (span, client); it also reports lists that are not strictly increasing or reach beyond the vector.  Kernel B: the
+// workgroup (1,024 threads: the gathers are the slow part, measured against 256 / 512 threads and 1 K ... 8 K spans) clears a
+// span-sized accumulator in LDS, adds every client's entries that fall into its span (128-bit add =
+// two LDS atomics; the low one returns the old value, which tells the lane exactly whether ITS add wrapped -- integer
+// adds commute, so the sum does not depend on the order), then writes src + accumulator (or src - accumulator, base
+// instead of src when there is none) for the WHOLE span: the dense output is written exactly once, coalesced.
+constexpr int kSpan = 4096;         // positions per span: 64 KiB of 128-bit accumulators, two workgroups per CU
+constexpr int kSpanThreads = 1024;
+constexpr int kSpanBatch = 4;       // entries whose loads a lane keeps in flight at once
 struct ScatterTable {
     const uint32_t *loc[kMaxScatter];
     const uint64_t *vals[kMaxScatter];
     uint64_t k[kMaxScatter], sub_lo[kMaxScatter], sub_hi[kMaxScatter];
 };
 
-__global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const ScatterTable tb, int C, uint64_t n_spans, uint32_t *start)
+constexpr int kBoundsPerThread = 8;
+__global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const ScatterTable tb, int C, uint64_t n_spans, uint64_t total, uint32_t *start,
+                                                                     uint32_t *err_flag)
 {
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x;
-    if (i >= (n_spans + 1) * static_cast<uint64_t>(C)) return;
-    const int c = static_cast<int>(i % C);
-    const uint64_t pos = (i / C) * kSpan;
+    const int c = blockIdx.y;
+    const uint64_t k = tb.k[c];
     const uint32_t *loc = tb.loc[c];
-    uint64_t lo = 0, hi = tb.k[c];
-    while (lo < hi) {                                   // lower_bound(loc, pos)
-        const uint64_t mid = (lo + hi) >> 1;
-        if (loc[mid] < pos) lo = mid + 1; else hi = mid;
+#pragma unroll
+    for (int i = 0; i < kBoundsPerThread; i++) {
+        const uint64_t q = (static_cast<uint64_t>(blockIdx.x) * kBoundsPerThread + i) * kStreamThreads + threadIdx.x;
+        if (q > k) return;                               // q == k closes the list: the spans behind the last entry
+        const uint64_t prev = q ? loc[q - 1] : 0, cur = q < k ? loc[q] : 0;
+        if (q < k && (cur >= total || (q && cur <= prev))) *err_flag = 1;
+        const uint64_t s_first = q ? std::min<uint64_t>(prev / kSpan, n_spans) + 1 : 0;
+        const uint64_t s_last = q < k ? std::min<uint64_t>(cur / kSpan, n_spans) : n_spans;
+        for (uint64_t sp = s_first; sp <= s_last; sp++) start[sp * C + c] = static_cast<uint32_t>(q);
     }
-    start[i] = static_cast<uint32_t>(lo);
 }
 
-__global__ __launch_bounds__(kStreamThreads) void span_reduce_kernel(const ScatterTable tb, int C, int L, uint64_t total, const uint32_t *start,
-                                                                     uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo, uint64_t mask_hi,
-                                                                     bool accumulate_into_out, uint64_t *out, uint32_t *err_flag)
+// One batch of a span's entries, gathered into registers: flat entry f belongs to the client c with prefix[c] <= f < prefix[c + 1].
+struct SpanBatch { uint32_t r[kSpanBatch]; int own[kSpanBatch]; u128 v[kSpanBatch]; };
+
+template <int THREADS>
+__device__ __forceinline__ void span_gather(SpanBatch &g, uint32_t f0, uint32_t n_entries, const uint32_t *prefix, const uint32_t *begin,
+                                            const uint32_t *const *s_loc, const uint64_t *const *s_vals, int L, uint32_t p0)
 {
-    __shared__ unsigned long long acc[2 * kSpan];
-    __shared__ uint32_t s_begin[kMaxScatter], s_prefix[kMaxScatter + 1];
+#pragma unroll
+    for (int e = 0; e < kSpanBatch; e++) {
+        const uint32_t fe = f0 + e * THREADS;
+        const uint32_t f = fe < n_entries ? fe : f0;     // surplus slots re-read the first entry (f0 < n_entries) and are not added
+        int c = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (prefix[c + step] <= f) c += step;
+        g.own[e] = c;
+        const uint64_t q = static_cast<uint64_t>(begin[c]) + (f - prefix[c]);
+        g.r[e] = s_loc[c][q] - p0;
+        g.v[e] = L == 2 ? ld128(s_vals[c] + 2 * q) : static_cast<u128>(s_vals[c][q]);
+    }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void span_add(const SpanBatch &g, uint32_t f0, uint32_t n_entries, unsigned long long *acc, const uint64_t *s_sub, int L,
+                                         uint64_t span_len, uint32_t *err_flag)
+{
+#pragma unroll
+    for (int e = 0; e < kSpanBatch; e++) {
+        if (f0 + e * THREADS >= n_entries) break;
+        if (g.r[e] >= span_len) { *err_flag = 1; continue; }      // position >= total, or a list that is not strictly increasing
+        const u128 w = g.v[e] - ((static_cast<u128>(s_sub[2 * g.own[e] + 1]) << 64) | s_sub[2 * g.own[e]]);
+        const unsigned long long wlo = static_cast<unsigned long long>(w), whi = static_cast<unsigned long long>(w >> 64);
+        if (L == 2) {
+            const unsigned long long old = atomicAdd(&acc[2 * g.r[e]], wlo);
+            atomicAdd(&acc[2 * g.r[e] + 1], whi + (old + wlo < old ? 1ull : 0ull));
+        } else {
+            atomicAdd(&acc[g.r[e]], wlo);
+        }
+    }
+}
+
+template <int SPAN, int THREADS>
+__global__ __launch_bounds__(THREADS) void span_reduce_kernel(const ScatterTable tb, int C, int L, uint64_t total, const uint32_t *start,
+                                                              uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo, uint64_t mask_hi,
+                                                              const uint64_t *src, bool negate, uint64_t *out, uint32_t *err_flag)
+{
+    __shared__ unsigned long long acc[2 * SPAN];
+    __shared__ uint32_t s_begin[kMaxScatter], s_prefix[2 * kMaxScatter + 2];
     __shared__ const uint32_t *s_loc[kMaxScatter];
     __shared__ const uint64_t *s_vals[kMaxScatter];
     __shared__ uint64_t s_sub[2 * kMaxScatter];
-    const uint64_t span = blockIdx.x, p0 = span * kSpan;
-    const uint64_t span_len = total - p0 < kSpan ? total - p0 : kSpan;
+    const uint64_t span = blockIdx.x, p0 = span * SPAN;
+    const uint64_t span_len = total - p0 < SPAN ? total - p0 : SPAN;
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * kSpan; i += kStreamThreads) acc[i] = 0;
-    // this span's slice [begin, begin + count) of every client's list, and the running total of the counts: the entries
-    // of ALL clients are then walked as one flat index space, so every load of the span is independent of the others
-    if (tid < C) {
-        const uint32_t b0 = start[span * C + tid], b1 = start[(span + 1) * C + tid];
-        s_begin[tid] = b0;
-        s_prefix[tid + 1] = b1 - b0;
-        s_loc[tid] = tb.loc[tid]; s_vals[tid] = tb.vals[tid];
-        s_sub[2 * tid] = tb.sub_lo[tid]; s_sub[2 * tid + 1] = tb.sub_hi[tid];
-    }
-    // entries at or beyond the end of the last span belong to no span at all
-    if (span + 1 == gridDim.x && tid < C && start[(span + 1) * C + tid] < tb.k[tid]) *err_flag = 1;
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        s_prefix[0] = 0;
-        for (int c = 0; c < C; c++) { run += s_prefix[c + 1]; s_prefix[c + 1] = run; }
+    for (int i = tid; i < (L == 2 ? 2 : 1) * SPAN; i += THREADS) acc[i] = 0;
+    // this span's slice [begin, begin + count) of every client's list (clamped: a malformed list was reported by kernel A and
+    // must not turn into reads outside the lists) and the running total of the counts, by a shuffle scan in the first wave:
+    // the entries of ALL clients are then walked as one flat index space -- consecutive lanes read consecutive entries
+    if (tid < 64) {
+        uint32_t cnt = 0;
+        if (tid < C) {
+            const uint32_t kc = static_cast<uint32_t>(tb.k[tid]);
+            const uint32_t b0 = min(start[span * C + tid], kc), b1 = min(start[(span + 1) * C + tid], kc);
+            cnt = b1 > b0 ? b1 - b0 : 0;
+            s_begin[tid] = b0;
+            s_loc[tid] = tb.loc[tid]; s_vals[tid] = tb.vals[tid];
+            s_sub[2 * tid] = tb.sub_lo[tid]; s_sub[2 * tid + 1] = tb.sub_hi[tid];
+        }
+        uint32_t run = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(run, d, 64);
+            if (tid >= d) run += up;
+        }
+        if (tid == 0) s_prefix[0] = 0;
+        s_prefix[tid + 1] = tid < C ? run : 0xffffffffu;        // sentinels: the owner search needs no bounds
+        s_prefix[tid + 65] = 0xffffffffu;
     }
     __syncthreads();
     const uint32_t n_entries = s_prefix[C];
-    for (uint32_t f = tid; f < n_entries; f += kStreamThreads) {
-        int lo = 0, hi = C;                             // client c with s_prefix[c] <= f < s_prefix[c + 1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_prefix[mid] <= f) lo = mid; else hi = mid;
-        }
-        const int c = lo;
-        const uint64_t q = static_cast<uint64_t>(s_begin[c]) + (f - s_prefix[c]);
-        const uint32_t r = s_loc[c][q] - static_cast<uint32_t>(p0);
-        if (r >= span_len) { *err_flag = 1; continue; }    // position >= total, or a list that is not strictly increasing
-        if (L == 2) {
-            const u128 v = ld128(s_vals[c] + 2 * q) - ((static_cast<u128>(s_sub[2 * c + 1]) << 64) | s_sub[2 * c]);
-            const unsigned long long vlo = static_cast<unsigned long long>(v), vhi = static_cast<unsigned long long>(v >> 64);
-            const unsigned long long old = atomicAdd(&acc[2 * r], vlo);
-            atomicAdd(&acc[2 * r + 1], vhi + (old + vlo < old ? 1ull : 0ull));
-        } else {
-            atomicAdd(&acc[r], static_cast<unsigned long long>(s_vals[c][q] - s_sub[2 * c]));
-        }
+    for (uint32_t f0 = tid; f0 < n_entries; f0 += kSpanBatch * THREADS) {
+        SpanBatch g;
+        span_gather<THREADS>(g, f0, n_entries, s_prefix, s_begin, s_loc, s_vals, L, static_cast<uint32_t>(p0));
+        span_add<THREADS>(g, f0, n_entries, acc, s_sub, L, span_len, err_flag);
     }
     __syncthreads();
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
     const u128 base = (static_cast<u128>(base_hi) << 64) | base_lo;
-    for (uint64_t r = tid; r < span_len; r += kStreamThreads) {
+    for (uint64_t r = tid; r < span_len; r += THREADS) {
         if (L == 2) {
-            u128 v = base + ((static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r]);
-            if (accumulate_into_out) v += ld128(out + 2 * (p0 + r));
-            st128_nt(out + 2 * (p0 + r), v & mask);
+            const u128 a = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
+            const u128 from = src ? ld128_nt(src + 2 * (p0 + r)) : base;
+            st128_nt(out + 2 * (p0 + r), (negate ? from - a : from + a) & mask);
         } else {
-            uint64_t v = base_lo + acc[r];
-            if (accumulate_into_out) v += out[p0 + r];
-            __builtin_nontemporal_store(v & mask_lo, out + p0 + r);
+            const uint64_t from = src ? __builtin_nontemporal_load(src + p0 + r) : base_lo;
+            __builtin_nontemporal_store((negate ? from - acc[r] : from + acc[r]) & mask_lo, out + p0 + r);
         }
     }
 }
 
 uint64_t span_count(uint64_t total) { return (total + kSpan - 1) / kSpan; }
 
-// out[p] = base + sum over clients c and entries q with loc[c][q] == p of (vals[c][q] - sub[c])   (mod 2^b), every p < total;
-// loc[c] strictly increasing.  start_dev: (span_count(total) + 1) * C words of scratch.
+// out[p] = from[p] +/- sum over clients c and entries q with loc[c][q] == p of (vals[c][q] - sub[c])   (mod 2^b), every p < total,
+// from = src_dev when given (may be out_dev), the constant base otherwise; loc[c] strictly increasing.
+// start_dev: (span_count(total) + 1) * C words of scratch.
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
-                              uint32_t *start_dev, bool accumulate_into_out, uint64_t *out_dev)
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev)
 {
     if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
     if (total == 0) return hipSuccess;
     const int L = env.b > 64 ? 2 : 1;
     ScatterTable tb{};
+    uint64_t kmax = 0;
     for (int c = 0; c < C; c++) {
+        if (k[c] >= (1ull << 32)) return hipErrorInvalidValue;
         tb.loc[c] = loc_dev[c]; tb.vals[c] = vals_dev[c]; tb.k[c] = k[c];
         tb.sub_lo[c] = sub ? sub[static_cast<size_t>(L) * c] : 0;
         tb.sub_hi[c] = sub && L == 2 ? sub[2 * c + 1] : 0;
+        kmax = std::max(kmax, k[c]);
     }
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
-    const uint64_t n_spans = span_count(total), n_bounds = (n_spans + 1) * static_cast<uint64_t>(C);
-    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>((n_bounds + kStreamThreads - 1) / kStreamThreads)), dim3(kStreamThreads), 0,
-                       env.stream, tb, C, n_spans, start_dev);
-    hipLaunchKernelGGL(span_reduce_kernel, dim3(static_cast<unsigned>(n_spans)), dim3(kStreamThreads), 0, env.stream, tb, C, L, total, start_dev,
-                       base_lo, base_hi, lo, hi, accumulate_into_out, out_dev, env.err_flag);
+    const uint64_t n_spans = span_count(total);
+    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0,
+                       env.stream, tb, C, n_spans, total, start_dev, env.err_flag);
+    hipLaunchKernelGGL((span_reduce_kernel<kSpan, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
+                       start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
     return hipGetLastError();
 }
 

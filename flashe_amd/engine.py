@@ -328,6 +328,13 @@ class Engine:
         fn = self._lib.flashe_sparse_minus_mask_sorted_dev if sorted_lists else self._lib.flashe_sparse_minus_mask_dev
         self._check(fn(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, self._ptr(out)))
 
+    def sparse_decrypt_dev(self, it, locs, ks, total, n_jobs, agg, out, sorted_lists=False):
+        """out = (agg - dense minus-mask of the location lists) mod 2^b in the pass that builds the mask."""
+        p, _keep = self._ptr_array(locs)
+        k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        self._check(self._lib.flashe_sparse_decrypt_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs,
+                                                        1 if sorted_lists else 0, self._ptr(agg), self._ptr(out)))
+
     def sparse_dense_mask_dev(self, it, sels, total, out):
         p, _keep = self._ptr_array(sels)
         self._check(self._lib.flashe_sparse_dense_mask_dev(self._h, it, len(sels), p, total, self._ptr(out)))

@@ -295,6 +295,12 @@ int flashe_sparse_minus_mask_dev(flashe_ctx *ctx, uint32_t iter, int C, const ui
  * itself when the lists qualify. */
 int flashe_sparse_minus_mask_sorted_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev,
                                         const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out_dev);
+/* The single-mask sparse DECRYPT in the pass that builds the mask: out = (agg - minus-mask) mod 2^b, i.e. set_idx_list_single's
+ * sparse branch (jzf_flashe.py:316-343) followed by _multiprocessing_decrypt_single's `value - minus` (:531-532) without the dense
+ * mask ever reaching HBM.  Same arguments as flashe_sparse_minus_mask[_sorted]_dev plus the aggregate (total x L limbs, must not be out_dev).
+ * new: fusion of two reference steps. */
+int flashe_sparse_decrypt_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                              uint64_t total, uint32_t n_jobs, int sorted, const uint64_t *agg_dev, uint64_t *out_dev);
 int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc,
                              const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out);
 /* Dense-position selected masks -- _static_prepare_decrypt_spar as ONE chunk

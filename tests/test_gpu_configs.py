@@ -169,6 +169,9 @@ def test_config5_sparse_top1pct_50_clients(E, oracle):
     assert np.array_equal(mask, oracle.sparse_minus_mask(KEY, it, locs, total, J, b))
     eng.combine_dev(total, d_agg, 2, None, d_mask, d_dec)
     dec = d_dec.download(np.uint64, 2 * total).reshape(total, 2)
+    # what bench.py --config 5 runs: mask construction and decrypt in one pass, the dense mask never reaches HBM
+    eng.sparse_decrypt_dev(it, d_loc, [k] * C, total, J, d_agg, d_mask, sorted_lists=True)
+    assert np.array_equal(d_mask.download(np.uint64, 2 * total).reshape(total, 2), dec)
     want = np.full(total, np.uint64((C * zero) & (2 ** 64 - 1)), dtype=np.uint64)
     whi = np.zeros(total, dtype=np.uint64)
     for c in range(C):

@@ -698,7 +698,7 @@ def test_sparse_config5_shape_small(E, oracle):
 
 
 @pytest.mark.parametrize("b,total,C", [(128, 50_000, 7), (100, 4099, 3), (64, 30_001, 5), (20, 9999, 9), (128, 64, 4), (128, 300_000, 70), (128, 2048, 2),
-                                       (128, 2049, 2)])
+                                       (128, 2049, 2), (128, 4096, 2), (128, 4097, 3), (64, 8193, 4)])
 def test_sparse_aggregate_fused_vs_dense_path(E, oracle, b, total, C):
     """flashe_sparse_aggregate_dev == expand_to_dense per client + element-wise reduce (overlapping location sets,
     full-range zero values, an empty client, a client that covers every position)."""
@@ -730,6 +730,17 @@ def test_sparse_aggregate_fused_vs_dense_path(E, oracle, b, total, C):
     for sorted_lists in (False, True):
         eng.sparse_minus_mask_dev(4, dl, ks, total, 16, out, sorted_lists=sorted_lists)
         assert np.array_equal(out.download(np.uint64, total * Lb).reshape(total, Lb), mm), sorted_lists
+    # the single-mask sparse decrypt in the pass that builds the mask: out = aggregate - minus-mask (jzf_flashe.py:531-532)
+    agg_in = rand_limbs(rng, total, b)
+    d_agg = eng.upload(agg_in)
+    want_dec = oracle.combine(b, agg_in, None, mm)
+    for sorted_lists in (False, True):
+        out.upload(np.full(total * Lb, 0xA5A5A5A5A5A5A5A5, dtype=np.uint64))
+        eng.sparse_decrypt_dev(4, dl, ks, total, 16, d_agg, out, sorted_lists=sorted_lists)
+        assert np.array_equal(out.download(np.uint64, total * Lb).reshape(total, Lb), want_dec), ("fused decrypt", sorted_lists)
+        assert np.array_equal(d_agg.download(np.uint64, total * Lb).reshape(total, Lb), agg_in)       # the aggregate is only read
+    with pytest.raises(E.FlasheError):
+        eng.sparse_decrypt_dev(4, dl, ks, total, 16, out, out, sorted_lists=True)                    # in place is refused
     if b not in (64, 128):
         with pytest.raises(Exception):                     # a zero value wider than int_bits
             eng.sparse_aggregate_dev(total, dl[:1], ks[:1], dv[:1], [[2 ** 64 - 1, 2 ** 64 - 1]], out)
