@@ -192,9 +192,20 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 
 size_t vec_bytes(const flashe_ctx *ctx, uint64_t n) { return static_cast<size_t>(n) * ctx->limbs * 8; }
 
-// RAII temp device buffer for the host-pointer wrappers
-constexpr size_t kPoolBlockMax = 64u << 20;        // larger staging buffers are not kept: at that size the transfer dominates
-constexpr size_t kPoolBlocks = 24;
+// RAII temp device buffer for the host-pointer wrappers.  Staging blocks are kept by the ctx and reused: a hipMalloc + hipFree
+// pair of a 160 MB block costs more than moving 160 MB over PCIe Gen5 on this platform (measured 7 ms against 2.9 ms,
+// tests/perf/e2e_calls.py).  The blocks a ctx keeps are bounded by a byte budget (FLASHE_STAGING_POOL_MB, default 8 GiB of the
+// 288 GB); beyond it the largest free block makes room, and a request that still does not fit is a plain allocation.
+constexpr size_t kPoolBlocks = 64;
+
+size_t pool_budget()
+{
+    static const size_t v = [] {
+        const char *e = getenv("FLASHE_STAGING_POOL_MB");
+        return (e && atoll(e) >= 0 ? static_cast<size_t>(atoll(e)) : static_cast<size_t>(8192)) << 20;
+    }();
+    return v;
+}
 
 struct Tmp {
     void *p = nullptr;
@@ -209,24 +220,48 @@ struct Tmp {
     hipError_t alloc(flashe_ctx *ctx, size_t bytes)
     {
         if (bytes == 0) bytes = 16;
-        if (bytes <= kPoolBlockMax) {
-            int best = -1;
-            for (size_t i = 0; i < ctx->pool.size(); i++)
-                if (!ctx->pool[i].used && ctx->pool[i].cap >= bytes && (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap)) best = static_cast<int>(i);
-            if (best < 0 && ctx->pool.size() < kPoolBlocks) {
-                size_t cap = 4096;
-                while (cap < bytes) cap <<= 1;
-                void *q = nullptr;
-                const hipError_t e = hipMalloc(&q, cap);
-                if (e != hipSuccess) return e;
-                ctx->pool.push_back(flashe_ctx::PoolBlock{q, cap, false});
-                best = static_cast<int>(ctx->pool.size()) - 1;
+        int best = -1;
+        for (size_t i = 0; i < ctx->pool.size(); i++)
+            if (!ctx->pool[i].used && ctx->pool[i].cap >= bytes && (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap)) best = static_cast<int>(i);
+        if (best < 0) {
+            // small blocks in powers of two, large ones in 2-MiB steps (a 160 MB vector must not pin 256 MB)
+            size_t cap = 4096;
+            if (bytes > (8u << 20)) cap = (bytes + (2u << 20) - 1) & ~static_cast<size_t>((2u << 20) - 1);
+            else while (cap < bytes) cap <<= 1;
+            size_t held = 0;
+            for (const auto &b : ctx->pool) held += b.cap;
+            // make room: drop free blocks, largest first (they are all too small for this request)
+            while ((held + cap > pool_budget() || ctx->pool.size() >= kPoolBlocks) && !ctx->pool.empty()) {
+                int victim = -1;
+                for (size_t i = 0; i < ctx->pool.size(); i++)
+                    if (!ctx->pool[i].used && (victim < 0 || ctx->pool[i].cap > ctx->pool[victim].cap)) victim = static_cast<int>(i);
+                if (victim < 0) break;
+                // live Tmp objects hold slot numbers: only the LAST slot can be removed without renumbering, so swap-free
+                // removal is limited to it; any other victim is freed in place and its slot kept as an empty one
+                (void)hipStreamSynchronize(ctx->env.stream);
+                (void)hipFree(ctx->pool[victim].p);
+                held -= ctx->pool[victim].cap;
+                if (static_cast<size_t>(victim) + 1 == ctx->pool.size()) ctx->pool.pop_back();
+                else { ctx->pool[victim].p = nullptr; ctx->pool[victim].cap = 0; }
             }
-            if (best >= 0) {
-                ctx->pool[best].used = true;
-                p = ctx->pool[best].p; owner = ctx; slot = best;
-                return hipSuccess;
+            if (held + cap <= pool_budget()) {
+                int slot_new = -1;
+                for (size_t i = 0; i < ctx->pool.size(); i++)
+                    if (!ctx->pool[i].used && ctx->pool[i].cap == 0) { slot_new = static_cast<int>(i); break; }
+                if (slot_new >= 0 || ctx->pool.size() < kPoolBlocks) {
+                    void *q = nullptr;
+                    const hipError_t e = hipMalloc(&q, cap);
+                    if (e != hipSuccess) return e;
+                    if (slot_new >= 0) ctx->pool[slot_new] = flashe_ctx::PoolBlock{q, cap, false};
+                    else { ctx->pool.push_back(flashe_ctx::PoolBlock{q, cap, false}); slot_new = static_cast<int>(ctx->pool.size()) - 1; }
+                    best = slot_new;
+                }
             }
+        }
+        if (best >= 0) {
+            ctx->pool[best].used = true;
+            p = ctx->pool[best].p; owner = ctx; slot = best;
+            return hipSuccess;
         }
         return hipMalloc(&p, bytes);
     }
@@ -460,6 +495,22 @@ int flashe_dev_free(flashe_ctx *ctx, void *dptr)
 {
     CHECK_CTX(ctx);
     if (dptr) { HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); HIP_TRY(ctx, hipFree(dptr)); }
+    return FLASHE_OK;
+}
+// Page-locked host memory for callers that keep their vectors on the host: the DMA engines read and write it directly (no
+// staging copy, no page pinning per transfer), and a buffer that is REUSED spares the page faults a fresh allocation pays on
+// its first transfer.  Not tied to a ctx: a buffer may outlive the ctx it was used with.
+int flashe_host_alloc(size_t bytes, void **hptr)
+{
+    if (!hptr) return FLASHE_EINVAL;
+    *hptr = nullptr;
+    const hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocPortable);
+    if (e != hipSuccess) { *hptr = nullptr; return fail(nullptr, FLASHE_ENOMEM, "hipHostMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    return FLASHE_OK;
+}
+int flashe_host_free(void *hptr)
+{
+    if (hptr && hipHostFree(hptr) != hipSuccess) return fail(nullptr, FLASHE_EIO, "hipHostFree failed");
     return FLASHE_OK;
 }
 int flashe_memcpy_h2d(flashe_ctx *ctx, void *dst, const void *src, size_t bytes)

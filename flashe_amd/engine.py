@@ -2,6 +2,9 @@
 int_bits); `DeviceBuffer` = a vector resident in HBM.  No arithmetic happens in Python.
 """
 import ctypes
+import os
+import threading
+import weakref
 
 import numpy as np
 
@@ -53,6 +56,87 @@ def prp_block(key, block):
     return bytes(out)
 
 
+class _HostPool:
+    """Recycled host memory behind the result arrays of the host-array API.  A fresh 160 MB array costs 4-7 ms of page faults on its
+    first transfer -- more than the 2.9 ms PCIe Gen5 needs to fill it (tests/perf/e2e_calls.py) -- and NumPy hands large arrays
+    straight back to the OS, so every call would pay that again.  Blocks the caller has dropped (all views of the array dead) are
+    kept and reused, up to FLASHE_HOST_POOL_MB (default 4096; 0 = plain np.empty).  FLASHE_HOST_POOL_PINNED=1 backs the blocks
+    with page-locked memory (flashe_host_alloc) for platforms whose pageable transfers are slow; allocating those is itself slow,
+    which only a long-running caller earns back."""
+    MIN_BYTES = 1 << 20
+    STEP = 2 << 20
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._free = {}                 # capacity -> [block]
+        self._held = 0                  # bytes parked in the free lists
+        self._budget = max(0, int(os.environ.get("FLASHE_HOST_POOL_MB", "4096"))) << 20
+        self._pinned = os.environ.get("FLASHE_HOST_POOL_PINNED", "0") not in ("", "0")
+
+    class _Pinned:
+        def __init__(self, cap):
+            p = c_vp()
+            rc = _lib.load().flashe_host_alloc(cap, ctypes.byref(p))
+            if rc:
+                raise MemoryError("flashe_host_alloc")
+            self.addr = p.value
+
+        def __del__(self):
+            try:
+                _lib.load().flashe_host_free(self.addr)
+            except Exception:
+                pass
+
+    class _Pageable:
+        def __init__(self, cap):
+            self.arr = np.empty(cap, dtype=np.uint8)
+            self.addr = self.arr.ctypes.data
+
+    def empty(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes < self.MIN_BYTES or self._budget == 0:
+            return np.zeros(shape, dtype=dtype)
+        cap = (nbytes + self.STEP - 1) // self.STEP * self.STEP
+        block = None
+        with self._lock:
+            lst = self._free.get(cap)
+            if lst:
+                block = lst.pop()
+                self._held -= cap
+        if block is None:
+            try:
+                block = (self._Pinned if self._pinned else self._Pageable)(cap)
+            except MemoryError:
+                return np.empty(shape, dtype=dtype)
+        lease = (ctypes.c_char * nbytes).from_address(block.addr)      # dies with the last view of the array
+        fin = weakref.finalize(lease, self._release, block, cap)
+        fin.atexit = False
+        return np.frombuffer(lease, dtype=dtype).reshape(shape)
+
+    def _release(self, block, cap):
+        with self._lock:
+            if self._held + cap <= self._budget:
+                self._free.setdefault(cap, []).append(block)
+                self._held += cap
+        # otherwise the block dies here
+
+    def trim(self):
+        """Give every parked block back."""
+        with self._lock:
+            self._free.clear()
+            self._held = 0
+
+
+_HOST_POOL = _HostPool()
+
+
+def host_empty(shape, dtype=np.uint64):
+    """An uninitialised result array, from the recycling pool when it is large (see _HostPool)."""
+    return _HOST_POOL.empty(shape, dtype)
+
+
 class DeviceBuffer:
     """`nbytes` of HBM owned by an Engine.  `.ptr` is the raw device address."""
 
@@ -82,7 +166,7 @@ class DeviceBuffer:
 
     def download(self, dtype=np.uint64, count=None):
         n = self.nbytes // np.dtype(dtype).itemsize if count is None else count
-        out = np.empty(n, dtype=dtype)
+        out = host_empty(n, dtype)
         self.engine._check(self.engine._lib.flashe_memcpy_d2h(self.engine._h, out.ctypes.data, self.ptr, out.nbytes))
         return out
 
@@ -349,7 +433,7 @@ class Engine:
         return arr
 
     def mask(self, it, idx_list, n, n_jobs):
-        out = np.zeros((n, self.limbs), dtype=np.uint64)
+        out = host_empty((n, self.limbs))
         p, _keep = _u32_list(idx_list)
         self._check(self._lib.flashe_mask(self._h, it, p, len(idx_list), n, n_jobs, out.ctypes.data))
         return out
@@ -357,14 +441,14 @@ class Engine:
     def encrypt(self, it, idx, scheme, n_jobs, pt):
         pt = self._vec(pt, allow_pt=True)
         n = pt.shape[0]
-        ct = np.zeros((n, self.limbs), dtype=np.uint64)
+        ct = host_empty((n, self.limbs))
         self._check(self._lib.flashe_encrypt(self._h, it, idx, scheme, n, n_jobs, pt.ctypes.data, pt.shape[1], ct.ctypes.data))
         return ct
 
     def decrypt(self, it, add_idx, minus_idx, n_jobs, ct):
         ct = self._vec(ct)
         n = ct.shape[0]
-        out = np.zeros_like(ct)
+        out = host_empty(ct.shape)
         pa, _a = _u32_list(add_idx)
         pm, _m = _u32_list(minus_idx)
         self._check(self._lib.flashe_decrypt(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs,
@@ -376,7 +460,7 @@ class Engine:
         n = inp.shape[0]
         add = self._vec(add) if add is not None else None
         minus = self._vec(minus) if minus is not None else None
-        out = np.zeros((n, self.limbs), dtype=np.uint64)
+        out = host_empty((n, self.limbs))
         self._check(self._lib.flashe_combine(self._h, n, inp.ctypes.data, inp.shape[1],
                                              add.ctypes.data if add is not None else None,
                                              minus.ctypes.data if minus is not None else None, out.ctypes.data))
@@ -387,7 +471,7 @@ class Engine:
         n = cts[0].shape[0]
         if any(c.shape[0] != n for c in cts):
             raise ValueError("operands differ in length")
-        out = np.zeros((n, self.limbs), dtype=np.uint64)
+        out = host_empty((n, self.limbs))
         tab = (c_vp * len(cts))(*[c.ctypes.data for c in cts])
         self._check(self._lib.flashe_aggregate_elem(self._h, len(cts), ctypes.cast(tab, ctypes.POINTER(c_vp)), n, out.ctypes.data))
         return out
@@ -414,7 +498,7 @@ class Engine:
         p = np.ascontiguousarray(p, dtype=np.uint64).reshape(-1)
         if p.shape[0] != (n * self.int_bits + 63) // 64:
             raise ValueError("packed operand has the wrong number of limbs")
-        out = np.zeros((n, self.limbs), dtype=np.uint64)
+        out = host_empty((n, self.limbs))
         self._check(self._lib.flashe_unpack(self._h, n, p.ctypes.data, out.ctypes.data))
         return out
 
@@ -422,7 +506,7 @@ class Engine:
         loc = np.ascontiguousarray(loc, dtype=np.uint32)
         vals = self._vec(vals) if len(loc) else np.zeros((0, self.limbs), dtype=np.uint64)
         z = (c_u64 * 2)(*([int(v) for v in np.asarray(zero_limbs).reshape(-1)] + [0])[:2])
-        out = np.zeros((total, self.limbs), dtype=np.uint64)
+        out = host_empty((total, self.limbs))
         self._check(self._lib.flashe_expand_to_dense(self._h, total, len(loc), loc.ctypes.data, vals.ctypes.data,
                                                      ctypes.cast(z, c_u64p), out.ctypes.data))
         return out
@@ -431,7 +515,7 @@ class Engine:
         locs = [np.ascontiguousarray(l, dtype=np.uint32) for l in locs]
         tab = (c_vp * max(len(locs), 1))(*[l.ctypes.data for l in locs])
         k = (c_u64 * max(len(locs), 1))(*[len(l) for l in locs])
-        out = np.zeros((total, self.limbs), dtype=np.uint64)
+        out = host_empty((total, self.limbs))
         self._check(self._lib.flashe_sparse_minus_mask(self._h, it, len(locs), ctypes.cast(tab, ctypes.POINTER(c_vp)),
                                                        ctypes.cast(k, c_u64p), total, n_jobs, out.ctypes.data))
         return out
@@ -441,7 +525,7 @@ class Engine:
         if any(s.shape[0] != total for s in sels):
             raise ValueError("selector length must equal total")
         tab = (c_vp * max(len(sels), 1))(*[s.ctypes.data for s in sels])
-        out = np.zeros((total, self.limbs), dtype=np.uint64)
+        out = host_empty((total, self.limbs))
         self._check(self._lib.flashe_sparse_dense_mask(self._h, it, len(sels), ctypes.cast(tab, ctypes.POINTER(c_vp)),
                                                        total, out.ctypes.data))
         return out

@@ -83,6 +83,10 @@ int flashe_prp_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16
 /* ---- device memory, stream, events -------------------------------------------------- */
 int flashe_dev_alloc(flashe_ctx *ctx, size_t bytes, void **dptr);
 int flashe_dev_free(flashe_ctx *ctx, void *dptr);
+/* new: page-locked (pinned) host memory, for callers that hand host vectors to the host-pointer calls repeatedly: DMA without
+ * a staging copy, and a reused buffer spares the page faults of a fresh one.  Independent of any ctx. */
+int flashe_host_alloc(size_t bytes, void **hptr);
+int flashe_host_free(void *hptr);
 int flashe_memcpy_h2d(flashe_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int flashe_memcpy_d2h(flashe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int flashe_memcpy_d2d(flashe_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);

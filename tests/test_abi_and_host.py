@@ -91,3 +91,38 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
         src.write_text('#include "flashe.h"\nint main(void) { return FLASHE_OK + (int)sizeof(flashe_ctx *) * 0; }\n')
         subprocess.check_call([comp, std, "-Wall", "-Werror", "-pedantic", "-I", os.path.dirname(hdr), "-c", str(src),
                                "-o", str(tmp_path / f"t_{ext}.o")])
+
+
+def test_host_result_pool_recycles_only_dead_arrays(monkeypatch):
+    """The result arrays of the host-array API come from a recycling pool (engine._HostPool): a block is reused only after EVERY
+    view of the array that leased it is gone, two live arrays never share memory, small arrays stay plain (zeroed) NumPy
+    allocations, and the parked bytes respect the budget."""
+    import gc
+    import numpy as np
+    from flashe_amd import engine
+    pool = engine._HostPool()
+    a = pool.empty((300_000, 2), np.uint64)                     # 4.8 MB
+    assert a.shape == (300_000, 2) and a.dtype == np.uint64 and a.flags.writeable
+    addr = a.ctypes.data
+    a[:] = 5
+    view = a[100:200, 1]
+    del a
+    b = pool.empty((300_000, 2), np.uint64)
+    assert b.ctypes.data != addr, "a block with a live view was handed out again"
+    assert int(view.sum()) == 500
+    del view
+    gc.collect()
+    c = pool.empty((300_000, 2), np.uint64)
+    assert c.ctypes.data == addr, "a dead array's block was not recycled"
+    small = pool.empty(1000, np.float64)
+    assert small.base is None and not small.any()               # an ordinary zeroed array
+    # budget: parked bytes never exceed it
+    monkeypatch.setenv("FLASHE_HOST_POOL_MB", "6")
+    tight = engine._HostPool()
+    xs = [tight.empty(500_000, np.uint64) for _ in range(4)]    # 4 MB each
+    del xs
+    gc.collect()
+    assert tight._held <= 6 << 20
+    monkeypatch.setenv("FLASHE_HOST_POOL_MB", "0")
+    off = engine._HostPool()
+    assert off.empty(500_000, np.uint64).base is None
