@@ -63,6 +63,9 @@ def parse():
                          "exchange hide under the next chunk's launch; pipelined: last client's encrypt chunked, reduce / exchange / "
                          "decrypt on a side stream; sequential: all local encrypts in one launch, then reduce (+ exchange) fused with "
                          "the decrypt")
+    ap.add_argument("--cus-free", type=int, default=None,
+                    help="PRF launches leave this many CUs free for the RCCL transfer kernels of the overlapped schedules (default: 0, or "
+                         "whichever of 0 / 16 / 32 / 48 calibrates fastest when ranks exchange)")
     ap.add_argument("--force-dist", action="store_true",
                     help="with 1 GPU: still create the RCCL communicator and run the N > 1 exchange path (world size 1)")
     ap.add_argument("--settle-rounds", type=int, default=32,
@@ -400,18 +403,29 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
                 raise
             return False
 
-    def quick_ms(cand, rounds=8):
+    # An RCCL transfer kernel (36.8 KiB of LDS, 248-256 VGPRs per lane) never shares a CU with a PRF workgroup (128 KiB of LDS), and it
+    # starts only when ALL its channels find a CU: beside a PRF launch that fills the device it simply waits for the launch to end
+    # (tests/perf/rccl_overlap.py: 16 channels need 16 free CUs, the default configuration 32).  So the schedules that hide the
+    # exchange under the next chunk's encrypts are also tried with the PRF launches leaving CUs free; results do not depend on it.
+    cus = eng.cu_count
+    free_options = [args.cus_free] if args.cus_free is not None else [0, 16, 32, 48] if (rnd.exchange and not args.test_comm_dir) else [0]
+
+    def quick_ms(cand, free=0, rounds=8):
         """Untimed-region calibration: ms per round of a schedule, MAX over ranks."""
+        eng.set_cu_limit(cus - free if free else 0)
         for it in range(2):
             run_schedule(cand, it)
-        return timed_region(ops, rounds, lambda k: run_schedule(cand, k)) * 1e3 / rounds
+        ms = timed_region(ops, rounds, lambda k: run_schedule(cand, k)) * 1e3 / rounds
+        eng.set_cu_limit(0)
+        return ms
 
-    schedule, calibration = None, None
+    schedule, calibration, cus_free = None, None, args.cus_free or 0
     if calibrate and len(candidates) > 1:
         usable = [c for c in candidates if passes(c)]
         if len(usable) > 1:
-            calibration = {c: quick_ms(c) for c in usable}
-            schedule = min(calibration, key=calibration.get)
+            table = {(c, f): quick_ms(c, f) for c in usable for f in (free_options if c != "sequential" else [0])}
+            schedule, cus_free = min(table, key=table.get)
+            calibration = {(c if not f else f"{c}, {f} CUs left free"): ms for (c, f), ms in table.items()}
         elif usable:
             schedule = usable[0]
         candidates = []
@@ -426,6 +440,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
     # The parity check above leaves the GPU idle while the host compares 1e7 elements, and its clocks drop: run rounds
     # for ~0.1 s so that the timed region does not start on a cold device even when --warmup is small, then the W
     # warmup steps proper, right before the timed region.
+    eng.set_cu_limit(cus - cus_free if cus_free else 0)
     for it in range(args.settle_rounds):          # a fixed count: every rank must issue the same collectives
         run_schedule(schedule, it)
         if it % 8 == 7:
@@ -479,7 +494,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
                                          "(-> plaintext aggregate) and exchange hidden on a side stream",
                                 "pipelined": f"reduce / exchange / decrypt chunk-pipelined on a side stream ({Q} chunks)",
                                 "sequential": "two launches: all local encrypts, then reduce fused with decrypt"}[schedule],
-                   "schedule_calibration_ms": calibration, "collectives": ("TEST DOUBLE: files, all ranks on one GPU (figures meaningless)" if args.test_comm_dir else
+                   "schedule_calibration_ms": calibration, "cus_left_free_for_the_exchange": cus_free, "collectives": ("TEST DOUBLE: files, all ranks on one GPU (figures meaningless)" if args.test_comm_dir else
                                    "RCCL through libflashe_hip.so (no PyTorch)") if ops.comm else None,
                    "parity": "bit-exact (decrypted aggregate == plaintext sum on every rank, checked in-run)"},
         "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "flashe_ctx_destroy": (c_int, [c_vp]),
     "flashe_ctx_set_key": (c_int, [c_vp, c_u8p]),
     "flashe_ctx_int_bits": (c_int, [c_vp]),
+    "flashe_ctx_set_cu_limit": (c_int, [c_vp, c_int]),
+    "flashe_ctx_cu_count": (c_int, [c_vp]),
     "flashe_ctx_set_prf_backend": (c_int, [c_vp, c_int]),
     "flashe_last_error": (ctypes.c_char_p, [c_vp]),
     "flashe_selftest": (c_int, [c_vp]),

@@ -315,7 +315,7 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
             return bail(FLASHE_EIO, "hipStreamCreate", e);
         ctx->own_stream = true;
     }
-    ctx->env.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->env.num_cus = ctx->device_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->env.b = int_bits;
     // Te0 followed by Te1..Te3 (byte rotations of Te0): 4 KiB; the kernels fill LDS from the first KiB and use the
     // whole table for wave-uniform lookups through the scalar cache.  Word 1024 = the iter shift (kernels.hip), 0 by default.
@@ -401,6 +401,19 @@ int flashe_ctx_set_prf_backend(flashe_ctx *ctx, int backend)
     ctx->env.prf_backend = backend;
     return FLASHE_OK;
 }
+
+// The persistent launches of this ctx fill `cus` compute units instead of the whole device (0 = all again).  A PRF workgroup
+// holds 128 KiB of a CU's 160 KiB of LDS and most of its vector registers, so a kernel that needs more than the remainder --
+// RCCL's transfer kernels: 36.8 KiB of LDS, 248-256 VGPRs per lane -- only ever starts on a CU that has none: without a few
+// free CUs an exchange on another stream would wait for the whole PRF launch instead of running beside it.
+int flashe_ctx_set_cu_limit(flashe_ctx *ctx, int cus)
+{
+    CHECK_CTX(ctx);
+    if (cus < 0) return fail(ctx, FLASHE_EINVAL, "flashe_ctx_set_cu_limit: negative count");
+    ctx->env.num_cus = cus == 0 || cus > ctx->device_cus ? ctx->device_cus : cus;
+    return FLASHE_OK;
+}
+int flashe_ctx_cu_count(const flashe_ctx *ctx) { return ctx ? ctx->device_cus : FLASHE_EINVAL; }
 
 int flashe_ctx_int_bits(const flashe_ctx *ctx) { return ctx ? ctx->int_bits : FLASHE_EINVAL; }
 

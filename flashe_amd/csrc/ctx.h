@@ -9,6 +9,7 @@
 
 struct flashe_ctx {
     int device = 0;
+    int device_cus = 0;       // compute units of the device (env.num_cus is what launches may use: flashe_ctx_set_cu_limit)
     int int_bits = 0;
     int limbs = 0;
     bool own_stream = false;
@@ -24,8 +25,9 @@ struct flashe_ctx {
     Buf acc_tmp[2];   // ping-pong partial sums when a packed reduce has more than kMaxOps operands
     Buf sp_ws;        // sparsifier workspace (select state, histogram, per-block counts)
     Buf bounds;       // span reduce: first entry of every client in every span
-    // staging blocks of the host-pointer twins: hipMalloc / hipFree cost more than the kernels on LeNet-sized vectors, so blocks
-    // up to kPoolBlockMax bytes are kept and reused (the twins are synchronous: a block is free again when its call returns)
+    // staging blocks of the host-pointer twins: hipMalloc / hipFree cost more than the kernels on LeNet-sized vectors and more than
+    // the PCIe transfer on 160 MB ones, so blocks are kept and reused within a byte budget (the twins are synchronous: a block is
+    // free again when its call returns)
     struct PoolBlock { void *p; size_t cap; bool used; };
     std::vector<PoolBlock> pool;
     bool capturing = false;   // between flashe_graph_begin and flashe_graph_end

@@ -231,6 +231,15 @@ class Engine:
         assert len(key) == 32
         self._check(self._lib.flashe_ctx_set_key(self._h, (ctypes.c_uint8 * 32).from_buffer_copy(key)))
 
+    def set_cu_limit(self, cus):
+        """Persistent launches of this engine fill `cus` compute units (0 = all): leaves CUs free for kernels of another stream that
+        cannot share a CU with a PRF workgroup (RCCL's)."""
+        self._check(self._lib.flashe_ctx_set_cu_limit(self._h, int(cus)))
+
+    @property
+    def cu_count(self):
+        return int(self._lib.flashe_ctx_cu_count(self._h))
+
     def set_prf_backend(self, backend):
         """0 = auto, 1 = LDS T-table kernel, 2 = bit-sliced VALU kernel (identical results)."""
         self._check(self._lib.flashe_ctx_set_prf_backend(self._h, int(backend)))

@@ -57,6 +57,12 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
 int flashe_ctx_destroy(flashe_ctx *ctx);
 int flashe_ctx_set_key(flashe_ctx *ctx, const uint8_t key[32]);
 int flashe_ctx_int_bits(const flashe_ctx *ctx);
+/* new: how many compute units the persistent launches of this ctx occupy (0 = the whole device; flashe_ctx_cu_count = what the
+ * device has).  The PRF workgroups hold 128 KiB of LDS per CU, so a kernel from ANOTHER stream that needs more than the rest (RCCL's
+ * transfer kernels do) runs beside a PRF launch only on CUs that launch leaves free: the multi-GPU schedules that hide the exchange
+ * under the next chunk's encrypts set this to cu_count - 16 or so.  Results do not depend on it. */
+int flashe_ctx_set_cu_limit(flashe_ctx *ctx, int cus);
+int flashe_ctx_cu_count(const flashe_ctx *ctx);
 /* Which implementation of the AES-256 PRF the fused kernels use (results are identical):
  * 0 = automatic, 1 = LDS T-table kernel, 2 = bit-sliced VALU kernel (b > 64, single add prefix with
  * at most one minus prefix; other shapes always use the table kernel).  Also settable at ctx creation
