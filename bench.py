@@ -461,7 +461,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
     ms_per_step = elapsed * 1e3 / K
     pt_bytes = 8
     enc_avg_ms = float(np.mean(enc_ms)) if enc_ms else float("nan")
-    chained = os.environ.get("FLASHE_CHAIN", "1") != "0" and L == 2
+    chained = os.environ.get("FLASHE_CHAIN", "1") != "0"          # consecutive clients share their PRF streams (every bit width)
     if schedule == "fused":
         # per launch: C encrypt links (u64 plaintext in, L-limb ciphertext out) + the mask-difference job (L limbs out) over one
         # chunk of the vector; a chain of C clients is C + 1 AES streams, the mask difference two more
@@ -474,7 +474,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
     else:
         vec = (C - 1) if (schedule == "pipelined" and C > 1) else C
         alg_bytes = vec * n * (pt_bytes + 8 * L)          # u64 plaintext in + L-limb ciphertext out, per client vector
-        blocks = (vec + 1 if chained else 2 * vec) * n / (1 if L == 2 else 128 // b)
+        blocks = (vec + 1 if chained else 2 * vec) * (n if L == 2 else -(-n // (128 // b)))
         kernel_key = "prf_chain_kernel" if L == 2 else "prf_small_chain_kernel"
         kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub = encrypt: {vec} consecutive clients per launch share "
                        f"{vec + 1} PRF streams, ct_c = pt_c + S_c - S_(c+1))") if L == 2 else \
@@ -482,7 +482,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
              f"{vec}-client chain)")
     achieved = alg_bytes / (enc_avg_ms * 1e-3) / 1e9
     ratio, tsrc = traffic_ratio(kernel_key)
-    lookups = 196.1 if chained else 196.5
+    lookups = (196.1 if chained else 196.5) if L == 2 else 208.0    # b <= 64: one-step counter shortcut only
     out.update({
         "value": total * n / (elapsed / K), "ms_per_step": ms_per_step, "scaling": scaling,
         "config": {"workload": f"BASELINE config {cfg}: n={n}-element vector, 64-bit plaintext / {b}-bit modulus, "
