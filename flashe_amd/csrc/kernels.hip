@@ -1277,9 +1277,10 @@ __device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool v
     }
 }
 
-// m = 2 (43 <= b <= 64): the two elements of a lane's block are adjacent 8-byte words in memory, so the lane adds and stores them
-// itself -- ONE 16-byte load and store per lane for a whole block inside the range, no staging through LDS, no index
-// arithmetic (-9.5 % on ten 1e7-element vectors at b = 64); chunk ends and range ends take the per-element form.
+// m <= 4 (26 <= b <= 64): the elements of a lane's block are adjacent 8-byte words in memory, so the lane adds and stores them
+// itself in 16-byte accesses -- one (m = 2) or two (m = 3, 4) per lane for a whole block inside the range, no staging through
+// LDS, no index arithmetic (-9.5 % at b = 64, -12 % at b = 40 and 32 on ten 1e7-element vectors; the same in 8-byte accesses
+// was 60-130 % SLOWER, and 16-byte accesses at m >= 5 lose too); chunk ends and range ends take the per-element form.
 __device__ __forceinline__ void small_direct(bool valid, int cnt, uint64_t j0, u128 D, const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
                                              uint64_t first, uint64_t range_end, const SmallParams &p)
 {
@@ -1292,6 +1293,24 @@ __device__ __forceinline__ void small_direct(bool valid, int cnt, uint64_t j0, u
         r[0] = (pt[0] + static_cast<uint64_t>(D)) & p.mask_lo;
         r[1] = (pt[1] + static_cast<uint64_t>(D >> p.b)) & p.mask_lo;
         __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(out + k));
+        return;
+    }
+    if (cnt == p.m && p.m >= 3 && j0 >= first && j0 + p.m <= range_end) {      // whole block of 3 or 4 elements: two 16-byte accesses
+        const uint64_t k = j0 - first;
+        u64x2 a = {0ull, 0ull}, c = {0ull, 0ull};
+        if (in) {
+            a = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + k));
+            if (p.m == 4) c = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + k + 2));
+            else c[0] = __builtin_nontemporal_load(in + k + 2);
+        }
+        u64x2 r0, r1;
+        r0[0] = (a[0] + static_cast<uint64_t>(D)) & p.mask_lo;
+        r0[1] = (a[1] + static_cast<uint64_t>(D >> p.b)) & p.mask_lo;
+        r1[0] = (c[0] + static_cast<uint64_t>(D >> (2 * p.b))) & p.mask_lo;
+        r1[1] = (c[1] + static_cast<uint64_t>(D >> (3 * p.b))) & p.mask_lo;
+        __builtin_nontemporal_store(r0, reinterpret_cast<u64x2 *>(out + k));
+        if (p.m == 4) __builtin_nontemporal_store(r1, reinterpret_cast<u64x2 *>(out + k + 2));
+        else __builtin_nontemporal_store(r1[0], out + k + 2);
         return;
     }
     uint64_t pt[4] = {0ull, 0ull, 0ull, 0ull};
@@ -1360,7 +1379,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
     const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
     uint32_t *row0 = scratch + wave * 256;
     const u128 top = (static_cast<u128>(p.top_hi) << 64) | p.top_lo;
-    const bool direct = p.m == 2 && !p.no_direct;      // m = 3, 4 measured: 8-byte accesses at a 24 / 32-byte lane stride lose 60-130 % against the staged walk
+    const bool direct = p.m <= 4 && !p.no_direct;       // m >= 5 measured 35-150 % slower than the staged walk (40 .. 64-byte lane stride)      // m = 3, 4 measured: 8-byte accesses at a 24 / 32-byte lane stride lose 60-130 % against the staged walk
     const uint64_t Ng = uniform64(d_cend[n_chains - 1]);
     int cur = 0;
     uint64_t cbeg = 0;

@@ -12,7 +12,7 @@ sys.path.insert(0, %r)
 from flashe_amd.engine import Engine, SCHEME_DOUBLE
 from oracle import flashe_oracle as orc
 out = []
-for b, n, C in [(64, 10_000_000, 10), (48, 10_000_000, 10), (40, 10_000_000, 10), (32, 10_000_000, 10), (20, 10_000_000, 10), (23, 61_706, 100), (64, 10_000_000, 1)]:
+for b, n, C in [(64, 10_000_000, 10), (48, 10_000_000, 10), (40, 10_000_000, 10), (32, 10_000_000, 10), (25, 10_000_000, 10), (20, 10_000_000, 10), (16, 10_000_000, 10), (23, 61_706, 100), (64, 10_000_000, 1)]:
     eng = Engine(bytes(range(32)), b)
     host = [np.random.default_rng(c).integers(0, 2**min(b, 63), n, dtype=np.uint64) for c in range(min(C, 3))]
     pts = [eng.upload(host[c %% len(host)]) for c in range(C)]
@@ -38,7 +38,7 @@ print(" | ".join(out))
 
 VAR = sys.argv[1] if len(sys.argv) > 1 else "FLASHE_CHAIN"        # or FLASHE_SMALL_DIRECT
 for rnd in range(2):
-    for v in ("1", "0"):
+    for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("1", "0")):
         env = dict(os.environ, OMP_WAIT_POLICY="passive")
         env[VAR] = v
         r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)

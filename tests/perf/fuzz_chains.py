@@ -17,7 +17,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.Generator(np.random.PCG64(int(sys.argv[2]) if len(sys.argv) > 2 else 1))
 engines = {}
 for case in range(cases):
-    b = int(rng.choice([128, 128, 127, 100, 65, 64, 64, 57, 43, 42, 33, 23, 20, 8, 1]))
+    b = int(rng.choice([128, 128, 127, 100, 65, 64, 64, 57, 43, 42, 40, 33, 32, 26, 25, 23, 20, 8, 1]))
     L = 2 if b > 64 else 1
     n = int(rng.choice([1, 63, 64, 255, 256, 257, 1000, 4097, 61_706, 100_003, 300_000, int(rng.integers(1, 2_000_000))]))
     J = int(rng.choice([1, 3, 7, 16]))
