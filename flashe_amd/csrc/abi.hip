@@ -230,12 +230,19 @@ struct Tmp {
             else while (cap < bytes) cap <<= 1;
             size_t held = 0;
             for (const auto &b : ctx->pool) held += b.cap;
-            // make room: drop free blocks, largest first (they are all too small for this request)
-            while ((held + cap > pool_budget() || ctx->pool.size() >= kPoolBlocks) && !ctx->pool.empty()) {
+            auto no_slot = [&] {
+                if (ctx->pool.size() < kPoolBlocks) return false;
+                for (const auto &b : ctx->pool)
+                    if (!b.used && b.cap == 0) return false;
+                return true;
+            };
+            // make room: drop parked blocks, largest first (they are all too small for this request); a request beyond the whole
+            // budget is a plain allocation and evicts nothing
+            while (cap <= pool_budget() && (held + cap > pool_budget() || no_slot())) {
                 int victim = -1;
                 for (size_t i = 0; i < ctx->pool.size(); i++)
-                    if (!ctx->pool[i].used && (victim < 0 || ctx->pool[i].cap > ctx->pool[victim].cap)) victim = static_cast<int>(i);
-                if (victim < 0) break;
+                    if (!ctx->pool[i].used && ctx->pool[i].cap && (victim < 0 || ctx->pool[i].cap > ctx->pool[victim].cap)) victim = static_cast<int>(i);
+                if (victim < 0) break;                   // nothing parked is left to give up
                 // live Tmp objects hold slot numbers: only the LAST slot can be removed without renumbering, so swap-free
                 // removal is limited to it; any other victim is freed in place and its slot kept as an empty one
                 (void)hipStreamSynchronize(ctx->env.stream);

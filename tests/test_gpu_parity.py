@@ -660,6 +660,45 @@ def test_bench_multi_rank_flow(extra, tmp_path):
     assert d["config"]["clients_total"] == (9 if extra[1] == "2" else 5)
 
 
+def test_staging_pool_under_a_tight_budget():
+    """The host-pointer calls keep their device staging blocks (abi.hip `Tmp`) within FLASHE_STAGING_POOL_MB: with 3 MB allowed,
+    a mix of sizes forces reuse, eviction of parked blocks, slots emptied in place and plain allocations for what does not
+    fit -- every result still equals the oracle's, and the recycled host result arrays (engine._HostPool, 2 MB allowed) never
+    alias while alive.  Own process: both budgets are read once."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+from flashe_amd.engine import Engine, SCHEME_DOUBLE
+from oracle import flashe_oracle as orc
+KEY = bytes(range(32))
+eng = Engine(KEY, 128)
+rng = np.random.Generator(np.random.PCG64(5))
+sizes = [1000, 90_000, 3, 250_000, 40_000, 90_000, 131_072, 1, 250_000, 70_000, 1000, 200_000]
+alive = []
+for rep in range(3):
+    for i, n in enumerate(sizes):
+        pt = rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+        ct = eng.encrypt(rep, i, SCHEME_DOUBLE, 16, pt)
+        assert np.array_equal(ct, orc.encrypt(KEY, rep, i, "double", 16, 128, pt)), ("encrypt", rep, n)
+        dec = eng.decrypt(rep, [i + 1], [i], 16, ct)
+        assert np.array_equal(dec[:, 0], pt) and not dec[:, 1].any(), ("decrypt", rep, n)
+        agg = eng.aggregate_elem([ct, ct, dec])
+        assert np.array_equal(agg, orc.aggregate_elem([ct, ct, dec], 128)), ("aggregate", rep, n)
+        alive.append((ct, ct.copy()))
+        if len(alive) > 4:
+            alive.pop(0)
+        for a, c in alive:
+            assert np.array_equal(a, c), "a live result array was overwritten"
+print("POOL_OK")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, FLASHE_STAGING_POOL_MB="3", FLASHE_HOST_POOL_MB="2", OMP_WAIT_POLICY="passive"))
+    assert r.returncode == 0 and "POOL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("b,n", [(128, 50001), (120, 40003), (65, 999), (64, 70001), (33, 12345), (23, 61706),
                                  (20, 100000), (8, 4097), (7, 30000), (1, 10000)])
 def test_pack_unpack_vs_oracle(E, oracle, b, n):
