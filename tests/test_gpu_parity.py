@@ -660,6 +660,31 @@ def test_bench_multi_rank_flow(extra, tmp_path):
     assert d["config"]["clients_total"] == (9 if extra[1] == "2" else 5)
 
 
+def test_cu_limit_changes_the_launch_shape_not_the_result(E, oracle):
+    """flashe_ctx_set_cu_limit (CUs left free for RCCL's transfer kernels): the persistent launches fill fewer CUs, every result
+    stays bit-identical -- chained wide launch, b <= 64 chain, reduce fused with the decrypt, a one-CU extreme."""
+    n, C = 300_007, 5
+    for b in (128, 64):
+        eng = make(E, b)
+        assert eng.cu_count >= 64
+        Lb = L(b)
+        rng = np.random.Generator(np.random.PCG64(b))
+        pts = [rng.integers(0, 2 ** 63, n, dtype=np.uint64) for _ in range(C)]
+        dp = [eng.upload(p) for p in pts]
+        want = [oracle.encrypt(KEY, 3, c, "double", 16, b, pts[c]) for c in range(C)]
+        for limit in (eng.cu_count - 32, 7, 1, 0, 10 ** 6):
+            eng.set_cu_limit(limit)
+            dc = [eng.alloc_vec(n) for _ in range(C)]
+            eng.encrypt_batch_dev(3, list(range(C)), E.SCHEME_DOUBLE, n, 16, dp, 1, dc)
+            for c in range(C):
+                assert np.array_equal(dc[c].download(np.uint64, n * Lb).reshape(n, Lb), want[c]), (b, limit, c)
+            out = eng.alloc_vec(n)
+            eng.decrypt_dev(3, [C], [0], n, 16, dc[0], out)
+            assert np.array_equal(out.download(np.uint64, n * Lb).reshape(n, Lb), oracle.decrypt(KEY, 3, [C], [0], 16, b, want[0])), (b, limit)
+        with pytest.raises(E.FlasheError):
+            eng.set_cu_limit(-1)
+
+
 def test_staging_pool_under_a_tight_budget():
     """The host-pointer calls keep their device staging blocks (abi.hip `Tmp`) within FLASHE_STAGING_POOL_MB: with 3 MB allowed,
     a mix of sizes forces reuse, eviction of parked blocks, slots emptied in place and plain allocations for what does not
