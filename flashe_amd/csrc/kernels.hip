@@ -1047,7 +1047,7 @@ struct SmallParams {
     uint64_t n;               // length of the whole vector (defines the chunking)
     uint32_t n_jobs, iter;
     int b, m;
-    int no_direct;            // A/B knob (FLASHE_SMALL_DIRECT=0): stage every output through the LDS rows
+    int no_direct;            // A/B knob FLASHE_SMALL_DIRECT: 0 = stage every output through the LDS rows, 2 = general walk instead of the b <= 32 fast walk
     uint32_t m_magic;         // ceil(2^32 / m): x / m == (x * m_magic) >> 32 for x < 2^13
     uint64_t mask_lo;
     uint64_t top_lo, top_hi;  // the top bit of every b-bit slot of the 128-bit word (SWAR subtraction)
@@ -1277,6 +1277,65 @@ __device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool v
     }
 }
 
+// b <= 32, the common tile (64 whole blocks inside the range): the walk of small_walk with everything per element that can be
+// hoisted hoisted -- the (block, slot) of element lane + 64 i advances by additions (no multiply: v_mul_hi / v_mul_lo are
+// quarter-rate), a value is one 32-bit funnel shift of two row words, the sum needs only its low word (b <= 32), no range
+// checks.  The per-element VALU work of the general walk cost as much as the AES rounds it follows (b = 20: 0.53 ms against
+// 0.29 ms without outputs).
+constexpr uint32_t kWalkBatch = 8;                      // plaintext loads in flight per lane (a rolled loop would wait for each)
+struct WalkPt { uint32_t v[kWalkBatch]; };
+
+// the first kWalkBatch plaintext words of the lane's walk, requested BEFORE the AES rounds of the stream that completes this
+// output: their latency hides under the rounds
+__device__ __forceinline__ WalkPt small_walk32_load(const uint64_t *__restrict__ in, uint64_t e0, uint64_t first, uint32_t lane, uint32_t m)
+{
+    WalkPt r;
+    const uint64_t *pin = in ? in + (e0 - first) + lane : nullptr;
+#pragma unroll
+    for (uint32_t u = 0; u < kWalkBatch; u++) {
+        r.v[u] = 0u;
+        if (pin && u < m) r.v[u] = static_cast<uint32_t>(__builtin_nontemporal_load(pin + 64u * u));
+    }
+    return r;
+}
+
+__device__ __forceinline__ void small_walk32(uint32_t *row0, uint32_t lane, uint64_t e0, u128 D, const WalkPt &pt0, const uint64_t *__restrict__ in,
+                                             uint64_t *__restrict__ out, uint64_t first, const SmallParams &p, uint32_t blk0, uint32_t o0)
+{
+    *reinterpret_cast<uint4 *>(row0 + 4 * lane) = make_uint4(static_cast<uint32_t>(D), static_cast<uint32_t>(D >> 32),
+                                                             static_cast<uint32_t>(D >> 64), static_cast<uint32_t>(D >> 96));
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t m = static_cast<uint32_t>(p.m), b = static_cast<uint32_t>(p.b);
+    const uint32_t q64 = 64u / m, r64b = (64u % m) * b, mb = m * b, mask = static_cast<uint32_t>(p.mask_lo);
+    const uint64_t *pin = in ? in + (e0 - first) + lane : nullptr;
+    uint64_t *pout = out + (e0 - first) + lane;
+    uint32_t blk = blk0, o = o0;
+    for (uint32_t i0 = 0; i0 < m; i0 += kWalkBatch) {
+        uint32_t pt[kWalkBatch], val[kWalkBatch];
+#pragma unroll
+        for (uint32_t u = 0; u < kWalkBatch; u++) {
+            pt[u] = pt0.v[u];
+            if (i0) {                                      // (m > kWalkBatch: b < 16) later batches are loaded here
+                pt[u] = 0u;
+                if (pin && i0 + u < m) pt[u] = static_cast<uint32_t>(__builtin_nontemporal_load(pin + 64u * (i0 + u)));
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kWalkBatch; u++) {
+            const uint32_t *w = row0 + 4 * blk + (o >> 5);
+            // bits o .. o + 31 of the block: o + b <= 128, so past word 3 only bits that the mask removes are read
+            val[u] = __builtin_amdgcn_alignbit(w[1], w[0], o & 31u);
+            o += r64b; blk += q64;
+            if (o >= mb) { o -= mb; blk++; }
+            if (blk > 63u) blk = 63u;                     // (slots beyond the tile's last element: not stored)
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kWalkBatch; u++)
+            if (i0 + u < m) __builtin_nontemporal_store(static_cast<uint64_t>((pt[u] + val[u]) & mask), pout + 64u * (i0 + u));
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // m <= 4 (26 <= b <= 64): the elements of a lane's block are adjacent 8-byte words in memory, so the lane adds and stores them
 // itself in 16-byte accesses -- one (m = 2) or two (m = 3, 4) per lane for a whole block inside the range, no staging through
 // LDS, no index arithmetic (-9.5 % at b = 64, -12 % at b = 40 and 32 on ten 1e7-element vectors; the same in 8-byte accesses
@@ -1379,7 +1438,9 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
     const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
     uint32_t *row0 = scratch + wave * 256;
     const u128 top = (static_cast<u128>(p.top_hi) << 64) | p.top_lo;
-    const bool direct = p.m <= 4 && !p.no_direct;       // m >= 5 measured 35-150 % slower than the staged walk (40 .. 64-byte lane stride)      // m = 3, 4 measured: 8-byte accesses at a 24 / 32-byte lane stride lose 60-130 % against the staged walk
+    const bool direct = p.m <= 4 && !p.no_direct;
+    const bool walk32 = p.b <= 32 && !direct && p.no_direct != 2;     // (FLASHE_SMALL_DIRECT=2: A/B knob, general walk everywhere)
+    const uint32_t wblk0 = lane / m32, wo0 = (lane - wblk0 * m32) * static_cast<uint32_t>(p.b);       // m >= 5 measured 35-150 % slower than the staged walk (40 .. 64-byte lane stride)      // m = 3, 4 measured: 8-byte accesses at a 24 / 32-byte lane stride lose 60-130 % against the staged walk
     const uint64_t Ng = uniform64(d_cend[n_chains - 1]);
     int cur = 0;
     uint64_t cbeg = 0;
@@ -1400,17 +1461,31 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
         const CtrVar xA = ctr_var(rk, lr, ctrA);
         CtrVar xB{};
         if (PAIR) xB = ctr_var(rk, lr, ctrB);
+        // the common tile: 64 whole blocks, all inside the range -> their 64 m elements are one contiguous run
+        uint64_t e0A = 0, e0B = 0;
+        bool fastA = false, fastB = false;
+        if (walk32) {
+            e0A = uniform64(j0A);
+            fastA = __ballot(vA && cntA == p.m) == ~0ull && e0A >= first && e0A + 64u * m64 <= range_end;
+            if (PAIR) {
+                e0B = uniform64(j0B);
+                fastB = __ballot(vB && cntB == p.m) == ~0ull && e0B >= first && e0B + 64u * m64 <= range_end;
+            }
+        }
         u128 prevA = 0, prevB = 0;
         if (PAIR) {
             // two blocks per lane on the same prefix, one stream per step
             for (int c = 0; c < n_streams; c++) {
                 const CtrPrefix pre = load_prefix(pre_lds, sbase + c);
+                const int link = single ? c : c - 1;
+                WalkPt ptA{}, ptB{};
+                if (link >= 0 && fastA) ptA = small_walk32_load(tb.in[link0 + link], e0A, first, lane, m32);
+                if (link >= 0 && fastB) ptB = small_walk32_load(tb.in[link0 + link], e0B, first, lane, m32);
                 uint32_t s[2][4];
                 ctr_round1(pre, xA, s[0]);
                 ctr_round1(pre, xB, s[1]);
                 aes256_rounds<2, 2>(rk, lr, s);
                 const u128 SA = words_to_u128(s[0]), SB = words_to_u128(s[1]);
-                const int link = single ? c : c - 1;
                 if (link >= 0) {
                     const uint64_t *in = tb.in[link0 + link];
                     uint64_t *out = tb.out[link0 + link];
@@ -1421,8 +1496,10 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                         small_direct(vA, cntA, j0A, DA, in, out, first, range_end, p);
                         small_direct(vB, cntB, j0B, DB, in, out, first, range_end, p);
                     } else {
-                        small_walk(row0, lane, vA, cntA, j0A, DA, in, out, first, range_end, p);
-                        small_walk(row0, lane, vB, cntB, j0B, DB, in, out, first, range_end, p);
+                        if (fastA) small_walk32(row0, lane, e0A, DA, ptA, in, out, first, p, wblk0, wo0);
+                        else small_walk(row0, lane, vA, cntA, j0A, DA, in, out, first, range_end, p);
+                        if (fastB) small_walk32(row0, lane, e0B, DB, ptB, in, out, first, p, wblk0, wo0);
+                        else small_walk(row0, lane, vB, cntB, j0B, DB, in, out, first, range_end, p);
                     }
                 }
                 prevA = SA; prevB = SB;
@@ -1433,20 +1510,25 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
             for (int c = 0; c < n_streams; c += 2) {
                 const bool has1 = c + 1 < n_streams;
                 const CtrPrefix pre0 = load_prefix(pre_lds, sbase + c), pre1 = load_prefix(pre_lds, sbase + (has1 ? c + 1 : c));
+                const int l0 = single ? c : c - 1;
+                WalkPt pt0{}, pt1{};
+                if (fastA && l0 >= 0) pt0 = small_walk32_load(tb.in[link0 + l0], e0A, first, lane, m32);
+                if (fastA && has1) pt1 = small_walk32_load(tb.in[link0 + l0 + 1], e0A, first, lane, m32);
                 uint32_t s[2][4];
                 ctr_round1(pre0, xA, s[0]);
                 ctr_round1(pre1, xA, s[1]);
                 aes256_rounds<2, 2>(rk, lr, s);
                 const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
-                const int l0 = single ? c : c - 1;
                 if (l0 >= 0) {
                     const u128 D = single ? S0 : ((prevA | top) - (S0 & ~top)) ^ ((prevA ^ ~S0) & top);
                     if (direct) small_direct(vA, cntA, j0A, D, tb.in[link0 + l0], tb.out[link0 + l0], first, range_end, p);
+                    else if (fastA) small_walk32(row0, lane, e0A, D, pt0, tb.in[link0 + l0], tb.out[link0 + l0], first, p, wblk0, wo0);
                     else small_walk(row0, lane, vA, cntA, j0A, D, tb.in[link0 + l0], tb.out[link0 + l0], first, range_end, p);
                 }
                 if (has1) {
                     const u128 D = single ? S1 : ((S0 | top) - (S1 & ~top)) ^ ((S0 ^ ~S1) & top);
                     if (direct) small_direct(vA, cntA, j0A, D, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, range_end, p);
+                    else if (fastA) small_walk32(row0, lane, e0A, D, pt1, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, p, wblk0, wo0);
                     else small_walk(row0, lane, vA, cntA, j0A, D, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, range_end, p);
                 }
                 prevA = has1 ? S1 : S0;
@@ -1885,7 +1967,7 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
     if (env.codec || n >= (1ull << 32) || n == 0) return hipErrorNotSupported;
     SmallParams p{};
     p.n = n; p.n_jobs = n_jobs; p.iter = iter; p.b = env.b; p.m = 128 / env.b; p.te0 = env.te0_dev;
-    { static const bool off = getenv("FLASHE_SMALL_DIRECT") && atoi(getenv("FLASHE_SMALL_DIRECT")) == 0; p.no_direct = off ? 1 : 0; }
+    { static const int v = getenv("FLASHE_SMALL_DIRECT") ? atoi(getenv("FLASHE_SMALL_DIRECT")) : 1; p.no_direct = v == 0 ? 1 : v == 2 ? 2 : 0; }
     p.m_magic = static_cast<uint32_t>(((1ull << 32) + p.m - 1) / p.m);
     uint64_t hi;
     masks_of(env.b, &p.mask_lo, &hi);
