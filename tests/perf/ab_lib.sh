@@ -1,7 +1,7 @@
 #!/bin/bash
 # default bench line under two builds of the library (FLASHE_LIB_NAME), interleaved.  usage: ab_lib.sh <other .so name> [bench args]
 OTHER=$1; shift
-for i in 1 2 3; do
+for i in $(seq 1 ${AB_ROUNDS:-3}); do
   for lib in libflashe_hip.so "$OTHER"; do
     FLASHE_LIB_NAME=$lib timeout 200 python bench.py --no-cpu-baseline --no-e2e "$@" < /dev/null 2>/dev/null | L=$lib python -c '
 import sys, json, os
