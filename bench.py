@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 # The oracle's OpenMP team (parity gates, CPU baseline) must SLEEP between its parallel regions: spinning workers burn the
 # container's CPU quota and the throttling hits the thread that submits GPU work (measured: 100 launches 0.3 ms -> 4.9 ms).
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+# RCCL shares device memory between the ranks of a node through dmabuf IPC handles; the legacy IPC mode is not supported by the host
+# driver of this pool (hipIpcGetMemHandle: invalid argument).  Must be in the environment before the HIP runtime starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 KEY = bytes(range(32))
