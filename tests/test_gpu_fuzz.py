@@ -1,0 +1,29 @@
+"""Short, seeded runs of the differential fuzzers under tests/perf/ inside the GPU gate: random job lists of chained PRF launches
+(every bit-width class: one element per block, direct outputs for 2 .. 4 elements per block, the fast and the general walk) and
+random sparse rounds (span bounds / span reduce / fused sparse decrypt), each compared with the oracle.  The long runs
+(hundreds of cases per seed) are in tests/perf/README.md."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "perf", script)] + [str(a) for a in args], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("seed", [101, 102])
+def test_fuzz_chained_launches(seed):
+    assert "FUZZ_OK 120 cases" in _run("fuzz_chains.py", 120, seed)
+
+
+def test_fuzz_sparse_round():
+    assert "FUZZ_SPARSE_OK 20 cases" in _run("fuzz_sparse.py", 20, 103)
