@@ -374,7 +374,7 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds})
         if (b->p) (void)hipFree(b->p);
     for (flashe_ctx::PoolBlock &pb : ctx->pool)
-        if (pb.p) (void)hipFree(pb.p);
+        if (pb.p) { (void)hipMemset(pb.p, 0, pb.cap); (void)hipFree(pb.p); }      // staging blocks held plaintexts and ciphertexts
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
     // the expanded AES-256 key leaves neither HBM nor host memory behind
     if (ctx->rkw_dev) { (void)hipMemset(ctx->rkw_dev, 0, 256); (void)hipFree(ctx->rkw_dev); }
