@@ -63,3 +63,17 @@ for mb in (16, 160):
         hip.hipStreamSynchronize(s1); hip.hipStreamSynchronize(s2)
     s = t(duplex)
     print(f"{'pinned H2D + D2H concurrently':40s} {s * 1e3:8.2f} ms  {2 * nbytes / s / 1e9:6.1f} GB/s total")
+    page2 = np.ones(nbytes // 8, dtype=np.uint64)
+    pb = page2.ctypes.data
+    times = {}
+
+    def duplex_pageable():
+        t0 = time.perf_counter()
+        chk(hip.hipMemcpyAsync(dev, pa, nbytes, H2D, s1), "a")
+        times["after_h2d_call"] = time.perf_counter() - t0
+        chk(hip.hipMemcpyAsync(pb, dev2, nbytes, D2H, s2), "a")
+        times["after_d2h_call"] = time.perf_counter() - t0
+        hip.hipStreamSynchronize(s1); hip.hipStreamSynchronize(s2)
+    s = t(duplex_pageable)
+    print(f"{'pageable H2D + D2H, two streams':40s} {s * 1e3:8.2f} ms  {2 * nbytes / s / 1e9:6.1f} GB/s total "
+          f"(the H2D call returned after {times['after_h2d_call'] * 1e3:.2f} ms, the D2H call after {times['after_d2h_call'] * 1e3:.2f} ms)")
