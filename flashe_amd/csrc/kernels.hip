@@ -2589,15 +2589,29 @@ __global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const Scatt
     const int c = blockIdx.y;
     const uint64_t k = tb.k[c];
     const uint32_t *loc = tb.loc[c];
+    const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (int i = 0; i < kBoundsPerThread; i++) {
         const uint64_t q = (static_cast<uint64_t>(blockIdx.x) * kBoundsPerThread + i) * kStreamThreads + threadIdx.x;
-        if (q > k) return;                               // q == k closes the list: the spans behind the last entry
-        const uint64_t prev = q ? loc[q - 1] : 0, cur = q < k ? loc[q] : 0;
-        if (q < k && (cur >= total || (q && cur <= prev))) *err_flag = 1;
-        const uint64_t s_first = q ? std::min<uint64_t>(prev / kSpan, n_spans) + 1 : 0;
+        // q == k closes the list (the spans behind the last entry); lanes beyond it open nothing
+        const bool live = q <= k;
+        const uint64_t prev = live && q ? loc[q - 1] : 0, cur = live && q < k ? loc[q] : 0;
+        if (live && q < k && (cur >= total || (q && cur <= prev))) *err_flag = 1;
         const uint64_t s_last = q < k ? std::min<uint64_t>(cur / kSpan, n_spans) : n_spans;
-        for (uint64_t sp = s_first; sp <= s_last; sp++) start[sp * C + c] = static_cast<uint32_t>(q);
+        const uint64_t s_first = !live ? s_last + 1 : q ? std::min<uint64_t>(prev / kSpan, n_spans) + 1 : 0;
+        const bool is_long = s_first + 16 <= s_last;
+        if (!is_long)
+            for (uint64_t sp = s_first; sp <= s_last; sp++) start[sp * C + c] = static_cast<uint32_t>(q);
+        // a long run of empty spans (a short list over a long vector, an empty client): the wave fills it together instead of one
+        // lane storing span after span
+        uint64_t pending = __ballot(is_long);
+        while (pending) {
+            const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
+            const uint64_t a = __shfl(s_first, src, 64), b = __shfl(s_last, src, 64);
+            const uint32_t qq = static_cast<uint32_t>(__shfl(q, src, 64));
+            for (uint64_t x = a + lane; x <= b; x += 64u) start[x * C + c] = qq;
+            pending &= pending - 1;
+        }
     }
 }
 
