@@ -56,16 +56,16 @@ def parse():
     ap.add_argument("--bits", type=int, default=128)
     ap.add_argument("--n-jobs", type=int, default=16)
     ap.add_argument("--prf-backend", choices=["auto", "table", "bitslice", "hybrid", "bitslice16"], default="auto")
-    ap.add_argument("--pipeline-chunks", type=int, default=4,
+    ap.add_argument("--pipeline-chunks", type=int, default=None,
                     help="> 0: chunks of the pipelined / fused schedules (reduce, exchange, decrypt of chunk q run on a side stream "
-                         "under the launch of chunk q + 1); 0: sequential phases only")
+                         "under the launch of chunk q + 1); 0: sequential phases only; default: 3, 4 and 8 take part in the calibration")
     ap.add_argument("--schedule", choices=["default", "auto", "fused", "pipelined", "sequential"], default="default",
-                    help="default: sequential (two launches) on one GPU, 'auto' when ranks exchange; auto: whichever schedule is "
-                         "fastest in a short untimed calibration on this box / node; fused: per chunk one launch does every local "
-                         "encrypt plus the decrypt mask difference, the reduce (which then yields the plaintext aggregate) and the "
-                         "exchange hide under the next chunk's launch; pipelined: last client's encrypt chunked, reduce / exchange / "
-                         "decrypt on a side stream; sequential: all local encrypts in one launch, then reduce (+ exchange) fused with "
-                         "the decrypt")
+                    help="default = auto: whichever schedule (and chunk count, and number of CUs left free for the exchange) is fastest in an "
+                         "untimed calibration on this box / node, after a clock ramp, best of two passes in opposite orders; fused: per chunk one "
+                         "launch does every local encrypt plus the decrypt mask difference, the reduce (which then yields the plaintext "
+                         "aggregate) and the exchange hide under the next chunk's launch; pipelined: last client's encrypt chunked, reduce / "
+                         "exchange / decrypt on a side stream; sequential: all local encrypts in one launch, then reduce (+ exchange) fused "
+                         "with the decrypt")
     ap.add_argument("--cus-free", type=int, default=None,
                     help="PRF launches leave this many CUs free for the RCCL transfer kernels of the overlapped schedules (default: 0, or "
                          "whichever of 0 / 16 / 32 / 48 calibrates fastest when ranks exchange)")
@@ -287,7 +287,7 @@ def main():
     eng.selftest()
     backend = {"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend]
     eng.set_prf_backend(backend)
-    two_streams = args.pipeline_chunks > 0 and args.schedule != "sequential" and cfg in (2, 4)
+    two_streams = (args.pipeline_chunks is None or args.pipeline_chunks > 0) and args.schedule != "sequential" and cfg in (2, 4)
     side = Engine(KEY, b, device=local_rank) if two_streams else None
     if args.test_comm_dir:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -356,12 +356,14 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
     rnd = ShardedRound(ops, n, b, mine, J, rank=rank, world=world, total_clients=total, force_collectives=args.force_dist)
     host_pts = {c: plaintext(c, n, b) for c in mine}
     pts = [(ops.upload(host_pts[c]), 0) for c in mine]
-    Q = max(args.pipeline_chunks, 1)
+    Qs = [max(args.pipeline_chunks, 1)] if args.pipeline_chunks is not None else [3, 4, 8]
+    Qbox = {"Q": Qs[len(Qs) // 2]}                       # the chunk count run_schedule uses (the calibration varies it)
     enc_ev = [(eng.event(), eng.event()) for _ in range(K)]
     ph_ev = [[eng.event() for _ in range(3)] for _ in range(K)]
 
     def run_schedule(schedule, it, k=None):
         """One round.  k = index of the timed step (events recorded) or None (warmup / parity run)."""
+        Q = Qbox["Q"]
         if schedule == "fused":
             # one bracketed launch per round (chunk k mod Q): event records are not free on a stream
             evs = [enc_ev[k] if (k is not None and q == k % Q) else None for q in range(Q)]
@@ -388,11 +390,9 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
     # used only if it passes; otherwise fall back to the next simpler one.
     order = ["fused", "pipelined", "sequential"]
     start = args.schedule
-    calibrate = start == "auto" or (start == "default" and rnd.exchange)
+    calibrate = start in ("auto", "default")
     if calibrate:
         start = "fused"
-    elif start == "default":
-        start = "sequential"
     if start == "fused" and b <= 64:
         start = "pipelined"              # the one-launch job list needs b > 64
     candidates = order[order.index(start):] if ops.side is not None else ["sequential"]
@@ -413,37 +413,62 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
     cus = eng.cu_count
     free_options = [args.cus_free] if args.cus_free is not None else [0, 16, 32, 48] if (rnd.exchange and not args.test_comm_dir) else [0]
 
-    def quick_ms(cand, free=0, rounds=8):
-        """Untimed-region calibration: ms per round of a schedule, MAX over ranks."""
+    def configure(cand):
+        sched, free, q = cand
+        Qbox["Q"] = q
         eng.set_cu_limit(cus - free if free else 0)
-        for it in range(2):
-            run_schedule(cand, it)
-        ms = timed_region(ops, rounds, lambda k: run_schedule(cand, k)) * 1e3 / rounds
-        eng.set_cu_limit(0)
-        return ms
 
-    schedule, calibration, cus_free = None, None, args.cus_free or 0
+    def quick_ms(cand, rounds=8):
+        """Untimed-region calibration: ms per round of (schedule, CUs left free, chunks), MAX over ranks."""
+        configure(cand)
+        for it in range(2):
+            run_schedule(cand[0], it)
+        return timed_region(ops, rounds, lambda k: run_schedule(cand[0], k)) * 1e3 / rounds
+
+    chosen, calibration = None, None
     if calibrate and len(candidates) > 1:
         usable = [c for c in candidates if passes(c)]
-        if len(usable) > 1:
-            table = {(c, f): quick_ms(c, f) for c in usable for f in (free_options if c != "sequential" else [0])}
-            schedule, cus_free = min(table, key=table.get)
-            calibration = {(c if not f else f"{c}, {f} CUs left free"): ms for (c, f), ms in table.items()}
-        elif usable:
-            schedule = usable[0]
+        cands = []
+        for c in usable:
+            if c == "sequential":
+                cands.append((c, 0, Qbox["Q"]))
+            elif c == "fused":
+                cands += [(c, f, q) for q in Qs for f in free_options]
+            else:
+                cands += [(c, f, Qs[len(Qs) // 2]) for f in free_options]
+        if len(cands) > 1:
+            # The parity checks left the device idle and its clock low, and the clock needs tens of milliseconds of load to come back
+            # (DESIGN.md section 4: 1.87 -> 2.30 GHz): whatever is measured first would lose.  So: a ramp, then every candidate twice,
+            # the second pass in the opposite order, best of the two.
+            configure(cands[-1])
+            for it in range(40):
+                run_schedule(cands[-1][0], it)
+            table = {}
+            for sweep in (cands, cands[::-1]):
+                for cand in sweep:
+                    table[cand] = min(table.get(cand, float("inf")), quick_ms(cand))
+            chosen = min(table, key=table.get)
+            calibration = {f"{c}" + (f", {q} chunks" if c != "sequential" else "") + (f", {f} CUs left free" if f else ""): round(ms, 4)
+                           for (c, f, q), ms in table.items()}
+            configure(chosen)
+            if not passes(chosen[0]):        # the chosen chunk count / CU limit, checked like the schedule itself
+                chosen = ("sequential", 0, Qbox["Q"])
+        elif cands:
+            chosen = cands[0]
         candidates = []
-    for cand in ([] if schedule else candidates):
+    for cand in ([] if chosen else candidates):
         if passes(cand):
-            schedule = cand
+            chosen = (cand, args.cus_free or 0, Qbox["Q"])
             break
         if rank == 0:
             print(f"warning: schedule {cand} unusable; falling back", file=sys.stderr)
-    if schedule is None:
+    if chosen is None:
         raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum")
+    schedule, cus_free, Q = chosen
+    configure(chosen)
     # The parity check above leaves the GPU idle while the host compares 1e7 elements, and its clocks drop: run rounds
     # for ~0.1 s so that the timed region does not start on a cold device even when --warmup is small, then the W
     # warmup steps proper, right before the timed region.
-    eng.set_cu_limit(cus - cus_free if cus_free else 0)
     for it in range(args.settle_rounds):          # a fixed count: every rank must issue the same collectives
         run_schedule(schedule, it)
         if it % 8 == 7:

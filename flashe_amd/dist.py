@@ -402,6 +402,16 @@ class ShardedRound:
         key = ("pipe", chunks)
         if getattr(self, "_pipe_key", None) == key:
             return
+        # the buffers of every chunk count used so far are kept: a calibration that alternates between chunk counts must not pay
+        # (or time) a gigabyte of allocations per switch
+        cache = self.__dict__.setdefault("_pipe_cache", {})
+        if getattr(self, "_pipe_key", None) is not None:
+            cache[self._pipe_key] = {k: getattr(self, k) for k in ("p_sub", "p_chunk", "p_partial", "p_result", "p_recv", "p_agg", "p_dec", "p_dmask")}
+        if key in cache:
+            for k, v in cache[key].items():
+                setattr(self, k, v)
+            self._pipe_key = key
+            return
         n, W, L, ops = self.n, self.world, self.L, self.ops
         sub = ((n + chunks * W - 1) // (chunks * W) + ALIGN - 1) // ALIGN * ALIGN
         self.p_sub, self.p_chunk = sub, sub * W

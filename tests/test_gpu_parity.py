@@ -656,7 +656,9 @@ def test_bench_multi_rank_flow(extra, tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 3 and d["steps"] == 3 and d["value"] > 0 and "bit-exact" in d["config"]["parity"]
     assert d["scaling"] == ("weak" if extra[1] == "2" else "strong")
-    assert set(d["config"]["schedule_calibration_ms"]) == {"fused", "pipelined", "sequential"}
+    cal = d["config"]["schedule_calibration_ms"]
+    assert "sequential" in cal and {k.split(",")[0] for k in cal} == {"fused", "pipelined", "sequential"} and \
+        {"fused, 3 chunks", "fused, 4 chunks", "fused, 8 chunks"} <= set(cal)
     assert d["config"]["clients_total"] == (9 if extra[1] == "2" else 5)
 
 
