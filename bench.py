@@ -60,12 +60,13 @@ def parse():
                     help="> 0: chunks of the pipelined / fused schedules (reduce, exchange, decrypt of chunk q run on a side stream "
                          "under the launch of chunk q + 1); 0: sequential phases only; default: 3, 4 and 8 take part in the calibration")
     ap.add_argument("--schedule", choices=["default", "auto", "fused", "pipelined", "sequential"], default="default",
-                    help="default = auto: whichever schedule (and chunk count, and number of CUs left free for the exchange) is fastest in an "
-                         "untimed calibration on this box / node, after a clock ramp, best of two passes in opposite orders; fused: per chunk one "
-                         "launch does every local encrypt plus the decrypt mask difference, the reduce (which then yields the plaintext "
-                         "aggregate) and the exchange hide under the next chunk's launch; pipelined: last client's encrypt chunked, reduce / "
-                         "exchange / decrypt on a side stream; sequential: all local encrypts in one launch, then reduce (+ exchange) fused "
-                         "with the decrypt")
+                    help="default: the two-launch round for config 2 on one GPU (the form profiles/ documents kernel by kernel), 'auto' for "
+                         "config 4 and whenever ranks exchange; auto: whichever schedule (and chunk count, and number of CUs left free for the "
+                         "exchange) is fastest in an untimed calibration on this box / node, after a clock ramp, best of two passes in opposite "
+                         "orders; fused: per chunk one launch does every local encrypt plus the decrypt mask difference, the reduce (which then "
+                         "yields the plaintext aggregate) and the exchange hide under the next chunk's launch; pipelined: last client's "
+                         "encrypt chunked, reduce / exchange / decrypt on a side stream; sequential: all local encrypts in one launch, then "
+                         "reduce (+ exchange) fused with the decrypt")
     ap.add_argument("--cus-free", type=int, default=None,
                     help="PRF launches leave this many CUs free for the RCCL transfer kernels of the overlapped schedules (default: 0, or "
                          "whichever of 0 / 16 / 32 / 48 calibrates fastest when ranks exchange)")
@@ -390,9 +391,14 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
     # used only if it passes; otherwise fall back to the next simpler one.
     order = ["fused", "pipelined", "sequential"]
     start = args.schedule
-    calibrate = start in ("auto", "default")
+    # default: BASELINE config 2 on one GPU runs the two-launch round -- the form whose per-kernel figures profiles/ holds (one chained
+    # launch over the whole vector per round; a calibrated run mixes launch shapes in a trace) -- everything else is calibrated;
+    # `--schedule auto` calibrates config 2 on one GPU as well (the fused round is 0-6 % faster there, depending on the box)
+    calibrate = start == "auto" or (start == "default" and (rnd.exchange or cfg != 2))
     if calibrate:
         start = "fused"
+    elif start == "default":
+        start = "sequential"
     if start == "fused" and b <= 64:
         start = "pipelined"              # the one-launch job list needs b > 64
     candidates = order[order.index(start):] if ops.side is not None else ["sequential"]
@@ -522,7 +528,10 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
                                          "(-> plaintext aggregate) and exchange hidden on a side stream",
                                 "pipelined": f"reduce / exchange / decrypt chunk-pipelined on a side stream ({Q} chunks)",
                                 "sequential": "two launches: all local encrypts, then reduce fused with decrypt"}[schedule],
-                   "schedule_calibration_ms": calibration, "cus_left_free_for_the_exchange": cus_free, "collectives": ("TEST DOUBLE: files, all ranks on one GPU (figures meaningless)" if args.test_comm_dir else
+                   "schedule_calibration_ms": calibration, "cus_left_free_for_the_exchange": cus_free,
+                   "schedule_note": None if calibration or args.schedule != "default" else
+                   "config 2 on one GPU runs the two-launch round by default (the form profiles/ documents kernel by kernel); --schedule auto "
+                   "also tries the fused and pipelined rounds (fused: 0-6 % faster, depending on the box)", "collectives": ("TEST DOUBLE: files, all ranks on one GPU (figures meaningless)" if args.test_comm_dir else
                                    "RCCL through libflashe_hip.so (no PyTorch)") if ops.comm else None,
                    "parity": "bit-exact (decrypted aggregate == plaintext sum on every rank, checked in-run)"},
         "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
