@@ -126,3 +126,21 @@ def test_host_result_pool_recycles_only_dead_arrays(monkeypatch):
     monkeypatch.setenv("FLASHE_HOST_POOL_MB", "0")
     off = engine._HostPool()
     assert off.empty(500_000, np.uint64).base is None
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "c_round")
+    cmd = ["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_round.c"),
+           "-L", os.path.join(ROOT, "flashe_amd"), "-l:libflashe_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "flashe_amd"),
+           "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def test_c_example_builds_against_the_header_and_the_library(tmp_path):
+    """examples/c_round.c -- a whole round through the C ABI from plain C11, host vectors in and out -- compiles without warnings
+    against include/flashe.h and links against the shared library (it RUNS in the GPU suite)."""
+    assert os.path.exists(_build_c_example(tmp_path))

@@ -687,6 +687,15 @@ def test_cu_limit_changes_the_launch_shape_not_the_result(E, oracle):
             eng.set_cu_limit(-1)
 
 
+def test_c_example_round_runs(tmp_path):
+    """The drop-in boundary from a non-Python host: examples/c_round.c (plain C11 against include/flashe.h) encrypts four clients'
+    vectors, reduces, telescopes the prefix list and decrypts -- the result must be the plain sum."""
+    import subprocess
+    from test_abi_and_host import _build_c_example
+    r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C_ROUND OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
 def test_staging_pool_under_a_tight_budget():
     """The host-pointer calls keep their device staging blocks (abi.hip `Tmp`) within FLASHE_STAGING_POOL_MB: with 3 MB allowed,
     a mix of sizes forces reuse, eviction of parked blocks, slots emptied in place and plain allocations for what does not
