@@ -687,6 +687,41 @@ def test_cu_limit_changes_the_launch_shape_not_the_result(E, oracle):
             eng.set_cu_limit(-1)
 
 
+def test_contexts_are_independent_across_threads(E, oracle):
+    """One ctx is not thread-safe, different ctxs are (include/flashe.h): four threads, each with its own engine (own stream, key
+    and bit width), run host-pointer and device calls concurrently -- ctypes releases the GIL during every call -- and every
+    result equals the oracle's; the shared pieces underneath (host result pool, library-level statics) must hold."""
+    import threading
+    errors = []
+
+    def worker(t):
+        try:
+            key = bytes((17 * t + i) & 255 for i in range(32))
+            b = (128, 64, 100, 23)[t]
+            eng = E.Engine(key, b, device=0)
+            rng = np.random.Generator(np.random.PCG64(900 + t))
+            for rep in range(12):
+                n = int(rng.integers(1, 200_000))
+                pt = rng.integers(0, 2 ** min(b, 63), n, dtype=np.uint64)
+                ct = eng.encrypt(rep, t, E.SCHEME_DOUBLE, 16, pt)
+                assert np.array_equal(ct, oracle.encrypt(key, rep, t, "double", 16, b, pt)), (t, rep, "encrypt")
+                dec = eng.decrypt(rep, [t + 1], [t], 16, ct)
+                assert np.array_equal(dec[:, 0], pt), (t, rep, "decrypt")
+                d = eng.upload(ct)
+                out = eng.alloc_vec(n)
+                eng.aggregate_elem_dev([d, d, d], n, out)
+                assert np.array_equal(out.download(np.uint64, ct.size).reshape(ct.shape), oracle.aggregate_elem([ct, ct, ct], b)), (t, rep, "reduce")
+        except Exception as exc:          # pragma: no cover - reported below
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(600)
+    assert not errors, errors
+
+
 def test_c_example_round_runs(tmp_path):
     """The drop-in boundary from a non-Python host: examples/c_round.c (plain C11 against include/flashe.h) encrypts four clients'
     vectors, reduces, telescopes the prefix list and decrypts -- the result must be the plain sum."""
