@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 # The oracle's OpenMP team (parity gates, CPU baseline) must SLEEP between its parallel regions: spinning workers burn the
 # container's CPU quota and the throttling hits the thread that submits GPU work (measured: 100 launches 0.3 ms -> 4.9 ms).
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("NCCL_DEBUG", "WARN")     # RCCL's own warnings go to stderr: the first multi-GPU run must not fail silently
 # RCCL shares device memory between the ranks of a node through dmabuf IPC handles; the legacy IPC mode is not supported by the host
 # driver of this pool (hipIpcGetMemHandle: invalid argument).  Must be in the environment before the HIP runtime starts.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -59,14 +60,23 @@ def parse():
     ap.add_argument("--pipeline-chunks", type=int, default=None,
                     help="> 0: chunks of the pipelined / fused schedules (reduce, exchange, decrypt of chunk q run on a side stream "
                          "under the launch of chunk q + 1); 0: sequential phases only; default: 3, 4 and 8 take part in the calibration")
-    ap.add_argument("--schedule", choices=["default", "auto", "fused", "pipelined", "sequential"], default="default",
+    ap.add_argument("--schedule", choices=["default", "auto", "fused", "pipelined", "sequential", "partial-agg"], default="default",
                     help="default: the two-launch round for config 2 on one GPU (the form profiles/ documents kernel by kernel), 'auto' for "
                          "config 4 and whenever ranks exchange; auto: whichever schedule (and chunk count, and number of CUs left free for the "
                          "exchange) is fastest in an untimed calibration on this box / node, after a clock ramp, best of two passes in opposite "
                          "orders; fused: per chunk one launch does every local encrypt plus the decrypt mask difference, the reduce (which then "
                          "yields the plaintext aggregate) and the exchange hide under the next chunk's launch; pipelined: last client's "
                          "encrypt chunked, reduce / exchange / decrypt on a side stream; sequential: all local encrypts in one launch, then "
-                         "reduce (+ exchange) fused with the decrypt")
+                         "reduce (+ exchange) fused with the decrypt; partial-agg: the sequential round with the encrypt launch also writing the "
+                         "local partial aggregate sum_c ct_c (SURVEY.md section 5: each GPU encrypts and locally mod-adds its share), so that "
+                         "the second launch decrypts (or exchanges) ONE vector instead of re-reading C ciphertexts.  With several GPUs the "
+                         "sequential round is always timed first and kept as the fallback line")
+    ap.add_argument("--deadline", type=float, default=float(os.environ.get("FLASHE_BENCH_DEADLINE_S", "420")),
+                    help="N > 1: seconds the start-up + sequential round may take before every rank gives up (RCCL has no timeouts)")
+    ap.add_argument("--calibration-deadline", type=float, default=float(os.environ.get("FLASHE_BENCH_CALIBRATION_DEADLINE_S", "150")),
+                    help="N > 1: seconds the optional overlapped schedules (calibration + their timed region) may take; when it passes, or "
+                         "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
+    ap.add_argument("--no-unchained", action="store_true", help="skip the FLASHE_CHAIN=0 reference measurement (config 2, one GPU)")
     ap.add_argument("--cus-free", type=int, default=None,
                     help="PRF launches leave this many CUs free for the RCCL transfer kernels of the overlapped schedules (default: 0, or "
                          "whichever of 0 / 16 / 32 / 48 calibrates fastest when ranks exchange)")
@@ -79,10 +89,6 @@ def parse():
                     help="elements of the workload the CPU baseline round runs on (default: all of config 2; ~0.2-2 s)")
     ap.add_argument("--no-python-baseline", action="store_true", help="skip the structure-faithful Python baseline (~10-20 s)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the one PCIe-inclusive round through the host-pointer API")
-    ap.add_argument("--test-comm-dir", default=None,
-                    help="TEST HOOK (tests/test_gpu_parity.py): every rank uses device 0 and the exchange goes through files in this "
-                         "directory (tests/shm_comm.py) instead of RCCL, so that the N > 1 flow of this script can run on a one-GPU box; "
-                         "the JSON line says so and the figure means nothing")
     return ap.parse_args()
 
 
@@ -258,7 +264,26 @@ def sum_mod(vectors, n, b):
     return lo, hi
 
 
-def main():
+class _NoWatchdog:
+    """World size 1: nothing to wait for, nothing to fall back to."""
+    exit_code = 0
+
+    def arm(self, seconds, phase):
+        pass
+
+    def disarm(self):
+        pass
+
+    def finish(self):
+        return True
+
+    def abort(self, reason):
+        pass
+
+
+def main(comm_factory=None, device_override=None):
+    """comm_factory(rank, world) / device_override: TEST SEAMS, never set by this script -- tests/bench_shm.py runs this very flow with
+    several ranks on ONE GPU by passing a file-based double of RcclComm (tests/shm_comm.py) and device 0 for every rank."""
     if len(sys.argv) == 3 and sys.argv[1] == "--py-baseline-child":
         b, C, ns = (int(v) for v in sys.argv[2].split(","))
         print(json.dumps(python_structure_baseline(b, C, [plaintext(c, ns, b) for c in range(C)], ns)), flush=True)
@@ -266,53 +291,89 @@ def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
-        # launched bare: start the per-GPU processes BEFORE anything touches the GPU (flashe_amd.dist.spawn, no torchrun needed)
+        # launched bare: start the per-GPU processes BEFORE anything touches the GPU (flashe_amd.dist.spawn, no torchrun needed);
+        # spawn watches all ranks and stops the rest when one fails
         from flashe_amd.dist import spawn
-        sys.exit(spawn(args.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
+        sys.exit(spawn(args.gpus, [os.path.abspath(sys.argv[0])] + sys.argv[1:]))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
-    import numpy as np
-    from flashe_amd.dist import HipOps, RcclComm, ShardedRound, deal_clients
-    from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine
-
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    b, K, W, J = args.bits, args.steps, args.warmup, args.n_jobs
-    L = 2 if b > 64 else 1
-    cfg = args.config
-    n = args.n or {2: 10_000_000, 3: LENET, 4: RESNET50, 5: RESNET50}[cfg]
-
-    if args.test_comm_dir:
-        local_rank = 0
-    eng = Engine(KEY, b, device=local_rank)
-    eng.selftest()
-    backend = {"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend]
-    eng.set_prf_backend(backend)
-    two_streams = (args.pipeline_chunks is None or args.pipeline_chunks > 0) and args.schedule != "sequential" and cfg in (2, 4)
-    side = Engine(KEY, b, device=local_rank) if two_streams else None
-    if args.test_comm_dir:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from shm_comm import ShmComm
-        comm = ShmComm(rank, world, args.test_comm_dir)
-    else:
-        comm = RcclComm.from_env(eng) if (world > 1 or args.force_dist) else None
-    ops = HipOps(eng, side, comm)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if device_override is None else device_override
 
     out = {"metric": "ciphertexts/sec (enc+agg+dec), 1e7-elem vector; achieved HBM GB/s fraction", "unit": "ciphertexts/s",
-           "n_gpus": world, "steps": K, "warmup": W, "higher_is_better": True, "vs_baseline": None,
-           "dtype": "u128" if L == 2 else "u64", "data": "synthetic"}
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+           "dtype": "u128" if args.bits > 64 else "u64", "data": "synthetic"}
 
-    if cfg in (2, 4):
-        result = bench_dense(args, cfg, n, ops, rank, world, out)
-    elif cfg == 3:
-        result = bench_precompute(args, n, ops, rank, world, out)
+    # N > 1: RCCL has no timeouts, so every rank runs a watchdog (flashe_amd.dist.Watchdog: per-phase deadline + an abort file any
+    # rank can raise).  When it fires, rank 0 prints the best line it already holds -- the plain sequential round is timed FIRST
+    # and kept as the fallback -- and every rank leaves through os._exit (an exit, never an exec).
+    state = {"fallback": None}
+    if world > 1:
+        from flashe_amd.dist import Watchdog
+
+        def on_fire(reason):
+            print(f"rank {rank}: watchdog: {reason}", file=sys.stderr)
+            if rank != 0:
+                return
+            line = state["fallback"]
+            if line is not None:
+                line["config"]["schedule_fallback_reason"] = reason
+            else:
+                line = dict(out, value=None, ms_per_step=None, error=f"no round completed: {reason}")
+            print(json.dumps(line), flush=True)
+        wd = Watchdog(rank, world, on_fire)
+        wd.arm(args.deadline, "start-up (engine, RCCL communicator) and the sequential round")
     else:
-        result = bench_sparse(args, n, ops, rank, world, out)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+        wd = _NoWatchdog()
+
+    try:
+        from flashe_amd.dist import HipOps, RcclComm
+        from flashe_amd.engine import Engine
+        b = args.bits
+        cfg = args.config
+        n = args.n or {2: 10_000_000, 3: LENET, 4: RESNET50, 5: RESNET50}[cfg]
+        eng = Engine(KEY, b, device=local_rank)
+        eng.selftest()
+        backend = {"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend]
+        eng.set_prf_backend(backend)
+        two_streams = (args.pipeline_chunks is None or args.pipeline_chunks > 0) and args.schedule != "sequential" and cfg in (2, 4)
+        side = Engine(KEY, b, device=local_rank) if two_streams else None
+        if comm_factory is not None:
+            comm = comm_factory(rank, world)
+        else:
+            comm = RcclComm.from_env(eng) if (world > 1 or args.force_dist) else None
+        ops = HipOps(eng, side, comm)
+
+        if cfg in (2, 4):
+            result = bench_dense(args, cfg, n, ops, rank, world, out, wd, state)
+        elif cfg == 3:
+            result = bench_precompute(args, n, ops, rank, world, out)
+        else:
+            result = bench_sparse(args, n, ops, rank, world, out)
+        if not wd.finish():                   # the watchdog got there first and is printing / exiting
+            time.sleep(30)
+            os._exit(wd.exit_code)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+    except BaseException as exc:
+        if world == 1:
+            raise
+        # a rank that stops must take the others with it (they would wait in their next collective forever): raise the abort flag,
+        # every watchdog fires within a poll interval -- rank 0's prints the fallback line if the sequential round is already in
+        import traceback
+        traceback.print_exc()
+        wd.abort(f"{type(exc).__name__}: {exc}")
+        time.sleep(30)
+        os._exit(wd.exit_code)
     if comm is not None:
+        # the line is out; nothing after this point may keep the process (or its GPU) alive
+        if world > 1:
+            import threading
+            threading.Timer(30.0, lambda: os._exit(0)).start()
         ops.barrier()
         comm.close()
+        if world > 1:
+            sys.stdout.flush()
+            os._exit(0)
 
 
 def timed_region(ops, K, step):
@@ -337,13 +398,14 @@ def traffic_ratio(kernel_key):
 
 
 # ---- configs 2 and 4: dense double-mask round, clients sharded over ranks ------------------------------------------------
-def bench_dense(args, cfg, n, ops, rank, world, out):
+def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
     import numpy as np
+    from oracle import flashe_oracle as orc          # parity gate only (before any timed region)
     from flashe_amd.dist import ShardedRound, deal_clients
-    from flashe_amd.engine import SCHEME_DOUBLE
     eng = ops.engine
     b, K, W, J = args.bits, args.steps, args.warmup, args.n_jobs
     L = 2 if b > 64 else 1
+    is_double = bool(getattr(ops.comm, "IS_TEST_DOUBLE", False))
     if cfg == 2:
         cpr = args.clients or 10                          # weak scaling: every GPU plays `cpr` clients
         total = world * cpr
@@ -361,6 +423,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
     Qbox = {"Q": Qs[len(Qs) // 2]}                       # the chunk count run_schedule uses (the calibration varies it)
     enc_ev = [(eng.event(), eng.event()) for _ in range(K)]
     ph_ev = [[eng.event() for _ in range(3)] for _ in range(K)]
+    partial = args.schedule == "partial-agg"
 
     def run_schedule(schedule, it, k=None):
         """One round.  k = index of the timed step (events recorded) or None (warmup / parity run)."""
@@ -372,77 +435,206 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
         if schedule == "pipelined":
             return rnd.run_pipelined(it, pts, 1, chunks=Q, batch_events=enc_ev[k] if (k is not None and C > 1) else None)
         if k is None:
-            return rnd.run(it, pts, 1)
+            return rnd.run(it, pts, 1, partial_agg=partial)
         eng.record(ph_ev[k][0])
-        rnd.encrypt_phase(it, pts, 1)              # one launch: every local client's encrypt (one chain of C + 1 streams)
+        rnd.encrypt_phase(it, pts, 1, partial_agg=partial)   # one launch: every local client's encrypt (one chain of C + 1 streams)
         eng.record(ph_ev[k][1])
-        res = rnd.reduce_decrypt_phase(it)         # reduce (+ exchange) fused with the decrypt of its result
+        res = rnd.reduce_decrypt_phase(it, partial_agg=partial)   # reduce (+ exchange) fused with the decrypt of its result
         eng.record(ph_ev[k][2])
         return res
 
     lo, hi = sum_mod((host_pts[c] if c in host_pts else plaintext(c, n, b) for c in range(total)), n, b)   # one vector at a time
+    orc.build()
+    want_ct = {}
+
+    def ciphertext_ok():
+        """The ciphertexts the timed kernels write are the reference's: the first and the last local client's vector at iter 0 against
+        the oracle's encrypt (the round trip alone would pass for ANY mask stream, double masks telescope)."""
+        for c in sorted({0, C - 1}) if C else []:
+            if c not in want_ct:
+                want_ct[c] = orc.encrypt(KEY, 0, mine[c], "double", J, b, host_pts[mine[c]])
+            if not np.array_equal(ops.read(rnd.ct[c], n * L).reshape(n, L), want_ct[c]):
+                return False
+        return True
 
     def parity_ok(res):
         got = ops.read((res, 0), n * L).reshape(n, L)
-        good = np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi))
+        good = np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi)) and ciphertext_ok()
         return ops.allreduce(1.0 if good else 0.0, 1) > 0.5          # every rank must agree on the schedule used
 
-    # parity gate before any timing counts: decrypted aggregate == plaintext sum (mod 2^b).  A schedule is
-    # used only if it passes; otherwise fall back to the next simpler one.
-    order = ["fused", "pipelined", "sequential"]
-    start = args.schedule
-    # default: BASELINE config 2 on one GPU runs the two-launch round -- the form whose per-kernel figures profiles/ holds (one chained
-    # launch over the whole vector per round; a calibrated run mixes launch shapes in a trace) -- everything else is calibrated;
-    # `--schedule auto` calibrates config 2 on one GPU as well (the fused round is 0-6 % faster there, depending on the box)
-    calibrate = start == "auto" or (start == "default" and (rnd.exchange or cfg != 2))
-    if calibrate:
-        start = "fused"
-    elif start == "default":
-        start = "sequential"
-    if start == "fused" and b <= 64:
-        start = "pipelined"              # the one-launch job list needs b > 64
-    candidates = order[order.index(start):] if ops.side is not None else ["sequential"]
-
-    def passes(cand):
-        try:
-            return parity_ok(run_schedule(cand, 0))
-        except Exception as exc:          # never lose the measurement to an optional schedule
-            print(f"rank {rank}: schedule {cand} raised {exc!r}", file=sys.stderr)
-            if world > 1:
-                raise
-            return False
-
-    # An RCCL transfer kernel (36.8 KiB of LDS, 248-256 VGPRs per lane) never shares a CU with a PRF workgroup (128 KiB of LDS), and it
-    # starts only when ALL its channels find a CU: beside a PRF launch that fills the device it simply waits for the launch to end
-    # (tests/perf/rccl_overlap.py: 16 channels need 16 free CUs, the default configuration 32).  So the schedules that hide the
-    # exchange under the next chunk's encrypts are also tried with the PRF launches leaving CUs free; results do not depend on it.
     cus = eng.cu_count
-    free_options = [args.cus_free] if args.cus_free is not None else [0, 16, 32, 48] if (rnd.exchange and not args.test_comm_dir) else [0]
 
     def configure(cand):
         sched, free, q = cand
         Qbox["Q"] = q
         eng.set_cu_limit(cus - free if free else 0)
 
-    def quick_ms(cand, rounds=8):
-        """Untimed-region calibration: ms per round of (schedule, CUs left free, chunks), MAX over ranks."""
+    def measure(cand):
+        """Settle + W warmup + EXACTLY K timed rounds of one configuration -> (elapsed s, launch ms list, phase ms array or None)."""
+        schedule = cand[0]
         configure(cand)
-        for it in range(2):
-            run_schedule(cand[0], it)
-        return timed_region(ops, rounds, lambda k: run_schedule(cand[0], k)) * 1e3 / rounds
+        # The parity check leaves the GPU idle while the host compares 1e7 elements, and its clocks drop: run rounds for ~0.1 s so that
+        # the timed region does not start on a cold device even when --warmup is small, then the W warmup steps proper.
+        for it in range(args.settle_rounds):          # a fixed count: every rank must issue the same collectives
+            run_schedule(schedule, it)
+            if it % 8 == 7:
+                ops.sync()
+        for w in range(W):
+            run_schedule(schedule, w)
+        elapsed = timed_region(ops, K, lambda k: run_schedule(schedule, k, k))
+        if schedule == "sequential":
+            enc_pairs = [(p[0], p[1]) for p in ph_ev]      # the batched encrypt launch of every timed round
+        else:
+            enc_pairs = enc_ev if (schedule == "fused" or C > 1) else []
+        enc_ms = [eng.elapsed_ms(e0, e1) for e0, e1 in enc_pairs]
+        ph = np.array([[eng.elapsed_ms(p[i], p[i + 1]) for i in range(2)] for p in ph_ev]) if schedule == "sequential" else None
+        return elapsed, enc_ms, ph
 
-    chosen, calibration = None, None
-    if calibrate and len(candidates) > 1:
-        usable = [c for c in candidates if passes(c)]
+    rccl_world = ops.comm.rccl_world() if (ops.comm is not None and hasattr(ops.comm, "rccl_world")) else None
+    ranks_counted = int(round(ops.allreduce(1.0, 2))) if ops.comm is not None else 1      # a SUM over the communicator: every rank adds 1
+
+    def make_line(cand, elapsed, enc_ms, ph, calibration, parity_all_ranks):
+        schedule, cus_free, Q = cand
+        ms_per_step = elapsed * 1e3 / K
+        pt_bytes = 8
+        enc_avg_ms = float(np.mean(enc_ms)) if enc_ms else float("nan")
+        chained = os.environ.get("FLASHE_CHAIN", "1") != "0"          # consecutive clients share their PRF streams (every bit width)
+        if schedule == "fused":
+            # per launch: C encrypt links (u64 plaintext in, L-limb ciphertext out) + the mask-difference job (L limbs out) over one
+            # chunk of the vector; a chain of C clients is C + 1 AES streams, the mask difference two more
+            elems = n / Q
+            alg_bytes = elems * (C * (pt_bytes + 8 * L)) + (elems / world) * 8 * L
+            blocks = (C + 1 if chained else 2 * C) * elems + 2 * elems / world
+            kernel_key = "prf_chain_kernel"
+            kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub: {C} client encrypts sharing {C + 1} streams + "
+                           f"decrypt mask difference, 1/{Q} of the vector per launch)")
+        else:
+            vec = (C - 1) if (schedule == "pipelined" and C > 1) else C
+            alg_bytes = vec * n * (pt_bytes + 8 * L) + (n * 8 * L if (partial and schedule == "sequential") else 0)
+            blocks = (vec + 1 if chained else 2 * vec) * (n if L == 2 else -(-n // (128 // b)))
+            kernel_key = "prf_chain_kernel" if L == 2 else "prf_small_chain_kernel"
+            kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub = encrypt: {vec} consecutive clients per launch share "
+                           f"{vec + 1} PRF streams, ct_c = pt_c + S_c - S_(c+1)"
+                           + (", plus the local partial aggregate sum_c ct_c written by the same launch)" if partial and schedule == "sequential" else ")")) if L == 2 else \
+                (f"prf_small_chain_kernel (b <= 64: one AES block = {128 // b} elements, a lane owns its block(s) for all {vec + 1} streams of the "
+                 f"{vec}-client chain)")
+        achieved = alg_bytes / (enc_avg_ms * 1e-3) / 1e9
+        ratio, tsrc = traffic_ratio(kernel_key)
+        lookups = (196.1 if chained else 196.5) if L == 2 else 208.0    # b <= 64: one-step counter shortcut only
+        lds_peak = 32 * cus * 2.4e9                                      # ds_read_b32: 32 lanes per clock per CU (MI355X_MICROARCH.md, LDS)
+        frac_lds = lookups * blocks / (enc_avg_ms * 1e-3) / lds_peak
+        # the round's algorithmic bytes on this GPU (SURVEY.md 8d): C encrypts (pt in, ct out) + the C-way reduce (C in, 1 out) + the
+        # decrypt of its result (1 in, 1 out); with several GPUs the reduce / decrypt cover a 1/world slice after the exchange
+        round_bytes = n * (C * (pt_bytes + 8 * L) + 8 * L * (C + 1)) + (n / world) * (8 * L * (world + 1 if world > 1 else 0) + 16 * L)
+        line = dict(out)
+        line.update({
+            "value": total * n / (elapsed / K), "ms_per_step": ms_per_step, "scaling": scaling,
+            "config": {"workload": f"BASELINE config {cfg}: n={n}-element vector, 64-bit plaintext / {b}-bit modulus, "
+                                   + (f"{C} clients per GPU" if cfg == 2 else f"{total} clients dealt {[len(x) for x in deal_clients(total, world)]} over the GPUs")
+                                   + f", double mask, n_jobs={J}; round = {total} encrypts + {total}-way aggregate + 1 decrypt"
+                                   + (f"; {world} GPUs: all-to-all reduce-scatter (grouped ncclSend/ncclRecv) + sliced decrypt + all-gather" if world > 1 else ""),
+                       "n": n, "int_bits": b, "clients_total": total, "clients_this_gpu": C, "mask": "double", "prf_backend": args.prf_backend,
+                       "schedule": {"fused": f"{Q} chunks; per chunk one launch = all local encrypts + decrypt mask difference; reduce "
+                                             "(-> plaintext aggregate) and exchange hidden on a side stream",
+                                    "pipelined": f"reduce / exchange / decrypt chunk-pipelined on a side stream ({Q} chunks)",
+                                    "sequential": ("two launches: all local encrypts + their local partial aggregate, then the decrypt of it"
+                                                   if partial else "two launches: all local encrypts, then reduce fused with decrypt")}[schedule],
+                       "schedule_name": "partial-agg" if (partial and schedule == "sequential") else schedule,
+                       "schedule_calibration_ms": calibration, "cus_left_free_for_the_exchange": cus_free,
+                       "schedule_fallback_reason": None,
+                       "schedule_note": None if calibration or args.schedule != "default" else
+                       "config 2 on one GPU runs the two-launch round by default (the form profiles/ documents kernel by kernel); --schedule auto "
+                       "also tries the fused and pipelined rounds (fused: 0-6 % faster, depending on the box)",
+                       "collectives": (getattr(ops.comm, "LABEL", None) or "RCCL through libflashe_hip.so (no PyTorch)") if ops.comm else None,
+                       "rccl_world": rccl_world, "ranks_counted_by_allreduce": ranks_counted, "ranks_parity_ok": bool(parity_all_ranks),
+                       "parity": "bit-exact (on every rank, checked in-run before timing: decrypted aggregate == plaintext sum, and the first and "
+                                 "last local client's ciphertext == the oracle's encrypt)"},
+            "roofline": {"kernel": kernel_name, "bound": "lds" if L == 2 or 128 // b <= 4 else "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "frac_hbm": achieved / HBM_PEAK_GBPS, "frac_lds": frac_lds,
+                         "traffic": ratio * alg_bytes if ratio else None,
+                         "traffic_source": (f"{tsrc}: HBM bytes per algorithmic byte measured once with rocprofv3 PMC passes on this kernel "
+                                            "(FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) x this run's algorithmic bytes; not re-measured in-run")
+                         if ratio else None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": enc_avg_ms, "launches_timed": len(enc_ms),
+                         "aes_blocks_per_launch": blocks, "aes_blocks_per_s": blocks / (enc_avg_ms * 1e-3),
+                         # LDS lookups per AES block: 11 full rounds x 16 + the final round's 16 + 4 (round 2) + the element's one
+                         # counter-dependent lookup of round 1 shared by its C + 1 blocks; half-tile tails take 208
+                         "lds_lookup_bound": {"lookups_per_block": lookups, "peak_lookups_per_s_at_2.4GHz": lds_peak,
+                                              "achieved_lookups_per_s": lookups * blocks / (enc_avg_ms * 1e-3),
+                                              "frac_at_2.4GHz": frac_lds},
+                         "note": "integer path: this kernel's roof is the AES rate (LDS lookups: `bound`, `frac_lds`), not HBM; `frac` = `frac_hbm` is "
+                                 "the HBM fraction, reported as required"},
+            "round_hbm_frac": round_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "round_algorithmic_bytes_this_gpu": round_bytes,
+            "phases_ms": ({"round": ms_per_step, "note": "phases overlap in this schedule"} if schedule != "sequential" else
+                          {"encrypt_xC": float(ph[:, 0].mean()), "reduce_plus_decrypt": float(ph[:, 1].mean())}),
+        })
+        return line
+
+    # ---- phase A: the plain two-launch round (collectives on the main stream, nothing overlapped), FIRST -------------------------
+    # parity gate before any timing counts; then its K timed rounds.  With several ranks this line is kept as the fallback: whatever
+    # happens in the optional schedules afterwards (exception, disagreement, a hang until the deadline), rank 0 still prints it.
+    seq = ("sequential", 0, Qbox["Q"])
+    configure(seq)
+    if not parity_ok(run_schedule("sequential", 0)):
+        raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum, or ciphertext != oracle")
+    want_explicit = args.schedule in ("fused", "pipelined")
+    seq_elapsed = seq_line = None
+    if not (want_explicit and world == 1):
+        seq_elapsed, seq_enc, seq_ph = measure(seq)
+        if rank == 0:
+            seq_line = make_line(seq, seq_elapsed, seq_enc, seq_ph, None, True)
+        state["fallback"] = seq_line
+        wd.exit_code = 0                                   # from here on a valid line exists: a fallback is a success
+
+    # ---- phase B: the overlapped schedules, optional, under their own deadline ---------------------------------------------------
+    # default: BASELINE config 2 on one GPU runs the two-launch round -- the form whose per-kernel figures profiles/ holds (one chained
+    # launch over the whole vector per round; a calibrated run mixes launch shapes in a trace) -- everything else is calibrated;
+    # `--schedule auto` calibrates config 2 on one GPU as well (the fused round is 0-6 % faster there, depending on the box)
+    calibrate = args.schedule == "auto" or (args.schedule == "default" and (rnd.exchange or cfg != 2))
+    if ops.side is None or args.schedule in ("sequential", "partial-agg"):
+        overlapped = []
+    elif calibrate:
+        overlapped = ["fused", "pipelined"]
+    elif want_explicit:
+        overlapped = [args.schedule]
+    else:
+        overlapped = []                                    # config 2 on one GPU, default: the two-launch round only
+    if b <= 64:                                            # the one-launch job list of the fused round needs b > 64
+        overlapped = list(dict.fromkeys("pipelined" if s_ == "fused" else s_ for s_ in overlapped))
+    line = seq_line
+    if overlapped:
+        wd.arm(args.calibration_deadline, "calibration of the overlapped schedules")
+        # An RCCL transfer kernel (36.8 KiB of LDS, 248-256 VGPRs per lane) never shares a CU with a PRF workgroup (128 KiB of LDS), and
+        # it starts only when ALL its channels find a CU: beside a PRF launch that fills the device it simply waits for the launch to end
+        # (tests/perf/rccl_overlap.py: 16 channels need 16 free CUs, the default configuration 32).  So the schedules that hide the
+        # exchange under the next chunk's encrypts are also tried with the PRF launches leaving CUs free; results do not depend on it.
+        free_options = [args.cus_free] if args.cus_free is not None else [0, 16, 32, 48] if (rnd.exchange and not is_double) else [0]
+
+        def quick_ms(cand, rounds=8):
+            """Untimed-region calibration: ms per round of (schedule, CUs left free, chunks), MAX over ranks."""
+            configure(cand)
+            for it in range(2):
+                run_schedule(cand[0], it)
+            return timed_region(ops, rounds, lambda k: run_schedule(cand[0], k)) * 1e3 / rounds
+
+        usable = []
+        for s_ in overlapped:
+            configure((s_, 0, Qs[len(Qs) // 2]))
+            if parity_ok(run_schedule(s_, 0)):
+                usable.append(s_)
+            elif rank == 0:
+                print(f"warning: schedule {s_} fails the parity gate; not used", file=sys.stderr)
         cands = []
         for c in usable:
-            if c == "sequential":
-                cands.append((c, 0, Qbox["Q"]))
-            elif c == "fused":
+            if c == "fused":
                 cands += [(c, f, q) for q in Qs for f in free_options]
             else:
                 cands += [(c, f, Qs[len(Qs) // 2]) for f in free_options]
-        if len(cands) > 1:
+        chosen, calibration = None, None
+        if calibrate and cands:
+            cands.append(seq)
             # The parity checks left the device idle and its clock low, and the clock needs tens of milliseconds of load to come back
             # (DESIGN.md section 4: 1.87 -> 2.30 GHz): whatever is measured first would lose.  So: a ramp, then every candidate twice,
             # the second pass in the opposite order, best of the two.
@@ -456,115 +648,68 @@ def bench_dense(args, cfg, n, ops, rank, world, out):
             chosen = min(table, key=table.get)
             calibration = {f"{c}" + (f", {q} chunks" if c != "sequential" else "") + (f", {f} CUs left free" if f else ""): round(ms, 4)
                            for (c, f, q), ms in table.items()}
-            configure(chosen)
-            if not passes(chosen[0]):        # the chosen chunk count / CU limit, checked like the schedule itself
-                chosen = ("sequential", 0, Qbox["Q"])
+            if chosen[0] != "sequential":
+                configure(chosen)
+                if not parity_ok(run_schedule(chosen[0], 0)):   # the chosen chunk count / CU limit, checked like the schedule itself
+                    chosen = seq
         elif cands:
-            chosen = cands[0]
-        candidates = []
-    for cand in ([] if chosen else candidates):
-        if passes(cand):
-            chosen = (cand, args.cus_free or 0, Qbox["Q"])
-            break
-        if rank == 0:
-            print(f"warning: schedule {cand} unusable; falling back", file=sys.stderr)
-    if chosen is None:
-        raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum")
-    schedule, cus_free, Q = chosen
-    configure(chosen)
-    # The parity check above leaves the GPU idle while the host compares 1e7 elements, and its clocks drop: run rounds
-    # for ~0.1 s so that the timed region does not start on a cold device even when --warmup is small, then the W
-    # warmup steps proper, right before the timed region.
-    for it in range(args.settle_rounds):          # a fixed count: every rank must issue the same collectives
-        run_schedule(schedule, it)
-        if it % 8 == 7:
-            ops.sync()
-    for w in range(W):
-        run_schedule(schedule, w)
-    elapsed = timed_region(ops, K, lambda k: run_schedule(schedule, k, k))
-
-    if schedule == "sequential":
-        enc_pairs = [(p[0], p[1]) for p in ph_ev]      # the batched encrypt launch of every timed round
-    else:
-        enc_pairs = enc_ev if (schedule == "fused" or C > 1) else []
-    enc_ms = [eng.elapsed_ms(e0, e1) for e0, e1 in enc_pairs]
-    ph = np.array([[eng.elapsed_ms(p[i], p[i + 1]) for i in range(2)] for p in ph_ev]) if schedule == "sequential" else None
+            chosen = cands[0]                                    # an explicit --schedule fused / pipelined
+        if chosen is not None and chosen[0] != "sequential":
+            elapsed, enc_ms, ph = measure(chosen)
+            if rank == 0:
+                line = make_line(chosen, elapsed, enc_ms, ph, calibration, True)
+                if seq_elapsed is not None:
+                    line["sequential_ms_per_step"] = seq_elapsed * 1e3 / K
+        elif rank == 0 and line is not None:
+            line["config"]["schedule_calibration_ms"] = calibration
+        configure(seq)
+    wd.arm(args.deadline, "closing")
     if rank != 0:
         return None
+    if line is None:
+        raise SystemExit(f"--schedule {args.schedule} did not produce a usable round here (it needs a side stream and must pass the parity gate)")
 
-    ms_per_step = elapsed * 1e3 / K
-    pt_bytes = 8
-    enc_avg_ms = float(np.mean(enc_ms)) if enc_ms else float("nan")
-    chained = os.environ.get("FLASHE_CHAIN", "1") != "0"          # consecutive clients share their PRF streams (every bit width)
-    if schedule == "fused":
-        # per launch: C encrypt links (u64 plaintext in, L-limb ciphertext out) + the mask-difference job (L limbs out) over one
-        # chunk of the vector; a chain of C clients is C + 1 AES streams, the mask difference two more
-        elems = n / Q
-        alg_bytes = elems * (C * (pt_bytes + 8 * L)) + (elems / world) * 8 * L
-        blocks = (C + 1 if chained else 2 * C) * elems + 2 * elems / world
-        kernel_key = "prf_chain_kernel"
-        kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub: {C} client encrypts sharing {C + 1} streams + "
-                       f"decrypt mask difference, 1/{Q} of the vector per launch)")
-    else:
-        vec = (C - 1) if (schedule == "pipelined" and C > 1) else C
-        alg_bytes = vec * n * (pt_bytes + 8 * L)          # u64 plaintext in + L-limb ciphertext out, per client vector
-        blocks = (vec + 1 if chained else 2 * vec) * (n if L == 2 else -(-n // (128 // b)))
-        kernel_key = "prf_chain_kernel" if L == 2 else "prf_small_chain_kernel"
-        kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub = encrypt: {vec} consecutive clients per launch share "
-                       f"{vec + 1} PRF streams, ct_c = pt_c + S_c - S_(c+1))") if L == 2 else \
-            (f"prf_small_chain_kernel (b <= 64: one AES block = {128 // b} elements, a lane owns its block(s) for all {vec + 1} streams of the "
-             f"{vec}-client chain)")
-    achieved = alg_bytes / (enc_avg_ms * 1e-3) / 1e9
-    ratio, tsrc = traffic_ratio(kernel_key)
-    lookups = (196.1 if chained else 196.5) if L == 2 else 208.0    # b <= 64: one-step counter shortcut only
-    out.update({
-        "value": total * n / (elapsed / K), "ms_per_step": ms_per_step, "scaling": scaling,
-        "config": {"workload": f"BASELINE config {cfg}: n={n}-element vector, 64-bit plaintext / {b}-bit modulus, "
-                               + (f"{C} clients per GPU" if cfg == 2 else f"{total} clients dealt {[len(x) for x in deal_clients(total, world)]} over the GPUs")
-                               + f", double mask, n_jobs={J}; round = {total} encrypts + {total}-way aggregate + 1 decrypt"
-                               + (f"; {world} GPUs: all-to-all reduce-scatter (grouped ncclSend/ncclRecv) + sliced decrypt + all-gather" if world > 1 else ""),
-                   "n": n, "int_bits": b, "clients_total": total, "clients_this_gpu": C, "mask": "double", "prf_backend": args.prf_backend,
-                   "schedule": {"fused": f"{Q} chunks; per chunk one launch = all local encrypts + decrypt mask difference; reduce "
-                                         "(-> plaintext aggregate) and exchange hidden on a side stream",
-                                "pipelined": f"reduce / exchange / decrypt chunk-pipelined on a side stream ({Q} chunks)",
-                                "sequential": "two launches: all local encrypts, then reduce fused with decrypt"}[schedule],
-                   "schedule_calibration_ms": calibration, "cus_left_free_for_the_exchange": cus_free,
-                   "schedule_note": None if calibration or args.schedule != "default" else
-                   "config 2 on one GPU runs the two-launch round by default (the form profiles/ documents kernel by kernel); --schedule auto "
-                   "also tries the fused and pipelined rounds (fused: 0-6 % faster, depending on the box)", "collectives": ("TEST DOUBLE: files, all ranks on one GPU (figures meaningless)" if args.test_comm_dir else
-                                   "RCCL through libflashe_hip.so (no PyTorch)") if ops.comm else None,
-                   "parity": "bit-exact (decrypted aggregate == plaintext sum on every rank, checked in-run)"},
-        "roofline": {"kernel": kernel_name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": ratio * alg_bytes if ratio else None,
-                     "traffic_source": (f"{tsrc}: HBM bytes per algorithmic byte measured once with rocprofv3 PMC passes on this kernel "
-                                        "(FETCH_SIZE doubled per the gfx950 note, + WRITE_SIZE) x this run's algorithmic bytes; not re-measured in-run")
-                     if ratio else None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": enc_avg_ms, "launches_timed": len(enc_ms),
-                     "aes_blocks_per_launch": blocks, "aes_blocks_per_s": blocks / (enc_avg_ms * 1e-3),
-                     # LDS lookups per AES block: 11 full rounds x 16 + the final round's 16 + 4 (round 2) + the element's one
-                     # counter-dependent lookup of round 1 shared by its C + 1 blocks; half-tile tails take 208
-                     "lds_lookup_bound": {"lookups_per_block": lookups, "peak_lookups_per_s_at_2.4GHz": 32 * 256 * 2.4e9,
-                                          "achieved_lookups_per_s": lookups * blocks / (enc_avg_ms * 1e-3),
-                                          "frac_at_2.4GHz": lookups * blocks / (enc_avg_ms * 1e-3) / (32 * 256 * 2.4e9)},
-                     "note": "integer path: the kernel is AES(LDS lookup)-rate bound, HBM fraction reported as required"},
-        "phases_ms": ({"round": ms_per_step, "note": "phases overlap in this schedule"} if schedule != "sequential" else
-                      {"encrypt_xC": float(ph[:, 0].mean()), "reduce_plus_decrypt": float(ph[:, 1].mean())}),
-    })
     if world == 1:
         hp = [host_pts[c] for c in mine]
+        if cfg == 2 and not args.no_unchained and args.schedule in ("default", "sequential"):
+            line.update(unchained_round(args, n, b, J, mine, total, pts, K))
         if not args.no_e2e:
-            out["e2e_ms_incl_pcie"], out["e2e_first_round_ms"] = e2e_round_ms(eng, hp, n, b, J)
-            out["e2e_note"] = ("one round through the host-pointer twins (flashe_encrypt x C, flashe_aggregate_elem, flashe_decrypt): pageable "
-                               "host vectors, H2D + kernel + D2H per call, calls back to back; the first round also allocates the staging blocks "
-                               "and faults in the result arrays, later rounds reuse them; never `value`")
+            line["e2e_ms_incl_pcie"], line["e2e_first_round_ms"] = e2e_round_ms(eng, hp, n, b, J)
+            line["e2e_note"] = ("one round through the host-pointer twins (flashe_encrypt x C, flashe_aggregate_elem, flashe_decrypt): pageable "
+                                "host vectors, H2D + kernel + D2H per call, calls back to back; the first round also allocates the staging blocks "
+                                "and faults in the result arrays, later rounds reuse them; never `value`")
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(J, b, C, hp, args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(J, b, C, hp, args.cpu_sample)
             if not args.no_python_baseline:
                 pyb = python_structure_baseline_child(b, C, 1_000_000)  # n = 1e6 per phase; regenerates the plaintext prefix from the seeds
                 if pyb:
-                    out["cpu_baseline_python"] = pyb
-    return out
+                    line["cpu_baseline_python"] = pyb
+    return line
+
+
+def unchained_round(args, n, b, J, mine, total, pts, K):
+    """The same K rounds with stream sharing OFF (FLASHE_CHAIN=0 on a second ctx: every client computes both of its streams, what a
+    GPU that hosts only one client pays), measured outside the timed region and reported beside `value`."""
+    from flashe_amd.dist import HipOps, ShardedRound
+    from flashe_amd.engine import Engine
+    old = os.environ.get("FLASHE_CHAIN")
+    os.environ["FLASHE_CHAIN"] = "0"
+    try:
+        eng_u = Engine(KEY, b, device=0)
+    finally:
+        if old is None:
+            os.environ.pop("FLASHE_CHAIN", None)
+        else:
+            os.environ["FLASHE_CHAIN"] = old
+    ops_u = HipOps(eng_u, None, None)
+    rnd_u = ShardedRound(ops_u, n, b, mine, J, rank=0, world=1, total_clients=total)
+    for it in range(12):
+        rnd_u.run(it, pts, 1)
+    s = timed_region(ops_u, K, lambda k: rnd_u.run(k, pts, 1))
+    eng_u.close()
+    return {"ms_per_step_unchained": s * 1e3 / K, "value_unchained": total * n / (s / K),
+            "unchained_note": "the same round with FLASHE_CHAIN=0: every client computes both of its PRF streams (2 C instead of C + 1 AES "
+                              "blocks per element-position), i.e. what C GPUs hosting one client each would pay per client"}
 
 
 def e2e_round_ms(eng, host_pts, n, b, J):

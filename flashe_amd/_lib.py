@@ -81,6 +81,8 @@ _SIGNATURES = {
     "flashe_graph_destroy": (c_int, [c_vp]),
     "flashe_prf_jobs_dev": (c_int, [c_vp, c_u32, c_u64, c_u32, c_int, ctypes.POINTER(PrfJob)]),
     "flashe_encrypt_batch_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp)]),
+    "flashe_encrypt_batch_sum_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp),
+                                             c_vp]),
     "flashe_decrypt_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
     "flashe_decrypt": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
     "flashe_mask_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_vp]),

@@ -756,6 +756,38 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
     return FLASHE_OK;
 }
 
+int flashe_encrypt_batch_sum_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec, const uint32_t *idx,
+                                 const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev, uint64_t *sum_out_dev)
+{
+    CHECK_CTX(ctx);
+    if (!sum_out_dev && n && n_vec) return fail(ctx, FLASHE_EINVAL, "flashe_encrypt_batch_sum_dev: null sum_out_dev");
+    if (n && n_vec && ((ctx->limbs == 2 && !aligned16(sum_out_dev)) || (reinterpret_cast<uintptr_t>(sum_out_dev) & 7u)))
+        return fail(ctx, FLASHE_EINVAL, "sum_out_dev must be aligned like a ciphertext vector");
+    if (n_vec > 0 && n) {
+        for (int v = 0; v < n_vec; v++)
+            if (ct_dev && ct_dev[v] == sum_out_dev) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the ciphertext vectors");
+    }
+    if (scheme == FLASHE_SCHEME_DOUBLE && n && n_vec > 0 && idx && pt_dev && ct_dev) {
+        // one launch: the chained encrypt keeps the running sum of its outputs in registers and stores it once
+        bool ok = true;
+        for (int v = 0; v < n_vec && ok; v++) ok = pt_dev[v] && ct_dev[v];
+        if (ok) {
+            for (int v = 0; v < n_vec; v++) {
+                int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev[v], pt_dev[v], pt_limbs);
+                if (rc) return rc;
+            }
+            const hipError_t e = launch_prf_batch_sum(ctx->env, iter, n_vec, idx, pt_dev, pt_limbs, ct_dev, sum_out_dev, n, n_jobs);
+            if (e == hipSuccess) return FLASHE_OK;
+            if (e != hipErrorNotSupported) HIP_TRY(ctx, e);
+        }
+    }
+    // every other shape: the encrypts, then the reduce of what they wrote
+    int rc = flashe_encrypt_batch_dev(ctx, iter, scheme, n, n_jobs, n_vec, idx, pt_dev, pt_limbs, ct_dev);
+    if (rc || n == 0) return rc;
+    if (n_vec == 0) { HIP_TRY(ctx, hipMemsetAsync(sum_out_dev, 0, n * ctx->limbs * 8, ctx->env.stream)); return FLASHE_OK; }
+    return flashe_aggregate_elem_dev(ctx, n_vec, ct_dev, n, sum_out_dev);
+}
+
 int flashe_prf_jobs_dev(flashe_ctx *ctx, uint32_t iter, uint64_t n, uint32_t n_jobs, int n_entries, const flashe_prf_job *entries)
 {
     CHECK_CTX(ctx);

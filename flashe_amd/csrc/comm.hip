@@ -38,6 +38,7 @@ struct RcclApi {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;          // optional
 };
 
 RcclApi &rccl()
@@ -65,7 +66,8 @@ RcclApi &rccl()
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-        if (!ok) { dlclose(api.handle); api.handle = nullptr; }
+        if (!ok) { dlclose(api.handle); api.handle = nullptr; return; }
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
     });
     return api;
 }
@@ -130,7 +132,15 @@ int flashe_rccl_destroy(flashe_comm *comm)
 }
 
 int flashe_rccl_rank(const flashe_comm *comm) { return comm ? comm->rank : FLASHE_EINVAL; }
-int flashe_rccl_world(const flashe_comm *comm) { return comm ? comm->world : FLASHE_EINVAL; }
+// What RCCL itself says the communicator spans (ncclCommCount), so that a caller can prove the group really has `world` ranks;
+// the value passed to flashe_rccl_init if this RCCL lacks the query.
+int flashe_rccl_world(const flashe_comm *comm)
+{
+    if (!comm) return FLASHE_EINVAL;
+    int count = 0;
+    if (comm->comm && rccl().CommCount && rccl().CommCount(comm->comm, &count) == ncclSuccess) return count;
+    return comm->world;
+}
 
 // Piece p of `send` (at send + p * send_stride) goes to rank p; the piece received from rank p lands at recv + p * recv_stride.
 int flashe_rccl_all_to_all(flashe_ctx *ctx, flashe_comm *comm, const void *send_dev, size_t send_stride, void *recv_dev, size_t recv_stride,

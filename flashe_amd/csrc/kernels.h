@@ -60,6 +60,11 @@ constexpr int kMaxUniformBatch = 128;   // equal-length whole vectors per launch
 hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx,
                             const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n,
                             uint32_t n_jobs);
+// The same batch as ONE chain that also writes sum_v out[v] mod 2^b to sum_out_dev (the local partial aggregate).  Returns
+// hipErrorNotSupported -- nothing launched -- unless the batch is one run of consecutive cipher indices of the double mask with
+// int_bits > 64, at most kMaxUniformBatch vectors, long enough to fill the chip: the caller then encrypts and reduces separately.
+hipError_t launch_prf_batch_sum(const LaunchEnv &env, uint32_t iter, int n_vec, const uint32_t *idx, const uint64_t *const *in_dev,
+                                int in_limbs, uint64_t *const *out_dev, uint64_t *sum_out_dev, uint64_t n, uint32_t n_jobs);
 
 // General form of the batched launch: out[k] = in[k] + term(iter, add_idx, first + k)
 // - [dbl] term(iter, minus_idx, first + k) for k < count; in_dev may be null (zeros); pointers address element `first`.
@@ -93,6 +98,7 @@ struct PrfChain {
     const uint64_t *const *in_dev;
     int in_limbs;
     uint64_t *const *out_dev;
+    uint64_t *sum_out_dev = nullptr;   // optional (int_bits > 64, n_out <= kMaxLinks): receives sum_c out[c] mod 2^b, written by the same launch
 };
 hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs);
 

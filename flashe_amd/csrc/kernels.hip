@@ -641,6 +641,7 @@ struct ChainTable {
     uint32_t idx[kMaxLinks + kMaxChains];              // prefix index of every stream
     const uint64_t *in[kMaxLinks];                     // may be null (zeros); addresses element first[chain]
     uint64_t *out[kMaxLinks];
+    uint64_t *sum_out[kMaxChains];                     // SUM kernels only: where sum_c out_c of the chain goes (null = nowhere)
 };
 
 __device__ __forceinline__ CtrPrefix load_prefix(const uint32_t *pre_lds, int s)
@@ -668,7 +669,11 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
            (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32)))) << 32);
 }
 
-template <int THREADS>
+// SUM: the launch also writes the chain's LOCAL PARTIAL AGGREGATE sum_c out_c mod 2^b ("each GPU encrypts and
+// locally mod-adds its share"; the arbiter's reduce jzf_aggregator.py:424-430 applied to the ciphertexts this GPU has just produced):
+// every out_c of an element passes through the lane's registers in turn, so the running sum costs 4 VGPRs per element and one
+// non-temporal 16-byte store, and the C ciphertexts are never re-read for the reduce.
+template <int THREADS, bool SUM>
 __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, const ChainTable tb, int n_chains, int all_half_arg,
                                                               uint32_t iter0, uint64_t mask_lo, uint64_t mask_hi,
                                                               const uint32_t *__restrict__ te0, const Codec cq)
@@ -750,12 +755,15 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
             uint32_t vA0 = T3(jl ^ rk.w[3], SEL_B0), vA1 = T3((jl + 64u) ^ rk.w[3], SEL_B0);
             uint32_t vB0 = T3((jl + 128u) ^ rk.w[3], SEL_B0), vB1 = T3((jl + 192u) ^ rk.w[3], SEL_B0);
             u128 pA0 = 0, pA1 = 0, pB0 = 0, pB1 = 0;
+            u128 qA0 = 0, qA1 = 0, qB0 = 0, qB1 = 0;                   // SUM: running sum of the outputs of the lane's four elements
+            uint64_t *const sum_out = SUM ? tb.sum_out[cur] : nullptr;
             for (int c = 0; c < n_streams; c++) {
                 const CtrPrefix pre = load_prefix(pre_lds, sbase + c);
                 const CtrUniform U = ctr_uniform(rk, te0, pre, x3);
                 const int link = single ? c : c - 1;                   // the output this stream completes
                 const uint64_t *in = link >= 0 ? tb.in[link0 + link] : nullptr;
                 uint64_t *out = link >= 0 ? tb.out[link0 + link] : nullptr;
+                const bool last_stream = c == n_streams - 1;
 #pragma unroll 1
                 for (int p = 0; p < 2; p++) {
                     const uint64_t jb = tj + 128u * p;
@@ -790,6 +798,22 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                             if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
                             if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
                         }
+                        if constexpr (SUM) {
+                            // (the sums do not take part in the register rotation of the rolled pair loop: p is wave-uniform, a scalar
+                            // branch around four adds is cheaper than eight more moves per pair)
+                            if (link >= 0) {
+                                if (p == 0) { qA0 += r0; qA1 += r1; } else { qB0 += r0; qB1 += r1; }
+                            }
+                            if (last_stream && sum_out != nullptr) {
+                                if (p == 0) {
+                                    if (a0) st128_nt(sum_out + 2 * k0, qA0 & mask);
+                                    if (a1) st128_nt(sum_out + 2 * k1, qA1 & mask);
+                                } else {
+                                    if (a0) st128_nt(sum_out + 2 * k0, qB0 & mask);
+                                    if (a1) st128_nt(sum_out + 2 * k1, qB1 & mask);
+                                }
+                            }
+                        }
                         pA0 = c0; pA1 = c1;
                     }
                     swap_regs(pA0, pB0); swap_regs(pA1, pB1); swap_regs(vA0, vB0); swap_regs(vA1, vB1);
@@ -800,7 +824,8 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
             const uint64_t j0 = tj + lane, j1 = j0 + 64u, k0 = j0 - first, k1 = j1 - first;
             const bool a0 = j0 >= first && j0 < end, a1 = j1 >= first && j1 < end;
             const CtrVar xv0 = ctr_var(rk, lr, static_cast<uint32_t>(j0)), xv1 = ctr_var(rk, lr, static_cast<uint32_t>(j1));
-            u128 p0 = 0, p1 = 0;
+            u128 p0 = 0, p1 = 0, q0 = 0, q1 = 0;
+            uint64_t *const sum_out = SUM ? tb.sum_out[cur] : nullptr;
             for (int c = 0; c < n_streams; c++) {
                 const CtrPrefix pre = load_prefix(pre_lds, sbase + c);
                 const int link = single ? c : c - 1;
@@ -830,6 +855,13 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                 } else {
                     if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
                     if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
+                }
+                if constexpr (SUM) {
+                    if (link >= 0) { q0 += r0; q1 += r1; }
+                    if (c == n_streams - 1 && sum_out != nullptr) {
+                        if (a0) st128_nt(sum_out + 2 * k0, q0 & mask);
+                        if (a1) st128_nt(sum_out + 2 * k1, q1 & mask);
+                    }
                 }
                 p0 = c0; p1 = c1;
             }
@@ -1731,6 +1763,24 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
     return launch_prf_jobs(e2, iter, dbl, n_vec, jobs.data(), n, n_jobs);
 }
 
+hipError_t launch_prf_batch_sum(const LaunchEnv &env, uint32_t iter, int n_vec, const uint32_t *idx, const uint64_t *const *in_dev,
+                                int in_limbs, uint64_t *const *out_dev, uint64_t *sum_out_dev, uint64_t n, uint32_t n_jobs)
+{
+    if (n == 0 || n_vec == 0) return hipSuccess;
+    if (!env.use_chain || env.b <= 64 || env.codec || n_vec > kMaxLinks || !sum_out_dev) return hipErrorNotSupported;
+    if (env.prf_backend != PRF_AUTO && env.prf_backend != PRF_TABLE) return hipErrorNotSupported;
+    for (int v = 1; v < n_vec; v++) if (idx[v] != idx[v - 1] + 1u) return hipErrorNotSupported;     // one run of consecutive clients
+    // an uncut chain of a short vector leaves most waves idle (launch_prf_chains cuts such chains for parallelism, a summed chain
+    // cannot be cut): below two whole tiles per wave the separate reduce is the better plan
+    const uint64_t waves = static_cast<uint64_t>(env.num_cus) * (kPrfThreads / 64);
+    if ((n + 255) / 256 < 2 * waves) return hipErrorNotSupported;
+    std::vector<uint32_t> sidx(idx, idx + n_vec);
+    sidx.push_back(idx[n_vec - 1] + 1u);
+    PrfChain ch{sidx.data(), n_vec, false, 0, n, in_dev, in_limbs, out_dev};
+    ch.sum_out_dev = sum_out_dev;
+    return launch_prf_chains(env, iter, 1, &ch, n, n_jobs);
+}
+
 // b <= 64 form of launch_prf_jobs
 static hipError_t launch_prf_jobs_small(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n,
                                         uint32_t n_jobs)
@@ -1882,10 +1932,13 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
     struct Piece { const PrfChain *ch; int l0, l1; uint64_t tiles; };
     std::vector<Piece> pieces;
     uint64_t total_tiles = 0;
+    bool summed = false;
     for (int i = 0; i < n_chains; i++) {
         const PrfChain &c = chains[i];
         if (c.count == 0 || c.n_out == 0) continue;
         if (((c.first + c.count - 1) >> 32) != (c.first >> 32)) return hipErrorNotSupported;     // the CTR shortcuts need one counter window
+        // a chain that also writes the sum of its outputs is never cut (a piece would only know its own share of the sum)
+        if (c.sum_out_dev) { if (c.n_out > kMaxLinks) return hipErrorNotSupported; summed = true; }
         const uint64_t tiles = (c.first + c.count - (c.first & ~255ull) + 255) / 256;
         pieces.push_back(Piece{&c, 0, c.n_out, tiles});
         total_tiles += tiles;
@@ -1906,14 +1959,14 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
     std::vector<Piece> cut;
     for (const Piece &pc : pieces) {
         int parts = (pc.l1 + kMaxLinks - 1) / kMaxLinks;
-        if (all_half && 2 * total_tiles < waves) {
+        if (all_half && 2 * total_tiles < waves && !pc.ch->sum_out_dev) {
             const uint64_t want = waves / (2 * total_tiles);
             const int cap = std::max(1, pc.l1 / 4);
             parts = std::max<int>(parts, static_cast<int>(std::min<uint64_t>(want, static_cast<uint64_t>(cap))));
             parts = std::min(parts, std::max(1, kMaxChains / static_cast<int>(pieces.size())));
             parts = std::max(parts, (pc.l1 + kMaxLinks - 1) / kMaxLinks);
         }
-        if (force_parts > 0) parts = std::max(std::min(force_parts, pc.l1), (pc.l1 + kMaxLinks - 1) / kMaxLinks);
+        if (force_parts > 0 && !pc.ch->sum_out_dev) parts = std::max(std::min(force_parts, pc.l1), (pc.l1 + kMaxLinks - 1) / kMaxLinks);
         for (int k = 0; k < parts; k++) {
             const int a = static_cast<int>(static_cast<int64_t>(pc.l1) * k / parts), b = static_cast<int>(static_cast<int64_t>(pc.l1) * (k + 1) / parts);
             if (b > a) cut.push_back(Piece{pc.ch, a, b, pc.tiles});
@@ -1934,6 +1987,7 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
             tb.link0[nc] = static_cast<uint16_t>(links); tb.sbase[nc] = static_cast<uint16_t>(streams);
             tb.len[nc] = static_cast<uint8_t>(len);
             tb.flags[nc] = static_cast<uint8_t>((c.single ? 1 : 0) | (c.in_limbs == 2 ? 2 : 0));
+            tb.sum_out[nc] = c.sum_out_dev;
             for (int s = 0; s < ns; s++) tb.idx[streams + s] = c.idx[pc.l0 + s];
             for (int l = 0; l < len; l++) {
                 tb.in[links + l] = c.in_dev ? c.in_dev[pc.l0 + l] : nullptr;
@@ -1952,8 +2006,12 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
             if (cut.size() != 1 || cut[0].l1 - cut[0].l0 != 1) return hipErrorInvalidValue;      // one job, one output
             cq = *env.codec;
         }
-        hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc, (all_half ? 1 : 0) | probe,
-                           iter, lo, hi, env.te0_dev, cq);
+        if (summed)
+            hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, true>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
+                               (all_half ? 1 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
+        else
+            hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, false>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
+                               (all_half ? 1 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -1965,6 +2023,7 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
 static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs)
 {
     if (env.codec || n >= (1ull << 32) || n == 0) return hipErrorNotSupported;
+    for (int i = 0; i < n_chains; i++) if (chains[i].sum_out_dev) return hipErrorNotSupported;      // the fused sum lives in the wide kernel
     SmallParams p{};
     p.n = n; p.n_jobs = n_jobs; p.iter = iter; p.b = env.b; p.m = 128 / env.b; p.te0 = env.te0_dev;
     { static const int v = getenv("FLASHE_SMALL_DIRECT") ? atoi(getenv("FLASHE_SMALL_DIRECT")) : 1; p.no_direct = v == 0 ? 1 : v == 2 ? 2 : 0; }

@@ -31,7 +31,7 @@ import numpy as np
 from . import _lib
 from .engine import SCHEME_DOUBLE, Engine, limbs_of, telescope
 
-__all__ = ["HipOps", "RcclComm", "ShardedRound", "slice_len", "deal_clients", "spawn", "rendezvous_unique_id"]
+__all__ = ["HipOps", "RcclComm", "ShardedRound", "slice_len", "deal_clients", "spawn", "rendezvous_unique_id", "Watchdog", "run_tag"]
 
 ALIGN = 256         # slice and chunk boundaries are multiples of this many elements (256 consecutive PRF counters share 3 bytes)
 
@@ -57,10 +57,27 @@ def deal_clients(total, world):
 # ------------------------------------------------------------------------------------------------------------------
 # process launch and rendezvous (no GPU call happens before the per-GPU processes exist)
 # ------------------------------------------------------------------------------------------------------------------
-def spawn(n_procs, argv, master_port=None, env=None):
+def _die_with_parent():
+    """preexec hook of a rank process (runs between fork and exec, before anything GPU): the kernel sends SIGKILL to the rank
+    when the launcher dies, so that even a `kill -9` of the launcher leaves no rank behind holding a GPU."""
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)      # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
+def spawn(n_procs, argv, master_port=None, env=None, deadline_s=None):
     """Start `n_procs` processes `python argv...`, one per GPU, with the usual RANK / LOCAL_RANK / WORLD_SIZE /
     MASTER_ADDR / MASTER_PORT environment, and wait for them.  Returns the first non-zero exit code (0 if none).
-    Call it BEFORE anything in the parent touches the GPU."""
+    Call it BEFORE anything in the parent touches the GPU.
+
+    All ranks are watched together: as soon as one exits non-zero (parity failure, OOM, ncclCommInitRank error) the others are
+    terminated -- RCCL has no timeout, a surviving rank would sit in its next collective forever, holding its GPU.  SIGTERM / SIGINT
+    of the launcher are forwarded, every rank runs in its own session (killpg reaches what it started) and is killed by the kernel if
+    the launcher itself is killed.  deadline_s: optional overall limit (exit code 124, like timeout(1)).  Never re-execs."""
+    import signal
     port = int(master_port or (29400 + os.getpid() % 500))
     run_id = f"{os.getpid()}_{int(time.time() * 1e3)}"
     procs = []
@@ -69,12 +86,143 @@ def spawn(n_procs, argv, master_port=None, env=None):
         e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_procs), LOCAL_WORLD_SIZE=str(n_procs),
                  MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FLASHE_RUN_ID=run_id)
         e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e))
-    rc = 0
-    for p in procs:
-        code = p.wait()
-        rc = rc or code
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=e, start_new_session=True, preexec_fn=_die_with_parent))
+
+    def stop_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    got = []
+    previous = {}
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            previous[sig] = signal.signal(sig, lambda s, _f: got.append(s))
+        except ValueError:                   # not the main thread: no handlers, the rest still works
+            pass
+    rc, t0, killing_since = 0, time.time(), None
+    try:
+        while any(p.poll() is None for p in procs):
+            for p in procs:
+                code = p.poll()
+                if code is not None and code != 0 and rc == 0:
+                    rc = code if code > 0 else 128 - code
+            if got and rc == 0:
+                rc = 128 + got[0]
+            if deadline_s is not None and time.time() - t0 > deadline_s and rc == 0:
+                rc = 124
+            if rc and killing_since is None:
+                killing_since = time.time()
+                stop_all(signal.SIGTERM)
+            elif killing_since is not None and time.time() - killing_since > 5.0:
+                stop_all(signal.SIGKILL)
+            time.sleep(0.05)
+        for p in procs:
+            code = p.returncode
+            if code and rc == 0:
+                rc = code if code > 0 else 128 - code
+    finally:
+        stop_all(signal.SIGKILL)
+        for sig, h in previous.items():
+            signal.signal(sig, h)
     return rc
+
+
+def run_tag(world):
+    """What names ONE launch on this node: every rank of it is a child of the same launcher process (torchrun's agent, or `spawn`),
+    whose pid keeps launches that reuse a port apart, so a file left behind by a crashed run is never mistaken for this run's."""
+    return "_".join([os.environ.get("MASTER_PORT", "0"),
+                     os.environ.get("FLASHE_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                     os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), str(os.getppid()), str(world)])
+
+
+def rdzv_dir():
+    import tempfile
+    return os.environ.get("FLASHE_RDZV_DIR", tempfile.gettempdir())
+
+
+class Watchdog:
+    """A deadline and an out-of-band abort channel for the ranks of one launch (RCCL collectives have no timeout: a rank that waits
+    for a peer that raised, died or took another branch waits forever).
+
+    Every rank runs one: a daemon thread that fires when the armed deadline passes or when ANY rank of the launch has called
+    `abort(reason)` (a file next to the rendezvous file, polled).  Firing calls `on_fire(reason)` -- e.g. rank 0 prints the result it
+    already holds -- and then leaves with os._exit: an exit, never an exec (a process that has touched the GPU must not be replaced
+    in place), and no interpreter teardown that could block on the stuck stream.  ctypes calls release the GIL, so the thread runs
+    while the main thread sits inside a collective."""
+
+    def __init__(self, rank, world, on_fire=None, poll_s=0.1):
+        import threading
+        self.rank, self.world, self.on_fire = rank, world, on_fire
+        self.exit_code = 3                      # what a firing exits with; callers lower it to 0 once a valid result is in hand
+        self.path = os.path.join(rdzv_dir(), f"flashe_abort_{os.getuid()}_{run_tag(world)}")
+        self._deadline, self._phase = None, ""
+        self._lock = threading.Lock()
+        self._done = False
+        self._poll = poll_s
+        self._thread = threading.Thread(target=self._watch, name="flashe-watchdog", daemon=True)
+        self._thread.start()
+
+    def arm(self, seconds, phase):
+        self._deadline, self._phase = time.time() + float(seconds), phase
+
+    def disarm(self):
+        self._deadline = None
+
+    def abort(self, reason):
+        """Tell every rank of the launch (this one included) to stop: the watchdogs fire within a poll interval."""
+        try:
+            fd = os.open(self.path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, "w") as f:
+                f.write(f"rank {self.rank}: {reason}")
+        except FileExistsError:
+            pass
+        except OSError:
+            self._fire(f"rank {self.rank}: {reason}")
+
+    def finish(self):
+        """The normal end: from here on the watchdog never fires (returns False if it already has)."""
+        with self._lock:
+            if self._done:
+                return False
+            self._done = True
+        if self.rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+        return True
+
+    def _fire(self, reason):
+        with self._lock:
+            if self._done:
+                return
+            self._done = True
+            try:
+                if self.on_fire:
+                    self.on_fire(reason)
+            finally:
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(self.exit_code)
+
+    def _watch(self):
+        while not self._done:
+            time.sleep(self._poll)
+            d = self._deadline
+            if d is not None and time.time() > d:
+                self._fire(f"deadline of phase '{self._phase}' passed on rank {self.rank}")
+            try:
+                if os.path.exists(self.path):
+                    with open(self.path) as f:
+                        why = f.read()
+                    if os.stat(self.path).st_uid == os.getuid():
+                        self._fire(why or "abort requested")
+            except OSError:
+                pass
 
 
 def rendezvous_unique_id(rank, world, make_id, timeout=300.0):
@@ -82,13 +230,8 @@ def rendezvous_unique_id(rank, world, make_id, timeout=300.0):
     (FLASHE_RDZV_DIR, default the system temp dir), keyed by MASTER_PORT and the launcher's run id -- the environment
     torchrun or `spawn` already provides; no sockets, no PyTorch."""
     import tempfile
-    # every rank of one launch is a child of the same launcher process (torchrun's agent, or `spawn`): its pid keeps launches
-    # that reuse a port apart, so a file left behind by a crashed run is never mistaken for this run's
-    tag = "_".join([os.environ.get("MASTER_PORT", "0"),
-                    os.environ.get("FLASHE_RUN_ID") or os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                    os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), str(os.getppid()), str(world)])
-    d = os.environ.get("FLASHE_RDZV_DIR", tempfile.gettempdir())
-    path = os.path.join(d, f"flashe_rccl_id_{os.getuid()}_{tag}")
+    d = rdzv_dir()
+    path = os.path.join(d, f"flashe_rccl_id_{os.getuid()}_{run_tag(world)}")
     if rank == 0:
         ident = bytes(make_id())
         fd, tmp = tempfile.mkstemp(prefix="flashe_rccl_id_", dir=d)          # 0600, a name nobody else can have prepared
@@ -163,6 +306,10 @@ class RcclComm:
 
     def barrier(self, engine):
         engine._check(self._lib.flashe_rccl_barrier(engine._h, self._h))
+
+    def rccl_world(self):
+        """The number of ranks RCCL itself reports for this communicator (ncclCommCount through flashe_rccl_world)."""
+        return int(self._lib.flashe_rccl_world(self._h))
 
     def close(self):
         if self._h is not None:
@@ -241,8 +388,13 @@ class HipOps:
             self._eng(side).wait_event(self._ev(name))
 
     # ---- cipher ----
-    def encrypt_batch(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts):
-        self.engine.encrypt_batch_dev(it, idx_list, scheme, n, n_jobs, [self._a(r) for r in pts], pt_limbs, [self._a(r) for r in cts])
+    def encrypt_batch(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts, sum_out=None):
+        """sum_out: optional ref that receives the sum of the ciphertexts (the local partial aggregate) from the same launch."""
+        if sum_out is not None:
+            self.engine.encrypt_batch_sum_dev(it, idx_list, scheme, n, n_jobs, [self._a(r) for r in pts], pt_limbs,
+                                              [self._a(r) for r in cts], self._a(sum_out))
+        else:
+            self.engine.encrypt_batch_dev(it, idx_list, scheme, n, n_jobs, [self._a(r) for r in pts], pt_limbs, [self._a(r) for r in cts])
 
     def encrypt_range(self, it, idx, scheme, n, n_jobs, first, count, pt, pt_limbs, ct):
         """pt / ct address element `first`."""
@@ -359,10 +511,15 @@ class ShardedRound:
         return (ref[0], ref[1] + words)
 
     # ---- sequential schedule -------------------------------------------------------------------------------------
-    def encrypt_phase(self, it, pts, pt_limbs):
-        """Every local client encrypts its vector (cipher idx = global client number)."""
+    def encrypt_phase(self, it, pts, pt_limbs, partial_agg=False):
+        """Every local client encrypts its vector (cipher idx = global client number).  partial_agg: the same launch also writes
+        this rank's partial aggregate, the sum of its clients' ciphertexts, to self.partial ("each GPU encrypts
+        and locally mod-adds its share"), so that reduce_decrypt_phase(partial_agg=True) does not re-read the ciphertexts."""
         if self.cpr:
-            self.ops.encrypt_batch(it, self.clients, self.scheme, self.n, self.n_jobs, pts, pt_limbs, self.ct)
+            self.ops.encrypt_batch(it, self.clients, self.scheme, self.n, self.n_jobs, pts, pt_limbs, self.ct,
+                                   sum_out=(self.partial, 0) if partial_agg else None)
+        elif partial_agg:
+            self.ops.zero((self.partial, 0), self.n * self.L)
 
     def _local_reduce(self, count, out, first=0, side=False):
         """out[first ..] = sum of the local ciphertexts on elements [first, first + count) (zeros on a rank without clients)."""
@@ -372,15 +529,20 @@ class ShardedRound:
         else:
             self.ops.zero(self._at(out, first * L), count * L)
 
-    def reduce_decrypt_phase(self, it):
+    def reduce_decrypt_phase(self, it, partial_agg=False):
         """Reduce (+ exchange) with the last reduce fused into the decrypt (one pass over its operands): without an exchange the
-        C local ciphertexts, with one the W received pieces of the owned slice."""
+        C local ciphertexts, with one the W received pieces of the owned slice.  partial_agg: self.partial already holds the local
+        sum (encrypt_phase(partial_agg=True)): it is decrypted, or exchanged, as it is."""
         add_idx, minus_idx = self._prefixes()
         ops, n, W, L = self.ops, self.n, self.world, self.L
         if not self.exchange:
-            ops.aggregate_decrypt(it, add_idx, minus_idx, n, self.n_jobs, 0, n, self.ct, (self.partial, 0), (self.result, 0))
+            if partial_agg:
+                ops.decrypt_range(it, add_idx, minus_idx, n, self.n_jobs, 0, n, (self.partial, 0), (self.result, 0))
+            else:
+                ops.aggregate_decrypt(it, add_idx, minus_idx, n, self.n_jobs, 0, n, self.ct, (self.partial, 0), (self.result, 0))
             return self.result
-        self._local_reduce(n, (self.partial, 0))
+        if not partial_agg:
+            self._local_reduce(n, (self.partial, 0))
         ops.all_to_all((self.partial, 0), self.slice * L, (self.recv, 0), self.slice * L, self.slice * L)
         if self.count > 0:
             ops.aggregate_decrypt(it, add_idx, minus_idx, n, self.n_jobs, self.first, self.count,
@@ -388,11 +550,12 @@ class ShardedRound:
         ops.all_gather((self.dec_slice, 0), (self.result, 0), self.slice * L)
         return self.result
 
-    def run(self, it, pts, pt_limbs):
+    def run(self, it, pts, pt_limbs, partial_agg=False):
         """pts: refs of this rank's plaintext vectors (one per local client).  Returns the buffer holding the decrypted
-        aggregate (first n*L words valid).  Two PRF launches per round on one GPU: every local encrypt, then reduce + decrypt."""
-        self.encrypt_phase(it, pts, pt_limbs)
-        return self.reduce_decrypt_phase(it)
+        aggregate (first n*L words valid).  Two PRF launches per round on one GPU: every local encrypt, then reduce + decrypt
+        (partial_agg: every local encrypt + their sum, then the decrypt of that sum)."""
+        self.encrypt_phase(it, pts, pt_limbs, partial_agg)
+        return self.reduce_decrypt_phase(it, partial_agg)
 
     # ---- chunk-pipelined schedules -------------------------------------------------------------------------------
     def _pipe_buffers(self, chunks):

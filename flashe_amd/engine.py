@@ -310,6 +310,15 @@ class Engine:
         pc, _b = self._ptr_array(cts)
         self._check(self._lib.flashe_encrypt_batch_dev(self._h, it, scheme, n, n_jobs, len(idx_list), pi, pp, pt_limbs, pc))
 
+    def encrypt_batch_sum_dev(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts, sum_out):
+        """encrypt_batch_dev that also writes sum_out = sum of the ciphertexts mod 2^b (the local partial aggregate): one launch for
+        a run of consecutive clients with int_bits > 64, the encrypts followed by the reduce otherwise."""
+        pi, _k = _u32_list(idx_list)
+        pp, _a = self._ptr_array(pts)
+        pc, _b = self._ptr_array(cts)
+        self._check(self._lib.flashe_encrypt_batch_sum_dev(self._h, it, scheme, n, n_jobs, len(idx_list), pi, pp, pt_limbs, pc,
+                                                           self._ptr(sum_out)))
+
     def prf_jobs_dev(self, it, n, n_jobs, jobs):
         """jobs: iterable of (add_idx, minus_idx or None, first, count, in_ptr or None, in_limbs, out_ptr); each writes
         out[k] = in[k] + term(it, add_idx, first + k) - term(it, minus_idx, first + k) for k < count (one launch for

@@ -156,6 +156,16 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
 int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
                              const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev);
 
+/* flashe_encrypt_batch_dev that ALSO writes the local partial aggregate sum_out[j] = sum_v ct[v][j] mod 2^b (new): what the
+ * arbiter's reduce (jzf_aggregator.py:424-430) yields for the clients this GPU hosts -- SURVEY.md section 5: "each GPU encrypts and
+ * locally mod-adds its share".  int_bits > 64, double mask, one run of consecutive cipher indices, a vector long enough to fill the
+ * device: ONE launch (every ciphertext of an element passes through the lane's registers, the running sum costs one extra 16-byte
+ * store per element and the C ciphertexts are never re-read).  Any other shape: the encrypts followed by flashe_aggregate_elem_dev.
+ * The ciphertexts are written as by flashe_encrypt_batch_dev; sum_out_dev (n x L limbs) must not be one of them. */
+int flashe_encrypt_batch_sum_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
+                                 const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev,
+                                 uint64_t *sum_out_dev);
+
 /* General batched form (new): every entry is one piece of mask arithmetic on elements
  * [first, first + count) of an n-element vector,
  *     out[k] = in[k] + term(iter, add_idx, first + k) - [has_minus] term(iter, minus_idx, first + k)   mod 2^b,
@@ -392,7 +402,7 @@ int flashe_rccl_unique_id(uint8_t id[FLASHE_RCCL_ID_BYTES]);       /* rank 0 mak
 int flashe_rccl_init(flashe_ctx *ctx, const uint8_t id[FLASHE_RCCL_ID_BYTES], int rank, int world, flashe_comm **out);
 int flashe_rccl_destroy(flashe_comm *comm);
 int flashe_rccl_rank(const flashe_comm *comm);
-int flashe_rccl_world(const flashe_comm *comm);
+int flashe_rccl_world(const flashe_comm *comm);          /* as RCCL itself reports it (ncclCommCount) */
 /* Piece p (bytes long, at send_dev + p * send_stride) goes to rank p; the piece from rank p lands at recv_dev + p * recv_stride.
  * Grouped ncclSend / ncclRecv: on xGMI every GPU pair has its own link, so the W - 1 transfers run concurrently. */
 int flashe_rccl_all_to_all(flashe_ctx *ctx, flashe_comm *comm, const void *send_dev, size_t send_stride,

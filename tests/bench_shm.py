@@ -1,0 +1,35 @@
+"""TEST WRAPPER (tests/test_gpu_parity.py): runs bench.py's own N > 1 flow -- process spawn, watchdog, sequential round first,
+calibration of the overlapped schedules, the one JSON line -- with several ranks on ONE GPU.  bench.main() is called with its two
+test seams: a file-based double of RcclComm (tests/shm_comm.py, directory from BENCH_SHM_DIR) instead of RCCL, and device 0 for
+every rank.  The printed figure is meaningless and labelled so.
+
+BENCH_SHM_INJECT=raise:R | hang:R makes rank R raise / block forever inside the first overlapped (fused) round -- what a first
+multi-GPU run may meet -- so that the tests can check the fallback: a valid sequential line within the deadline, exit code 0."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import bench
+    from shm_comm import ShmComm
+    inject = os.environ.get("BENCH_SHM_INJECT")
+    if inject and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        kind, r = inject.split(":")
+        if int(os.environ.get("RANK", "0")) == int(r):
+            from flashe_amd.dist import ShardedRound
+
+            def broken(self, *a, **k):
+                if kind == "raise":
+                    raise RuntimeError("injected failure of an optional schedule")
+                time.sleep(10 ** 6)
+            ShardedRound.run_fused = broken
+    bench.main(comm_factory=lambda rank, world: ShmComm(rank, world, os.environ["BENCH_SHM_DIR"]), device_override=0)
+
+
+if __name__ == "__main__":
+    main()

@@ -48,11 +48,11 @@ def main():
         want_packed = orc.combine(b, orc.unpack(agg_packed, n, b), add, minus)
         pts = [(ops.upload(host[c]), 0) for c in mine]
         rnd = ShardedRound(ops, n, b, mine, J, rank=rank, world=world, total_clients=C, scheme=scheme)
-        for mode in ("run", "pipe", "fused", "packed"):
+        for mode in ("run", "partial", "pipe", "fused", "packed"):
             if mode == "fused" and scheme != SCHEME_DOUBLE:
                 continue
-            if mode == "run":
-                out = rnd.run(4, pts, 1)
+            if mode in ("run", "partial"):
+                out = rnd.run(4, pts, 1, partial_agg=(mode == "partial"))
             elif mode == "pipe":
                 out = rnd.run_pipelined(4, pts, 1, chunks=3)
             elif mode == "fused":

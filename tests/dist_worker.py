@@ -26,7 +26,7 @@ class CraftedOps(OracleOps):
         super().__init__(b, comm)
         self.patterns = patterns          # global client number -> uint64 array [n, L]
 
-    def encrypt_batch(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts):
+    def encrypt_batch(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts, sum_out=None):
         for i, ct in zip(idx_list, cts):
             self._v(ct, n)[:] = self.patterns[i]
 
@@ -118,10 +118,11 @@ def main():
             want += p
         if b < 64:
             want &= np.uint64((1 << b) - 1)
-        for mode, chunks in (("run", 0), ("pipe", 4), ("pipe", 3), ("fused", 4), ("fused", 1), ("fused", 5)):
+        for mode, chunks in (("run", 0), ("partial", 0), ("pipe", 4), ("pipe", 3), ("fused", 4), ("fused", 1), ("fused", 5)):
             if mode == "fused" and scheme != SCHEME_DOUBLE:
                 continue
-            out = rnd.run(5, mine, 1) if mode == "run" else (rnd.run_pipelined if mode == "pipe" else rnd.run_fused)(5, mine, 1, chunks=chunks)
+            out = rnd.run(5, mine, 1, partial_agg=(mode == "partial")) if mode in ("run", "partial") else \
+                (rnd.run_pipelined if mode == "pipe" else rnd.run_fused)(5, mine, 1, chunks=chunks)
             res = result_of(ops, out, n, L)
             assert np.array_equal(res[:, 0], want), (rank, b, n, clients, mode, chunks)
             if L == 2:

@@ -91,9 +91,11 @@ class OracleOps:
     def _name(self, scheme):
         return "double" if scheme == SCHEME_DOUBLE else "single"
 
-    def encrypt_batch(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts):
+    def encrypt_batch(self, it, idx_list, scheme, n, n_jobs, pts, pt_limbs, cts, sum_out=None):
         for i, pt, ct in zip(idx_list, pts, cts):
             self._v(ct, n)[:] = orc.encrypt(KEY, it, i, self._name(scheme), n_jobs, self.b, np.ascontiguousarray(self._v(pt, n, pt_limbs)))
+        if sum_out is not None:
+            self._v(sum_out, n)[:] = orc.aggregate_elem([np.ascontiguousarray(self._v(ct, n)) for ct in cts], self.b)
 
     def encrypt_range(self, it, idx, scheme, n, n_jobs, first, count, pt, pt_limbs, ct):
         # pt / ct address element `first`: rebuild the whole-vector view the oracle wants

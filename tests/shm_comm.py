@@ -9,6 +9,8 @@ import numpy as np
 
 class ShmComm:
     MAX, MIN, SUM = 0, 1, 2
+    IS_TEST_DOUBLE = True
+    LABEL = "TEST DOUBLE: files, all ranks on one GPU (figures meaningless)"
 
     def __init__(self, rank, world, directory):
         self.rank, self.world, self.dir = rank, world, directory

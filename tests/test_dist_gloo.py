@@ -35,12 +35,12 @@ def test_single_rank_schedules(oracle):
         for p in pts:
             want += p
         for force in (False, True):
-            for mode in ("run", "pipe", "fused", "packed"):
+            for mode in ("run", "partial", "pipe", "fused", "packed"):
                 ops = OracleOps(b)
                 refs = [(ops.upload(p), 0) for p in pts]
                 rnd = ShardedRound(ops, n, b, cpr, 16, force_collectives=force)
-                if mode == "run":
-                    res = rnd.run(3, refs, 1)
+                if mode in ("run", "partial"):
+                    res = rnd.run(3, refs, 1, partial_agg=(mode == "partial"))
                 elif mode == "packed":
                     res = rnd.run_packed(3, refs, 1)
                 else:

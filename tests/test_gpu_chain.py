@@ -155,3 +155,35 @@ def test_chain_counter_window_fallback(E):
                 blk = lambda i: int.from_bytes(E.prp_block(KEY, it.to_bytes(4, "big") + i.to_bytes(4, "big") + ctr.to_bytes(8, "big")), "big")
                 want = (int(pt[e]) + blk(c) - blk(c + 1)) % (1 << 128)
                 assert int(got[e, 0]) | (int(got[e, 1]) << 64) == want, (first, c, e)
+
+
+@pytest.mark.parametrize("b,n,idx,scheme", [
+    (128, 2_300_017, list(range(7, 12)), "double"),        # ONE launch: whole tiles + half-tile tails, ragged end
+    (128, 4_200_001, list(range(10)), "double"),           # ONE launch: config-2 shape, shorter
+    (100, 2_200_013, [0, 1, 2], "double"),                 # ONE launch, b < 128: the sum is masked like every ciphertext
+    (128, 100_003, list(range(10)), "double"),             # too short to fill the chip uncut: encrypts, then the reduce
+    (128, 2_300_017, [5, 6, 7, 20, 21], "double"),         # broken run (two chains): encrypts, then the reduce
+    (128, 2_200_013, [3, 4, 5], "single"),                 # single mask: encrypts, then the reduce
+    (64, 300_007, [0, 1, 2, 3], "double"), (20, 50_001, [2, 3], "double"),      # int_bits <= 64
+    (128, 3000, list(range(130)), "double"),               # more outputs than one launch holds
+])
+def test_encrypt_batch_with_partial_aggregate(E, oracle, b, n, idx, scheme):
+    """flashe_encrypt_batch_sum_dev: every ciphertext equals the oracle's encrypt, and the partial aggregate equals the oracle's
+    element-wise reduce (jzf_aggregator.py:424-430) of those ciphertexts -- in the one-launch form (running sum in registers) and in
+    every shape that falls back to encrypt + reduce."""
+    eng = E.Engine(KEY, b, device=0)
+    Lb = L(b)
+    rng = np.random.Generator(np.random.PCG64(n + len(idx) + b))
+    pts = [rng.integers(0, 2 ** min(b, 64), n, dtype=np.uint64) for _ in idx]
+    dpt = [eng.upload(p) for p in pts]
+    dct = [eng.alloc_vec(n) for _ in idx]
+    dsum = eng.alloc_vec(n)
+    eng._check(eng._lib.flashe_memset_dev(eng._h, dsum.ptr, 0xA5, dsum.nbytes))
+    eng.encrypt_batch_sum_dev(6, idx, E.SCHEME_DOUBLE if scheme == "double" else E.SCHEME_SINGLE, n, 16, dpt, 1, dct, dsum)
+    want = [oracle.encrypt(KEY, 6, i, scheme, 16, b, p) for i, p in zip(idx, pts)]
+    step = 1 if len(idx) <= 12 else 11
+    for v in list(range(0, len(idx), step)) + [len(idx) - 1]:
+        assert np.array_equal(dct[v].download(np.uint64, n * Lb).reshape(n, Lb), want[v]), (b, n, v)
+    assert np.array_equal(dsum.download(np.uint64, n * Lb).reshape(n, Lb), oracle.aggregate_elem(want, b)), (b, n, "partial aggregate")
+    with pytest.raises(E.FlasheError):
+        eng.encrypt_batch_sum_dev(6, idx, E.SCHEME_DOUBLE, n, 16, dpt, 1, dct, dct[0])      # the sum must not alias a ciphertext

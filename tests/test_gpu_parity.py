@@ -638,28 +638,65 @@ def test_sharded_round_several_ranks_real_kernels(world, tmp_path):
     assert "DIST_GPU_MULTI_OK" in outs[0][0]
 
 
-@pytest.mark.parametrize("extra", [["--config", "2", "--clients", "3"], ["--config", "4", "--clients", "5"]])
-def test_bench_multi_rank_flow(extra, tmp_path):
-    """bench.py's own N > 1 glue -- process spawn, per-rank parity gate with agreement between ranks, schedule calibration, barriers and
-    MAX-over-ranks timing, the one JSON line from rank 0 -- run with 3 ranks on this one GPU through the file-based comm double (the
-    printed figure is meaningless and labelled so).  Weak scaling (config 2) and the strong-scaling deal of config 4."""
+def _bench_shm(tmp_path, extra, env_extra=None, timeout=600):
+    """tests/bench_shm.py = bench.py's own main() with 3 ranks on this one GPU over the file-based comm double."""
     import json
     import subprocess
     import sys
+    import time
     from conftest import ROOT
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--n", "300007", "--steps", "3", "--warmup", "1", "--settle-rounds", "2",
-           "--no-cpu-baseline", "--no-e2e", "--test-comm-dir", str(tmp_path)] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_shm.py"), "--gpus", "3", "--n", "300007", "--steps", "3", "--warmup", "1",
+           "--settle-rounds", "2", "--no-cpu-baseline", "--no-e2e"] + extra
+    env = dict(os.environ, OMP_WAIT_POLICY="passive", BENCH_SHM_DIR=str(tmp_path), FLASHE_RDZV_DIR=str(tmp_path))
+    env.update(env_extra or {})
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    return r, [json.loads(l) for l in lines], time.time() - t0
+
+
+@pytest.mark.parametrize("extra", [["--config", "2", "--clients", "3"], ["--config", "4", "--clients", "5"]])
+def test_bench_multi_rank_flow(extra, tmp_path):
+    """bench.py's own N > 1 glue -- process spawn, per-rank parity gate with agreement between ranks, the sequential round timed first,
+    schedule calibration, barriers and MAX-over-ranks timing, the one JSON line from rank 0 -- run with 3 ranks on this one GPU through
+    the file-based comm double (the printed figure is meaningless and labelled so).  Weak scaling (config 2) and the strong-scaling
+    deal of config 4."""
+    r, lines, _ = _bench_shm(tmp_path, extra)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    d = lines[0]
     assert d["n_gpus"] == 3 and d["steps"] == 3 and d["value"] > 0 and "bit-exact" in d["config"]["parity"]
     assert d["scaling"] == ("weak" if extra[1] == "2" else "strong")
     cal = d["config"]["schedule_calibration_ms"]
     assert "sequential" in cal and {k.split(",")[0] for k in cal} == {"fused", "pipelined", "sequential"} and \
         {"fused, 3 chunks", "fused, 4 chunks", "fused, 8 chunks"} <= set(cal)
     assert d["config"]["clients_total"] == (9 if extra[1] == "2" else 5)
+    assert d["config"]["ranks_counted_by_allreduce"] == 3 and d["config"]["ranks_parity_ok"] is True
+    assert d["config"]["schedule_fallback_reason"] is None and "TEST DOUBLE" in d["config"]["collectives"]
+    if d["config"]["schedule_name"] != "sequential":
+        assert d["sequential_ms_per_step"] > 0          # the line that would have been the fallback was measured first
+
+
+@pytest.mark.parametrize("inject", ["raise:1", "hang:2", "raise:0"])
+def test_bench_multi_rank_falls_back_to_the_sequential_line(inject, tmp_path):
+    """The first real multi-GPU run must not come back empty: with an overlapped schedule that raises on one rank, or blocks one
+    rank forever (the others then sit in their collective), every rank leaves at the deadline at the latest and rank 0 prints the
+    sequential line it had already measured, exit code 0, `config.schedule_fallback_reason` saying why."""
+    r, lines, took = _bench_shm(tmp_path, ["--config", "2", "--clients", "3", "--calibration-deadline", "25"], {"BENCH_SHM_INJECT": inject}, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = lines[0]
+    assert d["value"] > 0 and d["n_gpus"] == 3 and d["config"]["schedule_name"] == "sequential"
+    why = d["config"]["schedule_fallback_reason"]
+    assert why and (("injected failure" in why) if inject.startswith("raise") else ("deadline" in why)), why
+    assert took < 200, took
+
+
+def test_bench_partial_agg_schedule_multi_rank(tmp_path):
+    """--schedule partial-agg with 3 ranks: the encrypt launch writes each rank's partial aggregate, which is what the exchange sends."""
+    r, lines, _ = _bench_shm(tmp_path, ["--config", "2", "--clients", "3", "--schedule", "partial-agg"])
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    assert lines[0]["config"]["schedule_name"] == "partial-agg" and lines[0]["value"] > 0 and lines[0]["config"]["ranks_parity_ok"] is True
 
 
 def test_cu_limit_changes_the_launch_shape_not_the_result(E, oracle):
