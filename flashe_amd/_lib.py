@@ -58,6 +58,8 @@ _SIGNATURES = {
     "flashe_prp_block": (c_int, [c_u8p, c_u8p, c_u8p]),
     "flashe_dev_alloc": (c_int, [c_vp, c_size, ctypes.POINTER(c_vp)]),
     "flashe_dev_free": (c_int, [c_vp, c_vp]),
+    "flashe_dev_trim": (c_int, [c_int]),
+    "flashe_dev_pool_stats": (c_int, [c_int, c_u64p, c_u64p, c_u64p]),
     "flashe_host_alloc": (c_int, [c_size, ctypes.POINTER(c_vp)]),
     "flashe_host_free": (c_int, [c_vp]),
     "flashe_memcpy_h2d": (c_int, [c_vp, c_vp, c_vp, c_size]),

@@ -73,11 +73,12 @@ class FlasheClient(object):
         self.cipher.masking_scheme = choice
         self.cipher.masks = masks
 
-    def encrypt(self, plaintext):
-        return self.cipher.encrypt(plaintext)
+    def encrypt(self, plaintext, device=None):
+        """device (new): True keeps the ciphertext in HBM and returns a DeviceVector, see FlasheCipher.encrypt."""
+        return self.cipher.encrypt(plaintext, device=device)
 
-    def decrypt(self, ciphertext):
-        return self.cipher.decrypt(ciphertext)
+    def decrypt(self, ciphertext, device=None):
+        return self.cipher.decrypt(ciphertext, device=device)
 
     def get_idx_list(self):
         return self.cipher.get_idx_list()

@@ -14,6 +14,14 @@ As a fast path they also accept ``uint64`` arrays -- shape ``[n]`` (values < 2**
 ``[n, L]`` little-endian limbs, L = ceil(int_bits / 64) -- and then return ``[n, L]``
 (``[n]`` when L == 1 and the input was 1-D) without ever building Python ints.
 
+Device-resident mode (new): ``encrypt`` / ``decrypt`` / ``aggregate`` take ``device=True`` and
+then return a `DeviceVector` (the result stays in HBM; ``.to_host()`` downloads it), and they
+accept a `DeviceVector` wherever they accept an array -- a `DeviceVector` input makes the
+output one too unless ``device=False``.  A round then uploads each plaintext once and
+downloads one result, instead of bouncing every ciphertext device -> host -> device between
+the three calls.  The reference's type check is kept: anything that is neither an ndarray nor
+a `DeviceVector` gives ``None``.
+
 `N_JOBS` mirrors the reference's module global (jzf_flashe.py:7): for int_bits <= 64 the
 PRF counters depend on chunks_idx(range(n), N_JOBS), so every party must use the same
 value (the reference uses cpu_count(); set `flashe_amd.cipher.N_JOBS` to match a peer).
@@ -24,7 +32,7 @@ from multiprocessing import cpu_count
 import numpy as np
 
 from . import engine as _engine
-from .engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine
+from .engine import SCHEME_DOUBLE, SCHEME_SINGLE, DeviceVector, Engine
 
 import logging
 import time
@@ -37,7 +45,7 @@ LOGGER = logging.getLogger("flashe_amd.cipher")
 BITS_PER_BYTES = 8
 _M64 = (1 << 64) - 1
 
-__all__ = ["FlasheCipher", "aggregate", "N_JOBS"]
+__all__ = ["FlasheCipher", "aggregate", "DeviceVector", "N_JOBS"]
 
 
 # ------------------------------------------------------------------------------ conversions
@@ -290,111 +298,170 @@ class FlasheCipher(object):
         if len(vec) != n:
             raise ValueError(f"operands could not be broadcast together with shapes ({n},) ({len(vec)},) ")
 
-    def _encrypt_single(self, value):                                    # jzf_flashe.py:431-454
+    # ---- device-resident operands (new) ----
+    @staticmethod
+    def _wants_device(value, device):
+        return isinstance(value, DeviceVector) if device is None else bool(device)
+
+    def _on_device(self, value, full_width=False):
+        """(DeviceVector on this cipher's engine, kind of the host form).  full_width: the operand must have L limbs."""
         eng = self._engine
+        if isinstance(value, DeviceVector):
+            if value.device != getattr(eng, "device", 0):
+                raise ValueError(f"DeviceVector lives on device {value.device}, this cipher on device {eng.device}")
+            if value.limbs != eng.limbs and (full_width or value.limbs != 1):
+                raise ValueError(f"expected {eng.limbs} limbs per element, got {value.limbs}")
+            value.wait_on(eng)
+            return value, "u64_2d"
         limbs, kind = _to_limbs(value, eng.limbs)
-        ct = eng.encrypt(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_SINGLE, N_JOBS, limbs)
+        if full_width and limbs.shape[1] != eng.limbs:
+            limbs = np.concatenate([limbs, np.zeros((limbs.shape[0], eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
+        return DeviceVector.from_host(eng, limbs), kind
+
+    @staticmethod
+    def _deliver(out, kind, want_device):
+        return out.mark_ready() if want_device else _from_limbs(out.to_host(), kind)
+
+    def _encrypt_single(self, value, device=None):                       # jzf_flashe.py:431-454
+        eng = self._engine
+        if self._wants_device(value, device) or isinstance(value, DeviceVector):
+            dv, kind = self._on_device(value)
+            out = DeviceVector(eng, len(dv))
+            eng.encrypt_dev(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_SINGLE, len(dv), N_JOBS, dv.buf, dv.limbs, out.buf)
+            ct = self._deliver(out, kind, self._wants_device(value, device))
+        else:
+            limbs, kind = _to_limbs(value, eng.limbs)
+            ct = _from_limbs(eng.encrypt(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_SINGLE, N_JOBS, limbs), kind)
         if 'add' in self.next_iter_encrypt_prepared:
             del self.next_iter_encrypt_prepared['add']
-        return _from_limbs(ct, kind)
+        return ct
 
-    def _encrypt_double(self, value):                                    # jzf_flashe.py:456-488
+    def _encrypt_double(self, value, device=None):                       # jzf_flashe.py:456-488
         eng = self._engine
-        limbs, kind = _to_limbs(value, eng.limbs)
-        n = limbs.shape[0]
-        if 'add' not in self.next_iter_encrypt_prepared:
-            ct = eng.encrypt(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_DOUBLE, N_JOBS, limbs)
+        want_dev = self._wants_device(value, device)
+        prepared = 'add' in self.next_iter_encrypt_prepared
+        if want_dev or prepared or isinstance(value, DeviceVector):
+            dv, kind = self._on_device(value)
+            n = len(dv)
+            out = DeviceVector(eng, n)
+            if not prepared:
+                eng.encrypt_dev(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_DOUBLE, n, N_JOBS, dv.buf, dv.limbs, out.buf)
+            else:
+                add = self.next_iter_encrypt_prepared['add']
+                minus = self.next_iter_encrypt_prepared['minus']
+                self._check_prepared_len(add, n)
+                eng.combine_dev(n, dv.buf, dv.limbs, add.buf, minus.buf, out.buf)
+            ct = self._deliver(out, kind, want_dev)
         else:
-            add = self.next_iter_encrypt_prepared['add']
-            minus = self.next_iter_encrypt_prepared['minus']
-            self._check_prepared_len(add, n)
-            dpt = eng.upload(limbs)
-            dct = eng.alloc_vec(n)
-            eng.combine_dev(n, dpt, limbs.shape[1], add.buf, minus.buf, dct)
-            ct = dct.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
+            limbs, kind = _to_limbs(value, eng.limbs)
+            ct = _from_limbs(eng.encrypt(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_DOUBLE, N_JOBS, limbs), kind)
         if 'add' in self.next_iter_encrypt_prepared:
             del self.next_iter_encrypt_prepared['add']
         if 'minus' in self.next_iter_encrypt_prepared:
             del self.next_iter_encrypt_prepared['minus']
-        return _from_limbs(ct, kind)
+        return ct
+
+    def _begin(self, name):
+        """Phase markers with the reference's own wording (jzf_aggregator.py:729,747,821-826,881-890 bracket their phases with
+        LOGGER.info("begin encryption") / ("end encryption"), which its log post-processing turns into per-phase times): the same
+        two INFO lines on this module's logger, the end line also carrying n and the wall time."""
+        if LOGGER.isEnabledFor(logging.INFO):
+            LOGGER.info("begin %s", name)
+        return time.perf_counter()
 
     def _phase(self, name, n, t0):
-        if LOGGER.isEnabledFor(logging.DEBUG):
-            LOGGER.debug("phase=%s scheme=%s iter=%s n=%d seconds=%.6f", name, self.masking_scheme, self.iter_index, n, time.perf_counter() - t0)
+        if LOGGER.isEnabledFor(logging.INFO):
+            LOGGER.info("end %s (scheme=%s iter=%s n=%d seconds=%.6f)", name, self.masking_scheme, self.iter_index, n, time.perf_counter() - t0)
 
-    def encrypt(self, plaintext):                                        # jzf_flashe.py:490-504
+    def encrypt(self, plaintext, device=None):                           # jzf_flashe.py:490-504
+        """device: None = the result has the form of the input (ndarray -> ndarray, DeviceVector -> DeviceVector);
+        True = keep the ciphertext in HBM and return a DeviceVector; False = return a host array."""
         if self.prp_seed is not None:
             if self.masking_scheme == "double":
                 self.set_idx_list(mode="encrypt")
             else:
                 self.set_idx_list_single(mode="encrypt")
-            if not isinstance(plaintext, np.ndarray):
+            if not isinstance(plaintext, (np.ndarray, DeviceVector)):
                 return None
-            t0 = time.perf_counter()
-            out = self._encrypt_double(plaintext) if self.masking_scheme == "double" else self._encrypt_single(plaintext)
-            self._phase("encrypt", len(plaintext), t0)
+            t0 = self._begin("encryption")
+            out = self._encrypt_double(plaintext, device) if self.masking_scheme == "double" else self._encrypt_single(plaintext, device)
+            self._phase("encryption", len(plaintext), t0)
             return out
         return None
 
     # ------------------------------------------------------------------ decrypt
-    def _decrypt_single(self, value):                                    # jzf_flashe.py:506-535
+    def _decrypt_single(self, value, device=None):                       # jzf_flashe.py:506-535
         eng = self._engine
-        limbs, kind = _to_limbs(value, eng.limbs)
-        n = limbs.shape[0]
-        if limbs.shape[1] != eng.limbs:
-            limbs = np.concatenate([limbs, np.zeros((n, eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
-        if self.masks is None:
-            minus_idx = [self._idx_of(p) for p in self.index_prefix_for_minus]
-            out = eng.decrypt(self.iter_index, [], minus_idx, N_JOBS, limbs)
+        want_dev = self._wants_device(value, device)
+        if want_dev or self.masks is not None or isinstance(value, DeviceVector):
+            dv, kind = self._on_device(value, full_width=True)
+            n = len(dv)
+            out = DeviceVector(eng, n)
+            if self.masks is None:
+                minus_idx = [self._idx_of(p) for p in self.index_prefix_for_minus]
+                eng.decrypt_dev(self.iter_index, [], minus_idx, n, N_JOBS, dv.buf, out.buf)
+            else:
+                minus = self.next_iter_decrypt_prepared['minus']
+                self._check_prepared_len(minus, n)
+                eng.combine_dev(n, dv.buf, eng.limbs, None, minus.buf, out.buf)
+            res = self._deliver(out, kind, want_dev)
         else:
-            minus = self.next_iter_decrypt_prepared['minus']
-            self._check_prepared_len(minus, n)
-            din = eng.upload(limbs)
-            dout = eng.alloc_vec(n)
-            eng.combine_dev(n, din, eng.limbs, None, minus.buf, dout)
-            out = dout.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
+            limbs, kind = _to_limbs(value, eng.limbs)
+            n = limbs.shape[0]
+            if limbs.shape[1] != eng.limbs:
+                limbs = np.concatenate([limbs, np.zeros((n, eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
+            minus_idx = [self._idx_of(p) for p in self.index_prefix_for_minus]
+            res = _from_limbs(eng.decrypt(self.iter_index, [], minus_idx, N_JOBS, limbs), kind)
         if 'minus' in self.next_iter_decrypt_prepared:
             del self.next_iter_decrypt_prepared['minus']
-        return _from_limbs(out, kind)
+        return res
 
-    def _decrypt_double(self, value):                                    # jzf_flashe.py:537-582
+    def _decrypt_double(self, value, device=None):                       # jzf_flashe.py:537-582
         eng = self._engine
-        limbs, kind = _to_limbs(value, eng.limbs)
-        n = limbs.shape[0]
-        if limbs.shape[1] != eng.limbs:
-            limbs = np.concatenate([limbs, np.zeros((n, eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
+        want_dev = self._wants_device(value, device)
         add_idx, minus_idx = [], []
         if self.masks is None and (self.index_prefix_for_minus or self.index_prefix_for_add):
             add_idx = [self._idx_of(p) for p in self.index_prefix_for_add]
             minus_idx = [self._idx_of(p) for p in self.index_prefix_for_minus]
         online = bool(add_idx or minus_idx)
-        if 'add' not in self.next_iter_decrypt_prepared:
-            if not online:
-                raise KeyError('add')                                     # what the reference raises (:570)
-            out = eng.decrypt(self.iter_index, add_idx, minus_idx, N_JOBS, limbs)
+        prepared = 'add' in self.next_iter_decrypt_prepared
+        if not prepared and not online:
+            _to_limbs(value, eng.limbs) if isinstance(value, np.ndarray) else None      # (conversion errors come first, as in the reference)
+            raise KeyError('add')                                         # what the reference raises (:570)
+        if want_dev or prepared or isinstance(value, DeviceVector):
+            dv, kind = self._on_device(value, full_width=True)
+            n = len(dv)
+            out = DeviceVector(eng, n)
+            if not prepared:
+                eng.decrypt_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, dv.buf, out.buf)
+            else:
+                padd = self.next_iter_decrypt_prepared['add']
+                pminus = self.next_iter_decrypt_prepared['minus']
+                self._check_prepared_len(padd, n)
+                eng.combine_dev(n, dv.buf, eng.limbs, padd.buf, pminus.buf, out.buf)
+                if online:                                                # extras merged in (:557-564)
+                    eng.decrypt_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, out.buf, out.buf)
+            res = self._deliver(out, kind, want_dev)
         else:
-            padd = self.next_iter_decrypt_prepared['add']
-            pminus = self.next_iter_decrypt_prepared['minus']
-            self._check_prepared_len(padd, n)
-            din = eng.upload(limbs)
-            dout = eng.alloc_vec(n)
-            eng.combine_dev(n, din, eng.limbs, padd.buf, pminus.buf, dout)
-            if online:                                                    # extras merged in (:557-564)
-                eng.decrypt_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, dout, dout)
-            out = dout.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
+            limbs, kind = _to_limbs(value, eng.limbs)
+            n = limbs.shape[0]
+            if limbs.shape[1] != eng.limbs:
+                limbs = np.concatenate([limbs, np.zeros((n, eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
+            res = _from_limbs(eng.decrypt(self.iter_index, add_idx, minus_idx, N_JOBS, limbs), kind)
         for d in (self.next_iter_decrypt_prepared, self.next_iter_decrypt_prepared_idx):
             for k in ('add', 'minus'):
                 if k in d:
                     del d[k]
-        return _from_limbs(out, kind)
+        return res
 
-    def decrypt(self, ciphertext):                                       # jzf_flashe.py:584-594
+    def decrypt(self, ciphertext, device=None):                          # jzf_flashe.py:584-594
+        """device: as for encrypt()."""
         if self.prp_seed is not None:
-            if not isinstance(ciphertext, np.ndarray):
+            if not isinstance(ciphertext, (np.ndarray, DeviceVector)):
                 return None
-            t0 = time.perf_counter()
-            out = self._decrypt_double(ciphertext) if self.masking_scheme == "double" else self._decrypt_single(ciphertext)
-            self._phase("decrypt", len(ciphertext), t0)
+            t0 = self._begin("decryption")
+            out = self._decrypt_double(ciphertext, device) if self.masking_scheme == "double" else self._decrypt_single(ciphertext, device)
+            self._phase("decryption", len(ciphertext), t0)
             return out
         return None
 
@@ -421,57 +488,71 @@ class FlasheCipher(object):
         self.next_iter_decrypt_prepared_idx['minus'] = [0]
 
     # ------------------------------------------------------------------ arbiter reduce (new)
-    def aggregate(self, ciphertexts, packed=False):
+    def aggregate(self, ciphertexts, packed=False, device=None):
         """Server-side reduce of a list of ciphertext vectors.  The reference has no such method;
         this equals Arbiter.aggregate_model's flashe branch: element-wise
         (jzf_aggregator.py:424-430) or, with packed=True, on the bit-packed integers
-        (jzf_aggregator.py:406-419), returned unpacked."""
+        (jzf_aggregator.py:406-419), returned unpacked.  Operands may be DeviceVectors (they stay where they are);
+        device: as for encrypt() -- None returns a DeviceVector iff the first operand is one."""
         eng = self._engine or self._engine_cls(bytes(32), self.int_bits, device=self._device)
-        return aggregate(ciphertexts, self.int_bits, packed=packed, device=self._device, _engine=eng)
+        t0 = self._begin("aggregation")
+        out = aggregate(ciphertexts, self.int_bits, packed=packed, device=self._device, _engine=eng, keep_on_device=device)
+        self._phase("aggregation", len(out), t0)
+        return out
 
 
-def aggregate(ciphertexts, int_bits, packed=False, device=0, _engine=None):
+def aggregate(ciphertexts, int_bits, packed=False, device=0, _engine=None, keep_on_device=None):
     """reduce(lambda x, y: (x + y) % mod, models) on the GPU.
 
     packed=False: mod = 1 << int_bits per element (jzf_aggregator.py:424-430).
     packed=True : every operand is bit-packed (JZFTransferableWeights.compress,
     jzf_weights.py:155-195), added mod 1 << (int_bits * n) with carries crossing element
-    boundaries (jzf_aggregator.py:406-419), then unpacked again (decompress, :197-231)."""
+    boundaries (jzf_aggregator.py:406-419), then unpacked again (decompress, :197-231).
+    keep_on_device: True = return a DeviceVector, False = a host array, None = what the first operand is."""
     if len(ciphertexts) == 0:
         raise TypeError("reduce() of empty sequence with no initial value")
     eng = _engine or Engine(bytes(32), int_bits, device=device)
+    want_dev = isinstance(ciphertexts[0], DeviceVector) if keep_on_device is None else bool(keep_on_device)
     # an operand passed several times (the notebook's `[ct] * num_clients`) is converted and uploaded once
     seen, conv = {}, []
     for c in ciphertexts:
         if id(c) not in seen:
-            a, k = _to_limbs(np.asarray(c) if not isinstance(c, np.ndarray) else c, eng.limbs)
-            if a.shape[1] != eng.limbs:
-                a = np.concatenate([a, np.zeros((a.shape[0], eng.limbs - a.shape[1]), dtype=np.uint64)], axis=1)
-            seen[id(c)] = (a, k)
+            if isinstance(c, DeviceVector):
+                if c.limbs != eng.limbs:
+                    raise ValueError(f"expected {eng.limbs} limbs per element, got {c.limbs}")
+                c.wait_on(eng)
+                seen[id(c)] = (c, "u64_2d")
+            else:
+                a, k = _to_limbs(np.asarray(c) if not isinstance(c, np.ndarray) else c, eng.limbs)
+                if a.shape[1] != eng.limbs:
+                    a = np.concatenate([a, np.zeros((a.shape[0], eng.limbs - a.shape[1]), dtype=np.uint64)], axis=1)
+                seen[id(c)] = (a, k)
         conv.append(seen[id(c)])
     kind = conv[0][1]
     arrs = [a for a, _k in conv]
-    n = arrs[0].shape[0]
-    if any(a.shape[0] != n for a in arrs):
+    n = len(arrs[0])
+    if any(len(a) != n for a in arrs):
         raise ValueError("operands could not be broadcast together")
+    if not packed and not want_dev and not any(isinstance(a, DeviceVector) for a in arrs) and hasattr(eng, "aggregate_elem") and len(arrs) <= 64:
+        # all operands on the host, result wanted on the host: the host-pointer twin (chunk-pipelined upload / reduce / download)
+        return _from_limbs(eng.aggregate_elem(arrs), kind)
     dev = {}
     for a in arrs:
         if id(a) not in dev:
-            dev[id(a)] = eng.upload(a)
+            dev[id(a)] = a.buf if isinstance(a, DeviceVector) else eng.upload(a)
     dsrc = [dev[id(a)] for a in arrs]
+    out = DeviceVector(eng, n)
     if not packed:
-        dsum = eng.alloc_vec(n)
-        eng.aggregate_elem_dev(dsrc, n, dsum)
-        out = dsum.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
+        eng.aggregate_elem_dev(dsrc, n, out.buf)
     else:
         total_bits = n * int_bits
         n_limbs = (total_bits + 63) // 64
         dpk = [eng.alloc(max(n_limbs * 8, 16)) for _ in arrs]
-        for s, p in zip(dsrc, dpk):
-            eng.pack_dev(n, s, p)
+        for s_, p_ in zip(dsrc, dpk):
+            eng.pack_dev(n, s_, p_)
         dsum = eng.alloc(max(n_limbs * 8, 16))
         eng.aggregate_packed_dev(dpk, n_limbs, total_bits, dsum)
-        dout = eng.alloc_vec(n)
-        eng.unpack_dev(n, dsum, dout)
-        out = dout.download(np.uint64, n * eng.limbs).reshape(n, eng.limbs)
-    return _from_limbs(out, kind)
+        eng.unpack_dev(n, dsum, out.buf)
+    if want_dev:
+        return out.mark_ready()
+    return _from_limbs(out.to_host(), kind)

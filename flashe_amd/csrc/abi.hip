@@ -1,6 +1,7 @@
 // C ABI of libflashe_hip.so (see include/flashe.h).  Host-side glue only: context, key
 // schedule, device buffers, argument checks, and the host-pointer convenience wrappers.
 #include "ctx.h"
+#include "blockpool.h"
 
 #include <algorithm>
 #include <cstdarg>
@@ -8,6 +9,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -384,6 +386,7 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     if (ctx->env.stream2) { (void)hipStreamSynchronize(ctx->env.stream2); (void)hipStreamDestroy(ctx->env.stream2); }
     if (ctx->env.ev_fork) (void)hipEventDestroy(ctx->env.ev_fork);
     if (ctx->env.ev_join) (void)hipEventDestroy(ctx->env.ev_join);
+    for (hipEvent_t &ev : ctx->ev_copy) if (ev) (void)hipEventDestroy(ev);
     if (ctx->own_stream && ctx->env.stream) (void)hipStreamDestroy(ctx->env.stream);
     delete ctx;
     return FLASHE_OK;
@@ -504,17 +507,72 @@ int flashe_prp_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16
 }
 
 // ---- memory / stream / events ----
+namespace {
+
+struct HipBackend final : flashe_pool::Backend {
+    int alloc(void **p, size_t bytes) override { const hipError_t e = hipMalloc(p, bytes); if (e != hipSuccess) (void)hipGetLastError(); return static_cast<int>(e); }
+    int release(void *p) override { return static_cast<int>(hipFree(p)); }
+    int sync_all() override { return static_cast<int>(hipDeviceSynchronize()); }
+    void wipe(void *p, size_t bytes) override { (void)hipMemset(p, 0, bytes); }
+};
+
+// one cache per device (flashe_dev_alloc / flashe_dev_free run with the ctx's device current); FLASHE_DEV_POOL_MB = how many MiB of
+// freed blocks a device keeps parked (default 16 GiB of the 288 GB; 0 = every free is a hipFree)
+flashe_pool::DeviceCache *dev_cache(int device)
+{
+    constexpr int kMaxDev = 64;
+    static HipBackend backend;
+    static flashe_pool::DeviceCache *caches[kMaxDev] = {};
+    static std::mutex mu;
+    if (device < 0 || device >= kMaxDev) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!caches[device]) {
+        const char *e = getenv("FLASHE_DEV_POOL_MB");
+        const size_t mb = e && atoll(e) >= 0 ? static_cast<size_t>(atoll(e)) : static_cast<size_t>(16384);
+        caches[device] = new flashe_pool::DeviceCache(&backend, mb << 20);
+    }
+    return caches[device];
+}
+
+}  // namespace
+
 int flashe_dev_alloc(flashe_ctx *ctx, size_t bytes, void **dptr)
 {
     CHECK_CTX(ctx);
     if (!dptr) return fail(ctx, FLASHE_EINVAL, "flashe_dev_alloc: null out pointer");
-    HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 16));
+    flashe_pool::DeviceCache *cache = ctx->capturing ? nullptr : dev_cache(ctx->device);
+    if (!cache) { HIP_TRY(ctx, hipMalloc(dptr, bytes ? bytes : 16)); return FLASHE_OK; }
+    const int rc = cache->alloc(bytes, dptr);
+    if (rc) HIP_TRY(ctx, static_cast<hipError_t>(rc));
     return FLASHE_OK;
 }
 int flashe_dev_free(flashe_ctx *ctx, void *dptr)
 {
     CHECK_CTX(ctx);
-    if (dptr) { HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); HIP_TRY(ctx, hipFree(dptr)); }
+    if (!dptr) return FLASHE_OK;
+    flashe_pool::DeviceCache *cache = dev_cache(ctx->device);
+    if (!cache) { HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); HIP_TRY(ctx, hipFree(dptr)); return FLASHE_OK; }
+    // parked, not freed: the block is handed out again only after a device-wide synchronisation (blockpool.h), which is the
+    // guarantee hipFree gave -- kernels of any stream that still read it finish first
+    const int rc = cache->release(dptr);
+    if (rc) HIP_TRY(ctx, static_cast<hipError_t>(rc));
+    return FLASHE_OK;
+}
+int flashe_dev_trim(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return FLASHE_ENODEV;
+    if (hipSetDevice(device) != hipSuccess) return FLASHE_EIO;
+    if (flashe_pool::DeviceCache *cache = dev_cache(device)) cache->trim();
+    return FLASHE_OK;
+}
+int flashe_dev_pool_stats(int device, uint64_t *parked_bytes, uint64_t *hits, uint64_t *misses)
+{
+    flashe_pool::DeviceCache *cache = dev_cache(device);
+    if (!cache) return FLASHE_EINVAL;
+    if (parked_bytes) *parked_bytes = cache->held_bytes();
+    if (hits) *hits = cache->hits();
+    if (misses) *misses = cache->misses();
     return FLASHE_OK;
 }
 // Page-locked host memory for callers that keep their vectors on the host: the DMA engines read and write it directly (no
@@ -1401,6 +1459,67 @@ int flashe_sparsify_dev(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x_d
         HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));                                         \
     } while (0)
 
+// Pipelined form of the big twins (encrypt / decrypt / aggregate_elem): the vector is cut into chunks; chunk q's upload and kernel run
+// on the ctx stream while chunk q - 1's result travels back on a second stream, so a call costs max(upload, download) instead of
+// their sum.  It needs a PAGE-LOCKED destination: a download into pageable memory blocks the host until it is done (measured: an H2D
+// and a D2H issued on two streams take 5.96 ms with pageable buffers, 3.46 ms pinned, tests/perf/pcie_probe.py), while an upload from
+// pageable memory -- blocking as well -- runs at the pinned rate and overlaps with a download that is already in flight.  So the
+// path is taken when the caller's output pointer is pinned (flashe_host_alloc / hipHostMalloc / hipHostRegister; the Python layer's
+// result pool hands out such arrays) and the vector is large enough for chunks to matter.
+namespace {
+
+constexpr size_t kPipeMinBytes = 16u << 20;
+
+bool host_pinned(const void *p)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // plain malloc memory: an error, not a type
+    return a.type == hipMemoryTypeHost;
+}
+
+// elements per chunk: FLASHE_TWIN_CHUNK_MB of output (default 32 MB), a multiple of 4096 elements (block- and tile-aligned for every b)
+uint64_t pipe_chunk_elems(const flashe_ctx *ctx)
+{
+    const char *e = getenv("FLASHE_TWIN_CHUNK_MB");          // read per call: a tuning knob, and tests shrink it
+    const long v = e ? atol(e) : 32;
+    const size_t mb = static_cast<size_t>(v < 1 ? 1 : v);
+    const uint64_t per = (mb << 20) / (static_cast<size_t>(ctx->limbs) * 8);
+    return std::max<uint64_t>(4096, per & ~static_cast<uint64_t>(4095));
+}
+
+bool pipe_wanted(const flashe_ctx *ctx, uint64_t n, const void *out_host)
+{
+    const char *e = getenv("FLASHE_TWIN_PIPELINE");
+    const bool off = e && atoi(e) == 0;
+    return !off && !ctx->capturing && ctx->env.stream2 && vec_bytes(ctx, n) >= kPipeMinBytes && n > pipe_chunk_elems(ctx) && host_pinned(out_host);
+}
+
+// chunk results: device -> pinned host on the second stream, behind everything the ctx stream has been given so far
+hipError_t pipe_copy_out(flashe_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, int q)
+{
+    hipEvent_t &ev = ctx->ev_copy[q & 1];
+    hipError_t e;
+    if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventRecord(ev, ctx->env.stream)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(ctx->env.stream2, ev, 0)) != hipSuccess) return e;
+    return hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->env.stream2);
+}
+
+// both streams idle: the staging blocks may be handed back (also on the error paths: a copy must not outlive its block's lease)
+hipError_t pipe_drain(flashe_ctx *ctx)
+{
+    const hipError_t a = hipStreamSynchronize(ctx->env.stream), b = hipStreamSynchronize(ctx->env.stream2);
+    return a != hipSuccess ? a : b;
+}
+
+}  // namespace
+
+#define PIPE_TRY(expr)                                                       \
+    do {                                                                     \
+        hipError_t pe_ = (expr);                                             \
+        if (pe_ != hipSuccess) { (void)pipe_drain(ctx); HIP_TRY(ctx, pe_); } \
+    } while (0)
+
 int flashe_mask(flashe_ctx *ctx, uint32_t iter, const uint32_t *idx, int n_idx, uint64_t n, uint32_t n_jobs, uint64_t *out)
 {
     CHECK_CTX(ctx);
@@ -1424,6 +1543,21 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uin
     Tmp dp, dc;
     HIP_TRY(ctx, dp.alloc(ctx, static_cast<size_t>(n) * pt_limbs * 8));
     HIP_TRY(ctx, dc.alloc(ctx, vec_bytes(ctx, n)));
+    if (pipe_wanted(ctx, n, ct)) {
+        const uint64_t ch = pipe_chunk_elems(ctx);
+        int q = 0;
+        for (uint64_t f = 0; f < n; f += ch, q++) {
+            const uint64_t cnt = std::min(ch, n - f);
+            PIPE_TRY(hipMemcpyAsync(dp.as<uint64_t>() + f * pt_limbs, pt + f * pt_limbs, static_cast<size_t>(cnt) * pt_limbs * 8, hipMemcpyHostToDevice,
+                                    ctx->env.stream));
+            const int rc = flashe_encrypt_range_dev(ctx, iter, idx, scheme, n, n_jobs, f, cnt, dp.as<uint64_t>() + f * pt_limbs, pt_limbs,
+                                                    dc.as<uint64_t>() + f * ctx->limbs);
+            if (rc) { (void)pipe_drain(ctx); return rc; }
+            PIPE_TRY(pipe_copy_out(ctx, ct + f * ctx->limbs, dc.as<uint64_t>() + f * ctx->limbs, vec_bytes(ctx, cnt), q));
+        }
+        HIP_TRY(ctx, pipe_drain(ctx));
+        return FLASHE_OK;
+    }
     H2D(dp.p, pt, static_cast<size_t>(n) * pt_limbs * 8);
     int rc = flashe_encrypt_dev(ctx, iter, idx, scheme, n, n_jobs, dp.as<uint64_t>(), pt_limbs, dc.as<uint64_t>());
     if (rc) return rc;
@@ -1440,6 +1574,20 @@ int flashe_decrypt(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int 
     Tmp di, dout;
     HIP_TRY(ctx, di.alloc(ctx, vec_bytes(ctx, n)));
     HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, n)));
+    if (pipe_wanted(ctx, n, out)) {
+        const uint64_t ch = pipe_chunk_elems(ctx);
+        int q = 0;
+        for (uint64_t f = 0; f < n; f += ch, q++) {
+            const uint64_t cnt = std::min(ch, n - f), off = f * ctx->limbs;
+            PIPE_TRY(hipMemcpyAsync(di.as<uint64_t>() + off, in + off, vec_bytes(ctx, cnt), hipMemcpyHostToDevice, ctx->env.stream));
+            const int rc = flashe_decrypt_range_dev(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, f, cnt, di.as<uint64_t>() + off,
+                                                    dout.as<uint64_t>() + off);
+            if (rc) { (void)pipe_drain(ctx); return rc; }
+            PIPE_TRY(pipe_copy_out(ctx, out + off, dout.as<uint64_t>() + off, vec_bytes(ctx, cnt), q));
+        }
+        HIP_TRY(ctx, pipe_drain(ctx));
+        return FLASHE_OK;
+    }
     H2D(di.p, in, vec_bytes(ctx, n));
     int rc = flashe_decrypt_dev(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, di.as<uint64_t>(), dout.as<uint64_t>());
     if (rc) return rc;
@@ -1480,8 +1628,26 @@ int flashe_aggregate_elem(flashe_ctx *ctx, int C, const uint64_t *const *cts, ui
     for (int c = 0; c < C; c++) {
         if (!cts[c]) return fail(ctx, FLASHE_EINVAL, "operand %d is null", c);
         ptrs[c] = reinterpret_cast<const uint64_t *>(all.as<char>() + vb * c);
-        H2D(const_cast<uint64_t *>(ptrs[c]), cts[c], vec_bytes(ctx, n));
     }
+    if (pipe_wanted(ctx, n, out)) {
+        // upload bound (C vectors up, one down): the chunks hide the reduce kernels and the download under the uploads
+        const uint64_t ch = pipe_chunk_elems(ctx);
+        std::vector<const uint64_t *> part(C);
+        int q = 0;
+        for (uint64_t f = 0; f < n; f += ch, q++) {
+            const uint64_t cnt = std::min(ch, n - f), off = f * ctx->limbs;
+            for (int c = 0; c < C; c++) {
+                part[c] = ptrs[c] + off;
+                PIPE_TRY(hipMemcpyAsync(const_cast<uint64_t *>(part[c]), cts[c] + off, vec_bytes(ctx, cnt), hipMemcpyHostToDevice, ctx->env.stream));
+            }
+            const int rc = flashe_aggregate_elem_dev(ctx, C, part.data(), cnt, dout.as<uint64_t>() + off);
+            if (rc) { (void)pipe_drain(ctx); return rc; }
+            PIPE_TRY(pipe_copy_out(ctx, out + off, dout.as<uint64_t>() + off, vec_bytes(ctx, cnt), q));
+        }
+        HIP_TRY(ctx, pipe_drain(ctx));
+        return FLASHE_OK;
+    }
+    for (int c = 0; c < C; c++) H2D(const_cast<uint64_t *>(ptrs[c]), cts[c], vec_bytes(ctx, n));
     int rc = flashe_aggregate_elem_dev(ctx, C, ptrs.data(), n, dout.as<uint64_t>());
     if (rc) return rc;
     D2H(out, dout.p, vec_bytes(ctx, n));

@@ -32,6 +32,7 @@ struct flashe_ctx {
     std::vector<PoolBlock> pool;
     bool capturing = false;   // between flashe_graph_begin and flashe_graph_end
     uint32_t key_epoch = 0;   // bumped by flashe_ctx_set_key: a graph replays the key it was captured with
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};   // hand-off events of the pipelined host-pointer twins (created on first use)
     uint32_t *err_flag_host = nullptr;   // host-mapped word the sparse kernels set when they skip an out-of-range location
 };
 

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import SCHEME_DOUBLE, SCHEME_SINGLE, FlasheError, PrfJob, c_int, c_u32, c_u32p, c_u64, c_u64p, c_vp
 
-__all__ = ["Engine", "DeviceBuffer", "limbs_of", "SCHEME_SINGLE", "SCHEME_DOUBLE", "FlasheError",
+__all__ = ["Engine", "DeviceBuffer", "DeviceVector", "limbs_of", "SCHEME_SINGLE", "SCHEME_DOUBLE", "FlasheError",
            "chunks", "telescope", "prp_block"]
 
 
@@ -60,20 +60,36 @@ class _HostPool:
     """Recycled host memory behind the result arrays of the host-array API.  A fresh 160 MB array costs 4-7 ms of page faults on its
     first transfer -- more than the 2.9 ms PCIe Gen5 needs to fill it (tests/perf/e2e_calls.py) -- and NumPy hands large arrays
     straight back to the OS, so every call would pay that again.  Blocks the caller has dropped (all views of the array dead) are
-    kept and reused, up to FLASHE_HOST_POOL_MB (default 4096; 0 = plain np.empty).  FLASHE_HOST_POOL_PINNED=1 backs the blocks
-    with page-locked memory (flashe_host_alloc) for platforms whose pageable transfers are slow; allocating those is itself slow,
-    which only a long-running caller earns back."""
+    kept and reused, up to FLASHE_HOST_POOL_MB (default 4096; 0 = plain np.empty).
+
+    Page-locked blocks: the host-pointer twins pipeline a large call (upload + kernel of one chunk beside the download of the
+    previous one) only into a PINNED result array -- 85 -> 70 ms for the config-2 round (tests/perf/e2e_pinned.py) -- but pinning
+    160 MB costs 30 ms, which only a caller that comes back earns.  FLASHE_HOST_POOL_PINNED = auto (default): the first
+    PIN_AFTER leases of a size class are pageable, from then on the class is served from page-locked blocks (a long-running job ends up
+    all pinned, a one-shot script never pays); 1: always; 0: never.
+
+    A recycled block is handed out UNINITIALISED, like np.empty: it still holds whatever result it carried before (a ciphertext, or a
+    decrypted aggregate) until the call that leased it has overwritten all of it -- every Engine method does.  FLASHE_HOST_POOL_WIPE=1
+    zeroes blocks as they return to the pool."""
     MIN_BYTES = 1 << 20
     STEP = 2 << 20
+    PIN_AFTER = 16                  # > the 12 result arrays of one config-2 round: a single round never pays for pinning
 
     def __init__(self):
-        self._lock = threading.Lock()
+        # re-entrant: _release runs from weakref.finalize callbacks, and a garbage collection triggered INSIDE the locked region
+        # (it allocates) may finalise another pooled array on the same thread
+        self._lock = threading.RLock()
         self._free = {}                 # capacity -> [block]
+        self._leases = {}               # capacity -> how many arrays of that class have been handed out
         self._held = 0                  # bytes parked in the free lists
         self._budget = max(0, int(os.environ.get("FLASHE_HOST_POOL_MB", "4096"))) << 20
-        self._pinned = os.environ.get("FLASHE_HOST_POOL_PINNED", "0") not in ("", "0")
+        mode = os.environ.get("FLASHE_HOST_POOL_PINNED", "auto").strip().lower()
+        self._pinned = "never" if mode in ("", "0", "off", "no") else "always" if mode in ("1", "on", "yes") else "auto"
+        self._wipe = os.environ.get("FLASHE_HOST_POOL_WIPE", "0") not in ("", "0")
 
     class _Pinned:
+        pinned = True
+
         def __init__(self, cap):
             p = c_vp()
             rc = _lib.load().flashe_host_alloc(cap, ctypes.byref(p))
@@ -88,6 +104,8 @@ class _HostPool:
                 pass
 
     class _Pageable:
+        pinned = False
+
         def __init__(self, cap):
             self.arr = np.empty(cap, dtype=np.uint8)
             self.addr = self.arr.ctypes.data
@@ -101,25 +119,49 @@ class _HostPool:
         cap = (nbytes + self.STEP - 1) // self.STEP * self.STEP
         block = None
         with self._lock:
+            count = self._leases[cap] = self._leases.get(cap, 0) + 1
+            want_pinned = self._pinned == "always" or (self._pinned == "auto" and count > self.PIN_AFTER)
             lst = self._free.get(cap)
             if lst:
-                block = lst.pop()
-                self._held -= cap
+                # a page-locked block if there is one; a pageable one only while the class is not being pinned
+                pick = next((i for i in range(len(lst) - 1, -1, -1) if lst[i].pinned), None)
+                if pick is None and not want_pinned:
+                    pick = len(lst) - 1
+                if pick is not None:
+                    block = lst.pop(pick)
+                    self._held -= cap
+                elif self._held + cap > self._budget:
+                    self._held -= cap                         # make room for the pinned replacement: one parked pageable block goes
+                    lst.pop()
         if block is None:
             try:
-                block = (self._Pinned if self._pinned else self._Pageable)(cap)
+                block = (self._Pinned if want_pinned else self._Pageable)(cap)
             except MemoryError:
-                return np.empty(shape, dtype=dtype)
+                try:
+                    block = self._Pageable(cap)
+                except MemoryError:
+                    return np.empty(shape, dtype=dtype)
         lease = (ctypes.c_char * nbytes).from_address(block.addr)      # dies with the last view of the array
         fin = weakref.finalize(lease, self._release, block, cap)
         fin.atexit = False
         return np.frombuffer(lease, dtype=dtype).reshape(shape)
 
     def _release(self, block, cap):
+        if self._wipe:
+            ctypes.memset(block.addr, 0, cap)
         with self._lock:
+            lst = self._free.get(cap)
+            if lst is None:
+                lst = self._free[cap] = []
             if self._held + cap <= self._budget:
-                self._free.setdefault(cap, []).append(block)
+                lst.append(block)
                 self._held += cap
+            elif block.pinned:
+                # a page-locked block is worth more than a parked pageable one of its class
+                for i, other in enumerate(lst):
+                    if not other.pinned:
+                        lst[i] = block
+                        break
         # otherwise the block dies here
 
     def trim(self):
@@ -169,6 +211,70 @@ class DeviceBuffer:
         out = host_empty(n, dtype)
         self.engine._check(self.engine._lib.flashe_memcpy_d2h(self.engine._h, out.ctypes.data, self.ptr, out.nbytes))
         return out
+
+
+class DeviceVector:
+    """A vector of `n` elements (L = `limbs` uint64 limbs each) that STAYS in HBM between calls of the drop-in API: what
+    FlasheCipher.encrypt / aggregate / decrypt return with device=True and accept in place of an ndarray, so that a round moves
+    plaintexts up once and the result down once instead of bouncing every ciphertext device -> host -> device
+    (jzf_weights.py:334-338 -> jzf_flashe_block.py:142-174 is the call chain this shortens).  `.to_host()` downloads it.
+
+    The producing engine records an event behind its last write; a consumer on another engine (another FlasheCipher = another
+    stream) makes its stream wait for it on the device, the host never blocks."""
+
+    def __init__(self, engine, n, limbs=None, buf=None):
+        self.engine, self.n = engine, int(n)
+        self.limbs = int(limbs or engine.limbs)
+        self.buf = buf if buf is not None else engine.alloc_vec(self.n, self.limbs)
+        self._ready = None
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def ptr(self):
+        return self.buf.ptr
+
+    @property
+    def shape(self):
+        return (self.n, self.limbs)
+
+    @property
+    def device(self):
+        return getattr(self.engine, "device", 0)
+
+    @classmethod
+    def from_host(cls, engine, arr):
+        """Upload a uint64 array of shape [n] or [n, k]."""
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        if arr.ndim == 1:
+            arr = arr.reshape(-1, 1)
+        return cls(engine, arr.shape[0], arr.shape[1], buf=engine.upload(arr))
+
+    def mark_ready(self):
+        """Called by the producer after enqueueing the kernels that write the vector."""
+        if hasattr(self.engine, "event"):
+            if self._ready is None:
+                self._ready = self.engine.event()
+            self.engine.record(self._ready)
+        return self
+
+    def wait_on(self, engine):
+        """Make `engine`'s stream wait (on the device) until the vector is complete."""
+        if engine is not self.engine and self._ready is not None:
+            engine.wait_event(self._ready)
+
+    def to_host(self):
+        """uint64 array [n, limbs] (from the recycling host pool); blocks until the vector is complete."""
+        return self.buf.download(np.uint64, self.n * self.limbs).reshape(self.n, self.limbs)
+
+    def __del__(self):
+        try:
+            if self._ready is not None and self.engine._h is not None:
+                self.engine.event_destroy(self._ready)
+            self._ready = None
+        except Exception:
+            pass
 
 
 class Graph:
@@ -293,7 +399,7 @@ class Engine:
     def _ptr(x):
         if x is None:
             return None
-        return x.ptr if isinstance(x, DeviceBuffer) else int(x)
+        return x.ptr if isinstance(x, (DeviceBuffer, DeviceVector)) else int(x)
 
     # -- device-pointer API (asynchronous on the ctx stream) -----------------------------------
     def mask_dev(self, it, idx_list, n, n_jobs, out):

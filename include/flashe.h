@@ -87,8 +87,15 @@ int flashe_telescope(uint32_t *raw, int n_raw, uint32_t *add_out, uint32_t *minu
 int flashe_prp_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16]);
 
 /* ---- device memory, stream, events -------------------------------------------------- */
+/* Device blocks come from a per-device caching allocator (new): flashe_dev_free PARKS the block (a hipMalloc + hipFree pair of a
+ * 160 MB block costs more than moving it over PCIe), flashe_dev_alloc hands a parked block of the same size class out again --
+ * after a device-wide synchronisation has happened since it was parked, which keeps hipFree's guarantee that kernels of any
+ * stream still reading the block finish first.  FLASHE_DEV_POOL_MB bounds the parked bytes per device (default 16384, 0 = off);
+ * flashe_dev_trim gives every parked block of a device back (zeroed first). */
 int flashe_dev_alloc(flashe_ctx *ctx, size_t bytes, void **dptr);
 int flashe_dev_free(flashe_ctx *ctx, void *dptr);
+int flashe_dev_trim(int device);
+int flashe_dev_pool_stats(int device, uint64_t *parked_bytes, uint64_t *hits, uint64_t *misses);
 /* new: page-locked (pinned) host memory, for callers that hand host vectors to the host-pointer calls repeatedly: DMA without
  * a staging copy, and a reused buffer spares the page faults of a fresh one.  Independent of any ctx. */
 int flashe_host_alloc(size_t bytes, void **hptr);

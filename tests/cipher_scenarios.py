@@ -49,6 +49,41 @@ def run_round_case(cm, c):
         assert ints(d.decrypt(agg)) == unhex(c["dec_elem"])
         d.set_idx_list(raw_idx_list=list(c["uploaded"]), mode="decrypt")
         assert ints(d.decrypt(aggp)) == unhex(c["dec_packed"])
+    run_round_case_with_handles(cm, c)
+
+
+def run_round_case_with_handles(cm, c):
+    """The same round with the results kept on the device between the three calls (DeviceVector handles): every client uploads its
+    plaintext once, the ciphertexts never visit the host, one download at the end -- and every intermediate, downloaded for the
+    check, equals the fixture."""
+    from oracle.flashe_oracle import limbs_to_ints
+    b, n, it, scheme, C = c["b"], c["n"], c["iter"], c["scheme"], c["num_clients"]
+    cm.N_JOBS = c["n_jobs"]
+    if n == 0:
+        return
+    handles = {}
+    for i, pt in c["pt"].items():
+        ci = new_cipher(cm, b, scheme, int(i), it, C)
+        h = ci.encrypt(obj(unhex(pt)), device=True)
+        assert isinstance(h, cm.DeviceVector) and len(h) == n
+        assert limbs_to_ints(h.to_host()) == unhex(c["ct"][i]), (scheme, b, n, i)
+        handles[int(i)] = h
+    d = new_cipher(cm, b, scheme, 0, it, C)
+    models = [handles[i] for i in c["uploaded"]]
+    agg = d.aggregate(models)                                  # DeviceVector in -> DeviceVector out
+    assert isinstance(agg, cm.DeviceVector) and limbs_to_ints(agg.to_host()) == unhex(c["agg_elem"])
+    aggp = d.aggregate(models, packed=True)
+    assert isinstance(aggp, cm.DeviceVector) and limbs_to_ints(aggp.to_host()) == unhex(c["agg_packed"])
+    mixed = d.aggregate([models[0].to_host()] + models[1:], device=False)      # host and device operands mixed, host result
+    assert isinstance(mixed, np.ndarray) and limbs_to_ints(mixed) == unhex(c["agg_elem"])
+    d.set_idx_list(raw_idx_list=list(c["uploaded"]), mode="decrypt")
+    dec = d.decrypt(agg)
+    assert isinstance(dec, cm.DeviceVector) and limbs_to_ints(dec.to_host()) == unhex(c["dec_elem"])
+    d.set_idx_list(raw_idx_list=list(c["uploaded"]), mode="decrypt")
+    dec_host = d.decrypt(aggp, device=False)                   # a handle in, a host array out
+    assert isinstance(dec_host, np.ndarray) and limbs_to_ints(dec_host) == unhex(c["dec_packed"])
+    h2 = new_cipher(cm, b, scheme, int(c["uploaded"][0]), it, C).encrypt(cm.DeviceVector.from_host(d.engine, handles[int(c["uploaded"][0])].to_host()[:, :1] * 0 + 5))
+    assert isinstance(h2, cm.DeviceVector)                     # a device-resident plaintext gives a device-resident ciphertext
 
 
 def run_precompute_case(cm, c):

@@ -60,6 +60,9 @@ class OracleEngine:
         return orc.aggregate_elem(cts, self.int_bits)
 
     # device API on FakeBufs
+    def encrypt_dev(self, it, idx, scheme, n, n_jobs, pt, pt_limbs, ct):
+        ct.arr = orc.encrypt(self.key, it, idx, self._sch(scheme), n_jobs, self.int_bits, np.ascontiguousarray(pt.arr).reshape(n, pt_limbs))
+
     def aggregate_elem_dev(self, cts, n, out):
         out.arr = orc.aggregate_elem([np.ascontiguousarray(c.arr).reshape(n, self.limbs) for c in cts], self.int_bits)
 

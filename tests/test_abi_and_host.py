@@ -128,6 +128,66 @@ def test_host_result_pool_recycles_only_dead_arrays(monkeypatch):
     assert off.empty(500_000, np.uint64).base is None
 
 
+def test_host_result_pool_pins_a_size_class_that_keeps_coming_back(monkeypatch):
+    """FLASHE_HOST_POOL_PINNED=auto: the first PIN_AFTER arrays of a size class are pageable, later ones page-locked (here a stand-in
+    block type, no GPU), a returning pinned block is preferred over parked pageable ones, `0` never pins, `1` always does, and
+    FLASHE_HOST_POOL_WIPE zeroes a block on its way back."""
+    import gc
+    import numpy as np
+    from flashe_amd import engine
+
+    made = []
+
+    class FakePinned(engine._HostPool._Pageable):
+        pinned = True
+
+        def __init__(self, cap):
+            super().__init__(cap)
+            made.append(cap)
+
+    def kinds(pool, k):
+        out = []
+        for _ in range(k):
+            a = pool.empty(400_000, np.uint64)               # 3.2 MB -> one size class
+            out.append(a)
+        return out
+
+    monkeypatch.setenv("FLASHE_HOST_POOL_PINNED", "auto")
+    pool = engine._HostPool()
+    monkeypatch.setattr(pool, "_Pinned", FakePinned)
+    monkeypatch.setattr(pool, "PIN_AFTER", 3)
+    first = kinds(pool, 3)
+    assert made == []                                         # leases 1-3: pageable
+    del first
+    gc.collect()
+    assert sum(len(v) for v in pool._free.values()) == 3
+    a = pool.empty(400_000, np.uint64)                        # lease 4: the class is pinned from here on, parked pageable blocks stay parked
+    assert len(made) == 1
+    addr = a.ctypes.data
+    del a
+    gc.collect()
+    b = pool.empty(400_000, np.uint64)                        # the pinned block comes back before any pageable one
+    assert b.ctypes.data == addr and len(made) == 1
+    for mode, want in (("0", 0), ("1", 2)):
+        made.clear()
+        monkeypatch.setenv("FLASHE_HOST_POOL_PINNED", mode)
+        p2 = engine._HostPool()
+        monkeypatch.setattr(p2, "_Pinned", FakePinned)
+        keep = kinds(p2, 2)
+        assert len(made) == want, mode
+        del keep
+    monkeypatch.setenv("FLASHE_HOST_POOL_WIPE", "1")
+    monkeypatch.setenv("FLASHE_HOST_POOL_PINNED", "0")
+    p3 = engine._HostPool()
+    x = p3.empty(400_000, np.uint64)
+    x[:] = 7
+    addr = x.ctypes.data
+    del x
+    gc.collect()
+    y = p3.empty(400_000, np.uint64)
+    assert y.ctypes.data == addr and not y.any()
+
+
 def _build_c_example(tmp_path):
     import subprocess
     from conftest import ROOT

@@ -1190,3 +1190,69 @@ def test_error_codes(E):
     d = eng.alloc_vec(8)
     with pytest.raises(E.FlasheError):
         eng.aggregate_packed_dev([d], 16, 1024, d)      # out aliases an operand
+
+
+@pytest.mark.parametrize("b,n", [(128, 1_300_003), (20, 2_500_001), (64, 2_100_000)])
+def test_pipelined_host_twins_with_pinned_results(E, oracle, b, n, monkeypatch):
+    """The host-pointer twins cut large vectors into chunks (upload + kernel of chunk q beside the download of chunk q - 1) when the
+    result array is page-locked -- the engine's result pool with FLASHE_HOST_POOL_PINNED=1.  Same bytes as the one-shot form and the
+    oracle: encrypt (double / single), a dropout decrypt with prefix lists, the reduce; ragged last chunk, chunk size shrunk to 4 MB so
+    that several chunks and both hand-off events take part; b <= 64 chunk boundaries fall inside the reference's n_jobs chunks."""
+    monkeypatch.setenv("FLASHE_HOST_POOL_PINNED", "1")
+    monkeypatch.setenv("FLASHE_TWIN_CHUNK_MB", "4")
+    monkeypatch.setattr(E, "_HOST_POOL", E._HostPool())
+    eng = make(E, b)
+    Lb = L(b)
+    rng = np.random.Generator(np.random.PCG64(n))
+    pts = [rng.integers(0, 2 ** min(b, 64), n, dtype=np.uint64) for _ in range(3)]
+    cts = [eng.encrypt(5, c, E.SCHEME_DOUBLE, 7, pts[c]) for c in range(3)]
+    for c in range(3):
+        assert np.array_equal(cts[c], oracle.encrypt(KEY, 5, c, "double", 7, b, pts[c])), (b, c)
+    assert np.array_equal(eng.encrypt(5, 9, E.SCHEME_SINGLE, 7, pts[0]), oracle.encrypt(KEY, 5, 9, "single", 7, b, pts[0]))
+    agg = eng.aggregate_elem(cts)
+    assert np.array_equal(agg, oracle.aggregate_elem(cts, b))
+    dec = eng.decrypt(5, [3, 7], [0, 5], 7, agg)
+    assert np.array_equal(dec, oracle.decrypt(KEY, 5, [3, 7], [0, 5], 7, b, agg))
+    # the pageable-result form of the same calls (no pipeline) gives the same arrays
+    monkeypatch.setenv("FLASHE_TWIN_PIPELINE", "0")
+    assert np.array_equal(eng.encrypt(5, 1, E.SCHEME_DOUBLE, 7, pts[1]), cts[1]) and np.array_equal(eng.aggregate_elem(cts), agg)
+
+
+def test_device_block_cache_reuse_is_safe_across_streams(E, oracle):
+    """flashe_dev_free parks a block, flashe_dev_alloc hands it out again (no hipMalloc / hipFree pair per DeviceVector) -- but only
+    after a device-wide synchronisation, so a kernel of ANOTHER ctx that still reads the block when its owner drops it sees the old
+    contents to the end: a 32-operand reduce on ctx B reads a vector that ctx A frees, re-allocates (same address) and overwrites."""
+    import ctypes
+    a, b_ = make(E, 128), make(E, 128)
+    n = 3_000_001
+    rng = np.random.Generator(np.random.PCG64(4))
+    x = rng.integers(0, 2 ** 64, size=(n, 2), dtype=np.uint64)
+    want = oracle.aggregate_elem([x] * 32, 128)
+    dx = a.upload(x)
+    lib = a._lib
+    h0, m0 = ctypes.c_uint64(), ctypes.c_uint64()
+    lib.flashe_dev_pool_stats(0, None, ctypes.byref(h0), ctypes.byref(m0))
+    for rep in range(4):
+        d = a.alloc_vec(n)
+        a.combine_dev(n, dx, 2, None, None, d)                      # d <- x on A's stream
+        a.sync()
+        out = b_.alloc_vec(n)
+        b_.aggregate_elem_dev([d] * 32, n, out)                     # B reads d for a while (1.5 GB of loads)
+        ptr = d.ptr
+        d.free()                                                    # parked while B still reads it
+        d2 = a.alloc_vec(n)
+        assert d2.ptr == ptr, "the parked block was not reused"
+        a._check(lib.flashe_memset_dev(a._h, d2.ptr, 0xFF, d2.nbytes))
+        a.sync()
+        assert np.array_equal(out.download(np.uint64, 2 * n).reshape(n, 2), want), rep
+        d2.free()
+        out.free()
+    h1, m1, parked = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    lib.flashe_dev_pool_stats(0, ctypes.byref(parked), ctypes.byref(h1), ctypes.byref(m1))
+    assert h1.value - h0.value >= 7 and parked.value >= 2 * (48 << 20)
+    assert lib.flashe_dev_trim(0) == 0
+    lib.flashe_dev_pool_stats(0, ctypes.byref(parked), None, None)
+    assert parked.value == 0
+    d3 = a.alloc_vec(n)                                             # still works after a trim
+    a.combine_dev(n, dx, 2, None, None, d3)
+    assert np.array_equal(d3.download(np.uint64, 2 * n).reshape(n, 2), x)
