@@ -13,10 +13,13 @@ is; only its missing third-party imports are shimmed in sys.modules --
     .encrypt(block) is forwarded to the system libcrypto 3 EVP aes-256-ecb (no padding)
     through ctypes.  AES-256 is FIPS-197, so any conformant implementation gives the
     same bytes; the shim itself is checked against FIPS-197 C.3 below.
-jzf_aggregator.py cannot be imported at all (it imports modules that are not in the
-tree), so the two arbiter reduces (jzf_aggregator.py:406-419, :424-430) are evaluated
-here exactly as written there: reduce(lambda x, y: (x + y) % mod, models) on Python ints /
-object arrays.
+jzf_aggregator.py imports sibling modules that are not in the tree (jzf_additive_mask_block,
+jzf_simple_block) or need absent libraries (bfv / ckks / paillier blocks): those get empty
+stand-ins in sys.modules (_import_aggregator), after which the module imports and its
+Client.sparsify (:578-623) and Arbiter.expand_to_dense (:150-165) are CALLED, unbound, on stub
+objects.  The two arbiter reduces (:406-419, :424-430) are inline expressions of a long method
+and are evaluated here exactly as written there: reduce(lambda x, y: (x + y) % mod, models) on
+Python ints / object arrays.
 """
 import collections
 import collections.abc
@@ -359,6 +362,7 @@ def gen_pack():
 
 # --------------------------------------------------------------------------- sparse
 def gen_sparse():
+    RA = _import_aggregator()
     rng = np.random.RandomState(9)
     cases = []
     for b, total, n_jobs, C, frac, it in [(128, 200, 4, 3, 0.2, 2), (64, 301, 8, 4, 0.1, 0), (20, 150, 3, 2, 0.3, 5)]:
@@ -376,16 +380,8 @@ def gen_sparse():
             zero = int(rng.randint(0, 1 << 15))                               # trailing plain value
             zeros.append(zero)
             ups.append(ct + [zero])
-        # Arbiter.expand_to_dense (jzf_aggregator.py:150-165) restated, then the element-wise reduce
-        dense = []
-        for c in range(C):
-            a = np.array(ups[c], dtype=object)
-            zero, a = a[-1], a[:-1]
-            e = np.zeros(total, dtype=object)
-            e[locs[c]] = a
-            zl = list(set(np.arange(total).tolist()) - set(locs[c]))
-            e[zl] = zero
-            dense.append(e)
+        # Arbiter.expand_to_dense (jzf_aggregator.py:150-165), the reference's own method, then the element-wise reduce
+        dense = ref_expand_to_dense(RA, ups, locs, total)
         agg = reduce(lambda x, y: (x + y) % mod, dense)
         d = new_cipher(b, "single", 0, it, C)
         d.masks = [list(l) for l in locs]
@@ -513,29 +509,37 @@ def gen_codec():
 
 # --------------------------------------------------------------------------- sparsifier (f-3)
 def gen_sparsify():
-    """Client.sparsify (jzf_aggregator.py:578-623), one layer, restated literally (jzf_aggregator cannot be
-    imported): top-k by |layer| (taken BEFORE the residual is added), residual accumulation across two rounds.
-    Values are distinct in magnitude so numpy's unstable argsort has a unique answer."""
+    """Client.sparsify (jzf_aggregator.py:578-623) CALLED on a stub client for one-layer models: top-k by |layer| (taken BEFORE
+    the residual is added), residual accumulation across two rounds.  Its last three statements encode the location list with
+    jzf_weights._to_bytes, which overflows under NumPy >= 2 (`s <<= ...` on a NumPy integer, jzf_weights.py:81 -- the wire format is
+    covered by pack.json through _to_bytes_old): for the call, the module's _to_bytes / _from_bytes names are replaced by recorders,
+    which is also how the location list -- a local of the method -- is read out.  Values are distinct in magnitude so NumPy's unstable
+    argsort has a unique answer."""
+    RA = _import_aggregator()
+    seen = []
+
+    def rec_to_bytes(locations, bits):
+        seen.append(([int(v) for v in locations], int(bits)))
+        return b"", 0
+
+    RA._to_bytes, RA._from_bytes = rec_to_bytes, (lambda enc, le, bits: [])
     cases = []
     for dtype, n, sparsity, seed in [("float32", 1000, 0.01, 1), ("float32", 4099, 0.1, 2), ("float64", 777, 0.05, 3),
                                      ("float32", 50, 0.001, 4), ("float32", 300, 1.0, 5)]:
         rng = np.random.RandomState(seed)
-        remain = None
+        client = types.SimpleNamespace(remain_weights=None, _sparsity=sparsity, shape_dict_used_for_sparsification=None)
         rounds = []
         for rd in range(2):
             layer = rng.standard_normal(n).astype(dtype)
             while len(np.unique(np.abs(layer))) != n:          # float32 magnitudes can collide: redraw
                 layer = rng.standard_normal(n).astype(dtype)
-            flatten = layer.flatten()
-            abs_flatten = np.abs(flatten)
-            if remain is not None:
-                flatten += remain
-            idx = max(1, int(np.floor(sparsity * n)))
-            location = sorted(abs_flatten.argsort()[-idx:][::-1])
-            masked_layer = flatten[location]
-            flatten[location] = 0.0
-            remain = flatten
-            rounds.append({"layer": layer.tobytes().hex(), "k": idx, "location": [int(v) for v in location],
+            w = _Weights({"layer": layer.copy()})
+            enc, le, bits, base = RA.Client.sparsify(client, w)
+            location, got_bits = seen.pop()
+            assert base == n and bits == got_bits == int(n).bit_length() and not seen
+            masked_layer, remain = w._weights["layer"], client.remain_weights["layer"]
+            assert masked_layer.dtype == remain.dtype == np.dtype(dtype) and client.shape_dict_used_for_sparsification == {"layer": (n,)}
+            rounds.append({"layer": layer.tobytes().hex(), "k": len(location), "location": location,
                            "masked": masked_layer.tobytes().hex(), "remain": remain.tobytes().hex()})
         cases.append({"dtype": dtype, "n": n, "sparsity": sparsity, "rounds": rounds})
     dump("sparsify.json", {"cases": cases})
@@ -635,6 +639,27 @@ def _import_block():
     return RB
 
 
+def _import_aggregator():
+    """federatedml/framework/homo/procedure/jzf_aggregator.py imports seven sibling block modules (:15-21); two are not in the tree
+    (jzf_additive_mask_block, jzf_simple_block) and three need libraries this image lacks (bfv / ckks / paillier).  None of them is
+    touched by the two methods called here, so they get empty stand-ins; jzf_flashe_block and jzf_plain_block import for real."""
+    _import_block()
+    pkg = "federatedml.framework.homo.procedure."
+    for nm in ("jzf_additive_mask_block", "jzf_simple_block", "jzf_bfv_block", "jzf_ckks_block", "jzf_paillier_block"):
+        sys.modules.setdefault(pkg + nm, types.ModuleType(pkg + nm))
+    from federatedml.framework.homo.procedure import jzf_aggregator as RA
+    return RA
+
+
+def ref_expand_to_dense(RA, uploads, masks, total):
+    """Arbiter.expand_to_dense (jzf_aggregator.py:150-165) itself, on stand-ins for the model objects it walks (one flattened layer
+    per client: the compact ciphertexts followed by the un-encrypted quantised zero); returns the dense object arrays it leaves in
+    mo._weights."""
+    models = [types.SimpleNamespace(_weights={"flat": np.array(u, dtype=object)}) for u in uploads]
+    RA.Arbiter.expand_to_dense(types.SimpleNamespace(), models, [list(m) for m in masks], total)
+    return [m._weights["flat"] for m in models]
+
+
 class _Wire:
     """Stand-in for a federation transfer variable: records what is sent, replays it on get()."""
 
@@ -654,6 +679,7 @@ def gen_block():
     double-mask job with precompute over two rounds, the second with a dropout; (3) a sparse job with mask = "dynamic",
     where the arbiter's hint switches the clients to single masks over compact positions."""
     RB = _import_block()
+    RA = _import_aggregator()
     rng = np.random.RandomState(321)
     dm = []
     for total, sets in [(40, [[1, 2, 3], [1, 2, 3], [1, 2, 3]]), (40, [[0, 5], [7, 9], [11]]), (30, [list(range(30))] * 4), (25, [[3, 4, 5, 6]]),
@@ -725,12 +751,7 @@ def gen_block():
             zero = int(rng.randint(0, 1 << 15))
             zeros.append(zero)
             ups.append([int(v) for v in RB._Client.encrypt(cls[c], np.array(pt, dtype=object))] + [zero])
-        dense_vecs = []
-        for c in range(C):                                           # Arbiter.expand_to_dense (jzf_aggregator.py:150-165)
-            e = np.zeros(total, dtype=object)
-            e[masks[c]] = np.array(ups[c][:-1], dtype=object)
-            e[list(set(range(total)) - set(masks[c]))] = ups[c][-1]
-            dense_vecs.append(e)
+        dense_vecs = ref_expand_to_dense(RA, ups, masks, total)     # Arbiter.expand_to_dense (jzf_aggregator.py:150-165), called
         agg = reduce(lambda x, y: (x + y) % mod, dense_vecs)
         RB._Client.set_idx_list(cls[0], list(range(C)))
         dec = [int(v) for v in RB._Client.decrypt(cls[0], agg)]
