@@ -198,8 +198,6 @@ size_t vec_bytes(const flashe_ctx *ctx, uint64_t n) { return static_cast<size_t>
 // pair of a 160 MB block costs more than moving 160 MB over PCIe Gen5 on this platform (measured 7 ms against 2.9 ms,
 // tests/perf/e2e_calls.py).  The blocks a ctx keeps are bounded by a byte budget (FLASHE_STAGING_POOL_MB, default 8 GiB of the
 // 288 GB); beyond it the largest free block makes room, and a request that still does not fit is a plain allocation.
-constexpr size_t kPoolBlocks = 64;
-
 size_t pool_budget()
 {
     static const size_t v = [] {
@@ -209,6 +207,14 @@ size_t pool_budget()
     return v;
 }
 
+struct HipBackend final : flashe_pool::Backend {
+    int alloc(void **p, size_t bytes) override { const hipError_t e = hipMalloc(p, bytes); if (e != hipSuccess) (void)hipGetLastError(); return static_cast<int>(e); }
+    int release(void *p) override { return static_cast<int>(hipFree(p)); }
+    int sync_all() override { return static_cast<int>(hipDeviceSynchronize()); }
+    void wipe(void *p, size_t bytes) override { (void)hipMemset(p, 0, bytes); }
+};
+HipBackend &hip_backend() { static HipBackend b; return b; }
+
 struct Tmp {
     void *p = nullptr;
     flashe_ctx *owner = nullptr;
@@ -216,63 +222,14 @@ struct Tmp {
     ~Tmp()
     {
         if (!p) return;
-        if (slot >= 0) owner->pool[slot].used = false;
+        if (slot >= 0) owner->staging->give_back(slot);
         else (void)hipFree(p);
     }
     hipError_t alloc(flashe_ctx *ctx, size_t bytes)
     {
-        if (bytes == 0) bytes = 16;
-        int best = -1;
-        for (size_t i = 0; i < ctx->pool.size(); i++)
-            if (!ctx->pool[i].used && ctx->pool[i].cap >= bytes && (best < 0 || ctx->pool[i].cap < ctx->pool[best].cap)) best = static_cast<int>(i);
-        if (best < 0) {
-            // small blocks in powers of two, large ones in 2-MiB steps (a 160 MB vector must not pin 256 MB)
-            size_t cap = 4096;
-            if (bytes > (8u << 20)) cap = (bytes + (2u << 20) - 1) & ~static_cast<size_t>((2u << 20) - 1);
-            else while (cap < bytes) cap <<= 1;
-            size_t held = 0;
-            for (const auto &b : ctx->pool) held += b.cap;
-            auto no_slot = [&] {
-                if (ctx->pool.size() < kPoolBlocks) return false;
-                for (const auto &b : ctx->pool)
-                    if (!b.used && b.cap == 0) return false;
-                return true;
-            };
-            // make room: drop parked blocks, largest first (they are all too small for this request); a request beyond the whole
-            // budget is a plain allocation and evicts nothing
-            while (cap <= pool_budget() && (held + cap > pool_budget() || no_slot())) {
-                int victim = -1;
-                for (size_t i = 0; i < ctx->pool.size(); i++)
-                    if (!ctx->pool[i].used && ctx->pool[i].cap && (victim < 0 || ctx->pool[i].cap > ctx->pool[victim].cap)) victim = static_cast<int>(i);
-                if (victim < 0) break;                   // nothing parked is left to give up
-                // live Tmp objects hold slot numbers: only the LAST slot can be removed without renumbering, so swap-free
-                // removal is limited to it; any other victim is freed in place and its slot kept as an empty one
-                (void)hipStreamSynchronize(ctx->env.stream);
-                (void)hipFree(ctx->pool[victim].p);
-                held -= ctx->pool[victim].cap;
-                if (static_cast<size_t>(victim) + 1 == ctx->pool.size()) ctx->pool.pop_back();
-                else { ctx->pool[victim].p = nullptr; ctx->pool[victim].cap = 0; }
-            }
-            if (held + cap <= pool_budget()) {
-                int slot_new = -1;
-                for (size_t i = 0; i < ctx->pool.size(); i++)
-                    if (!ctx->pool[i].used && ctx->pool[i].cap == 0) { slot_new = static_cast<int>(i); break; }
-                if (slot_new >= 0 || ctx->pool.size() < kPoolBlocks) {
-                    void *q = nullptr;
-                    const hipError_t e = hipMalloc(&q, cap);
-                    if (e != hipSuccess) return e;
-                    if (slot_new >= 0) ctx->pool[slot_new] = flashe_ctx::PoolBlock{q, cap, false};
-                    else { ctx->pool.push_back(flashe_ctx::PoolBlock{q, cap, false}); slot_new = static_cast<int>(ctx->pool.size()) - 1; }
-                    best = slot_new;
-                }
-            }
-        }
-        if (best >= 0) {
-            ctx->pool[best].used = true;
-            p = ctx->pool[best].p; owner = ctx; slot = best;
-            return hipSuccess;
-        }
-        return hipMalloc(&p, bytes);
+        if (!ctx->staging) ctx->staging = new flashe_pool::StagingPool(&hip_backend(), pool_budget());
+        owner = ctx;
+        return static_cast<hipError_t>(ctx->staging->lease(bytes, &p, &slot));
     }
     template <class T> T *as() { return static_cast<T *>(p); }
 };
@@ -357,9 +314,11 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
     if ((e = hipEventCreateWithFlags(&ctx->env.ev_join, hipEventDisableTiming)) != hipSuccess) return bail(FLASHE_EIO, "hipEventCreate", e);
     if (const char *be = getenv("FLASHE_PRF_BACKEND")) {
         if (!strcmp(be, "table")) ctx->env.prf_backend = PRF_TABLE;
+#ifdef FLASHE_WITH_BITSLICE
         else if (!strcmp(be, "bitslice")) ctx->env.prf_backend = PRF_BITSLICE;
         else if (!strcmp(be, "hybrid")) ctx->env.prf_backend = PRF_HYBRID;
         else if (!strcmp(be, "bitslice16")) ctx->env.prf_backend = PRF_BITSLICE16;
+#endif
     }
     if (const char *pm = getenv("FLASHE_HYBRID_BS_PERMILLE")) ctx->env.hybrid_bs_permille = atoi(pm);
     ctx->env.use_chain = 1;
@@ -375,8 +334,7 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     if (ctx->env.stream) (void)hipStreamSynchronize(ctx->env.stream);
     for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds})
         if (b->p) (void)hipFree(b->p);
-    for (flashe_ctx::PoolBlock &pb : ctx->pool)
-        if (pb.p) { (void)hipMemset(pb.p, 0, pb.cap); (void)hipFree(pb.p); }      // staging blocks held plaintexts and ciphertexts
+    if (ctx->staging) { ctx->staging->destroy(); delete ctx->staging; ctx->staging = nullptr; }      // staging blocks held plaintexts and ciphertexts (wiped)
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
     // the expanded AES-256 key leaves neither HBM nor host memory behind
     if (ctx->rkw_dev) { (void)hipMemset(ctx->rkw_dev, 0, 256); (void)hipFree(ctx->rkw_dev); }
@@ -408,6 +366,11 @@ int flashe_ctx_set_prf_backend(flashe_ctx *ctx, int backend)
     if (!ctx) return FLASHE_EINVAL;
     if (backend < PRF_AUTO || backend > PRF_BITSLICE16)
         return fail(ctx, FLASHE_EINVAL, "unknown PRF backend %d", backend);
+#ifndef FLASHE_WITH_BITSLICE
+    if (backend != PRF_AUTO && backend != PRF_TABLE)
+        return fail(ctx, FLASHE_EINVAL, "PRF backend %d (bit-sliced) is not in this library: build libflashe_hip_bitslice.so with `make -C "
+                                        "flashe_amd/csrc bitslice` and select it with FLASHE_LIB_NAME", backend);
+#endif
     ctx->env.prf_backend = backend;
     return FLASHE_OK;
 }
@@ -509,19 +472,11 @@ int flashe_prp_block(const uint8_t key[32], const uint8_t in[16], uint8_t out[16
 // ---- memory / stream / events ----
 namespace {
 
-struct HipBackend final : flashe_pool::Backend {
-    int alloc(void **p, size_t bytes) override { const hipError_t e = hipMalloc(p, bytes); if (e != hipSuccess) (void)hipGetLastError(); return static_cast<int>(e); }
-    int release(void *p) override { return static_cast<int>(hipFree(p)); }
-    int sync_all() override { return static_cast<int>(hipDeviceSynchronize()); }
-    void wipe(void *p, size_t bytes) override { (void)hipMemset(p, 0, bytes); }
-};
-
 // one cache per device (flashe_dev_alloc / flashe_dev_free run with the ctx's device current); FLASHE_DEV_POOL_MB = how many MiB of
 // freed blocks a device keeps parked (default 16 GiB of the 288 GB; 0 = every free is a hipFree)
 flashe_pool::DeviceCache *dev_cache(int device)
 {
     constexpr int kMaxDev = 64;
-    static HipBackend backend;
     static flashe_pool::DeviceCache *caches[kMaxDev] = {};
     static std::mutex mu;
     if (device < 0 || device >= kMaxDev) return nullptr;
@@ -529,7 +484,7 @@ flashe_pool::DeviceCache *dev_cache(int device)
     if (!caches[device]) {
         const char *e = getenv("FLASHE_DEV_POOL_MB");
         const size_t mb = e && atoll(e) >= 0 ? static_cast<size_t>(atoll(e)) : static_cast<size_t>(16384);
-        caches[device] = new flashe_pool::DeviceCache(&backend, mb << 20);
+        caches[device] = new flashe_pool::DeviceCache(&hip_backend(), mb << 20);
     }
     return caches[device];
 }

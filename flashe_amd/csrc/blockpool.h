@@ -137,4 +137,93 @@ private:
     uint64_t epoch_ = 0, hits_ = 0, misses_ = 0;
 };
 
+// Staging blocks of the synchronous host-pointer twins, one pool per ctx (not thread-safe, like the ctx): a call leases the device
+// blocks it stages its operands in and gives them back when it returns.  Blocks are kept between calls within a byte budget --
+// a hipMalloc + hipFree pair per 160 MB block cost 7 ms against 2.9 ms for the transfer itself (tests/perf/e2e_calls.py) -- the
+// smallest free block that fits is taken; when a new block is needed and the budget or the slot table is full, parked blocks are
+// dropped largest first; a request that still does not fit (or exceeds the whole budget) is a plain allocation, slot -1, which the
+// caller releases through the backend.
+class StagingPool {
+public:
+    StagingPool(Backend *backend, size_t budget_bytes, size_t max_blocks = 64) : be_(backend), budget_(budget_bytes), max_blocks_(max_blocks) {}
+
+    // *p = a device block of at least `bytes`; *slot = its pool slot, or -1 for a plain allocation.  Returns the backend's error code.
+    int lease(size_t bytes, void **p, int *slot)
+    {
+        if (bytes == 0) bytes = 16;
+        *p = nullptr; *slot = -1;
+        int best = -1;
+        for (size_t i = 0; i < blocks_.size(); i++)
+            if (!blocks_[i].used && blocks_[i].cap >= bytes && (best < 0 || blocks_[i].cap < blocks_[best].cap)) best = static_cast<int>(i);
+        if (best < 0) {
+            const size_t cap = size_class(bytes);
+            size_t held = 0;
+            for (const Block &b : blocks_) held += b.cap;
+            auto no_slot = [&] {
+                if (blocks_.size() < max_blocks_) return false;
+                for (const Block &b : blocks_)
+                    if (!b.used && b.cap == 0) return false;
+                return true;
+            };
+            // make room: drop parked blocks, largest first (they are all too small for this request); a request beyond the whole
+            // budget is a plain allocation and evicts nothing
+            while (cap <= budget_ && (held + cap > budget_ || no_slot())) {
+                int victim = -1;
+                for (size_t i = 0; i < blocks_.size(); i++)
+                    if (!blocks_[i].used && blocks_[i].cap && (victim < 0 || blocks_[i].cap > blocks_[victim].cap)) victim = static_cast<int>(i);
+                if (victim < 0) break;                   // nothing parked is left to give up
+                // live leases hold slot numbers: only the LAST slot can be removed without renumbering; any other victim is freed in
+                // place and its slot kept as an empty one
+                be_->wipe(blocks_[victim].p, blocks_[victim].cap);
+                (void)be_->release(blocks_[victim].p);
+                held -= blocks_[victim].cap;
+                if (static_cast<size_t>(victim) + 1 == blocks_.size()) blocks_.pop_back();
+                else { blocks_[victim].p = nullptr; blocks_[victim].cap = 0; }
+            }
+            if (held + cap <= budget_) {
+                int slot_new = -1;
+                for (size_t i = 0; i < blocks_.size(); i++)
+                    if (!blocks_[i].used && blocks_[i].cap == 0) { slot_new = static_cast<int>(i); break; }
+                if (slot_new >= 0 || blocks_.size() < max_blocks_) {
+                    void *q = nullptr;
+                    const int rc = be_->alloc(&q, cap);
+                    if (rc) return rc;
+                    if (slot_new >= 0) blocks_[slot_new] = Block{q, cap, false};
+                    else { blocks_.push_back(Block{q, cap, false}); slot_new = static_cast<int>(blocks_.size()) - 1; }
+                    best = slot_new;
+                }
+            }
+        }
+        if (best >= 0) {
+            blocks_[best].used = true;
+            *p = blocks_[best].p; *slot = best;
+            return 0;
+        }
+        return be_->alloc(p, bytes);
+    }
+
+    void give_back(int slot)
+    {
+        if (slot >= 0 && static_cast<size_t>(slot) < blocks_.size()) blocks_[slot].used = false;
+    }
+
+    // every block goes back to the device, wiped (they held plaintexts and ciphertexts)
+    void destroy()
+    {
+        for (Block &b : blocks_)
+            if (b.p) { be_->wipe(b.p, b.cap); (void)be_->release(b.p); }
+        blocks_.clear();
+    }
+
+    size_t held_bytes() const { size_t h = 0; for (const Block &b : blocks_) h += b.cap; return h; }
+    size_t slots() const { return blocks_.size(); }
+    size_t leased() const { size_t k = 0; for (const Block &b : blocks_) k += b.used ? 1 : 0; return k; }
+
+private:
+    struct Block { void *p; size_t cap; bool used; };
+    Backend *be_;
+    size_t budget_, max_blocks_;
+    std::vector<Block> blocks_;
+};
+
 }  // namespace flashe_pool

@@ -3,6 +3,7 @@
 #pragma once
 #include "flashe.h"
 #include "kernels.h"
+#include "blockpool.h"
 
 #include <string>
 #include <vector>
@@ -28,8 +29,7 @@ struct flashe_ctx {
     // staging blocks of the host-pointer twins: hipMalloc / hipFree cost more than the kernels on LeNet-sized vectors and more than
     // the PCIe transfer on 160 MB ones, so blocks are kept and reused within a byte budget (the twins are synchronous: a block is
     // free again when its call returns)
-    struct PoolBlock { void *p; size_t cap; bool used; };
-    std::vector<PoolBlock> pool;
+    flashe_pool::StagingPool *staging = nullptr;   // (policy in blockpool.h, so that it can be tested on the host under sanitizers)
     bool capturing = false;   // between flashe_graph_begin and flashe_graph_end
     uint32_t key_epoch = 0;   // bumped by flashe_ctx_set_key: a graph replays the key it was captured with
     hipEvent_t ev_copy[2] = {nullptr, nullptr};   // hand-off events of the pipelined host-pointer twins (created on first use)

@@ -965,6 +965,10 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
     }
 }
 
+// The bit-sliced PRF backends are NOT part of the default library: they measured 2.5x the VALU work of the table kernel (DESIGN.md
+// section 4.3) and nothing selects them by default.  `make bitslice` builds libflashe_hip_bitslice.so with them (-DFLASHE_WITH_BITSLICE,
+// the generated header comes from tools/bitslice/gen_bitslice.py at build time); FLASHE_LIB_NAME selects that library.
+#ifdef FLASHE_WITH_BITSLICE
 // ------------------------------------------------------------------------------------------
 // Bit-sliced AES-256 PRF (b > 64): pure VALU, no LDS.
 //
@@ -1057,6 +1061,7 @@ __global__ __launch_bounds__(kBsThreads, WAVES) void prf_wide_bsp_kernel(const u
         }
     }
 }
+#endif  // FLASHE_WITH_BITSLICE
 
 // ---- b <= 64, one add / at most one minus prefix: many jobs per launch, coalesced element traffic ----
 // A lane still encrypts one AES block (m = 128 / b elements, counter = chunk begin + block index), but the m
@@ -1620,6 +1625,7 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
         e2.prf_backend = PRF_TABLE;
         return launch_prf(e2, iter, add, n_add, minus, n_minus, n, n_jobs, first, count, in_dev, in_limbs, out_dev);
     }
+#ifdef FLASHE_WITH_BITSLICE
     if (env.prf_backend == PRF_HYBRID && env.b > 64 && n_add == 1 && n_minus <= 1 && env.stream2) {
         // split [first, first + count): tail -> bit-sliced kernel on stream2, head -> table kernel here.
         // The bit-sliced share is a whole number of passes of all its waves (1 wave per SIMD).
@@ -1653,6 +1659,7 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
         }
         return hipSuccess;
     }
+#endif
     IdxLists lists;
     for (int k = 0; k < kMaxIdx; k++) { lists.add[k] = k < n_add ? add[k] : 0; lists.minus[k] = k < n_minus ? minus[k] : 0; }
     PrfParams p{};
@@ -1663,6 +1670,7 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
     if (env.codec) p.cq = *env.codec;
     masks_of(env.b, &p.mask_lo, &p.mask_hi);
     const bool bs_shape = env.b > 64 && n_add == 1 && n_minus <= 1;
+#ifdef FLASHE_WITH_BITSLICE
     if (bs_shape && env.prf_backend == PRF_BITSLICE16) {
         // waves per SIMD the kernel variant is compiled for (register budget 256 / 168 / 128 VGPRs)
         static const int kWaves = [] { const char *e = getenv("FLASHE_BS16_WAVES"); int w = e ? atoi(e) : 3; return w < 2 || w > 4 ? 3 : w; }();
@@ -1689,7 +1697,9 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
         else
             hipLaunchKernelGGL(prf_wide_bs_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(kBsThreads), 0, env.stream,
                                env.rkw_dev, p, lists.add[0], 0u);
-    } else if (bs_shape && !(env.codec && (!env.use_chain || ((first + count - 1) >> 32) != (first >> 32)))) {
+    } else
+#endif
+    if (bs_shape && !(env.codec && (!env.use_chain || ((first + count - 1) >> 32) != (first >> 32)))) {
         const PrfJob job{lists.add[0], lists.minus[0], first, count, in_dev, in_limbs, out_dev};
         return launch_prf_jobs(env, iter, n_minus == 1, 1, &job, n, n_jobs);
     } else if (env.b > 64) {

@@ -66,7 +66,9 @@ int flashe_ctx_cu_count(const flashe_ctx *ctx);
 /* Which implementation of the AES-256 PRF the fused kernels use (results are identical):
  * 0 = automatic, 1 = LDS T-table kernel, 2 = bit-sliced VALU kernel (b > 64, single add prefix with
  * at most one minus prefix; other shapes always use the table kernel).  Also settable at ctx creation
- * through the environment variable FLASHE_PRF_BACKEND=table|bitslice. */
+ * through the environment variable FLASHE_PRF_BACKEND=table|bitslice.  The bit-sliced kernels are measured
+ * alternatives (2.5x the VALU work of the table kernel) and are NOT in libflashe_hip.so: they are built by
+ * `make -C flashe_amd/csrc bitslice` into libflashe_hip_bitslice.so; the product library answers FLASHE_EINVAL. */
 #define FLASHE_PRF_AUTO     0
 #define FLASHE_PRF_TABLE    1
 #define FLASHE_PRF_BITSLICE 2

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <random>
 #include <set>
@@ -23,8 +24,8 @@ struct Mock final : Backend {
     int alloc(void **p, size_t bytes) override
     {
         if (used + bytes > capacity) return 2;                        // "hipErrorOutOfMemory"
-        *p = malloc(bytes ? bytes : 1);
-        memset(*p, 0xCD, bytes);
+        *p = malloc(real(bytes));               // (the "device" backs only the first page of a block with real memory: the
+        memset(*p, 0xCD, real(bytes));          // policy sees the full sizes, the sanitizer still guards what the callers touch)
         blocks[*p] = bytes; used += bytes; allocs++;
         return 0;
     }
@@ -36,7 +37,8 @@ struct Mock final : Backend {
         return 0;
     }
     int sync_all() override { syncs++; return 0; }
-    void wipe(void *p, size_t bytes) override { memset(p, 0, bytes); wiped.insert(p); }
+    void wipe(void *p, size_t bytes) override { memset(p, 0, real(bytes)); wiped.insert(p); }
+    static size_t real(size_t bytes) { return bytes < 4096 ? (bytes ? bytes : 1) : 4096; }
 };
 
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "%s:%d: CHECK failed: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
@@ -45,7 +47,7 @@ int main()
 {
     CHECK(size_class(1) == 4096 && size_class(4097) == 8192 && size_class(8u << 20) == (8u << 20));
     CHECK(size_class((8u << 20) + 1) == (10u << 20) && size_class(160000000) % (2u << 20) == 0 && size_class(160000000) - 160000000 < (2u << 20));
-    for (unsigned seed = 1; seed <= 8; seed++) {
+    for (unsigned seed = 1; seed <= 20; seed++) {
         Mock mock(static_cast<size_t>(96) << 20);
         const size_t budget = static_cast<size_t>(seed % 4 == 0 ? 0 : 24) << 20;
         DeviceCache cache(&mock, budget);
@@ -54,7 +56,7 @@ int main()
         std::vector<Live> live;
         std::map<void *, uint64_t> parked_at;        // sync count of the mock when the model saw the block freed
         const size_t sizes[] = {1, 100, 4096, 5000, 70000, 1u << 20, (3u << 20) + 5, 9u << 20, 17u << 20, 30u << 20};
-        for (int step = 0; step < 1500; step++) {
+        for (int step = 0; step < 4000; step++) {
             const int op = rng() % 100;
             if (op < 55 || live.empty()) {
                 const size_t want = sizes[rng() % (sizeof sizes / sizeof *sizes)];
@@ -65,7 +67,7 @@ int main()
                 for (const Live &l : live) CHECK(l.p != p);                                          // never handed out twice
                 auto it = parked_at.find(p);
                 if (it != parked_at.end()) { CHECK(mock.syncs > it->second); parked_at.erase(it); }  // reused only after a later synchronisation
-                memset(p, 0xAB, want);                                                               // the caller writes its block (ASan: in bounds)
+                memset(p, 0xAB, Mock::real(want));                                                               // the caller writes its block (ASan: in bounds)
                 live.push_back(Live{p, want});
             } else if (op < 95) {
                 const size_t i = rng() % live.size();
@@ -91,6 +93,39 @@ int main()
         cache.trim();
         CHECK(mock.blocks.empty() && mock.used == 0 && mock.allocs == mock.frees);
         if (budget) CHECK(cache.hits() > 0);
+    }
+    // ---- the staging pool of the host-pointer twins: leases of a call are given back when it returns ----
+    for (unsigned seed = 1; seed <= 12; seed++) {
+        Mock mock(static_cast<size_t>(64) << 20);
+        const size_t budget = static_cast<size_t>(seed % 5 == 0 ? 0 : seed % 3 == 0 ? 3 : 20) << 20;
+        StagingPool pool(&mock, budget, seed % 4 == 0 ? 4 : 64);
+        std::mt19937 rng(1000 + seed);
+        const size_t sizes[] = {1, 4096, 70000, 1u << 20, (2u << 20) + 7, 5u << 20, 9u << 20, 13u << 20};
+        for (int call = 0; call < 1200; call++) {
+            // one "call": up to four leases alive at once, all returned at the end (what Tmp's destructors do)
+            struct Lease { void *p; int slot; size_t want; };
+            std::vector<Lease> mine;
+            const int k = 1 + rng() % 4;
+            for (int i = 0; i < k; i++) {
+                const size_t want = sizes[rng() % (sizeof sizes / sizeof *sizes)];
+                void *p = nullptr; int slot = -2;
+                const int rc = pool.lease(want, &p, &slot);
+                if (rc) { CHECK(rc == 2); continue; }                                   // the "device" is full: reported, nothing leaked
+                CHECK(p && mock.blocks.count(p) && mock.blocks[p] >= want && slot >= -1);
+                for (const Lease &l : mine) CHECK(l.p != p && (slot < 0 || l.slot != slot));   // two live leases never share a block
+                memset(p, 0x5A, Mock::real(want));
+                mine.push_back(Lease{p, slot, want});
+            }
+            CHECK(pool.leased() == static_cast<size_t>(std::count_if(mine.begin(), mine.end(), [](const Lease &l) { return l.slot >= 0; })));
+            for (const Lease &l : mine) {
+                if (l.slot >= 0) pool.give_back(l.slot);
+                else CHECK(mock.release(l.p) == 0);                                     // plain allocation: the caller frees it
+            }
+            CHECK(pool.leased() == 0 && pool.held_bytes() <= budget && pool.slots() <= 64);
+            CHECK(mock.used == pool.held_bytes());
+        }
+        pool.destroy();
+        CHECK(mock.blocks.empty() && mock.allocs == mock.frees);
     }
     printf("BLOCKPOOL_OK\n");
     return 0;

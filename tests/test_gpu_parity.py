@@ -12,6 +12,9 @@ from conftest import GOLDEN, load_golden, unhex
 pytestmark = pytest.mark.gpu
 
 KEY = bytes(range(32))
+# The bit-sliced PRF backends live in a separate library (make -C flashe_amd/csrc bitslice): tests/test_gpu_bitslice.py re-runs the
+# backend-parametrised tests of this file in a process that loads it (FLASHE_LIB_NAME) with this switch on.
+BITSLICE_BACKENDS = [2, 4] if os.environ.get("FLASHE_TEST_BITSLICE") == "1" else []
 
 
 @pytest.fixture(scope="module")
@@ -181,7 +184,7 @@ def test_encrypt_decrypt_vs_oracle(E, oracle, b, n, J):
     assert np.array_equal(eng.mask(it, [9], n, J), oracle.mask(KEY, it, 9, n, J, b))
 
 
-@pytest.mark.parametrize("backend", [2, 4])
+@pytest.mark.parametrize("backend", BITSLICE_BACKENDS)
 @pytest.mark.parametrize("b,n", [(128, 100003), (128, 1024), (128, 1), (128, 2049), (127, 4099), (65, 70001), (100, 1000000)])
 def test_bitsliced_prf_backend_vs_oracle(E, oracle, b, n, backend):
     """The bit-sliced VALU PRF kernels (2: 32 blocks per lane, 4: packed, 16 blocks per lane) must give the
@@ -210,7 +213,7 @@ def test_bitsliced_prf_backend_vs_oracle(E, oracle, b, n, backend):
     assert np.array_equal(eng.encrypt(it, 5, E.SCHEME_DOUBLE, 16, pt), ct)
 
 
-@pytest.mark.parametrize("backend", [1, 2, 4])
+@pytest.mark.parametrize("backend", [1] + BITSLICE_BACKENDS)
 def test_counter_window_across_2_32(E, backend):
     """A launch whose counters straddle 2^32 (and one just below / above it) must take the generic
     first-round path; expected values come from the host AES, element by element."""
@@ -237,6 +240,18 @@ def test_counter_window_across_2_32(E, backend):
             ctr = first + e
             want = int.from_bytes(E.prp_block(KEY, it.to_bytes(4, "big") + idx.to_bytes(4, "big") + ctr.to_bytes(8, "big")), "big")
             assert int(gm[e, 0]) | (int(gm[e, 1]) << 64) == want
+
+
+def test_default_library_has_no_bitsliced_backends(E):
+    """The product library contains what runs: asking it for a bit-sliced backend fails loudly and names the build that has them."""
+    if BITSLICE_BACKENDS:
+        pytest.skip("running against libflashe_hip_bitslice.so")
+    eng = make(E, 128)
+    for backend in (2, 3, 4):
+        with pytest.raises(E.FlasheError, match="make -C flashe_amd/csrc bitslice"):
+            eng.set_prf_backend(backend)
+    eng.set_prf_backend(1)
+    eng.set_prf_backend(0)
 
 
 def test_counter_window_large_launches(E):

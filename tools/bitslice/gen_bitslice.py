@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generates flashe_amd/csrc/aes_bitslice_gen.h: bit-sliced AES-256 round functions as straight-line
+"""Generates flashe_amd/csrc/bitslice/aes_bitslice_gen.h (or the path given as the first argument; not tracked, `make bitslice`
+and tests/test_bitslice_host.py run this generator): bit-sliced AES-256 round functions as straight-line
 v_bitop3_b32 (3-input LUT) code, mapped from the verified Boyar-Peralta S-box circuit plus
 ShiftRows / MixColumns / AddRoundKey expressed on bit planes.
 
@@ -282,7 +283,8 @@ def emit(net, luts, flat_out, fname, S, K):
 
 
 def main():
-    out_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "flashe_amd", "csrc", "aes_bitslice_gen.h")
+    out_path = sys.argv[1] if len(sys.argv) > 1 else \
+        os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "flashe_amd", "csrc", "bitslice", "aes_bitslice_gen.h")
     parts = ["// GENERATED by tools/bitslice/gen_bitslice.py -- do not edit.\n"
              "// Bit-sliced AES-256 round functions on 128 bit planes (plane[8*B + k] = bit k of state byte B,\n"
              "// 32 blocks per 32-bit word), as 3-input LUT (v_bitop3_b32) straight-line code.\n"
