@@ -29,6 +29,17 @@ static int int_to_limbs(PyObject *o, int limbs, uint64_t *out)
         return 0;
     }
     /* beyond int64: the low 64 * limbs bits of the two's complement representation */
+#if PY_VERSION_HEX >= 0x030D0000
+    /* CPython 3.13 changed the private _PyLong_AsByteArray / _PyLong_NumBits signatures and added a public call that does exactly
+     * this: the low 16 bytes of the two's complement value, little endian, whatever the magnitude */
+    {
+        unsigned char nb[16];
+        if (PyLong_AsNativeBytes(o, nb, 16, Py_ASNATIVEBYTES_LITTLE_ENDIAN) < 0) return -1;
+        memcpy(&out[0], nb, 8);
+        if (limbs == 2) memcpy(&out[1], nb + 8, 8);
+        return 0;
+    }
+#else
     unsigned char buf[17];
     size_t nbits = _PyLong_NumBits(o);
     if (nbits == (size_t)-1 && PyErr_Occurred()) return -1;
@@ -50,6 +61,7 @@ static int int_to_limbs(PyObject *o, int limbs, uint64_t *out)
     memcpy(&out[0], buf, 8);
     if (limbs == 2) memcpy(&out[1], buf + 8, 8);
     return 0;
+#endif
 }
 
 /* objs: the data of a 1-D numpy object array (n borrowed references); out: [n][limbs].  0 = ok, -1 = Python error set. */
@@ -62,6 +74,9 @@ int flashe_pyconv_ints_to_limbs(PyObject **objs, Py_ssize_t n, int limbs, uint64
         if (i + 16 < n) __builtin_prefetch(objs[i + 16], 0, 0);
         PyObject *o = objs[i];
         uint64_t *dst = out + (size_t)i * limbs;
+#if PY_VERSION_HEX < 0x030C0000
+        /* (the in-place digit read relies on the PyLongObject layout of CPython <= 3.11: ob_size + ob_digit; 3.12 moved it to
+         * long_value.lv_tag, where the generic path below takes over) */
         if (PyLong_CheckExact(o)) {
             /* one- and two-digit non-negative ints (< 2^60): read the digits in place */
             const Py_ssize_t sz = Py_SIZE(o);
@@ -72,6 +87,7 @@ int flashe_pyconv_ints_to_limbs(PyObject **objs, Py_ssize_t n, int limbs, uint64
                 continue;
             }
         }
+#endif
         if (int_to_limbs(o, limbs, dst) < 0) return -1;
     }
     return 0;
@@ -86,7 +102,11 @@ int flashe_pyconv_limbs_to_ints(const uint64_t *in, Py_ssize_t n, int limbs, PyO
         const uint64_t *p = in + (size_t)i * limbs;
         PyObject *v;
         if (limbs == 1 || p[1] == 0) v = PyLong_FromUnsignedLongLong(p[0]);
+#if PY_VERSION_HEX >= 0x030D0000
+        else v = PyLong_FromUnsignedNativeBytes(p, 16, Py_ASNATIVEBYTES_LITTLE_ENDIAN);
+#else
         else v = _PyLong_FromByteArray((const unsigned char *)p, 16, 1, 0);
+#endif
         if (!v) return -1;
         PyObject *old = objs[i];
         objs[i] = v;

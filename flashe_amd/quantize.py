@@ -122,6 +122,11 @@ class QuantizingClient(object):
     surface).  The arithmetic runs in the HIP kernels; uniforms come from NumPy's global generator exactly as in the reference."""
 
     def __init__(self, int_bits, from_arbiter=None, to_arbiter=None, batch=False, element_bits=16, padding=True, secure=True, device=0):
+        # the reference's other branches: padding=False leaves `ret` unassigned in quantize / unquantize (UnboundLocalError, its
+        # code there is commented out, :466-479, :518-531), secure=False takes the plain-text r_max path this engine does not mirror
+        if padding is False or secure is False:
+            raise NotImplementedError("QuantizingClient mirrors the secure + padding path (jzf_quantize.py:436-465, :509-517); "
+                                      "padding=False / secure=False are not implemented")
         self.int_bits, self.batch, self.element_bits, self.padding, self.secure = int_bits, batch, element_bits, padding, secure
         self.from_arbiter, self.to_arbiter = from_arbiter, to_arbiter
         self.num_clients = None
@@ -219,13 +224,15 @@ class QuantizingClient(object):
         return weights
 
     def unnormalize(self, weights):                                  # :549-564
-        eng = _engine(64, self._device)
         for layer_cnt, k in enumerate(weights.walking_order):
             d, a = self._shift(weights._weights[k], self.past_layer_mean_list[layer_cnt])
-            mean, std = eng.mean_std_dev(a.size, d, a.dtype == np.float64)
-            weights._weights[k] = d.download(a.dtype, a.size).reshape(a.shape)
-            # np.float64 scalars, as np.mean / np.std leave them in the reference: the scalar's type decides the dtype the next
-            # round's `-=` and clip / scale arithmetic run in (_loop_dtype)
-            self.past_layer_mean_list[layer_cnt] = np.float64(mean)
-            self.past_layer_std_list[layer_cnt] = np.float64(std)
+            host = d.download(a.dtype, a.size).reshape(a.shape)
+            weights._weights[k] = host
+            # The statistics the next round's alpha is derived from: np.mean / np.std of the array just produced, on the host, exactly
+            # the calls the reference makes (:558-561) -- same summation order (NumPy's pairwise loops), same scalar type (np.float64,
+            # or np.float32 for a float32 layer, which decides the dtype the next round's `-=` and clip / scale arithmetic run in).
+            # A parallel device reduction (flashe_mean_std_dev) agrees only to ~1e-12, and one ulp of std moves alpha = alpha_opt * std
+            # and with it stochastic-rounding results of later rounds; the layer is on the host at this point anyway.
+            self.past_layer_mean_list[layer_cnt] = np.mean(host)
+            self.past_layer_std_list[layer_cnt] = np.std(host)
         return weights

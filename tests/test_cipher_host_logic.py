@@ -221,3 +221,14 @@ def test_flashe_client_flows_from_reference_fixture(cipher_cls):
                 dec = clients[c].decrypt(agg)
                 assert [int(v) for v in dec] == unhex(rd["dec"][str(c)]), (b, rd["iter"], c, "decrypt")
                 clients[c].prepare_encrypt()
+
+
+def test_quantizing_client_refuses_the_branches_it_does_not_mirror():
+    """padding=False leaves the reference's own quantize() without a result (its code there is commented out) and secure=False is the
+    plain-text path: the mirror says so instead of quantising silently."""
+    from flashe_amd.quantize import QuantizingClient
+    for kw in ({"padding": False}, {"secure": False}):
+        with pytest.raises(NotImplementedError):
+            QuantizingClient(64, **kw)
+    QuantizingClient(64, padding=True, secure=True)
+    QuantizingClient(64, padding=None, secure=None)        # a job file without the keys

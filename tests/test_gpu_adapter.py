@@ -33,8 +33,8 @@ def _arr(hexstr, dtype, shape=None):
 # ------------------------------------------------------------------------------------------------ f-1: orchestration
 def test_quantizing_client_against_reference_fixture():
     """QuantizingClient.normalize -> quantize -> (arbiter) -> unquantize -> unnormalize, two rounds, every intermediate equal to
-    what the reference produced with the same NumPy draws: bit-exact for everything element-wise (floats compared as bytes), and
-    the per-layer mean / std -- a float64 reduction whose summation order differs from NumPy's -- to 1e-10 relative."""
+    what the reference produced with the same NumPy draws: bit-exact for everything, floats compared as bytes / hex -- the
+    per-layer mean / std included (np.mean / np.std of the host array, the reference's own calls)."""
     from flashe_amd.quantize import QuantizingClient
     g = load_golden("quantclient.json")
     assert len(g["clients"]) == 4
@@ -86,10 +86,9 @@ def test_quantizing_client_against_reference_fixture():
             w2 = qc.unnormalize(w2)
             for k in w2.walking_order:
                 assert np.asarray(w2._weights[k], dtype=np.float64).tobytes() == bytes.fromhex(rd["unnormalized"][k]), (rd_i, k, "unnormalize")
-            for got, want in zip(qc.past_layer_mean_list, rd["new_mean"]):
-                assert got == pytest.approx(float.fromhex(want), rel=1e-10, abs=1e-13)
-            for got, want in zip(qc.past_layer_std_list, rd["new_std"]):
-                assert got == pytest.approx(float.fromhex(want), rel=1e-10, abs=1e-13)
+            assert [float(v).hex() for v in qc.past_layer_mean_list] == rd["new_mean"], (rd_i, "mean")
+            assert [float(v).hex() for v in qc.past_layer_std_list] == rd["new_std"], (rd_i, "std")
+            assert all(isinstance(v, np.floating) for v in qc.past_layer_mean_list + qc.past_layer_std_list)
             del seed_state
 
 
