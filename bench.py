@@ -673,6 +673,17 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
         hp = [host_pts[c] for c in mine]
         if cfg == 2 and not args.no_unchained and args.schedule in ("default", "sequential"):
             line.update(unchained_round(args, n, b, J, mine, total, pts, K))
+            # the partial-agg form of the same round (--schedule partial-agg makes it the timed one), beside `value`: parity first
+            res = rnd.run(0, pts, 1, partial_agg=True)
+            if not parity_ok(res):
+                raise SystemExit("PARITY FAILURE: partial-agg round")
+            for it in range(12):
+                rnd.run(it, pts, 1, partial_agg=True)
+            s_pa = timed_region(ops, K, lambda k: rnd.run(k, pts, 1, partial_agg=True))
+            line.update({"ms_per_step_partial_agg": s_pa * 1e3 / K, "value_partial_agg": total * n / (s_pa / K),
+                         "partial_agg_note": "the same round with the encrypt launch also writing the local partial aggregate (sum of its C "
+                                             "ciphertexts, SURVEY.md section 5), so that the second launch decrypts one vector instead of "
+                                             "re-reading C: --schedule partial-agg times it as `value`; measured here outside the timed region"})
         if not args.no_e2e:
             line["e2e_ms_incl_pcie"], line["e2e_first_round_ms"] = e2e_round_ms(eng, hp, n, b, J)
             line["e2e_note"] = ("one round through the host-pointer twins (flashe_encrypt x C, flashe_aggregate_elem, flashe_decrypt): pageable "

@@ -5,11 +5,13 @@ OUT=$REPO/gpurun_out/bench_configs.jsonl
 mkdir -p "$REPO/gpurun_out"; : > "$OUT"
 run() { echo "# bench.py $*" >> "$OUT"; timeout 600 python "$REPO/bench.py" "$@" < /dev/null 2>/dev/null | grep '^{' >> "$OUT"; }
 run
+run --schedule partial-agg --no-cpu-baseline --no-e2e
 run --schedule auto --no-cpu-baseline --no-e2e
 FLASHE_RCCL_SELF_SENDRECV=1 run --force-dist --no-cpu-baseline --no-e2e
 run --config 3 --no-cpu-baseline
 run --config 3 --bits 23 --no-cpu-baseline
 run --config 4 --no-cpu-baseline
+run --config 4 --schedule partial-agg --no-cpu-baseline
 run --config 5 --no-cpu-baseline
 run --bits 64 --no-cpu-baseline --no-e2e
 run --bits 20 --no-cpu-baseline --no-e2e
