@@ -1386,8 +1386,13 @@ __device__ __forceinline__ void small_direct(bool valid, int cnt, uint64_t j0, u
         u64x2 pt = {0ull, 0ull};
         if (in) pt = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + k));
         u64x2 r;
-        r[0] = (pt[0] + static_cast<uint64_t>(D)) & p.mask_lo;
-        r[1] = (pt[1] + static_cast<uint64_t>(D >> p.b)) & p.mask_lo;
+        if (p.b == 64) {            // the two slots are the two halves: no variable 128-bit shift, no mask
+            r[0] = pt[0] + static_cast<uint64_t>(D);
+            r[1] = pt[1] + static_cast<uint64_t>(D >> 64);
+        } else {
+            r[0] = (pt[0] + static_cast<uint64_t>(D)) & p.mask_lo;
+            r[1] = (pt[1] + static_cast<uint64_t>(D >> p.b)) & p.mask_lo;
+        }
         __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(out + k));
         return;
     }
@@ -1420,6 +1425,18 @@ __device__ __forceinline__ void small_direct(bool valid, int cnt, uint64_t j0, u
 #pragma unroll
     for (int t = 0; t < 4; t++)
         if (ok[t]) __builtin_nontemporal_store((pt[t] + static_cast<uint64_t>(D >> (p.b * t))) & p.mask_lo, out + (j0 + t - first));
+}
+
+// per b-bit slot (prev - cur) mod 2^b of two 128-bit words (SWAR: borrows must not cross slots); b == 64: the slots are the two
+// halves and two plain 64-bit subtractions do it (-2 % on ten 1e7-element vectors: the output arithmetic, not the lookup count,
+// is what separates this kernel from the wide one -- tests/perf/experiments/r03_small_win_kernel.patch)
+__device__ __forceinline__ u128 slot_diff(u128 prev, u128 cur, u128 top, int b)
+{
+    if (b == 64) {
+        const uint64_t lo = static_cast<uint64_t>(prev) - static_cast<uint64_t>(cur), hi = static_cast<uint64_t>(prev >> 64) - static_cast<uint64_t>(cur >> 64);
+        return (static_cast<u128>(hi) << 64) | lo;
+    }
+    return ((prev | top) - (cur & ~top)) ^ ((prev ^ ~cur) & top);
 }
 
 template <bool PAIR>
@@ -1527,8 +1544,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                     const uint64_t *in = tb.in[link0 + link];
                     uint64_t *out = tb.out[link0 + link];
                     // per slot (previous - current) mod 2^b: the previous stream is this client's add stream, the current its minus stream
-                    const u128 DA = single ? SA : ((prevA | top) - (SA & ~top)) ^ ((prevA ^ ~SA) & top);
-                    const u128 DB = single ? SB : ((prevB | top) - (SB & ~top)) ^ ((prevB ^ ~SB) & top);
+                    const u128 DA = single ? SA : slot_diff(prevA, SA, top, p.b);
+                    const u128 DB = single ? SB : slot_diff(prevB, SB, top, p.b);
                     if (direct) {
                         small_direct(vA, cntA, j0A, DA, in, out, first, range_end, p);
                         small_direct(vB, cntB, j0B, DB, in, out, first, range_end, p);
@@ -1557,13 +1574,13 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 aes256_rounds<2, 2>(rk, lr, s);
                 const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
                 if (l0 >= 0) {
-                    const u128 D = single ? S0 : ((prevA | top) - (S0 & ~top)) ^ ((prevA ^ ~S0) & top);
+                    const u128 D = single ? S0 : slot_diff(prevA, S0, top, p.b);
                     if (direct) small_direct(vA, cntA, j0A, D, tb.in[link0 + l0], tb.out[link0 + l0], first, range_end, p);
                     else if (fastA) small_walk32(row0, lane, e0A, D, pt0, tb.in[link0 + l0], tb.out[link0 + l0], first, p, wblk0, wo0);
                     else small_walk(row0, lane, vA, cntA, j0A, D, tb.in[link0 + l0], tb.out[link0 + l0], first, range_end, p);
                 }
                 if (has1) {
-                    const u128 D = single ? S1 : ((S0 | top) - (S1 & ~top)) ^ ((S0 ^ ~S1) & top);
+                    const u128 D = single ? S1 : slot_diff(S0, S1, top, p.b);
                     if (direct) small_direct(vA, cntA, j0A, D, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, range_end, p);
                     else if (fastA) small_walk32(row0, lane, e0A, D, pt1, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, p, wblk0, wo0);
                     else small_walk(row0, lane, vA, cntA, j0A, D, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, range_end, p);
