@@ -669,6 +669,20 @@ class Engine:
     def unbatch_dev(self, n_batches, inp, field_bits, out):
         self._check(self._lib.flashe_unbatch_dev(self._h, n_batches, self._ptr(inp), field_bits, self._ptr(out)))
 
+    def numpy_random_dev(self, n, out=None):
+        """np.random.random(n) generated on the device, bit for bit, from NumPy's GLOBAL legacy generator: its MT19937 state is read,
+        advanced on the device and put back, so host draws before and after continue one stream.  Returns the DeviceBuffer of n
+        float64 (`out` or a new one).  Raises if the global generator is not MT19937."""
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            raise FlasheError(-22, f"np.random's bit generator is {st[0]}, not MT19937")
+        key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        pos = c_u32(int(st[2]))
+        out = out if out is not None else self.alloc(max(8 * int(n), 16))
+        self._check(self._lib.flashe_mt19937_random_dev(self._h, key.ctypes.data_as(c_u32p), ctypes.byref(pos), int(n), self._ptr(out)))
+        np.random.set_state((st[0], key, int(pos.value), st[3], st[4]))
+        return out
+
     def quantize_encrypt_dev(self, it, idx, scheme, n, n_jobs, x, x_is_f64, alpha, element_bits, u, ct):
         """ct = encrypt(quantize(x)) in one launch (un-batched values); x float32 / float64, u float64 uniforms, all device-resident."""
         self._check(self._lib.flashe_quantize_encrypt_dev(self._h, it, idx, scheme, n, n_jobs, self._ptr(x), 1 if x_is_f64 else 0,

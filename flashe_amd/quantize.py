@@ -5,11 +5,18 @@ QuantizingClient (quantize / unquantize / normalize / unnormalize, jzf_quantize.
 arguments and results.
 
 Stochastic rounding: the reference draws its uniforms with ``np.random.random(size)`` (numpy's
-global legacy generator).  The mirror makes the *same* host-side draw and ships the numbers to the
-kernel, so with the same seed the quantised integers are bit-identical; pass ``uniforms=`` to
-supply the draws yourself.
+global legacy generator).  The mirror consumes the *same* stream, so with the same seed the quantised
+integers are bit-identical: small layers draw on the host and ship the numbers, layers of at least
+DEVICE_RNG_MIN elements generate them ON THE DEVICE from NumPy's own MT19937 state
+(`flashe_mt19937_random_dev`: the state is read, advanced on the device exactly as NumPy would advance
+it, and put back -- host draws before and after continue one stream; FLASHE_DEVICE_RNG=0 turns it
+off).  Pass ``uniforms=`` to supply the draws yourself.
 """
+import os
+
 import numpy as np
+
+DEVICE_RNG_MIN = 1 << 16
 
 from .engine import Engine
 
@@ -31,8 +38,21 @@ def _static_quantize_padding_asymmetric(value, alpha, int_bits, uniforms=None, d
     """jzf_quantize.py:55-67."""
     value = np.asarray(value)
     shape = value.shape
-    u = np.random.random(shape) if uniforms is None else np.asarray(uniforms, dtype=np.float64)
-    q = _engine(64, device).quantize(value.reshape(-1), alpha, int_bits, u.reshape(-1)).reshape(shape)
+    eng = _engine(64, device)
+    n = int(value.size)
+    if (uniforms is None and n >= DEVICE_RNG_MIN and os.environ.get("FLASHE_DEVICE_RNG", "1") != "0"
+            and hasattr(eng, "numpy_random_dev") and np.random.get_state()[0] == "MT19937"):
+        # np.random.random(shape) generated where it is consumed: no host loop over n draws, no 8 B / element upload
+        x = np.ascontiguousarray(value).reshape(-1)
+        if x.dtype not in (np.float32, np.float64):
+            x = x.astype(np.float64)
+        dx, dq = eng.upload(x), eng.alloc(8 * n)
+        du = eng.numpy_random_dev(n)
+        eng.quantize_dev(n, dx, x.dtype == np.float64, alpha, int_bits, du, dq)
+        q = dq.download(np.uint64, n).reshape(shape)
+    else:
+        u = np.random.random(shape) if uniforms is None else np.asarray(uniforms, dtype=np.float64)
+        q = eng.quantize(value.reshape(-1), alpha, int_bits, u.reshape(-1)).reshape(shape)
     return _as_object(q) if as_object else q
 
 

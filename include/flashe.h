@@ -361,6 +361,15 @@ int flashe_decrypt_unquantize_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t
 int flashe_shift_dev(flashe_ctx *ctx, uint64_t n, void *x_dev, int x_is_f64, double shift, int wide);
 int flashe_mean_std_dev(flashe_ctx *ctx, uint64_t n, const void *x_dev, int x_is_f64, double *mean, double *stddev);
 
+/* np.random.random(n) ON THE DEVICE, bit for bit (new): the stochastic-rounding draws of _static_quantize_padding_asymmetric
+ * (jzf_quantize.py:61, `np.random.random(value.shape)`) come from NumPy's global MT19937 generator; this writes the same n doubles
+ * to u_dev -- mt19937_next_double: a = next >> 5, b = next >> 6, (a * 2^26 + b) / 2^53 -- from the generator state the caller hands
+ * in (key[624] and pos exactly as np.random.get_state() returns them, HOST memory) and advances that state in place as NumPy would,
+ * so that the caller can put it back (np.random.set_state) and host draws continue the same stream.  One workgroup walks the
+ * stream (the recurrence is sequential across 624-word blocks): ~1 ns per double, 5x a host core, and no 8 B/element upload.
+ * Synchronous. */
+int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uint32_t *pos, uint64_t n, double *u_dev);
+
 /* _static_quantize_padding_asymmetric -- federatedml/secureprotol/jzf_quantize.py:55-67:
  * q = floor(clip(x, -alpha, alpha) + alpha) * (2^element_bits - 1) / (2 alpha) + u), with numpy's
  * dtype rules (x_is_f64 == 0: x is float32 and every step before "+ u" is a float32 operation).

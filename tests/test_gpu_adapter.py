@@ -218,3 +218,42 @@ def test_flashe_client_on_the_device_against_reference_fixture():
         clients[0].set_idx_list(list(range(C)))
         dec = clients[0].decrypt(agg)
         assert [int(v) for v in dec] == unhex(case["dec"]), b
+
+
+@pytest.mark.parametrize("seed,pos,n", [(1, None, 1), (2, None, 311), (3, None, 312), (4, None, 313), (5, 0, 1000), (6, 1, 1000), (7, 623, 5), (8, 624, 700),
+                                        (9, 17, 100_003), (10, None, 2_000_001)])
+def test_numpy_random_on_the_device_is_numpy_bit_for_bit(seed, pos, n):
+    """flashe_mt19937_random_dev: np.random.random(n) generated on the device from NumPy's own MT19937 state -- the same doubles, and the
+    same generator state afterwards, as the host call; odd positions (pairs straddling the 624-word blocks), the position-624 state a
+    fresh twist leaves, one draw, exactly one block, a million."""
+    from flashe_amd.engine import Engine
+    eng = Engine(KEY, 64, device=0)
+    np.random.seed(seed)
+    if pos is not None:
+        st = np.random.get_state()
+        np.random.set_state((st[0], st[1], pos, st[3], st[4]))
+    st0 = np.random.get_state()
+    want = np.random.random(n)
+    st_want = np.random.get_state()
+    follow_want = np.random.random(7)
+    np.random.set_state(st0)
+    got = eng.numpy_random_dev(n).download(np.float64, n)
+    assert got.tobytes() == want.tobytes()
+    st_got = np.random.get_state()
+    assert st_got[2] == st_want[2] and np.array_equal(st_got[1], st_want[1])
+    assert np.random.random(7).tobytes() == follow_want.tobytes()          # host draws continue the stream
+
+
+def test_quantize_with_device_draws_equals_host_draws(monkeypatch):
+    """_static_quantize_padding_asymmetric on a layer large enough for the device RNG: the same integers as with host draws from the
+    same seed, and the global generator left in the same state."""
+    from flashe_amd import quantize as qz
+    for dt in (np.float32, np.float64):
+        x = np.random.Generator(np.random.PCG64(5)).standard_normal(200_003).astype(dt)
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("FLASHE_DEVICE_RNG", flag)
+            np.random.seed(99)
+            np.random.random(3)                                             # an odd position in the stream
+            res[flag] = (qz._static_quantize_padding_asymmetric(x, 2.5, 16, as_object=False), np.random.random(2))
+        assert np.array_equal(res["1"][0], res["0"][0]) and res["1"][1].tobytes() == res["0"][1].tobytes(), dt
