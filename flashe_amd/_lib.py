@@ -114,6 +114,7 @@ _SIGNATURES = {
     "flashe_sparse_decrypt_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_int, c_vp, c_vp]),
     "flashe_sparse_minus_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
     "flashe_sparse_minus_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp]),
+    "flashe_sparse_double_masks_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_vp, c_vp]),
     "flashe_sparse_dense_mask_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_sparse_dense_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_quantize_encrypt_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),

@@ -274,21 +274,16 @@ class FlasheCipher(object):
                 # crashes for N_JOBS > 1 -- see DESIGN.md)
                 eng = self._engine
                 total = self.total
-                one_hots = []
-                for m in self.masks:
-                    a = np.zeros(total, dtype=np.uint8)
-                    a[np.asarray(m, dtype=np.int64)] = 1
-                    one_hots.append(a)
-                num_clients = len(self.masks)
-                minus, add = [], [np.zeros(total, dtype=np.uint8)]
-                for c in range(num_clients):
-                    minus.append(one_hots[c] & (1 - one_hots[c - 1]) if c > 0 else one_hots[c])
-                    add.append(one_hots[c] & (1 - one_hots[c + 1]) if c < num_clients - 1 else one_hots[c])
+                # the run analysis works on SETS of positions (one-hot vectors in the reference): sorted, duplicates dropped
+                locs = [np.unique(np.asarray(m, dtype=np.int64)) for m in self.masks]
+                for l in locs:
+                    if len(l) and (int(l[-1]) >= total or int(l[0]) < -total):
+                        raise IndexError(f"index {int(l[-1]) if int(l[-1]) >= total else int(l[0])} is out of bounds for axis 0 with size {total}")
+                locs = [np.unique(np.where(l < 0, l + total, l)).astype(np.uint32) for l in locs]         # (negative indices wrap, as in NumPy)
                 va, vm = _DevVec(eng, total), _DevVec(eng, total)
-                da = [eng.upload(a) for a in add]
-                dm = [eng.upload(m) for m in minus]
-                eng.sparse_dense_mask_dev(self.iter_index, da, total, va.buf)
-                eng.sparse_dense_mask_dev(self.iter_index, dm, total, vm.buf)
+                dloc = [eng.upload(l) for l in locs]
+                # every list entry looks its position up in the neighbouring clients' lists on the device; no one-hot vectors
+                eng.sparse_double_masks_dev(self.iter_index, dloc, [len(l) for l in locs], total, va.buf, vm.buf)
                 eng.sync()
                 self.next_iter_decrypt_prepared['add'] = va
                 self.next_iter_decrypt_prepared['minus'] = vm

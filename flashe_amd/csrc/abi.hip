@@ -1308,6 +1308,57 @@ int flashe_sparse_decrypt_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint3
     return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, sorted != 0, agg_dev, out_dev);
 }
 
+int flashe_sparse_double_masks_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total,
+                                   uint64_t *add_out_dev, uint64_t *minus_out_dev)
+{
+    CHECK_CTX(ctx);
+    if (C < 0 || (C && (!loc_dev || !k)) || (total && (!add_out_dev || !minus_out_dev)) || add_out_dev == minus_out_dev)
+        return fail(ctx, FLASHE_EINVAL, "flashe_sparse_double_masks_dev: bad arguments");
+    if (ctx->limbs == 2 && (!aligned16(add_out_dev) || !aligned16(minus_out_dev))) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    if (total >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "total must be below 2^32 (32-bit locations)");
+    uint64_t kmax = 0;
+    for (int c = 0; c < C; c++) {
+        if (k[c] > total) return fail(ctx, FLASHE_EINVAL, "client %d: more locations (%llu) than positions (%llu)", c,
+                                      static_cast<unsigned long long>(k[c]), static_cast<unsigned long long>(total));
+        if (k[c] && !loc_dev[c]) return fail(ctx, FLASHE_EINVAL, "client %d: null location list", c);
+        kmax = std::max(kmax, k[c]);
+    }
+    if (total == 0) return FLASHE_OK;
+    if (C == 0 || kmax == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(add_out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
+        HIP_TRY(ctx, hipMemsetAsync(minus_out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
+        return FLASHE_OK;
+    }
+    const uint64_t kpad = (kmax + 1) & ~1ull;
+    const int group = std::min(C, kMaxScatter);
+    int rc = ensure(ctx, ctx->stream_tmp, 2 * vec_bytes(ctx, kpad) * static_cast<size_t>(group));
+    if (rc) return rc;
+    if ((rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(group) * sizeof(uint32_t)))) return rc;
+    uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
+    const uint64_t stride = kpad * static_cast<uint64_t>(ctx->limbs);
+    for (int c0 = 0; c0 < C; c0 += group) {
+        const int nc = std::min(group, C - c0);
+        const uint32_t *locs[kMaxScatter + 2];
+        uint64_t ks[kMaxScatter + 2];
+        uint64_t *va[kMaxScatter], *vm[kMaxScatter];
+        for (int e = -1; e <= nc; e++) {
+            const int c = c0 + e;
+            const bool there = c >= 0 && c < C && k[c];
+            locs[e + 1] = there ? loc_dev[c] : nullptr;
+            ks[e + 1] = there ? k[c] : 0;
+        }
+        for (int e = 0; e < nc; e++) { va[e] = tmp + stride * static_cast<uint64_t>(2 * e); vm[e] = tmp + stride * static_cast<uint64_t>(2 * e + 1); }
+        HIP_TRY(ctx, launch_sparse_edge_prf(ctx->env, iter, nc, static_cast<uint32_t>(c0), locs, ks, va, vm));
+        // the compact values go to their dense positions through the span reduce (it also validates the lists: a position >= total or a
+        // list that is not strictly increasing is skipped and reported by the next synchronising call)
+        HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, va, k + c0, nullptr, 0, 0, total, static_cast<uint32_t *>(ctx->bounds.p),
+                                        c0 ? add_out_dev : nullptr, false, add_out_dev));
+        HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, vm, k + c0, nullptr, 0, 0, total, static_cast<uint32_t *>(ctx->bounds.p),
+                                        c0 ? minus_out_dev : nullptr, false, minus_out_dev));
+    }
+    return FLASHE_OK;
+}
+
 int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel_dev, uint64_t total,
                                  uint64_t *out_dev)
 {

@@ -151,6 +151,12 @@ uint64_t span_count(uint64_t total);
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
                               uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev);
+// Sparse + double mask (jzf_flashe.py:388-426, :155-225): compact (add, minus) mask values of a group of nc <= kMaxScatter clients
+// c0 .. c0 + nc - 1 at their own sorted locations -- entry q of client c gets term(c + 1, p) unless client c + 1 holds p, and
+// term(c, p) unless client c - 1 holds p (dense-position counters, one chunk).  loc / k carry nc + 2 entries: the group's lists
+// framed by the neighbouring clients' (null / 0 where there is none).
+hipError_t launch_sparse_edge_prf(const LaunchEnv &env, uint32_t iter, int nc, uint32_t c0, const uint32_t *const *loc_with_neighbours,
+                                  const uint64_t *k_with_neighbours, uint64_t *const *va_dev, uint64_t *const *vm_dev);
 // out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
 hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uint8_t *sel_dev,
                                  const uint64_t *stream_dev, uint64_t *out_dev);

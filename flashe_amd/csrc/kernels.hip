@@ -2832,6 +2832,81 @@ hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const
     return hipGetLastError();
 }
 
+// ---- sparse + double mask: the masks of the run EDGES, computed only where they are needed -------------------------------------
+// set_idx_list's sparse branch of the double mask (jzf_flashe.py:388-426) runs a per-position analysis of the clients' one-hot
+// location vectors: position p of client c needs term(c + 1, p) on the ADD side unless client c + 1 holds p too (the masks of
+// neighbouring clients telescope), and term(c, p) on the MINUS side unless client c - 1 holds p -- _static_prepare_decrypt_spar
+// (:155-225) then evaluates the PRF at exactly the selected dense positions (a block without a selected slot costs no AES).  Here
+// the work items are the clients' own list entries: entry q of client c looks its position up in the two neighbouring (sorted)
+// lists and computes at most two AES blocks with the counter of the DENSE position (one chunk, begin = 0: counter = p / m, slot
+// p % m), writing compact (add, minus) values that the span reduce then scatters -- sum_c k_c block pairs instead of
+// (C + 1) x total blocks and no per-list one-hot of `total` bytes.
+struct EdgeTable {
+    const uint32_t *loc[kMaxScatter + 2];     // entry e + 1 = client c0 + e; entries 0 and nc + 1 = the neighbours outside the group (or null)
+    uint64_t k[kMaxScatter + 2];
+    uint64_t *va[kMaxScatter], *vm[kMaxScatter];
+    uint64_t end[kMaxScatter];                // running total of the group's entries
+};
+
+__device__ __forceinline__ bool sorted_contains(const uint32_t *__restrict__ a, uint64_t n, uint32_t x)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && a[lo] == x;
+}
+
+__global__ __launch_bounds__(kPrfThreads) void sparse_edge_prf_kernel(const RoundKeys rk, const EdgeTable tb, int nc, uint32_t c0, uint32_t iter0, int b,
+                                                                      uint64_t mask_lo, uint64_t mask_hi, const uint32_t *__restrict__ te0)
+{
+    const uint32_t iter = iter0 + te0[kIterShiftWord];
+    __shared__ uint32_t tab[kTabWords];
+    fill_tables(tab, te0);
+    const LaneRegs lr = lane_regs(tab);
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const uint32_t m = b > 64 ? 1u : 128u / static_cast<uint32_t>(b);
+    const uint64_t n_items = tb.end[nc - 1];
+    for (uint64_t f = static_cast<uint64_t>(blockIdx.x) * kPrfThreads + threadIdx.x; f < n_items; f += static_cast<uint64_t>(gridDim.x) * kPrfThreads) {
+        int e = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (e + step < nc && tb.end[e + step - 1] <= f) e += step;
+        const uint64_t q = f - (e ? tb.end[e - 1] : 0);
+        const uint32_t p = tb.loc[e + 1][q];
+        const bool in_prev = tb.loc[e] && sorted_contains(tb.loc[e], tb.k[e], p);
+        const bool in_next = tb.loc[e + 2] && sorted_contains(tb.loc[e + 2], tb.k[e + 2], p);
+        const uint32_t c = c0 + static_cast<uint32_t>(e);
+        const uint64_t ctr = p / m;
+        uint32_t s[2][4];
+        set_block(s[0], iter, c + 1u, ctr);            // add side: list (prefix) c + 1
+        set_block(s[1], iter, c, ctr);                 // minus side: list c
+        aes256_encrypt<2>(rk, lr, s);
+        const int sh = static_cast<int>(static_cast<uint32_t>(b) * (p - static_cast<uint32_t>(ctr) * m));
+        const u128 A = in_next ? static_cast<u128>(0) : (words_to_u128(s[0]) >> sh) & mask;
+        const u128 M = in_prev ? static_cast<u128>(0) : (words_to_u128(s[1]) >> sh) & mask;
+        if (b > 64) { st128(tb.va[e] + 2 * q, A); st128(tb.vm[e] + 2 * q, M); }
+        else { tb.va[e][q] = static_cast<uint64_t>(A); tb.vm[e][q] = static_cast<uint64_t>(M); }
+    }
+}
+
+hipError_t launch_sparse_edge_prf(const LaunchEnv &env, uint32_t iter, int nc, uint32_t c0, const uint32_t *const *loc_with_neighbours,
+                                  const uint64_t *k_with_neighbours, uint64_t *const *va_dev, uint64_t *const *vm_dev)
+{
+    if (nc < 1 || nc > kMaxScatter) return hipErrorInvalidValue;
+    EdgeTable tb{};
+    uint64_t total = 0;
+    for (int e = 0; e < nc + 2; e++) { tb.loc[e] = loc_with_neighbours[e]; tb.k[e] = k_with_neighbours[e]; }
+    for (int e = 0; e < nc; e++) { tb.va[e] = va_dev[e]; tb.vm[e] = vm_dev[e]; total += tb.k[e + 1]; tb.end[e] = total; }
+    if (total == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    hipLaunchKernelGGL(sparse_edge_prf_kernel, dim3(grid_for(env, total, kPrfThreads)), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc, c0, iter, env.b, lo,
+                       hi, env.te0_dev);
+    return hipGetLastError();
+}
+
 // out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
 __global__ __launch_bounds__(kStreamThreads) void sel_accumulate_kernel(uint64_t n, int L, const uint8_t *sel, const uint64_t *stream,
                                                                         uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)

@@ -543,6 +543,14 @@ class Engine:
         self._check(self._lib.flashe_sparse_decrypt_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs,
                                                         1 if sorted_lists else 0, self._ptr(agg), self._ptr(out)))
 
+    def sparse_double_masks_dev(self, it, locs, ks, total, add_out, minus_out):
+        """Both dense masks of the sparse + double decrypt (set_idx_list's run analysis + _static_prepare_decrypt_spar) straight from
+        the clients' strictly increasing location lists."""
+        p, _keep = self._ptr_array(locs)
+        k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        self._check(self._lib.flashe_sparse_double_masks_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total,
+                                                             self._ptr(add_out), self._ptr(minus_out)))
+
     def sparse_dense_mask_dev(self, it, sels, total, out):
         p, _keep = self._ptr_array(sels)
         self._check(self._lib.flashe_sparse_dense_mask_dev(self._h, it, len(sels), p, total, self._ptr(out)))

@@ -335,6 +335,16 @@ int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32
 /* Dense-position selected masks -- _static_prepare_decrypt_spar as ONE chunk
  * (jzf_flashe.py:155-225, begin = 0): out[p] = sum_i sel[i][p] * term(iter, i, p) mod 2^b,
  * sel[i] a 0/1 byte vector of length total.  sel is a HOST array of n_lists pointers. */
+/* The sparse branch of set_idx_list for the DOUBLE mask as one operation (new) -- jzf_flashe.py:388-426 (per-position run analysis of
+ * the clients' one-hot location vectors) + _static_prepare_decrypt_spar (:155-225, dense-position counters, one chunk, begin = 0):
+ *   add_out[p]   = sum over clients c that hold p while client c + 1 does not (or c is the last) of term(iter, c + 1, p)
+ *   minus_out[p] = sum over clients c that hold p while client c - 1 does not (or c is the first) of term(iter, c, p)      (mod 2^b)
+ * straight from the clients' STRICTLY INCREASING location lists (what Client.sparsify emits): every list entry looks its position up
+ * in the two neighbouring lists and computes at most two AES blocks, the span reduce scatters the compact values -- sum_c k_c block
+ * pairs instead of (C + 1) x total blocks, no one-hot vectors of `total` bytes per list (the reference itself skips blocks without a
+ * selected slot, :170, :201).  loc is a HOST array of C device pointers, k a HOST array; add_out / minus_out: total x L limbs each. */
+int flashe_sparse_double_masks_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                   uint64_t total, uint64_t *add_out_dev, uint64_t *minus_out_dev);
 int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel_dev,
                                  uint64_t total, uint64_t *out_dev);
 int flashe_sparse_dense_mask(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel,

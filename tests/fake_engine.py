@@ -89,5 +89,18 @@ class OracleEngine:
     def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out):
         out.arr = orc.sparse_minus_mask(self.key, it, [l.arr for l in locs], total, n_jobs, self.int_bits)
 
+    def sparse_double_masks_dev(self, it, locs, ks, total, add_out, minus_out):
+        # the reference's own formulation: one-hot vectors, run analysis (jzf_flashe.py:388-407), dense-position masks
+        ohs = []
+        for l in locs:
+            a = np.zeros(total, dtype=np.uint8)
+            a[np.asarray(l.arr, dtype=np.int64)] = 1
+            ohs.append(a)
+        C = len(ohs)
+        minus = [ohs[c] & (1 - ohs[c - 1]) if c > 0 else ohs[c] for c in range(C)]
+        add = [np.zeros(total, dtype=np.uint8)] + [ohs[c] & (1 - ohs[c + 1]) if c < C - 1 else ohs[c] for c in range(C)]
+        add_out.arr = orc.sparse_dense_mask(self.key, it, add, total, self.int_bits)
+        minus_out.arr = orc.sparse_dense_mask(self.key, it, minus, total, self.int_bits)
+
     def sparse_dense_mask_dev(self, it, sels, total, out):
         out.arr = orc.sparse_dense_mask(self.key, it, [s.arr for s in sels], total, self.int_bits)

@@ -1271,3 +1271,51 @@ def test_device_block_cache_reuse_is_safe_across_streams(E, oracle):
     d3 = a.alloc_vec(n)                                             # still works after a trim
     a.combine_dev(n, dx, 2, None, None, d3)
     assert np.array_equal(d3.download(np.uint64, 2 * n).reshape(n, 2), x)
+
+
+@pytest.mark.parametrize("b,total,C,frac", [(128, 20_011, 5, 0.2), (64, 30_001, 4, 0.3), (20, 9_999, 7, 0.5), (128, 300_007, 70, 0.02), (7, 5000, 3, 0.9),
+                                             (128, 1000, 1, 0.1), (100, 4096, 3, 1.0)])
+def test_sparse_double_masks_from_location_lists(E, oracle, b, total, C, frac):
+    """flashe_sparse_double_masks_dev (the sparse branch of set_idx_list for the double mask: run analysis + dense-position masks,
+    jzf_flashe.py:388-426, :155-225) straight from the clients' sorted location lists, against the reference's own formulation --
+    one-hot vectors, per-position run analysis on the host, _static_prepare_decrypt_spar through the oracle -- and against the
+    selector-based entry point.  Neighbouring clients share many positions (their masks cancel there), one list is empty, one full;
+    more clients than one launch group holds (70 > 64)."""
+    eng = make(E, b)
+    Lb = L(b)
+    rng = np.random.Generator(np.random.PCG64(total + C))
+    base = np.sort(rng.choice(total, max(1, int(total * frac)), replace=False))
+    locs = []
+    for c in range(C):
+        keep = base[rng.random(len(base)) < 0.7]                               # heavy overlap between neighbours
+        extra = rng.choice(total, max(1, len(base) // 10), replace=False)
+        locs.append(np.unique(np.concatenate([keep, extra])).astype(np.uint32))
+    if C >= 4:
+        locs[2] = np.zeros(0, dtype=np.uint32)                                 # a client that uploaded nothing
+    if frac == 1.0:
+        locs[1] = np.arange(total, dtype=np.uint32)
+    ohs = []
+    for l in locs:
+        a = np.zeros(total, dtype=np.uint8)
+        a[l] = 1
+        ohs.append(a)
+    minus = [ohs[c] & (1 - ohs[c - 1]) if c > 0 else ohs[c] for c in range(C)]
+    add = [np.zeros(total, dtype=np.uint8)] + [ohs[c] & (1 - ohs[c + 1]) if c < C - 1 else ohs[c] for c in range(C)]
+    want_add, want_minus = oracle.sparse_dense_mask(KEY, 11, add, total, b), oracle.sparse_dense_mask(KEY, 11, minus, total, b)
+    dloc = [eng.upload(l) if len(l) else eng.alloc(16) for l in locs]
+    da, dm = eng.alloc_vec(total), eng.alloc_vec(total)
+    eng._check(eng._lib.flashe_memset_dev(eng._h, da.ptr, 0x5A, da.nbytes))
+    eng.sparse_double_masks_dev(11, dloc, [len(l) for l in locs], total, da, dm)
+    assert np.array_equal(da.download(np.uint64, total * Lb).reshape(total, Lb), want_add), (b, total, "add")
+    assert np.array_equal(dm.download(np.uint64, total * Lb).reshape(total, Lb), want_minus), (b, total, "minus")
+    if C <= 7:
+        assert np.array_equal(eng.sparse_dense_mask(11, add, total), want_add)        # the selector-based entry point agrees
+    # a list that is not strictly increasing is reported, nothing is written out of bounds
+    if C >= 2 and len(locs[0]) > 3:
+        bad = locs[0].copy()
+        bad[1], bad[2] = bad[2], bad[1]
+        dloc[0] = eng.upload(bad)
+        eng.sparse_double_masks_dev(11, dloc, [len(l) for l in locs], total, da, dm)
+        with pytest.raises(E.FlasheError):
+            eng.sync()
+            da.download(np.uint64, 2)
