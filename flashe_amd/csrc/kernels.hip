@@ -500,8 +500,8 @@ struct UniformJobTable {
 };
 constexpr int kBigEpl = 4;
 
-// KIND 0 / 1 only name the instantiation (one job / several jobs per launch), so that profiles list the batched
-// launches and the single-vector / chunk launches as separate kernels; KIND 2 additionally compiles the summed
+// KIND 0 / 1 / 3 only name the instantiation (one job / several jobs per launch / a lone latency-bound job in 256-thread
+// workgroups), so that profiles list them as separate kernels; KIND 2 additionally compiles the summed
 // input (reduce fused in): its operands are loaded before the AES rounds and added after them, so their HBM
 // latency hides under the lookups of the same element.
 constexpr int kSumRegs = 10;            // operands held in registers across the rounds (more are added up front)
@@ -1853,9 +1853,21 @@ static hipError_t launch_prf_jobs_small(const LaunchEnv &env, uint32_t iter, boo
 
 // Jobs -> chains: neighbours over the same element range are linked when the minus prefix of one is the add prefix of the
 // next (double mask), or simply collected (single mask).  hipErrorNotSupported = use the job-table kernel.
+// A lone double-mask job that cannot fill the chip is latency bound: the chained kernel would run its two streams one after the
+// other (two dependent 14-round passes per lane, ~3.2 us each on a lone wave), the job-table kernel runs an element's add and minus
+// block as ONE software-pipelined pair.  Such jobs take the job-table kernel in 256-thread workgroups (one element per lane, a
+// LeNet-sized vector spreads over 241 CUs instead of 61).
+static bool lone_small_double_job(const LaunchEnv &env, bool dbl, int n_entries, const PrfJob *jobs)
+{
+    static const bool on = !(getenv("FLASHE_SMALL_LATENCY") && atoi(getenv("FLASHE_SMALL_LATENCY")) == 0);
+    return on && env.b > 64 && dbl && n_entries == 1 && !env.codec && jobs[0].n_in <= 1 && jobs[0].count &&
+           jobs[0].count <= 256ull * static_cast<uint64_t>(env.num_cus) && ((jobs[0].first + jobs[0].count - 1) >> 32) == (jobs[0].first >> 32);
+}
+
 static hipError_t launch_jobs_as_chains(const LaunchEnv &env, uint32_t iter, bool dbl, int n_entries, const PrfJob *jobs, uint64_t n, uint32_t n_jobs)
 {
     if (!env.use_chain) return hipErrorNotSupported;
+    if (lone_small_double_job(env, dbl, n_entries, jobs)) return hipErrorNotSupported;
     struct Build { std::vector<uint32_t> idx; std::vector<const uint64_t *> in; std::vector<uint64_t *> out; uint64_t first, count; int in_limbs; };
     std::vector<Build> bs;
     for (int e = 0; e < n_entries; e++) {
@@ -1901,6 +1913,20 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
         return hipSuccess;
     }
     if (env.b <= 64) return launch_prf_jobs_small(env, iter, dbl, n_entries, jobs, n, n_jobs);
+    if (lone_small_double_job(env, dbl, n_entries, jobs)) {
+        constexpr int kLatThreads = 256;
+        JobTable tb{};
+        tb.add[0] = jobs[0].add_idx; tb.minus[0] = jobs[0].minus_idx; tb.first[0] = jobs[0].first; tb.count[0] = jobs[0].count;
+        tb.in[0] = jobs[0].in_dev; tb.out[0] = jobs[0].out_dev; tb.in_limbs[0] = static_cast<uint8_t>(jobs[0].in_limbs); tb.n_in[0] = 1;
+        tb.big_end[0] = 0; tb.small_end[0] = (jobs[0].count + kLatThreads - 1) / kLatThreads;
+        uint64_t lo, hi;
+        masks_of(env.b, &lo, &hi);
+        const uint64_t cus = static_cast<uint64_t>(env.num_cus);
+        const int grid = static_cast<int>(tb.small_end[0] < cus ? tb.small_end[0] : cus);
+        hipLaunchKernelGGL((prf_wide_batch_kernel<true, kLatThreads, 3, JobTable>), dim3(grid), dim3(kLatThreads), 0, env.stream, env.rk, tb, 1, n, iter, lo,
+                           hi, env.te0_dev);
+        return hipGetLastError();
+    }
     JobTable tb{};
     int nv = 0;
     uint64_t big[kMaxBatch];
