@@ -528,8 +528,10 @@ def aggregate(ciphertexts, int_bits, packed=False, device=0, _engine=None, keep_
     n = len(arrs[0])
     if any(len(a) != n for a in arrs):
         raise ValueError("operands could not be broadcast together")
-    if not packed and not want_dev and not any(isinstance(a, DeviceVector) for a in arrs) and hasattr(eng, "aggregate_elem") and len(arrs) <= 64:
-        # all operands on the host, result wanted on the host: the host-pointer twin (chunk-pipelined upload / reduce / download)
+    if (not packed and not want_dev and not any(isinstance(a, DeviceVector) for a in arrs) and hasattr(eng, "aggregate_elem")
+            and len(arrs) <= 64 and len({id(a) for a in arrs}) == len(arrs)):
+        # distinct operands, all on the host, result wanted on the host: the host-pointer twin (chunk-pipelined upload / reduce /
+        # download); repeated operands take the path below, which uploads each array once
         return _from_limbs(eng.aggregate_elem(arrs), kind)
     dev = {}
     for a in arrs:

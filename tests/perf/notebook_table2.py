@@ -54,6 +54,15 @@ def main():
             assert [int(v) for v in ct[:2000]] == [int(v) for v in want_ct[:2000, 0]]
             assert [int(v) for v in dec[:5000]] == [int(v) * C % (1 << b) for v in vals[:5000]]
             row[kind] = {"encrypt_s": t_enc, "add10_s": t_add, "decrypt_s": t_dec}
+        # the same three calls with DeviceVector handles between them (round 3): the plaintext goes up once, the ciphertext and the
+        # sum stay in HBM, the decrypted vector comes down once
+        t_enc, h = timed(lambda: c.encrypt(vals, device=True))
+        t_add, hagg = timed(lambda: c.aggregate([h] * C))
+        c.set_idx_list(raw_idx_list=[0] * C, mode="decrypt")
+        t_dec, dec = timed(lambda: c.decrypt(hagg, device=False))
+        assert [int(v) for v in np.asarray(dec).reshape(-1)[:5000]] == [int(v) * C % (1 << b) for v in vals[:5000]]
+        row["uint64_device_handles"] = {"encrypt_s": t_enc, "add10_s": t_add, "decrypt_s": t_dec,
+                                        "note": "encrypt includes the upload, decrypt the download; add10 moves nothing"}
         rows.append(row)
     print(json.dumps({"notebook_table2_on_mi355x": rows,
                       "reference_published_c5_4xlarge_s": {"16384": {"encrypt": 2.63, "add10_incl_compress": 7.12, "decrypt": 2.40},
