@@ -64,19 +64,25 @@ static int int_to_limbs(PyObject *o, int limbs, uint64_t *out)
 #endif
 }
 
-/* objs: the data of a 1-D numpy object array (n borrowed references); out: [n][limbs].  0 = ok, -1 = Python error set. */
+/* objs: the data of a 1-D numpy object array (n borrowed references); out: [n][limbs].  0 = ok, -1 = Python error set.
+ *
+ * Large arrays are read by several threads: the common case -- exact ints below 2^60 -- needs no CPython call at all (type pointer,
+ * size and digits are plain memory reads of immutable objects that the array keeps alive, and the calling thread holds the GIL for
+ * the whole call, so no Python code runs meanwhile); the workers never touch the interpreter.  The loop is one cache miss per element
+ * (the ints live wherever the allocator put them), which is exactly what more threads overlap.  Whatever is not such an int (wider
+ * values, negative ones, NumPy scalars) is left to a serial second pass through the C API. */
 int flashe_pyconv_ints_to_limbs(PyObject **objs, Py_ssize_t n, int limbs, uint64_t *out)
 {
     if (limbs != 1 && limbs != 2) { PyErr_SetString(PyExc_ValueError, "limbs must be 1 or 2"); return -1; }
+    int leftovers = 0;
+#if PY_VERSION_HEX < 0x030C0000
+    /* (the in-place digit read relies on the PyLongObject layout of CPython <= 3.11: ob_size + ob_digit; 3.12 moved it to
+     * long_value.lv_tag, where the generic path below takes everything) */
+#pragma omp parallel for schedule(static) reduction(| : leftovers) if (n >= 131072)
     for (Py_ssize_t i = 0; i < n; i++) {
-        /* the ints live wherever the allocator put them: the pointer array tells us where the NEXT ones are, so fetch ahead
-         * (this loop is otherwise one cache miss per element) */
         if (i + 16 < n) __builtin_prefetch(objs[i + 16], 0, 0);
         PyObject *o = objs[i];
         uint64_t *dst = out + (size_t)i * limbs;
-#if PY_VERSION_HEX < 0x030C0000
-        /* (the in-place digit read relies on the PyLongObject layout of CPython <= 3.11: ob_size + ob_digit; 3.12 moved it to
-         * long_value.lv_tag, where the generic path below takes over) */
         if (PyLong_CheckExact(o)) {
             /* one- and two-digit non-negative ints (< 2^60): read the digits in place */
             const Py_ssize_t sz = Py_SIZE(o);
@@ -87,8 +93,18 @@ int flashe_pyconv_ints_to_limbs(PyObject **objs, Py_ssize_t n, int limbs, uint64
                 continue;
             }
         }
+        leftovers = 1;
+    }
+    if (!leftovers) return 0;
+#else
+    leftovers = 1;
 #endif
-        if (int_to_limbs(o, limbs, dst) < 0) return -1;
+    for (Py_ssize_t i = 0; i < n; i++) {
+        PyObject *o = objs[i];
+#if PY_VERSION_HEX < 0x030C0000
+        if (PyLong_CheckExact(o)) { const Py_ssize_t sz = Py_SIZE(o); if (sz == 0 || sz == 1 || sz == 2) continue; }      /* done above */
+#endif
+        if (int_to_limbs(o, limbs, out + (size_t)i * limbs) < 0) return -1;
     }
     return 0;
 }

@@ -10,7 +10,7 @@ PYINC=$(python3 -c "import sysconfig; print(sysconfig.get_paths()['include'])")
 trap 'make -s -C oracle clean all; make -s -C flashe_amd/csrc ../_pyconv.so -B >/dev/null' EXIT
 gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -fopenmp -std=gnu11 -ffp-contract=off -maes -msse4.1 \
     -shared -o oracle/libflashe_oracle.so oracle/flashe_oracle.c -lm
-gcc -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -shared -I"$PYINC" -o flashe_amd/_pyconv.so flashe_amd/csrc/pyconv.c
+gcc -O1 -g -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -shared -I"$PYINC" -o flashe_amd/_pyconv.so flashe_amd/csrc/pyconv.c
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1 OMP_NUM_THREADS=2 \
     python3 -m pytest -x -q tests/test_oracle_golden.py tests/test_cipher_host_logic.py tests/test_properties.py -m "not gpu" -p no:cacheprovider
 # the block pools behind flashe_dev_alloc / the host-pointer twins' staging (flashe_amd/csrc/blockpool.h) with a mock device
