@@ -107,6 +107,112 @@ class FlasheClient(object):
     def unnormalize(self, weights):
         return self.quantizer.unnormalize(weights)
 
+    # ---- the client step with nothing on the host in between (new) ------------------------------------------------------------
+    def _fusable(self):
+        c = self.cipher
+        return (not self.batch and c.masks is None and c.prp_seed is not None and not c.next_iter_encrypt_prepared
+                and hasattr(c.engine, "quantize_encrypt_dev"))
+
+    def quantize_encrypt(self, weights, device=True):
+        """`self.quantize(weights)` followed by `weights.encrypted(self)` -- QuantizingClient.quantize (jzf_quantize.py:394-491), then
+        JZFWeights.encrypted -> _Client.encrypt for every layer in walking order (jzf_weights.py:334-338, :446-450,
+        jzf_flashe_block.py:142-150) -- with no host round trip in between: a layer goes up once as it is (4 or 8 bytes per value), its
+        stochastic-rounding draws are generated on the device from NumPy's own stream (small layers: drawn on the host), ONE launch
+        quantises and encrypts (flashe_quantize_encrypt_dev).  Bit-identical to the two calls, layer by layer, with the same seed.
+        Layers come back as DeviceVectors (device=True: the ciphertext stays in HBM for `aggregate`) or as uint64 limb arrays [n, L];
+        their shapes are kept for `decrypt_unquantize`.  Batched quantisation, sparse masks and precomputed encrypt masks take the
+        two-call path and return what it returns."""
+        from . import cipher as _cipher_mod
+        from .engine import DeviceVector
+        from .quantize import ACIQ, DEVICE_RNG_MIN, _loop_dtype
+        q, c = self.quantizer, self.cipher
+        if q.layer_size_list is None:
+            q.set_layer_size_list(weights)
+        if not self._fusable():
+            weights = self.quantize(weights)
+            for k in weights.walking_order:
+                weights._weights[k] = self.cipher.encrypt(weights._weights[k])
+            return weights
+        eng = c.engine
+        aciq = ACIQ(q.element_bits)
+        alphas = []
+        for i, _size in enumerate(q.layer_size_list):
+            a = aciq.get_alpha_gaus_direct(q.past_layer_std_list[i])
+            alphas.append(0.1 if a == 0 else a)
+        q.r_max_list, q.alpha_list = [], []
+        self._layer_shapes = {}
+        c.set_idx_list(mode="encrypt")
+        scheme = 1 if c.masking_scheme == "double" else 0
+        layer_cnt = 0
+        for k in weights.walking_order:
+            if k == 'zzz':
+                alpha = 1.0
+            else:
+                alpha = alphas[layer_cnt]
+                q.r_max_list.append(alpha * q.num_clients)
+                q.alpha_list.append(alpha)
+            layer = np.asarray(weights._weights[k])
+            self._layer_shapes[k] = layer.shape
+            flat = np.ascontiguousarray(layer).reshape(-1)
+            if flat.dtype not in (np.float32, np.float64):
+                flat = flat.astype(np.float64)
+            want = _loop_dtype(flat.dtype, alpha)
+            if flat.dtype != want:
+                flat = flat.astype(want)
+            n = int(flat.size)
+            dx = eng.upload(flat)
+            if n >= DEVICE_RNG_MIN and np.random.get_state()[0] == "MT19937":
+                du = eng.numpy_random_dev(n)
+            else:
+                du = eng.upload(np.random.random(layer.shape).reshape(-1))
+            ct = DeviceVector(eng, n)
+            eng.quantize_encrypt_dev(c.iter_index, c.idx, scheme, n, _cipher_mod.N_JOBS, dx, flat.dtype == np.float64, float(alpha),
+                                     q.element_bits, du, ct.buf)
+            weights._weights[k] = ct.mark_ready() if device else ct.to_host()
+            layer_cnt += 1
+        return weights
+
+    def decrypt_unquantize(self, weights):
+        """`weights.decrypted(self)` followed by `self.unquantize(weights)` (jzf_weights.py:334-335 -> _Client.decrypt, then
+        QuantizingClient.unquantize, jzf_quantize.py:493-540) as ONE launch per layer (flashe_decrypt_unquantize_dev): the aggregate
+        -- a DeviceVector, uint64 limbs or object ints -- is decrypted with the prefixes `set_idx_list` left behind and comes back as
+        the unquantised float64 layer, reshaped as `quantize_encrypt` saw it.  Precomputed decrypt masks, sparse masks and batched
+        values take the two-call path."""
+        from . import cipher as _cipher_mod
+        from .engine import DeviceVector
+        q, c = self.quantizer, self.cipher
+        fus = (not self.batch and c.masks is None and c.prp_seed is not None and not c.next_iter_decrypt_prepared
+               and hasattr(c.engine, "decrypt_unquantize_dev"))
+        if not fus:
+            for k in weights.walking_order:
+                v = self.cipher.decrypt(weights._weights[k], device=False)
+                weights._weights[k] = v
+            return self.unquantize(weights)
+        eng = c.engine
+        if c.masking_scheme == "double":
+            add_idx = [c._idx_of(p) for p in (c.index_prefix_for_add or [])]
+            minus_idx = [c._idx_of(p) for p in (c.index_prefix_for_minus or [])]
+            if not add_idx and not minus_idx:
+                raise KeyError('add')
+        else:
+            add_idx, minus_idx = [], [c._idx_of(p) for p in c.index_prefix_for_minus]
+        shapes = getattr(self, "_layer_shapes", {})
+        for layer_cnt, k in enumerate(weights.walking_order):
+            alpha = q.alpha_list[layer_cnt] if k != 'zzz' else 1.0
+            v = weights._weights[k]
+            if not isinstance(v, DeviceVector):
+                v = np.asarray(v)
+                if v.dtype == object:
+                    v = v.reshape(-1)
+            dv, _kind = c._on_device(v, full_width=True)
+            n = len(dv)
+            dout = eng.alloc(max(8 * n, 16))
+            eng.decrypt_unquantize_dev(c.iter_index, add_idx, minus_idx, n, _cipher_mod.N_JOBS, dv.buf, float(alpha), q.element_bits,
+                                       q.num_clients, dout)
+            out = dout.download(np.float64, n)
+            weights._weights[k] = out.reshape(shapes.get(k, out.shape))
+        return weights
+
     def prepare_encrypt(self):
         if self.precompute:
             self.cipher.prepare_encrypt()
