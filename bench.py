@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--calibration-deadline", type=float, default=float(os.environ.get("FLASHE_BENCH_CALIBRATION_DEADLINE_S", "150")),
                     help="N > 1: seconds the optional overlapped schedules (calibration + their timed region) may take; when it passes, or "
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
+    ap.add_argument("--no-partial-agg", action="store_true",
+                    help="N > 1: keep the separate local reduce in the sequential round instead of letting the encrypt launch write the partial aggregate")
     ap.add_argument("--no-unchained", action="store_true", help="skip the FLASHE_CHAIN=0 reference measurement (config 2, one GPU)")
     ap.add_argument("--cus-free", type=int, default=None,
                     help="PRF launches leave this many CUs free for the RCCL transfer kernels of the overlapped schedules (default: 0, or "
@@ -423,7 +425,10 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
     Qbox = {"Q": Qs[len(Qs) // 2]}                       # the chunk count run_schedule uses (the calibration varies it)
     enc_ev = [(eng.event(), eng.event()) for _ in range(K)]
     ph_ev = [[eng.event() for _ in range(3)] for _ in range(K)]
-    partial = args.schedule == "partial-agg"
+    # With an exchange the sequential round sends each rank's partial aggregate: the encrypt launch writes it ("each
+    # GPU encrypts and locally mod-adds its share"), which removes the separate local reduce (16 (C + 1) B per element of HBM traffic) from
+    # the path the first multi-GPU run is guaranteed to report.  One GPU: only on request (the default line stays the two-launch round).
+    partial = args.schedule == "partial-agg" or (world > 1 and args.schedule in ("default", "auto") and not args.no_partial_agg)
 
     def run_schedule(schedule, it, k=None):
         """One round.  k = index of the timed step (events recorded) or None (warmup / parity run)."""
