@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, choices=[2, 3, 4, 5], default=2, help="BASELINE.json configuration (default 2 = the headline)")
+    ap.add_argument("--config", type=int, choices=[1, 2, 3, 4, 5], default=2, help="BASELINE.json configuration (default 2 = the headline)")
     ap.add_argument("--n", type=int, default=None, help="vector length (default: the configuration's)")
     ap.add_argument("--clients", type=int, default=None, help="config 2: clients per GPU; configs 3-5: clients in all")
     ap.add_argument("--bits", type=int, default=128)
@@ -332,7 +332,10 @@ def main(comm_factory=None, device_override=None):
         from flashe_amd.engine import Engine
         b = args.bits
         cfg = args.config
-        n = args.n or {2: 10_000_000, 3: LENET, 4: RESNET50, 5: RESNET50}[cfg]
+        n = args.n or {1: 10_000, 2: 10_000_000, 3: LENET, 4: RESNET50, 5: RESNET50}[cfg]
+        if cfg == 1 and args.bits == 128:
+            b = args.bits = 64                      # config 1 is quoted on a 64-bit modulus
+            out["dtype"] = "u64"
         eng = Engine(KEY, b, device=local_rank)
         eng.selftest()
         backend = {"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend]
@@ -347,6 +350,8 @@ def main(comm_factory=None, device_override=None):
 
         if cfg in (2, 4):
             result = bench_dense(args, cfg, n, ops, rank, world, out, wd, state)
+        elif cfg == 1:
+            result = bench_plumbing(args, n, ops, rank, world, out)
         elif cfg == 3:
             result = bench_precompute(args, n, ops, rank, world, out)
         else:
@@ -784,6 +789,81 @@ def e2e_handles_ms(host_pts, n, b, J):
         return min(times[1:]), times[0]
     finally:
         cm.N_JOBS = old
+
+
+# ---- config 1: the reference's own CPU-runnable case (plumbing): fp32 -> 32-bit quantise -> 64-bit modulus, 2 clients, single mask ---
+def bench_plumbing(args, n, ops, rank, world, out):
+    """Per round: both clients quantise + encrypt their fp32 vector (one fused launch each, stochastic-rounding draws resident), the
+    arbiter adds the two ciphertexts, the result is decrypted + unquantised (one fused launch).  1e4 elements: launch bound; the line
+    exists so that every BASELINE configuration has one, the parity of this configuration is tests/golden/config1.npz."""
+    import numpy as np
+    from oracle import flashe_oracle as orc          # parity gate only
+    from flashe_amd.engine import SCHEME_SINGLE
+    from flashe_amd.quantize import ACIQ
+    eng = ops.engine
+    b, K, W, J = args.bits, args.steps, args.warmup, args.n_jobs
+    C, eb = args.clients or 2, 32
+    L = 2 if b > 64 else 1
+    alpha = float(ACIQ(eb).get_alpha_gaus_direct(1.0))
+    rng = np.random.Generator(np.random.PCG64(7))
+    xs = [rng.standard_normal(n).astype(np.float32) for _ in range(C)]
+    us = [rng.random(n) for _ in range(C)]
+    dx, du = [ops.upload(x) for x in xs], [ops.upload(u) for u in us]
+    cts = [eng.alloc_vec(n) for _ in range(C)]
+    agg, res = eng.alloc_vec(n), eng.alloc(8 * n)
+    ev = [[eng.event() for _ in range(3)] for _ in range(K)]
+
+    def step(it, k=None):
+        if k is not None:
+            eng.record(ev[k][0])
+        for c in range(C):
+            eng.quantize_encrypt_dev(it, c, SCHEME_SINGLE, n, J, dx[c], False, alpha, eb, du[c], cts[c])
+        if k is not None:
+            eng.record(ev[k][1])
+        eng.aggregate_elem_dev(cts, n, agg)
+        eng.decrypt_unquantize_dev(it, [], list(range(C)), n, J, agg, alpha, eb, C, res)
+        if k is not None:
+            eng.record(ev[k][2])
+
+    step(0)
+    orc.build()
+    q = [orc.quantize(xs[c], alpha, eb, us[c]) for c in range(C)]
+    want_ct = [orc.encrypt(KEY, 0, c, "single", J, b, q[c]) for c in range(C)]
+    for c in range(C):
+        assert np.array_equal(cts[c].download(np.uint64, n * L).reshape(n, L), want_ct[c]), f"PARITY FAILURE client {c}"
+    want = orc.unquantize(orc.decrypt(KEY, 0, [], list(range(C)), J, b, orc.aggregate_elem(want_ct, b)), alpha, eb, C)
+    assert res.download(np.float64, n).tobytes() == want.tobytes(), "PARITY FAILURE (decrypt + unquantise)"
+    for it in range(max(W, 3)):
+        step(it)
+    elapsed = timed_region(ops, K, lambda k: step(k, k))
+    if rank != 0:
+        return None
+    ph = np.array([[eng.elapsed_ms(e[i], e[i + 1]) for i in range(2)] for e in ev])
+    enc_ms = float(ph[:, 0].mean())
+    alg_bytes = C * n * (4 + 8 + 8 * L)                   # fp32 value + its draw in, ciphertext out
+    out.update({
+        "value": world * C * n / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
+        "config": {"workload": f"BASELINE config 1: n={n}-element random fp32 vector, {eb}-bit quantise, {b}-bit modulus, {C} clients, single mask, "
+                               f"n_jobs={J}; step = {C} x (quantise + encrypt, one fused launch) + aggregate + (decrypt + unquantise, one fused launch)"
+                               + ("; independent replicas per GPU" if world > 1 else ""),
+                   "n": n, "int_bits": b, "clients_total": C, "mask": "single",
+                   "parity": "bit-exact (ciphertexts and the unquantised result vs the oracle, checked in-run; the reference-generated fixture of "
+                             "this configuration is tests/golden/config1.npz)"},
+        "roofline": {"kernel": "prf_small_jobs_kernel (AES-256 PRF fused with the quantiser front end: fp32 -> stochastic rounding -> + mask)",
+                     "bound": "hbm", "achieved": alg_bytes / (enc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg_bytes / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes / C,
+                     "avg_launch_ms": enc_ms / C, "launches_timed": K * C, "note": "launch-bound at 1e4 elements"},
+        "phases_ms": {"quantize_encrypt_xC": enc_ms, "aggregate_plus_decrypt_unquantize": float(ph[:, 1].mean())},
+    })
+    if world == 1 and not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        for _ in range(20):
+            qq = [orc.quantize(xs[c], alpha, eb, us[c]) for c in range(C)]
+            cc = [orc.encrypt(KEY, 0, c, "single", J, b, qq[c]) for c in range(C)]
+            orc.unquantize(orc.decrypt(KEY, 0, [], list(range(C)), J, b, orc.aggregate_elem(cc, b)), alpha, eb, C)
+        out["cpu_baseline"] = {"value": C * n / ((time.perf_counter() - t0) / 20), "unit": "ciphertexts/s", "cores": min(orc.num_threads(), usable_cpus()),
+                               "kind": "port", "sample": "20 full rounds of the same workload through oracle/flashe_oracle.c"}
+    return out
 
 
 # ---- config 3: LeNet-sized model, 100 clients, double mask + mask precompute ---------------------------------------------

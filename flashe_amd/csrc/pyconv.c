@@ -10,6 +10,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#define FAST_DIGITS 5          /* 30-bit digits read / written in place: values below 2^150 */
+
 /* value mod 2^(64 * limbs) of any Python int (negative values wrap like Python's `&`), two's complement */
 static int int_to_limbs(PyObject *o, int limbs, uint64_t *out)
 {
@@ -84,12 +86,15 @@ int flashe_pyconv_ints_to_limbs(PyObject **objs, Py_ssize_t n, int limbs, uint64
         PyObject *o = objs[i];
         uint64_t *dst = out + (size_t)i * limbs;
         if (PyLong_CheckExact(o)) {
-            /* one- and two-digit non-negative ints (< 2^60): read the digits in place */
+            /* non-negative ints of up to FAST_DIGITS digits (30-bit digits: < 2^150, i.e. every 128-bit ciphertext): read the digits in
+             * place, reduced mod 2^(64 limbs) by the truncation of the accumulator */
             const Py_ssize_t sz = Py_SIZE(o);
             const digit *d = ((PyLongObject *)o)->ob_digit;
-            if (sz == 1 || sz == 0 || sz == 2) {
-                dst[0] = sz == 0 ? 0 : sz == 1 ? (uint64_t)d[0] : ((uint64_t)d[0] | ((uint64_t)d[1] << PyLong_SHIFT));
-                if (limbs == 2) dst[1] = 0;
+            if (sz >= 0 && sz <= FAST_DIGITS) {
+                unsigned __int128 v = 0;
+                for (Py_ssize_t j = 0; j < sz; j++) v |= (unsigned __int128)d[j] << (PyLong_SHIFT * j);
+                dst[0] = (uint64_t)v;
+                if (limbs == 2) dst[1] = (uint64_t)(v >> 64);
                 continue;
             }
         }
@@ -102,7 +107,7 @@ int flashe_pyconv_ints_to_limbs(PyObject **objs, Py_ssize_t n, int limbs, uint64
     for (Py_ssize_t i = 0; i < n; i++) {
         PyObject *o = objs[i];
 #if PY_VERSION_HEX < 0x030C0000
-        if (PyLong_CheckExact(o)) { const Py_ssize_t sz = Py_SIZE(o); if (sz == 0 || sz == 1 || sz == 2) continue; }      /* done above */
+        if (PyLong_CheckExact(o)) { const Py_ssize_t sz = Py_SIZE(o); if (sz >= 0 && sz <= FAST_DIGITS) continue; }      /* done above */
 #endif
         if (int_to_limbs(o, limbs, out + (size_t)i * limbs) < 0) return -1;
     }
@@ -118,7 +123,18 @@ int flashe_pyconv_limbs_to_ints(const uint64_t *in, Py_ssize_t n, int limbs, PyO
         const uint64_t *p = in + (size_t)i * limbs;
         PyObject *v;
         if (limbs == 1 || p[1] == 0) v = PyLong_FromUnsignedLongLong(p[0]);
-#if PY_VERSION_HEX >= 0x030D0000
+#if PY_VERSION_HEX < 0x030C0000 && PYLONG_BITS_IN_DIGIT == 30
+        else {
+            /* a 65..128-bit value: allocate the int with its digit count and write the 30-bit digits directly (the generic byte-array
+             * constructor costs ~4x as much) */
+            const unsigned __int128 x = ((unsigned __int128)p[1] << 64) | p[0];
+            const int bits = 128 - __builtin_clzll(p[1]);
+            const int nd = (bits + PyLong_SHIFT - 1) / PyLong_SHIFT;
+            PyLongObject *lv = _PyLong_New(nd);
+            if (lv) for (int j = 0; j < nd; j++) lv->ob_digit[j] = (digit)((x >> (PyLong_SHIFT * j)) & PyLong_MASK);
+            v = (PyObject *)lv;
+        }
+#elif PY_VERSION_HEX >= 0x030D0000
         else v = PyLong_FromUnsignedNativeBytes(p, 16, Py_ASNATIVEBYTES_LITTLE_ENDIAN);
 #else
         else v = _PyLong_FromByteArray((const unsigned char *)p, 16, 1, 0);
