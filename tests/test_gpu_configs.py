@@ -1,5 +1,7 @@
 """BASELINE.json configurations 3, 4 and 5 at FULL size on one MI355X, through the same code paths bench.py --config runs, every
 ciphertext (or, where the dense oracle form would not fit the host, an equivalent sparse restatement) compared with the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -181,3 +183,39 @@ def test_config5_sparse_top1pct_50_clients(E, oracle):
         whi[locs[c]] += (new < d).astype(np.uint64) - borrow
         want[locs[c]] = new
     assert np.array_equal(dec[:, 0], want) and np.array_equal(dec[:, 1], whi)
+
+
+@pytest.mark.parametrize("args,keys", [
+    (["--config", "1"], ["cpu_baseline"]),
+    (["--config", "2", "--n", "2300017", "--no-python-baseline"], ["value_partial_agg", "value_unchained", "e2e_ms_device_handles", "cpu_baseline", "round_hbm_frac"]),
+    (["--config", "2", "--n", "2300017", "--schedule", "partial-agg", "--no-cpu-baseline", "--no-e2e"], []),
+    (["--config", "2", "--n", "500000", "--schedule", "auto", "--no-cpu-baseline", "--no-e2e"], []),
+    (["--config", "3", "--clients", "7", "--no-cpu-baseline"], []),
+    (["--config", "5", "--n", "400000", "--clients", "5", "--no-cpu-baseline"], []),
+])
+def test_bench_lines_on_one_gpu(args, keys):
+    """bench.py on one GPU, every configuration and schedule at reduced size: the in-run parity gates (round trip AND ciphertexts
+    against the oracle) pass, exactly one JSON line comes out and it carries the contract's fields plus `roofline` -- and the
+    extra figures the default line reports beside `value`."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--settle-rounds", "2"] + args,
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_WAIT_POLICY="passive"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
+    rl = d["roofline"]
+    assert rl["bound"] in ("hbm", "lds", "mfma") and rl["peak"] == 8000.0 and rl["unit"] == "GB/s" and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9
+    assert "bit-exact" in d["config"]["parity"]
+    for k in keys:
+        assert k in d, k
+    if "--schedule" in args:
+        want = args[args.index("--schedule") + 1]
+        assert d["config"]["schedule_name"] == want or want == "auto"
