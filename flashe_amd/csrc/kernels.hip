@@ -1331,7 +1331,15 @@ __device__ __forceinline__ WalkPt small_walk32_load(const uint64_t *__restrict__
 #pragma unroll
     for (uint32_t u = 0; u < kWalkBatch; u++) {
         r.v[u] = 0u;
+        // b <= 32: only the low word of the 8-byte element takes part (little endian: the first four bytes); a 4-byte load holds one
+        // VGPR while it is in flight instead of two -- up to sixteen fewer live registers across the AES rounds of a pair in a
+        // kernel that sits at 128 VGPRs with spills.  Two builds alternated in one process (tests/perf/ab_two_libs.py), ten
+        // 1e7-element vectors: b = 16 0.343 -> 0.310 ms, b = 20 0.351 -> 0.346, b = 25 and b = 8 unchanged
+#ifdef FLASHE_WALK_LOAD64       // (A/B build: tests/perf/ab_two_libs.py)
         if (pin && u < m) r.v[u] = static_cast<uint32_t>(__builtin_nontemporal_load(pin + 64u * u));
+#else
+        if (pin && u < m) r.v[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pin + 64u * u));
+#endif
     }
     return r;
 }
@@ -1354,7 +1362,7 @@ __device__ __forceinline__ void small_walk32(uint32_t *row0, uint32_t lane, uint
             pt[u] = pt0.v[u];
             if (i0) {                                      // (m > kWalkBatch: b < 16) later batches are loaded here
                 pt[u] = 0u;
-                if (pin && i0 + u < m) pt[u] = static_cast<uint32_t>(__builtin_nontemporal_load(pin + 64u * (i0 + u)));
+                if (pin && i0 + u < m) pt[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(pin + 64u * (i0 + u)));
             }
         }
 #pragma unroll
