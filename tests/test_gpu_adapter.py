@@ -230,7 +230,11 @@ def test_flashe_client_on_the_device_against_reference_fixture():
 
 
 @pytest.mark.parametrize("seed,pos,n", [(1, None, 1), (2, None, 311), (3, None, 312), (4, None, 313), (5, 0, 1000), (6, 1, 1000), (7, 623, 5), (8, 624, 700),
-                                        (9, 17, 100_003), (10, None, 2_000_001)])
+                                        (9, 17, 100_003), (10, None, 2_000_001),
+                                        # substreams (65,536 doubles each, started by jumping ahead): exactly one, one word more, odd positions,
+                                        # a stream that ends on a block / substream boundary, many substreams
+                                        (11, 0, 65_536), (12, 1, 65_536), (13, 2, 65_536), (14, 0, 65_537), (15, 623, 131_072), (16, 624, 196_608),
+                                        (17, 5, 65_536 * 3 - 2), (18, None, 10_000_019), (19, 100, 312 * 1000), (20, 101, 312 * 1000 + 5)])
 def test_numpy_random_on_the_device_is_numpy_bit_for_bit(seed, pos, n):
     """flashe_mt19937_random_dev: np.random.random(n) generated on the device from NumPy's own MT19937 state -- the same doubles, and the
     same generator state afterwards, as the host call; odd positions (pairs straddling the 624-word blocks), the position-624 state a
