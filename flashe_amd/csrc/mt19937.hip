@@ -336,6 +336,9 @@ JumpTables &jump_tables()
 
 }  // namespace
 
+// Host only (no device needed): builds the jump polynomials and checks them against the generator.
+extern "C" int flashe_mt19937_jump_selfcheck(void) { return jump_tables().ok ? FLASHE_OK : FLASHE_EIO; }
+
 extern "C" int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uint32_t *pos, uint64_t n, double *u_dev)
 {
     CHECK_CTX(ctx);

@@ -380,6 +380,8 @@ int flashe_mean_std_dev(flashe_ctx *ctx, uint64_t n, const void *x_dev, int x_is
  * parallel, one workgroup each: 1e7 doubles in 0.5 ms (np.random.random: 27-35 ms on a host core), and no 8 B/element upload.
  * Synchronous.  FLASHE_MT_PARALLEL=0 keeps the one-workgroup walk. */
 int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uint32_t *pos, uint64_t n, double *u_dev);
+/* Host only: builds the twelve jump polynomials x^(2^17 2^j) mod phi and checks the first against the generator itself. */
+int flashe_mt19937_jump_selfcheck(void);
 
 /* _static_quantize_padding_asymmetric -- federatedml/secureprotol/jzf_quantize.py:55-67:
  * q = floor(clip(x, -alpha, alpha) + alpha) * (2^element_bits - 1) / (2 alpha) + u), with numpy's

@@ -204,3 +204,13 @@ def test_c_example_builds_against_the_header_and_the_library(tmp_path):
     """examples/c_round.c -- a whole round through the C ABI from plain C11, host vectors in and out -- compiles without warnings
     against include/flashe.h and links against the shared library (it RUNS in the GPU suite)."""
     assert os.path.exists(_build_c_example(tmp_path))
+
+
+def test_mt19937_jump_polynomials_self_check():
+    """The jump polynomials behind the parallel np.random.random (x^(S 2^j) mod phi, built on the host from the 135-term characteristic
+    polynomial) reproduce the generator: word S + w of a test stream equals the XOR of the words the polynomial selects (no GPU needed)."""
+    import time
+    from flashe_amd import _lib
+    t0 = time.time()
+    assert _lib.load().flashe_mt19937_jump_selfcheck() == 0
+    assert time.time() - t0 < 20
