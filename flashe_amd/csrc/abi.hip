@@ -332,7 +332,7 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     if (!ctx) return FLASHE_EINVAL;
     (void)hipSetDevice(ctx->device);
     if (ctx->env.stream) (void)hipStreamSynchronize(ctx->env.stream);
-    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds})
+    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds, &ctx->mt_ws})
         if (b->p) (void)hipFree(b->p);
     if (ctx->staging) { ctx->staging->destroy(); delete ctx->staging; ctx->staging = nullptr; }      // staging blocks held plaintexts and ciphertexts (wiped)
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);

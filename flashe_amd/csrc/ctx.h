@@ -26,6 +26,7 @@ struct flashe_ctx {
     Buf acc_tmp[2];   // ping-pong partial sums when a packed reduce has more than kMaxOps operands
     Buf sp_ws;        // sparsifier workspace (select state, histogram, per-block counts)
     Buf bounds;       // span reduce: first entry of every client in every span
+    Buf mt_ws;        // flashe_mt19937_random_dev: state in / out and the substream windows
     // staging blocks of the host-pointer twins: hipMalloc / hipFree cost more than the kernels on LeNet-sized vectors and more than
     // the PCIe transfer on 160 MB ones, so blocks are kept and reused within a byte budget (the twins are synchronous: a block is
     // free again when its call returns)

@@ -16,6 +16,7 @@
 // is advanced exactly as NumPy would have advanced it, so host draws continue the stream.
 #include "ctx.h"
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -363,8 +364,13 @@ extern "C" int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uin
             if (ctx->device < 0 || ctx->device >= 64) P = 1;
         }
         const size_t words = 1280 + static_cast<size_t>(P) * kMtN;
-        uint32_t *st = nullptr;
-        HIP_TRY(ctx, hipMalloc(&st, words * sizeof(uint32_t)));
+        if (ctx->mt_ws.cap < words * sizeof(uint32_t)) {             // scratch kept by the ctx: a hipMalloc + hipFree pair per call costs more than the call
+            if (ctx->mt_ws.p) { HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); HIP_TRY(ctx, hipFree(ctx->mt_ws.p)); ctx->mt_ws.p = nullptr; ctx->mt_ws.cap = 0; }
+            const size_t capb = std::max<size_t>(words * sizeof(uint32_t), 1u << 20);
+            HIP_TRY(ctx, hipMalloc(&ctx->mt_ws.p, capb));
+            ctx->mt_ws.cap = capb;
+        }
+        uint32_t *st = static_cast<uint32_t *>(ctx->mt_ws.p);
         hipError_t e = hipMemcpyAsync(st, host, sizeof host, hipMemcpyHostToDevice, ctx->env.stream);
         if (e == hipSuccess && P > 1) {
             uint32_t *&gdev = jt->dev[ctx->device];
@@ -396,7 +402,6 @@ extern "C" int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uin
         }
         if (e == hipSuccess) e = hipMemcpyAsync(host, st + 640, 624 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->env.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->env.stream);
-        (void)hipFree(st);
         HIP_TRY(ctx, e);
         host[624] = static_cast<uint32_t>(end - tfin * kMtN);
         n -= now;
