@@ -1,6 +1,7 @@
 """Short, seeded runs of the differential fuzzers under tests/perf/ inside the GPU gate: random job lists of chained PRF launches
 (every bit-width class: one element per block, direct outputs for 2 .. 4 elements per block, the fast and the general walk) and
-random sparse rounds (span bounds / span reduce / fused sparse decrypt), each compared with the oracle.  The long runs
+random sparse rounds (span bounds / span reduce / fused sparse decrypt), and the round-3 entry points (partial aggregate, run-edge sparse
+masks, MT19937 draws, pipelined host twins, recycled device blocks), each compared with the oracle.  The long runs
 (hundreds of cases per seed) are in tests/perf/README.md."""
 import os
 import subprocess
@@ -27,3 +28,7 @@ def test_fuzz_chained_launches(seed):
 
 def test_fuzz_sparse_round():
     assert "FUZZ_SPARSE_OK 20 cases" in _run("fuzz_sparse.py", 20, 103)
+
+
+def test_fuzz_round3_entry_points():
+    assert "FUZZ_R3_OK 40 cases" in _run("fuzz_round3.py", 8, 104)
