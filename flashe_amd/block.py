@@ -4,10 +4,15 @@ the arbiter's `dynamic_masking` cost model (:89-117).  Key exchange, uuid sync a
 transfer variables of the reference classes are control plane and are not reproduced; the PRP seed
 is handed in directly.
 """
+import os
+
 import numpy as np
 
 from .cipher import FlasheCipher
 from .quantize import QuantizingClient
+
+_RNG_RUN_MAX = 1 << 26          # draws per device call of quantize_encrypt (512 MiB of float64)
+_DOWNLOAD_WINDOW = 1 << 30      # bytes of unquantised layers decrypt_unquantize keeps on the device before it downloads them
 
 __all__ = ["dynamic_masking_choice", "FlasheClient"]
 
@@ -143,8 +148,23 @@ class FlasheClient(object):
         self._layer_shapes = {}
         c.set_idx_list(mode="encrypt")
         scheme = 1 if c.masking_scheme == "double" else 0
+        # the stochastic-rounding draws of consecutive layers are ONE stretch of NumPy's stream (np.random.random(layer.shape) per layer in
+        # walking order, jzf_quantize.py:55-67 under :417-462): a run of layers is drawn by one device call and every layer takes its
+        # slice -- one state round trip per run instead of one per layer.  Runs are capped so the draws of a huge model stay bounded.
+        order = list(weights.walking_order)
+        sizes = [int(np.asarray(weights._weights[k]).size) for k in order]
+        dev_rng = os.environ.get("FLASHE_DEVICE_RNG", "1") != "0" and np.random.get_state()[0] == "MT19937"
+        runs, at = {}, 0                                             # first layer of a run -> (layers in the run, draws)
+        while at < len(order):
+            end, tot = at, 0
+            while end < len(order) and (end == at or tot + sizes[end] <= _RNG_RUN_MAX):
+                tot += sizes[end]
+                end += 1
+            runs[at] = (end - at, tot)
+            at = end
         layer_cnt = 0
-        for k in weights.walking_order:
+        du_run, u_off = None, 0
+        for li, k in enumerate(order):
             if k == 'zzz':
                 alpha = 1.0
             else:
@@ -160,9 +180,14 @@ class FlasheClient(object):
             if flat.dtype != want:
                 flat = flat.astype(want)
             n = int(flat.size)
+            if li in runs:
+                du_run, u_off = None, 0
+                if dev_rng and runs[li][1] >= DEVICE_RNG_MIN:
+                    du_run = eng.numpy_random_dev(runs[li][1])
             dx = eng.upload(flat)
-            if n >= DEVICE_RNG_MIN and np.random.get_state()[0] == "MT19937":
-                du = eng.numpy_random_dev(n)
+            if du_run is not None:
+                du = du_run.ptr + 8 * u_off
+                u_off += n
             else:
                 du = eng.upload(np.random.random(layer.shape).reshape(-1))
             ct = DeviceVector(eng, n)
@@ -197,6 +222,16 @@ class FlasheClient(object):
         else:
             add_idx, minus_idx = [], [c._idx_of(p) for p in c.index_prefix_for_minus]
         shapes = getattr(self, "_layer_shapes", {})
+        pending, held = [], 0                # launches run ahead of the downloads: a layer comes down while the next ones are computed
+
+        def drain():
+            nonlocal held
+            for k_, n_, dout_, _dv in pending:
+                out = dout_.download(np.float64, n_)
+                weights._weights[k_] = out.reshape(shapes.get(k_, out.shape))
+            pending.clear()
+            held = 0
+
         for layer_cnt, k in enumerate(weights.walking_order):
             alpha = q.alpha_list[layer_cnt] if k != 'zzz' else 1.0
             v = weights._weights[k]
@@ -209,8 +244,11 @@ class FlasheClient(object):
             dout = eng.alloc(max(8 * n, 16))
             eng.decrypt_unquantize_dev(c.iter_index, add_idx, minus_idx, n, _cipher_mod.N_JOBS, dv.buf, float(alpha), q.element_bits,
                                        q.num_clients, dout)
-            out = dout.download(np.float64, n)
-            weights._weights[k] = out.reshape(shapes.get(k, out.shape))
+            pending.append((k, n, dout, dv))
+            held += 8 * n
+            if held >= _DOWNLOAD_WINDOW:
+                drain()
+        drain()
         return weights
 
     def prepare_encrypt(self):

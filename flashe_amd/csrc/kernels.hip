@@ -2017,10 +2017,25 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
         if (const char *e = getenv("FLASHE_CHAIN_PROBE")) probe = atoi(e) == 1 ? 0x100 : atoi(e) == 2 ? 0x200 : 0;
     }
     // cut: (1) table limits, (2) parallelism of short launches (never below 4 outputs per piece: a cut costs one stream)
+    // (3) SINGLE chains have no shared stream, a cut is free: cut until the launch has two whole tiles per wave and runs in whole tiles
+    //     (full two-step counter shortcut, two pairs per lane) -- 61,706 x 100 masks: 100.5 -> 93.5 us, 1e6 x 12: 175.8 -> 163.4 us,
+    //     255,570 x 50 (config 5): 182.4 -> 179 us (tests/perf/sweep_chain.py single)
+    bool only_single = true;
+    for (const Piece &pc : pieces) only_single &= pc.ch->single && !pc.ch->sum_out_dev;
+    int single_parts = 0;
+    if (only_single && all_half && !force_parts && !(tune && getenv("FLASHE_CHAIN_HALF"))) {
+        single_parts = static_cast<int>(std::min<uint64_t>((2 * waves + total_tiles - 1) / total_tiles, kMaxChains / pieces.size()));
+        if (single_parts < 1) single_parts = 1;
+        uint64_t cut_tiles = 0;
+        for (const Piece &pc : pieces) cut_tiles += pc.tiles * static_cast<uint64_t>(std::min(single_parts, pc.l1));
+        all_half = 2 * cut_tiles < waves;       // a workgroup with fewer tiles than waves halves them by itself (n_full = 0 in the kernel)
+    }
     std::vector<Piece> cut;
     for (const Piece &pc : pieces) {
         int parts = (pc.l1 + kMaxLinks - 1) / kMaxLinks;
-        if (all_half && 2 * total_tiles < waves && !pc.ch->sum_out_dev) {
+        if (single_parts) {
+            parts = std::max(parts, std::min(single_parts, pc.l1));
+        } else if (all_half && 2 * total_tiles < waves && !pc.ch->sum_out_dev) {
             const uint64_t want = waves / (2 * total_tiles);
             const int cap = std::max(1, pc.l1 / 4);
             parts = std::max<int>(parts, static_cast<int>(std::min<uint64_t>(want, static_cast<uint64_t>(cap))));

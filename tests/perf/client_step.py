@@ -52,3 +52,32 @@ for name in ("fused, device handles", "fused, host arrays", "two calls (object a
         best = min(best, time.perf_counter() - t0)
         del out
     print(f"{name:62s}: {best * 1e3:9.1f} ms for {len(sizes)} layers, {total} parameters", flush=True)
+
+if "--profile" in sys.argv:                 # where the host time of the fused step goes
+    import cProfile
+    import pstats
+    cl = client()
+    w = W({k: v.copy() for k, v in layers.items()})
+    np.random.seed(1)
+    cl.quantize_encrypt(W({k: v.copy() for k, v in layers.items()}), device=True)
+    pr = cProfile.Profile()
+    pr.enable()
+    out = cl.quantize_encrypt(w, device=True)
+    cl.cipher.engine.sync()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+
+# the way back: the aggregate of C such models (here: C copies of this client's ciphertexts) decrypted and unquantised
+cl = client()
+w = W({k: v.copy() for k, v in layers.items()})
+np.random.seed(1)
+enc = cl.quantize_encrypt(w, device=True)
+agg = W({k: cl.cipher.aggregate([enc._weights[k]] * C) for k in enc.walking_order})
+cl.cipher.set_idx_list(raw_idx_list=list(range(1)) * C, mode="decrypt")
+best = 1e9
+for rep in range(3):
+    a2 = W(dict(agg._weights))
+    t0 = time.perf_counter()
+    back = cl.decrypt_unquantize(a2)
+    best = min(best, time.perf_counter() - t0)
+print(f"{'decrypt_unquantize of the aggregate (handles in, float64 layers out)':62s}: {best * 1e3:9.1f} ms", flush=True)

@@ -8,7 +8,7 @@ import numpy as np
 
 os.environ["FLASHE_CHAIN_TUNE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from flashe_amd.engine import SCHEME_DOUBLE, Engine  # noqa: E402
+from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine  # noqa: E402
 
 eng = Engine(bytes(range(32)), 128)
 e0, e1 = eng.event(), eng.event()
@@ -34,15 +34,27 @@ def setenv(**kw):
             os.environ["FLASHE_CHAIN_" + k.upper()] = str(v)
 
 
-for n, C in [(61_706, 100), (61_706, 1), (61_706, 10), (1_000_000, 10), (250_000, 100)]:
+# usage: sweep_chain.py            the double-mask shapes of config 3
+#        sweep_chain.py single     single-mask shapes (config 5: 50 clients x 255,570 compact entries; one chain, independent streams)
+SHAPES = [(61_706, 100), (61_706, 1), (61_706, 10), (1_000_000, 10), (250_000, 100)]
+SCHEME = SCHEME_DOUBLE
+GRIDS = (None, 128, 64)
+if len(sys.argv) > 1 and sys.argv[1] == "single":
+    SHAPES, SCHEME, GRIDS = [(255_570, 50), (61_706, 100), (1_000_000, 12)], SCHEME_SINGLE, (None,)
+for n, C in SHAPES:
     pts = [eng.upload(np.arange(n, dtype=np.uint64)) for _ in range(C)]
     cts = [eng.alloc_vec(n) for _ in range(C)]
     idx = list(range(C))
-    run = lambda: eng.encrypt_batch_dev(0, idx, SCHEME_DOUBLE, n, 16, pts, 1, cts)
+    run = lambda: eng.encrypt_batch_dev(0, idx, SCHEME, n, 16, pts, 1, cts)
     setenv()
-    print(f"n={n} C={C}: default {timeit(run):.1f} us", flush=True)
+    blocks = n * (C if SCHEME == SCHEME_SINGLE else C + 1)
+    t = timeit(run)
+    print(f"n={n} C={C}: default {t:.1f} us = {blocks / t / 1e3:.1f} G blocks/s", flush=True)
     for half in (1, 0):
-        for parts in sorted({1, 2, 4, 8, 12, 16} & set(range(1, C + 1))):
-            for grid in (None, 128, 64):
+        for parts in sorted({1, 2, 3, 4, 6, 8, 12, 16} & set(range(1, C + 1))):
+            for grid in GRIDS:
                 setenv(half=half, parts=parts, grid=grid)
                 print(f"   half={half} parts={parts:2d} grid={grid}: {timeit(run):.1f} us", flush=True)
+    setenv()
+    t = timeit(run)          # again, with the clock where the sweep left it (the first line is measured on a cold chip)
+    print(f"   default again: {t:.1f} us = {blocks / t / 1e3:.1f} G blocks/s", flush=True)
