@@ -2030,13 +2030,23 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
         for (const Piece &pc : pieces) cut_tiles += pc.tiles * static_cast<uint64_t>(std::min(single_parts, pc.l1));
         all_half = 2 * cut_tiles < waves;       // a workgroup with fewer tiles than waves halves them by itself (n_full = 0 in the kernel)
     }
+    uint64_t cuttable_tiles = 0, fixed_items = 0;
+    for (const Piece &pc : pieces) {
+        if (pc.l1 >= 8 && !pc.ch->sum_out_dev) cuttable_tiles += pc.tiles;
+        else fixed_items += 2 * pc.tiles;
+    }
     std::vector<Piece> cut;
     for (const Piece &pc : pieces) {
         int parts = (pc.l1 + kMaxLinks - 1) / kMaxLinks;
         if (single_parts) {
             parts = std::max(parts, std::min(single_parts, pc.l1));
         } else if (all_half && 2 * total_tiles < waves && !pc.ch->sum_out_dev) {
-            const uint64_t want = waves / (2 * total_tiles);
+            // one half-tile item per wave of the chip, counting what the chains too short to be cut contribute anyway
+            // (mask precompute of config 3: a chain of 100 clients beside the one-output decrypt chain)
+            // (1.15 items per wave: 61,706 x 100 runs 117 us in 4 pieces, 107 in 8, 103-105 in 10-12, 109-115 in 16; 250,000 x 100 is best
+            // in 2 -- tests/perf/precompute_shape.py, sweep_chain.py)
+            const uint64_t aim = waves + waves * 15 / 100;
+            const uint64_t want = fixed_items < aim && cuttable_tiles ? (aim - fixed_items + cuttable_tiles) / (2 * cuttable_tiles) : 1;
             const int cap = std::max(1, pc.l1 / 4);
             parts = std::max<int>(parts, static_cast<int>(std::min<uint64_t>(want, static_cast<uint64_t>(cap))));
             parts = std::min(parts, std::max(1, kMaxChains / static_cast<int>(pieces.size())));
