@@ -8,6 +8,7 @@ run
 run --schedule partial-agg --no-cpu-baseline --no-e2e
 run --schedule auto --no-cpu-baseline --no-e2e
 FLASHE_RCCL_SELF_SENDRECV=1 run --force-dist --no-cpu-baseline --no-e2e
+run --config 1 --no-cpu-baseline
 run --config 3 --no-cpu-baseline
 run --config 3 --bits 23 --no-cpu-baseline
 run --config 4 --no-cpu-baseline
