@@ -5,12 +5,53 @@
  *
  * Built as flashe_amd/_pyconv.so and loaded with ctypes.PyDLL (the GIL is held during the calls); it links nothing:
  * the CPython symbols come from the running interpreter.  No arithmetic of the cipher happens here. */
+#define _GNU_SOURCE
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
 
 #define FAST_DIGITS 5          /* 30-bit digits read / written in place: values below 2^150 */
+
+/* Threads of the parallel read below: the CPUs this process may really use -- affinity mask capped by the cgroup CPU quota -- and at
+ * most 16.  OpenMP's own default is one thread per hardware thread of the HOST: a container with a 16-CPU quota on a 256-thread
+ * machine then runs 256 threads in 16 CPUs' worth of time slices, and a 262,144-element call that takes 2 ms took 10-100 ms
+ * (tests/perf/notebook_table2.py on the GPU box).  FLASHE_PYCONV_THREADS overrides. */
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+static int pyconv_threads(void)
+{
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 1;
+    const char *e = getenv("FLASHE_PYCONV_THREADS");
+    if (e && atoi(e) > 0) { cached = atoi(e); return cached; }
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");                       /* cgroup v2: "<quota|max> <period>" */
+    if (f) {
+        char q[32]; long period = 0;
+        if (fscanf(f, "%31s %ld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) {
+            const long c = atol(q) / period;
+            if (c >= 1 && c < n) n = (int)c;
+        }
+        fclose(f);
+    } else {
+        long quota = 0, period = 0;                                         /* cgroup v1 */
+        FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fp && fscanf(fq, "%ld", &quota) == 1 && fscanf(fp, "%ld", &period) == 1 && quota > 0 && period > 0) {
+            const long c = quota / period;
+            if (c >= 1 && c < n) n = (int)c;
+        }
+        if (fq) fclose(fq);
+        if (fp) fclose(fp);
+    }
+    if (n > 16) n = 16;
+    if (n < 1) n = 1;
+    cached = n;
+    return n;
+}
 
 /* value mod 2^(64 * limbs) of any Python int (negative values wrap like Python's `&`), two's complement */
 static int int_to_limbs(PyObject *o, int limbs, uint64_t *out)
@@ -80,7 +121,8 @@ int flashe_pyconv_ints_to_limbs(PyObject **objs, Py_ssize_t n, int limbs, uint64
 #if PY_VERSION_HEX < 0x030C0000
     /* (the in-place digit read relies on the PyLongObject layout of CPython <= 3.11: ob_size + ob_digit; 3.12 moved it to
      * long_value.lv_tag, where the generic path below takes everything) */
-#pragma omp parallel for schedule(static) reduction(| : leftovers) if (n >= 131072)
+    const int nthreads = n >= 131072 ? pyconv_threads() : 1;
+#pragma omp parallel for schedule(static) reduction(| : leftovers) num_threads(nthreads) if (nthreads > 1)
     for (Py_ssize_t i = 0; i < n; i++) {
         if (i + 16 < n) __builtin_prefetch(objs[i + 16], 0, 0);
         PyObject *o = objs[i];

@@ -18,8 +18,12 @@ for rep in range(6):
     t0 = time.perf_counter(); a, k = cm._to_limbs(obj, 1); t1 = time.perf_counter(); o = cm._from_limbs(a, k); t2 = time.perf_counter()
     t_in.append((t1 - t0) * 1e3); t_out.append((t2 - t1) * 1e3)
 assert int(o[5]) == int(obj[5])
-print("OMP_NUM_THREADS=%%s: ints -> limbs %%.1f ms, limbs -> ints %%.1f ms (best of 6)" %% (os.environ.get("OMP_NUM_THREADS", "default"), min(t_in), min(t_out)))
+print("FLASHE_PYCONV_THREADS=%%s: ints -> limbs %%.1f ms, limbs -> ints %%.1f ms (best of 6)" %% (os.environ.get("FLASHE_PYCONV_THREADS", "default (usable CPUs, at most 16)"), min(t_in), min(t_out)))
 ''' % ROOT
-for t in ("1", "4", "16", "1", "16"):
-    r = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, OMP_NUM_THREADS=t, OMP_WAIT_POLICY="passive"), capture_output=True, text=True)
+for t in ("1", "4", "16", "1", "16", None):
+    env = dict(os.environ)
+    env.pop("FLASHE_PYCONV_THREADS", None)
+    if t:
+        env["FLASHE_PYCONV_THREADS"] = t
+    r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
     print(r.stdout.strip() or "ERR " + r.stderr[-400:], flush=True)
