@@ -1086,6 +1086,16 @@ int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uin
         HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, n_minus == 1, 1, &job, n, n_jobs));
         return FLASHE_OK;
     }
+    if (ctx->limbs == 1 && n_add == 1 && n_minus <= 1) {
+        // b <= 64: the same fusion in the small-modulus form (FLASHE_SMALL_FUSED_REDUCE=0: two launches, the A/B switch)
+        static const bool off = getenv("FLASHE_SMALL_FUSED_REDUCE") && atoi(getenv("FLASHE_SMALL_FUSED_REDUCE")) == 0;
+        if (!off) {
+            const hipError_t e = launch_small_reduce_decrypt(ctx->env, iter, add_idx[0], n_minus == 1, n_minus ? minus_idx[0] : 0u, n, n_jobs, first, count,
+                                                             C, cts_dev, agg_out_dev, out_dev);
+            if (e == hipSuccess) return FLASHE_OK;
+            if (e != hipErrorNotSupported) HIP_TRY(ctx, e);
+        }
+    }
     uint64_t *agg = agg_out_dev;
     if (!agg) {
         rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, count));

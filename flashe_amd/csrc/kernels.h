@@ -115,6 +115,11 @@ constexpr int kMaxOps = 64;
 struct PtrTable { const uint64_t *p[kMaxOps]; };
 
 // ops: HOST array of C <= kMaxOps device pointers.  out may alias an operand.
+// b <= 64: out = (sum of the C operands + term(add) - [has_minus] term(minus)) mod 2^b on elements [first, first + count) in one pass
+// (pointers address element `first`; agg_out_dev may be null).  hipErrorNotSupported: reduce and decrypt in two launches instead.
+hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint32_t add_idx, bool has_minus, uint32_t minus_idx, uint64_t n,
+                                       uint32_t n_jobs, uint64_t first, uint64_t count, int C, const uint64_t *const *ops, uint64_t *agg_out_dev,
+                                       uint64_t *out_dev);
 hipError_t launch_aggregate_elem(const LaunchEnv &env, int C, const uint64_t *const *ops,
                                  uint64_t n, uint64_t *out_dev);
 

@@ -1599,6 +1599,224 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
     }
 }
 
+
+// ---- b <= 64: the reduce fused with the decrypt of its result (one add, at most one minus prefix) ----
+// out[j] = (sum_c ct_c[j] + term(add, j) - term(minus, j)) mod 2^b (jzf_aggregator.py:424-430 followed by jzf_flashe.py:570-571 with the
+// telescoped prefixes of :356-367) in ONE pass: a wave owns 64 consecutive AES blocks = 64 m consecutive elements, runs the add and the
+// minus block of its lane as one software-pipelined pair, puts the per-slot difference into its LDS row and then walks the 64 m
+// elements lane-contiguously, adding the C operands as it goes.  The element-wise reduce streams the C ciphertexts either way
+// (8 (C + 1) bytes per element); what this saves is the aggregate's round trip (write + read + write of 8 bytes per element) and a
+// launch, and the AES of one wave hides under the operand stream of the others.
+template <int CB, int EPL>
+__global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_kernel(const RoundKeys rk, const SmallParams p, uint32_t add_idx, uint32_t minus_idx,
+                                                                               int has_minus, uint64_t first, uint64_t count, uint64_t blk_first,
+                                                                               uint64_t blk_count, int C, const PtrTable ops, uint64_t *agg_out,
+                                                                               uint64_t *out)
+{
+    constexpr uint32_t WAVES = kSmallThreads / 64;
+    __shared__ uint32_t tab[kTabWords];
+    __shared__ uint32_t scratch[WAVES * 256 + 8];
+    const uint32_t iter = p.iter + p.te0[kIterShiftWord];
+    fill_tables(tab, p.te0);
+    const LaneRegs lr = lane_regs(tab);
+    const CtrPrefix pre_a = scalar_prefix(ctr_prefix(rk, lr, iter, add_idx, 0u));            // n < 2^32 (host-checked)
+    const CtrPrefix pre_m = scalar_prefix(ctr_prefix(rk, lr, iter, minus_idx, 0u));
+    const uint64_t J = p.n_jobs, d = p.n / J, r = p.n % J, m64 = static_cast<uint64_t>(p.m);
+    const uint32_t nb1_32 = static_cast<uint32_t>((d + 1 + m64 - 1) / m64), nb0_32 = static_cast<uint32_t>(d ? (d + m64 - 1) / m64 : 0);
+    const uint32_t d32 = static_cast<uint32_t>(d), r32 = static_cast<uint32_t>(r), m32 = static_cast<uint32_t>(p.m);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    uint32_t *row0 = scratch + wave * 256;
+    const u128 top = (static_cast<u128>(p.top_hi) << 64) | p.top_lo;
+    const uint64_t range_end = first + count;
+    const uint64_t n_tiles = (blk_count + 63u) / 64u;
+    const uint64_t *const *tab_ops = ops.p;
+    // a workgroup's sixteen waves take sixteen consecutive tiles at a time: 16 x 64 m contiguous elements of every operand
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * WAVES + wave; t < n_tiles; t += static_cast<uint64_t>(gridDim.x) * WAVES) {
+        const bool valid = t * 64u + lane < blk_count;
+        uint64_t j0 = 0;
+        int cnt = 0;
+        uint32_t ctr = 0;
+        small_block_params(static_cast<uint32_t>(blk_first + (valid ? t * 64u + lane : 0)), nb1_32, nb0_32, d32, r32, m32, p, &j0, &cnt, &ctr);
+        const CtrVar x = ctr_var(rk, lr, ctr);
+        uint32_t s[2][4];
+        ctr_round1(pre_a, x, s[0]);
+        ctr_round1(pre_m, x, s[1]);
+        if (!(has_minus & 0x100)) aes256_rounds<2, 2>(rk, lr, s);          // (0x100: timing probe without the rounds, FLASHE_SMALL_REDUCE_PROBE)
+        const u128 Sa = words_to_u128(s[0]), Sm = words_to_u128(s[1]);
+        const u128 D = (has_minus & 1) ? slot_diff(Sa, Sm, top, p.b) : Sa;
+        *reinterpret_cast<uint4 *>(row0 + 4 * lane) = make_uint4(static_cast<uint32_t>(D), static_cast<uint32_t>(D >> 32),
+                                                                 static_cast<uint32_t>(D >> 64), static_cast<uint32_t>(D >> 96));
+        __builtin_amdgcn_wave_barrier();
+        // the tile's elements: blocks are whole except the last one of a chunk, so the 64 blocks are runs of consecutive elements
+        // broken only after a partial block; each run is walked lane-contiguously
+        const uint64_t valid_mask = __ballot(valid);
+        uint64_t partial_mask = __ballot(valid && cnt < p.m);
+        const int n_valid = __popcll(valid_mask);
+        const uint32_t j0_lo = static_cast<uint32_t>(j0), j0_hi = static_cast<uint32_t>(j0 >> 32);
+        int lane_base = 0;
+        while (lane_base < n_valid) {
+            const int P = partial_mask ? static_cast<int>(__ffsll(static_cast<unsigned long long>(partial_mask))) - 1 : -1;
+            const uint64_t e0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_lo, lane_base)) |
+                                (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_hi, lane_base))) << 32);
+            const uint32_t n_elems = P >= 0 ? static_cast<uint32_t>(P - lane_base) * m32 + static_cast<uint32_t>(__builtin_amdgcn_readlane(cnt, P))
+                                            : static_cast<uint32_t>(n_valid - lane_base) * m32;
+            for (uint32_t x0 = lane; x0 < n_elems; x0 += 64u * EPL) {
+                // EPL elements per lane per step (x0, x0 + 64, ...), CB operands of each requested before the first is used
+                uint64_t k[EPL], sum[EPL];
+                bool ok[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    const uint32_t x = x0 + 64u * e;
+                    const uint64_t j = e0 + x;
+                    ok[e] = x < n_elems && j >= first && j < range_end;
+                    k[e] = ok[e] ? j - first : (e ? k[e - 1] : 0);
+                    sum[e] = 0;
+                }
+                for (int c = 0; c < C; c += CB) {
+                    uint64_t v[CB][EPL];
+#pragma unroll
+                    for (int u = 0; u < CB; u++) {
+                        const uint64_t *src = tab_ops[c + u < C ? c + u : C - 1];       // surplus slots of the last step re-read an operand and are not added
+#pragma unroll
+                        for (int e = 0; e < EPL; e++) v[u][e] = __builtin_nontemporal_load(src + k[e]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < CB; u++) {
+                        if (c + u < C) {
+#pragma unroll
+                            for (int e = 0; e < EPL; e++) sum[e] += v[u][e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    if (!ok[e]) continue;
+                    const uint32_t x = x0 + 64u * e;
+                    const uint32_t blk = static_cast<uint32_t>((static_cast<uint64_t>(x) * p.m_magic) >> 32);
+                    const uint32_t o = static_cast<uint32_t>(p.b) * (x - blk * m32);
+                    const uint32_t *w = row0 + 4 * (lane_base + blk) + (o >> 5);
+                    const uint32_t sh = o & 31u;
+                    uint64_t val = ((static_cast<uint64_t>(w[1]) << 32) | w[0]) >> sh;
+                    if (sh) val |= static_cast<uint64_t>(w[2]) << (64u - sh);
+                    if (agg_out) __builtin_nontemporal_store(sum[e] & p.mask_lo, agg_out + k[e]);
+                    __builtin_nontemporal_store((sum[e] + val) & p.mask_lo, out + k[e]);
+                }
+            }
+            if (P < 0) break;
+            lane_base = P + 1;
+            partial_mask &= partial_mask - 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
+// The same for b <= 32 (m >= 4) in tiles of 32 blocks: lanes 0-31 run the add-stream block, lanes 32-63 the minus-stream block of the
+// SAME 32 AES blocks (one block per lane), both go to the wave's LDS row, and the walk takes slot(add) - slot(minus) per element.
+// A 64-block tile is 64 m elements -- 1,024 at b = 8 -- and a 1e7-element vector then has only 2.4 tiles per wave of the chip: the
+// last, partly filled round of tiles cost up to 26 % (a wave streams no faster because its neighbours are idle).  Half the tile size
+// halves that, and with b <= 32 the sums and the slots are 32-bit: operands are read as 4-byte low words.
+// (Built and dropped: the sixteen waves of a workgroup meeting at a barrier and walking their 512 m elements TOGETHER, 1,024
+// consecutive elements of every operand per step -- 0.19 ms without the AES rounds where the per-wave walk takes 0.18, and with them
+// 0.23 against 0.187: one workgroup per CU in lockstep means nobody streams while everybody runs its rounds.)
+template <int CB>
+__global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kernel(const RoundKeys rk, const SmallParams p, uint32_t add_idx,
+                                                                                     uint32_t minus_idx, int has_minus, uint64_t first, uint64_t count,
+                                                                                     uint64_t blk_first, uint64_t blk_count, int C, const PtrTable ops,
+                                                                                     uint64_t *agg_out, uint64_t *out)
+{
+    constexpr uint32_t WAVES = kSmallThreads / 64, EPL = 2;
+    __shared__ uint32_t tab[kTabWords];
+    __shared__ uint32_t scratch[WAVES * 256 + 8];
+    const uint32_t iter = p.iter + p.te0[kIterShiftWord];
+    fill_tables(tab, p.te0);
+    const LaneRegs lr = lane_regs(tab);
+    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, l32 = lane & 31u;
+    const CtrPrefix pre = ctr_prefix(rk, lr, iter, half ? minus_idx : add_idx, 0u);          // n < 2^32 (host-checked)
+    const uint64_t J = p.n_jobs, d = p.n / J, r = p.n % J, m64 = static_cast<uint64_t>(p.m);
+    const uint32_t nb1_32 = static_cast<uint32_t>((d + 1 + m64 - 1) / m64), nb0_32 = static_cast<uint32_t>(d ? (d + m64 - 1) / m64 : 0);
+    const uint32_t d32 = static_cast<uint32_t>(d), r32 = static_cast<uint32_t>(r), m32 = static_cast<uint32_t>(p.m);
+    const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    uint32_t *row0 = scratch + wave * 256;
+    const uint32_t mask = static_cast<uint32_t>(p.mask_lo);
+    const uint64_t range_end = first + count;
+    const uint64_t n_tiles = (blk_count + 31u) / 32u;
+    const uint64_t *const *tab_ops = ops.p;
+    const bool drop = half && !(has_minus & 1);                   // no minus prefix: the upper half contributes zeros
+    for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * WAVES + wave; t < n_tiles; t += static_cast<uint64_t>(gridDim.x) * WAVES) {
+        const bool valid = t * 32u + l32 < blk_count;
+        uint64_t j0 = 0;
+        int cnt = 0;
+        uint32_t ctr = 0;
+        small_block_params(static_cast<uint32_t>(blk_first + (valid ? t * 32u + l32 : 0)), nb1_32, nb0_32, d32, r32, m32, p, &j0, &cnt, &ctr);
+        const CtrVar x = ctr_var(rk, lr, ctr);
+        uint32_t s[1][4];
+        ctr_round1(pre, x, s[0]);
+        if (!(has_minus & 0x100)) aes256_rounds<1, 2>(rk, lr, s);        // (0x100: timing probe without the rounds)
+        // row word order = little-endian words of the 128-bit block value (word 0 = bits 0..31)
+        *reinterpret_cast<uint4 *>(row0 + 4 * lane) = drop ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(s[0][3], s[0][2], s[0][1], s[0][0]);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t valid_mask = static_cast<uint32_t>(__ballot(valid));
+        uint32_t partial_mask = static_cast<uint32_t>(__ballot(valid && cnt < p.m));
+        const int n_valid = __popc(valid_mask);
+        const uint32_t j0_lo = static_cast<uint32_t>(j0), j0_hi = static_cast<uint32_t>(j0 >> 32);
+        int lane_base = 0;
+        while (lane_base < n_valid) {
+            const int P = partial_mask ? static_cast<int>(__ffs(partial_mask)) - 1 : -1;
+            const uint64_t e0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_lo, lane_base)) |
+                                (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_hi, lane_base))) << 32);
+            const uint32_t n_elems = P >= 0 ? static_cast<uint32_t>(P - lane_base) * m32 + static_cast<uint32_t>(__builtin_amdgcn_readlane(cnt, P))
+                                            : static_cast<uint32_t>(n_valid - lane_base) * m32;
+            for (uint32_t x0 = lane; x0 < n_elems; x0 += 64u * EPL) {
+                uint64_t k[EPL];
+                uint32_t sum[EPL];
+                bool ok[EPL];
+#pragma unroll
+                for (uint32_t e = 0; e < EPL; e++) {
+                    const uint32_t xx = x0 + 64u * e;
+                    const uint64_t j = e0 + xx;
+                    ok[e] = xx < n_elems && j >= first && j < range_end;
+                    k[e] = ok[e] ? j - first : (e ? k[e - 1] : 0);
+                    sum[e] = 0;
+                }
+                for (int c = 0; c < C; c += CB) {
+                    uint32_t v[CB][EPL];
+#pragma unroll
+                    for (int u = 0; u < CB; u++) {
+                        const uint64_t *src = tab_ops[c + u < C ? c + u : C - 1];       // surplus slots of the last step re-read an operand and are not added
+#pragma unroll
+                        for (uint32_t e = 0; e < EPL; e++) v[u][e] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src + k[e]));
+                    }
+#pragma unroll
+                    for (int u = 0; u < CB; u++) {
+                        if (c + u < C) {
+#pragma unroll
+                            for (uint32_t e = 0; e < EPL; e++) sum[e] += v[u][e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (uint32_t e = 0; e < EPL; e++) {
+                    if (!ok[e]) continue;
+                    const uint32_t xx = x0 + 64u * e;
+                    const uint32_t blk = static_cast<uint32_t>((static_cast<uint64_t>(xx) * p.m_magic) >> 32);
+                    const uint32_t o = static_cast<uint32_t>(p.b) * (xx - blk * m32);
+                    const uint32_t *wa = row0 + 4 * (lane_base + blk) + (o >> 5), *wm = wa + 128;
+                    // bits o .. o + 31 of the block: o + b <= 128, so past word 3 only bits that the mask removes are read
+                    const uint32_t val = __builtin_amdgcn_alignbit(wa[1], wa[0], o & 31u) - __builtin_amdgcn_alignbit(wm[1], wm[0], o & 31u);
+                    if (agg_out) __builtin_nontemporal_store(static_cast<uint64_t>(sum[e] & mask), agg_out + k[e]);
+                    __builtin_nontemporal_store(static_cast<uint64_t>((sum[e] + val) & mask), out + k[e]);
+                }
+            }
+            if (P < 0) break;
+            lane_base = P + 1;
+            partial_mask &= partial_mask - 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Known-answer helper: raw AES of nblk blocks given as big-endian words.
 __global__ __launch_bounds__(kPrfThreads) void aes_blocks_kernel(const RoundKeys rk, const uint32_t *te0, uint32_t nblk,
                                                                  const uint32_t *in, uint32_t *out)
@@ -2104,12 +2322,9 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
     return hipSuccess;
 }
 
-// b <= 64 form of launch_prf_chains.  hipErrorNotSupported (-> job-table kernel) for what this kernel does not carry: a fused
-// codec, vectors of 2^32 elements or more.
-static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs)
+// the per-launch constants of the b <= 64 chained kernels (n < 2^32)
+static SmallParams small_params_of(const LaunchEnv &env, uint32_t iter, uint64_t n, uint32_t n_jobs)
 {
-    if (env.codec || n >= (1ull << 32) || n == 0) return hipErrorNotSupported;
-    for (int i = 0; i < n_chains; i++) if (chains[i].sum_out_dev) return hipErrorNotSupported;      // the fused sum lives in the wide kernel
     SmallParams p{};
     p.n = n; p.n_jobs = n_jobs; p.iter = iter; p.b = env.b; p.m = 128 / env.b; p.te0 = env.te0_dev;
     { static const int v = getenv("FLASHE_SMALL_DIRECT") ? atoi(getenv("FLASHE_SMALL_DIRECT")) : 1; p.no_direct = v == 0 ? 1 : v == 2 ? 2 : 0; }
@@ -2119,11 +2334,71 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
     unsigned __int128 top = 0;
     for (int t = 0; t < p.m; t++) top |= static_cast<unsigned __int128>(1) << (env.b * t + env.b - 1);
     p.top_lo = static_cast<uint64_t>(top); p.top_hi = static_cast<uint64_t>(top >> 64);
-    {
-        const uint64_t mm = p.m, d = n / n_jobs, nb1 = (d + 1 + mm - 1) / mm, nb0 = d ? (d + mm - 1) / mm : 0;
-        p.nb1_magic = nb1 > 1 && nb1 < (1ull << 32) ? static_cast<uint32_t>((1ull << 32) / nb1) : 0;
-        p.nb0_magic = nb0 > 1 && nb0 < (1ull << 32) ? static_cast<uint32_t>((1ull << 32) / nb0) : 0;
+    const uint64_t mm = p.m, d = n / n_jobs, nb1 = (d + 1 + mm - 1) / mm, nb0 = d ? (d + mm - 1) / mm : 0;
+    p.nb1_magic = nb1 > 1 && nb1 < (1ull << 32) ? static_cast<uint32_t>((1ull << 32) / nb1) : 0;
+    p.nb0_magic = nb0 > 1 && nb0 < (1ull << 32) ? static_cast<uint32_t>((1ull << 32) / nb0) : 0;
+    return p;
+}
+
+// The reduce fused with the decrypt of its result for b <= 64 (small_reduce_decrypt_kernel): elements [first, first + count) of an
+// n-element vector; the C operand pointers, agg_out (may be null) and out address element `first`.  hipErrorNotSupported for what
+// the kernel does not carry (the caller then reduces and decrypts in two launches).
+hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint32_t add_idx, bool has_minus, uint32_t minus_idx, uint64_t n,
+                                       uint32_t n_jobs, uint64_t first, uint64_t count, int C, const uint64_t *const *ops, uint64_t *agg_out_dev,
+                                       uint64_t *out_dev)
+{
+    if (env.b > 64 || env.codec || n >= (1ull << 32) || n == 0 || n_jobs == 0 || C < 1 || C > kMaxOps) return hipErrorNotSupported;
+    if (env.prf_backend != PRF_AUTO && env.prf_backend != PRF_TABLE) return hipErrorNotSupported;
+    if (count == 0) return hipSuccess;
+    const SmallParams p = small_params_of(env, iter, n, n_jobs);
+    const uint64_t bf = block_of(first, n, n_jobs, p.m), bc = block_of(first + count - 1, n, n_jobs, p.m) - bf + 1;
+    PtrTable t;
+    for (int c = 0; c < kMaxOps; c++) t.p[c] = c < C ? ops[c] : nullptr;
+    const uint64_t tiles = (bc + 63) / 64, groups = (tiles + kSmallThreads / 64 - 1) / (kSmallThreads / 64), cus = static_cast<uint64_t>(env.num_cus);
+    const int grid = static_cast<int>(groups < cus ? groups : cus);
+    // operands per step (two elements per lane per step): FEWER streams at once stream faster at full occupancy -- ten 1e7-element
+    // operands without the AES rounds: 0.180 ms in steps of 2, 0.188-0.193 in steps of 4-5, 0.225 in steps of 8; four elements per lane
+    // per step changed nothing at m = 6 and wastes slots at m = 2 (tests/perf/small_reduce_decrypt.py; FLASHE_SMALL_REDUCE_CB = 1, 2, 4, 8)
+    int cb = C < 2 ? 1 : 2;
+    { static const int force = getenv("FLASHE_SMALL_REDUCE_CB") ? atoi(getenv("FLASHE_SMALL_REDUCE_CB")) : 0; if (force >= 1) cb = force; }
+    static const int probe = getenv("FLASHE_SMALL_REDUCE_PROBE") ? 0x100 : 0;
+#define SRD_LAUNCH(CB)                                                                                                                      \
+    hipLaunchKernelGGL((small_reduce_decrypt_kernel<CB, 2>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, p, add_idx, minus_idx, \
+                       (has_minus ? 1 : 0) | probe, first, count, bf, bc, C, t, agg_out_dev, out_dev)
+    static const bool split_off = getenv("FLASHE_SMALL_REDUCE_SPLIT") && atoi(getenv("FLASHE_SMALL_REDUCE_SPLIT")) == 0;
+    if (env.b <= 32 && !split_off) {
+        // 32-block tiles, the two streams in the two halves of the wave (see small_reduce_decrypt_split_kernel)
+        const uint64_t tiles32 = (bc + 31) / 32, groups32 = (tiles32 + kSmallThreads / 64 - 1) / (kSmallThreads / 64);
+        const int grid32 = static_cast<int>(groups32 < cus ? groups32 : cus);
+#define SRDS_LAUNCH(CB)                                                                                                                       \
+    hipLaunchKernelGGL((small_reduce_decrypt_split_kernel<CB>), dim3(grid32), dim3(kSmallThreads), 0, env.stream, env.rk, p, add_idx, minus_idx, \
+                       (has_minus ? 1 : 0) | probe, first, count, bf, bc, C, t, agg_out_dev, out_dev)
+        switch (cb) {
+        case 1: SRDS_LAUNCH(1); break;
+        case 2: case 3: SRDS_LAUNCH(2); break;
+        case 4: case 5: case 6: case 7: SRDS_LAUNCH(4); break;
+        default: SRDS_LAUNCH(8); break;
+        }
+#undef SRDS_LAUNCH
+        return hipGetLastError();
     }
+    switch (cb) {
+    case 1: SRD_LAUNCH(1); break;
+    case 2: case 3: SRD_LAUNCH(2); break;
+    case 4: case 5: case 6: case 7: SRD_LAUNCH(4); break;
+    default: SRD_LAUNCH(8); break;
+    }
+#undef SRD_LAUNCH
+    return hipGetLastError();
+}
+
+// b <= 64 form of launch_prf_chains.  hipErrorNotSupported (-> job-table kernel) for what this kernel does not carry: a fused
+// codec, vectors of 2^32 elements or more.
+static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs)
+{
+    if (env.codec || n >= (1ull << 32) || n == 0) return hipErrorNotSupported;
+    for (int i = 0; i < n_chains; i++) if (chains[i].sum_out_dev) return hipErrorNotSupported;      // the fused sum lives in the wide kernel
+    const SmallParams p = small_params_of(env, iter, n, n_jobs);
     struct Piece { const PrfChain *ch; int l0, l1; uint64_t blk_first, blk_count; };
     std::vector<Piece> pieces;
     uint64_t total_blocks = 0;

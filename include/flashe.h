@@ -256,8 +256,9 @@ int flashe_aggregate_elem(flashe_ctx *ctx, int C, const uint64_t *const *cts,
 /* The element-wise reduce fused with the decrypt of its result (new): agg = sum_c cts[c] mod 2^b
  * (stored to agg_out_dev unless NULL), out = agg + sum term(add) - sum term(minus) -- exactly
  * flashe_aggregate_elem_dev followed by flashe_decrypt_range_dev on elements [first, first + count)
- * of the n-element vector, in one pass over the ciphertexts when they are equally spaced in
- * memory (one launch, the aggregate never re-read); any other shape runs the two calls.
+ * of the n-element vector, in ONE pass over the ciphertexts (one launch, the aggregate never
+ * re-read) for one add and at most one minus prefix -- int_bits > 64: ciphertexts equally spaced
+ * in memory; int_bits <= 64: any C <= 64 operands (n < 2^32); any other shape runs the two calls.
  * cts_dev / agg_out_dev / out_dev address element `first`. */
 int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter,
                                        const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,

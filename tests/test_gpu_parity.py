@@ -382,10 +382,14 @@ def test_prf_jobs_vs_oracle(E, oracle, b, n, J):
 
 
 @pytest.mark.parametrize("b,n,J,C", [(128, 70_001, 16, 10), (100, 5000, 3, 3), (128, 2_100_000, 1, 2), (128, 300_000, 16, 13), (64, 30_000, 16, 4),
-                                     (20, 9999, 7, 70)])
+                                     (20, 9999, 7, 70), (64, 1_000_003, 16, 10), (20, 1_000_003, 16, 10), (23, 61_706, 16, 5), (7, 4099, 3, 2),
+                                     (1, 777, 1, 3), (33, 50_000, 8, 4), (32, 50_001, 5, 11), (16, 200_000, 16, 64), (40, 99_999, 16, 3),
+                                     (25, 1100, 2000, 2), (20, 70_000, 16, 17), (64, 70_001, 16, 9)])
 def test_aggregate_decrypt_fused_vs_oracle(E, oracle, b, n, J, C):
     """flashe_aggregate_decrypt_range_dev == aggregate_elem followed by decrypt: equally spaced ciphertexts (one launch for
-    b > 64), scattered ones, prefix lists, sub-ranges; with and without storing the aggregate."""
+    b > 64), scattered ones, prefix lists, sub-ranges; with and without storing the aggregate.  b <= 64 with one add and at most one
+    minus prefix is one launch too (small_reduce_decrypt_kernel: chunk ends inside a wave's tile, more jobs than elements, 64 operands;
+    70 operands and prefix lists take the two-launch form)."""
     eng = make(E, b)
     Lb = L(b)
     rng = np.random.Generator(np.random.PCG64(n + C))
