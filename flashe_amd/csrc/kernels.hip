@@ -515,6 +515,15 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
     fill_tables(tab, te0);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+#ifdef FLASHE_KIND2_STAGGER
+    // experiment: odd waves run one dummy pair of blocks first, so that half the workgroup is half an AES pass out of phase with the
+    // other half (do the waves of a CU otherwise alternate TOGETHER between waiting for their operands and running their rounds?)
+    if (KIND == 2 && ((threadIdx.x >> 6) & 1u)) {
+        uint32_t s[2][4] = {{threadIdx.x, 1u, 2u, 3u}, {4u, 5u, 6u, threadIdx.x}};
+        aes256_rounds<2, 2>(rk, lr, s);
+        asm volatile("" ::"v"(s[0][0] ^ s[1][0]));
+    }
+#endif
     const uint64_t n_big = tb.big_end_of(n_vec - 1), total_tiles = n_big + tb.small_end_of(n_vec - 1);
     const uint32_t wave64 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
     const uint32_t lane = threadIdx.x & 63u;

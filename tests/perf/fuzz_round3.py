@@ -5,6 +5,7 @@
   draws   flashe_mt19937_random_dev         (np.random.random continued from an arbitrary stream position, state handed back)
   twins   flashe_encrypt / _aggregate_elem / _decrypt on host pointers with random chunk sizes of the copy pipeline
   handles DeviceVector blocks recycled through the caching allocator between calls of different sizes
+  fused   flashe_aggregate_decrypt_range_dev at b <= 64 (the one-launch reduce + decrypt and its fallbacks: sub-ranges, up to 65 operands)
 usage: fuzz_round3.py [cases per family] [seed] [families, comma separated]"""
 import os
 import sys
@@ -197,7 +198,43 @@ def fuzz_handles(rng, case):
     return f"b={b} C={C}"
 
 
-FAMILIES = {"sum": fuzz_sum, "edges": fuzz_edges, "draws": fuzz_draws, "twins": fuzz_twins, "handles": fuzz_handles}
+def fuzz_fused(rng, case):
+    """flashe_aggregate_decrypt_range_dev at b <= 64: one launch (small_reduce_decrypt kernels) or the two-launch fallback."""
+    b = int(rng.choice([64, 64, 63, 48, 40, 33, 32, 32, 31, 25, 23, 20, 20, 17, 16, 12, 9, 8, 7, 5, 3, 2, 1]))
+    n = pick_n(rng) // 3 + 1
+    J = int(rng.choice([1, 2, 3, 7, 16, 16, 33, 1000, n + 5]))
+    C = int(rng.choice([1, 2, 3, 4, 5, 9, 10, 11, 16, 17, 33, 64, 65]))
+    if C * n > 30_000_000:
+        n = 30_000_000 // C
+    it = int(rng.integers(0, 2 ** 32))
+    kind = rng.integers(0, 5)
+    add, minus = [([C], [0]), ([int(rng.integers(0, 2 ** 32 - 1))], []), ([int(rng.integers(0, 100))], [int(rng.integers(0, 100))]),
+                  ([3, 9], [0, 5]), ([], [1, 2])][kind]
+    first = int(rng.integers(0, n)) if rng.random() < 0.5 else 0
+    count = int(rng.integers(1, n - first + 1)) if rng.random() < 0.6 else n - first
+    keep = rng.random() < 0.5
+    eng = E.Engine(KEY, b, device=0)
+    cts = [rng.integers(0, 2 ** 64, n, dtype=np.uint64) & np.uint64((1 << b) - 1 if b < 64 else 2 ** 64 - 1) for _ in range(C)]
+    if rng.random() < 0.2 and b <= 32:
+        for c in cts:
+            c |= np.uint64(0xABCD) << np.uint64(40)          # junk above bit 32 of the container: only the value mod 2^b counts
+    d = [eng.upload(c) for c in cts]
+    out, ao = eng.alloc_vec(count), eng.alloc_vec(count)
+    eng.aggregate_decrypt_range_dev(it, add, minus, n, J, first, count, [x.ptr + 8 * first for x in d], ao if keep else None, out)
+    m = np.uint64((1 << b) - 1 if b < 64 else 2 ** 64 - 1)
+    agg = np.zeros(n, dtype=np.uint64)
+    for c in cts:
+        agg += c
+    agg &= m
+    want = orc.combine(b, agg.reshape(-1, 1)[first:first + count], orc.mask_sum(KEY, it, add, n, J, b)[first:first + count],
+                       orc.mask_sum(KEY, it, minus, n, J, b)[first:first + count])
+    assert np.array_equal(out.download(np.uint64, count).reshape(-1, 1), want), ("fused/out", case, b, n, J, C, add, minus, first, count)
+    if keep:
+        assert np.array_equal(ao.download(np.uint64, count), agg[first:first + count]), ("fused/agg", case, b, n, J, C, first, count)
+    return f"b={b} n={n} J={J} C={C} add={add} minus={minus} first={first} count={count} keep={keep}"
+
+
+FAMILIES = {"sum": fuzz_sum, "edges": fuzz_edges, "draws": fuzz_draws, "twins": fuzz_twins, "handles": fuzz_handles, "fused": fuzz_fused}
 
 
 def main():
