@@ -1039,9 +1039,12 @@ int flashe_aggregate_elem_dev(flashe_ctx *ctx, int C, const uint64_t *const *cts
 {
     CHECK_CTX(ctx);
     if (C < 1 || !cts_dev || (n && !out_dev)) return fail(ctx, FLASHE_EINVAL, "aggregate_elem: bad arguments (C = %d)", C);
-    if (!aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    // two-limb vectors: 16-byte aligned; one-limb vectors: 8 bytes suffice (a sub-range may start at an odd element: slower 8-byte form)
+    const uintptr_t need = ctx->limbs == 2 ? 15u : 7u;
+    if (reinterpret_cast<uintptr_t>(out_dev) & need) return fail(ctx, FLASHE_EINVAL, "device vectors must be %d-byte aligned", static_cast<int>(need + 1));
     for (int c = 0; c < C; c++)
-        if (!cts_dev[c] || !aligned16(cts_dev[c])) return fail(ctx, FLASHE_EINVAL, "operand %d is null or not 16-byte aligned", c);
+        if (!cts_dev[c] || (reinterpret_cast<uintptr_t>(cts_dev[c]) & need))
+            return fail(ctx, FLASHE_EINVAL, "operand %d is null or not %d-byte aligned", c, static_cast<int>(need + 1));
     if (n == 0) return FLASHE_OK;
     // at most kMaxOps operands per pass; later passes fold the running sum (out) back in
     std::vector<const uint64_t *> ops;

@@ -515,15 +515,6 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
     fill_tables(tab, te0);
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
-#ifdef FLASHE_KIND2_STAGGER
-    // experiment: odd waves run one dummy pair of blocks first, so that half the workgroup is half an AES pass out of phase with the
-    // other half (do the waves of a CU otherwise alternate TOGETHER between waiting for their operands and running their rounds?)
-    if (KIND == 2 && ((threadIdx.x >> 6) & 1u)) {
-        uint32_t s[2][4] = {{threadIdx.x, 1u, 2u, 3u}, {4u, 5u, 6u, threadIdx.x}};
-        aes256_rounds<2, 2>(rk, lr, s);
-        asm volatile("" ::"v"(s[0][0] ^ s[1][0]));
-    }
-#endif
     const uint64_t n_big = tb.big_end_of(n_vec - 1), total_tiles = n_big + tb.small_end_of(n_vec - 1);
     const uint32_t wave64 = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x & ~63u));
     const uint32_t lane = threadIdx.x & 63u;
@@ -2627,6 +2618,18 @@ __global__ __launch_bounds__(kStreamThreads) void aggregate_elem_kernel(int C, c
     }
 }
 
+// one-limb vectors whose operands are only 8-byte aligned (a sub-range that starts at an odd element): one element per lane
+__global__ __launch_bounds__(kStreamThreads) void aggregate_elem8_kernel(int C, const PtrTable ops, uint64_t n, uint64_t *out, uint64_t mask_lo)
+{
+    const uint64_t *const *tab = ops.p;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n; j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        uint64_t a = 0;
+#pragma unroll 4
+        for (int c = 0; c < C; c++) a += __builtin_nontemporal_load(tab[c] + j);
+        __builtin_nontemporal_store(a & mask_lo, out + j);
+    }
+}
+
 static inline PtrTable make_table(int C, const uint64_t *const *ops)
 {
     PtrTable t;
@@ -2642,6 +2645,13 @@ hipError_t launch_aggregate_elem(const LaunchEnv &env, int C, const uint64_t *co
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
     const uint64_t n_limbs = env.b > 64 ? 2 * n : n;
+    bool a16 = (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0;
+    for (int c = 0; c < C; c++) a16 = a16 && (reinterpret_cast<uintptr_t>(ops[c]) & 15u) == 0;
+    if (!a16) {
+        if (env.b > 64) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(aggregate_elem8_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n, out_dev, lo);
+        return hipGetLastError();
+    }
     // a lane has C 16-byte loads in flight per slot: with many operands FEWER resident waves stream faster (measured at
     // C = 10, n = 1e7: 8 / 4 / 2 / 1 blocks per CU -> 5.5 / 5.9 / 6.0 / 4.4 TB/s; two operands want 4-8)
     const int bpc = C >= 3 ? 2 : 8;

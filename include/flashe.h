@@ -248,7 +248,8 @@ int flashe_combine_batch_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint6
 
 /* ---- arbiter reduce ----------------------------------------------------------------- */
 /* Element-wise: out[j] = sum_c cts[c][j] mod 2^b -- jzf_aggregator.py:424-430.
- * cts is a HOST array of C pointers (device pointers for _dev). */
+ * cts is a HOST array of C pointers (device pointers for _dev).  Device vectors of two-limb elements must be
+ * 16-byte aligned; one-limb vectors 8-byte (16-byte aligned operands take the faster 16-byte form). */
 int flashe_aggregate_elem_dev(flashe_ctx *ctx, int C, const uint64_t *const *cts_dev,
                               uint64_t n, uint64_t *out_dev);
 int flashe_aggregate_elem(flashe_ctx *ctx, int C, const uint64_t *const *cts,
