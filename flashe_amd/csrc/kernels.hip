@@ -3012,7 +3012,11 @@ __global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t total,
 // two LDS atomics; the low one returns the old value, which tells the lane exactly whether ITS add wrapped -- integer
 // adds commute, so the sum does not depend on the order), then writes src + accumulator (or src - accumulator, base
 // instead of src when there is none) for the WHOLE span: the dense output is written exactly once, coalesced.
-constexpr int kSpan = 4096;         // positions per span: 64 KiB of 128-bit accumulators, two workgroups per CU
+#ifndef FLASHE_SPAN
+#define FLASHE_SPAN 4096
+#endif
+constexpr int kSpan = FLASHE_SPAN;  // positions per span: 64 KiB of 128-bit accumulators, two workgroups per CU (8,192 = 128 KiB, one workgroup per CU,
+                                    // twice as long slices per client: aggregate 0.171 against 0.169 ms, fused decrypt 0.442 against 0.420 -- config 5)
 constexpr int kSpanThreads = 1024;
 constexpr int kSpanBatch = 4;       // entries whose loads a lane keeps in flight at once
 struct ScatterTable {
