@@ -608,7 +608,10 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
             }
             acc += words_to_u128(s[0]);
             if (DBL) acc -= words_to_u128(s[DBL ? 1 : 0]);
-            st128(out + 2 * k, acc & mask);   // plain store: measured, part of it is still in the Infinity Cache for the reduce
+            // plain store: measured, part of a ciphertext is still in the Infinity Cache for the reduce that follows; the result of the
+            // fused reduce + decrypt is read by nobody on the device: non-temporal (0.379 -> 0.367 ms for ten 1e7-element operands)
+            if (KIND == 2) st128_nt(out + 2 * k, acc & mask);
+            else st128(out + 2 * k, acc & mask);
         }
     }
 }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two BUILDS of the library alternated inside one process: the reduce fused with the decrypt of its result (ten 1e7-element
 128-bit ciphertexts in, one decrypted vector out) and the whole two-launch round, HIP-event times.
-usage: ab_two_libs_reduce.py <other .so in flashe_amd/> [C ...]"""
+usage: ab_two_libs_reduce.py <other .so in flashe_amd/> [more .so ...] [C ...]"""
 import os
 import sys
 
@@ -19,10 +19,12 @@ def engine_from(name, b):
     return Engine(bytes(range(32)), b)
 
 
-other = sys.argv[1]
+others = [a for a in sys.argv[1:] if a.endswith(".so")]
 n, b = 10_000_000, 128
-for C in [int(v) for v in sys.argv[2:]] or [10, 4, 16]:
-    engs = {"libflashe_hip.so": engine_from("libflashe_hip.so", b), other: engine_from(other, b)}
+for C in [int(v) for v in sys.argv[1:] if not v.endswith(".so")] or [10, 4, 16]:
+    engs = {"libflashe_hip.so": engine_from("libflashe_hip.so", b)}
+    for o in others:
+        engs[o] = engine_from(o, b)
     runs = {}
     for name, eng in engs.items():
         pts = [eng.upload(np.random.default_rng(c).integers(0, 2 ** 62, n, dtype=np.uint64)) for c in range(C)]
