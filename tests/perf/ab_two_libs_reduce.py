@@ -34,8 +34,11 @@ for C in [int(v) for v in sys.argv[1:] if not v.endswith(".so")] or [10, 4, 16]:
         enc = (lambda e=eng, p=pts, v=views: e.encrypt_batch_dev(0, list(range(C)), SCHEME_DOUBLE, n, 16, p, 1, v))
         red = (lambda e=eng, v=views, o=out: e.aggregate_decrypt_range_dev(0, [C], [0], n, 16, 0, n, v, None, o))
         enc()
-        runs[name] = (eng, red, (lambda a=enc, r=red: (a(), r())), eng.event(), eng.event(), (pts, cts, out))
-    for what, idx in (("reduce+decrypt", 1), ("round", 2)):
+        psum = eng.alloc_vec(n)
+        part = (lambda e=eng, p=pts, v=views, q=psum, o=out: (e.encrypt_batch_sum_dev(0, list(range(C)), SCHEME_DOUBLE, n, 16, p, 1, v, q),
+                                                               e.decrypt_dev(0, [C], [0], n, 16, q, o)))
+        runs[name] = (eng, red, (lambda a=enc, r=red: (a(), r())), eng.event(), eng.event(), (pts, cts, out, psum), part)
+    for what, idx in (("reduce+decrypt", 1), ("round", 2), ("partial-agg round", 6)):
         res = {k: [] for k in engs}
         for rep in range(6):
             for name, r in runs.items():
