@@ -78,6 +78,9 @@ def parse():
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
     ap.add_argument("--no-partial-agg", action="store_true",
                     help="N > 1: keep the separate local reduce in the sequential round instead of letting the encrypt launch write the partial aggregate")
+    ap.add_argument("--layout", choices=["u64", "u32"], default="u64",
+                    help="u32 (config 2, --bits <= 32): plaintexts and ciphertexts as uint32 arrays -- the compact layout of the *_u32_dev entry "
+                         "points; the default is the ABI's one-limb layout (uint64 per element)")
     ap.add_argument("--no-unchained", action="store_true", help="skip the FLASHE_CHAIN=0 reference measurement (config 2, one GPU)")
     ap.add_argument("--cus-free", type=int, default=None,
                     help="PRF launches leave this many CUs free for the RCCL transfer kernels of the overlapped schedules (default: 0, or "
@@ -348,7 +351,9 @@ def main(comm_factory=None, device_override=None):
             comm = RcclComm.from_env(eng) if (world > 1 or args.force_dist) else None
         ops = HipOps(eng, side, comm)
 
-        if cfg in (2, 4):
+        if cfg == 2 and args.layout == "u32":
+            result = bench_compact(args, n, ops, rank, world, out)
+        elif cfg in (2, 4):
             result = bench_dense(args, cfg, n, ops, rank, world, out, wd, state)
         elif cfg == 1:
             result = bench_plumbing(args, n, ops, rank, world, out)
@@ -957,6 +962,69 @@ def bench_precompute(args, n, ops, rank, world, out):
     })
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(J, b, C, host_pts, n)
+    return out
+
+
+# ---- config 2 at int_bits <= 32 in the compact layout (uint32 per element) --------------------------------------------------------
+def bench_compact(args, n, ops, rank, world, out):
+    """The config-2 round -- C encrypts in one chained launch, the C-way reduce fused with the decrypt of its result -- on uint32
+    plaintext / ciphertext arrays (flashe_encrypt_batch_u32_dev, flashe_aggregate_decrypt_u32_dev): the same values as the one-limb
+    layout, half the bytes.  Several GPUs: independent replicas."""
+    import numpy as np
+    from oracle import flashe_oracle as orc          # parity gate only (before the timed region)
+    from flashe_amd.engine import SCHEME_DOUBLE
+    eng = ops.engine
+    b, K, W, J = args.bits, args.steps, args.warmup, args.n_jobs
+    if b > 32:
+        raise SystemExit("--layout u32 needs --bits <= 32")
+    C = args.clients or 10
+    host_pts = [plaintext(c, n, b) for c in range(C)]
+    pts = [ops.upload(p.astype(np.uint32)) for p in host_pts]
+    cts = [eng.alloc(4 * n + 16) for _ in range(C)]
+    dec = eng.alloc(4 * n + 16)
+    idx = list(range(C))
+    ev = [[eng.event() for _ in range(3)] for _ in range(K)]
+
+    def step(it, k=None):
+        if k is not None:
+            eng.record(ev[k][0])
+        eng.encrypt_batch_u32_dev(it, idx, SCHEME_DOUBLE, n, J, pts, cts)
+        if k is not None:
+            eng.record(ev[k][1])
+        eng.aggregate_decrypt_u32_dev(it, [C], [0], n, J, 0, n, cts, None, dec, 4)
+        if k is not None:
+            eng.record(ev[k][2])
+
+    step(0)
+    lo, _hi = sum_mod(host_pts, n, b)
+    assert np.array_equal(dec.download(np.uint32, n).astype(np.uint64), lo), "PARITY FAILURE (round trip)"
+    orc.build()
+    for c in (0, C - 1):
+        assert np.array_equal(cts[c].download(np.uint32, n), orc.encrypt(KEY, 0, c, "double", J, b, host_pts[c])[:, 0].astype(np.uint32)), f"PARITY FAILURE client {c}"
+    for it in range(max(W, 12)):
+        step(it)
+    elapsed = timed_region(ops, K, lambda k: step(k, k))
+    if rank != 0:
+        return None
+    ph = np.array([[eng.elapsed_ms(e[i], e[i + 1]) for i in range(2)] for e in ev])
+    enc_ms = float(ph[:, 0].mean())
+    m = 128 // b
+    alg_bytes = C * n * (4 + 4)
+    blocks = (C + 1) * ((n + m - 1) // m)
+    achieved = alg_bytes / (enc_ms * 1e-3) / 1e9
+    out.update({
+        "value": world * C * n / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak", "dtype": "u32",
+        "config": {"workload": f"BASELINE config 2 at int_bits = {b}: n={n}-element vector, {C} clients per GPU, double mask, n_jobs={J}, uint32 "
+                               "plaintext / ciphertext arrays (compact layout); round = one chained launch for the encrypts + the reduce fused with "
+                               "the decrypt" + ("; independent replicas per GPU" if world > 1 else ""),
+                   "n": n, "int_bits": b, "clients_total": C, "mask": "double", "layout": "uint32 per element",
+                   "parity": "bit-exact (round trip + two clients' ciphertexts vs the oracle, checked in-run)"},
+        "roofline": {"kernel": "prf_small_chain_kernel<PAIR, uint32> (chained encrypts, 4-byte elements)", "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": enc_ms, "launches_timed": K,
+                     "aes_blocks_per_launch": blocks, "aes_blocks_per_s": blocks / (enc_ms * 1e-3)},
+        "phases_ms": {"encrypt_xC": enc_ms, "reduce_plus_decrypt": float(ph[:, 1].mean())},
+    })
     return out
 
 

@@ -769,6 +769,90 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
     return FLASHE_OK;
 }
 
+// ---- compact layout for int_bits <= 32 (new; no reference counterpart) ----
+// The ABI stores one element per uint64 limb whatever int_bits is.  At the widths the reference's own jobs ship (int_bits = 20, 23)
+// that is 8 bytes moved for 20 useful bits, and the b <= 32 kernels are bound by exactly those bytes.  The *_u32_dev entry points
+// take and produce the same VALUES as uint32 arrays: the hot round (batched encrypt, reduce fused with the decrypt of its result)
+// moves half the bytes; flashe_widen_u32_dev / flashe_narrow_u32_dev convert at the edges.
+static int check_range(flashe_ctx *ctx, uint64_t n, uint64_t first, uint64_t count);
+static int check_u32(flashe_ctx *ctx, uint64_t n, uint32_t n_jobs)
+{
+    if (ctx->int_bits > 32) return fail(ctx, FLASHE_EINVAL, "the uint32 layout needs int_bits <= 32, this ctx has %d", ctx->int_bits);
+    if (n >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "the uint32 layout needs n < 2^32");
+    if (n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "n_jobs must be >= 1");
+    if (ctx->env.prf_backend != PRF_AUTO && ctx->env.prf_backend != PRF_TABLE) return fail(ctx, FLASHE_EINVAL, "the uint32 layout runs on the table PRF only");
+    if (!ctx->env.use_chain) return fail(ctx, FLASHE_EINVAL, "the uint32 layout needs the chained kernels (FLASHE_CHAIN=0 is set)");
+    return FLASHE_OK;
+}
+
+int flashe_encrypt_batch_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec, const uint32_t *idx,
+                                 const uint32_t *const *pt_dev, uint32_t *const *ct_dev)
+{
+    CHECK_CTX(ctx);
+    if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    if (n_vec < 0 || (n_vec && (!idx || !pt_dev || !ct_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
+    int rc = check_u32(ctx, n, n_jobs);
+    if (rc) return rc;
+    if (n == 0 || n_vec == 0) return FLASHE_OK;
+    for (int v = 0; v < n_vec; v++) {
+        if (!pt_dev[v] || !ct_dev[v]) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
+        if ((reinterpret_cast<uintptr_t>(pt_dev[v]) | reinterpret_cast<uintptr_t>(ct_dev[v])) & 3u) return fail(ctx, FLASHE_EINVAL, "vector %d: not 4-byte aligned", v);
+    }
+    LaunchEnv env = ctx->env;
+    env.elem32 = 1;
+    const int cap = kMaxUniformBatch;
+    const int per_launch = (n_vec + (n_vec + cap - 1) / cap - 1) / ((n_vec + cap - 1) / cap);
+    for (int v0 = 0; v0 < n_vec; v0 += per_launch) {
+        const int nv = std::min(per_launch, n_vec - v0);
+        const hipError_t e = launch_prf_batch(env, iter, scheme == FLASHE_SCHEME_DOUBLE, nv, idx + v0, reinterpret_cast<const uint64_t *const *>(pt_dev + v0), 1,
+                                              reinterpret_cast<uint64_t *const *>(ct_dev + v0), n, n_jobs);
+        HIP_TRY(ctx, e);
+    }
+    return FLASHE_OK;
+}
+
+int flashe_aggregate_decrypt_u32_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                                     uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count, int C, const uint32_t *const *cts_dev,
+                                     void *agg_out_dev, void *out_dev, int out_elem_bytes)
+{
+    CHECK_CTX(ctx);
+    if (C < 1 || C > kMaxOps || !cts_dev || (count && !out_dev)) return fail(ctx, FLASHE_EINVAL, "aggregate_decrypt_u32: bad arguments (C = %d, at most %d)", C, kMaxOps);
+    if (out_elem_bytes != 4 && out_elem_bytes != 8) return fail(ctx, FLASHE_EINVAL, "out_elem_bytes must be 4 or 8");
+    if (n_add != 1 || n_minus < 0 || n_minus > 1 || !add_idx || (n_minus && !minus_idx))
+        return fail(ctx, FLASHE_EINVAL, "aggregate_decrypt_u32: one add and at most one minus prefix (widen the vectors for prefix lists)");
+    int rc = check_u32(ctx, n, n_jobs);
+    if (rc) return rc;
+    rc = check_range(ctx, n, first, count);
+    if (rc) return rc;
+    if (count == 0) return FLASHE_OK;
+    for (int c = 0; c < C; c++)
+        if (!cts_dev[c] || (reinterpret_cast<uintptr_t>(cts_dev[c]) & 3u)) return fail(ctx, FLASHE_EINVAL, "operand %d is null or not 4-byte aligned", c);
+    const uintptr_t need = static_cast<uintptr_t>(out_elem_bytes - 1);
+    if ((reinterpret_cast<uintptr_t>(out_dev) | reinterpret_cast<uintptr_t>(agg_out_dev)) & need) return fail(ctx, FLASHE_EINVAL, "outputs must be %d-byte aligned", out_elem_bytes);
+    LaunchEnv env = ctx->env;
+    env.elem32 = 1;
+    HIP_TRY(ctx, launch_small_reduce_decrypt(env, iter, add_idx[0], n_minus == 1, n_minus ? minus_idx[0] : 0u, n, n_jobs, first, count, C,
+                                             reinterpret_cast<const uint64_t *const *>(cts_dev), static_cast<uint64_t *>(agg_out_dev),
+                                             static_cast<uint64_t *>(out_dev), out_elem_bytes));
+    return FLASHE_OK;
+}
+
+int flashe_widen_u32_dev(flashe_ctx *ctx, uint64_t n, const uint32_t *in_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "widen_u32: null vector");
+    HIP_TRY(ctx, launch_widen_u32(ctx->env, n, in_dev, out_dev));
+    return FLASHE_OK;
+}
+
+int flashe_narrow_u32_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint32_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "narrow_u32: null vector");
+    HIP_TRY(ctx, launch_narrow_u32(ctx->env, n, in_dev, out_dev));
+    return FLASHE_OK;
+}
+
 int flashe_encrypt_batch_sum_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec, const uint32_t *idx,
                                  const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev, uint64_t *sum_out_dev)
 {

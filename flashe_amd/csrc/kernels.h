@@ -39,6 +39,7 @@ struct LaunchEnv {
     const Codec *codec;        // host pointer, null except inside the fused quantise / unquantise entry points (single-job launches)
     uint32_t *err_flag;        // host-mapped word: set to 1 when a sparse kernel skips an out-of-range / out-of-order location
     int use_chain;             // 1 (default): jobs over the same range that share a prefix share the PRF stream (prf_chain_kernel)
+    int elem32 = 0;            // 1 inside the *_u32_dev entry points (int_bits <= 32): plaintext / ciphertext vectors are uint32 arrays
 };
 
 enum { PRF_AUTO = 0, PRF_TABLE = 1, PRF_BITSLICE = 2, PRF_HYBRID = 3, PRF_BITSLICE16 = 4 };
@@ -117,9 +118,13 @@ struct PtrTable { const uint64_t *p[kMaxOps]; };
 // ops: HOST array of C <= kMaxOps device pointers.  out may alias an operand.
 // b <= 64: out = (sum of the C operands + term(add) - [has_minus] term(minus)) mod 2^b on elements [first, first + count) in one pass
 // (pointers address element `first`; agg_out_dev may be null).  hipErrorNotSupported: reduce and decrypt in two launches instead.
+// (env.elem32: the operands are uint32 arrays; out_elem_bytes = 4: so are agg_out_dev and out_dev)
 hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint32_t add_idx, bool has_minus, uint32_t minus_idx, uint64_t n,
                                        uint32_t n_jobs, uint64_t first, uint64_t count, int C, const uint64_t *const *ops, uint64_t *agg_out_dev,
-                                       uint64_t *out_dev);
+                                       uint64_t *out_dev, int out_elem_bytes = 8);
+// uint32 <-> uint64 element arrays (zero extension / truncation), n elements
+hipError_t launch_widen_u32(const LaunchEnv &env, uint64_t n, const uint32_t *in_dev, uint64_t *out_dev);
+hipError_t launch_narrow_u32(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint32_t *out_dev);
 hipError_t launch_aggregate_elem(const LaunchEnv &env, int C, const uint64_t *const *ops,
                                  uint64_t n, uint64_t *out_dev);
 

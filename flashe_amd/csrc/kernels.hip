@@ -1272,8 +1272,11 @@ __device__ __forceinline__ void small_block_params(uint32_t B32, uint32_t nb1_32
 
 // The wave's 64 blocks hold D (16 bytes per lane, b-bit slots): out[j] = (in[j] + slot) mod 2^b for every element of the tile
 // that lies in [first, range_end), coalesced whenever the tile has at most one partial block (a chunk end).
-__device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool valid, int cnt, uint64_t j0, u128 D, const uint64_t *in,
-                                           uint64_t *out, uint64_t first, uint64_t range_end, const SmallParams &p)
+// ET: the element type of the vectors in memory -- uint64_t (one limb per element, the ABI's layout) or, for int_bits <= 32,
+// uint32_t (the compact layout of the *_u32_dev entry points: half the bytes of a kernel that is bound by them)
+template <class ET>
+__device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool valid, int cnt, uint64_t j0, u128 D, const ET *in,
+                                           ET *out, uint64_t first, uint64_t range_end, const SmallParams &p)
 {
     const uint64_t valid_mask = __ballot(valid), partial_mask = __ballot(valid && cnt < p.m);
     if (__popcll(partial_mask) <= 1) {
@@ -1301,8 +1304,8 @@ __device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool v
                 if (sh) val |= static_cast<uint64_t>(w[2]) << (64u - sh);
                 const uint64_t j = e0 + x;
                 if (j >= first && j < range_end) {
-                    const uint64_t pt = in ? __builtin_nontemporal_load(in + (j - first)) : 0ull;
-                    __builtin_nontemporal_store((pt + val) & p.mask_lo, out + (j - first));
+                    const uint64_t pt = in ? static_cast<uint64_t>(__builtin_nontemporal_load(in + (j - first))) : 0ull;
+                    __builtin_nontemporal_store(static_cast<ET>((pt + val) & p.mask_lo), out + (j - first));
                 }
             }
         }
@@ -1312,7 +1315,7 @@ __device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool v
             const uint64_t j = j0 + tt;
             if (j < first || j >= range_end) continue;
             const uint64_t val = extract64(D, p.b * tt);
-            out[j - first] = ((in ? in[j - first] : 0ull) + val) & p.mask_lo;
+            out[j - first] = static_cast<ET>(((in ? static_cast<uint64_t>(in[j - first]) : 0ull) + val) & p.mask_lo);
         }
     }
 }
@@ -1327,10 +1330,11 @@ struct WalkPt { uint32_t v[kWalkBatch]; };
 
 // the first kWalkBatch plaintext words of the lane's walk, requested BEFORE the AES rounds of the stream that completes this
 // output: their latency hides under the rounds
-__device__ __forceinline__ WalkPt small_walk32_load(const uint64_t *__restrict__ in, uint64_t e0, uint64_t first, uint32_t lane, uint32_t m)
+template <class ET>
+__device__ __forceinline__ WalkPt small_walk32_load(const ET *__restrict__ in, uint64_t e0, uint64_t first, uint32_t lane, uint32_t m)
 {
     WalkPt r;
-    const uint64_t *pin = in ? in + (e0 - first) + lane : nullptr;
+    const ET *pin = in ? in + (e0 - first) + lane : nullptr;
 #pragma unroll
     for (uint32_t u = 0; u < kWalkBatch; u++) {
         r.v[u] = 0u;
@@ -1347,16 +1351,17 @@ __device__ __forceinline__ WalkPt small_walk32_load(const uint64_t *__restrict__
     return r;
 }
 
-__device__ __forceinline__ void small_walk32(uint32_t *row0, uint32_t lane, uint64_t e0, u128 D, const WalkPt &pt0, const uint64_t *__restrict__ in,
-                                             uint64_t *__restrict__ out, uint64_t first, const SmallParams &p, uint32_t blk0, uint32_t o0)
+template <class ET>
+__device__ __forceinline__ void small_walk32(uint32_t *row0, uint32_t lane, uint64_t e0, u128 D, const WalkPt &pt0, const ET *__restrict__ in,
+                                             ET *__restrict__ out, uint64_t first, const SmallParams &p, uint32_t blk0, uint32_t o0)
 {
     *reinterpret_cast<uint4 *>(row0 + 4 * lane) = make_uint4(static_cast<uint32_t>(D), static_cast<uint32_t>(D >> 32),
                                                              static_cast<uint32_t>(D >> 64), static_cast<uint32_t>(D >> 96));
     __builtin_amdgcn_wave_barrier();
     const uint32_t m = static_cast<uint32_t>(p.m), b = static_cast<uint32_t>(p.b);
     const uint32_t q64 = 64u / m, r64b = (64u % m) * b, mb = m * b, mask = static_cast<uint32_t>(p.mask_lo);
-    const uint64_t *pin = in ? in + (e0 - first) + lane : nullptr;
-    uint64_t *pout = out + (e0 - first) + lane;
+    const ET *pin = in ? in + (e0 - first) + lane : nullptr;
+    ET *pout = out + (e0 - first) + lane;
     uint32_t blk = blk0, o = o0;
     for (uint32_t i0 = 0; i0 < m; i0 += kWalkBatch) {
         uint32_t pt[kWalkBatch], val[kWalkBatch];
@@ -1379,7 +1384,7 @@ __device__ __forceinline__ void small_walk32(uint32_t *row0, uint32_t lane, uint
         }
 #pragma unroll
         for (uint32_t u = 0; u < kWalkBatch; u++)
-            if (i0 + u < m) __builtin_nontemporal_store(static_cast<uint64_t>((pt[u] + val[u]) & mask), pout + 64u * (i0 + u));
+            if (i0 + u < m) __builtin_nontemporal_store(static_cast<ET>((pt[u] + val[u]) & mask), pout + 64u * (i0 + u));
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -1450,7 +1455,7 @@ __device__ __forceinline__ u128 slot_diff(u128 prev, u128 cur, u128 top, int b)
     return ((prev | top) - (cur & ~top)) ^ ((prev ^ ~cur) & top);
 }
 
-template <bool PAIR>
+template <bool PAIR, class ET = uint64_t>
 __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const RoundKeys rk, const SmallChainTable tb, int n_chains, const SmallParams p)
 {
     constexpr uint32_t WAVES = kSmallThreads / 64, TILE = PAIR ? 128u : 64u;
@@ -1544,8 +1549,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 const CtrPrefix pre = load_prefix(pre_lds, sbase + c);
                 const int link = single ? c : c - 1;
                 WalkPt ptA{}, ptB{};
-                if (link >= 0 && fastA) ptA = small_walk32_load(tb.in[link0 + link], e0A, first, lane, m32);
-                if (link >= 0 && fastB) ptB = small_walk32_load(tb.in[link0 + link], e0B, first, lane, m32);
+                if (link >= 0 && fastA) ptA = small_walk32_load(reinterpret_cast<const ET *>(tb.in[link0 + link]), e0A, first, lane, m32);
+                if (link >= 0 && fastB) ptB = small_walk32_load(reinterpret_cast<const ET *>(tb.in[link0 + link]), e0B, first, lane, m32);
                 uint32_t s[2][4];
                 ctr_round1(pre, xA, s[0]);
                 ctr_round1(pre, xB, s[1]);
@@ -1554,17 +1559,19 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 if (link >= 0) {
                     const uint64_t *in = tb.in[link0 + link];
                     uint64_t *out = tb.out[link0 + link];
+                    const ET *ein = reinterpret_cast<const ET *>(in);
+                    ET *eout = reinterpret_cast<ET *>(out);
                     // per slot (previous - current) mod 2^b: the previous stream is this client's add stream, the current its minus stream
                     const u128 DA = single ? SA : slot_diff(prevA, SA, top, p.b);
                     const u128 DB = single ? SB : slot_diff(prevB, SB, top, p.b);
-                    if (direct) {
+                    if (direct) {                                  // (never with the compact layout: the host turns `direct` off)
                         small_direct(vA, cntA, j0A, DA, in, out, first, range_end, p);
                         small_direct(vB, cntB, j0B, DB, in, out, first, range_end, p);
                     } else {
-                        if (fastA) small_walk32(row0, lane, e0A, DA, ptA, in, out, first, p, wblk0, wo0);
-                        else small_walk(row0, lane, vA, cntA, j0A, DA, in, out, first, range_end, p);
-                        if (fastB) small_walk32(row0, lane, e0B, DB, ptB, in, out, first, p, wblk0, wo0);
-                        else small_walk(row0, lane, vB, cntB, j0B, DB, in, out, first, range_end, p);
+                        if (fastA) small_walk32(row0, lane, e0A, DA, ptA, ein, eout, first, p, wblk0, wo0);
+                        else small_walk(row0, lane, vA, cntA, j0A, DA, ein, eout, first, range_end, p);
+                        if (fastB) small_walk32(row0, lane, e0B, DB, ptB, ein, eout, first, p, wblk0, wo0);
+                        else small_walk(row0, lane, vB, cntB, j0B, DB, ein, eout, first, range_end, p);
                     }
                 }
                 prevA = SA; prevB = SB;
@@ -1577,8 +1584,8 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 const CtrPrefix pre0 = load_prefix(pre_lds, sbase + c), pre1 = load_prefix(pre_lds, sbase + (has1 ? c + 1 : c));
                 const int l0 = single ? c : c - 1;
                 WalkPt pt0{}, pt1{};
-                if (fastA && l0 >= 0) pt0 = small_walk32_load(tb.in[link0 + l0], e0A, first, lane, m32);
-                if (fastA && has1) pt1 = small_walk32_load(tb.in[link0 + l0 + 1], e0A, first, lane, m32);
+                if (fastA && l0 >= 0) pt0 = small_walk32_load(reinterpret_cast<const ET *>(tb.in[link0 + l0]), e0A, first, lane, m32);
+                if (fastA && has1) pt1 = small_walk32_load(reinterpret_cast<const ET *>(tb.in[link0 + l0 + 1]), e0A, first, lane, m32);
                 uint32_t s[2][4];
                 ctr_round1(pre0, xA, s[0]);
                 ctr_round1(pre1, xA, s[1]);
@@ -1586,15 +1593,19 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
                 if (l0 >= 0) {
                     const u128 D = single ? S0 : slot_diff(prevA, S0, top, p.b);
+                    const ET *ein = reinterpret_cast<const ET *>(tb.in[link0 + l0]);
+                    ET *eout = reinterpret_cast<ET *>(tb.out[link0 + l0]);
                     if (direct) small_direct(vA, cntA, j0A, D, tb.in[link0 + l0], tb.out[link0 + l0], first, range_end, p);
-                    else if (fastA) small_walk32(row0, lane, e0A, D, pt0, tb.in[link0 + l0], tb.out[link0 + l0], first, p, wblk0, wo0);
-                    else small_walk(row0, lane, vA, cntA, j0A, D, tb.in[link0 + l0], tb.out[link0 + l0], first, range_end, p);
+                    else if (fastA) small_walk32(row0, lane, e0A, D, pt0, ein, eout, first, p, wblk0, wo0);
+                    else small_walk(row0, lane, vA, cntA, j0A, D, ein, eout, first, range_end, p);
                 }
                 if (has1) {
                     const u128 D = single ? S1 : slot_diff(S0, S1, top, p.b);
+                    const ET *ein = reinterpret_cast<const ET *>(tb.in[link0 + l0 + 1]);
+                    ET *eout = reinterpret_cast<ET *>(tb.out[link0 + l0 + 1]);
                     if (direct) small_direct(vA, cntA, j0A, D, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, range_end, p);
-                    else if (fastA) small_walk32(row0, lane, e0A, D, pt1, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, p, wblk0, wo0);
-                    else small_walk(row0, lane, vA, cntA, j0A, D, tb.in[link0 + l0 + 1], tb.out[link0 + l0 + 1], first, range_end, p);
+                    else if (fastA) small_walk32(row0, lane, e0A, D, pt1, ein, eout, first, p, wblk0, wo0);
+                    else small_walk(row0, lane, vA, cntA, j0A, D, ein, eout, first, range_end, p);
                 }
                 prevA = has1 ? S1 : S0;
             }
@@ -1723,12 +1734,15 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_kernel(con
 // (Built and dropped: the sixteen waves of a workgroup meeting at a barrier and walking their 512 m elements TOGETHER, 1,024
 // consecutive elements of every operand per step -- 0.19 ms without the AES rounds where the per-wave walk takes 0.18, and with them
 // 0.23 against 0.187: one workgroup per CU in lockstep means nobody streams while everybody runs its rounds.)
-template <int CB>
+// IT / OT: element type of the operands / of agg_out and out in memory (uint64_t, or uint32_t for the compact layout)
+template <int CB, class IT = uint64_t, class OT = uint64_t>
 __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kernel(const RoundKeys rk, const SmallParams p, uint32_t add_idx,
                                                                                      uint32_t minus_idx, int has_minus, uint64_t first, uint64_t count,
                                                                                      uint64_t blk_first, uint64_t blk_count, int C, const PtrTable ops,
-                                                                                     uint64_t *agg_out, uint64_t *out)
+                                                                                     uint64_t *agg_out_, uint64_t *out_)
 {
+    OT *const agg_out = reinterpret_cast<OT *>(agg_out_);
+    OT *const out = reinterpret_cast<OT *>(out_);
     constexpr uint32_t WAVES = kSmallThreads / 64, EPL = 2;
     __shared__ uint32_t tab[kTabWords];
     __shared__ uint32_t scratch[WAVES * 256 + 8];
@@ -1789,7 +1803,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kern
                     for (int u = 0; u < CB; u++) {
                         const uint64_t *src = tab_ops[c + u < C ? c + u : C - 1];       // surplus slots of the last step re-read an operand and are not added
 #pragma unroll
-                        for (uint32_t e = 0; e < EPL; e++) v[u][e] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(src + k[e]));
+                        for (uint32_t e = 0; e < EPL; e++) v[u][e] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(reinterpret_cast<const IT *>(src) + k[e]));
                     }
 #pragma unroll
                     for (int u = 0; u < CB; u++) {
@@ -1808,8 +1822,8 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kern
                     const uint32_t *wa = row0 + 4 * (lane_base + blk) + (o >> 5), *wm = wa + 128;
                     // bits o .. o + 31 of the block: o + b <= 128, so past word 3 only bits that the mask removes are read
                     const uint32_t val = __builtin_amdgcn_alignbit(wa[1], wa[0], o & 31u) - __builtin_amdgcn_alignbit(wm[1], wm[0], o & 31u);
-                    if (agg_out) __builtin_nontemporal_store(static_cast<uint64_t>(sum[e] & mask), agg_out + k[e]);
-                    __builtin_nontemporal_store(static_cast<uint64_t>((sum[e] + val) & mask), out + k[e]);
+                    if (agg_out) __builtin_nontemporal_store(static_cast<OT>(sum[e] & mask), agg_out + k[e]);
+                    __builtin_nontemporal_store(static_cast<OT>((sum[e] + val) & mask), out + k[e]);
                 }
             }
             if (P < 0) break;
@@ -2348,9 +2362,11 @@ static SmallParams small_params_of(const LaunchEnv &env, uint32_t iter, uint64_t
 // the kernel does not carry (the caller then reduces and decrypts in two launches).
 hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint32_t add_idx, bool has_minus, uint32_t minus_idx, uint64_t n,
                                        uint32_t n_jobs, uint64_t first, uint64_t count, int C, const uint64_t *const *ops, uint64_t *agg_out_dev,
-                                       uint64_t *out_dev)
+                                       uint64_t *out_dev, int out_elem_bytes)
 {
     if (env.b > 64 || env.codec || n >= (1ull << 32) || n == 0 || n_jobs == 0 || C < 1 || C > kMaxOps) return hipErrorNotSupported;
+    if ((env.elem32 || out_elem_bytes == 4) && env.b > 32) return hipErrorInvalidValue;
+    if (out_elem_bytes != 8 && !(out_elem_bytes == 4 && env.elem32)) return hipErrorInvalidValue;
     if (env.prf_backend != PRF_AUTO && env.prf_backend != PRF_TABLE) return hipErrorNotSupported;
     if (count == 0) return hipSuccess;
     const SmallParams p = small_params_of(env, iter, n, n_jobs);
@@ -2373,18 +2389,26 @@ hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint
         // 32-block tiles, the two streams in the two halves of the wave (see small_reduce_decrypt_split_kernel)
         const uint64_t tiles32 = (bc + 31) / 32, groups32 = (tiles32 + kSmallThreads / 64 - 1) / (kSmallThreads / 64);
         const int grid32 = static_cast<int>(groups32 < cus ? groups32 : cus);
-#define SRDS_LAUNCH(CB)                                                                                                                       \
-    hipLaunchKernelGGL((small_reduce_decrypt_split_kernel<CB>), dim3(grid32), dim3(kSmallThreads), 0, env.stream, env.rk, p, add_idx, minus_idx, \
-                       (has_minus ? 1 : 0) | probe, first, count, bf, bc, C, t, agg_out_dev, out_dev)
+#define SRDS_LAUNCH(CB, IT, OT)                                                                                                               \
+    hipLaunchKernelGGL((small_reduce_decrypt_split_kernel<CB, IT, OT>), dim3(grid32), dim3(kSmallThreads), 0, env.stream, env.rk, p, add_idx,  \
+                       minus_idx, (has_minus ? 1 : 0) | probe, first, count, bf, bc, C, t, agg_out_dev, out_dev)
+#define SRDS_PICK(CB)                                                                                                                          \
+    do {                                                                                                                                        \
+        if (!env.elem32) SRDS_LAUNCH(CB, uint64_t, uint64_t);                                                                                   \
+        else if (out_elem_bytes == 4) SRDS_LAUNCH(CB, uint32_t, uint32_t);                                                                      \
+        else SRDS_LAUNCH(CB, uint32_t, uint64_t);                                                                                               \
+    } while (0)
         switch (cb) {
-        case 1: SRDS_LAUNCH(1); break;
-        case 2: case 3: SRDS_LAUNCH(2); break;
-        case 4: case 5: case 6: case 7: SRDS_LAUNCH(4); break;
-        default: SRDS_LAUNCH(8); break;
+        case 1: SRDS_PICK(1); break;
+        case 2: case 3: SRDS_PICK(2); break;
+        case 4: case 5: case 6: case 7: SRDS_PICK(4); break;
+        default: SRDS_PICK(8); break;
         }
+#undef SRDS_PICK
 #undef SRDS_LAUNCH
         return hipGetLastError();
     }
+    if (env.elem32) return hipErrorNotSupported;              // (FLASHE_SMALL_REDUCE_SPLIT=0 has no compact form)
     switch (cb) {
     case 1: SRD_LAUNCH(1); break;
     case 2: case 3: SRD_LAUNCH(2); break;
@@ -2401,7 +2425,11 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
 {
     if (env.codec || n >= (1ull << 32) || n == 0) return hipErrorNotSupported;
     for (int i = 0; i < n_chains; i++) if (chains[i].sum_out_dev) return hipErrorNotSupported;      // the fused sum lives in the wide kernel
-    const SmallParams p = small_params_of(env, iter, n, n_jobs);
+    SmallParams p = small_params_of(env, iter, n, n_jobs);
+    if (env.elem32) {
+        if (env.b > 32) return hipErrorInvalidValue;
+        p.no_direct = 1;                      // the 16-byte direct accesses of m <= 4 assume 8-byte elements: b = 32 walks its rows like b < 32
+    }
     struct Piece { const PrfChain *ch; int l0, l1; uint64_t blk_first, blk_count; };
     std::vector<Piece> pieces;
     uint64_t total_blocks = 0;
@@ -2461,8 +2489,11 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
         }
         const uint64_t cus = static_cast<uint64_t>(env.num_cus);
         const int grid = static_cast<int>(tiles < cus ? tiles : cus);
-        if (pair) hipLaunchKernelGGL(prf_small_chain_kernel<true>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
-        else hipLaunchKernelGGL(prf_small_chain_kernel<false>, dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+        if (env.elem32) {
+            if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+            else hipLaunchKernelGGL((prf_small_chain_kernel<false, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+        } else if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+        else hipLaunchKernelGGL((prf_small_chain_kernel<false>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -2488,6 +2519,30 @@ static inline int stream_grid(const LaunchEnv &env, uint64_t items)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return static_cast<int>(blocks);
+}
+
+// the compact layout of the *_u32_dev entry points <-> the ABI's one-limb vectors
+__global__ __launch_bounds__(kStreamThreads) void widen_u32_kernel(uint64_t n, const uint32_t *in, uint64_t *out)
+{
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n; j += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        out[j] = in[j];
+}
+__global__ __launch_bounds__(kStreamThreads) void narrow_u32_kernel(uint64_t n, const uint64_t *in, uint32_t *out)
+{
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n; j += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        out[j] = static_cast<uint32_t>(in[j]);
+}
+hipError_t launch_widen_u32(const LaunchEnv &env, uint64_t n, const uint32_t *in_dev, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(widen_u32_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, in_dev, out_dev);
+    return hipGetLastError();
+}
+hipError_t launch_narrow_u32(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint32_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(narrow_u32_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, in_dev, out_dev);
+    return hipGetLastError();
 }
 
 // out = (in + add - minus) & mask.  L = 2: one 16-B element per lane-iteration.

@@ -488,6 +488,28 @@ class Engine:
         self._check(self._lib.flashe_aggregate_decrypt_range_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, first, count,
                                                                  len(cts), p, self._ptr(agg_out), self._ptr(out)))
 
+    # -- compact layout for int_bits <= 32: the same values as uint32 arrays (half the bytes of the kernels bound by them) --------
+    def encrypt_batch_u32_dev(self, it, idx_list, scheme, n, n_jobs, pts, cts):
+        """encrypt_batch_dev on uint32 plaintext and ciphertext vectors (int_bits <= 32)."""
+        pi, _k = _u32_list(idx_list)
+        pp, _a = self._ptr_array(pts)
+        pc, _b = self._ptr_array(cts)
+        self._check(self._lib.flashe_encrypt_batch_u32_dev(self._h, it, scheme, n, n_jobs, len(idx_list), pi, pp, pc))
+
+    def aggregate_decrypt_u32_dev(self, it, add_idx, minus_idx, n, n_jobs, first, count, cts, agg_out, out, out_elem_bytes=8):
+        """aggregate_decrypt_range_dev on uint32 operands (one add, at most one minus prefix); agg_out / out are uint32 or uint64 arrays."""
+        pa, _a = _u32_list(add_idx)
+        pm, _m = _u32_list(minus_idx)
+        p, _keep = self._ptr_array(cts)
+        self._check(self._lib.flashe_aggregate_decrypt_u32_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, first, count,
+                                                               len(cts), p, self._ptr(agg_out), self._ptr(out), int(out_elem_bytes)))
+
+    def widen_u32_dev(self, n, inp, out):
+        self._check(self._lib.flashe_widen_u32_dev(self._h, n, self._ptr(inp), self._ptr(out)))
+
+    def narrow_u32_dev(self, n, inp, out):
+        self._check(self._lib.flashe_narrow_u32_dev(self._h, n, self._ptr(inp), self._ptr(out)))
+
     def aggregate_packed_dev(self, packed, n_limbs, total_bits, out):
         p, _keep = self._ptr_array(packed)
         self._check(self._lib.flashe_aggregate_packed_dev(self._h, len(packed), p, n_limbs, total_bits, self._ptr(out)))

@@ -265,6 +265,24 @@ int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter,
                                        const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
                                        uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
                                        int C, const uint64_t *const *cts_dev, uint64_t *agg_out_dev, uint64_t *out_dev);
+/* Compact layout for int_bits <= 32 (new; no reference counterpart).  The ABI stores one element per uint64 limb whatever
+ * int_bits is; at the widths the reference's own jobs ship (int_bits = 20, 23: jzf configs) that is
+ * 8 bytes moved for 20 useful bits, and the kernels of those widths are bound by exactly those bytes.  These entry points take
+ * and produce the same VALUES as uint32 arrays, so that the hot round moves half of them:
+ *   flashe_encrypt_batch_u32_dev      = flashe_encrypt_batch_dev (jzf_flashe.py:456-488 per vector) on uint32 plaintexts and ciphertexts;
+ *   flashe_aggregate_decrypt_u32_dev  = flashe_aggregate_decrypt_range_dev with ONE add and at most one minus prefix (the no-dropout
+ *                                       decrypt and every single telescoped run, jzf_flashe.py:356-367) on up to 64 uint32 operands;
+ *                                       agg_out_dev (may be NULL) and out_dev are uint32 (out_elem_bytes = 4) or uint64 (8) arrays;
+ *   flashe_widen_u32_dev / flashe_narrow_u32_dev convert to and from the one-limb layout every other call uses.
+ * ct[j] here == (uint32) of what the uint64 call writes; n < 2^32; table PRF; pointers address element `first`. */
+int flashe_encrypt_batch_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
+                                 const uint32_t *idx, const uint32_t *const *pt_dev, uint32_t *const *ct_dev);
+int flashe_aggregate_decrypt_u32_dev(flashe_ctx *ctx, uint32_t iter,
+                                     const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                                     uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
+                                     int C, const uint32_t *const *cts_dev, void *agg_out_dev, void *out_dev, int out_elem_bytes);
+int flashe_widen_u32_dev(flashe_ctx *ctx, uint64_t n, const uint32_t *in_dev, uint64_t *out_dev);
+int flashe_narrow_u32_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint32_t *out_dev);
 /* Packed: each operand is ONE integer of total_bits bits (n_limbs = ceil(total_bits/64)
  * little-endian limbs); out = sum mod 2^total_bits -- jzf_aggregator.py:406-419. */
 int flashe_aggregate_packed_dev(flashe_ctx *ctx, int C, const uint64_t *const *packed_dev,

@@ -187,3 +187,52 @@ def test_encrypt_batch_with_partial_aggregate(E, oracle, b, n, idx, scheme):
     assert np.array_equal(dsum.download(np.uint64, n * Lb).reshape(n, Lb), oracle.aggregate_elem(want, b)), (b, n, "partial aggregate")
     with pytest.raises(E.FlasheError):
         eng.encrypt_batch_sum_dev(6, idx, E.SCHEME_DOUBLE, n, 16, dpt, 1, dct, dct[0])      # the sum must not alias a ciphertext
+
+
+@pytest.mark.parametrize("b,n,J,C,scheme", [(20, 100_003, 16, 10, "double"), (32, 70_001, 3, 4, "double"), (23, 61_706, 16, 100, "double"),
+                                           (16, 2_000_003, 16, 3, "double"), (8, 4099, 1, 2, "single"), (1, 777, 5, 2, "double"),
+                                           (31, 12, 16, 3, "double"), (20, 1_500_000, 16, 129, "single"), (25, 300_000, 7, 12, "double")])
+def test_compact_u32_layout_equals_the_one_limb_layout(E, oracle, b, n, J, C, scheme):
+    """flashe_encrypt_batch_u32_dev / flashe_aggregate_decrypt_u32_dev / widen / narrow (int_bits <= 32, the same values as uint32
+    arrays): every ciphertext equals the oracle's encrypt (jzf_flashe.py:456-488) truncated to 32 bits, the fused reduce + decrypt
+    equals aggregate (jzf_aggregator.py:424-430) + decrypt (jzf_flashe.py:570-571) on full and odd sub-ranges, with uint32 and uint64
+    results, with and without the stored aggregate; wider moduli and prefix lists are refused."""
+    eng = E.Engine(KEY, b, device=0)
+    rng = np.random.Generator(np.random.PCG64(n + C + b))
+    pts = [rng.integers(0, 2 ** b, n, dtype=np.uint64) for _ in range(C)]
+    idx = list(range(5, 5 + C))
+    d32 = [eng.upload(p.astype(np.uint32)) for p in pts]
+    c32 = [eng.alloc(4 * n + 16) for _ in range(C)]
+    eng.encrypt_batch_u32_dev(9, idx, E.SCHEME_DOUBLE if scheme == "double" else E.SCHEME_SINGLE, n, J, d32, c32)
+    want = [oracle.encrypt(KEY, 9, i, scheme, J, b, p) for i, p in zip(idx, pts)]
+    for v in sorted({0, C - 1, C // 2}):
+        assert np.array_equal(c32[v].download(np.uint32, n), want[v][:, 0].astype(np.uint32)), (b, n, v)
+    # widen: the compact ciphertext as a one-limb vector; narrow: back
+    w = eng.alloc_vec(n)
+    eng.widen_u32_dev(n, c32[0], w)
+    assert np.array_equal(w.download(np.uint64, n), want[0][:, 0])
+    back = eng.alloc(4 * n + 16)
+    eng.narrow_u32_dev(n, w, back)
+    assert np.array_equal(back.download(np.uint32, n), want[0][:, 0].astype(np.uint32))
+    if C > 64:
+        with pytest.raises(E.FlasheError):
+            eng.aggregate_decrypt_u32_dev(9, [3], [4], n, J, 0, n, c32, None, w)
+        return
+    agg = oracle.aggregate_elem(want, b)
+    for add, minus in (([idx[-1] + 1], [idx[0]]), ([7], [])):
+        full = oracle.combine(b, agg, oracle.mask_sum(KEY, 9, add, n, J, b), oracle.mask_sum(KEY, 9, minus, n, J, b))
+        for first, count in ((0, n), (1, n - 1), (min(n - 1, 257), max(1, (n - 257) // 2)), (n - 1, 1)):
+            if first + count > n:
+                continue
+            ptrs = [c.ptr + 4 * first for c in c32]
+            for out_bytes in (8, 4):
+                out, ao = eng.alloc(8 * count + 16), eng.alloc(8 * count + 16)
+                eng.aggregate_decrypt_u32_dev(9, add, minus, n, J, first, count, ptrs, ao, out, out_bytes)
+                dt = np.uint64 if out_bytes == 8 else np.uint32
+                assert np.array_equal(out.download(dt, count).astype(np.uint64), full[first:first + count, 0]), (b, n, first, count, out_bytes, add)
+                assert np.array_equal(ao.download(dt, count).astype(np.uint64), agg[first:first + count, 0]), (b, n, first, count, out_bytes)
+    with pytest.raises(E.FlasheError):
+        eng.aggregate_decrypt_u32_dev(9, [3, 4], [0], n, J, 0, n, c32, None, w)          # prefix lists: widen and use the general call
+    wide = E.Engine(KEY, 40, device=0)
+    with pytest.raises(E.FlasheError):
+        wide.encrypt_batch_u32_dev(9, idx, E.SCHEME_DOUBLE, n, J, d32, c32)

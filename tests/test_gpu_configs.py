@@ -192,6 +192,8 @@ def test_config5_sparse_top1pct_50_clients(E, oracle):
     (["--config", "2", "--n", "500000", "--schedule", "auto", "--no-cpu-baseline", "--no-e2e"], []),
     (["--config", "3", "--clients", "7", "--no-cpu-baseline"], []),
     (["--config", "5", "--n", "400000", "--clients", "5", "--no-cpu-baseline"], []),
+    (["--config", "2", "--bits", "20", "--n", "700001", "--no-cpu-baseline", "--no-e2e"], []),
+    (["--config", "2", "--bits", "20", "--layout", "u32", "--n", "700001"], []),
 ])
 def test_bench_lines_on_one_gpu(args, keys):
     """bench.py on one GPU, every configuration and schedule at reduced size: the in-run parity gates (round trip AND ciphertexts

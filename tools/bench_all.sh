@@ -16,6 +16,9 @@ run --config 4 --schedule partial-agg --no-cpu-baseline
 run --config 5 --no-cpu-baseline
 run --bits 64 --no-cpu-baseline --no-e2e
 run --bits 20 --no-cpu-baseline --no-e2e
+run --bits 20 --layout u32
+run --bits 16 --no-cpu-baseline --no-e2e
+run --bits 16 --layout u32
 python - "$OUT" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
