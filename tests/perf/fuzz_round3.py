@@ -5,6 +5,7 @@
   draws   flashe_mt19937_random_dev         (np.random.random continued from an arbitrary stream position, state handed back)
   twins   flashe_encrypt / _aggregate_elem / _decrypt on host pointers with random chunk sizes of the copy pipeline
   handles DeviceVector blocks recycled through the caching allocator between calls of different sizes
+  compact flashe_encrypt_batch_u32_dev / flashe_aggregate_decrypt_u32_dev (int_bits <= 32 on uint32 arrays)
   fused   flashe_aggregate_decrypt_range_dev at b <= 64 (the one-launch reduce + decrypt and its fallbacks: sub-ranges, up to 65 operands)
 usage: fuzz_round3.py [cases per family] [seed] [families, comma separated]"""
 import os
@@ -234,7 +235,43 @@ def fuzz_fused(rng, case):
     return f"b={b} n={n} J={J} C={C} add={add} minus={minus} first={first} count={count} keep={keep}"
 
 
-FAMILIES = {"sum": fuzz_sum, "edges": fuzz_edges, "draws": fuzz_draws, "twins": fuzz_twins, "handles": fuzz_handles, "fused": fuzz_fused}
+def fuzz_compact(rng, case):
+    """The uint32 layout (int_bits <= 32): flashe_encrypt_batch_u32_dev and flashe_aggregate_decrypt_u32_dev against the oracle."""
+    b = int(rng.choice([32, 32, 31, 25, 23, 20, 20, 17, 16, 12, 9, 8, 7, 5, 3, 2, 1]))
+    n = pick_n(rng) // 3 + 1
+    J = int(rng.choice([1, 2, 3, 7, 16, 16, 33, 1000, n + 5]))
+    C = int(rng.choice([1, 2, 3, 4, 5, 9, 10, 11, 16, 17, 33, 64]))
+    if C * n > 30_000_000:
+        n = 30_000_000 // C
+    it = int(rng.integers(0, 2 ** 32))
+    scheme = "double" if rng.random() < 0.8 else "single"
+    i0 = int(rng.integers(0, 1000))
+    idx = [i0 + c for c in range(C)] if rng.random() < 0.8 else [int(v) for v in rng.integers(0, 50, C)]
+    eng = E.Engine(KEY, b, device=0)
+    pts = [rng.integers(0, 2 ** b, n, dtype=np.uint64) for _ in range(C)]
+    d32 = [eng.upload(p.astype(np.uint32)) for p in pts]
+    c32 = [eng.alloc(4 * n + 16) for _ in range(C)]
+    eng.encrypt_batch_u32_dev(it, idx, E.SCHEME_DOUBLE if scheme == "double" else E.SCHEME_SINGLE, n, J, d32, c32)
+    want = [orc.encrypt(KEY, it, i, scheme, J, b, p) for i, p in zip(idx, pts)]
+    for v in sorted({0, C - 1, int(rng.integers(0, C))}):
+        assert np.array_equal(c32[v].download(np.uint32, n), want[v][:, 0].astype(np.uint32)), ("compact/ct", case, b, n, J, C, v, scheme)
+    add, minus = [([idx[-1] + 1], [idx[0]]), ([int(rng.integers(0, 2 ** 32 - 1))], []), ([int(rng.integers(0, 100))], [int(rng.integers(0, 100))])][int(rng.integers(0, 3))]
+    first = int(rng.integers(0, n)) if rng.random() < 0.5 else 0
+    count = int(rng.integers(1, n - first + 1)) if rng.random() < 0.6 else n - first
+    ob = int(rng.choice([4, 8]))
+    keep = rng.random() < 0.5
+    out, ao = eng.alloc(8 * count + 16), eng.alloc(8 * count + 16)
+    eng.aggregate_decrypt_u32_dev(it, add, minus, n, J, first, count, [c.ptr + 4 * first for c in c32], ao if keep else None, out, ob)
+    agg = orc.aggregate_elem(want, b)
+    full = orc.combine(b, agg[first:first + count], orc.mask_sum(KEY, it, add, n, J, b)[first:first + count], orc.mask_sum(KEY, it, minus, n, J, b)[first:first + count])
+    dt = np.uint64 if ob == 8 else np.uint32
+    assert np.array_equal(out.download(dt, count).astype(np.uint64), full[:, 0]), ("compact/out", case, b, n, J, C, add, minus, first, count, ob)
+    if keep:
+        assert np.array_equal(ao.download(dt, count).astype(np.uint64), agg[first:first + count, 0]), ("compact/agg", case, b, n, J, C, first, count, ob)
+    return f"b={b} n={n} J={J} C={C} {scheme} add={add} minus={minus} first={first} count={count} out_bytes={ob}"
+
+
+FAMILIES = {"sum": fuzz_sum, "edges": fuzz_edges, "draws": fuzz_draws, "twins": fuzz_twins, "handles": fuzz_handles, "fused": fuzz_fused, "compact": fuzz_compact}
 
 
 def main():
