@@ -785,7 +785,7 @@ def test_c_example_round_runs(tmp_path):
     import subprocess
     from test_abi_and_host import _build_c_example
     r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "C_ROUND OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+    assert r.returncode == 0 and "C_ROUND OK" in r.stdout and "C_ROUND_U32 OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
 
 
 def test_staging_pool_under_a_tight_budget():
