@@ -138,6 +138,8 @@ _SIGNATURES = {
     "flashe_unbatch": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
     "flashe_sparsify_dev": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
     "flashe_sparsify": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_vp, c_vp, c_vp]),
+    "flashe_sparsify_batch_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), c_vp, c_int, c_vp, c_vp, c_vp]),
+    "flashe_sparsify_batch": (c_int, [c_vp, c_int, ctypes.POINTER(c_u64), ctypes.POINTER(c_u64), c_vp, c_int, c_vp, c_vp, c_vp]),
     "flashe_rccl_unique_id": (c_int, [c_u8p]),
     "flashe_rccl_init": (c_int, [c_vp, c_u8p, c_int, c_int, ctypes.POINTER(c_vp)]),
     "flashe_rccl_destroy": (c_int, [c_vp]),

@@ -1552,6 +1552,35 @@ int flashe_sparsify_dev(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x_d
     return FLASHE_OK;
 }
 
+// Every layer of a model at once: layer l = elements [off_l, off_l + n[l]) of the flat vectors (layers back to back), its k[l] entries go
+// to [koff_l, koff_l + k[l]) of the flat outputs, locations relative to the layer.  n and k are HOST arrays.
+int flashe_sparsify_batch_dev(flashe_ctx *ctx, int n_layers, const uint64_t *n, const uint64_t *k, const void *x_dev, int x_is_f64, void *residual_dev,
+                              uint32_t *loc_dev, void *vals_dev)
+{
+    CHECK_CTX(ctx);
+    if (n_layers < 0 || (n_layers && (!n || !k))) return fail(ctx, FLASHE_EINVAL, "sparsify_batch: bad arguments");
+    if (n_layers == 0) return FLASHE_OK;
+    if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "sparsify_batch: not inside a graph capture (the layer table is uploaded synchronously)");
+    uint64_t total = 0, total_k = 0;
+    for (int l = 0; l < n_layers; l++) {
+        if (n[l] >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "sparsify_batch: layer %d: n must be < 2^32", l);
+        if (k[l] > n[l]) return fail(ctx, FLASHE_EINVAL, "sparsify_batch: layer %d: k (%llu) > n (%llu)", l, static_cast<unsigned long long>(k[l]),
+                                     static_cast<unsigned long long>(n[l]));
+        total += n[l]; total_k += k[l];
+    }
+    if (total == 0 || total_k == 0) return FLASHE_OK;
+    if (!x_dev || !loc_dev || !vals_dev) return fail(ctx, FLASHE_EINVAL, "null vector");
+    std::vector<unsigned char> desc(sparsify_batch_desc_bytes(n_layers));
+    const uint64_t blocks = sparsify_batch_layout(n_layers, n, k, desc.data());
+    if (blocks >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "sparsify_batch: too many elements");
+    int rc = ensure(ctx, ctx->sp_ws, sparsify_batch_workspace_bytes(n_layers, blocks));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sp_ws.p, desc.data(), desc.size(), hipMemcpyHostToDevice, ctx->env.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));                  // the table is on the device before `desc` goes away
+    HIP_TRY(ctx, launch_sparsify_batch(ctx->env, n_layers, blocks, x_dev, x_is_f64 != 0, residual_dev, loc_dev, vals_dev, ctx->sp_ws.p));
+    return FLASHE_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Host-pointer twins: H2D, the _dev call, D2H, synchronous.
 // ------------------------------------------------------------------------------------------
@@ -1966,6 +1995,30 @@ int flashe_sparsify(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x, int 
     if (residual) HIP_TRY(ctx, hipMemcpyAsync(residual, dr.p, n * es, hipMemcpyDeviceToHost, ctx->env.stream));
     HIP_TRY(ctx, hipMemcpyAsync(loc, dl.p, k * 4, hipMemcpyDeviceToHost, ctx->env.stream));
     D2H(vals, dv.p, k * es);
+    return FLASHE_OK;
+}
+
+int flashe_sparsify_batch(flashe_ctx *ctx, int n_layers, const uint64_t *n, const uint64_t *k, const void *x, int x_is_f64, void *residual,
+                          uint32_t *loc, void *vals)
+{
+    CHECK_CTX(ctx);
+    if (n_layers < 0 || (n_layers && (!n || !k))) return fail(ctx, FLASHE_EINVAL, "sparsify_batch: bad arguments");
+    uint64_t total = 0, total_k = 0;
+    for (int l = 0; l < n_layers; l++) { total += n[l]; total_k += k[l]; }
+    if (total == 0 || total_k == 0) return FLASHE_OK;
+    if (!x || !loc || !vals) return fail(ctx, FLASHE_EINVAL, "null vector");
+    const size_t es = x_is_f64 ? 8 : 4;
+    Tmp dx, dr, dl, dv;
+    HIP_TRY(ctx, dx.alloc(ctx, total * es));
+    HIP_TRY(ctx, dl.alloc(ctx, total_k * 4));
+    HIP_TRY(ctx, dv.alloc(ctx, total_k * es));
+    H2D(dx.p, x, total * es);
+    if (residual) { HIP_TRY(ctx, dr.alloc(ctx, total * es)); H2D(dr.p, residual, total * es); }
+    int rc = flashe_sparsify_batch_dev(ctx, n_layers, n, k, dx.p, x_is_f64, residual ? dr.p : nullptr, dl.as<uint32_t>(), dv.p);
+    if (rc) return rc;
+    if (residual) HIP_TRY(ctx, hipMemcpyAsync(residual, dr.p, total * es, hipMemcpyDeviceToHost, ctx->env.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(loc, dl.p, total_k * 4, hipMemcpyDeviceToHost, ctx->env.stream));
+    D2H(vals, dv.p, total_k * es);
     return FLASHE_OK;
 }
 

@@ -188,6 +188,14 @@ hipError_t launch_unquantize(const LaunchEnv &env, uint64_t n, const uint64_t *v
 hipError_t launch_batch(const LaunchEnv &env, uint64_t n, const uint64_t *vals_dev, int field_bits, uint64_t *out_dev);
 hipError_t launch_unbatch(const LaunchEnv &env, uint64_t nb, const uint64_t *in_dev, int field_bits, uint64_t *out_dev);
 
+// Top-k of every layer of a model in one set of launches: the layers lie back to back in flat buffers.  The caller fills the host
+// layer table with sparsify_batch_layout (-> number of 1024-element blocks), copies its sparsify_batch_desc_bytes(L) bytes to the START
+// of a device workspace of sparsify_batch_workspace_bytes(L, blocks), then launches.
+size_t sparsify_batch_workspace_bytes(int L, uint64_t n_blocks);
+size_t sparsify_batch_desc_bytes(int L);
+uint64_t sparsify_batch_layout(int L, const uint64_t *n, const uint64_t *k, void *desc_host);
+hipError_t launch_sparsify_batch(const LaunchEnv &env, int L, uint64_t n_blocks, const void *x, bool is_f64, void *residual, uint32_t *loc, void *vals,
+                                 void *ws);
 // Top-k sparsifier; ws = device workspace of sparsify_workspace_bytes(n).
 size_t sparsify_workspace_bytes(uint64_t n);
 hipError_t launch_sparsify(const LaunchEnv &env, uint64_t n, uint64_t k, const void *x, bool is_f64, void *residual, uint32_t *loc,

@@ -171,6 +171,227 @@ static hipError_t sparsify_impl(const LaunchEnv &env, uint64_t n, uint64_t k, co
     return hipGetLastError();
 }
 
+// ---- every layer of a model in one set of launches ---------------------------------------------------------------------------
+// Client.sparsify walks the layers (jzf_aggregator.py:585-613): one top-k per layer.  Layer by layer that is 12 (float32) or 20
+// (float64) launches each -- a ResNet-50 has 161 layers, most of them far smaller than what fills the chip, so the model costs ~15 ms
+// of launches for 0.4 ms of work.  Here the layers lie back to back in ONE flat buffer, the 1024-element blocks of the stages never
+// cross a layer boundary (block b belongs to the layer l with blk0[l] <= b < blk0[l] + nb[l]), every layer has its own select state
+// and histogram, and each stage is ONE launch over all layers: 12 / 20 launches per model.
+struct SpLayer {                // per layer, in device memory
+    uint64_t off, n, k, koff;   // first element in the flat buffers, elements, entries to select, first entry in the flat outputs
+    uint32_t blk0, nb;          // first 1024-element block, number of blocks
+};
+
+__device__ __forceinline__ int spb_layer_of(const SpLayer *ly, int L, uint32_t b)
+{
+    int lo = 0, hi = L - 1;
+    while (lo < hi) {           // the last layer whose first block is <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (ly[mid].blk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__global__ void spb_init_kernel(const SpLayer *ly, SelectState *st, uint32_t *hist)
+{
+    const int l = blockIdx.x;
+    if (threadIdx.x == 0) { st[l].prefix = 0; st[l].mask = 0; st[l].remaining = ly[l].k; st[l].total_eq = 0; }
+    hist[l * 256 + threadIdx.x] = 0;
+}
+
+constexpr uint32_t kSpGroup = 8;        // consecutive blocks per workgroup of the histogram pass (one LDS histogram while the layer stays the same)
+
+template <typename T>
+__global__ __launch_bounds__(kSpThreads) void spb_hist_kernel(int L, const SpLayer *ly, uint32_t n_blocks, const T *x, const SelectState *st, int shift,
+                                                                uint32_t *hist)
+{
+    __shared__ uint32_t lh[256];
+    __shared__ int s_layer;
+    int cur = -1;
+    for (uint32_t s = 0; s < kSpGroup; s++) {
+        const uint32_t b = blockIdx.x * kSpGroup + s;
+        if (b >= n_blocks) break;
+        if (threadIdx.x == 0) s_layer = spb_layer_of(ly, L, b);
+        __syncthreads();
+        const int l = s_layer;
+        if (l != cur) {
+            if (cur >= 0 && threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[cur * 256 + threadIdx.x], lh[threadIdx.x]);
+            __syncthreads();
+            if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+            cur = l;
+            __syncthreads();
+        }
+        const uint64_t i = static_cast<uint64_t>(b - ly[l].blk0) * kSpThreads + threadIdx.x;
+        if (i < ly[l].n) {
+            const unsigned long long key = KeyOf<T>::get(x[ly[l].off + i]);
+            if ((key & st[l].mask) == st[l].prefix) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+    }
+    if (cur >= 0 && threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[cur * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+__global__ void spb_pick_digit_kernel(SelectState *st_all, int shift, uint32_t *hist_all)
+{
+    SelectState *st = st_all + blockIdx.x;
+    uint32_t *hist = hist_all + blockIdx.x * 256;
+    if (threadIdx.x == 0) {
+        unsigned long long remaining = st->remaining, acc = 0;
+        int d = 255;
+        for (; d > 0; d--) {
+            if (acc + hist[d] >= remaining) break;
+            acc += hist[d];
+        }
+        st->remaining = remaining - acc;
+        st->prefix |= static_cast<unsigned long long>(d) << shift;
+        st->mask |= 255ull << shift;
+    }
+    __syncthreads();
+    hist[threadIdx.x] = 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSpThreads) void spb_count_kernel(int L, const SpLayer *ly, const T *x, const SelectState *st, uint32_t *blk_gt, uint32_t *blk_eq)
+{
+    __shared__ uint32_t c[2];
+    __shared__ int s_layer;
+    if (threadIdx.x < 2) c[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_layer = spb_layer_of(ly, L, blockIdx.x);
+    __syncthreads();
+    const int l = s_layer;
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x - ly[l].blk0) * kSpThreads + threadIdx.x;
+    const bool live = i < ly[l].n;
+    const unsigned long long thr = st[l].prefix;
+    const unsigned long long key = live ? static_cast<unsigned long long>(KeyOf<T>::get(x[ly[l].off + i])) : 0ull;
+    const unsigned long long gt = __ballot(live && key > thr), eq = __ballot(live && key == thr);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&c[0], __popcll(gt)); atomicAdd(&c[1], __popcll(eq)); }
+    __syncthreads();
+    if (threadIdx.x == 0) { blk_gt[blockIdx.x] = c[0]; blk_eq[blockIdx.x] = c[1]; }
+}
+
+// per layer: exclusive scans over its blocks' counts (workgroup l scans layer l)
+__global__ __launch_bounds__(kSpThreads) void spb_scan_kernel(const SpLayer *ly, uint32_t *blk_gt_all, uint32_t *blk_eq_all, SelectState *st_all)
+{
+    __shared__ unsigned long long sums[2][kSpThreads];
+    const uint32_t n_blocks = ly[blockIdx.x].nb;
+    uint32_t *blk_gt = blk_gt_all + ly[blockIdx.x].blk0, *blk_eq = blk_eq_all + ly[blockIdx.x].blk0;
+    SelectState *st = st_all + blockIdx.x;
+    const uint32_t per = (n_blocks + kSpThreads - 1) / kSpThreads;
+    const uint32_t b0 = min(threadIdx.x * per, n_blocks), b1 = min(b0 + per, n_blocks);
+    unsigned long long g = 0, e = 0;
+    for (uint32_t b = b0; b < b1; b++) { g += blk_gt[b]; e += blk_eq[b]; }
+    sums[0][threadIdx.x] = g; sums[1][threadIdx.x] = e;
+    __syncthreads();
+    for (int off = 1; off < kSpThreads; off <<= 1) {
+        unsigned long long ag = 0, ae = 0;
+        if (static_cast<int>(threadIdx.x) >= off) { ag = sums[0][threadIdx.x - off]; ae = sums[1][threadIdx.x - off]; }
+        __syncthreads();
+        sums[0][threadIdx.x] += ag; sums[1][threadIdx.x] += ae;
+        __syncthreads();
+    }
+    if (threadIdx.x == kSpThreads - 1) st->total_eq = sums[1][threadIdx.x];
+    const unsigned long long own_g = g, own_e = e;
+    g = sums[0][threadIdx.x] - own_g; e = sums[1][threadIdx.x] - own_e;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t tg = blk_gt[b], te = blk_eq[b];
+        blk_gt[b] = static_cast<uint32_t>(g); blk_eq[b] = static_cast<uint32_t>(e);
+        g += tg; e += te;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kSpThreads) void spb_write_kernel(int L, const SpLayer *ly, const T *x_all, T *residual_all, const SelectState *st_all,
+                                                                 const uint32_t *blk_gt_off, const uint32_t *blk_eq_off, uint32_t *loc_all, T *vals_all)
+{
+    __shared__ uint32_t wg[kSpThreads / 64], we[kSpThreads / 64];
+    __shared__ int s_layer;
+    if (threadIdx.x == 0) s_layer = spb_layer_of(ly, L, blockIdx.x);
+    __syncthreads();
+    const int l = s_layer;
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x - ly[l].blk0) * kSpThreads + threadIdx.x;
+    const T *x = x_all + ly[l].off;
+    T *residual = residual_all ? residual_all + ly[l].off : nullptr;
+    uint32_t *loc = loc_all + ly[l].koff;
+    T *vals = vals_all + ly[l].koff;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long thr = st_all[l].prefix;
+    const unsigned long long skip = st_all[l].total_eq - st_all[l].remaining;      // the first `skip` ties (lowest indices) stay out
+    const bool live = i < ly[l].n;
+    const T xv = live ? x[i] : T(0);
+    const unsigned long long key = KeyOf<T>::get(xv);
+    const bool is_gt = live && key > thr, is_eq = live && key == thr;
+    const unsigned long long mg = __ballot(is_gt), me = __ballot(is_eq);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) { wg[wave] = __popcll(mg); we[wave] = __popcll(me); }
+    __syncthreads();
+    uint32_t og = 0, oe = 0;
+    for (int w = 0; w < wave; w++) { og += wg[w]; oe += we[w]; }
+    const unsigned long long gt_before = blk_gt_off[blockIdx.x] + og + __popcll(mg & below);
+    const unsigned long long eq_before = blk_eq_off[blockIdx.x] + oe + __popcll(me & below);
+    if (!live) return;
+    const bool selected = is_gt || (is_eq && eq_before >= skip);
+    const T v = xv + (residual ? residual[i] : T(0));
+    if (selected) {
+        const unsigned long long pos = gt_before + (eq_before > skip ? eq_before - skip : 0ull);
+        loc[pos] = static_cast<uint32_t>(i);
+        vals[pos] = v;
+        if (residual) residual[i] = T(0);
+    } else if (residual) {
+        residual[i] = v;
+    }
+}
+
+size_t sparsify_batch_workspace_bytes(int L, uint64_t n_blocks)
+{
+    return static_cast<size_t>(L) * (sizeof(SpLayer) + sizeof(SelectState) + 256 * 4) + 2 * n_blocks * 4 + 256;
+}
+
+size_t sparsify_batch_desc_bytes(int L) { return static_cast<size_t>(L) * sizeof(SpLayer); }
+
+// Fills the host copy of the layer table (layers back to back); returns the number of 1024-element blocks.
+uint64_t sparsify_batch_layout(int L, const uint64_t *n, const uint64_t *k, void *desc_host)
+{
+    SpLayer *ly = static_cast<SpLayer *>(desc_host);
+    uint64_t off = 0, koff = 0, blk = 0;
+    for (int l = 0; l < L; l++) {
+        const uint64_t nb = (n[l] + kSpThreads - 1) / kSpThreads;
+        ly[l] = SpLayer{off, n[l], k[l], koff, static_cast<uint32_t>(blk), static_cast<uint32_t>(nb)};
+        off += n[l]; koff += k[l]; blk += nb;
+    }
+    return blk;
+}
+
+template <typename T>
+static hipError_t sparsify_batch_impl(const LaunchEnv &env, int L, uint64_t n_blocks, const T *x, T *residual, uint32_t *loc, T *vals, void *ws)
+{
+    // workspace: SpLayer[L] (already uploaded) | SelectState[L] | hist[L][256] | blk_gt[n_blocks] | blk_eq[n_blocks]
+    const SpLayer *ly = static_cast<const SpLayer *>(ws);
+    SelectState *st = reinterpret_cast<SelectState *>(const_cast<SpLayer *>(ly) + L);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(st + L);
+    uint32_t *blk_gt = hist + static_cast<size_t>(L) * 256, *blk_eq = blk_gt + n_blocks;
+    const unsigned nb = static_cast<unsigned>(n_blocks);
+    hipLaunchKernelGGL(spb_init_kernel, dim3(L), dim3(256), 0, env.stream, ly, st, hist);
+    const unsigned hgrid = (nb + kSpGroup - 1) / kSpGroup;
+    for (int shift = KeyOf<T>::bits - 8; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(spb_hist_kernel<T>, dim3(hgrid), dim3(kSpThreads), 0, env.stream, L, ly, nb, x, st, shift, hist);
+        hipLaunchKernelGGL(spb_pick_digit_kernel, dim3(L), dim3(256), 0, env.stream, st, shift, hist);
+    }
+    hipLaunchKernelGGL(spb_count_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, L, ly, x, st, blk_gt, blk_eq);
+    hipLaunchKernelGGL(spb_scan_kernel, dim3(L), dim3(kSpThreads), 0, env.stream, ly, blk_gt, blk_eq, st);
+    hipLaunchKernelGGL(spb_write_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, L, ly, x, residual, st, blk_gt, blk_eq, loc, vals);
+    return hipGetLastError();
+}
+
+hipError_t launch_sparsify_batch(const LaunchEnv &env, int L, uint64_t n_blocks, const void *x, bool is_f64, void *residual, uint32_t *loc, void *vals,
+                                 void *ws)
+{
+    if (L <= 0 || n_blocks == 0) return hipSuccess;
+    return is_f64 ? sparsify_batch_impl<double>(env, L, n_blocks, static_cast<const double *>(x), static_cast<double *>(residual), loc,
+                                                static_cast<double *>(vals), ws)
+                  : sparsify_batch_impl<float>(env, L, n_blocks, static_cast<const float *>(x), static_cast<float *>(residual), loc,
+                                               static_cast<float *>(vals), ws);
+}
+
 size_t sparsify_workspace_bytes(uint64_t n)
 {
     const uint64_t nb = (n + kSpThreads - 1) / kSpThreads;

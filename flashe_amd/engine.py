@@ -777,6 +777,69 @@ class Engine:
         self._check(self._lib.flashe_sparsify_dev(self._h, n, k, self._ptr(x), 1 if x_is_f64 else 0, self._ptr(residual),
                                                   self._ptr(loc), self._ptr(vals)))
 
+    def sparsify_batch_dev(self, ns, ks, x, x_is_f64, residual, loc, vals):
+        """Top-k of every layer of a model in one set of launches: layers back to back in the flat device vectors x / residual, outputs
+        back to back in loc / vals (locations relative to their layer)."""
+        L = len(ns)
+        an = (c_u64 * max(L, 1))(*[int(v) for v in ns])
+        ak = (c_u64 * max(L, 1))(*[int(v) for v in ks])
+        self._check(self._lib.flashe_sparsify_batch_dev(self._h, L, an, ak, self._ptr(x), 1 if x_is_f64 else 0, self._ptr(residual),
+                                                        self._ptr(loc), self._ptr(vals)))
+
+    def sparsify_batch(self, layers, ks, residuals=None):
+        """[(loc uint32[k_l] ascending, vals[k_l], new residual or None) per layer] -- Client.sparsify's layer loop
+        (jzf_aggregator.py:585-613) as ONE upload, one set of launches and one download.  All layers share one float type."""
+        flats = [np.ascontiguousarray(l).reshape(-1) for l in layers]
+        dt = np.result_type(*[f.dtype for f in flats]) if flats else np.float64
+        if dt not in (np.float32, np.float64):
+            dt = np.float64
+        ns = [int(f.size) for f in flats]
+        ks = [int(v) for v in ks]
+        x = np.concatenate([f.astype(dt, copy=False) for f in flats]) if flats else np.zeros(0, dtype=dt)
+        res = None
+        if residuals is not None:
+            res = np.concatenate([np.ascontiguousarray(r, dtype=dt).reshape(-1) for r in residuals]) if flats else np.zeros(0, dtype=dt)
+        loc = np.zeros(sum(ks), dtype=np.uint32)
+        vals = np.zeros(sum(ks), dtype=dt)
+        L = len(ns)
+        an = (c_u64 * max(L, 1))(*ns)
+        ak = (c_u64 * max(L, 1))(*ks)
+        self._check(self._lib.flashe_sparsify_batch(self._h, L, an, ak, x.ctypes.data, 1 if dt == np.float64 else 0,
+                                                    res.ctypes.data if res is not None else None, loc.ctypes.data, vals.ctypes.data))
+        out, o, q = [], 0, 0
+        for n_l, k_l in zip(ns, ks):
+            out.append((loc[q:q + k_l], vals[q:q + k_l], None if res is None else res[o:o + n_l]))
+            o += n_l
+            q += k_l
+        return out
+
+    def sparsify_model(self, layers, ks, residual_dev=None, dtype=None):
+        """sparsify_batch for a caller that keeps the residuals ON THE DEVICE between rounds: every layer is copied straight into its
+        slot of one flat device buffer (no host-side concatenation), residual_dev (a DeviceBuffer of the flat residuals, updated in
+        place; None = no residual) never crosses PCIe, only the k_l selected entries come back.  -> [(loc, vals) per layer]."""
+        flats = [np.ascontiguousarray(l).reshape(-1) for l in layers]
+        dt = np.dtype(dtype) if dtype is not None else (np.result_type(*[f.dtype for f in flats]) if flats else np.dtype(np.float64))
+        if dt not in (np.float32, np.float64):
+            dt = np.dtype(np.float64)
+        ns = [int(f.size) for f in flats]
+        ks = [int(v) for v in ks]
+        total, total_k = sum(ns), sum(ks)
+        dx = self.alloc(max(total * dt.itemsize, 16))
+        off = 0
+        for f in flats:
+            f = f.astype(dt, copy=False)
+            if f.size:
+                self._check(self._lib.flashe_memcpy_h2d(self._h, dx.ptr + off, f.ctypes.data, f.nbytes))
+            off += f.nbytes
+        dl, dv = self.alloc(max(4 * total_k, 16)), self.alloc(max(dt.itemsize * total_k, 16))
+        self.sparsify_batch_dev(ns, ks, dx, dt == np.float64, residual_dev, dl, dv)
+        loc, vals = dl.download(np.uint32, total_k), dv.download(dt, total_k)
+        out, q = [], 0
+        for k_l in ks:
+            out.append((loc[q:q + k_l], vals[q:q + k_l]))
+            q += k_l
+        return out
+
     def sparsify(self, layer, k, residual=None):
         """-> (loc uint32[k] ascending, vals[k] = layer + residual at loc, new residual or None)."""
         layer = np.ascontiguousarray(layer).reshape(-1)

@@ -91,30 +91,67 @@ class Sparsifier(object):
     def __init__(self, sparsity, device=0):
         self._sparsity = sparsity
         self._device = device
-        self.remain_weights = None
+        self._remain_host = None            # name -> residual array (what the reference keeps in self.remain_weights)
+        self._remain_dev = None             # or: (DeviceBuffer of the flat residuals, names, sizes, dtype) -- they stay in HBM between rounds
         self.shape_dict_used_for_sparsification = None
+
+    @property
+    def remain_weights(self):
+        """name -> residual, as the reference's attribute.  The residuals live on the device between rounds (they are only ever read
+        and updated by the next sparsify); reading this attribute downloads them."""
+        if self._remain_dev is not None and self._remain_host is None:
+            buf, names, sizes, dt = self._remain_dev
+            flat = buf.download(dt, sum(sizes))
+            self._remain_host, o = {}, 0
+            for name, n in zip(names, sizes):
+                self._remain_host[name] = flat[o:o + n]
+                o += n
+        return self._remain_host
+
+    @remain_weights.setter
+    def remain_weights(self, value):
+        self._remain_host, self._remain_dev = value, None
 
     def sparsify(self, weights, walking_order=None):
         """weights: dict name -> float ndarray, replaced IN PLACE by the compact masked layers.
         Returns (encoded_locations, length, bits, total) like the reference."""
         eng = _engine(128, self._device)
-        if self.remain_weights is None:
-            self.remain_weights = {}
-        order = walking_order if walking_order is not None else sorted(weights.keys(), key=str)
+        order = list(walking_order) if walking_order is not None else sorted(weights.keys(), key=str)
         base, locations, shapes = 0, [], {}
+        layers, ks = [], []
         for k in order:
             layer = np.asarray(weights[k])
             shapes[k] = layer.shape
-            size = int(np.prod(layer.shape))
-            idx = max(1, int(np.floor(self._sparsity * size)))
-            remain = self.remain_weights.get(k)
-            if remain is None:
-                remain = np.zeros(size, dtype=layer.dtype if layer.dtype in (np.float32, np.float64) else np.float64)
-            loc, vals, new_remain = eng.sparsify(layer.reshape(-1), idx, remain)
+            layers.append(layer.reshape(-1))
+            ks.append(max(1, int(np.floor(self._sparsity * int(layer.size)))))
+        sizes = [int(l.size) for l in layers]
+        dtypes = {l.dtype for l in layers}
+        dt = next(iter(dtypes)) if len(dtypes) == 1 else None
+        if hasattr(eng, "sparsify_model") and dt in (np.float32, np.float64):
+            # every layer in one set of launches (a layer-by-layer walk is ~12 launches and three synchronous transfers PER LAYER), the
+            # layers copied straight into one flat device buffer, the residuals kept in HBM from round to round
+            dev = self._remain_dev
+            if dev is None or dev[1] != order or dev[2] != sizes or dev[3] != dt:
+                host = self._remain_host or {}
+                flat = np.concatenate([np.ascontiguousarray(host[k], dtype=dt).reshape(-1) if host.get(k) is not None else np.zeros(n, dtype=dt)
+                                       for k, n in zip(order, sizes)]) if sizes else np.zeros(0, dtype=dt)
+                dev = (eng.upload(flat) if flat.size else eng.alloc(16), order, sizes, dt)
+            results = eng.sparsify_model(layers, ks, dev[0], dt)
+            self._remain_dev, self._remain_host = dev, None
+        else:
+            remain = dict(self.remain_weights or {})
+            results = []
+            for k, layer, k_l in zip(order, layers, ks):
+                r = remain.get(k)
+                if r is None:
+                    r = np.zeros(layer.size, dtype=layer.dtype if layer.dtype in (np.float32, np.float64) else np.float64)
+                loc, vals, remain[k] = eng.sparsify(layer, k_l, r)
+                results.append((loc, vals))
+            self.remain_weights = remain
+        for k, layer, (loc, vals) in zip(order, layers, results):
             weights[k] = vals
-            self.remain_weights[k] = new_remain
             locations.append(loc.astype(np.uint64) + np.uint64(base))
-            base += size
+            base += int(layer.size)
         if self.shape_dict_used_for_sparsification is None:
             self.shape_dict_used_for_sparsification = shapes
         all_loc = np.concatenate(locations) if locations else np.zeros(0, dtype=np.uint64)

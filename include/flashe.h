@@ -438,6 +438,15 @@ int flashe_sparsify_dev(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x_d
                         uint32_t *loc_dev, void *vals_dev);
 int flashe_sparsify(flashe_ctx *ctx, uint64_t n, uint64_t k, const void *x, int x_is_f64, void *residual,
                     uint32_t *loc, void *vals);
+/* Client.sparsify for EVERY layer of a model in one set of launches (new): layer l is elements [off_l, off_l + n[l]) of the flat
+ * vectors x / residual (layers back to back, off_l = n[0] + ... + n[l-1]); its k[l] selected entries go to [koff_l, koff_l + k[l])
+ * of the flat outputs loc / vals (koff_l = k[0] + ... + k[l-1]), locations relative to the layer, ascending -- layer by layer exactly
+ * what flashe_sparsify gives (same tie rule).  n and k are HOST arrays; 12 (float32) / 20 (float64) launches per MODEL instead of per
+ * layer (a ResNet-50 has 161 layers).  The _dev form synchronises the ctx stream once (layer table upload); not inside a graph capture. */
+int flashe_sparsify_batch_dev(flashe_ctx *ctx, int n_layers, const uint64_t *n, const uint64_t *k, const void *x_dev, int x_is_f64,
+                              void *residual_dev, uint32_t *loc_dev, void *vals_dev);
+int flashe_sparsify_batch(flashe_ctx *ctx, int n_layers, const uint64_t *n, const uint64_t *k, const void *x, int x_is_f64,
+                          void *residual, uint32_t *loc, void *vals);
 
 /* ---- multi-GPU exchange (RCCL over xGMI; one process per GPU) ----------------------------------------------- */
 /* Replaces, inside one node, the arbiter's gather of client models + reduce in Python + broadcast of the aggregate

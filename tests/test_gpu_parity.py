@@ -1032,6 +1032,67 @@ def test_sparsify_golden_and_oracle(E, oracle):
     assert np.array_equal(w["a"], ref["a"].flatten()[want_a]) and sp.remain_weights["a"][want_a].sum() == 0
 
 
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_sparsify_every_layer_in_one_set_of_launches(E, oracle, dt):
+    """flashe_sparsify_batch[_dev] (Client.sparsify's layer loop, jzf_aggregator.py:585-613, as one set of launches): layer by layer
+    the same locations, values and residuals as the one-layer call and as the oracle -- layers of 1 .. 2.4 M elements, block-sized
+    and off-by-one sizes, k = 1 .. n, ties at the threshold, with and without residuals, a second round on the updated residuals;
+    and the dict-level Sparsifier on a model of 40 layers."""
+    eng = make(E, 128)
+    rng = np.random.Generator(np.random.PCG64(17))
+    sizes = [1, 2, 5, 150, 1023, 1024, 1025, 2048, 2400, 48_000, 61_706, 100_000, 2_359_296, 7, 4096, 3, 999_999]
+    layers, ks, res = [], [], []
+    for i, n in enumerate(sizes):
+        l = rng.standard_normal(n).astype(dt)
+        if n > 10:
+            l[::7] = l[3]                                 # many exact ties, often at the threshold
+        layers.append(l)
+        ks.append(int(max(1, [n // 100, n, 1, n - 1, n // 2][i % 5])))
+        res.append(rng.standard_normal(n).astype(dt))
+    for rnd in range(2):
+        got = eng.sparsify_batch(layers, ks, res)
+        for l, k, r, (loc, vals, new) in zip(layers, ks, res, got):
+            wl, wv, wr = oracle.sparsify(l, k, r)
+            assert np.array_equal(loc, wl) and vals.tobytes() == wv.tobytes() and new.tobytes() == wr.tobytes(), (dt, rnd, l.size, k)
+        res = [g[2].copy() for g in got]                                    # next round: the residuals this one left
+        layers = [rng.standard_normal(l.size).astype(dt) for l in layers]
+    got = eng.sparsify_batch(layers[:5], ks[:5], None)                     # no residuals
+    for l, k, (loc, vals, new) in zip(layers[:5], ks[:5], got):
+        wl, wv, _ = oracle.sparsify(l, k, np.zeros_like(l))
+        assert np.array_equal(loc, wl) and vals.tobytes() == wv.tobytes() and new is None
+    # device form on one flat buffer == host form
+    flat = np.concatenate(layers)
+    dx, dr = eng.upload(flat), eng.upload(np.concatenate(res))
+    dl, dv = eng.alloc(4 * sum(ks) + 16), eng.alloc(flat.itemsize * sum(ks) + 16)
+    eng.sparsify_batch_dev([l.size for l in layers], ks, dx, dt == np.float64, dr, dl, dv)
+    want = eng.sparsify_batch(layers, ks, res)
+    assert np.array_equal(dl.download(np.uint32, sum(ks)), np.concatenate([w[0] for w in want]))
+    assert dv.download(dt, sum(ks)).tobytes() == np.concatenate([w[1] for w in want]).tobytes()
+    assert dr.download(dt, flat.size).tobytes() == np.concatenate([w[2] for w in want]).tobytes()
+    with pytest.raises(E.FlasheError):
+        eng.sparsify_batch_dev([10, 20], [5, 21], dx, dt == np.float64, dr, dl, dv)      # k > n
+    # the dict-level mirror takes the batch path and equals the layer-by-layer walk
+    from flashe_amd import weights as wz
+    model = {f"l{i:02d}": rng.standard_normal(int(s)).astype(dt) for i, s in enumerate(rng.integers(1, 5000, 40))}
+    a, b = wz.Sparsifier(0.05), wz.Sparsifier(0.05)
+    real = E.Engine.sparsify_model
+    for rnd in range(3):                                      # the residuals of one round feed the next: on the device for a, on the host for b
+        model = {k: rng.standard_normal(v.size).astype(dt) for k, v in model.items()}
+        wa, wb = {k: v.copy() for k, v in model.items()}, {k: v.copy() for k, v in model.items()}
+        ea = a.sparsify(wa)
+        try:
+            del E.Engine.sparsify_model                       # force the layer-by-layer walk
+            eb = b.sparsify(wb)
+        finally:
+            E.Engine.sparsify_model = real
+        assert ea == eb and all(wa[k].tobytes() == wb[k].tobytes() for k in model), rnd
+        if rnd != 1:                                          # (round 1: a's residuals are never downloaded)
+            assert all(a.remain_weights[k].tobytes() == b.remain_weights[k].tobytes() for k in model), rnd
+    a.remain_weights = {k: v.copy() for k, v in b.remain_weights.items()}        # assigned from outside: uploaded again
+    wa, wb = {k: v.copy() for k, v in model.items()}, {k: v.copy() for k, v in model.items()}
+    assert a.sparsify(wa) == b.sparsify(wb) and all(a.remain_weights[k].tobytes() == b.remain_weights[k].tobytes() for k in model)
+
+
 # ------------------------------------------------------------------ BASELINE full sizes
 def _sum_u64(pts):
     lo = np.zeros_like(pts[0])
