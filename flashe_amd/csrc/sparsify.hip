@@ -32,6 +32,57 @@ template <> struct KeyOf<double> {
     __device__ static uint64_t get(double v) { return static_cast<uint64_t>(__double_as_longlong(v)) & 0x7fffffffffffffffull; }
 };
 
+// One histogram vote per lane with `on`.  The high digits of real weights are concentrated (a layer's magnitudes share a few
+// exponents): sixty-four lanes adding 1 to the same LDS word are sixty-four serialised atomics.  The digits the wave's lanes share
+// with its first few active lanes are therefore counted by ballot and added once; whatever is left votes lane by lane.
+__device__ __forceinline__ void sp_vote(uint32_t *lh, bool on, uint32_t digit)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long active = __ballot(on);
+#pragma unroll 1
+    for (int it = 0; it < 4 && active; it++) {
+        const int leader = static_cast<int>(__ffsll(static_cast<unsigned long long>(active))) - 1;
+        const uint32_t d0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(digit), leader));
+        const unsigned long long same = __ballot(on && digit == d0) & active;
+        if (__popcll(same) < 4) break;                            // spread out: not worth another round
+        if (lane == leader) atomicAdd(&lh[d0], static_cast<uint32_t>(__popcll(same)));
+        active &= ~same;
+    }
+    if ((active >> lane) & 1ull) atomicAdd(&lh[digit], 1u);
+}
+
+// The digit of this pass from the layer's 256-bin histogram: the highest d with count(bins > d) < remaining <= count(bins >= d).
+// 256 threads: suffix sums by a Hillis-Steele scan in LDS (a single thread walking the bins is 256 dependent loads, ~15 us).
+__device__ __forceinline__ void sp_pick(SelectState *st, int shift, uint32_t *hist)
+{
+    __shared__ unsigned long long suf[256];
+    __shared__ int s_d;
+    const int t = threadIdx.x;                                    // 0 .. 255
+    suf[t] = hist[255 - t];                                       // reversed: suf[t] will hold count(bins >= 255 - t)
+    if (t == 0) s_d = st->remaining == 0 ? 255 : 0;             // (nothing left to take: the walk from the top stops at once)
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned long long a = t >= off ? suf[t - off] : 0ull;
+        __syncthreads();
+        suf[t] += a;
+        __syncthreads();
+    }
+    const unsigned long long remaining = st->remaining;
+    // bin d = 255 - t is the one iff count(bins > d) < remaining <= count(bins >= d); bin 0 takes what no higher bin covers
+    const unsigned long long above = t ? suf[t - 1] : 0ull;
+    if (above < remaining && (suf[t] >= remaining || t == 255)) s_d = 255 - t;     // exactly one thread (suffix sums are monotone)
+    __syncthreads();
+    const int d = s_d;
+    if (t == 0) {
+        const unsigned long long acc = d < 255 ? suf[254 - d] : 0ull;              // count(bins > d)
+        st->remaining = remaining - acc;                                            // everything in the higher bins is taken whole
+        st->prefix |= static_cast<unsigned long long>(d) << shift;
+        st->mask |= 255ull << shift;
+    }
+    __syncthreads();
+    hist[t] = 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kSpThreads) void sp_hist_kernel(uint64_t n, const T *x, const SelectState *st, int shift, uint32_t *hist)
 {
@@ -42,7 +93,7 @@ __global__ __launch_bounds__(kSpThreads) void sp_hist_kernel(uint64_t n, const T
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * kSpThreads + threadIdx.x; i < n;
          i += static_cast<uint64_t>(gridDim.x) * kSpThreads) {
         const unsigned long long key = KeyOf<T>::get(x[i]);
-        if ((key & mask) == prefix) atomicAdd(&lh[(key >> shift) & 255u], 1u);
+        sp_vote(lh, (key & mask) == prefix, static_cast<uint32_t>((key >> shift) & 255u));
     }
     __syncthreads();
     if (threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
@@ -56,19 +107,7 @@ __global__ void sp_init_kernel(SelectState *st, unsigned long long k, uint32_t *
 
 __global__ void sp_pick_digit_kernel(SelectState *st, int shift, uint32_t *hist)
 {
-    if (threadIdx.x == 0) {
-        unsigned long long remaining = st->remaining, acc = 0;
-        int d = 255;
-        for (; d > 0; d--) {
-            if (acc + hist[d] >= remaining) break;
-            acc += hist[d];
-        }
-        st->remaining = remaining - acc;                 // everything in the higher bins is taken whole
-        st->prefix |= static_cast<unsigned long long>(d) << shift;
-        st->mask |= 255ull << shift;
-    }
-    __syncthreads();
-    hist[threadIdx.x] = 0;
+    sp_pick(st, shift, hist);
 }
 
 template <typename T>
@@ -192,6 +231,13 @@ __device__ __forceinline__ int spb_layer_of(const SpLayer *ly, int L, uint32_t b
     return lo;
 }
 
+// block b -> its layer, once per call (every stage then reads one word instead of searching the layer table)
+__global__ void spb_map_kernel(int L, const SpLayer *ly, uint32_t n_blocks, uint32_t *blk_layer)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_blocks) blk_layer[b] = static_cast<uint32_t>(spb_layer_of(ly, L, b));
+}
+
 __global__ void spb_init_kernel(const SpLayer *ly, SelectState *st, uint32_t *hist)
 {
     const int l = blockIdx.x;
@@ -202,19 +248,17 @@ __global__ void spb_init_kernel(const SpLayer *ly, SelectState *st, uint32_t *hi
 constexpr uint32_t kSpGroup = 8;        // consecutive blocks per workgroup of the histogram pass (one LDS histogram while the layer stays the same)
 
 template <typename T>
-__global__ __launch_bounds__(kSpThreads) void spb_hist_kernel(int L, const SpLayer *ly, uint32_t n_blocks, const T *x, const SelectState *st, int shift,
-                                                                uint32_t *hist)
+__global__ __launch_bounds__(kSpThreads) void spb_hist_kernel(const uint32_t *blk_layer, const SpLayer *ly, uint32_t n_blocks, const T *x,
+                                                                const SelectState *st, int shift, uint32_t *hist)
 {
     __shared__ uint32_t lh[256];
-    __shared__ int s_layer;
     int cur = -1;
     for (uint32_t s = 0; s < kSpGroup; s++) {
         const uint32_t b = blockIdx.x * kSpGroup + s;
         if (b >= n_blocks) break;
-        if (threadIdx.x == 0) s_layer = spb_layer_of(ly, L, b);
-        __syncthreads();
-        const int l = s_layer;
+        const int l = static_cast<int>(blk_layer[b]);
         if (l != cur) {
+            __syncthreads();                                      // every vote of the layer that ends here is in
             if (cur >= 0 && threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[cur * 256 + threadIdx.x], lh[threadIdx.x]);
             __syncthreads();
             if (threadIdx.x < 256) lh[threadIdx.x] = 0;
@@ -222,43 +266,27 @@ __global__ __launch_bounds__(kSpThreads) void spb_hist_kernel(int L, const SpLay
             __syncthreads();
         }
         const uint64_t i = static_cast<uint64_t>(b - ly[l].blk0) * kSpThreads + threadIdx.x;
-        if (i < ly[l].n) {
-            const unsigned long long key = KeyOf<T>::get(x[ly[l].off + i]);
-            if ((key & st[l].mask) == st[l].prefix) atomicAdd(&lh[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
+        const bool live = i < ly[l].n;
+        const unsigned long long key = live ? static_cast<unsigned long long>(KeyOf<T>::get(x[ly[l].off + i])) : 0ull;
+        sp_vote(lh, live && (key & st[l].mask) == st[l].prefix, static_cast<uint32_t>((key >> shift) & 255u));
     }
+    __syncthreads();
     if (cur >= 0 && threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[cur * 256 + threadIdx.x], lh[threadIdx.x]);
 }
 
 __global__ void spb_pick_digit_kernel(SelectState *st_all, int shift, uint32_t *hist_all)
 {
-    SelectState *st = st_all + blockIdx.x;
-    uint32_t *hist = hist_all + blockIdx.x * 256;
-    if (threadIdx.x == 0) {
-        unsigned long long remaining = st->remaining, acc = 0;
-        int d = 255;
-        for (; d > 0; d--) {
-            if (acc + hist[d] >= remaining) break;
-            acc += hist[d];
-        }
-        st->remaining = remaining - acc;
-        st->prefix |= static_cast<unsigned long long>(d) << shift;
-        st->mask |= 255ull << shift;
-    }
-    __syncthreads();
-    hist[threadIdx.x] = 0;
+    sp_pick(st_all + blockIdx.x, shift, hist_all + blockIdx.x * 256);
 }
 
 template <typename T>
-__global__ __launch_bounds__(kSpThreads) void spb_count_kernel(int L, const SpLayer *ly, const T *x, const SelectState *st, uint32_t *blk_gt, uint32_t *blk_eq)
+__global__ __launch_bounds__(kSpThreads) void spb_count_kernel(const uint32_t *blk_layer, const SpLayer *ly, const T *x, const SelectState *st, uint32_t *blk_gt,
+                                                                 uint32_t *blk_eq)
 {
     __shared__ uint32_t c[2];
-    __shared__ int s_layer;
     if (threadIdx.x < 2) c[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_layer = spb_layer_of(ly, L, blockIdx.x);
     __syncthreads();
-    const int l = s_layer;
+    const int l = static_cast<int>(blk_layer[blockIdx.x]);
     const uint64_t i = static_cast<uint64_t>(blockIdx.x - ly[l].blk0) * kSpThreads + threadIdx.x;
     const bool live = i < ly[l].n;
     const unsigned long long thr = st[l].prefix;
@@ -300,14 +328,12 @@ __global__ __launch_bounds__(kSpThreads) void spb_scan_kernel(const SpLayer *ly,
 }
 
 template <typename T>
-__global__ __launch_bounds__(kSpThreads) void spb_write_kernel(int L, const SpLayer *ly, const T *x_all, T *residual_all, const SelectState *st_all,
-                                                                 const uint32_t *blk_gt_off, const uint32_t *blk_eq_off, uint32_t *loc_all, T *vals_all)
+__global__ __launch_bounds__(kSpThreads) void spb_write_kernel(const uint32_t *blk_layer, const SpLayer *ly, const T *x_all, T *residual_all,
+                                                                 const SelectState *st_all, const uint32_t *blk_gt_off, const uint32_t *blk_eq_off,
+                                                                 uint32_t *loc_all, T *vals_all)
 {
     __shared__ uint32_t wg[kSpThreads / 64], we[kSpThreads / 64];
-    __shared__ int s_layer;
-    if (threadIdx.x == 0) s_layer = spb_layer_of(ly, L, blockIdx.x);
-    __syncthreads();
-    const int l = s_layer;
+    const int l = static_cast<int>(blk_layer[blockIdx.x]);
     const uint64_t i = static_cast<uint64_t>(blockIdx.x - ly[l].blk0) * kSpThreads + threadIdx.x;
     const T *x = x_all + ly[l].off;
     T *residual = residual_all ? residual_all + ly[l].off : nullptr;
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(kSpThreads) void spb_write_kernel(int L, const SpLa
     const unsigned long long gt_before = blk_gt_off[blockIdx.x] + og + __popcll(mg & below);
     const unsigned long long eq_before = blk_eq_off[blockIdx.x] + oe + __popcll(me & below);
     if (!live) return;
-    const bool selected = is_gt || (is_eq && eq_before >= skip);
+    const bool selected = ly[l].k != 0 && (is_gt || (is_eq && eq_before >= skip));       // (a layer that keeps nothing only updates its residual)
     const T v = xv + (residual ? residual[i] : T(0));
     if (selected) {
         const unsigned long long pos = gt_before + (eq_before > skip ? eq_before - skip : 0ull);
@@ -343,7 +369,7 @@ __global__ __launch_bounds__(kSpThreads) void spb_write_kernel(int L, const SpLa
 
 size_t sparsify_batch_workspace_bytes(int L, uint64_t n_blocks)
 {
-    return static_cast<size_t>(L) * (sizeof(SpLayer) + sizeof(SelectState) + 256 * 4) + 2 * n_blocks * 4 + 256;
+    return static_cast<size_t>(L) * (sizeof(SpLayer) + sizeof(SelectState) + 256 * 4) + 3 * n_blocks * 4 + 256;
 }
 
 size_t sparsify_batch_desc_bytes(int L) { return static_cast<size_t>(L) * sizeof(SpLayer); }
@@ -364,21 +390,22 @@ uint64_t sparsify_batch_layout(int L, const uint64_t *n, const uint64_t *k, void
 template <typename T>
 static hipError_t sparsify_batch_impl(const LaunchEnv &env, int L, uint64_t n_blocks, const T *x, T *residual, uint32_t *loc, T *vals, void *ws)
 {
-    // workspace: SpLayer[L] (already uploaded) | SelectState[L] | hist[L][256] | blk_gt[n_blocks] | blk_eq[n_blocks]
+    // workspace: SpLayer[L] (already uploaded) | SelectState[L] | hist[L][256] | blk_gt[n_blocks] | blk_eq[n_blocks] | blk_layer[n_blocks]
     const SpLayer *ly = static_cast<const SpLayer *>(ws);
     SelectState *st = reinterpret_cast<SelectState *>(const_cast<SpLayer *>(ly) + L);
     uint32_t *hist = reinterpret_cast<uint32_t *>(st + L);
-    uint32_t *blk_gt = hist + static_cast<size_t>(L) * 256, *blk_eq = blk_gt + n_blocks;
+    uint32_t *blk_gt = hist + static_cast<size_t>(L) * 256, *blk_eq = blk_gt + n_blocks, *blk_layer = blk_eq + n_blocks;
     const unsigned nb = static_cast<unsigned>(n_blocks);
+    hipLaunchKernelGGL(spb_map_kernel, dim3((nb + 255) / 256), dim3(256), 0, env.stream, L, ly, nb, blk_layer);
     hipLaunchKernelGGL(spb_init_kernel, dim3(L), dim3(256), 0, env.stream, ly, st, hist);
     const unsigned hgrid = (nb + kSpGroup - 1) / kSpGroup;
     for (int shift = KeyOf<T>::bits - 8; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(spb_hist_kernel<T>, dim3(hgrid), dim3(kSpThreads), 0, env.stream, L, ly, nb, x, st, shift, hist);
+        hipLaunchKernelGGL(spb_hist_kernel<T>, dim3(hgrid), dim3(kSpThreads), 0, env.stream, blk_layer, ly, nb, x, st, shift, hist);
         hipLaunchKernelGGL(spb_pick_digit_kernel, dim3(L), dim3(256), 0, env.stream, st, shift, hist);
     }
-    hipLaunchKernelGGL(spb_count_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, L, ly, x, st, blk_gt, blk_eq);
+    hipLaunchKernelGGL(spb_count_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, blk_layer, ly, x, st, blk_gt, blk_eq);
     hipLaunchKernelGGL(spb_scan_kernel, dim3(L), dim3(kSpThreads), 0, env.stream, ly, blk_gt, blk_eq, st);
-    hipLaunchKernelGGL(spb_write_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, L, ly, x, residual, st, blk_gt, blk_eq, loc, vals);
+    hipLaunchKernelGGL(spb_write_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, blk_layer, ly, x, residual, st, blk_gt, blk_eq, loc, vals);
     return hipGetLastError();
 }
 
