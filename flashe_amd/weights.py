@@ -132,7 +132,7 @@ class Sparsifier(object):
             # layers copied straight into one flat device buffer, the residuals kept in HBM from round to round
             dev = self._remain_dev
             if dev is None or dev[1] != order or dev[2] != sizes or dev[3] != dt:
-                host = self._remain_host or {}
+                host = self.remain_weights or {}            # (downloads what a differently shaped earlier round left on the device)
                 flat = np.concatenate([np.ascontiguousarray(host[k], dtype=dt).reshape(-1) if host.get(k) is not None else np.zeros(n, dtype=dt)
                                        for k, n in zip(order, sizes)]) if sizes else np.zeros(0, dtype=dt)
                 dev = (eng.upload(flat) if flat.size else eng.alloc(16), order, sizes, dt)

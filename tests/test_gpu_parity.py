@@ -1088,6 +1088,22 @@ def test_sparsify_every_layer_in_one_set_of_launches(E, oracle, dt):
         assert ea == eb and all(wa[k].tobytes() == wb[k].tobytes() for k in model), rnd
         if rnd != 1:                                          # (round 1: a's residuals are never downloaded)
             assert all(a.remain_weights[k].tobytes() == b.remain_weights[k].tobytes() for k in model), rnd
+    # a model whose layers change shape between rounds keeps the residuals of the layers it still has
+    c, d = wz.Sparsifier(0.05), wz.Sparsifier(0.05)
+    m1 = {"x": rng.standard_normal(3000).astype(dt), "y": rng.standard_normal(500).astype(dt)}
+    m2 = {"x": rng.standard_normal(3000).astype(dt), "z": rng.standard_normal(70).astype(dt)}
+    for sp_, forced in ((c, False), (d, True)):
+        for m in (m1, m2):
+            w = {k: v.copy() for k, v in m.items()}
+            if forced:
+                try:
+                    del E.Engine.sparsify_model
+                    sp_.sparsify(w)
+                finally:
+                    E.Engine.sparsify_model = real
+            else:
+                sp_.sparsify(w)
+    assert all(c.remain_weights[k].tobytes() == d.remain_weights[k].tobytes() for k in ("x", "z"))
     a.remain_weights = {k: v.copy() for k, v in b.remain_weights.items()}        # assigned from outside: uploaded again
     wa, wb = {k: v.copy() for k, v in model.items()}, {k: v.copy() for k, v in model.items()}
     assert a.sparsify(wa) == b.sparsify(wb) and all(a.remain_weights[k].tobytes() == b.remain_weights[k].tobytes() for k in model)
