@@ -35,7 +35,8 @@ if ROOT not in sys.path:
 # The oracle's OpenMP team (parity gates, CPU baseline) must SLEEP between its parallel regions: spinning workers burn the
 # container's CPU quota and the throttling hits the thread that submits GPU work (measured: 100 launches 0.3 ms -> 4.9 ms).
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-os.environ.setdefault("NCCL_DEBUG", "WARN")     # RCCL's own warnings go to stderr: the first multi-GPU run must not fail silently
+os.environ.setdefault("NCCL_DEBUG", "WARN")     # RCCL's own warnings: the first multi-GPU run must not fail silently
+os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # ... and they (and its version banner) stay off stdout, which carries the ONE JSON line
 # RCCL shares device memory between the ranks of a node through dmabuf IPC handles; the legacy IPC mode is not supported by the host
 # driver of this pool (hipIpcGetMemHandle: invalid argument).  Must be in the environment before the HIP runtime starts.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -78,6 +79,9 @@ def parse():
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
     ap.add_argument("--no-partial-agg", action="store_true",
                     help="N > 1: keep the separate local reduce in the sequential round instead of letting the encrypt launch write the partial aggregate")
+    ap.add_argument("--collective", choices=["all_to_all", "allreduce"], default="all_to_all",
+                    help="how the GPUs' partial aggregates meet in the sequential round: all_to_all = reduce-scatter from point-to-point transfers "
+                         "+ local mod-add + all-gather (any --bits); allreduce = ncclAllReduce(uint64, sum) + mask (--bits <= 64 only)")
     ap.add_argument("--layout", choices=["u64", "u32"], default="u64",
                     help="u32 (config 2, --bits <= 32): plaintexts and ciphertexts as uint32 arrays -- the compact layout of the *_u32_dev entry "
                          "points; the default is the ABI's one-limb layout (uint64 per element)")
@@ -286,6 +290,28 @@ class _NoWatchdog:
         pass
 
 
+class _CStdoutToStderr:
+    """While active, file descriptor 1 points at stderr: RCCL prints its version banner with printf at communicator creation when
+    NCCL_DEBUG is set (NCCL_DEBUG_FILE does not move it), and stdout must carry the ONE JSON line and nothing else.  The C stdio
+    buffer is flushed before descriptor 1 goes back."""
+
+    def __enter__(self):
+        import ctypes
+        sys.stdout.flush()
+        self._libc = ctypes.CDLL(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            self._libc.fflush(None)
+        finally:
+            os.dup2(self._saved, 1)
+            os.close(self._saved)
+        return False
+
+
 def main(comm_factory=None, device_override=None):
     """comm_factory(rank, world) / device_override: TEST SEAMS, never set by this script -- tests/bench_shm.py runs this very flow with
     several ranks on ONE GPU by passing a file-based double of RcclComm (tests/shm_comm.py) and device 0 for every rank."""
@@ -348,7 +374,10 @@ def main(comm_factory=None, device_override=None):
         if comm_factory is not None:
             comm = comm_factory(rank, world)
         else:
-            comm = RcclComm.from_env(eng) if (world > 1 or args.force_dist) else None
+            comm = None
+            if world > 1 or args.force_dist:
+                with _CStdoutToStderr():
+                    comm = RcclComm.from_env(eng)
         ops = HipOps(eng, side, comm)
 
         if cfg == 2 and args.layout == "u32":
@@ -428,7 +457,10 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
         mine = deal_clients(total, world)[rank]
         scaling = "strong"
     C = len(mine)
-    rnd = ShardedRound(ops, n, b, mine, J, rank=rank, world=world, total_clients=total, force_collectives=args.force_dist)
+    if args.collective == "allreduce" and b > 64:
+        raise SystemExit("--collective allreduce needs --bits <= 64 (RCCL has no 128-bit integer sum)")
+    rnd = ShardedRound(ops, n, b, mine, J, rank=rank, world=world, total_clients=total, force_collectives=args.force_dist,
+                       collective=args.collective)
     host_pts = {c: plaintext(c, n, b) for c in mine}
     pts = [(ops.upload(host_pts[c]), 0) for c in mine]
     Qs = [max(args.pipeline_chunks, 1)] if args.pipeline_chunks is not None else [3, 4, 8]
@@ -561,6 +593,8 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
                        "config 2 on one GPU runs the two-launch round by default (the form profiles/ documents kernel by kernel); --schedule auto "
                        "also tries the fused and pipelined rounds (fused: 0-6 % faster, depending on the box)",
                        "collectives": (getattr(ops.comm, "LABEL", None) or "RCCL through libflashe_hip.so (no PyTorch)") if ops.comm else None,
+                       "exchange": (("ncclAllReduce(uint64, sum) + mask" if args.collective == "allreduce" else
+                                     "grouped ncclSend / ncclRecv all-to-all + local mod-add + ncclAllGather") if ops.comm else None),
                        "rccl_world": rccl_world, "ranks_counted_by_allreduce": ranks_counted, "ranks_parity_ok": bool(parity_all_ranks),
                        "parity": "bit-exact (on every rank, checked in-run before timing: decrypted aggregate == plaintext sum, and the first and "
                                  "last local client's ciphertext == the oracle's encrypt)"},

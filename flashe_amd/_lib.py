@@ -148,6 +148,7 @@ _SIGNATURES = {
     "flashe_rccl_all_to_all": (c_int, [c_vp, c_vp, c_vp, c_size, c_vp, c_size, c_size]),
     "flashe_rccl_all_gather": (c_int, [c_vp, c_vp, c_vp, c_vp, c_size]),
     "flashe_rccl_reduce_scatter_modadd": (c_int, [c_vp, c_vp, c_vp, c_u64, c_vp, c_vp, c_vp]),
+    "flashe_rccl_allreduce_modadd_u64": (c_int, [c_vp, c_vp, c_vp, c_u64]),
     "flashe_rccl_allreduce_f64": (c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_double), c_int]),
     "flashe_rccl_barrier": (c_int, [c_vp, c_vp]),
 }

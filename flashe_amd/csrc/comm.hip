@@ -199,6 +199,21 @@ int flashe_rccl_reduce_scatter_modadd(flashe_ctx *ctx, flashe_comm *comm, const 
     return flashe_aggregate_elem_dev(ctx, static_cast<int>(ops.size()), ops.data(), slice_elems, out_slice_dev);
 }
 
+// int_bits <= 64: the cross-GPU mod-add as RCCL's own all-reduce (ncclAllReduce(ncclUint64, ncclSum) wraps mod
+// 2^64, the mask to int_bits follows): buf[j] = (sum over ranks of buf[j]) mod 2^b on every rank, in place, on the ctx stream.
+int flashe_rccl_allreduce_modadd_u64(flashe_ctx *ctx, flashe_comm *comm, uint64_t *buf_dev, uint64_t count)
+{
+    CHECK_CTX(ctx);
+    if (!comm || (count && !buf_dev)) return fail(ctx, FLASHE_EINVAL, "flashe_rccl_allreduce_modadd_u64: bad arguments");
+    if (ctx->limbs != 1) return fail(ctx, FLASHE_EINVAL, "flashe_rccl_allreduce_modadd_u64 needs int_bits <= 64 (wider moduli: flashe_rccl_reduce_scatter_modadd)");
+    if (count == 0) return FLASHE_OK;
+    // (one rank: nothing to add; FLASHE_RCCL_SELF_SENDRECV=1 makes the call anyway, so that a one-GPU box exercises the real collective)
+    static const bool through_rccl = [] { const char *e = getenv("FLASHE_RCCL_SELF_SENDRECV"); return e && atoi(e) != 0; }();
+    if (comm->world > 1 || through_rccl) NCCL_TRY(ctx, rccl().AllReduce(buf_dev, buf_dev, count, ncclUint64, ncclSum, comm->comm, ctx->env.stream));
+    if (ctx->int_bits < 64) return flashe_combine_dev(ctx, count, buf_dev, 1, nullptr, nullptr, buf_dev);      // & (2^b - 1)
+    return FLASHE_OK;
+}
+
 // Host-value all-reduce (timing and agreement between ranks): op 0 = max, 1 = min, 2 = sum.  Synchronous.
 int flashe_rccl_allreduce_f64(flashe_ctx *ctx, flashe_comm *comm, double *value, int op)
 {

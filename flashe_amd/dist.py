@@ -298,6 +298,10 @@ class RcclComm:
     def all_gather(self, engine, send_ptr, recv_ptr, nbytes):
         engine._check(self._lib.flashe_rccl_all_gather(engine._h, self._h, send_ptr, recv_ptr, nbytes))
 
+    def allreduce_modadd(self, engine, ptr, count):
+        """int_bits <= 64: buf[j] = (sum over ranks of buf[j]) mod 2^b on every rank, in place (ncclAllReduce(ncclUint64, ncclSum) + mask)."""
+        engine._check(self._lib.flashe_rccl_allreduce_modadd_u64(engine._h, self._h, ptr, int(count)))
+
     def allreduce(self, engine, value, op=0):
         import ctypes
         v = ctypes.c_double(float(value))
@@ -442,6 +446,10 @@ class HipOps:
     def all_gather(self, send, recv, words, side=False):
         self.comm.all_gather(self._eng(side), self._a(send), self._a(recv), 8 * words)
 
+    def allreduce_modadd(self, ref, words, side=False):
+        """int_bits <= 64: the vector at ref becomes the mod-2^b sum of all ranks' vectors, on every rank."""
+        self.comm.allreduce_modadd(self._eng(side), self._a(ref), words)
+
     def allreduce(self, value, op=0):
         if self.comm is None:
             self.sync()
@@ -474,7 +482,7 @@ class ShardedRound:
     per-rank counts may differ (deal_clients).  An int means "this many per rank, rank r hosts r*k .. r*k + k - 1"."""
 
     def __init__(self, ops, n, int_bits, clients, n_jobs, rank=0, world=1, total_clients=None, scheme=SCHEME_DOUBLE,
-                 force_collectives=False):
+                 force_collectives=False, collective="all_to_all"):
         if isinstance(clients, int):
             clients, total_clients = list(range(rank * clients, (rank + 1) * clients)), world * clients
         self.ops, self.n, self.b, self.n_jobs = ops, n, int_bits, n_jobs
@@ -485,6 +493,14 @@ class ShardedRound:
         # all-gather), which lets a single-GPU box exercise the exact RCCL code path
         self.exchange = world > 1 or force_collectives
         self.L = L = limbs_of(int_bits)
+        # how the partial aggregates meet (sequential schedule): "all_to_all" = reduce-scatter built from point-to-point transfers
+        # + local mod-add + all-gather (any int_bits: every GPU pair has its own xGMI link); "allreduce" = RCCL's own
+        # ncclAllReduce(uint64, sum) + mask, int_bits <= 64 only (SURVEY.md section 8e names both)
+        if collective not in ("all_to_all", "allreduce"):
+            raise ValueError(f"unknown collective {collective!r}")
+        if collective == "allreduce" and L != 1:
+            raise ValueError("collective='allreduce' needs int_bits <= 64 (RCCL has no 128-bit integer sum)")
+        self.collective = collective
         self.slice = slice_len(n, world)
         self.padded = self.slice * world
         # the local ciphertexts are equally spaced in ONE allocation: the fused reduce + decrypt walks them by stride
@@ -543,6 +559,12 @@ class ShardedRound:
             return self.result
         if not partial_agg:
             self._local_reduce(n, (self.partial, 0))
+        if self.collective == "allreduce":
+            # every rank ends up with the whole aggregate and decrypts it itself: at int_bits <= 64 the decrypt is 2 / m AES blocks
+            # per element, cheaper than gathering decrypted slices
+            ops.allreduce_modadd((self.partial, 0), n)
+            ops.decrypt_range(it, add_idx, minus_idx, n, self.n_jobs, 0, n, (self.partial, 0), (self.result, 0))
+            return self.result
         ops.all_to_all((self.partial, 0), self.slice * L, (self.recv, 0), self.slice * L, self.slice * L)
         if self.count > 0:
             ops.aggregate_decrypt(it, add_idx, minus_idx, n, self.n_jobs, self.first, self.count,

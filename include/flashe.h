@@ -475,6 +475,9 @@ int flashe_rccl_all_gather(flashe_ctx *ctx, flashe_comm *comm, const void *send_
 int flashe_rccl_reduce_scatter_modadd(flashe_ctx *ctx, flashe_comm *comm, const uint64_t *partial_dev, uint64_t slice_elems,
                                       uint64_t *recv_dev, const uint64_t *extra_dev, uint64_t *out_slice_dev);
 /* Host-value all-reduce, synchronous (timing: max over ranks; agreement: min): op 0 = max, 1 = min, 2 = sum. */
+/* int_bits <= 64: buf[j] = (sum over ranks of buf[j]) mod 2^b on every rank, in place -- ncclAllReduce(ncclUint64, ncclSum) + mask
+ * (the arbiter's reduce jzf_aggregator.py:424-430 across GPUs; wider moduli use flashe_rccl_reduce_scatter_modadd). */
+int flashe_rccl_allreduce_modadd_u64(flashe_ctx *ctx, flashe_comm *comm, uint64_t *buf_dev, uint64_t count);
 int flashe_rccl_allreduce_f64(flashe_ctx *ctx, flashe_comm *comm, double *value, int op);
 int flashe_rccl_barrier(flashe_ctx *ctx, flashe_comm *comm);
 

@@ -63,6 +63,11 @@ def main():
             assert np.array_equal(got, want_packed if mode == "packed" else want_elem), (rank, b, n, dealing, mode)
             if mode == "packed":
                 assert np.array_equal(ops.read((rnd.k_full, 0), len(agg_packed)), agg_packed), (rank, b, n, dealing)
+        if L == 1:                                                          # int_bits <= 64: the all-reduce form of the exchange
+            rnd_ar = ShardedRound(ops, n, b, mine, J, rank=rank, world=world, total_clients=C, scheme=scheme, collective="allreduce")
+            for partial in (False, True):
+                out = rnd_ar.run(4, pts, 1, partial_agg=partial)
+                assert np.array_equal(ops.read((out, 0), n * L).reshape(n, L), want_elem), (rank, b, n, dealing, "allreduce", partial)
         for c, ref in zip(mine, rnd.ct):                                   # this rank's own ciphertexts (chained launch) vs the oracle
             assert np.array_equal(ops.read(ref, n * L).reshape(n, L), cts[c]), (rank, b, c)
     # adversarial carries through whole limb slices, resolved by the device-side rule

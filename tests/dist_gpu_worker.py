@@ -63,6 +63,12 @@ def main():
                 if mode == "packed":
                     src = rnd.k_full if force else rnd.k_partial
                     assert np.array_equal(ops.read((src, 0), len(agg_packed)), agg_packed), (b, n, force)
+            if force and L == 1:
+                # int_bits <= 64: RCCL's own all-reduce (ncclAllReduce(uint64, sum) + mask) as the exchange, through the REAL library
+                rnd_ar = ShardedRound(ops, n, b, C, J, scheme=scheme, force_collectives=True, collective="allreduce")
+                for partial in (False, True):
+                    out = rnd_ar.run(4, pts, 1, partial_agg=partial)
+                    assert np.array_equal(ops.read((out, 0), n * L).reshape(n, L), want_elem), (b, n, "allreduce", partial)
     comm.barrier(eng)
     comm.close()
     assert "torch" not in sys.modules, "the multi-GPU path must not need PyTorch"

@@ -127,6 +127,12 @@ def main():
             assert np.array_equal(res[:, 0], want), (rank, b, n, clients, mode, chunks)
             if L == 2:
                 assert not res[:, 1].any()
+        if L == 1:
+            # the same round with RCCL's own all-reduce as the exchange (int_bits <= 64: SURVEY.md section 8e)
+            rnd_ar = ShardedRound(ops, n, b, mine_ids, n_jobs, rank=rank, world=world, total_clients=C, scheme=scheme, collective="allreduce")
+            for partial in (False, True):
+                res = result_of(ops, rnd_ar.run(5, mine, 1, partial_agg=partial), n, L)
+                assert np.array_equal(res[:, 0], want), (rank, b, n, clients, "allreduce", partial)
     packed_rounds(rank, world, comm)
     assert ops.allreduce(float(rank), 0) == world - 1 and ops.allreduce(float(rank + 1), 1) == 1.0
     dist.barrier()

@@ -39,6 +39,13 @@ class GlooComm:
         self.dist.all_gather_into_tensor(r, s)
         recv[: self.world * words] = r.numpy().view(np.uint64)
 
+    def allreduce_modadd(self, buf, words, b):
+        import torch
+        t = torch.from_numpy(buf[:words].view(np.int64).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)                       # int64 wraps mod 2^64
+        got = t.numpy().view(np.uint64)
+        buf[:words] = got & np.uint64((1 << b) - 1) if b < 64 else got
+
     def allreduce(self, value, op):
         import torch
         t = torch.tensor([float(value)], dtype=torch.float64)
@@ -174,6 +181,14 @@ class OracleOps:
             rb.a[ro:ro + words] = sb.a[so:so + words]
             return
         self.comm.all_gather(sb.a[so:], rb.a[ro:], words)
+
+    def allreduce_modadd(self, ref, words, side=False):
+        rb, ro = ref
+        if self.comm is None:
+            if self.b < 64:
+                rb.a[ro:ro + words] &= np.uint64((1 << self.b) - 1)
+            return
+        self.comm.allreduce_modadd(rb.a[ro:], words, self.b)
 
     def allreduce(self, value, op=0):
         return float(value) if self.comm is None else self.comm.allreduce(value, op)

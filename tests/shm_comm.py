@@ -58,6 +58,17 @@ class ShmComm:
         for p in range(self.world):
             self._h2d(engine, recv_ptr + p * nbytes, np.frombuffer(self._get(f"ag_{s}_{p}"), dtype=np.uint8))
 
+    def allreduce_modadd(self, engine, ptr, count):
+        s = self.seq = self.seq + 1
+        self._put(f"arm_{s}_{self.rank}", self._d2h(engine, ptr, 8 * count).tobytes())
+        tot = np.zeros(count, dtype=np.uint64)
+        for p in range(self.world):
+            tot += np.frombuffer(self._get(f"arm_{s}_{p}"), dtype=np.uint64)
+        b = engine.int_bits
+        if b < 64:
+            tot &= np.uint64((1 << b) - 1)
+        self._h2d(engine, ptr, tot)
+
     def allreduce(self, engine, value, op=0):
         engine.sync()
         s = self.seq = self.seq + 1

@@ -194,6 +194,8 @@ def test_config5_sparse_top1pct_50_clients(E, oracle):
     (["--config", "5", "--n", "400000", "--clients", "5", "--no-cpu-baseline"], []),
     (["--config", "2", "--bits", "20", "--n", "700001", "--no-cpu-baseline", "--no-e2e"], []),
     (["--config", "2", "--bits", "20", "--layout", "u32", "--n", "700001"], []),
+    (["--config", "2", "--n", "500000", "--force-dist", "--schedule", "sequential", "--no-cpu-baseline", "--no-e2e"], []),
+    (["--config", "2", "--bits", "20", "--n", "500000", "--force-dist", "--collective", "allreduce", "--schedule", "sequential", "--no-cpu-baseline", "--no-e2e"], []),
 ])
 def test_bench_lines_on_one_gpu(args, keys):
     """bench.py on one GPU, every configuration and schedule at reduced size: the in-run parity gates (round trip AND ciphertexts
@@ -208,6 +210,8 @@ def test_bench_lines_on_one_gpu(args, keys):
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
     assert len(lines) == 1, r.stdout[-2000:]
+    # stdout carries the JSON line and NOTHING else (with a communicator RCCL prints a version banner: it must land on stderr)
+    assert [l for l in r.stdout.splitlines() if l.strip()] == lines, r.stdout[-2000:]
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline"):

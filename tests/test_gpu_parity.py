@@ -696,6 +696,17 @@ def test_bench_multi_rank_flow(extra, tmp_path):
         assert d["sequential_ms_per_step"] > 0          # the line that would have been the fallback was measured first
 
 
+def test_bench_multi_rank_allreduce_exchange(tmp_path):
+    """bench.py --bits 20 --collective allreduce with 3 ranks through the comm double: the sequential round's exchange is the
+    all-reduce form (ncclAllReduce(uint64, sum) + mask for int_bits <= 64), parity on every rank."""
+    r, lines, _ = _bench_shm(tmp_path, ["--config", "2", "--clients", "3", "--bits", "20", "--collective", "allreduce", "--schedule", "sequential"])
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    d = lines[0]
+    assert d["n_gpus"] == 3 and d["value"] > 0 and d["config"]["ranks_parity_ok"] is True and "ncclAllReduce" in d["config"]["exchange"]
+    r, lines, _ = _bench_shm(tmp_path, ["--config", "2", "--clients", "3", "--collective", "allreduce", "--schedule", "sequential"])
+    assert r.returncode != 0 and not [l for l in lines if l.get("value")]              # 128-bit modulus: refused
+
+
 @pytest.mark.parametrize("inject", ["raise:1", "hang:2", "raise:0"])
 def test_bench_multi_rank_falls_back_to_the_sequential_line(inject, tmp_path):
     """The first real multi-GPU run must not come back empty: with an overlapped schedule that raises on one rank, or blocks one
