@@ -5,6 +5,7 @@
   draws   flashe_mt19937_random_dev         (np.random.random continued from an arbitrary stream position, state handed back)
   twins   flashe_encrypt / _aggregate_elem / _decrypt on host pointers with random chunk sizes of the copy pipeline
   handles DeviceVector blocks recycled through the caching allocator between calls of different sizes
+  layers  flashe_sparsify_batch (top-k of every layer of a random model in one set of launches)
   compact flashe_encrypt_batch_u32_dev / flashe_aggregate_decrypt_u32_dev (int_bits <= 32 on uint32 arrays)
   fused   flashe_aggregate_decrypt_range_dev at b <= 64 (the one-launch reduce + decrypt and its fallbacks: sub-ranges, up to 65 operands)
 usage: fuzz_round3.py [cases per family] [seed] [families, comma separated]"""
@@ -271,7 +272,33 @@ def fuzz_compact(rng, case):
     return f"b={b} n={n} J={J} C={C} {scheme} add={add} minus={minus} first={first} count={count} out_bytes={ob}"
 
 
-FAMILIES = {"sum": fuzz_sum, "edges": fuzz_edges, "draws": fuzz_draws, "twins": fuzz_twins, "handles": fuzz_handles, "fused": fuzz_fused, "compact": fuzz_compact}
+def fuzz_layers(rng, case):
+    """flashe_sparsify_batch: the top-k of every layer of a random model in one set of launches against the oracle, layer by layer."""
+    dt = np.float32 if rng.random() < 0.7 else np.float64
+    L = int(rng.choice([1, 2, 3, 7, 20, 60]))
+    sizes = [int(rng.choice([1, 2, 3, 17, 1023, 1024, 1025, 4096, int(rng.integers(1, 3000)), int(rng.integers(3000, 200_000))])) for _ in range(L)]
+    if rng.random() < 0.2:
+        sizes[int(rng.integers(0, L))] = int(rng.integers(200_000, 3_000_000))
+    layers, ks, res = [], [], []
+    for n in sizes:
+        x = rng.standard_normal(n).astype(dt)
+        mode = rng.integers(0, 4)
+        if mode == 0 and n > 4:
+            x[:: int(rng.integers(2, 9))] = x[0]                                 # ties, often at the threshold
+        elif mode == 1:
+            x = np.round(x * 4).astype(dt) / 4                                   # few distinct magnitudes, zeros among them
+        layers.append(x)
+        ks.append(int(rng.choice([1, n, max(1, n // 100), max(1, n // 2), int(rng.integers(1, n + 1))])))
+        res.append(rng.standard_normal(n).astype(dt) if rng.random() < 0.8 else np.zeros(n, dtype=dt))
+    eng = E.Engine(KEY, 128, device=0)
+    got = eng.sparsify_batch(layers, ks, res)
+    for i, (x, k, r, (loc, vals, new)) in enumerate(zip(layers, ks, res, got)):
+        wl, wv, wr = orc.sparsify(x, k, r)
+        assert np.array_equal(loc, wl) and vals.tobytes() == wv.tobytes() and new.tobytes() == wr.tobytes(), ("layers", case, np.dtype(dt).name, i, x.size, k)
+    return f"{np.dtype(dt).name} L={L} sizes={sizes[:6]}"
+
+
+FAMILIES = {"sum": fuzz_sum, "edges": fuzz_edges, "draws": fuzz_draws, "twins": fuzz_twins, "handles": fuzz_handles, "fused": fuzz_fused, "compact": fuzz_compact, "layers": fuzz_layers}
 
 
 def main():

@@ -31,4 +31,4 @@ def test_fuzz_sparse_round():
 
 
 def test_fuzz_round3_entry_points():
-    assert "FUZZ_R3_OK 56 cases" in _run("fuzz_round3.py", 8, 104)
+    assert "FUZZ_R3_OK 64 cases" in _run("fuzz_round3.py", 8, 104)
