@@ -3076,7 +3076,8 @@ __global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t total,
 constexpr int kSpan = FLASHE_SPAN;  // positions per span: 64 KiB of 128-bit accumulators, two workgroups per CU (8,192 = 128 KiB, one workgroup per CU,
                                     // twice as long slices per client: aggregate 0.171 against 0.169 ms, fused decrypt 0.442 against 0.420 -- config 5)
 constexpr int kSpanThreads = 1024;
-constexpr int kSpanBatch = 4;       // entries whose loads a lane keeps in flight at once
+constexpr int kSpanBatch = 2;       // entries whose loads a lane keeps in flight at once (config 5, aggregate / fused decrypt: 8: 0.256 / 0.484 ms,
+                                    // 4: 0.171 / 0.416, 2: 0.163 / 0.407, 1: 0.167 / 0.407 -- fewer gathers in flight stream faster here too)
 struct ScatterTable {
     const uint32_t *loc[kMaxScatter];
     const uint64_t *vals[kMaxScatter];
