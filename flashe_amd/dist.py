@@ -174,14 +174,25 @@ class Watchdog:
 
     def abort(self, reason):
         """Tell every rank of the launch (this one included) to stop: the watchdogs fire within a poll interval."""
+        import tempfile
+        tmp = None
         try:
-            fd = os.open(self.path, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            # the flag appears WITH its text or not at all (a watcher that found an empty file fired with no reason): written under a
+            # private name, then hard-linked to the flag's name -- link() is atomic and fails when another rank's flag is already there
+            fd, tmp = tempfile.mkstemp(prefix="flashe_abort_", dir=os.path.dirname(self.path))          # 0600
             with os.fdopen(fd, "w") as f:
                 f.write(f"rank {self.rank}: {reason}")
+            os.link(tmp, self.path)
         except FileExistsError:
             pass
         except OSError:
             self._fire(f"rank {self.rank}: {reason}")
+        finally:
+            if tmp is not None:
+                try:
+                    os.unlink(tmp)
+                except OSError:
+                    pass
 
     def finish(self):
         """The normal end: from here on the watchdog never fires (returns False if it already has)."""
