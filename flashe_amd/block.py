@@ -12,7 +12,6 @@ from .cipher import FlasheCipher
 from .quantize import QuantizingClient
 
 _RNG_RUN_MAX = 1 << 26          # draws per device call of quantize_encrypt (512 MiB of float64)
-_DOWNLOAD_WINDOW = 1 << 30      # bytes of unquantised layers decrypt_unquantize keeps on the device before it downloads them
 
 __all__ = ["dynamic_masking_choice", "FlasheClient"]
 
@@ -53,6 +52,7 @@ class FlasheClient(object):
         self.mask = args.get('mask', 'double')
         self.cipher = None
         self.quantizer = None
+        self.shape_dict = None           # layer shapes of the flattened model (what the aggregator-side Client keeps, jzf_aggregator.py:648)
         self._device = device
 
     def create_cipher(self, idx, num_clients, prp_seed):
@@ -112,31 +112,71 @@ class FlasheClient(object):
     def unnormalize(self, weights):
         return self.quantizer.unnormalize(weights)
 
+    # ---- flatten / unflatten: Client.flatten_weights / unflatten_weights of the aggregator (jzf_aggregator.py:625-671) ------------------
+    def flatten_weights(self, weights):
+        """Client.flatten_weights (jzf_aggregator.py:625-650): the layers, in walking order, become ONE vector under the first key; the
+        shapes (all but the sparse job's 'zzz' layer) are kept in `self.shape_dict` for unflatten_weights.  A reference job encrypts
+        this vector, so PRF counters and the int_bits <= 64 chunking run across the layers."""
+        parts, shape_dict, first_k = [np.array([])], {}, None
+        for k in list(weights.walking_order):
+            if first_k is None:
+                first_k = k
+            layer = np.asarray(weights._weights[k])
+            if k != "zzz":
+                shape_dict[k] = layer.shape
+            parts.append(layer.flatten())
+            del weights._weights[k]
+        self.shape_dict = shape_dict
+        if first_k is not None:
+            weights._weights[first_k] = np.concatenate(parts)
+        weights.walking_order = sorted(weights._weights.keys(), key=str)
+        return weights
+
+    def unflatten_weights(self, weights):
+        """Client.unflatten_weights (jzf_aggregator.py:652-671): cut the one vector back into `self.shape_dict`'s layers."""
+        only_key = weights.walking_order[0]
+        flat = weights._weights[only_key]
+        for k, shape in self.shape_dict.items():
+            size = int(np.prod(shape))
+            weights._weights[k] = flat[:size].reshape(shape)
+            flat = flat[size:]
+        weights.walking_order = sorted(weights._weights.keys(), key=str)
+        return weights
+
     # ---- the client step with nothing on the host in between (new) ------------------------------------------------------------
-    def _fusable(self):
+    def _fusable(self, weights=None):
         c = self.cipher
         return (not self.batch and c.masks is None and c.prp_seed is not None and not c.next_iter_encrypt_prepared
-                and hasattr(c.engine, "quantize_encrypt_dev"))
+                and hasattr(c.engine, "quantize_encrypt_model_dev") and (weights is None or "zzz" not in weights._weights))
 
     def quantize_encrypt(self, weights, device=True):
-        """`self.quantize(weights)` followed by `weights.encrypted(self)` -- QuantizingClient.quantize (jzf_quantize.py:394-491), then
-        JZFWeights.encrypted -> _Client.encrypt for every layer in walking order (jzf_weights.py:334-338, :446-450,
-        jzf_flashe_block.py:142-150) -- with no host round trip in between: a layer goes up once as it is (4 or 8 bytes per value), its
-        stochastic-rounding draws are generated on the device from NumPy's own stream (small layers: drawn on the host), ONE launch
-        quantises and encrypts (flashe_quantize_encrypt_dev).  Bit-identical to the two calls, layer by layer, with the same seed.
-        Layers come back as DeviceVectors (device=True: the ciphertext stays in HBM for `aggregate`) or as uint64 limb arrays [n, L];
-        their shapes are kept for `decrypt_unquantize`.  Batched quantisation, sparse masks and precomputed encrypt masks take the
-        two-call path and return what it returns."""
+        """What Client.secure_aggregate does between "begin encoding" and "end encryption" (jzf_aggregator.py:721-743):
+        `self.quantize(weights)` -> `flatten_weights` -> [sparse job: strip the trailing quantised zero] -> `weights.encrypted(self)`
+        -> [re-append it] -- QuantizingClient.quantize (jzf_quantize.py:394-491), then ONE cipher.encrypt over the flattened model
+        (jzf_weights.py:334-338 -> jzf_flashe_block.py:142-150), so that element j of the model is masked with PRF counter j whatever
+        layer it sits in -- with no host round trip in between: every layer goes up once as it is (4 or 8 bytes per value) into one flat
+        device buffer, the stochastic-rounding draws of the whole model are generated on the device from NumPy's own stream (small
+        models: drawn on the host), and ONE launch quantises and encrypts (flashe_quantize_encrypt_model_dev: per-layer alpha from a
+        device table).  Bit-identical to the reference's sequence with the same seed (tests/golden/clientstep.json).
+        The result has the reference's form: one key (the first of the walking order) holding the flattened ciphertext -- a
+        DeviceVector (device=True: it stays in HBM for `aggregate`) or uint64 limbs [n, L]; `self.shape_dict` keeps the shapes for
+        `decrypt_unquantize`.  Batched quantisation, sparse jobs (masks, the 'zzz' layer) and precomputed encrypt masks take the same
+        sequence call by call on the host and return object arrays like the reference."""
         from . import cipher as _cipher_mod
         from .engine import DeviceVector
         from .quantize import ACIQ, DEVICE_RNG_MIN, _loop_dtype
         q, c = self.quantizer, self.cipher
         if q.layer_size_list is None:
             q.set_layer_size_list(weights)
-        if not self._fusable():
-            weights = self.quantize(weights)
-            for k in weights.walking_order:
-                weights._weights[k] = self.cipher.encrypt(weights._weights[k])
+        if not self._fusable(weights):
+            sparse = "zzz" in weights._weights
+            weights = self.flatten_weights(self.quantize(weights))
+            k0 = weights.walking_order[0]
+            flat = weights._weights[k0]
+            if sparse:                                                       # jzf_aggregator.py:735-743
+                zero_quantized, flat = flat[-1], flat[:-1]
+            ct = self.cipher.encrypt(flat)
+            weights._weights[k0] = np.append(ct, [zero_quantized]) if sparse else ct
             return weights
         eng = c.engine
         aciq = ACIQ(q.element_bits)
@@ -145,74 +185,73 @@ class FlasheClient(object):
             a = aciq.get_alpha_gaus_direct(q.past_layer_std_list[i])
             alphas.append(0.1 if a == 0 else a)
         q.r_max_list, q.alpha_list = [], []
-        self._layer_shapes = {}
         c.set_idx_list(mode="encrypt")
         scheme = 1 if c.masking_scheme == "double" else 0
-        # the stochastic-rounding draws of consecutive layers are ONE stretch of NumPy's stream (np.random.random(layer.shape) per layer in
-        # walking order, jzf_quantize.py:55-67 under :417-462): a run of layers is drawn by one device call and every layer takes its
-        # slice -- one state round trip per run instead of one per layer.  Runs are capped so the draws of a huge model stay bounded.
         order = list(weights.walking_order)
-        sizes = [int(np.asarray(weights._weights[k]).size) for k in order]
-        dev_rng = os.environ.get("FLASHE_DEVICE_RNG", "1") != "0" and np.random.get_state()[0] == "MT19937"
-        runs, at = {}, 0                                             # first layer of a run -> (layers in the run, draws)
-        while at < len(order):
-            end, tot = at, 0
-            while end < len(order) and (end == at or tot + sizes[end] <= _RNG_RUN_MAX):
-                tot += sizes[end]
-                end += 1
-            runs[at] = (end - at, tot)
-            at = end
-        layer_cnt = 0
-        du_run, u_off = None, 0
+        host, starts, offs, shape_dict = [], [], [], {}
+        n, nbytes = 0, 0
         for li, k in enumerate(order):
-            if k == 'zzz':
-                alpha = 1.0
-            else:
-                alpha = alphas[layer_cnt]
-                q.r_max_list.append(alpha * q.num_clients)
-                q.alpha_list.append(alpha)
+            alpha = alphas[li]
+            q.r_max_list.append(alpha * q.num_clients)
+            q.alpha_list.append(alpha)
             layer = np.asarray(weights._weights[k])
-            self._layer_shapes[k] = layer.shape
+            shape_dict[k] = layer.shape
             flat = np.ascontiguousarray(layer).reshape(-1)
             if flat.dtype not in (np.float32, np.float64):
                 flat = flat.astype(np.float64)
-            want = _loop_dtype(flat.dtype, alpha)
+            want = _loop_dtype(flat.dtype, alpha)                         # the dtype NumPy's clip / scale arithmetic runs in
             if flat.dtype != want:
                 flat = flat.astype(want)
-            n = int(flat.size)
-            if li in runs:
-                du_run, u_off = None, 0
-                if dev_rng and runs[li][1] >= DEVICE_RNG_MIN:
-                    du_run = eng.numpy_random_dev(runs[li][1])
-            dx = eng.upload(flat)
-            if du_run is not None:
-                du = du_run.ptr + 8 * u_off
-                u_off += n
-            else:
-                du = eng.upload(np.random.random(layer.shape).reshape(-1))
-            ct = DeviceVector(eng, n)
-            eng.quantize_encrypt_dev(c.iter_index, c.idx, scheme, n, _cipher_mod.N_JOBS, dx, flat.dtype == np.float64, float(alpha),
-                                     q.element_bits, du, ct.buf)
-            weights._weights[k] = ct.mark_ready() if device else ct.to_host()
-            layer_cnt += 1
+            host.append(flat)
+            starts.append(n)
+            offs.append(nbytes)
+            n += int(flat.size)
+            nbytes += (flat.nbytes + 15) & ~15
+        xbuf = eng.alloc(max(nbytes, 16))
+        for flat, off in zip(host, offs):
+            xbuf.upload_at(off, flat)
+        table = [(starts[li], xbuf.ptr + offs[li], q.alpha_list[li], host[li].dtype == np.float64) for li in range(len(order))]
+        ct = DeviceVector(eng, n)
+        # the draws of consecutive layers are ONE stretch of NumPy's stream (np.random.random(layer.shape) per layer in walking order,
+        # jzf_quantize.py:55-67 under :417-462), i.e. flat element j takes draw j: a run of whole layers is drawn by one device call and
+        # quantised + encrypted by one launch over its range.  Runs are capped so the draws of a huge model stay bounded.
+        dev_rng = os.environ.get("FLASHE_DEVICE_RNG", "1") != "0" and np.random.get_state()[0] == "MT19937"
+        at = 0
+        while at < len(order):
+            end, tot = at, 0
+            while end < len(order) and (end == at or tot + host[end].size <= _RNG_RUN_MAX):
+                tot += int(host[end].size)
+                end += 1
+            if tot:
+                du = eng.numpy_random_dev(tot) if dev_rng and tot >= DEVICE_RNG_MIN else eng.upload(np.random.random(tot))
+                first = starts[at]
+                eng.quantize_encrypt_model_dev(c.iter_index, c.idx, scheme, n, _cipher_mod.N_JOBS, first, tot, table, q.element_bits, du,
+                                               ct.ptr + first * eng.limbs * 8)
+            at = end
+        for k in order:
+            del weights._weights[k]
+        self.shape_dict = shape_dict
+        if order:
+            weights._weights[order[0]] = ct.mark_ready() if device else ct.to_host()
+        weights.walking_order = sorted(weights._weights.keys(), key=str)
         return weights
 
     def decrypt_unquantize(self, weights):
-        """`weights.decrypted(self)` followed by `self.unquantize(weights)` (jzf_weights.py:334-335 -> _Client.decrypt, then
-        QuantizingClient.unquantize, jzf_quantize.py:493-540) as ONE launch per layer (flashe_decrypt_unquantize_dev): the aggregate
-        -- a DeviceVector, uint64 limbs or object ints -- is decrypted with the prefixes `set_idx_list` left behind and comes back as
-        the unquantised float64 layer, reshaped as `quantize_encrypt` saw it.  Precomputed decrypt masks, sparse masks and batched
-        values take the two-call path."""
+        """What Client.aggregate does between "begin decryption" and "end decoding" (jzf_aggregator.py:881-899): `weights.decrypted(self)`
+        (jzf_weights.py:334-335 -> _Client.decrypt) of the ONE flattened aggregate, `unflatten_weights` by `self.shape_dict`, then
+        QuantizingClient.unquantize layer by layer (jzf_quantize.py:493-540) -- as ONE launch (flashe_decrypt_unquantize_model_dev): the
+        aggregate -- a DeviceVector, uint64 limbs or object ints -- is decrypted with the prefixes `set_idx_list` left behind and comes
+        back as unquantised float64 layers.  Precomputed decrypt masks, sparse masks and batched values take the same sequence call by
+        call (the sparse job sets `self.shape_dict = shape_dict_used_for_sparsification` first, :893-894)."""
         from . import cipher as _cipher_mod
         from .engine import DeviceVector
         q, c = self.quantizer, self.cipher
         fus = (not self.batch and c.masks is None and c.prp_seed is not None and not c.next_iter_decrypt_prepared
-               and hasattr(c.engine, "decrypt_unquantize_dev"))
+               and hasattr(c.engine, "decrypt_unquantize_model_dev"))
+        k0 = weights.walking_order[0]
         if not fus:
-            for k in weights.walking_order:
-                v = self.cipher.decrypt(weights._weights[k], device=False)
-                weights._weights[k] = v
-            return self.unquantize(weights)
+            weights._weights[k0] = self.cipher.decrypt(weights._weights[k0], device=False)
+            return self.unquantize(self.unflatten_weights(weights))
         eng = c.engine
         if c.masking_scheme == "double":
             add_idx = [c._idx_of(p) for p in (c.index_prefix_for_add or [])]
@@ -221,35 +260,27 @@ class FlasheClient(object):
                 raise KeyError('add')
         else:
             add_idx, minus_idx = [], [c._idx_of(p) for p in c.index_prefix_for_minus]
-        shapes = getattr(self, "_layer_shapes", {})
-        pending, held = [], 0                # launches run ahead of the downloads: a layer comes down while the next ones are computed
-
-        def drain():
-            nonlocal held
-            for k_, n_, dout_, _dv in pending:
-                out = dout_.download(np.float64, n_)
-                weights._weights[k_] = out.reshape(shapes.get(k_, out.shape))
-            pending.clear()
-            held = 0
-
-        for layer_cnt, k in enumerate(weights.walking_order):
-            alpha = q.alpha_list[layer_cnt] if k != 'zzz' else 1.0
-            v = weights._weights[k]
-            if not isinstance(v, DeviceVector):
-                v = np.asarray(v)
-                if v.dtype == object:
-                    v = v.reshape(-1)
-            dv, _kind = c._on_device(v, full_width=True)
-            n = len(dv)
-            dout = eng.alloc(max(8 * n, 16))
-            eng.decrypt_unquantize_dev(c.iter_index, add_idx, minus_idx, n, _cipher_mod.N_JOBS, dv.buf, float(alpha), q.element_bits,
-                                       q.num_clients, dout)
-            pending.append((k, n, dout, dv))
-            held += 8 * n
-            if held >= _DOWNLOAD_WINDOW:
-                drain()
-        drain()
-        return weights
+        v = weights._weights[k0]
+        if not isinstance(v, DeviceVector):
+            v = np.asarray(v)
+            if v.dtype == object:
+                v = v.reshape(-1)
+        dv, _kind = c._on_device(v, full_width=True)
+        n = len(dv)
+        sizes = [int(np.prod(shape)) for shape in self.shape_dict.values()]
+        if sum(sizes) > n:
+            raise ValueError(f"the aggregate has {n} elements, shape_dict describes {sum(sizes)}")
+        table, at = [], 0
+        for li, size in enumerate(sizes):
+            table.append((at, None, q.alpha_list[li], False))
+            at += size
+        dout = eng.alloc(max(8 * n, 16))
+        if n:
+            eng.decrypt_unquantize_model_dev(c.iter_index, add_idx, minus_idx, n, _cipher_mod.N_JOBS, 0, n, dv.buf, table, q.element_bits,
+                                             q.num_clients, dout)
+        out = dout.download(np.float64, n)
+        weights._weights[k0] = out
+        return self.unflatten_weights(weights)
 
     def prepare_encrypt(self):
         if self.precompute:

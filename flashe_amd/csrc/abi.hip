@@ -238,7 +238,7 @@ struct Tmp {
 
 extern "C" {
 
-int flashe_abi_version(void) { return 1; }
+int flashe_abi_version(void) { return FLASHE_ABI_VERSION; }
 
 int flashe_device_count(int *count)
 {
@@ -320,7 +320,9 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
         else if (!strcmp(be, "bitslice16")) ctx->env.prf_backend = PRF_BITSLICE16;
 #endif
     }
+#ifdef FLASHE_TUNING
     if (const char *pm = getenv("FLASHE_HYBRID_BS_PERMILLE")) ctx->env.hybrid_bs_permille = atoi(pm);
+#endif
     ctx->env.use_chain = 1;
     if (const char *ch = getenv("FLASHE_CHAIN")) ctx->env.use_chain = atoi(ch) != 0;   // 0: every job computes both of its streams (A/B runs)
     *out = ctx;
@@ -332,7 +334,7 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     if (!ctx) return FLASHE_EINVAL;
     (void)hipSetDevice(ctx->device);
     if (ctx->env.stream) (void)hipStreamSynchronize(ctx->env.stream);
-    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds, &ctx->mt_ws})
+    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds, &ctx->mt_ws, &ctx->codec_tab})
         if (b->p) (void)hipFree(b->p);
     if (ctx->staging) { ctx->staging->destroy(); delete ctx->staging; ctx->staging = nullptr; }      // staging blocks held plaintexts and ciphertexts (wiped)
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
@@ -1002,6 +1004,106 @@ int flashe_decrypt_unquantize_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t
     return FLASHE_OK;
 }
 
+// ---- the same over a flattened model: one launch, per-layer parameters from a device table (jzf_aggregator.py:721-741, :887-899) ----
+static int check_range(flashe_ctx *ctx, uint64_t n, uint64_t first, uint64_t count);
+// validates the caller's table and stages the entries of the non-empty layers on the device (ctx->codec_tab)
+static int stage_codec_layers(flashe_ctx *ctx, uint64_t n, const flashe_codec_layer *layers, int n_layers, bool front, int element_bits,
+                              int num_clients, uint64_t first, uint64_t count, const CodecLayer **tab_dev, int *n_tab)
+{
+    if (n_layers < 1 || !layers) return fail(ctx, FLASHE_EINVAL, "the layer table needs at least one entry");
+    if (layers[0].start != 0) return fail(ctx, FLASHE_EINVAL, "layers[0].start must be 0");
+    if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "the model-wide codec calls stage their layer table per call and cannot be captured into a graph");
+    std::vector<CodecLayer> tab;
+    tab.reserve(static_cast<size_t>(n_layers));
+    for (int l = 0; l < n_layers; l++) {
+        const flashe_codec_layer &e = layers[l];
+        const uint64_t end = l + 1 < n_layers ? layers[l + 1].start : n;
+        if (e.start > end || end > n) return fail(ctx, FLASHE_EINVAL, "layer %d: starts must ascend and stay within n", l);
+        if (e.reserved) return fail(ctx, FLASHE_EINVAL, "layer %d: reserved field must be 0", l);
+        if (e.start == end) continue;                                   // an empty layer holds no element
+        if (!(e.alpha > 0)) return fail(ctx, FLASHE_EINVAL, "layer %d: alpha must be positive", l);
+        const bool touched = e.start < first + count && end > first;
+        if (front && touched && !e.x_dev) return fail(ctx, FLASHE_EINVAL, "layer %d: null x_dev", l);
+        if (front && (reinterpret_cast<uintptr_t>(e.x_dev) & (e.x_is_f64 ? 7u : 3u))) return fail(ctx, FLASHE_EINVAL, "layer %d: x_dev is misaligned", l);
+        tab.push_back(front ? codec_layer_front(e.start, e.x_dev, e.x_is_f64 != 0, e.alpha, element_bits)
+                            : codec_layer_back(e.start, e.alpha, element_bits, num_clients));
+    }
+    if (tab.empty()) { *tab_dev = nullptr; *n_tab = 0; return FLASHE_OK; }
+    int rc = ensure(ctx, ctx->codec_tab, tab.size() * sizeof(CodecLayer));
+    if (rc) return rc;
+    // (pageable source: the copy has left `tab` when the call returns; stream order keeps an earlier launch's table intact until it ends)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->codec_tab.p, tab.data(), tab.size() * sizeof(CodecLayer), hipMemcpyHostToDevice, ctx->env.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
+    *tab_dev = static_cast<const CodecLayer *>(ctx->codec_tab.p);
+    *n_tab = static_cast<int>(tab.size());
+    return FLASHE_OK;
+}
+
+int flashe_quantize_encrypt_model_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uint64_t n, uint32_t n_jobs, uint64_t first,
+                                      uint64_t count, const flashe_codec_layer *layers, int n_layers, int element_bits, const double *u_dev,
+                                      uint64_t *ct_dev)
+{
+    CHECK_CTX(ctx);
+    if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    if (count && (!u_dev || !ct_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (element_bits < 1 || element_bits > 62 || element_bits > ctx->int_bits)
+        return fail(ctx, FLASHE_EINVAL, "element_bits must be in [1, min(62, int_bits)], got %d", element_bits);
+    int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev, nullptr, 0);
+    if (rc || (rc = check_range(ctx, n, first, count))) return rc;
+    if (reinterpret_cast<uintptr_t>(u_dev) & 7u) return fail(ctx, FLASHE_EINVAL, "u_dev must be 8-byte aligned");
+    const CodecLayer *tab = nullptr;
+    int n_tab = 0;
+    rc = stage_codec_layers(ctx, n, layers, n_layers, true, element_bits, 1, first, count, &tab, &n_tab);
+    if (rc || count == 0) return rc;
+    Codec cq{};
+    cq.x = tab;                     // (non-null = front end on; the values come through the table)
+    cq.u = u_dev; cq.layers = tab; cq.n_layers = n_tab; cq.k0 = first;
+    LaunchEnv env = ctx->env;
+    env.codec = &cq;
+    const uint32_t add = idx, minus = idx + 1;
+    HIP_TRY(ctx, launch_prf(env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, first, count, nullptr, 0, ct_dev));
+    return FLASHE_OK;
+}
+
+int flashe_decrypt_unquantize_model_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                                        uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count, const uint64_t *in_dev,
+                                        const flashe_codec_layer *layers, int n_layers, int element_bits, int num_clients, double *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (count && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (num_clients < 1) return fail(ctx, FLASHE_EINVAL, "num_clients must be >= 1");
+    if (n_add + n_minus == 0) return fail(ctx, FLASHE_EINVAL, "decrypt_unquantize_model: at least one prefix (a round always has one)");
+    int rc = check_codec_bits(ctx, element_bits);
+    if (rc) return rc;
+    rc = check_prf_args(ctx, n_add, n_minus, n_jobs, in_dev, in_dev, ctx->limbs);
+    if (rc || (rc = check_range(ctx, n, first, count))) return rc;
+    if ((n_add && !add_idx) || (n_minus && !minus_idx)) return fail(ctx, FLASHE_EINVAL, "null prefix list");
+    const CodecLayer *tab = nullptr;
+    int n_tab = 0;
+    rc = stage_codec_layers(ctx, n, layers, n_layers, false, element_bits, num_clients, first, count, &tab, &n_tab);
+    if (rc || count == 0) return rc;
+    Codec cq{};
+    cq.fout = out_dev; cq.layers = tab; cq.n_layers = n_tab; cq.k0 = first;
+    // lists longer than one launch holds: all but the last group accumulate into ctx scratch, the last launch writes the floats
+    const uint64_t *src = in_dev;
+    int a = 0, m = 0;
+    if (n_add > kMaxIdx || n_minus > kMaxIdx) {
+        rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, count));
+        if (rc) return rc;
+        uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
+        while (n_add - a > kMaxIdx || n_minus - m > kMaxIdx) {
+            const int na = std::min(kMaxIdx, n_add - a), nm = std::min(kMaxIdx, n_minus - m);
+            HIP_TRY(ctx, launch_prf(ctx->env, iter, add_idx + a, na, minus_idx + m, nm, n, n_jobs, first, count, src, ctx->limbs, tmp));
+            a += na; m += nm; src = tmp;
+        }
+    }
+    LaunchEnv env = ctx->env;
+    env.codec = &cq;
+    HIP_TRY(ctx, launch_prf(env, iter, add_idx + a, n_add - a, minus_idx + m, n_minus - m, n, n_jobs, first, count, src, ctx->limbs,
+                            const_cast<uint64_t *>(src)));
+    return FLASHE_OK;
+}
+
 // ---- normalise / unnormalise (QuantizingClient.normalize / unnormalize, jzf_quantize.py:542-564) ----
 int flashe_shift_dev(flashe_ctx *ctx, uint64_t n, void *x_dev, int x_is_f64, double shift, int wide)
 {
@@ -1175,7 +1277,11 @@ int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uin
     }
     if (ctx->limbs == 1 && n_add == 1 && n_minus <= 1) {
         // b <= 64: the same fusion in the small-modulus form (FLASHE_SMALL_FUSED_REDUCE=0: two launches, the A/B switch)
+#ifdef FLASHE_TUNING
         static const bool off = getenv("FLASHE_SMALL_FUSED_REDUCE") && atoi(getenv("FLASHE_SMALL_FUSED_REDUCE")) == 0;
+#else
+        constexpr bool off = false;
+#endif
         if (!off) {
             const hipError_t e = launch_small_reduce_decrypt(ctx->env, iter, add_idx[0], n_minus == 1, n_minus ? minus_idx[0] : 0u, n, n_jobs, first, count,
                                                              C, cts_dev, agg_out_dev, out_dev);

@@ -27,6 +27,7 @@ struct flashe_ctx {
     Buf sp_ws;        // sparsifier workspace (select state, histogram, per-block counts)
     Buf bounds;       // span reduce: first entry of every client in every span
     Buf mt_ws;        // flashe_mt19937_random_dev: state in / out and the substream windows
+    Buf codec_tab;    // layer table of the fused quantise / unquantise over a flattened model
     // staging blocks of the host-pointer twins: hipMalloc / hipFree cost more than the kernels on LeNet-sized vectors and more than
     // the PCIe transfer on 160 MB ones, so blocks are kept and reused within a byte budget (the twins are synchronous: a block is
     // free again when its call returns)

@@ -12,13 +12,25 @@ struct RoundKeys { uint32_t w[60]; };
 // decrypt, jzf_quantize.py:55-67,102-107): front end = the plaintext of element k is the stochastic-rounded quantisation of a
 // float instead of a stored integer; back end = the result is written as the unquantised float64 instead of the integer.
 // Saves the 8-byte integer round trip through HBM on either side.  All-zero = off.
+// One layer of a FLATTENED model (jzf_aggregator.py:625-650: a job quantises layer by layer, each with its own alpha, then encrypts
+// the concatenation as one vector): device-resident table, sorted by start, empty layers left out.
+struct CodecLayer {
+    uint64_t start;            // flat index of the layer's first value
+    const void *x;             // front end: the layer's own float32 / float64 values (x[0] = flat element `start`)
+    double p0, p1, p2;         // front end: alpha, scale, den; back end: ac, two_a, uden
+    int x_is_f64, pad_;
+};
 struct Codec {
     const void *x;             // front end: float32 / float64 values (null = off)
     const double *u;           //            one uniform draw in [0, 1) per value
     double alpha, scale, den;  //            q = floor((clip(x, -alpha, alpha) + alpha) * scale / den + u), computed in x's type
-    int x_is_f64, pad_;
+    int x_is_f64, n_layers;
     double *fout;              // back end: float64 output (null = off)
     double ac, two_a, uden;    //           out = float(value) * two_a / uden - ac
+    // layer table (null = one layer described by the fields above): element k of the launch is flat element k0 + k of the model,
+    // its parameters (and, front end, its value) come from the layer that holds it; u and fout stay indexed by k
+    const CodecLayer *layers;
+    uint64_t k0;
 };
 
 // Everything a launch needs that is not a per-call argument.
@@ -175,6 +187,9 @@ hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uin
 // descriptors for LaunchEnv::codec
 Codec codec_quantize_front(const void *x_dev, bool is_f64, double alpha, int bits, const double *u_dev);
 void codec_unquantize_back(Codec *c, double alpha, int bits, int num_clients, double *out_dev);
+// the same per layer of a flattened model, as entries of the device table Codec::layers points to
+CodecLayer codec_layer_front(uint64_t start, const void *x_dev, bool is_f64, double alpha, int bits);
+CodecLayer codec_layer_back(uint64_t start, double alpha, int bits, int num_clients);
 // x <- x + shift in place (normalize / unnormalize, jzf_quantize.py:542-564).  f32 arrays: wide = the add runs in float64 and is
 // rounded once (NumPy's loop for a float64 scalar operand), otherwise in float32
 hipError_t launch_shift(const LaunchEnv &env, uint64_t n, void *x_dev, bool is_f64, double shift, bool wide);

@@ -17,6 +17,15 @@
 #include <cstdlib>
 #include <vector>
 
+// Timing probes and tuning knobs exist only in the -DFLASHE_TUNING build (make tuning -> libflashe_hip_tuning.so, what tests/perf/* load
+// through FLASHE_LIB_NAME): the product library reads none of these variables and carries none of the early-exit probe branches, so
+// no environment setting can make it return success without having computed what was asked.
+#ifdef FLASHE_TUNING
+#define FLASHE_TUNE_ENV(name) getenv(name)
+#else
+#define FLASHE_TUNE_ENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 namespace flashe {
 
 typedef unsigned __int128 u128;
@@ -350,17 +359,40 @@ __device__ __forceinline__ uint64_t quantize_one(T v, T alpha, T scale, T den, d
     return static_cast<uint64_t>(static_cast<int64_t>(floor(static_cast<double>(v) + u)));
 }
 
+// the layer of a flattened model that holds flat element `key`: the last table entry with start <= key
+__device__ __forceinline__ const CodecLayer *codec_layer_of(const Codec &c, uint64_t key)
+{
+    int lo = 0, hi = c.n_layers - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (c.layers[mid].start <= key) lo = mid; else hi = mid - 1;
+    }
+    return c.layers + lo;
+}
+
 __device__ __forceinline__ uint64_t codec_quantize(const Codec &c, uint64_t k)
 {
+    if (c.layers != nullptr) {
+        const uint64_t key = c.k0 + k;
+        const CodecLayer *L = codec_layer_of(c, key);
+        const uint64_t r = key - L->start;
+        return L->x_is_f64 ? quantize_one<double>(static_cast<const double *>(L->x)[r], L->p0, L->p1, L->p2, c.u[k])
+                           : quantize_one<float>(static_cast<const float *>(L->x)[r], static_cast<float>(L->p0), static_cast<float>(L->p1),
+                                                 static_cast<float>(L->p2), c.u[k]);
+    }
     return c.x_is_f64 ? quantize_one<double>(static_cast<const double *>(c.x)[k], c.alpha, c.scale, c.den, c.u[k])
                       : quantize_one<float>(static_cast<const float *>(c.x)[k], static_cast<float>(c.alpha), static_cast<float>(c.scale),
                                             static_cast<float>(c.den), c.u[k]);
 }
 
-// _static_unquantize_padding_asymmetric (jzf_quantize.py:102-107)
-__device__ __forceinline__ double codec_unquantize(const Codec &c, u128 v)
+// _static_unquantize_padding_asymmetric (jzf_quantize.py:102-107); k = the element's index in the launch (selects the layer)
+__device__ __forceinline__ double codec_unquantize(const Codec &c, uint64_t k, u128 v)
 {
 #pragma clang fp contract(off)
+    if (c.layers != nullptr) {
+        const CodecLayer *L = codec_layer_of(c, c.k0 + k);
+        return u128_to_double(v) * L->p1 / L->p2 - L->p0;
+    }
     return u128_to_double(v) * c.two_a / c.uden - c.ac;
 }
 
@@ -438,7 +470,7 @@ __global__ __launch_bounds__(kPrfThreads) void prf_wide_kernel(const RoundKeys r
                 acc -= words_to_u128(s[0]);
             }
         }
-        if (p.cq.fout) p.cq.fout[e] = codec_unquantize(p.cq, acc & mask);
+        if (p.cq.fout) p.cq.fout[e] = codec_unquantize(p.cq, e, acc & mask);
         else st128(p.out + 2 * e, acc & mask);
     }
 }
@@ -676,7 +708,9 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 // locally mod-adds its share"; the arbiter's reduce jzf_aggregator.py:424-430 applied to the ciphertexts this GPU has just produced):
 // every out_c of an element passes through the lane's registers in turn, so the running sum costs 4 VGPRs per element and one
 // non-temporal 16-byte store, and the C ciphertexts are never re-read for the reduce.
-template <int THREADS, bool SUM>
+// CODEC: the launch carries a fused quantise front end / unquantise back end (a one-output job); the plain instantiations -- every
+// encrypt of a round -- do not even see the descriptor.
+template <int THREADS, bool SUM, bool CODEC>
 __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, const ChainTable tb, int n_chains, int all_half_arg,
                                                               uint32_t iter0, uint64_t mask_lo, uint64_t mask_hi,
                                                               const uint32_t *__restrict__ te0, const Codec cq)
@@ -688,7 +722,9 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
     __shared__ uint64_t d_tlo[kMaxChains], d_cend[kMaxChains];
     int all_half = all_half_arg;
     fill_tables(tab, te0);
+#ifdef FLASHE_TUNING
     if (all_half & 0x100) return;                  // timing probes of the prologue (FLASHE_CHAIN_TUNE / FLASHE_CHAIN_PROBE only)
+#endif
     const LaneRegs lr = lane_regs(tab);
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
     {
@@ -732,7 +768,9 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
         }
         __syncthreads();
     }
+#ifdef FLASHE_TUNING
     if (all_half & 0x200) return;
+#endif
     all_half &= 1;
     const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
@@ -777,7 +815,7 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                         // predicated): otherwise the compiler must assume a load may still be in flight at the loop's back
                         // edge and drains the memory queue -- stores included -- every iteration
                         u128 x0 = 0, x1 = 0;
-                        if (cq.x != nullptr && link >= 0) {
+                        if (CODEC && cq.x != nullptr && link >= 0) {
                             if (a0) x0 = codec_quantize(cq, k0);
                             if (a1) x1 = codec_quantize(cq, k1);
                         } else if (in != nullptr && in2) {
@@ -794,9 +832,9 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                         loads_landed(x0, x1);
                         const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
                         const u128 r0 = x0 + (single ? c0 : pA0 - c0), r1 = x1 + (single ? c1 : pA1 - c1);
-                        if (cq.fout != nullptr) {
-                            if (a0 && link >= 0) cq.fout[k0] = codec_unquantize(cq, r0 & mask);
-                            if (a1 && link >= 0) cq.fout[k1] = codec_unquantize(cq, r1 & mask);
+                        if (CODEC && cq.fout != nullptr) {
+                            if (a0 && link >= 0) cq.fout[k0] = codec_unquantize(cq, k0, r0 & mask);
+                            if (a1 && link >= 0) cq.fout[k1] = codec_unquantize(cq, k1, r1 & mask);
                         } else {
                             if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
                             if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
@@ -835,7 +873,7 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                 const uint64_t *in = link >= 0 ? tb.in[link0 + link] : nullptr;
                 uint64_t *out = link >= 0 ? tb.out[link0 + link] : nullptr;
                 u128 x0 = 0, x1 = 0;
-                if (cq.x != nullptr && link >= 0) {
+                if (CODEC && cq.x != nullptr && link >= 0) {
                     if (a0) x0 = codec_quantize(cq, k0);
                     if (a1) x1 = codec_quantize(cq, k1);
                 } else if (in != nullptr && in2) {
@@ -852,9 +890,9 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                 loads_landed(x0, x1);
                 const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
                 const u128 r0 = x0 + (single ? c0 : p0 - c0), r1 = x1 + (single ? c1 : p1 - c1);
-                if (cq.fout != nullptr) {
-                    if (a0 && link >= 0) cq.fout[k0] = codec_unquantize(cq, r0 & mask);
-                    if (a1 && link >= 0) cq.fout[k1] = codec_unquantize(cq, r1 & mask);
+                if (CODEC && cq.fout != nullptr) {
+                    if (a0 && link >= 0) cq.fout[k0] = codec_unquantize(cq, k0, r0 & mask);
+                    if (a1 && link >= 0) cq.fout[k1] = codec_unquantize(cq, k1, r1 & mask);
                 } else {
                     if (a0 && out != nullptr) st128(out + 2 * k0, r0 & mask);
                     if (a1 && out != nullptr) st128(out + 2 * k1, r1 & mask);
@@ -960,7 +998,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_kernel(const RoundKey
             for (int u = 0; u < kTch; u++) {
                 const uint64_t j = j0 + t0 + u;
                 if (t0 + u < cnt && j >= p.first && j < range_end) {
-                    if (p.cq.fout) p.cq.fout[j - p.first] = codec_unquantize(p.cq, acc[u] & p.mask_lo);
+                    if (p.cq.fout) p.cq.fout[j - p.first] = codec_unquantize(p.cq, j - p.first, acc[u] & p.mask_lo);
                     else p.out[j - p.first] = acc[u] & p.mask_lo;
                 }
             }
@@ -1216,7 +1254,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
                     const uint64_t j = e0 + x;
                     if (j >= first && j < range_end) {
                         const uint64_t pt = p.cq.x ? codec_quantize(p.cq, j - first) : in ? __builtin_nontemporal_load(in + (j - first)) : 0ull;
-                        if (p.cq.fout) p.cq.fout[j - first] = codec_unquantize(p.cq, (pt + val) & p.mask_lo);
+                        if (p.cq.fout) p.cq.fout[j - first] = codec_unquantize(p.cq, j - first, (pt + val) & p.mask_lo);
                         else __builtin_nontemporal_store((pt + val) & p.mask_lo, out + (j - first));
                     }
                 }
@@ -1228,7 +1266,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
                 if (j < first || j >= range_end) continue;
                 const uint64_t val = extract64(D, p.b * tt);
                 const uint64_t pt = p.cq.x ? codec_quantize(p.cq, j - first) : in ? in[j - first] : 0ull;
-                if (p.cq.fout) p.cq.fout[j - first] = codec_unquantize(p.cq, (pt + val) & p.mask_lo);
+                if (p.cq.fout) p.cq.fout[j - first] = codec_unquantize(p.cq, j - first, (pt + val) & p.mask_lo);
                 else out[j - first] = (pt + val) & p.mask_lo;
             }
         }
@@ -1656,7 +1694,10 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_kernel(con
         uint32_t s[2][4];
         ctr_round1(pre_a, x, s[0]);
         ctr_round1(pre_m, x, s[1]);
-        if (!(has_minus & 0x100)) aes256_rounds<2, 2>(rk, lr, s);          // (0x100: timing probe without the rounds, FLASHE_SMALL_REDUCE_PROBE)
+#ifdef FLASHE_TUNING
+        if (!(has_minus & 0x100))                                          // (0x100: timing probe without the rounds, FLASHE_SMALL_REDUCE_PROBE)
+#endif
+        aes256_rounds<2, 2>(rk, lr, s);
         const u128 Sa = words_to_u128(s[0]), Sm = words_to_u128(s[1]);
         const u128 D = (has_minus & 1) ? slot_diff(Sa, Sm, top, p.b) : Sa;
         *reinterpret_cast<uint4 *>(row0 + 4 * lane) = make_uint4(static_cast<uint32_t>(D), static_cast<uint32_t>(D >> 32),
@@ -1770,7 +1811,10 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kern
         const CtrVar x = ctr_var(rk, lr, ctr);
         uint32_t s[1][4];
         ctr_round1(pre, x, s[0]);
-        if (!(has_minus & 0x100)) aes256_rounds<1, 2>(rk, lr, s);        // (0x100: timing probe without the rounds)
+#ifdef FLASHE_TUNING
+        if (!(has_minus & 0x100))                                        // (0x100: timing probe without the rounds)
+#endif
+        aes256_rounds<1, 2>(rk, lr, s);
         // row word order = little-endian words of the 128-bit block value (word 0 = bits 0..31)
         *reinterpret_cast<uint4 *>(row0 + 4 * lane) = drop ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(s[0][3], s[0][2], s[0][1], s[0][0]);
         __builtin_amdgcn_wave_barrier();
@@ -1933,7 +1977,7 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
 #ifdef FLASHE_WITH_BITSLICE
     if (bs_shape && env.prf_backend == PRF_BITSLICE16) {
         // waves per SIMD the kernel variant is compiled for (register budget 256 / 168 / 128 VGPRs)
-        static const int kWaves = [] { const char *e = getenv("FLASHE_BS16_WAVES"); int w = e ? atoi(e) : 3; return w < 2 || w > 4 ? 3 : w; }();
+        static const int kWaves = [] { const char *e = FLASHE_TUNE_ENV("FLASHE_BS16_WAVES"); int w = e ? atoi(e) : 3; return w < 2 || w > 4 ? 3 : w; }();
         const uint64_t tile = n_minus ? 512 : 1024;
         uint64_t waves = (count + tile - 1) / tile;
         uint64_t blocks = (waves + 3) / 4;
@@ -2102,7 +2146,7 @@ static hipError_t launch_prf_jobs_small(const LaunchEnv &env, uint32_t iter, boo
 // LeNet-sized vector spreads over 241 CUs instead of 61).
 static bool lone_small_double_job(const LaunchEnv &env, bool dbl, int n_entries, const PrfJob *jobs)
 {
-    static const bool on = !(getenv("FLASHE_SMALL_LATENCY") && atoi(getenv("FLASHE_SMALL_LATENCY")) == 0);
+    static const bool on = !(FLASHE_TUNE_ENV("FLASHE_SMALL_LATENCY") && atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_LATENCY")) == 0);
     return on && env.b > 64 && dbl && n_entries == 1 && !env.codec && jobs[0].n_in <= 1 && jobs[0].count &&
            jobs[0].count <= 256ull * static_cast<uint64_t>(env.num_cus) && ((jobs[0].first + jobs[0].count - 1) >> 32) == (jobs[0].first >> 32);
 }
@@ -2243,13 +2287,13 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
     const uint64_t waves = static_cast<uint64_t>(env.num_cus) * (kPrfThreads / 64);
     bool all_half = total_tiles < 2 * waves;
     // experiment knobs (tests/perf/sweep_chain.py), read per launch only when FLASHE_CHAIN_TUNE is set
-    static const bool tune = getenv("FLASHE_CHAIN_TUNE") != nullptr;
+    static const bool tune = FLASHE_TUNE_ENV("FLASHE_CHAIN_TUNE") != nullptr;
     int force_parts = 0, force_grid = 0, probe = 0;
     if (tune) {
-        if (const char *e = getenv("FLASHE_CHAIN_HALF")) all_half = atoi(e) != 0;
-        if (const char *e = getenv("FLASHE_CHAIN_PARTS")) force_parts = atoi(e);
-        if (const char *e = getenv("FLASHE_CHAIN_GRID")) force_grid = atoi(e);
-        if (const char *e = getenv("FLASHE_CHAIN_PROBE")) probe = atoi(e) == 1 ? 0x100 : atoi(e) == 2 ? 0x200 : 0;
+        if (const char *e = FLASHE_TUNE_ENV("FLASHE_CHAIN_HALF")) all_half = atoi(e) != 0;
+        if (const char *e = FLASHE_TUNE_ENV("FLASHE_CHAIN_PARTS")) force_parts = atoi(e);
+        if (const char *e = FLASHE_TUNE_ENV("FLASHE_CHAIN_GRID")) force_grid = atoi(e);
+        if (const char *e = FLASHE_TUNE_ENV("FLASHE_CHAIN_PROBE")) probe = atoi(e) == 1 ? 0x100 : atoi(e) == 2 ? 0x200 : 0;
     }
     // cut: (1) table limits, (2) parallelism of short launches (never below 4 outputs per piece: a cut costs one stream)
     // (3) SINGLE chains have no shared stream, a cut is free: cut until the launch has two whole tiles per wave and runs in whole tiles
@@ -2258,7 +2302,7 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
     bool only_single = true;
     for (const Piece &pc : pieces) only_single &= pc.ch->single && !pc.ch->sum_out_dev;
     int single_parts = 0;
-    if (only_single && all_half && !force_parts && !(tune && getenv("FLASHE_CHAIN_HALF"))) {
+    if (only_single && all_half && !force_parts && !(tune && FLASHE_TUNE_ENV("FLASHE_CHAIN_HALF"))) {
         single_parts = static_cast<int>(std::min<uint64_t>((2 * waves + total_tiles - 1) / total_tiles, kMaxChains / pieces.size()));
         if (single_parts < 1) single_parts = 1;
         uint64_t cut_tiles = 0;
@@ -2327,11 +2371,15 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
             if (cut.size() != 1 || cut[0].l1 - cut[0].l0 != 1) return hipErrorInvalidValue;      // one job, one output
             cq = *env.codec;
         }
-        if (summed)
-            hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, true>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
+        if (env.codec && summed) return hipErrorInvalidValue;
+        if (env.codec)
+            hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, false, true>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
+                               (all_half ? 1 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
+        else if (summed)
+            hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, true, false>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
                                (all_half ? 1 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
         else
-            hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, false>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
+            hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, false, false>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
                                (all_half ? 1 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
@@ -2344,7 +2392,7 @@ static SmallParams small_params_of(const LaunchEnv &env, uint32_t iter, uint64_t
 {
     SmallParams p{};
     p.n = n; p.n_jobs = n_jobs; p.iter = iter; p.b = env.b; p.m = 128 / env.b; p.te0 = env.te0_dev;
-    { static const int v = getenv("FLASHE_SMALL_DIRECT") ? atoi(getenv("FLASHE_SMALL_DIRECT")) : 1; p.no_direct = v == 0 ? 1 : v == 2 ? 2 : 0; }
+    { static const int v = FLASHE_TUNE_ENV("FLASHE_SMALL_DIRECT") ? atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_DIRECT")) : 1; p.no_direct = v == 0 ? 1 : v == 2 ? 2 : 0; }
     p.m_magic = static_cast<uint32_t>(((1ull << 32) + p.m - 1) / p.m);
     uint64_t hi;
     masks_of(env.b, &p.mask_lo, &hi);
@@ -2379,12 +2427,12 @@ hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint
     // operands without the AES rounds: 0.180 ms in steps of 2, 0.188-0.193 in steps of 4-5, 0.225 in steps of 8; four elements per lane
     // per step changed nothing at m = 6 and wastes slots at m = 2 (tests/perf/small_reduce_decrypt.py; FLASHE_SMALL_REDUCE_CB = 1, 2, 4, 8)
     int cb = C < 2 ? 1 : 2;
-    { static const int force = getenv("FLASHE_SMALL_REDUCE_CB") ? atoi(getenv("FLASHE_SMALL_REDUCE_CB")) : 0; if (force >= 1) cb = force; }
-    static const int probe = getenv("FLASHE_SMALL_REDUCE_PROBE") ? 0x100 : 0;
+    { static const int force = FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_CB") ? atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_CB")) : 0; if (force >= 1) cb = force; }
+    static const int probe = FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_PROBE") ? 0x100 : 0;
 #define SRD_LAUNCH(CB)                                                                                                                      \
     hipLaunchKernelGGL((small_reduce_decrypt_kernel<CB, 2>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, p, add_idx, minus_idx, \
                        (has_minus ? 1 : 0) | probe, first, count, bf, bc, C, t, agg_out_dev, out_dev)
-    static const bool split_off = getenv("FLASHE_SMALL_REDUCE_SPLIT") && atoi(getenv("FLASHE_SMALL_REDUCE_SPLIT")) == 0;
+    static const bool split_off = FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_SPLIT") && atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_SPLIT")) == 0;
     if (env.b <= 32 && !split_off) {
         // 32-block tiles, the two streams in the two halves of the wave (see small_reduce_decrypt_split_kernel)
         const uint64_t tiles32 = (bc + 31) / 32, groups32 = (tiles32 + kSmallThreads / 64 - 1) / (kSmallThreads / 64);
@@ -3435,6 +3483,19 @@ void codec_unquantize_back(Codec *c, double alpha, int bits, int num_clients, do
     c->ac = alpha * static_cast<double>(num_clients);
     c->two_a = 2 * c->ac;
     c->uden = static_cast<double>(((1ull << bits) - 1) * static_cast<uint64_t>(num_clients));
+}
+
+CodecLayer codec_layer_front(uint64_t start, const void *x_dev, bool is_f64, double alpha, int bits)
+{
+    const Codec c = codec_quantize_front(x_dev, is_f64, alpha, bits, nullptr);
+    return CodecLayer{start, x_dev, c.alpha, c.scale, c.den, c.x_is_f64, 0};
+}
+
+CodecLayer codec_layer_back(uint64_t start, double alpha, int bits, int num_clients)
+{
+    Codec c{};
+    codec_unquantize_back(&c, alpha, bits, num_clients, nullptr);
+    return CodecLayer{start, nullptr, c.ac, c.two_a, c.uden, 0, 0};
 }
 
 // x <- x + shift (normalize: shift = -mean, unnormalize: shift = +mean; a - b and a + (-b) round identically)

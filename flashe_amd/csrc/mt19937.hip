@@ -346,7 +346,11 @@ extern "C" int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uin
     if (!key || !pos || *pos > 624u || (n && !u_dev)) return fail(ctx, FLASHE_EINVAL, "flashe_mt19937_random_dev: bad arguments");
     if (n == 0) return FLASHE_OK;
     if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "flashe_mt19937_random_dev is synchronous (it returns the advanced state): not capturable");
+#ifdef FLASHE_TUNING
     static const bool serial_only = [] { const char *e = getenv("FLASHE_MT_PARALLEL"); return e && atoi(e) == 0; }();
+#else
+    constexpr bool serial_only = false;
+#endif
     // scratch: [0, 625) the state in (key + pos), [640, 1264) the state out, then the windows
     const uint64_t cap = (kSubWords << kJumpLevels) / 2;             // doubles one pass can cut into substreams
     uint32_t host[625];

@@ -206,6 +206,14 @@ class DeviceBuffer:
         self.engine._check(self.engine._lib.flashe_memcpy_h2d(self.engine._h, self.ptr, arr.ctypes.data, arr.nbytes))
         return self
 
+    def upload_at(self, offset, arr):
+        """Copy `arr` to byte `offset` of the block (layers of a model going into one flat buffer)."""
+        arr = np.ascontiguousarray(arr)
+        assert 0 <= offset and offset + arr.nbytes <= self.nbytes
+        if arr.nbytes:
+            self.engine._check(self.engine._lib.flashe_memcpy_h2d(self.engine._h, self.ptr + int(offset), arr.ctypes.data, arr.nbytes))
+        return self
+
     def download(self, dtype=np.uint64, count=None):
         n = self.nbytes // np.dtype(dtype).itemsize if count is None else count
         out = host_empty(n, dtype)
@@ -724,6 +732,31 @@ class Engine:
         pm, _m = _u32_list(minus_idx)
         self._check(self._lib.flashe_decrypt_unquantize_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, self._ptr(inp),
                                                             float(alpha), element_bits, num_clients, self._ptr(out)))
+
+    @staticmethod
+    def _codec_layers(layers):
+        """layers: iterable of (start, x device pointer or None, alpha, x_is_f64) -> ctypes array of flashe_codec_layer."""
+        layers = list(layers)
+        arr = (_lib.CodecLayer * max(len(layers), 1))()
+        for i, (start, x, alpha, is_f64) in enumerate(layers):
+            arr[i].start, arr[i].x_dev, arr[i].alpha, arr[i].x_is_f64, arr[i].reserved = int(start), x, float(alpha), 1 if is_f64 else 0, 0
+        return arr, len(layers)
+
+    def quantize_encrypt_model_dev(self, it, idx, scheme, n, n_jobs, first, count, layers, element_bits, u, ct):
+        """The fused quantise -> encrypt over elements [first, first + count) of a FLATTENED model of n values (PRF counters and, for
+        int_bits <= 64, the chunking run across the layers, as in a reference job: jzf_aggregator.py:721-741).  layers: (start, device
+        pointer of the layer's own first value, alpha, is_f64) in ascending start order; u / ct address element `first`."""
+        arr, nl = self._codec_layers(layers)
+        self._check(self._lib.flashe_quantize_encrypt_model_dev(self._h, it, idx, scheme, n, n_jobs, first, count, arr, nl, element_bits,
+                                                                self._ptr(u), self._ptr(ct)))
+
+    def decrypt_unquantize_model_dev(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, layers, element_bits, num_clients, out):
+        """The fused decrypt -> unquantise of the same flattened vector: layers = (start, None, alpha, False) per layer."""
+        pa, _a = _u32_list(add_idx)
+        pm, _m = _u32_list(minus_idx)
+        arr, nl = self._codec_layers(layers)
+        self._check(self._lib.flashe_decrypt_unquantize_model_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, first, count,
+                                                                  self._ptr(inp), arr, nl, element_bits, num_clients, self._ptr(out)))
 
     def shift_dev(self, n, x, x_is_f64, shift, wide=False):
         """x <- x + shift in place (normalize: shift = -mean)."""

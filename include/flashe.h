@@ -44,6 +44,14 @@ extern "C" {
 typedef struct flashe_ctx flashe_ctx;
 
 /* ---- library / device ------------------------------------------------------------- */
+/* ABI version of this header; flashe_abi_version() returns the one the library was built from.  Bumped whenever an exported
+ * signature or struct layout changes or entry points are added.
+ *   1  rounds 1-3 (entry points and flashe_prf_job fields were added without a bump: n_in / in_stride / sum_out_dev, the *_u32_dev,
+ *      *_sum_dev, sparse_double_masks, mt19937 and sparsify_batch calls -- a round-1 binding of flashe_prf_job is NOT compatible)
+ *   2  round 4: flashe_codec_layer + flashe_quantize_encrypt_model_dev / flashe_decrypt_unquantize_model_dev (the fused codec over a
+ *      flattened model); ctx-resident mask precompute (flashe_prepare_* / flashe_*_prepared_dev); flashe_span_bounds handles;
+ *      flashe_dynamic_masking_cost_dev; timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only) */
+#define FLASHE_ABI_VERSION 2
 int flashe_abi_version(void);
 int flashe_device_count(int *count);
 int flashe_limbs(int int_bits);                 /* 1 or 2; 0 if int_bits is out of range */
@@ -383,6 +391,31 @@ int flashe_quantize_encrypt_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, in
 int flashe_decrypt_unquantize_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add,
                                   const uint32_t *minus_idx, int n_minus, uint64_t n, uint32_t n_jobs,
                                   const uint64_t *in_dev, double alpha, int element_bits, int num_clients, double *out_dev);
+/* The same for a whole FLATTENED model in one launch -- what a reference job computes (Client.secure_aggregate,
+ * jzf_aggregator.py:721-741: QuantizingClient.quantize layer by layer, each layer with its own alpha, then Client.flatten_weights
+ * :625-650 and ONE cipher.encrypt over the concatenation; back: cipher.decrypt of the one vector, Client.unflatten_weights :652-671,
+ * unquantize layer by layer :887-899).  The PRF counters -- and for int_bits <= 64 the chunks_idx(range(n), n_jobs) chunking --
+ * therefore run across the layers: n is the length of the flattened vector, the call covers its elements [first, first + count)
+ * (ct_dev / in_dev / u_dev / out_dev address element `first`), and `layers` (HOST array, ascending `start`, layers[0].start == 0)
+ * says which alpha -- and, quantize_encrypt, which device array -- flat element j belongs to: the last entry with start <= j.
+ * x_dev of a layer points to that layer's OWN first value (the layers need not be contiguous in HBM and may mix float32 and
+ * float64); decrypt_unquantize ignores x_dev / x_is_f64.  u_dev[k] = the stochastic-rounding draw of flat element first + k: the
+ * reference draws np.random.random(layer.shape) layer by layer in walking order (jzf_quantize.py:61 under :417-462), i.e. one
+ * stretch of NumPy's stream in flat order.  Not capturable into a graph (the table is staged per call). */
+typedef struct flashe_codec_layer {
+    uint64_t start;        /* flat index of the layer's first value */
+    const void *x_dev;     /* quantize_encrypt: the layer's float32 / float64 values */
+    double alpha;          /* the layer's clipping threshold (QuantizingClient.alpha_list; 1.0 for the sparse job's 'zzz' layer) */
+    int32_t x_is_f64;
+    int32_t reserved;      /* 0 */
+} flashe_codec_layer;
+int flashe_quantize_encrypt_model_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uint64_t n, uint32_t n_jobs,
+                                      uint64_t first, uint64_t count, const flashe_codec_layer *layers, int n_layers,
+                                      int element_bits, const double *u_dev, uint64_t *ct_dev);
+int flashe_decrypt_unquantize_model_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add,
+                                        const uint32_t *minus_idx, int n_minus, uint64_t n, uint32_t n_jobs, uint64_t first,
+                                        uint64_t count, const uint64_t *in_dev, const flashe_codec_layer *layers, int n_layers,
+                                        int element_bits, int num_clients, double *out_dev);
 /* QuantizingClient.normalize / unnormalize (jzf_quantize.py:542-564): x <- x + shift in place (normalize passes -mean).  wide: for
  * float32 arrays the addition runs in float64 and is rounded once -- NumPy's loop when the scalar is a float64 (np.mean / np.std
  * results), as opposed to a Python float; bit-exact either way.  mean_std: the per-layer statistics unnormalize records for the next

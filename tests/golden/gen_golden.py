@@ -761,8 +761,152 @@ def gen_block():
     dump("block.json", {"key": KEY.hex(), "dynamic_masking": dm, "dense_precompute": dense, "sparse_dynamic": sparse})
 
 
+# --------------------------------------------------------------------------- the client step of a job
+def gen_clientstep():
+    """What a reference JOB does either side of the cipher, executed from the reference's own methods
+    (Client.secure_aggregate, jzf_aggregator.py:721-743, and Client.aggregate's tail, :881-898):
+        QuantizingClient.quantize -> Client.flatten_weights (:625-650) -> [sparse: strip the trailing quantised zero] ->
+        JZFOrderDictWeights.encrypted(cipher=_Client) -> [re-append it]
+    and back
+        _Client.set_idx_list -> JZFOrderDictWeights.decrypted -> Client.unflatten_weights (:652-671) -> QuantizingClient.unquantize.
+    flatten_weights leaves ONE vector, so the PRF counters -- and for int_bits <= 64 the chunks_idx chunking -- run across all layers.
+    The aggregator-side methods are called unbound on stub objects (they only touch self.shape_dict); the weights are real
+    JZFOrderDictWeights; the cipher is the reference FlasheCipher behind the reference _Client forwarders."""
+    RB = _import_block()
+    RA = _import_aggregator()
+    rng = np.random.RandomState(77)
+    cases = []
+    #        b   eb  C  n_jobs scheme    iter layers (name, shape, dtype, scale)
+    grid = [(128, 16, 3, 4, "double", 2, [("a_conv", (7, 5), "float32", 0.8), ("b_bias", (11,), "float32", 3.0), ("c_dense", (3, 4), "float64", 1.0)]),
+            (64, 12, 3, 7, "double", 0, [("a_conv", (9, 4), "float32", 1.0), ("b_bias", (5,), "float32", 0.5), ("c_dense", (17,), "float32", 2.0)]),
+            (20, 12, 3, 5, "double", 6, [("l0", (13, 3), "float32", 1.0), ("l1", (1,), "float32", 1.0), ("l2", (4, 5), "float64", 4.0)]),
+            (64, 32, 2, 8, "single", 1, [("w", (10, 10), "float32", 1.0), ("x", (3,), "float32", 1.0)]),
+            (23, 16, 4, 16, "double", 3, [("only", (61,), "float32", 1.0)])]
+    for b, eb, C, n_jobs, scheme, it, layer_specs in grid:
+        RF.N_JOBS = n_jobs
+        mod = 1 << b
+        clients = []
+        for c in range(C):
+            ci = RF.FlasheCipher(b, mask=scheme)
+            ci.idx = c
+            ci.generate_prp_seed(KEY)
+            ci.set_num_clients(C)
+            qc = RQ.QuantizingClient(b, None, None, False, eb, True, True)
+            qc.num_clients = C
+            st = types.SimpleNamespace(cipher=ci, quantizer=qc, precompute=False, mask=scheme)
+            st.encrypt = lambda x, st=st: RB._Client.encrypt(st, x)            # what JZFWeights.encrypted / decrypted call on the "cipher"
+            st.decrypt = lambda x, st=st: RB._Client.decrypt(st, x)
+            clients.append((st, types.SimpleNamespace(shape_dict=None)))       # (flashe_block client, aggregator-side Client stub)
+        rec_clients, flat_cts = [], []
+        for c, (st, agg_client) in enumerate(clients):
+            RB._Client.set_iter_index(st, it)
+            layers = {nm: (rng.standard_normal(sh) * sc).astype(dt) for nm, sh, dt, sc in layer_specs}
+            w = RW.JZFOrderDictWeights({k: v.copy() for k, v in layers.items()})
+            st.quantizer.set_layer_size_list(w)
+            seed = 9000 + 10 * b + c
+            np.random.seed(seed)
+            w = st.quantizer.quantize(w)                                           # jzf_aggregator.py:722
+            w = RA.Client.flatten_weights(agg_client, w)                           # :723
+            assert len(w.walking_order) == 1
+            flat_q = [int(v) for v in w._weights[w.walking_order[0]]]
+            w = w.encrypted(cipher=st, inplace=True)                               # :741
+            flat_ct = [int(v) for v in w._weights[w.walking_order[0]]]
+            flat_cts.append(flat_ct)
+            rec_clients.append({"seed": seed, "layers": {k: _fhex(v) for k, v in layers.items()}, "alpha": [float(a).hex() for a in st.quantizer.alpha_list],
+                                "flat_key": str(w.walking_order[0]), "flat_quantized": hxl(flat_q), "flat_ct": hxl(flat_ct),
+                                "shape_dict": {k: list(v) for k, v in agg_client.shape_dict.items()}})
+        n = len(flat_cts[0])
+        agg_elem = reduce(lambda x, y: (x + y) % mod, [np.array(v, dtype=object) for v in flat_cts])     # :424-430
+        pmod = 1 << (b * n)
+        agg_packed_int = reduce(lambda x, y: (x + y) % pmod, [packed_int(v, b) for v in flat_cts])      # :406-419
+        agg_packed = RW._from_bytes_old(agg_packed_int, n, b)
+        agg_packed.reverse()
+        outs = {}
+        for nm, agg in (("elem", agg_elem), ("packed", agg_packed)):
+            st, agg_client = clients[0]
+            RB._Client.set_idx_list(st, list(range(C)))                            # :883
+            w = RW.JZFOrderDictWeights({rec_clients[0]["flat_key"]: np.array([int(v) for v in agg], dtype=object)})
+            w = w.decrypted(cipher=st, inplace=True)                               # :887
+            dec = [int(v) for v in w._weights[w.walking_order[0]]]
+            w = RA.Client.unflatten_weights(agg_client, w)                         # :896
+            w = RB._Client.unquantize(st, w)                                       # :899
+            outs[nm] = {"dec": hxl(dec), "unquantized": {k: _fhex(np.array([float(v) for v in np.asarray(w._weights[k]).flatten()], dtype=np.float64))
+                                                         for k in agg_client.shape_dict}}
+        cases.append({"b": b, "element_bits": eb, "num_clients": C, "n_jobs": n_jobs, "scheme": scheme, "iter": it, "n": n,
+                      "layers": [[nm, list(sh), dt] for nm, sh, dt, _sc in layer_specs], "clients": rec_clients,
+                      "agg_elem": hxl(agg_elem), "agg_packed": hxl(agg_packed), "out_elem": outs["elem"], "out_packed": outs["packed"]})
+
+    # the sparse job: compact layers + the 'zzz' layer whose quantised zero rides un-encrypted behind the ciphertexts (:717-720, :735-743)
+    sparse = []
+    for b, eb, C, n_jobs, it, dense_specs, ks in [(128, 16, 3, 4, 5, [("a", (6, 5), "float32"), ("b", (20,), "float32")], [4, 3]),
+                                                  (64, 12, 2, 8, 2, [("p", (40,), "float64"), ("q", (3, 7), "float32")], [6, 2])]:
+        RF.N_JOBS = n_jobs
+        mod = 1 << b
+        total = int(sum(int(np.prod(sh)) for _nm, sh, _dt in dense_specs))
+        masks, ups, recs, clients = [], [], [], []
+        for c in range(C):
+            base, loc = 0, []
+            for (_nm, sh, _dt), k in zip(dense_specs, ks):
+                size = int(np.prod(sh))
+                loc += sorted((rng.choice(size, k, replace=False) + base).tolist())
+                base += size
+            masks.append(loc)
+        g, h = _Wire(), _Wire()
+        RB.Arbiter.dynamic_masking(types.SimpleNamespace(mask="dynamic", arbiter_to_guest=g, arbiter_to_host=h), masks, total, (it,))
+        for c in range(C):
+            ci = RF.FlasheCipher(b)
+            ci.idx = c
+            ci.generate_prp_seed(KEY)
+            ci.set_num_clients(C)
+            qc = RQ.QuantizingClient(b, None, None, False, eb, True, True)
+            qc.num_clients = C
+            st = types.SimpleNamespace(cipher=ci, quantizer=qc, precompute=False, mask="dynamic", arbiter_to_host=h)
+            st.encrypt = lambda x, st=st: RB._Client.encrypt(st, x)
+            st.decrypt = lambda x, st=st: RB._Client.decrypt(st, x)
+            agg_client = types.SimpleNamespace(shape_dict=None, shape_dict_used_for_sparsification={nm: tuple(sh) for nm, sh, _dt in dense_specs})
+            clients.append((st, agg_client))
+            RB._Client.set_iter_index(st, it)
+            ci.total = total                                                       # :707
+            RB.Host.dynamic_masking(st, (it,))                                     # :709
+            compact = {nm: (rng.standard_normal(k) * 1.5).astype(dt) for (nm, _sh, dt), k in zip(dense_specs, ks)}   # what sparsify leaves (:598)
+            w = RW.JZFOrderDictWeights({k_: v.copy() for k_, v in compact.items()})
+            st.quantizer.set_layer_size_list(w)                                    # (normalize's first call, before 'zzz' exists)
+            w._weights['zzz'] = np.array([0.0])                                    # :717-718
+            w.refresh_walking_order()
+            seed = 7000 + 10 * b + c
+            np.random.seed(seed)
+            w = st.quantizer.quantize(w)
+            w = RA.Client.flatten_weights(agg_client, w)
+            k0 = w.walking_order[0]
+            flat_q = [int(v) for v in w._weights[k0]]
+            zero_quantized = w._weights[k0][-1]                                    # :735-737
+            w._weights[k0] = w._weights[k0][:-1]
+            w = w.encrypted(cipher=st, inplace=True)
+            w._weights[k0] = np.append(w._weights[k0], [zero_quantized])           # :742-743
+            up = [int(v) for v in w._weights[k0]]
+            ups.append(up)
+            recs.append({"seed": seed, "layers": {k_: _fhex(v) for k_, v in compact.items()}, "alpha": [float(a).hex() for a in st.quantizer.alpha_list],
+                         "flat_key": str(k0), "flat_quantized": hxl(flat_q), "upload": hxl(up)})
+        dense_vecs = ref_expand_to_dense(RA, ups, masks, total)
+        agg = reduce(lambda x, y: (x + y) % mod, dense_vecs)
+        st, agg_client = clients[0]
+        RB._Client.set_idx_list(st, list(range(C)))
+        w = RW.JZFOrderDictWeights({recs[0]["flat_key"]: np.array([int(v) for v in agg], dtype=object)})
+        w = w.decrypted(cipher=st, inplace=True)
+        dec = [int(v) for v in w._weights[w.walking_order[0]]]
+        agg_client.shape_dict = agg_client.shape_dict_used_for_sparsification      # :893-894
+        # (the sparse job unquantises DENSE layers with the alphas of the compact ones: alpha_list has one entry per layer either way)
+        w = RA.Client.unflatten_weights(agg_client, w)
+        w = RB._Client.unquantize(st, w)
+        unq = {k_: _fhex(np.array([float(v) for v in np.asarray(w._weights[k_]).flatten()], dtype=np.float64)) for k_ in agg_client.shape_dict}
+        sparse.append({"b": b, "element_bits": eb, "num_clients": C, "n_jobs": n_jobs, "iter": it, "total": total, "choice": h.sent[0]["choice"],
+                       "dense_layers": [[nm, list(sh), dt] for nm, sh, dt in dense_specs], "ks": ks, "masks": masks, "clients": recs,
+                       "agg": hxl(agg), "dec": hxl(dec), "unquantized": unq})
+    dump("clientstep.json", {"key": KEY.hex(), "dense": cases, "sparse": sparse})
+
 
 if __name__ == "__main__":
+    gen_clientstep()
     gen_quantclient()
     gen_block()
     gen_sparsify()

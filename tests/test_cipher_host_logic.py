@@ -223,6 +223,82 @@ def test_flashe_client_flows_from_reference_fixture(cipher_cls):
                 clients[c].prepare_encrypt()
 
 
+class _W:
+    def __init__(self, layers):
+        self._weights = dict(layers)
+        self.walking_order = sorted(self._weights.keys(), key=str)
+
+
+def test_client_step_flatten_semantics_from_reference_fixture(cipher_cls):
+    """The client step of a reference JOB (tests/golden/clientstep.json, recorded by calling QuantizingClient.quantize ->
+    Client.flatten_weights -> JZFOrderDictWeights.encrypted(_Client) and back): the call-by-call path of FlasheClient on the engine
+    double, with the quantiser's per-layer output taken from the fixture (the quantiser itself needs the GPU: tests/test_gpu_adapter.py).
+    What this pins on the CPU: the layers are flattened BEFORE the encrypt -- one vector under the first key, PRF counters and the
+    int_bits <= 64 chunking across the layers -- the sparse job's trailing quantised zero rides un-encrypted, and unflatten cuts by
+    shape_dict."""
+    from flashe_amd.block import FlasheClient
+    g = load_golden("clientstep.json")
+    for case in g["dense"]:
+        b, C = case["b"], case["num_clients"]
+        cm.N_JOBS = case["n_jobs"]
+        args = {"quantize": {"int_bits": b, "batch": False, "element_bits": case["element_bits"], "padding": True, "secure": True},
+                "precompute": {"enable": False}}
+        sizes = [int(np.prod(sh)) for _nm, sh, _dt in case["layers"]]
+        for c, rec in enumerate(case["clients"]):
+            cl = FlasheClient(args)
+            cl.create_cipher(c, C, bytes(range(32)))
+            cl.cipher.masking_scheme = case["scheme"]
+            cl.set_iter_index(case["iter"])
+            flat_q = unhex(rec["flat_quantized"])
+            per_layer, at = {}, 0
+            for (nm, sh, _dt), size in zip(case["layers"], sizes):
+                per_layer[nm] = np.array(flat_q[at:at + size], dtype=object).reshape(sh)
+                at += size
+            cl.quantizer.layer_size_list = sizes
+            cl.quantizer.quantize = lambda w, per_layer=per_layer: _W(per_layer)        # (the GPU quantiser's output, from the fixture)
+            out = cl.quantize_encrypt(_W({nm: None for nm in per_layer}), device=False)
+            assert out.walking_order == [rec["flat_key"]]
+            assert [int(v) for v in out._weights[rec["flat_key"]]] == unhex(rec["flat_ct"]), (b, c)
+            assert {k: list(v) for k, v in cl.shape_dict.items()} == rec["shape_dict"]
+            if c == 0:
+                for agg_name, out_name in (("agg_elem", "out_elem"), ("agg_packed", "out_packed")):
+                    cl.set_idx_list(list(range(C)))
+                    w = _W({rec["flat_key"]: np.array(unhex(case[agg_name]), dtype=object)})
+                    w._weights[rec["flat_key"]] = cl.decrypt(w._weights[rec["flat_key"]])
+                    assert [int(v) for v in w._weights[rec["flat_key"]]] == unhex(case[out_name]["dec"]), (b, agg_name)
+                    w = cl.unflatten_weights(w)
+                    assert w.walking_order == sorted(per_layer) and all(w._weights[nm].shape == tuple(sh) for nm, sh, _dt in case["layers"])
+                    assert [int(v) for nm in w.walking_order for v in w._weights[nm].flatten()] == unhex(case[out_name]["dec"])
+    for case in g["sparse"]:
+        b, C = case["b"], case["num_clients"]
+        cm.N_JOBS = case["n_jobs"]
+        args = {"quantize": {"int_bits": b, "batch": False, "element_bits": case["element_bits"], "padding": True, "secure": True},
+                "precompute": {"enable": False}, "mask": "dynamic"}
+        for c, rec in enumerate(case["clients"]):
+            cl = FlasheClient(args)
+            cl.create_cipher(c, C, bytes(range(32)))
+            cl.set_iter_index(case["iter"])
+            cl.cipher.total = case["total"]
+            cl.dynamic_masking(case["choice"], case["masks"])
+            flat_q = unhex(rec["flat_quantized"])
+            per_layer, at = {}, 0
+            for (nm, _sh, _dt), k in zip(case["dense_layers"], case["ks"]):
+                per_layer[nm] = np.array(flat_q[at:at + k], dtype=object)
+                at += k
+            per_layer["zzz"] = np.array(flat_q[at:], dtype=object)
+            assert len(per_layer["zzz"]) == 1
+            cl.quantizer.layer_size_list = list(case["ks"])
+            cl.quantizer.quantize = lambda w, per_layer=per_layer: _W(per_layer)
+            out = cl.quantize_encrypt(_W({nm: None for nm in per_layer}))
+            assert out.walking_order == [rec["flat_key"]]
+            assert [int(v) for v in out._weights[rec["flat_key"]]] == unhex(rec["upload"]), (b, c)
+            assert int(out._weights[rec["flat_key"]][-1]) == flat_q[-1]                 # the quantised zero is NOT encrypted
+            if c == 0:
+                cl.set_idx_list(list(range(C)))
+                dec = cl.decrypt(np.array(unhex(case["agg"]), dtype=object))
+                assert [int(v) for v in dec] == unhex(case["dec"]), b
+
+
 def test_quantizing_client_refuses_the_branches_it_does_not_mirror():
     """padding=False leaves the reference's own quantize() without a result (its code there is commented out) and secure=False is the
     plain-text path: the mirror says so instead of quantising silently."""

@@ -280,71 +280,184 @@ class _W:
         self._weights = dict(layers)
 
 
-@pytest.mark.parametrize("b,scheme", [(128, "double"), (64, "single"), (20, "double")])
-def test_client_step_without_host_round_trips(b, scheme):
-    """FlasheClient.quantize_encrypt / decrypt_unquantize -- the reference's quantize -> encrypted(cipher) and decrypted(cipher) ->
-    unquantize (jzf_quantize.py:394-540, jzf_weights.py:334-338) with the layer going up once, the stochastic-rounding draws generated
-    on the device from NumPy's own stream (the 90,000-element layer) and one launch per layer and side -- against the two-call path
-    with the same seed: the same ciphertexts layer by layer, the same generator state afterwards, the same floats back; with
-    DeviceVector handles between the three parties' calls and with host arrays."""
+def _client_args(case, **extra):
+    d = {"quantize": {"int_bits": case["b"], "batch": False, "element_bits": case["element_bits"], "padding": True, "secure": True},
+         "precompute": {"enable": False}}
+    d.update(extra)
+    return d
+
+
+def _layers_of(case_layers, rec):
+    return {nm: _arr(rec["layers"][nm], np.dtype(dt), sh) for nm, sh, dt in case_layers}
+
+
+@pytest.mark.parametrize("case_i", range(5))
+@pytest.mark.parametrize("mode", ["fused-handles", "fused-host", "call-by-call"])
+def test_client_step_is_the_reference_jobs(case_i, mode, monkeypatch):
+    """The client step of a reference JOB against tests/golden/clientstep.json -- recorded by CALLING the reference:
+    QuantizingClient.quantize -> Client.flatten_weights (jzf_aggregator.py:625-650) -> JZFOrderDictWeights.encrypted(_Client), the arbiter's
+    two reduces, then decrypted -> Client.unflatten_weights (:652-671) -> unquantize.  The layers are flattened BEFORE the encrypt, so PRF
+    counters -- and for int_bits = 64 / 20 / 23 the chunks_idx chunking -- run across the whole model: the b <= 64 cases would fail for a
+    step that encrypts layer by layer.  FlasheClient.quantize_encrypt (one launch over the flattened model, per-layer alpha from a device
+    table) and the same sequence call by call must both give the fixture's flat ciphertext bit for bit with the fixture's seed, leave
+    NumPy's generator where the reference left it, and decrypt_unquantize must return the fixture's floats byte for byte from the
+    element-wise AND the packed aggregate."""
     from flashe_amd import cipher as cm
     from flashe_amd.block import FlasheClient
     from flashe_amd.engine import DeviceVector
-    cm.N_JOBS = 7
-    C = 3
-    args = {"quantize": {"int_bits": b, "batch": False, "element_bits": 12, "padding": True, "secure": True}, "precompute": {"enable": False}}
-    rng = np.random.Generator(np.random.PCG64(b))
-    models = [{"a_conv": (rng.standard_normal((300, 300)) * 0.5).astype(np.float32), "b_bias": rng.standard_normal(1000).astype(np.float32),
-               "c_dense": rng.standard_normal((50, 7))} for _ in range(C)]
-
-    def make_clients():
-        out = []
-        for c in range(C):
-            cl = FlasheClient(args)
-            cl.create_cipher(c, C, KEY)
-            cl.cipher.masking_scheme = scheme
-            cl.set_iter_index(4)
-            out.append(cl)
-        return out
-
-    # the two-call path (what the reference's call chain does), seeded
-    np.random.seed(31)
-    ref_cl = make_clients()
-    ref_ct = []
-    for c in range(C):
-        w = ref_cl[c].quantize(_W({k: v.copy() for k, v in models[c].items()}))
-        ref_ct.append({k: ref_cl[c].encrypt(np.asarray(w._weights[k]).reshape(-1)) for k in w.walking_order})
-    state_ref = np.random.get_state()
-    # the fused path, same seed
-    np.random.seed(31)
-    cl = make_clients()
-    handles = [cl[c].quantize_encrypt(_W({k: v.copy() for k, v in models[c].items()}), device=True) for c in range(C)]
-    st = np.random.get_state()
-    assert st[2] == state_ref[2] and np.array_equal(st[1], state_ref[1]), "the NumPy stream must be consumed identically"
     from oracle.flashe_oracle import limbs_to_ints
+    case = load_golden("clientstep.json")["dense"][case_i]
+    b, C, n = case["b"], case["num_clients"], case["n"]
+    cm.N_JOBS = case["n_jobs"]
+    clients, cts = [], []
+    for c, rec in enumerate(case["clients"]):
+        cl = FlasheClient(_client_args(case))
+        cl.create_cipher(c, C, KEY)
+        cl.cipher.masking_scheme = case["scheme"]
+        cl.set_iter_index(case["iter"])
+        if mode == "call-by-call":
+            monkeypatch.setattr(cl, "_fusable", lambda *a: False)
+        np.random.seed(rec["seed"])
+        out = cl.quantize_encrypt(_W(_layers_of(case["layers"], rec)), device=(mode == "fused-handles"))
+        st = np.random.get_state()
+        np.random.seed(rec["seed"])
+        np.random.random(n)
+        st_want = np.random.get_state()
+        assert st[2] == st_want[2] and np.array_equal(st[1], st_want[1]), "the NumPy stream must be consumed as the reference consumes it"
+        assert out.walking_order == [rec["flat_key"]] and list(out._weights) == [rec["flat_key"]]
+        v = out._weights[rec["flat_key"]]
+        if mode == "fused-handles":
+            assert isinstance(v, DeviceVector)
+            got = limbs_to_ints(v.to_host())
+        elif mode == "fused-host":
+            assert isinstance(v, np.ndarray) and v.dtype == np.uint64
+            got = limbs_to_ints(v)
+        else:
+            got = [int(x) for x in v]
+        assert got == unhex(rec["flat_ct"]), (b, c, mode)
+        assert [float(a).hex() for a in cl.quantizer.alpha_list] == rec["alpha"]
+        assert {k: list(sh) for k, sh in cl.shape_dict.items()} == rec["shape_dict"]
+        clients.append(cl)
+        cts.append(v)
+    # the arbiter's two reduces on what the clients produced
+    agg_elem = clients[0].cipher.aggregate(cts)
+    agg_packed = clients[0].cipher.aggregate(cts, packed=True)
+    as_ints = (lambda a: limbs_to_ints(a.to_host())) if mode == "fused-handles" else (lambda a: limbs_to_ints(a) if a.dtype == np.uint64 else [int(x) for x in a])
+    assert as_ints(agg_elem) == unhex(case["agg_elem"]) and as_ints(agg_packed) == unhex(case["agg_packed"])
+    for agg, out_name in ((agg_elem, "out_elem"), (agg_packed, "out_packed")):
+        clients[0].set_idx_list(list(range(C)))
+        back = clients[0].decrypt_unquantize(_W({case["clients"][0]["flat_key"]: agg}))
+        assert back.walking_order == sorted(nm for nm, _sh, _dt in case["layers"])
+        for nm, sh, _dt in case["layers"]:
+            a = back._weights[nm]
+            assert a.shape == tuple(sh)
+            assert np.asarray(a, dtype=np.float64).tobytes() == bytes.fromhex(case[out_name]["unquantized"][nm]), (b, mode, out_name, nm)
+    # object ints in (what an unmodified arbiter would hand back) give the same floats
+    clients[0].set_idx_list(list(range(C)))
+    back = clients[0].decrypt_unquantize(_W({case["clients"][0]["flat_key"]: np.array(unhex(case["agg_elem"]), dtype=object)}))
+    for nm, _sh, _dt in case["layers"]:
+        assert np.asarray(back._weights[nm], dtype=np.float64).tobytes() == bytes.fromhex(case["out_elem"]["unquantized"][nm])
+
+
+@pytest.mark.parametrize("case_i", range(2))
+def test_client_step_of_the_sparse_job(case_i):
+    """The sparse job's client step against the fixture recorded from the reference (jzf_aggregator.py:717-743, :881-899): compact layers
+    plus the 'zzz' layer, quantised, flattened, the trailing quantised zero stripped before and re-appended un-encrypted after the
+    (dynamic -> single mask, compact positions) encrypt; back: the dense aggregate decrypted with the sparse minus-mask, unflattened by
+    the DENSE shapes and unquantised."""
+    from flashe_amd import cipher as cm
+    from flashe_amd.block import FlasheClient
+    case = load_golden("clientstep.json")["sparse"][case_i]
+    b, C = case["b"], case["num_clients"]
+    cm.N_JOBS = case["n_jobs"]
+    cl0 = None
+    for c, rec in enumerate(case["clients"]):
+        cl = FlasheClient(_client_args(case, mask="dynamic"))
+        cl.create_cipher(c, C, KEY)
+        cl.set_iter_index(case["iter"])
+        cl.cipher.total = case["total"]
+        cl.dynamic_masking(case["choice"], case["masks"])
+        assert cl.cipher.masking_scheme == "single"
+        layers = {nm: _arr(rec["layers"][nm], np.dtype(dt)) for nm, _sh, dt in case["dense_layers"]}
+        w = _W(layers)
+        cl.quantizer.set_layer_size_list(w)                      # (normalize's first call, before 'zzz' exists)
+        w._weights["zzz"] = np.array([0.0])
+        w.walking_order = sorted(w._weights, key=str)
+        np.random.seed(rec["seed"])
+        out = cl.quantize_encrypt(w)
+        k0 = rec["flat_key"]
+        assert out.walking_order == [k0]
+        assert [int(v) for v in out._weights[k0]] == unhex(rec["upload"]), (b, c)
+        assert [float(a).hex() for a in cl.quantizer.alpha_list] == rec["alpha"]
+        cl0 = cl0 or cl
+    cl0.set_idx_list(list(range(C)))
+    cl0.shape_dict = {nm: tuple(sh) for nm, sh, _dt in case["dense_layers"]}         # shape_dict_used_for_sparsification (:893-894)
+    back = cl0.decrypt_unquantize(_W({case["clients"][0]["flat_key"]: np.array(unhex(case["agg"]), dtype=object)}))
+    for nm, sh, _dt in case["dense_layers"]:
+        a = np.asarray(back._weights[nm])
+        assert a.shape == tuple(sh)
+        assert np.array([float(v) for v in a.flatten()], dtype=np.float64).tobytes() == bytes.fromhex(case["unquantized"][nm]), (b, nm)
+
+
+@pytest.mark.parametrize("b,scheme,n_jobs", [(128, "double", 16), (64, "double", 7), (20, "double", 16), (64, "single", 5)])
+def test_client_step_of_a_large_model_vs_oracle(oracle, b, scheme, n_jobs):
+    """A model large enough for the device-side draws (90,000 + 1,000 + 350 + 70,001 values, float32 and float64 layers, an empty
+    layer): FlasheClient.quantize_encrypt in one launch against `_static_quantize_padding_asymmetric` (pinned by codec.json) layer by
+    layer with HOST draws from the same seed -> flatten -> the ORACLE's encrypt of the one flattened vector; the generator must end
+    where NumPy's own draws end; and decrypt_unquantize of the aggregate of three such clients against the oracle's decrypt + NumPy's
+    unquantise arithmetic."""
+    from flashe_amd import cipher as cm
+    from flashe_amd import quantize as qz
+    from flashe_amd.block import FlasheClient
+    cm.N_JOBS = n_jobs
+    C, eb, it = 3, 12, 9
+    case = {"b": b, "element_bits": eb}
+    rng = np.random.Generator(np.random.PCG64(b + n_jobs))
+    shapes = {"a_conv": ((300, 300), np.float32), "b_bias": ((1000,), np.float32), "c_dense": ((50, 7), np.float64), "d_empty": ((0,), np.float32),
+              "e_fc": ((70001,), np.float32)}
+    n = sum(int(np.prod(sh)) for sh, _dt in shapes.values())
+    handles, want_cts, clients = [], [], []
     for c in range(C):
-        assert cl[c].quantizer.alpha_list == ref_cl[c].quantizer.alpha_list
-        for k in handles[c].walking_order:
-            h = handles[c]._weights[k]
-            assert isinstance(h, DeviceVector)
-            assert limbs_to_ints(h.to_host()) == [int(v) for v in ref_ct[c][k]], (b, scheme, c, k)
-    # arbiter: the handles never leave the device; client 0 decrypts + unquantises in one launch per layer
-    agg = _W({k: cl[0].cipher.aggregate([handles[c]._weights[k] for c in range(C)]) for k in handles[0].walking_order})
-    cl[0].set_idx_list(list(range(C)))
-    got = cl[0].decrypt_unquantize(agg)
-    ref_agg = {k: ref_cl[0].cipher.aggregate([ref_ct[c][k] for c in range(C)]) for k in sorted(models[0])}
-    ref_cl[0].set_idx_list(list(range(C)))
-    want = {}
-    for k in sorted(models[0]):
-        ref_cl[0].set_idx_list(list(range(C)))
-        want[k] = ref_cl[0].decrypt(ref_agg[k])
-    want = ref_cl[0].unquantize(_W({k: np.asarray(v).reshape(models[0][k].shape) for k, v in want.items()}))
-    for k in got.walking_order:
-        assert got._weights[k].shape == models[0][k].shape
-        assert np.asarray(got._weights[k], dtype=np.float64).tobytes() == np.asarray(want._weights[k], dtype=np.float64).tobytes(), (b, scheme, k)
-    # host arrays instead of handles give the same bytes
-    np.random.seed(31)
-    cl2 = make_clients()
-    host = cl2[0].quantize_encrypt(_W({k: v.copy() for k, v in models[0].items()}), device=False)
-    for k in host.walking_order:
-        assert isinstance(host._weights[k], np.ndarray) and limbs_to_ints(host._weights[k]) == [int(v) for v in ref_ct[0][k]]
+        layers = {k: (rng.standard_normal(sh) * 0.7).astype(dt) for k, (sh, dt) in shapes.items()}
+        cl = FlasheClient(_client_args(case))
+        cl.create_cipher(c, C, KEY)
+        cl.cipher.masking_scheme = scheme
+        cl.set_iter_index(it)
+        np.random.seed(1234 + c)
+        np.random.random(5)                                        # an odd position in the stream
+        st0 = np.random.get_state()
+        handles.append(cl.quantize_encrypt(_W({k: v.copy() for k, v in layers.items()}), device=True))
+        st_got = np.random.get_state()
+        # expectation: host draws, the fixture-pinned quantiser, flatten, the oracle's encrypt of the ONE vector
+        np.random.set_state(st0)
+        flat_q = []
+        for li, k in enumerate(sorted(layers)):
+            alpha = cl.quantizer.alpha_list[li]
+            u = np.random.random(layers[k].size)
+            x = layers[k].reshape(-1)
+            if x.size:
+                flat_q.append(qz._static_quantize_padding_asymmetric(x, float(alpha), eb, uniforms=u, as_object=False).astype(np.uint64))
+        st_want = np.random.get_state()
+        assert st_got[2] == st_want[2] and np.array_equal(st_got[1], st_want[1])
+        flat_q = np.concatenate(flat_q)
+        assert flat_q.size == n
+        want = oracle.encrypt(KEY, it, c, scheme, n_jobs, b, flat_q)
+        got = handles[-1]._weights["a_conv"].to_host()
+        assert np.array_equal(got.reshape(want.shape), want), (b, scheme, c)
+        want_cts.append(want)
+        clients.append(cl)
+    agg = clients[0].cipher.aggregate([h._weights["a_conv"] for h in handles])
+    clients[0].set_idx_list(list(range(C)))
+    back = clients[0].decrypt_unquantize(_W({"a_conv": agg}))
+    agg_want = oracle.aggregate_elem(want_cts, b)
+    add_idx, minus_idx = ([C], [0]) if scheme == "double" else ([], list(range(C)))
+    dec = oracle.limbs_to_ints(oracle.decrypt(KEY, it, add_idx, minus_idx, n_jobs, b, agg_want))
+    at = 0
+    for li, k in enumerate(sorted(shapes)):
+        sh, _dt = shapes[k]
+        size = int(np.prod(sh))
+        alpha = clients[0].quantizer.alpha_list[li] * C
+        v = np.array(dec[at:at + size], dtype=np.float64) if size else np.zeros(0)
+        want = v * (2 * alpha) / (((1 << eb) - 1) * C) - alpha                      # jzf_quantize.py:102-107
+        assert back._weights[k].shape == sh and np.asarray(back._weights[k]).tobytes() == want.reshape(sh).tobytes(), (b, k)
+        at += size
