@@ -137,6 +137,7 @@ _SIGNATURES = {
     "flashe_mean_std_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "flashe_mt19937_random_dev": (c_int, [c_vp, c_u32p, c_u32p, c_u64, c_vp]),
     "flashe_mt19937_jump_selfcheck": (c_int, []),
+    "flashe_mt19937_plan": (c_int, [c_u32, c_u64, c_u32p, c_u32p, c_u32p]),
     "flashe_quantize_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),
     "flashe_quantize": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),
     "flashe_unquantize_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int, c_int, c_vp]),

@@ -340,6 +340,42 @@ JumpTables &jump_tables()
 // Host only (no device needed): builds the jump polynomials and checks them against the generator.
 extern "C" int flashe_mt19937_jump_selfcheck(void) { return jump_tables().ok ? FLASHE_OK : FLASHE_EIO; }
 
+// One pass of flashe_mt19937_random_dev: how many of the n_left doubles it takes from stream position pos0 (0 .. 624) and into how
+// many substreams it cuts them.  The jump tree has kJumpLevels levels, so a pass may span at most 2^kJumpLevels substreams WHATEVER
+// pos0 is: the cap leaves room for the up to 624 words in front of the first draw (with cap = S * 2^L / 2 and pos0 >= 2 the
+// last pass of a 2^28-draw call needed 2^L + 1 substreams and read one level past the table).
+static void mt_plan_pass(uint64_t pos0, uint64_t n_left, bool serial_only, uint64_t *now_out, uint32_t *P_out)
+{
+    const uint64_t cap = ((static_cast<uint64_t>(kSubWords) << kJumpLevels) - kMtN) / 2;
+    const uint64_t now = n_left < cap ? n_left : cap;
+    const uint64_t end = pos0 + 2 * now;
+    uint32_t P = serial_only ? 1u : static_cast<uint32_t>((end - 1 + kSubWords - 1) / kSubWords);
+    if (P < 1) P = 1;
+    *now_out = now;
+    *P_out = P;
+}
+
+// Host only: the pass plan of a call with n draws from stream position pos -- the largest substream count of any pass and the number
+// of substreams the jump tables can start (tests drive this at n around 2^28, where a pass is full).
+extern "C" int flashe_mt19937_plan(uint32_t pos, uint64_t n, uint32_t *max_substreams, uint32_t *substreams_available, uint32_t *passes)
+{
+    if (pos > 624u || !max_substreams || !substreams_available || !passes) return FLASHE_EINVAL;
+    uint64_t p = pos;
+    uint32_t mx = 0, cnt = 0;
+    while (n) {
+        uint64_t now;
+        uint32_t P;
+        mt_plan_pass(p, n, false, &now, &P);
+        mx = P > mx ? P : mx;
+        const uint64_t end = p + 2 * now, tfin = (end - 1) / kMtN;
+        p = end - tfin * kMtN;
+        n -= now;
+        cnt++;
+    }
+    *max_substreams = mx; *substreams_available = 1u << kJumpLevels; *passes = cnt;
+    return FLASHE_OK;
+}
+
 extern "C" int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uint32_t *pos, uint64_t n, double *u_dev)
 {
     CHECK_CTX(ctx);
@@ -352,15 +388,16 @@ extern "C" int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uin
     constexpr bool serial_only = false;
 #endif
     // scratch: [0, 625) the state in (key + pos), [640, 1264) the state out, then the windows
-    const uint64_t cap = (kSubWords << kJumpLevels) / 2;             // doubles one pass can cut into substreams
     uint32_t host[625];
     memcpy(host, key, 624 * sizeof(uint32_t));
     host[624] = *pos;
     while (n) {
-        const uint64_t now = n < cap ? n : cap;
-        const uint64_t pos0 = host[624], end = pos0 + 2 * now;
-        uint32_t P = serial_only ? 1u : static_cast<uint32_t>((end - 1 + kSubWords - 1) / kSubWords);
-        if (P < 1) P = 1;
+        uint64_t now;
+        uint32_t P;
+        const uint64_t pos0 = host[624];
+        mt_plan_pass(pos0, n, serial_only, &now, &P);
+        const uint64_t end = pos0 + 2 * now;
+        if (P > (1u << kJumpLevels)) return fail(ctx, FLASHE_EIO, "MT19937: a pass of %u substreams exceeds the %d-level jump table", P, kJumpLevels);
         JumpTables *jt = nullptr;
         if (P > 1) {
             jt = &jump_tables();

@@ -435,6 +435,9 @@ int flashe_mean_std_dev(flashe_ctx *ctx, uint64_t n, const void *x_dev, int x_is
 int flashe_mt19937_random_dev(flashe_ctx *ctx, uint32_t key[624], uint32_t *pos, uint64_t n, double *u_dev);
 /* Host only: builds the twelve jump polynomials x^(2^17 2^j) mod phi and checks the first against the generator itself. */
 int flashe_mt19937_jump_selfcheck(void);
+/* Host only: the pass plan of flashe_mt19937_random_dev for n draws from stream position pos -- the largest number of substreams any
+ * pass is cut into, the number the jump tables can start (a pass must never exceed it), and the number of passes. */
+int flashe_mt19937_plan(uint32_t pos, uint64_t n, uint32_t *max_substreams, uint32_t *substreams_available, uint32_t *passes);
 
 /* _static_quantize_padding_asymmetric -- federatedml/secureprotol/jzf_quantize.py:55-67:
  * q = floor(clip(x, -alpha, alpha) + alpha) * (2^element_bits - 1) / (2 alpha) + u), with numpy's

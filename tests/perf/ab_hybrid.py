@@ -33,7 +33,7 @@ print("%%.4f" %% best)
 
 for rnd in range(2):
     for backend, pm in ((1, 0), (3, 50), (3, 100), (3, 150), (3, 200)):
-        env = dict(os.environ, FLASHE_HYBRID_BS_PERMILLE=str(pm))
+        env = dict(os.environ, FLASHE_LIB_NAME=os.environ.get("FLASHE_LIB_NAME", "libflashe_hip_bitslice.so"), FLASHE_HYBRID_BS_PERMILLE=str(pm))
         out = subprocess.run([sys.executable, "-c", CODE, str(backend)], env=env, capture_output=True, text=True)
         res = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "ERR " + out.stderr[-300:]
         print(f"round {rnd} backend={'table' if backend == 1 else 'hybrid'} bitsliced share {pm / 10:.0f} %: {res} ms", flush=True)

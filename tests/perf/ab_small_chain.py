@@ -39,7 +39,7 @@ print(" | ".join(out))
 VAR = sys.argv[1] if len(sys.argv) > 1 else "FLASHE_CHAIN"        # or FLASHE_SMALL_DIRECT
 for rnd in range(2):
     for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("1", "0")):
-        env = dict(os.environ, OMP_WAIT_POLICY="passive")
+        env = dict(os.environ, OMP_WAIT_POLICY="passive", FLASHE_LIB_NAME=os.environ.get("FLASHE_LIB_NAME", "libflashe_hip_tuning.so"))
         env[VAR] = v
         r = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)
         print(f"round {rnd} {VAR}={v}: " + (r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "ERR " + r.stderr[-400:]), flush=True)

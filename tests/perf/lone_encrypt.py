@@ -36,5 +36,5 @@ print(" | ".join(out))
 ''' % ROOT
 for rep in range(2):
     for v in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, FLASHE_SMALL_LATENCY=v, OMP_WAIT_POLICY="passive"), capture_output=True, text=True)
+        r = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, FLASHE_LIB_NAME=os.environ.get("FLASHE_LIB_NAME", "libflashe_hip_tuning.so"), FLASHE_SMALL_LATENCY=v, OMP_WAIT_POLICY="passive"), capture_output=True, text=True)
         print(f"FLASHE_SMALL_LATENCY={v}: " + (r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "ERR " + r.stderr[-500:]), flush=True)

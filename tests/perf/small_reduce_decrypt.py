@@ -32,7 +32,7 @@ for b in [int(v) for v in sys.argv[1:]] or [20, 64]:
     for C in (10, 4, 16):
         row = []
         for name, env in (("two launches", {"FLASHE_SMALL_FUSED_REDUCE": "0"}), ("fused", {}), ("fused, no AES rounds (probe)", {"FLASHE_SMALL_REDUCE_PROBE": "1"})):
-            r = subprocess.run([sys.executable, "-c", CODE, str(b), str(C)], env=dict(os.environ, **env), capture_output=True, text=True)
+            r = subprocess.run([sys.executable, "-c", CODE, str(b), str(C)], env=dict(os.environ, FLASHE_LIB_NAME=os.environ.get("FLASHE_LIB_NAME", "libflashe_hip_tuning.so"), **env), capture_output=True, text=True)
             row.append(f"{name} {r.stdout.strip() or r.stderr[-300:]} ms")
         gb = (C + 1) * 10_000_000 * 8 / 1e9
         print(f"b={b} C={C} ({gb:.2f} GB): " + " | ".join(row), flush=True)

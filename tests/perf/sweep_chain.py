@@ -6,6 +6,7 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("FLASHE_LIB_NAME", "libflashe_hip_tuning.so")      # the knobs below exist only in the -DFLASHE_TUNING build
 os.environ["FLASHE_CHAIN_TUNE"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine  # noqa: E402

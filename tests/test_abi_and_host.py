@@ -82,6 +82,21 @@ def test_product_package_never_touches_the_oracle():
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
 
 
+def test_product_library_carries_no_probes_or_tuning_knobs():
+    """libflashe_hip.so must not be steerable into skipping work: the timing probes (early exits, launches without their AES rounds) and
+    the tuning knobs live only in the -DFLASHE_TUNING build (libflashe_hip_tuning.so, loaded by tests/perf/* through FLASHE_LIB_NAME).
+    The product binary does not even contain their names."""
+    from flashe_amd import _lib
+    blob = open(os.path.join(os.path.dirname(_lib.LIB_PATH), "libflashe_hip.so"), "rb").read()
+    for name in (b"PROBE", b"FLASHE_CHAIN_TUNE", b"FLASHE_CHAIN_HALF", b"FLASHE_CHAIN_PARTS", b"FLASHE_CHAIN_GRID", b"FLASHE_SMALL_REDUCE_CB",
+                 b"FLASHE_SMALL_REDUCE_SPLIT", b"FLASHE_HYBRID_BS_PERMILLE", b"FLASHE_BS16_WAVES", b"FLASHE_SMALL_DIRECT", b"FLASHE_SMALL_LATENCY",
+                 b"FLASHE_SMALL_FUSED_REDUCE", b"FLASHE_MT_PARALLEL"):
+        assert name not in blob, name
+    tuning = os.path.join(os.path.dirname(_lib.LIB_PATH), "libflashe_hip_tuning.so")
+    if os.path.exists(tuning):
+        assert b"FLASHE_CHAIN_PROBE" in open(tuning, "rb").read()
+
+
 def test_header_compiles_as_c_and_cxx(tmp_path):
     """include/flashe.h is a plain-C interface: it must compile stand-alone as C11 and as C++17."""
     import subprocess
@@ -214,3 +229,19 @@ def test_mt19937_jump_polynomials_self_check():
     t0 = time.time()
     assert _lib.load().flashe_mt19937_jump_selfcheck() == 0
     assert time.time() - t0 < 20
+
+
+def test_mt19937_pass_plan_never_exceeds_the_jump_table():
+    """a full pass of flashe_mt19937_random_dev from a stream position >= 2 needed 2^12 + 1 substreams and read one
+    level past the 12-level jump table (n >= 2^28 - 311).  The pass cap now leaves room for the words in front of the first draw; this
+    drives the host-side plan at the sizes where a pass is full, for every kind of starting position."""
+    import ctypes
+    from flashe_amd import _lib
+    lib = _lib.load()
+    for n in (1, 65_536, (1 << 28) - 312, (1 << 28) - 311, (1 << 28) - 1, 1 << 28, (1 << 28) + 1, (1 << 29) + 5, 3 * (1 << 28) + 77):
+        for pos in (0, 1, 2, 3, 311, 623, 624):
+            mx, avail, passes = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+            assert lib.flashe_mt19937_plan(pos, n, ctypes.byref(mx), ctypes.byref(avail), ctypes.byref(passes)) == 0
+            assert avail.value == 4096 and 1 <= mx.value <= avail.value, (n, pos, mx.value)
+            assert passes.value == -(-n // (((1 << 29) - 624) // 2))
+    assert lib.flashe_mt19937_plan(625, 1, ctypes.byref(mx), ctypes.byref(avail), ctypes.byref(passes)) == -22

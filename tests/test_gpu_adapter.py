@@ -461,3 +461,24 @@ def test_client_step_of_a_large_model_vs_oracle(oracle, b, scheme, n_jobs):
         want = v * (2 * alpha) / (((1 << eb) - 1) * C) - alpha                      # jzf_quantize.py:102-107
         assert back._weights[k].shape == sh and np.asarray(back._weights[k]).tobytes() == want.reshape(sh).tobytes(), (b, k)
         at += size
+
+
+def test_numpy_random_on_the_device_full_pass_from_an_odd_position():
+    """2^28 - 100 draws from stream position 5 -- a FULL pass of the jump tree, whose substream count used to exceed
+    the jump table by one.  Same doubles as NumPy (compared as 64-bit patterns), same generator state, and the stream continues."""
+    from flashe_amd.engine import Engine
+    eng = Engine(KEY, 64, device=0)
+    n = (1 << 28) - 100
+    np.random.seed(77)
+    st = np.random.get_state()
+    np.random.set_state((st[0], st[1], 5, st[3], st[4]))
+    st0 = np.random.get_state()
+    want = np.random.random(n)
+    st_want = np.random.get_state()
+    follow_want = np.random.random(3)
+    np.random.set_state(st0)
+    got = eng.numpy_random_dev(n).download(np.float64, n)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    st_got = np.random.get_state()
+    assert st_got[2] == st_want[2] and np.array_equal(st_got[1], st_want[1])
+    assert np.random.random(3).tobytes() == follow_want.tobytes()

@@ -1,6 +1,8 @@
 """GPU parity tests of the chained PRF launch (prf_chain_kernel): consecutive clients share their PRF streams
 (client c's minus stream is client c + 1's add stream, jzf_flashe.py:349-353), so a batch of C encrypts costs
 C + 1 AES streams.  Every ciphertext is compared bit for bit with the oracle, which computes each client on its own."""
+import os
+
 import numpy as np
 import pytest
 
@@ -236,3 +238,59 @@ def test_compact_u32_layout_equals_the_one_limb_layout(E, oracle, b, n, J, C, sc
     wide = E.Engine(KEY, 40, device=0)
     with pytest.raises(E.FlasheError):
         wide.encrypt_batch_u32_dev(9, idx, E.SCHEME_DOUBLE, n, J, d32, c32)
+
+
+_PROBE_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from flashe_amd.engine import Engine
+from oracle import flashe_oracle as orc
+orc.build()
+KEY = bytes(range(32))
+# b = 128: ten chained encrypts of a vector long enough for whole tiles, and the reduce fused with the decrypt
+n, C, it = 300_000, 4, 3
+eng = Engine(KEY, 128, device=0)
+rng = np.random.Generator(np.random.PCG64(5))
+pts = [rng.integers(0, 2 ** 64, n, dtype=np.uint64) for _ in range(C)]
+dp = [eng.upload(p) for p in pts]
+dc = [eng.alloc_vec(n) for _ in range(C)]
+eng.encrypt_batch_dev(it, list(range(C)), 1, n, 16, dp, 1, dc)
+cts = [d.download(np.uint64, 2 * n).reshape(n, 2) for d in dc]
+for c in range(C):
+    assert np.array_equal(cts[c], orc.encrypt(KEY, it, c, "double", 16, 128, pts[c])), ("encrypt", c)
+out = eng.alloc_vec(n)
+eng.aggregate_decrypt_range_dev(it, [C], [0], n, 16, 0, n, dc, None, out)
+want = orc.decrypt(KEY, it, [C], [0], 16, 128, orc.aggregate_elem(cts, 128))
+assert np.array_equal(out.download(np.uint64, 2 * n).reshape(n, 2), want), "reduce + decrypt"
+# b = 20: the small-modulus reduce fused with the decrypt (the launch FLASHE_SMALL_REDUCE_PROBE used to strip of its AES rounds)
+e20 = Engine(KEY, 20, device=0)
+p20 = [rng.integers(0, 2 ** 16, n, dtype=np.uint64) for _ in range(C)]
+d20 = [e20.upload(p) for p in p20]
+c20 = [e20.alloc_vec(n) for _ in range(C)]
+e20.encrypt_batch_dev(it, list(range(C)), 1, n, 7, d20, 1, c20)
+h20 = [d.download(np.uint64, n).reshape(n, 1) for d in c20]
+for c in range(C):
+    assert np.array_equal(h20[c], orc.encrypt(KEY, it, c, "double", 7, 20, p20[c])), ("encrypt b=20", c)
+o20 = e20.alloc_vec(n)
+e20.aggregate_decrypt_range_dev(it, [C], [0], n, 7, 0, n, c20, None, o20)
+w20 = orc.decrypt(KEY, it, [C], [0], 7, 20, orc.aggregate_elem(h20, 20))
+assert np.array_equal(o20.download(np.uint64, n).reshape(n, 1), w20), "reduce + decrypt b=20"
+assert np.array_equal(w20[:, 0], sum(p20) & np.uint64((1 << 20) - 1))
+print("PROBES-IGNORED-OK")
+"""
+
+
+def test_probe_variables_cannot_make_the_product_library_skip_work():
+    """FLASHE_CHAIN_TUNE + FLASHE_CHAIN_PROBE made the encrypt launch return after its table fill (rc 0, no ciphertext
+    written) and FLASHE_SMALL_REDUCE_PROBE made the b <= 64 reduce + decrypt skip its AES rounds.  Those branches are compiled out of
+    libflashe_hip.so: a process started with every probe / tuning variable set gets oracle-equal ciphertexts and results."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FLASHE_CHAIN_TUNE="1", FLASHE_CHAIN_PROBE="1", FLASHE_CHAIN_HALF="1", FLASHE_CHAIN_PARTS="3", FLASHE_CHAIN_GRID="7",
+               FLASHE_SMALL_REDUCE_PROBE="1", FLASHE_SMALL_REDUCE_CB="8", FLASHE_SMALL_REDUCE_SPLIT="0", FLASHE_HYBRID_BS_PERMILLE="500",
+               FLASHE_BS16_WAVES="2", FLASHE_SMALL_DIRECT="0", FLASHE_SMALL_LATENCY="0", FLASHE_SMALL_FUSED_REDUCE="0", FLASHE_MT_PARALLEL="0")
+    env.pop("FLASHE_LIB_NAME", None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _PROBE_CHILD, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PROBES-IGNORED-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
