@@ -78,7 +78,8 @@ def parse():
                     help="N > 1: seconds the optional overlapped schedules (calibration + their timed region) may take; when it passes, or "
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
     ap.add_argument("--no-partial-agg", action="store_true",
-                    help="N > 1: keep the separate local reduce in the sequential round instead of letting the encrypt launch write the partial aggregate")
+                    help="keep the separate local reduce in the sequential round instead of letting the encrypt launch write the partial aggregate "
+                         "(the default for int_bits > 64 and whenever ranks exchange)")
     ap.add_argument("--collective", choices=["all_to_all", "allreduce"], default="all_to_all",
                     help="how the GPUs' partial aggregates meet in the sequential round: all_to_all = reduce-scatter from point-to-point transfers "
                          "+ local mod-add + all-gather (any --bits); allreduce = ncclAllReduce(uint64, sum) + mask (--bits <= 64 only)")
@@ -469,8 +470,10 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
     ph_ev = [[eng.event() for _ in range(3)] for _ in range(K)]
     # With an exchange the sequential round sends each rank's partial aggregate: the encrypt launch writes it ("each
     # GPU encrypts and locally mod-adds its share"), which removes the separate local reduce (16 (C + 1) B per element of HBM traffic) from
-    # the path the first multi-GPU run is guaranteed to report.  One GPU: only on request (the default line stays the two-launch round).
-    partial = args.schedule == "partial-agg" or (world > 1 and args.schedule in ("default", "auto") and not args.no_partial_agg)
+    # the path the first multi-GPU run is guaranteed to report.  One GPU (round 4): the same form is the default for int_bits > 64 -- it is
+    # the fastest bit-exact round (the second launch decrypts ONE vector instead of re-reading C) and `value` reports the fastest; the
+    # classic two-launch round is measured beside it (`value_two_launch`).  int_bits <= 64 has no one-launch form of the sum.
+    partial = args.schedule == "partial-agg" or (args.schedule in ("default", "auto") and not args.no_partial_agg and (world > 1 or b > 64))
 
     def run_schedule(schedule, it, k=None):
         """One round.  k = index of the timed step (events recorded) or None (warmup / parity run)."""
@@ -559,8 +562,8 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
             vec = (C - 1) if (schedule == "pipelined" and C > 1) else C
             alg_bytes = vec * n * (pt_bytes + 8 * L) + (n * 8 * L if (partial and schedule == "sequential") else 0)
             blocks = (vec + 1 if chained else 2 * vec) * (n if L == 2 else -(-n // (128 // b)))
-            kernel_key = "prf_chain_kernel" if L == 2 else "prf_small_chain_kernel"
-            kernel_name = (f"prf_chain_kernel<1024> (fused AES-256 PRF + 128-bit add/sub = encrypt: {vec} consecutive clients per launch share "
+            kernel_key = ("prf_chain_kernel_sum" if (partial and schedule == "sequential") else "prf_chain_kernel") if L == 2 else "prf_small_chain_kernel"
+            kernel_name = (f"prf_chain_kernel<1024{', SUM' if (partial and schedule == 'sequential') else ''}> (fused AES-256 PRF + 128-bit add/sub = encrypt: {vec} consecutive clients per launch share "
                            f"{vec + 1} PRF streams, ct_c = pt_c + S_c - S_(c+1)"
                            + (", plus the local partial aggregate sum_c ct_c written by the same launch)" if partial and schedule == "sequential" else ")")) if L == 2 else \
                 (f"prf_small_chain_kernel (b <= 64: one AES block = {128 // b} elements, a lane owns its block(s) for all {vec + 1} streams of the "
@@ -590,15 +593,17 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
                        "schedule_calibration_ms": calibration, "cus_left_free_for_the_exchange": cus_free,
                        "schedule_fallback_reason": None,
                        "schedule_note": None if calibration or args.schedule != "default" else
-                       "config 2 on one GPU runs the two-launch round by default (the form profiles/ documents kernel by kernel); --schedule auto "
-                       "also tries the fused and pipelined rounds (fused: 0-6 % faster, depending on the box)",
+                       ("config 2 on one GPU: the encrypt launch also writes the local partial aggregate (SURVEY.md section 5), the second launch "
+                        "decrypts that one vector -- the fastest bit-exact round measured (value_two_launch = the classic encrypt, then reduce fused "
+                        "with decrypt); --schedule auto also tries the fused and pipelined rounds" if partial else
+                        "two-launch round (int_bits <= 64 has no one-launch form of the partial aggregate, or --no-partial-agg)"),
                        "collectives": (getattr(ops.comm, "LABEL", None) or "RCCL through libflashe_hip.so (no PyTorch)") if ops.comm else None,
                        "exchange": (("ncclAllReduce(uint64, sum) + mask" if args.collective == "allreduce" else
                                      "grouped ncclSend / ncclRecv all-to-all + local mod-add + ncclAllGather") if ops.comm else None),
                        "rccl_world": rccl_world, "ranks_counted_by_allreduce": ranks_counted, "ranks_parity_ok": bool(parity_all_ranks),
                        "parity": "bit-exact (on every rank, checked in-run before timing: decrypted aggregate == plaintext sum, and the first and "
                                  "last local client's ciphertext == the oracle's encrypt)"},
-            "roofline": {"kernel": kernel_name, "bound": "lds" if L == 2 or 128 // b <= 4 else "hbm",
+            "roofline": {"kernel": kernel_name, "kernel_key": kernel_key, "bound": "lds" if L == 2 or 128 // b <= 4 else "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "frac_hbm": achieved / HBM_PEAK_GBPS, "frac_lds": frac_lds,
                          "traffic": ratio * alg_bytes if ratio else None,
@@ -722,17 +727,24 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
         hp = [host_pts[c] for c in mine]
         if cfg == 2 and not args.no_unchained and args.schedule in ("default", "sequential"):
             line.update(unchained_round(args, n, b, J, mine, total, pts, K))
-            # the partial-agg form of the same round (--schedule partial-agg makes it the timed one), beside `value`: parity first
-            res = rnd.run(0, pts, 1, partial_agg=True)
+            # the OTHER form of the same round beside `value` (parity first; measured outside the timed region)
+            other = not partial
+            res = rnd.run(0, pts, 1, partial_agg=other)
             if not parity_ok(res):
-                raise SystemExit("PARITY FAILURE: partial-agg round")
+                raise SystemExit("PARITY FAILURE: " + ("partial-agg" if other else "two-launch") + " round")
             for it in range(12):
-                rnd.run(it, pts, 1, partial_agg=True)
-            s_pa = timed_region(ops, K, lambda k: rnd.run(k, pts, 1, partial_agg=True))
-            line.update({"ms_per_step_partial_agg": s_pa * 1e3 / K, "value_partial_agg": total * n / (s_pa / K),
-                         "partial_agg_note": "the same round with the encrypt launch also writing the local partial aggregate (sum of its C "
-                                             "ciphertexts, SURVEY.md section 5), so that the second launch decrypts one vector instead of "
-                                             "re-reading C: --schedule partial-agg times it as `value`; measured here outside the timed region"})
+                rnd.run(it, pts, 1, partial_agg=other)
+            s_o = timed_region(ops, K, lambda k: rnd.run(k, pts, 1, partial_agg=other))
+            if other:
+                line.update({"ms_per_step_partial_agg": s_o * 1e3 / K, "value_partial_agg": total * n / (s_o / K),
+                             "partial_agg_note": "the same round with the encrypt launch also writing the local partial aggregate (sum of its C "
+                                                 "ciphertexts, SURVEY.md section 5), so that the second launch decrypts one vector instead of "
+                                                 "re-reading C; measured here outside the timed region"})
+            else:
+                line.update({"ms_per_step_two_launch": s_o * 1e3 / K, "value_two_launch": total * n / (s_o / K),
+                             "two_launch_note": "the classic round -- every local encrypt in one chained launch, then the C-way reduce fused with "
+                                                "the decrypt of its result (re-reads the C ciphertexts) -- measured here outside the timed region; "
+                                                "`value` is the partial-aggregate form (--no-partial-agg makes this one the timed round)"})
         if not args.no_e2e:
             line["e2e_ms_incl_pcie"], line["e2e_first_round_ms"] = e2e_round_ms(eng, hp, n, b, J)
             line["e2e_note"] = ("one round through the host-pointer twins (flashe_encrypt x C, flashe_aggregate_elem, flashe_decrypt): pageable "

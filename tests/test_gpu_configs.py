@@ -187,7 +187,8 @@ def test_config5_sparse_top1pct_50_clients(E, oracle):
 
 @pytest.mark.parametrize("args,keys", [
     (["--config", "1"], ["cpu_baseline"]),
-    (["--config", "2", "--n", "2300017", "--no-python-baseline"], ["value_partial_agg", "value_unchained", "e2e_ms_device_handles", "cpu_baseline", "round_hbm_frac"]),
+    (["--config", "2", "--n", "2300017", "--no-python-baseline"], ["value_two_launch", "value_unchained", "e2e_ms_device_handles", "cpu_baseline", "round_hbm_frac"]),
+    (["--config", "2", "--n", "2300017", "--no-partial-agg", "--no-cpu-baseline", "--no-e2e"], ["value_partial_agg"]),
     (["--config", "2", "--n", "2300017", "--schedule", "partial-agg", "--no-cpu-baseline", "--no-e2e"], []),
     (["--config", "2", "--n", "500000", "--schedule", "auto", "--no-cpu-baseline", "--no-e2e"], []),
     (["--config", "3", "--clients", "7", "--no-cpu-baseline"], []),
@@ -222,6 +223,10 @@ def test_bench_lines_on_one_gpu(args, keys):
     assert "bit-exact" in d["config"]["parity"]
     for k in keys:
         assert k in d, k
+    if args[:4] == ["--config", "2", "--n", "2300017"] and "--schedule" not in args:
+        # the default round at int_bits > 64 is the fastest bit-exact one: the encrypt launch writes the partial aggregate
+        assert d["config"]["schedule_name"] == ("sequential" if "--no-partial-agg" in args else "partial-agg")
+        assert rl["kernel_key"] == ("prf_chain_kernel" if "--no-partial-agg" in args else "prf_chain_kernel_sum")
     if "--schedule" in args:
         want = args[args.index("--schedule") + 1]
         assert d["config"]["schedule_name"] == want or want == "auto"

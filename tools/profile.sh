@@ -3,7 +3,7 @@
 # separate PMC passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md's HBM section prescribes.
 # Raw output -> gpurun_out/prof/<tag>/ ; summarise with tools/summarize_profile.py.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 STEPS=${2:-20}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof/$TAG

@@ -75,7 +75,7 @@ def main(tag):
             for line in open(os.path.join(src, log)):
                 if line.startswith('{"metric'):
                     rl = json.loads(line)["roofline"]
-                    alg, dom_name = rl["algorithmic_bytes_per_launch"], rl["kernel"].split("<")[0].split(" ")[0]
+                    alg, dom_name = rl["algorithmic_bytes_per_launch"], rl.get("kernel_key") or rl["kernel"].split("<")[0].split(" ")[0]
         except OSError:
             pass
         if alg:
@@ -89,6 +89,8 @@ def main(tag):
         if "FETCH_SIZE" not in e or "WRITE_SIZE" not in e:
             continue
         short = k.replace("void ", "").replace("flashe::", "").split("<")[0].split("(")[0]
+        if short == "prf_chain_kernel" and "prf_chain_kernel<1024, true" in k:
+            short = "prf_chain_kernel_sum"          # the instantiation that also writes the local partial aggregate
         ent = {"full_name": k, "hbm_bytes_per_launch": e["hbm_bytes_per_launch_avg"], "fetch_kib_avg": e["FETCH_SIZE"]["avg"],
                "write_kib_avg": e["WRITE_SIZE"]["avg"], "launches": e["FETCH_SIZE"]["launches"]}
         if dom_name and short == dom_name and alg:
@@ -99,6 +101,19 @@ def main(tag):
         prev = traffic["kernels"].get(short)
         if prev is None or ent["launches"] > prev["launches"]:
             traffic["kernels"][short] = ent
+    # a ratio measured by an earlier round's passes stays available for the kernels this run did not time as its dominant one
+    # (bench.py --no-partial-agg times the plain chained launch): carried over with its origin
+    try:
+        prev_t = json.load(open(os.path.join(dst, "traffic.json")))
+        for key, ent in prev_t.get("kernels", {}).items():
+            if "hbm_bytes_per_algorithmic_byte" in ent and "hbm_bytes_per_algorithmic_byte" not in traffic["kernels"].get(key, {}):
+                keep = dict(ent)
+                keep.setdefault("measured_in", prev_t.get("source"))
+                if key in traffic["kernels"]:
+                    keep["this_run_other_shape"] = traffic["kernels"][key]
+                traffic["kernels"][key] = keep
+    except (OSError, ValueError):
+        pass
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     # The --stats average of the dominant kernel covers every launch of the process -- parity run, settle rounds, warmup (the first
     # ones after the host-side parity check run on a cold clock) and the K timed ones.  bench.py's roofline.avg_launch_ms covers the K
@@ -112,7 +127,13 @@ def main(tag):
                     steps, bench_ms = j["steps"], j["roofline"]["avg_launch_ms"]
         except OSError:
             pass
-        d_all = [v for k, vs in dur.items() if dom_name in k for v in vs]
+        def is_dom(k):
+            if dom_name == "prf_chain_kernel_sum":
+                return "prf_chain_kernel<1024, true" in k
+            if dom_name == "prf_chain_kernel":
+                return "prf_chain_kernel<1024, false" in k
+            return dom_name in k
+        d_all = [v for k, vs in dur.items() if is_dom(k) for v in vs]
         if steps and len(d_all) >= steps:
             json.dump({"kernel": dom_name, "launches_in_trace": len(d_all), "avg_us_all_launches": sum(d_all) / len(d_all) / 1e3,
                        "timed_launches": steps, "avg_us_last_timed_launches": sum(d_all[-steps:]) / steps / 1e3,
@@ -124,4 +145,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r03")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r04")
