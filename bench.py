@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--calibration-deadline", type=float, default=float(os.environ.get("FLASHE_BENCH_CALIBRATION_DEADLINE_S", "150")),
                     help="N > 1: seconds the optional overlapped schedules (calibration + their timed region) may take; when it passes, or "
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
+    ap.add_argument("--no-element-sharded", action="store_true",
+                    help="N > 1: skip the second partition (elements instead of clients sharded over the GPUs, SURVEY.md 8e (i)) that is timed "
+                         "after the main line and reported beside it as value_element_sharded")
     ap.add_argument("--no-partial-agg", action="store_true",
                     help="keep the separate local reduce in the sequential round instead of letting the encrypt launch write the partial aggregate "
                          "(the default for int_bits > 64 and whenever ranks exchange)")
@@ -717,6 +720,20 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
         elif rank == 0 and line is not None:
             line["config"]["schedule_calibration_ms"] = calibration
         configure(seq)
+    # ---- phase C: the OTHER partition of the same job -- elements instead of clients sharded over the GPUs ------------
+    # `value` stays north_star's client sharding; this is reported beside it.  Optional and under its own deadline: whatever happens
+    # here, the line above is what rank 0 prints.
+    if (world > 1 or args.force_dist) and not args.no_element_sharded:                # (the same decision on every rank)
+        if rank == 0:
+            state["fallback"] = line
+        wd.arm(args.calibration_deadline, "element-sharded round")
+        try:
+            extra = element_sharded_round(args, n, b, J, ops, rank, world, total, K, W, (lo, hi), orc)
+        except Exception as e:                                  # (a raise on one rank leaves the others to the watchdog: the line survives)
+            extra = {"element_sharded_error": f"{type(e).__name__}: {e}"}
+            wd.abort(f"element-sharded round raised on rank {rank}: {e}")
+        if rank == 0 and line is not None:
+            line.update(extra)
     wd.arm(args.deadline, "closing")
     if rank != 0:
         return None
@@ -762,6 +779,50 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
                 if pyb:
                     line["cpu_baseline_python"] = pyb
     return line
+
+
+def element_sharded_round(args, n, b, J, ops, rank, world, total, K, W, want, orc):
+    """The same job with ELEMENTS sharded over the ranks (flashe_amd.dist.ShardedRound(shard="elements")): every rank
+    runs the full chain of `total` clients (total + 1 PRF streams per element -- the stream sharing that client sharding loses when
+    clients are spread thin) on its own slice of the vectors, reduces and decrypts that slice; no exchange for the aggregate, one
+    all-gather of the decrypted slices (timed with and without it).  Parity gate as for the main line (result == plaintext sum, first
+    and last client's ciphertext slice == the oracle's), then settle + W warmup + EXACTLY K timed rounds, MAX over ranks."""
+    import numpy as np
+    from flashe_amd.dist import ShardedRound
+    L = 2 if b > 64 else 1
+    rnd = ShardedRound(ops, n, b, total, J, rank=rank, world=world, force_collectives=args.force_dist, shard="elements")
+    first, count = rnd.element_range()
+    pts = []
+    for c in range(total):
+        p = plaintext(c, n, b)
+        pts.append((ops.upload(p[first:first + count]) if count else ops.alloc(2), 0))
+        if c in (0, total - 1) and count:
+            wct = orc.encrypt(KEY, 0, c, "double", J, b, p)[first:first + count]
+            if c == 0:
+                want_first = wct
+            want_last = wct
+    res = rnd.run(0, pts, 1, partial_agg=True)
+    got = ops.read((res, 0), n * L).reshape(n, L)
+    lo, hi = want
+    good = np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi))
+    if count:
+        good = good and np.array_equal(ops.read(rnd.ct[0], count * L).reshape(count, L), want_first)
+        good = good and np.array_equal(ops.read(rnd.ct[total - 1], count * L).reshape(count, L), want_last)
+    if not ops.allreduce(1.0 if good else 0.0, 1) > 0.5:
+        return {"element_sharded_error": "parity gate failed"}
+    out = {}
+    for key, gather in (("", True), ("_no_gather", False)):
+        for it in range(min(args.settle_rounds, 16) + W):
+            rnd.run_elements(it, pts, 1, partial_agg=True, gather=gather)
+        s_el = timed_region(ops, K, lambda k: rnd.run_elements(k, pts, 1, partial_agg=True, gather=gather))
+        out["ms_per_step_element_sharded" + key] = s_el * 1e3 / K
+        out["value_element_sharded" + key] = total * n / (s_el / K)
+    out["element_sharded_note"] = (f"the same {total}-client job with ELEMENTS sharded over the {world} GPUs (SURVEY.md 8e (i)): every GPU runs the whole "
+                                   f"client chain ({total + 1} PRF streams) on {rnd.slice} elements of every vector, reduces and decrypts its slice; no "
+                                   "exchange for the aggregate, one all-gather of the decrypted slices (`_no_gather`: every GPU keeps its slice); "
+                                   "parity-gated like `value` (result == plaintext sum, ciphertext slices == the oracle's); `value` stays north_star's "
+                                   "client sharding")
+    return out
 
 
 def unchained_round(args, n, b, J, mine, total, pts, K):

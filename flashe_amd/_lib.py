@@ -91,6 +91,8 @@ _SIGNATURES = {
     "flashe_encrypt_batch_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp)]),
     "flashe_encrypt_batch_sum_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp),
                                              c_vp]),
+    "flashe_encrypt_batch_range_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_u64, c_u64, c_int, c_u32p, ctypes.POINTER(c_vp), c_int,
+                                               ctypes.POINTER(c_vp), c_vp]),
     "flashe_decrypt_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
     "flashe_decrypt": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
     "flashe_mask_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_vp]),
@@ -114,6 +116,7 @@ _SIGNATURES = {
     "flashe_packed_probe_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_packed_add_carry_dev": (c_int, [c_vp, c_u64, c_u64, c_u64, c_vp]),
     "flashe_packed_resolve_carry_dev": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_vp]),
+    "flashe_packed_resolve_carry_strided_dev": (c_int, [c_vp, c_u64, c_u64, c_vp, c_int, c_int, c_vp]),
     "flashe_pack_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_pack": (c_int, [c_vp, c_u64, c_vp, c_vp]),
     "flashe_unpack_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),

@@ -875,7 +875,7 @@ int flashe_encrypt_batch_sum_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uin
                 int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev[v], pt_dev[v], pt_limbs);
                 if (rc) return rc;
             }
-            const hipError_t e = launch_prf_batch_sum(ctx->env, iter, n_vec, idx, pt_dev, pt_limbs, ct_dev, sum_out_dev, n, n_jobs);
+            const hipError_t e = launch_prf_batch_sum(ctx->env, iter, n_vec, idx, pt_dev, pt_limbs, ct_dev, sum_out_dev, n, n_jobs, 0, n);
             if (e == hipSuccess) return FLASHE_OK;
             if (e != hipErrorNotSupported) HIP_TRY(ctx, e);
         }
@@ -1176,6 +1176,45 @@ int flashe_encrypt_range_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int s
     return FLASHE_OK;
 }
 
+// Every client's encrypt on ONE element slice of the vectors, optionally with the slice of their sum: the launch of a GPU that owns
+// elements [first, first + count) of every client vector (element sharding); pointers address element `first`.
+int flashe_encrypt_batch_range_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
+                                   int n_vec, const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev,
+                                   uint64_t *sum_out_dev)
+{
+    CHECK_CTX(ctx);
+    if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    if (n_vec < 0 || (n_vec && (!idx || !pt_dev || !ct_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
+    int rc = check_range(ctx, n, first, count);
+    if (rc) return rc;
+    if (n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "n_jobs must be >= 1");
+    if (ctx->env.prf_backend != PRF_AUTO && ctx->env.prf_backend != PRF_TABLE) return fail(ctx, FLASHE_EINVAL, "encrypt_batch_range runs on the table PRF only");
+    for (int v = 0; v < n_vec; v++) {
+        if (count && (!pt_dev[v] || !ct_dev[v])) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
+        if (ct_dev[v] == sum_out_dev && sum_out_dev) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the ciphertext vectors");
+        rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev[v], pt_dev[v], pt_limbs);
+        if (rc) return rc;
+    }
+    if (sum_out_dev && ((ctx->limbs == 2 && !aligned16(sum_out_dev)) || (reinterpret_cast<uintptr_t>(sum_out_dev) & 7u)))
+        return fail(ctx, FLASHE_EINVAL, "sum_out_dev must be aligned like a ciphertext vector");
+    if (count == 0) return FLASHE_OK;
+    if (n_vec == 0) { if (sum_out_dev) HIP_TRY(ctx, hipMemsetAsync(sum_out_dev, 0, vec_bytes(ctx, count), ctx->env.stream)); return FLASHE_OK; }
+    if (sum_out_dev && scheme == FLASHE_SCHEME_DOUBLE) {
+        const hipError_t e = launch_prf_batch_sum(ctx->env, iter, n_vec, idx, pt_dev, pt_limbs, ct_dev, sum_out_dev, n, n_jobs, first, count);
+        if (e == hipSuccess) return FLASHE_OK;
+        if (e != hipErrorNotSupported) HIP_TRY(ctx, e);
+    }
+    const int cap = (ctx->limbs == 2 || ctx->env.use_chain) ? kMaxUniformBatch : kMaxBatch;
+    const int per_launch = (n_vec + (n_vec + cap - 1) / cap - 1) / ((n_vec + cap - 1) / cap);
+    for (int v0 = 0; v0 < n_vec; v0 += per_launch) {
+        const int nv = std::min(per_launch, n_vec - v0);
+        HIP_TRY(ctx, launch_prf_batch_range(ctx->env, iter, scheme == FLASHE_SCHEME_DOUBLE, nv, idx + v0, pt_dev + v0, pt_limbs, ct_dev + v0, n, n_jobs,
+                                            first, count));
+    }
+    if (sum_out_dev) return flashe_aggregate_elem_dev(ctx, n_vec, ct_dev, count, sum_out_dev);
+    return FLASHE_OK;
+}
+
 int flashe_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx,
                              int n_minus, uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
                              const uint64_t *in_dev, uint64_t *out_dev)
@@ -1360,6 +1399,17 @@ int flashe_packed_resolve_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t 
     if (n_limbs != (total_bits + 63) / 64) return fail(ctx, FLASHE_EINVAL, "n_limbs must equal ceil(total_bits / 64)");
     if ((n_limbs && !x_dev) || n_below < 0 || (n_below && !infos_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
     HIP_TRY(ctx, launch_packed_resolve_carry(ctx->env, n_limbs, total_bits, infos_dev, n_below, x_dev));
+    return FLASHE_OK;
+}
+
+int flashe_packed_resolve_carry_strided_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t total_bits, const uint64_t *infos_dev, int n_below,
+                                            int stride_words, uint64_t *x_dev)
+{
+    CHECK_CTX(ctx);
+    if (n_limbs != (total_bits + 63) / 64) return fail(ctx, FLASHE_EINVAL, "n_limbs must equal ceil(total_bits / 64)");
+    if ((n_limbs && !x_dev) || n_below < 0 || (n_below && !infos_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (stride_words == 0 || stride_words % 3) return fail(ctx, FLASHE_EINVAL, "stride_words must be a non-zero multiple of 3");
+    HIP_TRY(ctx, launch_packed_resolve_carry(ctx->env, n_limbs, total_bits, infos_dev, n_below, x_dev, stride_words));
     return FLASHE_OK;
 }
 

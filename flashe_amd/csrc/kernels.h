@@ -77,7 +77,12 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
 // hipErrorNotSupported -- nothing launched -- unless the batch is one run of consecutive cipher indices of the double mask with
 // int_bits > 64, at most kMaxUniformBatch vectors, long enough to fill the chip: the caller then encrypts and reduces separately.
 hipError_t launch_prf_batch_sum(const LaunchEnv &env, uint32_t iter, int n_vec, const uint32_t *idx, const uint64_t *const *in_dev,
-                                int in_limbs, uint64_t *const *out_dev, uint64_t *sum_out_dev, uint64_t n, uint32_t n_jobs);
+                                int in_limbs, uint64_t *const *out_dev, uint64_t *sum_out_dev, uint64_t n, uint32_t n_jobs, uint64_t first,
+                                uint64_t count);
+// launch_prf_batch on elements [first, first + count) of the n-element vectors (pointers address element `first`): what a GPU that owns
+// an element slice of every client's vector runs
+hipError_t launch_prf_batch_range(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx, const uint64_t *const *in_dev,
+                                  int in_limbs, uint64_t *const *out_dev, uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count);
 
 // General form of the batched launch: out[k] = in[k] + term(iter, add_idx, first + k)
 // - [dbl] term(iter, minus_idx, first + k) for k < count; in_dev may be null (zeros); pointers address element `first`.
@@ -152,8 +157,10 @@ hipError_t launch_aggregate_packed(const LaunchEnv &env, int C, const uint64_t *
 hipError_t launch_packed_probe(const LaunchEnv &env, uint64_t n_limbs, const uint64_t *x_dev, uint64_t *info_dev);
 hipError_t launch_packed_add_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, uint64_t cin, uint64_t *x_dev);
 // the same with the carry-in derived on the device from the probe triples of the n_below slices underneath (infos_dev: 3 words each)
+// (stride_words: from one slice's triple to the next more significant one's; negative = the gathered triples run from the most
+// significant slice down and infos_dev points at the lowest slice's)
 hipError_t launch_packed_resolve_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, const uint64_t *infos_dev, int n_below,
-                                       uint64_t *x_dev);
+                                       uint64_t *x_dev, int stride_words = 3);
 
 hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);
 hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev);

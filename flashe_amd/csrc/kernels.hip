@@ -2024,7 +2024,13 @@ hipError_t launch_prf(const LaunchEnv &env, uint32_t iter, const uint32_t *add, 
 hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx,
                             const uint64_t *const *in_dev, int in_limbs, uint64_t *const *out_dev, uint64_t n, uint32_t n_jobs)
 {
-    if (n == 0 || n_vec == 0) return hipSuccess;
+    return launch_prf_batch_range(env, iter, dbl, n_vec, idx, in_dev, in_limbs, out_dev, n, n_jobs, 0, n);
+}
+
+hipError_t launch_prf_batch_range(const LaunchEnv &env, uint32_t iter, bool dbl, int n_vec, const uint32_t *idx, const uint64_t *const *in_dev,
+                                  int in_limbs, uint64_t *const *out_dev, uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count)
+{
+    if (count == 0 || n_vec == 0) return hipSuccess;
     if (n_vec > ((env.b > 64 || env.use_chain) ? kMaxUniform : kMaxBatch)) return hipErrorInvalidValue;
     if (env.use_chain) {
         // runs of consecutive clients share their streams (double mask); single mask: one stream per vector
@@ -2037,14 +2043,14 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
             starts.push_back(static_cast<int>(sidx.size()));
             for (int k = v; k < w; k++) sidx.push_back(idx[k]);
             if (dbl) sidx.push_back(idx[w - 1] + 1u);
-            chains.push_back(PrfChain{nullptr, w - v, !dbl, 0, n, in_dev + v, in_limbs, out_dev + v});
+            chains.push_back(PrfChain{nullptr, w - v, !dbl, first, count, in_dev + v, in_limbs, out_dev + v});
             v = w;
         }
         for (size_t c = 0; c < chains.size(); c++) chains[c].idx = sidx.data() + starts[c];
         const hipError_t e = launch_prf_chains(env, iter, static_cast<int>(chains.size()), chains.data(), n, n_jobs);
         if (e != hipErrorNotSupported) return e;
     }
-    if (env.b > 64 && n_vec > kMaxBatch) {
+    if (env.b > 64 && n_vec > kMaxBatch && first == 0 && count == n) {
         // many equal vectors: compact table, one launch
         if (n_vec > kMaxUniform) return hipErrorInvalidValue;
         UniformJobTable tb{};
@@ -2071,26 +2077,27 @@ hipError_t launch_prf_batch(const LaunchEnv &env, uint32_t iter, bool dbl, int n
     }
     std::vector<PrfJob> jobs(n_vec);
     for (int v = 0; v < n_vec; v++)
-        jobs[v] = PrfJob{idx[v], idx[v] + 1u, 0, n, in_dev[v], in_limbs, out_dev[v]};
+        jobs[v] = PrfJob{idx[v], idx[v] + 1u, first, count, in_dev[v], in_limbs, out_dev[v]};
     LaunchEnv e2 = env;
     e2.use_chain = 0;                        // the chained form was tried above
     return launch_prf_jobs(e2, iter, dbl, n_vec, jobs.data(), n, n_jobs);
 }
 
 hipError_t launch_prf_batch_sum(const LaunchEnv &env, uint32_t iter, int n_vec, const uint32_t *idx, const uint64_t *const *in_dev,
-                                int in_limbs, uint64_t *const *out_dev, uint64_t *sum_out_dev, uint64_t n, uint32_t n_jobs)
+                                int in_limbs, uint64_t *const *out_dev, uint64_t *sum_out_dev, uint64_t n, uint32_t n_jobs, uint64_t first,
+                                uint64_t count)
 {
-    if (n == 0 || n_vec == 0) return hipSuccess;
+    if (count == 0 || n_vec == 0) return hipSuccess;
     if (!env.use_chain || env.b <= 64 || env.codec || n_vec > kMaxLinks || !sum_out_dev) return hipErrorNotSupported;
     if (env.prf_backend != PRF_AUTO && env.prf_backend != PRF_TABLE) return hipErrorNotSupported;
     for (int v = 1; v < n_vec; v++) if (idx[v] != idx[v - 1] + 1u) return hipErrorNotSupported;     // one run of consecutive clients
     // an uncut chain of a short vector leaves most waves idle (launch_prf_chains cuts such chains for parallelism, a summed chain
     // cannot be cut): below two whole tiles per wave the separate reduce is the better plan
     const uint64_t waves = static_cast<uint64_t>(env.num_cus) * (kPrfThreads / 64);
-    if ((n + 255) / 256 < 2 * waves) return hipErrorNotSupported;
+    if ((count + 255) / 256 < 2 * waves) return hipErrorNotSupported;
     std::vector<uint32_t> sidx(idx, idx + n_vec);
     sidx.push_back(idx[n_vec - 1] + 1u);
-    PrfChain ch{sidx.data(), n_vec, false, 0, n, in_dev, in_limbs, out_dev};
+    PrfChain ch{sidx.data(), n_vec, false, first, count, in_dev, in_limbs, out_dev};
     ch.sum_out_dev = sum_out_dev;
     return launch_prf_chains(env, iter, 1, &ch, n, n_jobs);
 }
@@ -2925,15 +2932,19 @@ constexpr int kRippleThreads = 1024;
 // infos != null: the carry-in is derived on the device from the (low limb, body-all-ones, carry-out) triples of the limb
 // slices below this one (ranks 0 .. n_below - 1 of a packed reduce cut across GPUs): a slice passes its carry-in on when all its
 // body limbs are ones and the low limb overflows, on top of its own carry-out.
+// stride: words from one slice's triple to the next more significant one's (3 = slice 0 first; -3 = the lowest slice's triple is the
+// LAST of the gathered ones and infos points at it: slices numbered from the most significant end, as element slices of a packed
+// vector are -- element 0 is the most significant, jzf_weights.py:59-62).
 __global__ __launch_bounds__(kRippleThreads) void packed_add_carry_kernel(uint64_t n_limbs, uint64_t top_mask, uint64_t cin, uint64_t *x,
-                                                                          const uint64_t *__restrict__ infos, int n_below)
+                                                                          const uint64_t *__restrict__ infos, int n_below, int stride)
 {
     __shared__ int first_stop;
     const int tid = threadIdx.x;
     if (infos) {
         uint64_t carry = 0;
         for (int g = 0; g < n_below; g++) {
-            const uint64_t low = infos[3 * g], ones = infos[3 * g + 1], cout = infos[3 * g + 2];
+            const uint64_t *t = infos + static_cast<int64_t>(g) * stride;
+            const uint64_t low = t[0], ones = t[1], cout = t[2];
             carry = cout + ((ones && low + carry < low) ? 1ull : 0ull);
         }
         cin = carry;
@@ -2975,17 +2986,18 @@ hipError_t launch_packed_add_carry(const LaunchEnv &env, uint64_t n_limbs, uint6
     const unsigned top = static_cast<unsigned>(total_bits % 64);
     const uint64_t top_mask = top ? ((1ull << top) - 1) : ~0ull;
     hipLaunchKernelGGL(packed_add_carry_kernel, dim3(1), dim3(kRippleThreads), 0, env.stream, n_limbs, top_mask, cin, x_dev,
-                       static_cast<const uint64_t *>(nullptr), 0);
+                       static_cast<const uint64_t *>(nullptr), 0, 3);
     return hipGetLastError();
 }
 
 hipError_t launch_packed_resolve_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, const uint64_t *infos_dev, int n_below,
-                                       uint64_t *x_dev)
+                                       uint64_t *x_dev, int stride_words)
 {
     if (n_limbs == 0) return hipSuccess;
     const unsigned top = static_cast<unsigned>(total_bits % 64);
     const uint64_t top_mask = top ? ((1ull << top) - 1) : ~0ull;
-    hipLaunchKernelGGL(packed_add_carry_kernel, dim3(1), dim3(kRippleThreads), 0, env.stream, n_limbs, top_mask, 0ull, x_dev, infos_dev, n_below);
+    hipLaunchKernelGGL(packed_add_carry_kernel, dim3(1), dim3(kRippleThreads), 0, env.stream, n_limbs, top_mask, 0ull, x_dev, infos_dev, n_below,
+                       stride_words);
     return hipGetLastError();
 }
 

@@ -415,6 +415,22 @@ class HipOps:
         """pt / ct address element `first`."""
         self.engine.encrypt_range_dev(it, idx, scheme, n, n_jobs, first, count, self._a(pt), pt_limbs, self._a(ct))
 
+    def encrypt_batch_range(self, it, idx_list, scheme, n, n_jobs, first, count, pts, pt_limbs, cts, sum_out=None):
+        """Every listed client's encrypt on elements [first, first + count) (refs address element `first`), optionally with the slice
+        of their sum from the same launch: what a rank that owns an element slice of every client vector runs."""
+        self.engine.encrypt_batch_range_dev(it, idx_list, scheme, n, n_jobs, first, count, [self._a(r) for r in pts], pt_limbs,
+                                            [self._a(r) for r in cts], self._a(sum_out))
+
+    class _View:
+        """`words`-offset window into a device buffer (keeps the buffer alive): lets a schedule hand out a result that does not start
+        at the beginning of its allocation as a plain buffer."""
+
+        def __init__(self, buf, off_words):
+            self.parent, self.ptr = buf, buf.ptr + 8 * int(off_words)
+
+    def view(self, buf, off_words):
+        return HipOps._View(buf, off_words) if off_words else buf
+
     def decrypt_range(self, it, add_idx, minus_idx, n, n_jobs, first, count, inp, out, side=False):
         self._eng(side).decrypt_range_dev(it, add_idx, minus_idx, n, n_jobs, first, count, self._a(inp), self._a(out))
 
@@ -443,8 +459,12 @@ class HipOps:
     def packed_probe(self, x, n_limbs, info):
         self.engine.packed_probe_dev(n_limbs, self._a(x), self._a(info))
 
-    def packed_resolve_carry(self, x, n_limbs, total_bits, infos, n_below):
-        self.engine.packed_resolve_carry_dev(n_limbs, total_bits, self._a(infos), n_below, self._a(x))
+    def packed_resolve_carry(self, x, n_limbs, total_bits, infos, n_below, stride_words=3):
+        """stride_words = -3: `infos` points at the LOWEST slice's triple and the more significant ones lie in front of it."""
+        if stride_words == 3:
+            self.engine.packed_resolve_carry_dev(n_limbs, total_bits, self._a(infos), n_below, self._a(x))
+        else:
+            self.engine.packed_resolve_carry_strided_dev(n_limbs, total_bits, self._a(infos), n_below, stride_words, self._a(x))
 
     def zero(self, ref, words):
         self.engine._check(self.engine._lib.flashe_memset_dev(self.engine._h, self._a(ref), 0, int(words) * 8))
@@ -493,8 +513,18 @@ class ShardedRound:
     per-rank counts may differ (deal_clients).  An int means "this many per rank, rank r hosts r*k .. r*k + k - 1"."""
 
     def __init__(self, ops, n, int_bits, clients, n_jobs, rank=0, world=1, total_clients=None, scheme=SCHEME_DOUBLE,
-                 force_collectives=False, collective="all_to_all"):
-        if isinstance(clients, int):
+                 force_collectives=False, collective="all_to_all", shard="clients"):
+        if shard not in ("clients", "elements"):
+            raise ValueError(f"unknown shard {shard!r}")
+        self.shard = shard
+        if shard == "elements":
+            # SURVEY.md 8e (i): rank g owns a contiguous element slice of EVERY client's vector and plays every client on it.  Mask
+            # streams are position-indexed, so the element-wise aggregate needs no exchange at all (an optional all-gather hands the
+            # decrypted slices to every rank) and the packed aggregate one carry triple per slice boundary.  `clients` = how many
+            # clients upload (or their numbers 0 .. C - 1); every rank passes the same.
+            total_clients = clients if isinstance(clients, int) else len(clients)
+            clients = list(range(total_clients))
+        elif isinstance(clients, int):
             clients, total_clients = list(range(rank * clients, (rank + 1) * clients)), world * clients
         self.ops, self.n, self.b, self.n_jobs = ops, n, int_bits, n_jobs
         self.clients, self.cpr = list(clients), len(clients)
@@ -515,11 +545,12 @@ class ShardedRound:
         self.slice = slice_len(n, world)
         self.padded = self.slice * world
         # the local ciphertexts are equally spaced in ONE allocation: the fused reduce + decrypt walks them by stride
-        self.ct_stride = stride = (n * L + 1) // 2 * 2                   # every vector 16-byte aligned
+        held = self.slice if shard == "elements" else n                  # elements of a client vector this rank holds
+        self.ct_stride = stride = (held * L + 1) // 2 * 2                # every vector 16-byte aligned
         self.ct_all = ops.alloc(max(self.cpr, 1) * stride)
         self.ct = [(self.ct_all, c * stride) for c in range(self.cpr)]
-        self.partial = ops.alloc(self.padded * L)                        # local aggregate, padded to world slices
-        self.recv = ops.alloc(self.padded * L) if self.exchange else None
+        self.partial = ops.alloc((self.slice if shard == "elements" else self.padded) * L)   # local aggregate (client sharding: padded to world slices)
+        self.recv = ops.alloc(self.padded * L) if (self.exchange and shard == "clients") else None
         self.agg_slice = ops.alloc(self.slice * L)
         self.dec_slice = ops.alloc(self.slice * L)
         self.result = ops.alloc(self.padded * L)                         # plaintext aggregate on every rank
@@ -587,8 +618,100 @@ class ShardedRound:
         """pts: refs of this rank's plaintext vectors (one per local client).  Returns the buffer holding the decrypted
         aggregate (first n*L words valid).  Two PRF launches per round on one GPU: every local encrypt, then reduce + decrypt
         (partial_agg: every local encrypt + their sum, then the decrypt of that sum)."""
+        if self.shard == "elements":
+            return self.run_elements(it, pts, pt_limbs, partial_agg=partial_agg)
         self.encrypt_phase(it, pts, pt_limbs, partial_agg)
         return self.reduce_decrypt_phase(it, partial_agg)
+
+    # ---- element sharding (SURVEY.md 8e (i)) ---------------------------------------------------------------------------
+    def element_range(self, packed=False):
+        """(first, count): the elements of every client vector this rank owns under shard="elements".  Element-wise aggregate:
+        slices of `slice_len(n, world)` elements counted from the FRONT.  Packed aggregate: counted from the END -- rank g owns
+        [max(0, n - (W - g) S), max(0, n - (W - 1 - g) S)) -- so that every slice boundary is a whole number of 64-bit limbs above bit 0
+        of the packed integer (element n - 1 sits at bit 0, element 0 is the most significant, jzf_weights.py:59-62): S is a multiple
+        of 256 elements, hence S * b a multiple of 64 bits whatever b is."""
+        if not packed:
+            return self.first, self.count
+        n, W, S, g = self.n, self.world, self.slice, self.rank
+        lo, hi = max(0, n - (W - g) * S), max(0, n - (W - 1 - g) * S)
+        return lo, hi - lo
+
+    def run_elements(self, it, pts, pt_limbs, partial_agg=True, gather=True):
+        """The round with ELEMENTS sharded over the ranks: every rank runs the full client chain (C + 1 PRF streams, whatever the
+        number of GPUs -- client sharding loses the stream sharing when clients are spread thin) on its own slice of the vectors,
+        reduces and decrypts that slice, and nothing is exchanged for it: the one collective is the optional all-gather of the
+        decrypted slices (gather=False leaves every rank with its slice in the returned buffer).  pts: refs of this rank's SLICE of
+        every client's plaintext (element `element_range()[0]` at the ref), clients in order 0 .. C - 1.  partial_agg (default): the
+        encrypt launch also writes the slice of the ciphertexts' sum, the second launch decrypts it."""
+        assert self.shard == "elements", 'run_elements needs ShardedRound(shard="elements")'
+        ops, n, L = self.ops, self.n, self.L
+        first, count = self.first, self.count
+        add_idx, minus_idx = self._prefixes()
+        if count:
+            ops.encrypt_batch_range(it, self.clients, self.scheme, n, self.n_jobs, first, count, pts, pt_limbs, self.ct,
+                                    sum_out=(self.partial, 0) if partial_agg else None)
+            if partial_agg:
+                ops.decrypt_range(it, add_idx, minus_idx, n, self.n_jobs, first, count, (self.partial, 0), (self.dec_slice, 0))
+            else:
+                ops.aggregate_decrypt(it, add_idx, minus_idx, n, self.n_jobs, first, count, self.ct, (self.partial, 0), (self.dec_slice, 0))
+        if not (gather and self.exchange):
+            return self.dec_slice
+        ops.all_gather((self.dec_slice, 0), (self.result, 0), self.slice * L)
+        return self.result
+
+    def _elements_packed_buffers(self):
+        if getattr(self, "ek_nl", None) is not None:
+            return
+        ops, W, S, L = self.ops, self.world, self.slice, self.L
+        lo, cnt = self.element_range(packed=True)
+        self.ek_lo, self.ek_cnt = lo, cnt
+        self.ek_top = lo == 0                                     # the most significant non-empty slice: its carry-out is dropped
+        self.ek_nl = nl = (cnt * self.b + 63) // 64
+        even = (nl + 2 + 1) // 2 * 2
+        self.ek_packed = [ops.alloc(even) for _ in range(self.cpr)]     # every packed slice with two zero limbs on top
+        self.ek_sum = ops.alloc(even)
+        self.ek_info = ops.alloc(4)
+        self.ek_infos = ops.alloc(3 * W + 1)
+        self.ek_agg = ops.alloc(max(cnt, 1) * L)
+        self.ek_piece = ops.alloc(S * L)                          # the decrypted slice, right-aligned in an S-element piece
+        self.ek_all = ops.alloc(W * S * L) if self.exchange else None
+
+    def run_elements_packed(self, it, pts, pt_limbs, gather=True):
+        """The element-sharded round with the arbiter's PACKED reduce (jzf_aggregator.py:406-419: every model one n*b-bit integer,
+        carries cross element boundaries).  Each rank packs and adds its slice of the C ciphertexts one limb wider than the slice
+        (the extra limb is the slice's carry-out); the ONLY exchange for the reduce is an all-gather of one (low limb, all-ones flag,
+        carry-out) triple per rank, from which every rank resolves its carry-in on the device -- the slices less significant than
+        rank g's are those of ranks g + 1 .. W - 1 (element 0 is the most significant), hence the backward walk over the gathered
+        triples.  pts: refs of this rank's slice `element_range(packed=True)` of every client's plaintext.  Returns a buffer whose
+        first n*L words are the decrypted aggregate (gather=True), or this rank's slice right-aligned in an S-element piece."""
+        assert self.shard == "elements", 'run_elements_packed needs ShardedRound(shard="elements")'
+        ops, n, L, W, S, b = self.ops, self.n, self.L, self.world, self.slice, self.b
+        self._elements_packed_buffers()
+        lo, cnt, nl, top = self.ek_lo, self.ek_cnt, self.ek_nl, self.ek_top
+        add_idx, minus_idx = self._prefixes()
+        ops.zero((self.ek_info, 0), 3)
+        if cnt:
+            ops.encrypt_batch_range(it, self.clients, self.scheme, n, self.n_jobs, lo, cnt, pts, pt_limbs, self.ct)
+            for c in range(self.cpr):
+                ops.pack(cnt, self.ct[c], (self.ek_packed[c], 0))
+            rows = [(p, 0) for p in self.ek_packed]
+            if top:
+                ops.aggregate_packed(rows, nl, cnt * b, (self.ek_sum, 0))
+            else:
+                ops.aggregate_packed(rows, nl + 1, 64 * (nl + 1), (self.ek_sum, 0))
+                ops.packed_probe((self.ek_sum, 0), nl + 1, (self.ek_info, 0))
+        if self.exchange:
+            ops.all_gather((self.ek_info, 0), (self.ek_infos, 0), 3)
+            below = W - 1 - self.rank
+            if cnt and below:
+                ops.packed_resolve_carry((self.ek_sum, 0), nl, cnt * b if top else 64 * nl, (self.ek_infos, 3 * (W - 1)), below, stride_words=-3)
+        if cnt:
+            ops.unpack(cnt, (self.ek_sum, 0), (self.ek_agg, 0))
+            ops.decrypt_range(it, add_idx, minus_idx, n, self.n_jobs, lo, cnt, (self.ek_agg, 0), (self.ek_piece, (S - cnt) * L))
+        if not (gather and self.exchange):
+            return ops.view(self.ek_piece, (S - cnt) * L)
+        ops.all_gather((self.ek_piece, 0), (self.ek_all, 0), S * L)
+        return ops.view(self.ek_all, (W * S - n) * L)
 
     # ---- chunk-pipelined schedules -------------------------------------------------------------------------------
     def _pipe_buffers(self, chunks):
@@ -749,6 +872,8 @@ class ShardedRound:
         derive its carry-in ON THE DEVICE, including the case where a carry ripples through a whole slice
         (flashe_packed_resolve_carry_dev); all-gather of the slices.  Every rank then unpacks and decrypts the
         aggregate, as every client of the reference does."""
+        if self.shard == "elements":
+            return self.run_elements_packed(it, pts, pt_limbs)
         ops, n, W = self.ops, self.n, self.world
         self._packed_buffers()
         nl, sl, bits = self.k_nl, self.k_sl, self.k_bits

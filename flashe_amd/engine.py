@@ -433,6 +433,15 @@ class Engine:
         self._check(self._lib.flashe_encrypt_batch_sum_dev(self._h, it, scheme, n, n_jobs, len(idx_list), pi, pp, pt_limbs, pc,
                                                            self._ptr(sum_out)))
 
+    def encrypt_batch_range_dev(self, it, idx_list, scheme, n, n_jobs, first, count, pts, pt_limbs, cts, sum_out=None):
+        """encrypt_batch_dev on elements [first, first + count) of the n-element vectors -- the launch of a GPU that owns that slice of
+        every client's vector (pointers address element `first`); sum_out (optional) receives the slice of the ciphertexts' sum."""
+        pi, _k = _u32_list(idx_list)
+        pp, _a = self._ptr_array(pts)
+        pc, _b = self._ptr_array(cts)
+        self._check(self._lib.flashe_encrypt_batch_range_dev(self._h, it, scheme, n, n_jobs, first, count, len(idx_list), pi, pp, pt_limbs, pc,
+                                                             self._ptr(sum_out)))
+
     def prf_jobs_dev(self, it, n, n_jobs, jobs):
         """jobs: iterable of (add_idx, minus_idx or None, first, count, in_ptr or None, in_limbs, out_ptr); each writes
         out[k] = in[k] + term(it, add_idx, first + k) - term(it, minus_idx, first + k) for k < count (one launch for
@@ -533,6 +542,9 @@ class Engine:
     def packed_resolve_carry_dev(self, n_limbs, total_bits, infos, n_below, x):
         """x <- (x + carry_in) mod 2^total_bits, carry_in derived on the device from the probe triples of the n_below slices below."""
         self._check(self._lib.flashe_packed_resolve_carry_dev(self._h, n_limbs, total_bits, self._ptr(infos), n_below, self._ptr(x)))
+
+    def packed_resolve_carry_strided_dev(self, n_limbs, total_bits, infos, n_below, stride_words, x):
+        self._check(self._lib.flashe_packed_resolve_carry_strided_dev(self._h, n_limbs, total_bits, self._ptr(infos), n_below, stride_words, self._ptr(x)))
 
     def pack_dev(self, n, inp, out):
         self._check(self._lib.flashe_pack_dev(self._h, n, self._ptr(inp), self._ptr(out)))

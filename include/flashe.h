@@ -173,6 +173,15 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
 int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
                              const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev);
 
+/* flashe_encrypt_batch_dev on ONE element slice [first, first + count) of the n-element vectors (new): the launch of a GPU that owns
+ * that slice of EVERY client's vector -- element sharding, SURVEY.md section 8e (i): mask streams are position-indexed, so the slices
+ * need no exchange for the element-wise aggregate.  pt_dev[v] / ct_dev[v] / sum_out_dev address element `first`; n and n_jobs still
+ * describe the whole vector (the int_bits <= 64 chunking).  sum_out_dev (may be NULL): receives the slice of sum_v ct[v] mod 2^b,
+ * from the same launch when flashe_encrypt_batch_sum_dev's conditions hold for the slice, from a reduce launch otherwise. */
+int flashe_encrypt_batch_range_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, uint64_t first,
+                                   uint64_t count, int n_vec, const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs,
+                                   uint64_t *const *ct_dev, uint64_t *sum_out_dev);
+
 /* flashe_encrypt_batch_dev that ALSO writes the local partial aggregate sum_out[j] = sum_v ct[v][j] mod 2^b (new): what the
  * arbiter's reduce (jzf_aggregator.py:424-430) yields for the clients this GPU hosts -- SURVEY.md section 5: "each GPU encrypts and
  * locally mod-adds its share".  int_bits > 64, double mask, one run of consecutive cipher indices, a vector long enough to fill the
@@ -311,7 +320,12 @@ int flashe_packed_add_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t tota
 /* add_carry with the carry-in derived ON THE DEVICE from the probe triples of the n_below slices underneath (infos_dev =
  * the all-gathered 3-word infos, slice 0 first): no host round trip between the exchange of the infos and the ripple. */
 int flashe_packed_resolve_carry_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t total_bits,
-                                    const uint64_t *infos_dev, int n_below, uint64_t *x_dev);              /* new */
+                                    const uint64_t *infos_dev, int n_below, uint64_t *x_dev);
+/* The same with the triples `stride_words` apart (a non-zero multiple of 3; infos_dev points at the LOWEST slice's triple): -3 walks
+ * gathered triples that run from the most significant slice down -- element slices of a packed vector, whose element 0 is the most
+ * significant (jzf_weights.py:59-62), gathered in rank order. */
+int flashe_packed_resolve_carry_strided_dev(flashe_ctx *ctx, uint64_t n_limbs, uint64_t total_bits, const uint64_t *infos_dev,
+                                            int n_below, int stride_words, uint64_t *x_dev);              /* new */
 
 /* ---- bit-packing codec ---------------------------------------------------------------- */
 /* pack: P = sum_j x[j] << (b * (n-1-j)) as ceil(n*b/64) little-endian limbs --

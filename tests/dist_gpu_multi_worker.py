@@ -70,6 +70,57 @@ def main():
                 assert np.array_equal(ops.read((out, 0), n * L).reshape(n, L), want_elem), (rank, b, n, dealing, "allreduce", partial)
         for c, ref in zip(mine, rnd.ct):                                   # this rank's own ciphertexts (chained launch) vs the oracle
             assert np.array_equal(ops.read(ref, n * L).reshape(n, L), cts[c]), (rank, b, c)
+    # ---- element sharding: every rank plays EVERY client on its own slice of the vectors; real kernels on ranges with
+    # non-zero `first`, the chained launch with the slice of the partial aggregate, the backward carry walk of the packed reduce
+    for b, n, C, J, scheme in [(128, 300_007, 10, 16, SCHEME_DOUBLE), (128, 70_001, 3, 16, SCHEME_DOUBLE), (20, 50_001, 4, 16, SCHEME_DOUBLE),
+                               (64, 7777, 3, 4, SCHEME_SINGLE), (128, 999, 2, 1, SCHEME_DOUBLE), (33, 2_100_003, 2, 8, SCHEME_DOUBLE)]:
+        L = 2 if b > 64 else 1
+        eng = Engine(KEY, b, device=0)
+        ops = HipOps(eng, None, comm)
+        host = [np.random.Generator(np.random.PCG64(170 + c)).integers(0, 2 ** min(b, 64), n, dtype=np.uint64) for c in range(C)]
+        name = "double" if scheme == SCHEME_DOUBLE else "single"
+        cts = [orc.encrypt(KEY, 4, c, name, J, b, host[c]) for c in range(C)]
+        if scheme == SCHEME_DOUBLE:
+            add, minus = orc.mask_sum(KEY, 4, [C], n, J, b), orc.mask_sum(KEY, 4, [0], n, J, b)
+        else:
+            add, minus = np.zeros((n, L), dtype=np.uint64), orc.mask_sum(KEY, 4, list(range(C)), n, J, b)
+        want_elem = orc.combine(b, orc.aggregate_elem(cts, b), add, minus)
+        want_packed = orc.combine(b, orc.unpack(orc.aggregate_packed([orc.pack(ct, b) for ct in cts], n * b), n, b), add, minus)
+        rnd = ShardedRound(ops, n, b, C, J, rank=rank, world=world, scheme=scheme, shard="elements")
+        first, count = rnd.element_range()
+        pts = [(ops.upload(host[c][first:first + count]) if count else ops.alloc(2), 0) for c in range(C)]
+        for partial in (True, False):
+            out = rnd.run(4, pts, 1, partial_agg=partial)
+            assert np.array_equal(ops.read((out, 0), n * L).reshape(n, L), want_elem), (rank, b, n, C, "elements", partial)
+            for c in range(C):
+                if count:
+                    assert np.array_equal(ops.read(rnd.ct[c], count * L).reshape(count, L), cts[c][first:first + count]), (rank, b, c, "elements ct")
+        lo, cnt = rnd.element_range(packed=True)
+        ptsp = [(ops.upload(host[c][lo:lo + cnt]) if cnt else ops.alloc(2), 0) for c in range(C)]
+        out = rnd.run_packed(4, ptsp, 1)
+        assert np.array_equal(ops.read((out, 0), n * L).reshape(n, L), want_packed), (rank, b, n, C, "elements packed")
+    # carries rippling through whole element slices of the packed integer
+    for b, n in [(128, 256 * world + 5), (64, 300 * world), (20, 256 * world + 17)]:
+        L = 2 if b > 64 else 1
+        ones = np.full((n, L), np.uint64(2 ** 64 - 1) if b >= 64 else np.uint64(2 ** b - 1), dtype=np.uint64)
+        one = np.zeros((n, L), dtype=np.uint64)
+        one[n - 1, 0] = 1
+        pats = [ones, one]
+        eng = Engine(KEY, b, device=0)
+        ops = HipOps(eng, None, comm)
+        rnd = ShardedRound(ops, n, b, 2, 1, rank=rank, world=world, shard="elements")
+        lo, cnt = rnd.element_range(packed=True)
+        if cnt:
+            for c in range(2):
+                sl = np.ascontiguousarray(pats[c][lo:lo + cnt])
+                eng._check(eng._lib.flashe_memcpy_h2d(eng._h, ops._a(rnd.ct[c]), sl.ctypes.data, sl.nbytes))
+        ops.encrypt_batch_range = lambda *a, **k: None            # keep the planted "ciphertexts"
+        rnd.run_elements_packed(0, [(ops.alloc(2), 0)] * 2, 1)
+        want = sum(int.from_bytes(orc.pack(p, b).tobytes(), "little") for p in pats) % (1 << (n * b))
+        if cnt:
+            nl = (cnt * b + 63) // 64
+            got = int.from_bytes(ops.read((rnd.ek_sum, 0), nl).tobytes(), "little") & ((1 << (cnt * b)) - 1)
+            assert got == (want >> ((n - lo - cnt) * b)) & ((1 << (cnt * b)) - 1), (rank, b, n, "element-sharded carry ripple")
     # adversarial carries through whole limb slices, resolved by the device-side rule
     for b, n in [(128, 64), (64, 37), (20, 500)]:
         L = 2 if b > 64 else 1

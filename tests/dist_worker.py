@@ -87,6 +87,83 @@ def packed_rounds(rank, world, comm):
             assert got == want, (rank, b, n, hex(got)[:40], hex(want)[:40])
 
 
+def element_sharded_rounds(rank, world, comm):
+    """ShardedRound(shard="elements") -- SURVEY.md 8e (i): every rank plays EVERY client on its own element slice; the element-wise
+    aggregate needs no exchange (only the optional all-gather of the result), the packed one an all-gather of one carry triple per
+    rank.  Against the one-process oracle: the decrypted aggregate, every rank's ciphertext slices, and for the packed reduce the
+    carries that cross slice boundaries (crafted ciphertexts: ripples through whole slices)."""
+    for b, n, C, n_jobs, scheme in [(128, 1000, 3, 8, SCHEME_DOUBLE), (128, 77, 1, 1, SCHEME_DOUBLE), (20, 999, 4, 16, SCHEME_DOUBLE),
+                                    (64, 1300, 2, 4, SCHEME_SINGLE), (23, 700, 5, 16, SCHEME_DOUBLE), (128, 3, 2, 1, SCHEME_DOUBLE),
+                                    (7, 600, 3, 2, SCHEME_DOUBLE)]:
+        L = 2 if b > 64 else 1
+        name = "double" if scheme == SCHEME_DOUBLE else "single"
+        ops = OracleOps(b, comm)
+        rnd = ShardedRound(ops, n, b, C, n_jobs, rank=rank, world=world, scheme=scheme, shard="elements")
+        all_pts = [plain(3000 + c, n, max(1, min(b, 64) - 8)) for c in range(C)]
+        cts = [orc.encrypt(KEY, 6, c, name, n_jobs, b, all_pts[c]) for c in range(C)]
+        want = np.zeros(n, dtype=np.uint64)
+        for p in all_pts:
+            want += p
+        if b < 64:
+            want &= np.uint64((1 << b) - 1)
+        first, count = rnd.element_range()
+        assert first == min(rank * rnd.slice, n) and count == min(rnd.slice, n - first)
+        mine = [(ops.upload(all_pts[c][first:first + count]) if count else ops.alloc(2), 0) for c in range(C)]
+        for partial in (True, False):
+            out = rnd.run(6, mine, 1, partial_agg=partial)
+            res = result_of(ops, out, n, L)
+            assert np.array_equal(res[:, 0], want) and (L == 1 or not res[:, 1].any()), (rank, b, n, C, "elements", partial)
+            for c in range(C):
+                if count:
+                    assert np.array_equal(ops.read(rnd.ct[c], count * L).reshape(count, L), cts[c][first:first + count]), (rank, b, c, "ct slice")
+        own = result_of(ops, rnd.run_elements(6, mine, 1, gather=False), count, L) if count else np.zeros((0, L), dtype=np.uint64)
+        assert np.array_equal(own[:, 0], want[first:first + count])
+        # the packed reduce: carries cross element AND slice boundaries
+        lo, cnt = rnd.element_range(packed=True)
+        assert (n - lo) % 256 == 0 or lo == 0
+        assert cnt == 0 or ((n - lo - cnt) * b) % 64 == 0, "a slice must end on a limb boundary of the packed integer"
+        minep = [(ops.upload(all_pts[c][lo:lo + cnt]) if cnt else ops.alloc(2), 0) for c in range(C)]
+        outp = rnd.run_packed(6, minep, 1)
+        agg = orc.aggregate_packed([orc.pack(ct, b) for ct in cts], n * b)
+        if scheme == SCHEME_DOUBLE:
+            add, minus = orc.mask_sum(KEY, 6, [C], n, n_jobs, b), orc.mask_sum(KEY, 6, [0], n, n_jobs, b)
+        else:
+            add, minus = np.zeros((n, L), dtype=np.uint64), orc.mask_sum(KEY, 6, list(range(C)), n, n_jobs, b)
+        wantp = orc.combine(b, orc.unpack(agg, n, b), add, minus)
+        assert np.array_equal(result_of(ops, outp, n, L), wantp), (rank, b, n, C, "elements packed")
+    # carries that ripple through whole slices
+    for b, n in [(128, 64 * world * 4), (64, 300 * world), (20, 256 * world + 17), (128, 5), (8, 256 * (world - 1) + 1)]:
+        L = 2 if b > 64 else 1
+        ones = np.full((n, L), np.uint64(2 ** 64 - 1) if b >= 64 else np.uint64(2 ** b - 1), dtype=np.uint64)
+        one = np.zeros((n, L), dtype=np.uint64)
+        one[n - 1, 0] = 1
+        big = np.zeros((n, L), dtype=np.uint64)
+        big[n // 2, 0] = 3
+        for pats in ([ones, one], [ones] * 3, [ones, one, big, ones, one], [big, one]):
+            ops = CraftedRangeOps(b, pats, comm)
+            rnd = ShardedRound(ops, n, b, len(pats), 1, rank=rank, world=world, shard="elements")
+            lo, cnt = rnd.element_range(packed=True)
+            rnd.run_elements_packed(0, [(ops.alloc(max(cnt, 1)), 0)] * len(pats), 1)
+            want = sum(int.from_bytes(orc.pack(p, b).tobytes(), "little") for p in pats) % (1 << (n * b))
+            # this rank's slice of the packed sum: bits [(n - lo - cnt) b, (n - lo) b) of the whole integer
+            if cnt:
+                nl = (cnt * b + 63) // 64
+                got = int.from_bytes(ops.read((rnd.ek_sum, 0), nl).tobytes(), "little") & ((1 << (cnt * b)) - 1)
+                assert got == (want >> ((n - lo - cnt) * b)) & ((1 << (cnt * b)) - 1), (rank, b, n, len(pats), hex(got)[:40])
+
+
+class CraftedRangeOps(OracleOps):
+    """Ciphertext slices replaced by chosen bit patterns (element sharding)."""
+
+    def __init__(self, b, patterns, comm):
+        super().__init__(b, comm)
+        self.patterns = patterns
+
+    def encrypt_batch_range(self, it, idx_list, scheme, n, n_jobs, first, count, pts, pt_limbs, cts, sum_out=None):
+        for i, ct in zip(idx_list, cts):
+            self._v(ct, count)[:] = self.patterns[i][first:first + count]
+
+
 def main():
     dist.init_process_group("gloo")
     comm = GlooComm()
@@ -134,6 +211,7 @@ def main():
                 res = result_of(ops, rnd_ar.run(5, mine, 1, partial_agg=partial), n, L)
                 assert np.array_equal(res[:, 0], want), (rank, b, n, clients, "allreduce", partial)
     packed_rounds(rank, world, comm)
+    element_sharded_rounds(rank, world, comm)
     assert ops.allreduce(float(rank), 0) == world - 1 and ops.allreduce(float(rank + 1), 1) == 1.0
     dist.barrier()
     if rank == 0:

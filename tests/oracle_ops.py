@@ -111,6 +111,20 @@ class OracleOps:
         full = orc.encrypt(KEY, it, idx, self._name(scheme), n_jobs, self.b, full_pt)
         self._v(ct, count)[:] = full[first:first + count]
 
+    def encrypt_batch_range(self, it, idx_list, scheme, n, n_jobs, first, count, pts, pt_limbs, cts, sum_out=None):
+        assert first <= n and count <= n - first
+        for i, pt, ct in zip(idx_list, pts, cts):
+            self.encrypt_range(it, i, scheme, n, n_jobs, first, count, pt, pt_limbs, ct)
+        if sum_out is not None and count:
+            self._v(sum_out, count)[:] = orc.aggregate_elem([np.ascontiguousarray(self._v(ct, count)) for ct in cts], self.b)
+
+    def view(self, buf, off_words):
+        if not off_words:
+            return buf
+        v = HostBuf(2)
+        v.a = buf.a[off_words:]
+        return v
+
     def _masks(self, it, add_idx, minus_idx, n, n_jobs, first, count):
         return (orc.mask_sum(KEY, it, add_idx, n, n_jobs, self.b)[first:first + count],
                 orc.mask_sum(KEY, it, minus_idx, n, n_jobs, self.b)[first:first + count])
@@ -155,11 +169,11 @@ class OracleOps:
         a, i = self._w(x, n_limbs), self._w(info, 3)
         i[0], i[1], i[2] = a[0], int(bool((a[1:n_limbs - 1] == np.uint64(2 ** 64 - 1)).all())), a[n_limbs - 1]
 
-    def packed_resolve_carry(self, x, n_limbs, total_bits, infos, n_below):
-        inf = self._w(infos, 3 * n_below).reshape(n_below, 3)
+    def packed_resolve_carry(self, x, n_limbs, total_bits, infos, n_below, stride_words=3):
+        buf, off = infos
         carry = 0
         for g in range(n_below):
-            low, ones, cout = (int(v) for v in inf[g])
+            low, ones, cout = (int(v) for v in buf.a[off + g * stride_words:off + g * stride_words + 3])
             carry = cout + (1 if (ones and low + carry >= 1 << 64) else 0)
         a = self._w(x, n_limbs)
         v = (int.from_bytes(a.tobytes(), "little") + carry) % (1 << total_bits)

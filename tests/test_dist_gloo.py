@@ -56,6 +56,28 @@ def test_single_rank_schedules(oracle):
                     assert np.array_equal(got, ref), (b, n, mode, force)
 
 
+def test_single_rank_element_sharding(oracle):
+    """ShardedRound(shard="elements") on one rank (the slice is the whole vector), with and without the forced (identity) all-gather:
+    the same decrypted aggregate as the client-sharded round, element-wise and packed."""
+    import numpy as np
+    from flashe_amd.dist import ShardedRound
+    from oracle_ops import OracleOps
+    for b, n, C in [(128, 5000, 3), (64, 3000, 2), (20, 2500, 4), (128, 256, 1)]:
+        L = 2 if b > 64 else 1
+        pts = [np.random.Generator(np.random.PCG64(70 + c)).integers(0, 2 ** (min(b, 64) - 8), n, dtype=np.uint64) for c in range(C)]
+        cts = [oracle.encrypt(KEY, 3, c, "double", 16, b, pts[c]) for c in range(C)]
+        want = oracle.decrypt(KEY, 3, [C], [0], 16, b, oracle.aggregate_elem(cts, b))
+        wantp = oracle.decrypt(KEY, 3, [C], [0], 16, b, oracle.unpack(oracle.aggregate_packed([oracle.pack(ct, b) for ct in cts], n * b), n, b))
+        for force in (False, True):
+            ops = OracleOps(b)
+            refs = [(ops.upload(p), 0) for p in pts]
+            rnd = ShardedRound(ops, n, b, C, 16, force_collectives=force, shard="elements")
+            assert rnd.element_range() == (0, n) and rnd.element_range(packed=True) == (0, n)
+            for partial in (True, False):
+                assert np.array_equal(ops.read((rnd.run(3, refs, 1, partial_agg=partial), 0), n * L).reshape(n, L), want), (b, n, force, partial)
+            assert np.array_equal(ops.read((rnd.run_packed(3, refs, 1), 0), n * L).reshape(n, L), wantp), (b, n, force, "packed")
+
+
 def test_rendezvous_file_hands_the_id_to_every_rank(tmp_path, monkeypatch):
     """The torch-free rendezvous of flashe_amd.dist: rank 0 publishes 128 bytes atomically, the others poll for them."""
     import threading

@@ -694,6 +694,10 @@ def test_bench_multi_rank_flow(extra, tmp_path):
     assert d["config"]["schedule_fallback_reason"] is None and "TEST DOUBLE" in d["config"]["collectives"]
     if d["config"]["schedule_name"] not in ("sequential", "partial-agg"):
         assert d["sequential_ms_per_step"] > 0          # the line that would have been the fallback was measured first
+    # both partitions in the one line: `value` = clients sharded over the ranks, beside it the element-sharded round
+    # (every rank plays every client on its slice; parity-gated in-run), with and without the all-gather of the decrypted slices
+    assert "element_sharded_error" not in d, d.get("element_sharded_error")
+    assert d["value_element_sharded"] > 0 and d["value_element_sharded_no_gather"] > 0 and d["ms_per_step_element_sharded"] > 0
 
 
 def test_bench_multi_rank_allreduce_exchange(tmp_path):
