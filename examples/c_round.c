@@ -100,5 +100,70 @@ int main(void)
     for (int c = 0; c < C; c++) { CHECK(flashe_dev_free(ctx, (void *)dpt[c])); CHECK(flashe_dev_free(ctx, dct[c])); }
     CHECK(flashe_dev_free(ctx, dout));
     flashe_ctx_destroy(ctx);
-    return bad32 == 0 ? 0 : 1;
+    if (bad32) return 1;
+
+    /* BASELINE config 3's shape from plain C: a LeNet-sized gradient (61,706 parameters), 100 clients, double mask with MASK
+     * PRECOMPUTE (FlasheCipher.prepare_encrypt / prepare_decrypt, jzf_flashe.py:599-666).  The masks are computed in "idle time" and
+     * stay inside the ctx; the online encrypt and decrypt then run no AES at all and consume the cache -- the consume-once state machine
+     * of the reference (:483-486, :573-580) is the library's, not the caller's.  One ctx plays the parties in turn here; a deployment
+     * holds one ctx per party.  Second half: client 37 drops out, so the decrypt needs two prefixes the precompute does not cover
+     * (set_idx_list skips {C} / {0}, :372-386): they are computed online and merged in by the same call. */
+    enum { C3 = 100, DROPPED = 37 };
+    const uint64_t n3 = 61706;
+    const uint32_t it3 = 11;
+    if (flashe_ctx_create(&ctx, key, 128, 0, NULL) != FLASHE_OK) {
+        fprintf(stderr, "flashe_ctx_create: %s\n", flashe_last_error(NULL));
+        return 1;
+    }
+    uint64_t *sum_all = calloc(n3, sizeof *sum_all), *sum_drop = calloc(n3, sizeof *sum_drop);
+    uint64_t *pt3[C3], *ct3[C3], *agg3 = malloc(n3 * 16), *dec3 = malloc(n3 * 16);
+    const uint64_t *ops3[C3];
+    for (int c = 0; c < C3; c++) {
+        pt3[c] = malloc(n3 * sizeof **pt3);
+        ct3[c] = malloc(n3 * 16);
+        for (uint64_t j = 0; j < n3; j++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            pt3[c][j] = x >> 10;                                 /* 54-bit plaintexts: 100 of them sum below 2^64 */
+            sum_all[j] += pt3[c][j];
+            if (c != DROPPED) sum_drop[j] += pt3[c][j];
+        }
+        /* idle time of round it3 - 1: the masks of round it3 (the caller passes iter + 1) */
+        CHECK(flashe_prepare_encrypt(ctx, it3, (uint32_t)c, FLASHE_SCHEME_DOUBLE, n3, N_JOBS));
+        /* online: ct = pt + add - minus, no AES; the cache is consumed */
+        CHECK(flashe_encrypt_prepared(ctx, n3, pt3[c], 1, ct3[c]));
+        if (flashe_prepared_query(ctx, FLASHE_PREPARED_ENCRYPT, NULL, NULL, NULL) != 0) { fprintf(stderr, "cache not consumed\n"); return 1; }
+        ops3[c] = ct3[c];
+    }
+    /* a consumed cache refuses a second encrypt; and the prepared encrypt equals the online one */
+    uint64_t *again = malloc(n3 * 16);
+    if (flashe_encrypt_prepared(ctx, n3, pt3[0], 1, again) != FLASHE_EINVAL) { fprintf(stderr, "a consumed cache must refuse a second encrypt\n"); return 1; }
+    CHECK(flashe_encrypt(ctx, it3, 0, FLASHE_SCHEME_DOUBLE, n3, N_JOBS, pt3[0], 1, again));
+    uint64_t differ = 0;
+    for (uint64_t j = 0; j < 2 * n3; j++) differ += again[j] != ct3[0][j];
+    /* nobody dropped: everything the decrypt needs was precomputed */
+    CHECK(flashe_aggregate_elem(ctx, C3, ops3, n3, agg3));
+    CHECK(flashe_prepare_decrypt(ctx, it3, C3, n3, N_JOBS));
+    CHECK(flashe_decrypt_prepared(ctx, it3, NULL, 0, NULL, 0, n3, N_JOBS, agg3, dec3));
+    uint64_t bad3 = 0;
+    for (uint64_t j = 0; j < n3; j++) bad3 += dec3[2 * j] != sum_all[j] || dec3[2 * j + 1] != 0;
+    /* client DROPPED missing: uploaded = {0 .. C3-1} \ {DROPPED} telescopes to +term(DROPPED) +term(C3) -term(0) -term(DROPPED + 1);
+     * {C3} / {0} are in the cache, the other two go online */
+    int m = 0;
+    for (int c = 0; c < C3; c++) if (c != DROPPED) ops3[m++] = ct3[c];
+    CHECK(flashe_aggregate_elem(ctx, m, ops3, n3, agg3));
+    uint32_t raw3[C3], add3[C3], minus3[C3], xa[C3], xm[C3];
+    int runs3 = 0, na = 0, nm = 0;
+    m = 0;
+    for (int c = 0; c < C3; c++) if (c != DROPPED) raw3[m++] = (uint32_t)c;
+    CHECK(flashe_telescope(raw3, m, add3, minus3, &runs3));
+    for (int r = 0; r < runs3; r++) { if (add3[r] != C3) xa[na++] = add3[r]; if (minus3[r] != 0) xm[nm++] = minus3[r]; }
+    CHECK(flashe_prepare_decrypt(ctx, it3, C3, n3, N_JOBS));
+    CHECK(flashe_decrypt_prepared(ctx, it3, xa, na, xm, nm, n3, N_JOBS, agg3, dec3));
+    uint64_t bad3d = 0;
+    for (uint64_t j = 0; j < n3; j++) bad3d += dec3[2 * j] != sum_drop[j] || dec3[2 * j + 1] != 0;
+    printf("C_ROUND_PRECOMPUTE %s: n=%" PRIu64 " clients=%d mismatches=%" PRIu64 " dropout_runs=%d extra_prefixes=%d+%d dropout_mismatches=%" PRIu64
+           " prepared_vs_online_differences=%" PRIu64 "\n",
+           bad3 == 0 && bad3d == 0 && differ == 0 ? "OK" : "FAILED", n3, C3, bad3, runs3, na, nm, bad3d, differ);
+    flashe_ctx_destroy(ctx);
+    return bad3 == 0 && bad3d == 0 && differ == 0 ? 0 : 1;
 }

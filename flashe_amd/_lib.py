@@ -91,6 +91,15 @@ _SIGNATURES = {
     "flashe_encrypt_batch_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp)]),
     "flashe_encrypt_batch_sum_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp),
                                              c_vp]),
+    "flashe_dynamic_masking_cost_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64p, c_u64p]),
+    "flashe_prepare_encrypt": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32]),
+    "flashe_prepare_decrypt": (c_int, [c_vp, c_u32, c_u32, c_u64, c_u32]),
+    "flashe_prepared_query": (c_int, [c_vp, c_int, c_u64p, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
+    "flashe_prepared_discard": (c_int, [c_vp, c_int]),
+    "flashe_encrypt_prepared_dev": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
+    "flashe_encrypt_prepared": (c_int, [c_vp, c_u64, c_vp, c_int, c_vp]),
+    "flashe_decrypt_prepared_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
+    "flashe_decrypt_prepared": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),
     "flashe_encrypt_batch_range_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_u64, c_u64, c_int, c_u32p, ctypes.POINTER(c_vp), c_int,
                                                ctypes.POINTER(c_vp), c_vp]),
     "flashe_decrypt_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, c_vp]),

@@ -16,20 +16,29 @@ _RNG_RUN_MAX = 1 << 26          # draws per device call of quantize_encrypt (512
 __all__ = ["dynamic_masking_choice", "FlasheClient"]
 
 
-def dynamic_masking_choice(masks, total):
-    """Arbiter.dynamic_masking's decision (jzf_flashe_block.py:92-112): "single" unless double masking
-    would need strictly fewer PRF blocks.  single_cost = 2 * sum(len(mask)); double_cost = 2 * single_cost
-    minus 2 per position shared by consecutive clients (their masks cancel)."""
+def dynamic_masking_choice(masks, total, engine=None):
+    """Arbiter.dynamic_masking's decision (jzf_flashe_block.py:92-112): "single" unless double masking would need strictly fewer PRF
+    blocks.  single_cost = 2 * sum(len(mask)); double_cost = 2 * single_cost minus 2 per position shared by consecutive clients
+    (their masks cancel).  The reference builds a one-hot vector of `total` entries per client and ANDs neighbours; the positions two
+    clients share are the intersection of their location SETS, so nothing of size `total` is needed:
+      * masks given as `(device buffer, length)` pairs -- strictly increasing uint32 lists already in HBM (what Sparsifier emits), with
+        `engine` the Engine they live on: counted on the device (flashe_dynamic_masking_cost_dev), config-5 size in well under 1 ms;
+      * host lists / arrays: sorted-set intersection of neighbours (np.intersect1d), O(k log k)."""
+    if engine is not None and masks and all(isinstance(m, tuple) for m in masks):
+        single_cost, double_cost = engine.dynamic_masking_cost_dev([m[0] for m in masks], [m[1] for m in masks])
+        return "single" if single_cost <= double_cost else "double"
     single_cost = 2 * sum(len(m) for m in masks)
     double_cost = 2 * single_cost
-    one_hots = []
+    sets = []
     for m in masks:
-        oh = np.zeros(total, dtype=np.uint8)
-        oh[np.asarray(m, dtype=np.int64)] = 1
-        one_hots.append(oh)
+        a = np.asarray(m, dtype=np.int64).reshape(-1)
+        if a.size and (int(a.max()) >= total or int(a.min()) < -total):
+            bad = int(a.max()) if int(a.max()) >= total else int(a.min())
+            raise IndexError(f"index {bad} is out of bounds for axis 0 with size {total}")
+        sets.append(np.unique(np.where(a < 0, a + total, a)))          # (one_hot[mask] = 1: a set; negative indices wrap as in NumPy)
     canceled = 0
-    for i in range(len(masks) - 1):
-        canceled += int((one_hots[i] & one_hots[i + 1]).sum())
+    for i in range(len(sets) - 1):
+        canceled += int(np.intersect1d(sets[i], sets[i + 1], assume_unique=True).size)
     double_cost -= canceled * 2
     return "single" if single_cost <= double_cost else "double"
 

@@ -147,6 +147,21 @@ class _DevVec:
         return self.buf.download(np.uint64, self.n * eng.limbs).reshape(self.n, eng.limbs)
 
 
+class _CtxMask:
+    """A precomputed mask held INSIDE the engine's ctx (flashe_prepare_encrypt / flashe_prepare_decrypt): the entry the reference keeps
+    in next_iter_encrypt_prepared / next_iter_decrypt_prepared, as a handle.  The C ABI owns the vector and the consume-once rule; this
+    object only says that (and how long) it is there."""
+
+    def __init__(self, which, part, n):
+        self.which, self.part, self.n = which, part, n
+
+    def __len__(self):
+        return self.n
+
+    def to_host(self, eng):
+        return eng.prepared_download(self.which, self.part)
+
+
 class FlasheCipher(object):
     """Drop-in for federatedml.secureprotol.jzf_flashe.FlasheCipher (jzf_flashe.py:228-666)."""
 
@@ -345,7 +360,10 @@ class FlasheCipher(object):
                 add = self.next_iter_encrypt_prepared['add']
                 minus = self.next_iter_encrypt_prepared['minus']
                 self._check_prepared_len(add, n)
-                eng.combine_dev(n, dv.buf, dv.limbs, add.buf, minus.buf, out.buf)
+                if isinstance(add, _CtxMask):
+                    eng.encrypt_prepared_dev(n, dv.buf, dv.limbs, out.buf)          # the ctx adds its cached masks and drops them
+                else:
+                    eng.combine_dev(n, dv.buf, dv.limbs, add.buf, minus.buf, out.buf)
             ct = self._deliver(out, kind, want_dev)
         else:
             limbs, kind = _to_limbs(value, eng.limbs)
@@ -433,9 +451,13 @@ class FlasheCipher(object):
                 padd = self.next_iter_decrypt_prepared['add']
                 pminus = self.next_iter_decrypt_prepared['minus']
                 self._check_prepared_len(padd, n)
-                eng.combine_dev(n, dv.buf, eng.limbs, padd.buf, pminus.buf, out.buf)
-                if online:                                                # extras merged in (:557-564)
-                    eng.decrypt_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, out.buf, out.buf)
+                if isinstance(padd, _CtxMask):
+                    # the ctx's cached masks, the extras (dropouts) computed online and merged in (:557-564), the cache dropped
+                    eng.decrypt_prepared_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, dv.buf, out.buf)
+                else:
+                    eng.combine_dev(n, dv.buf, eng.limbs, padd.buf, pminus.buf, out.buf)
+                    if online:                                            # extras merged in (:557-564)
+                        eng.decrypt_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, out.buf, out.buf)
             res = self._deliver(out, kind, want_dev)
         else:
             limbs, kind = _to_limbs(value, eng.limbs)
@@ -461,24 +483,22 @@ class FlasheCipher(object):
         return None
 
     # ------------------------------------------------------------------ mask precompute
-    def _prepare(self, it, add_idx, minus_idx):
-        eng = self._engine
-        n = self.num_params
-        va, vm = _DevVec(eng, n), _DevVec(eng, n)
-        eng.mask_dev(it, [add_idx], n, N_JOBS, va.buf)
-        eng.mask_dev(it, [minus_idx], n, N_JOBS, vm.buf)
-        eng.sync()
-        return va, vm
-
+    # The masks live inside the engine's ctx (flashe_prepare_encrypt / flashe_prepare_decrypt): both streams in one launch, consumed by
+    # the next flashe_encrypt_prepared_dev / flashe_decrypt_prepared_dev -- the state machine of :483-486 / :573-580 is the C ABI's, the
+    # dict entries below are its handles (so callers that test `'add' in cipher.next_iter_encrypt_prepared` keep working).
     def prepare_encrypt(self):                                           # jzf_flashe.py:599-631
         (self.iter_index + 1).to_bytes(4, 'big')                          # same range check as the reference
-        va, vm = self._prepare(self.iter_index + 1, self.idx, self.idx + 1)
-        self.next_iter_encrypt_prepared = {'add': va, 'minus': vm}
+        eng, n = self._engine, self.num_params
+        eng.prepare_encrypt(self.iter_index + 1, self.idx, SCHEME_DOUBLE, n, N_JOBS)
+        eng.sync()
+        self.next_iter_encrypt_prepared = {'add': _CtxMask(eng.PREPARED_ENCRYPT, 'add', n), 'minus': _CtxMask(eng.PREPARED_ENCRYPT, 'minus', n)}
 
     def prepare_decrypt(self):                                           # jzf_flashe.py:633-666
-        va, vm = self._prepare(self.iter_index, self.num_clients, 0)
-        self.next_iter_decrypt_prepared['add'] = va
-        self.next_iter_decrypt_prepared['minus'] = vm
+        eng, n = self._engine, self.num_params
+        eng.prepare_decrypt(self.iter_index, self.num_clients, n, N_JOBS)
+        eng.sync()
+        self.next_iter_decrypt_prepared['add'] = _CtxMask(eng.PREPARED_DECRYPT, 'add', n)
+        self.next_iter_decrypt_prepared['minus'] = _CtxMask(eng.PREPARED_DECRYPT, 'minus', n)
         self.next_iter_decrypt_prepared_idx['add'] = [self.num_clients]
         self.next_iter_decrypt_prepared_idx['minus'] = [0]
 

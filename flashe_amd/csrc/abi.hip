@@ -334,7 +334,8 @@ int flashe_ctx_destroy(flashe_ctx *ctx)
     if (!ctx) return FLASHE_EINVAL;
     (void)hipSetDevice(ctx->device);
     if (ctx->env.stream) (void)hipStreamSynchronize(ctx->env.stream);
-    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds, &ctx->mt_ws, &ctx->codec_tab})
+    for (flashe_ctx::Buf *b : {&ctx->summaries, &ctx->stream_tmp, &ctx->acc_tmp[0], &ctx->acc_tmp[1], &ctx->sp_ws, &ctx->bounds, &ctx->mt_ws, &ctx->codec_tab, &ctx->prep_enc.add,
+                               &ctx->prep_enc.minus, &ctx->prep_dec.add, &ctx->prep_dec.minus})
         if (b->p) (void)hipFree(b->p);
     if (ctx->staging) { ctx->staging->destroy(); delete ctx->staging; ctx->staging = nullptr; }      // staging blocks held plaintexts and ciphertexts (wiped)
     if (ctx->te0_dev) (void)hipFree(ctx->te0_dev);
@@ -1243,6 +1244,99 @@ int flashe_combine_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, int 
     return FLASHE_OK;
 }
 
+// ---- ctx-resident mask precompute (FlasheCipher.prepare_encrypt / prepare_decrypt, jzf_flashe.py:599-666; consumption :457,
+// :483-486, :557-580) ----
+static int prepare_masks(flashe_ctx *ctx, flashe_ctx::Prepared &pr, uint32_t iter, uint32_t add_idx, bool has_minus, uint32_t minus_idx,
+                         uint64_t n, uint32_t n_jobs)
+{
+    if (n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "n_jobs must be >= 1");
+    pr.valid = false;
+    int rc = ensure(ctx, pr.add, std::max<size_t>(vec_bytes(ctx, n), 16));
+    if (rc == FLASHE_OK && has_minus) rc = ensure(ctx, pr.minus, std::max<size_t>(vec_bytes(ctx, n), 16));
+    if (rc) return rc;
+    if (n) {
+        // both streams in ONE launch: two single-mask jobs with no input (a chain without subtraction)
+        PrfJob jobs[2] = {PrfJob{add_idx, 0u, 0, n, nullptr, 0, static_cast<uint64_t *>(pr.add.p)},
+                          PrfJob{minus_idx, 0u, 0, n, nullptr, 0, static_cast<uint64_t *>(pr.minus.p)}};
+        HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, has_minus ? 2 : 1, jobs, n, n_jobs));
+    }
+    pr.n = n; pr.has_minus = has_minus; pr.iter = iter; pr.add_idx = add_idx; pr.minus_idx = minus_idx;
+    pr.valid = true;
+    return FLASHE_OK;
+}
+
+int flashe_prepare_encrypt(flashe_ctx *ctx, uint32_t iter_next, uint32_t idx, int scheme, uint64_t num_params, uint32_t n_jobs)
+{
+    CHECK_CTX(ctx);
+    if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    return prepare_masks(ctx, ctx->prep_enc, iter_next, idx, scheme == FLASHE_SCHEME_DOUBLE, idx + 1u, num_params, n_jobs);
+}
+
+int flashe_prepare_decrypt(flashe_ctx *ctx, uint32_t iter, uint32_t num_clients, uint64_t num_params, uint32_t n_jobs)
+{
+    CHECK_CTX(ctx);
+    return prepare_masks(ctx, ctx->prep_dec, iter, num_clients, true, 0u, num_params, n_jobs);
+}
+
+int flashe_prepared_query(flashe_ctx *ctx, int which, uint64_t *n, const uint64_t **add_dev, const uint64_t **minus_dev)
+{
+    if (!ctx) return FLASHE_EINVAL;
+    if (which != FLASHE_PREPARED_ENCRYPT && which != FLASHE_PREPARED_DECRYPT) return fail(ctx, FLASHE_EINVAL, "which must be FLASHE_PREPARED_ENCRYPT or _DECRYPT");
+    const flashe_ctx::Prepared &pr = which == FLASHE_PREPARED_ENCRYPT ? ctx->prep_enc : ctx->prep_dec;
+    if (n) *n = pr.valid ? pr.n : 0;
+    if (add_dev) *add_dev = pr.valid ? static_cast<const uint64_t *>(pr.add.p) : nullptr;
+    if (minus_dev) *minus_dev = (pr.valid && pr.has_minus) ? static_cast<const uint64_t *>(pr.minus.p) : nullptr;
+    return pr.valid ? 1 : 0;
+}
+
+int flashe_prepared_discard(flashe_ctx *ctx, int which)
+{
+    if (!ctx) return FLASHE_EINVAL;
+    if (which & ~(FLASHE_PREPARED_ENCRYPT | FLASHE_PREPARED_DECRYPT)) return fail(ctx, FLASHE_EINVAL, "unknown cache %d", which);
+    if (which & FLASHE_PREPARED_ENCRYPT) ctx->prep_enc.valid = false;
+    if (which & FLASHE_PREPARED_DECRYPT) ctx->prep_dec.valid = false;
+    return FLASHE_OK;
+}
+
+int flashe_encrypt_prepared_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *pt_dev, int pt_limbs, uint64_t *ct_dev)
+{
+    CHECK_CTX(ctx);
+    flashe_ctx::Prepared &pr = ctx->prep_enc;
+    if (!pr.valid) return fail(ctx, FLASHE_EINVAL, "no prepared encrypt masks: call flashe_prepare_encrypt first (they are consumed by one encrypt)");
+    // (a length mismatch leaves the cache in place, as NumPy's broadcast error does in the reference, jzf_flashe.py:480)
+    if (n != pr.n) return fail(ctx, FLASHE_EINVAL, "the prepared masks cover %llu elements, the plaintext has %llu",
+                               static_cast<unsigned long long>(pr.n), static_cast<unsigned long long>(n));
+    if (n && (!pt_dev || !ct_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_prf_args(ctx, 1, 0, 1, ct_dev, pt_dev, pt_limbs);
+    if (rc) return rc;
+    if (n) HIP_TRY(ctx, launch_combine(ctx->env, n, pt_dev, pt_limbs, static_cast<const uint64_t *>(pr.add.p),
+                                       pr.has_minus ? static_cast<const uint64_t *>(pr.minus.p) : nullptr, ct_dev));
+    pr.valid = false;                                                    // consumed (:483-486)
+    return FLASHE_OK;
+}
+
+int flashe_decrypt_prepared_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                                uint64_t n, uint32_t n_jobs, const uint64_t *in_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    flashe_ctx::Prepared &pr = ctx->prep_dec;
+    if (!pr.valid) return fail(ctx, FLASHE_EINVAL, "no prepared decrypt masks: call flashe_prepare_decrypt first (they are consumed by one decrypt)");
+    if (n != pr.n) return fail(ctx, FLASHE_EINVAL, "the prepared masks cover %llu elements, the aggregate has %llu",
+                               static_cast<unsigned long long>(pr.n), static_cast<unsigned long long>(n));
+    if (n && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    int rc = check_prf_args(ctx, n_add, n_minus, n_jobs, out_dev, in_dev, ctx->limbs);
+    if (rc) return rc;
+    if ((n_add && !add_idx) || (n_minus && !minus_idx)) return fail(ctx, FLASHE_EINVAL, "null prefix list");
+    if (n) {
+        // value + prepared add - prepared minus (:570-571), then the prefixes the precompute does not cover, merged in online (:557-564)
+        HIP_TRY(ctx, launch_combine(ctx->env, n, in_dev, ctx->limbs, static_cast<const uint64_t *>(pr.add.p),
+                                    static_cast<const uint64_t *>(pr.minus.p), out_dev));
+        if (n_add || n_minus) HIP_TRY(ctx, prf_lists(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, 0, n, out_dev, ctx->limbs, out_dev));
+    }
+    pr.valid = false;                                                    // consumed (:573-580)
+    return FLASHE_OK;
+}
+
 int flashe_combine_batch_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
                              const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev)
 {
@@ -1612,6 +1706,41 @@ int flashe_sparse_double_masks_dev(flashe_ctx *ctx, uint32_t iter, int C, const 
     return FLASHE_OK;
 }
 
+// Arbiter.dynamic_masking's decision inputs (jzf_flashe_block.py:92-112) from device-resident, strictly increasing location lists:
+// single_cost = 2 sum_c k_c; double_cost = 2 single_cost - 2 (positions shared by consecutive clients).  Synchronous.
+int flashe_dynamic_masking_cost_dev(flashe_ctx *ctx, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t *single_cost,
+                                    uint64_t *double_cost)
+{
+    CHECK_CTX(ctx);
+    if (C < 0 || !single_cost || !double_cost || (C && (!loc_dev || !k))) return fail(ctx, FLASHE_EINVAL, "dynamic_masking_cost: bad arguments");
+    if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "flashe_dynamic_masking_cost_dev is synchronous: not capturable");
+    uint64_t entries = 0;
+    for (int c = 0; c < C; c++) {
+        if (k[c] && !loc_dev[c]) return fail(ctx, FLASHE_EINVAL, "list %d is null", c);
+        if (k[c] >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "list %d is too long", c);
+        entries += k[c];
+    }
+    unsigned long long shared = 0;
+    if (C > 1 && entries) {
+        int rc = ensure(ctx, ctx->bounds, 4096);
+        if (rc) return rc;
+        unsigned long long *cnt = static_cast<unsigned long long *>(ctx->bounds.p);
+        HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof *cnt, ctx->env.stream));
+        for (int c0 = 0; c0 + 1 < C; c0 += kMaxScatter) {
+            const int nc = std::min(kMaxScatter, C - 1 - c0);                  // clients c0 .. c0 + nc - 1 each look into their successor
+            const uint32_t *loc[kMaxScatter + 1];
+            uint64_t kk[kMaxScatter + 1];
+            for (int e = 0; e <= nc; e++) { loc[e] = loc_dev[c0 + e]; kk[e] = k[c0 + e]; }
+            HIP_TRY(ctx, launch_shared_positions(ctx->env, nc, loc, kk, cnt));
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(&shared, cnt, sizeof shared, hipMemcpyDeviceToHost, ctx->env.stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
+    }
+    *single_cost = 2 * entries;
+    *double_cost = 4 * entries - 2 * static_cast<uint64_t>(shared);
+    return FLASHE_OK;
+}
+
 int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel_dev, uint64_t total,
                                  uint64_t *out_dev)
 {
@@ -1850,6 +1979,39 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uin
     int rc = flashe_encrypt_dev(ctx, iter, idx, scheme, n, n_jobs, dp.as<uint64_t>(), pt_limbs, dc.as<uint64_t>());
     if (rc) return rc;
     D2H(ct, dc.p, vec_bytes(ctx, n));
+    return FLASHE_OK;
+}
+
+// host-pointer twins of the prepared calls (synchronous: H2D + one HBM-bound kernel + D2H; the masks never leave the device)
+int flashe_encrypt_prepared(flashe_ctx *ctx, uint64_t n, const uint64_t *pt, int pt_limbs, uint64_t *ct)
+{
+    CHECK_CTX(ctx);
+    if (n && (!pt || !ct)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (pt_limbs != 1 && pt_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "pt_limbs must be 1 or %d", ctx->limbs);
+    if (n == 0) return flashe_encrypt_prepared_dev(ctx, 0, nullptr, pt_limbs, nullptr);
+    Tmp dp, dc;
+    HIP_TRY(ctx, dp.alloc(ctx, static_cast<size_t>(n) * pt_limbs * 8));
+    HIP_TRY(ctx, dc.alloc(ctx, vec_bytes(ctx, n)));
+    H2D(dp.p, pt, static_cast<size_t>(n) * pt_limbs * 8);
+    int rc = flashe_encrypt_prepared_dev(ctx, n, dp.as<uint64_t>(), pt_limbs, dc.as<uint64_t>());
+    if (rc) return rc;
+    D2H(ct, dc.p, vec_bytes(ctx, n));
+    return FLASHE_OK;
+}
+
+int flashe_decrypt_prepared(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
+                            uint64_t n, uint32_t n_jobs, const uint64_t *in, uint64_t *out)
+{
+    CHECK_CTX(ctx);
+    if (n && (!in || !out)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (n == 0) return flashe_decrypt_prepared_dev(ctx, iter, add_idx, n_add, minus_idx, n_minus, 0, n_jobs, nullptr, nullptr);
+    Tmp di, dout;
+    HIP_TRY(ctx, di.alloc(ctx, vec_bytes(ctx, n)));
+    HIP_TRY(ctx, dout.alloc(ctx, vec_bytes(ctx, n)));
+    H2D(di.p, in, vec_bytes(ctx, n));
+    int rc = flashe_decrypt_prepared_dev(ctx, iter, add_idx, n_add, minus_idx, n_minus, n, n_jobs, di.as<uint64_t>(), dout.as<uint64_t>());
+    if (rc) return rc;
+    D2H(out, dout.p, vec_bytes(ctx, n));
     return FLASHE_OK;
 }
 

@@ -28,6 +28,11 @@ struct flashe_ctx {
     Buf bounds;       // span reduce: first entry of every client in every span
     Buf mt_ws;        // flashe_mt19937_random_dev: state in / out and the substream windows
     Buf codec_tab;    // layer table of the fused quantise / unquantise over a flattened model
+    // ctx-resident mask precompute (flashe_prepare_encrypt / flashe_prepare_decrypt): the masks of the reference's next_iter_*_prepared
+    // caches (jzf_flashe.py:599-666) stay in HBM inside the ctx and are consumed by the next flashe_encrypt_prepared* /
+    // flashe_decrypt_prepared* call; the blocks are kept for the next round's masks
+    struct Prepared { Buf add, minus; uint64_t n = 0; bool valid = false, has_minus = false; uint32_t iter = 0, add_idx = 0, minus_idx = 0; };
+    Prepared prep_enc, prep_dec;
     // staging blocks of the host-pointer twins: hipMalloc / hipFree cost more than the kernels on LeNet-sized vectors and more than
     // the PCIe transfer on 160 MB ones, so blocks are kept and reused within a byte budget (the twins are synchronous: a block is
     // free again when its call returns)

@@ -186,6 +186,10 @@ hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const
 // framed by the neighbouring clients' (null / 0 where there is none).
 hipError_t launch_sparse_edge_prf(const LaunchEnv &env, uint32_t iter, int nc, uint32_t c0, const uint32_t *const *loc_with_neighbours,
                                   const uint64_t *k_with_neighbours, uint64_t *const *va_dev, uint64_t *const *vm_dev);
+// Adds to *count_dev the number of list entries of clients 0 .. nc - 1 whose position the NEXT client's (sorted) list holds too.
+// loc_with_next / k_with_next carry nc + 1 entries: the group's lists followed by the client after the group (null / 0 if none).
+hipError_t launch_shared_positions(const LaunchEnv &env, int nc, const uint32_t *const *loc_with_next, const uint64_t *k_with_next,
+                                   unsigned long long *count_dev);
 // out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
 hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uint8_t *sel_dev,
                                  const uint64_t *stream_dev, uint64_t *out_dev);

@@ -3383,6 +3383,40 @@ hipError_t launch_sparse_edge_prf(const LaunchEnv &env, uint32_t iter, int nc, u
     return hipGetLastError();
 }
 
+// ---- Arbiter.dynamic_masking's cost model on the device (jzf_flashe_block.py:92-112) -----------------------------------------------
+// canceled_out_pairs = sum over consecutive clients (c, c + 1) of the positions both hold (the reference ANDs one-hot vectors of
+// `total` entries): every list entry of client c looks its position up in client c + 1's sorted list -- the neighbour lookup of
+// sparse_edge_prf_kernel without the AES -- and the hits are counted (wave ballot, one atomic per wave).
+__global__ __launch_bounds__(kStreamThreads) void shared_positions_kernel(const EdgeTable tb, int nc, unsigned long long *count)
+{
+    const uint64_t n_items = tb.end[nc - 1];
+    unsigned long long mine = 0;
+    for (uint64_t f = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; f < n_items; f += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        int e = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (e + step < nc && tb.end[e + step - 1] <= f) e += step;
+        const uint64_t q = f - (e ? tb.end[e - 1] : 0);
+        const uint32_t p = tb.loc[e + 1][q];
+        if (tb.loc[e + 2] && sorted_contains(tb.loc[e + 2], tb.k[e + 2], p)) mine++;
+    }
+    for (int off = 32; off; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
+hipError_t launch_shared_positions(const LaunchEnv &env, int nc, const uint32_t *const *loc_with_next, const uint64_t *k_with_next,
+                                   unsigned long long *count_dev)
+{
+    if (nc < 1 || nc > kMaxScatter) return hipErrorInvalidValue;
+    EdgeTable tb{};
+    uint64_t total = 0;
+    for (int e = 0; e < nc; e++) { tb.loc[e + 1] = loc_with_next[e]; tb.k[e + 1] = k_with_next[e]; total += k_with_next[e]; tb.end[e] = total; }
+    tb.loc[nc + 1] = loc_with_next[nc]; tb.k[nc + 1] = k_with_next[nc];
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(shared_positions_kernel, dim3(stream_grid(env, total)), dim3(kStreamThreads), 0, env.stream, tb, nc, count_dev);
+    return hipGetLastError();
+}
+
 // out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
 __global__ __launch_bounds__(kStreamThreads) void sel_accumulate_kernel(uint64_t n, int L, const uint8_t *sel, const uint64_t *stream,
                                                                         uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)

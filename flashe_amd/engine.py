@@ -457,6 +457,47 @@ class Engine:
                             None if sum_out is None else self._ptr(sum_out))
         self._check(self._lib.flashe_prf_jobs_dev(self._h, it, n, n_jobs, len(jobs), arr))
 
+    # -- mask precompute resident in the ctx (FlasheCipher.prepare_encrypt / prepare_decrypt, jzf_flashe.py:599-666) ---------------
+    PREPARED_ENCRYPT, PREPARED_DECRYPT = 1, 2
+
+    def prepare_encrypt(self, it_next, idx, scheme, num_params, n_jobs):
+        self._check(self._lib.flashe_prepare_encrypt(self._h, it_next, idx, scheme, num_params, n_jobs))
+
+    def prepare_decrypt(self, it, num_clients, num_params, n_jobs):
+        self._check(self._lib.flashe_prepare_decrypt(self._h, it, num_clients, num_params, n_jobs))
+
+    def prepared_query(self, which):
+        """(held?, n, add device pointer, minus device pointer) of the ctx's encrypt / decrypt mask cache."""
+        n, a, m = c_u64(0), c_vp(), c_vp()
+        rc = self._lib.flashe_prepared_query(self._h, which, ctypes.byref(n), ctypes.byref(a), ctypes.byref(m))
+        if rc < 0:
+            self._check(rc)
+        return bool(rc), int(n.value), a.value, m.value
+
+    def prepared_discard(self, which):
+        self._check(self._lib.flashe_prepared_discard(self._h, which))
+
+    def prepared_download(self, which, part):
+        """The cached `add` / `minus` mask as a uint64 array [n, L] (None when nothing is held)."""
+        held, n, a, m = self.prepared_query(which)
+        ptr = a if part == "add" else m
+        if not held or not ptr:
+            return None
+        out = host_empty((n, self.limbs), np.uint64)
+        if n:
+            self._check(self._lib.flashe_memcpy_d2h(self._h, out.ctypes.data, ptr, out.nbytes))
+        return out
+
+    def encrypt_prepared_dev(self, n, pt, pt_limbs, ct):
+        """ct = pt + add - minus from the ctx's prepared encrypt masks (no AES); consumes them."""
+        self._check(self._lib.flashe_encrypt_prepared_dev(self._h, n, self._ptr(pt), pt_limbs, self._ptr(ct)))
+
+    def decrypt_prepared_dev(self, it, add_idx, minus_idx, n, n_jobs, inp, out):
+        """out = inp + add - minus from the ctx's prepared decrypt masks, plus the listed extra prefixes computed online; consumes them."""
+        pa, _a = _u32_list(add_idx)
+        pm, _m = _u32_list(minus_idx)
+        self._check(self._lib.flashe_decrypt_prepared_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, self._ptr(inp), self._ptr(out)))
+
     def decrypt_dev(self, it, add_idx, minus_idx, n, n_jobs, inp, out):
         pa, _a = _u32_list(add_idx)
         pm, _m = _u32_list(minus_idx)
@@ -592,6 +633,15 @@ class Engine:
         k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
         self._check(self._lib.flashe_sparse_double_masks_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total,
                                                              self._ptr(add_out), self._ptr(minus_out)))
+
+    def dynamic_masking_cost_dev(self, locs, ks):
+        """(single_cost, double_cost) of Arbiter.dynamic_masking (jzf_flashe_block.py:92-112) from device-resident, strictly increasing
+        location lists: the positions consecutive clients share are counted on the device, no one-hot vectors."""
+        p, _keep = self._ptr_array(locs)
+        kk = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        single, double = c_u64(0), c_u64(0)
+        self._check(self._lib.flashe_dynamic_masking_cost_dev(self._h, len(locs), p, kk, ctypes.byref(single), ctypes.byref(double)))
+        return int(single.value), int(double.value)
 
     def sparse_dense_mask_dev(self, it, sels, total, out):
         p, _keep = self._ptr_array(sels)

@@ -173,6 +173,34 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
 int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
                              const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev);
 
+/* ---- mask precompute, resident in the ctx (FlasheCipher.prepare_encrypt / prepare_decrypt, jzf_flashe.py:599-666) ----
+ * The reference computes the next round's masks in idle time and caches them in next_iter_encrypt_prepared / next_iter_decrypt_prepared;
+ * the NEXT encrypt / decrypt then only adds vectors (no AES) and deletes the cache (:457, :483-486, :557-580).  Here the cache lives in
+ * HBM inside the ctx -- a C caller needs no state machine of its own:
+ *   flashe_prepare_encrypt(iter_next, idx, scheme, num_params): masks term(iter_next, idx) and, double mask, term(iter_next, idx + 1)
+ *       of length num_params (:599-631; the caller passes iter + 1);
+ *   flashe_prepare_decrypt(iter, num_clients, num_params): term(iter, num_clients) and term(iter, 0) -- nobody dropped (:633-666);
+ *   flashe_encrypt_prepared[_dev](n, pt): ct = (pt + add - minus) mod 2^b from the cache, which is CONSUMED; FLASHE_EINVAL without a
+ *       cache, or -- cache kept, like NumPy's broadcast error in the reference -- when n differs from num_params;
+ *   flashe_decrypt_prepared[_dev](iter, extra add / minus prefixes, n, in): out = in + add - minus from the cache plus the prefixes the
+ *       precompute does not cover (dropouts: what set_idx_list leaves after skipping {num_clients} / {0}, :372-386), computed online
+ *       and merged in (:557-564); consumes the cache;
+ *   flashe_prepared_query(which, &n, &add_dev, &minus_dev): 1 / 0 = a cache is / is not held; its length and device vectors (valid
+ *       until consumed or re-prepared); flashe_prepared_discard(which) drops it (which: FLASHE_PREPARED_ENCRYPT | _DECRYPT).
+ * prepare_* are asynchronous on the ctx stream like every *_dev call. */
+#define FLASHE_PREPARED_ENCRYPT 1
+#define FLASHE_PREPARED_DECRYPT 2
+int flashe_prepare_encrypt(flashe_ctx *ctx, uint32_t iter_next, uint32_t idx, int scheme, uint64_t num_params, uint32_t n_jobs);
+int flashe_prepare_decrypt(flashe_ctx *ctx, uint32_t iter, uint32_t num_clients, uint64_t num_params, uint32_t n_jobs);
+int flashe_prepared_query(flashe_ctx *ctx, int which, uint64_t *n, const uint64_t **add_dev, const uint64_t **minus_dev);
+int flashe_prepared_discard(flashe_ctx *ctx, int which);
+int flashe_encrypt_prepared_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *pt_dev, int pt_limbs, uint64_t *ct_dev);
+int flashe_encrypt_prepared(flashe_ctx *ctx, uint64_t n, const uint64_t *pt, int pt_limbs, uint64_t *ct);
+int flashe_decrypt_prepared_dev(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx,
+                                int n_minus, uint64_t n, uint32_t n_jobs, const uint64_t *in_dev, uint64_t *out_dev);
+int flashe_decrypt_prepared(flashe_ctx *ctx, uint32_t iter, const uint32_t *add_idx, int n_add, const uint32_t *minus_idx,
+                            int n_minus, uint64_t n, uint32_t n_jobs, const uint64_t *in, uint64_t *out);
+
 /* flashe_encrypt_batch_dev on ONE element slice [first, first + count) of the n-element vectors (new): the launch of a GPU that owns
  * that slice of EVERY client's vector -- element sharding, SURVEY.md section 8e (i): mask streams are position-indexed, so the slices
  * need no exchange for the element-wise aggregate.  pt_dev[v] / ct_dev[v] / sum_out_dev address element `first`; n and n_jobs still
@@ -387,6 +415,14 @@ int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32
  * selected slot, :170, :201).  loc is a HOST array of C device pointers, k a HOST array; add_out / minus_out: total x L limbs each. */
 int flashe_sparse_double_masks_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                                    uint64_t total, uint64_t *add_out_dev, uint64_t *minus_out_dev);
+/* The arbiter's per-round choice between single and double masks for a sparse job (Arbiter.dynamic_masking,
+ * jzf_flashe_block.py:92-112): single_cost = 2 sum_c len(mask_c); double_cost = 2 single_cost - 2 canceled, canceled = the positions
+ * consecutive clients share (the reference ANDs one-hot vectors of `total` entries per pair).  Here every list entry of client c is
+ * looked up in client c + 1's list on the device -- no one-hots, sum_c k_c binary searches.  loc_dev: HOST array of C device pointers
+ * to STRICTLY INCREASING lists (what Client.sparsify emits), k: HOST array of their lengths.  The caller decides: "single" iff
+ * single_cost <= double_cost (:106).  Synchronous. */
+int flashe_dynamic_masking_cost_dev(flashe_ctx *ctx, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                    uint64_t *single_cost, uint64_t *double_cost);
 int flashe_sparse_dense_mask_dev(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel_dev,
                                  uint64_t total, uint64_t *out_dev);
 int flashe_sparse_dense_mask(flashe_ctx *ctx, uint32_t iter, int n_lists, const uint8_t *const *sel,

@@ -69,6 +69,42 @@ class OracleEngine:
     def mask_dev(self, it, idx_list, n, n_jobs, out):
         out.arr = orc.mask_sum(self.key, it, idx_list, n, n_jobs, self.int_bits)
 
+    # ctx-resident mask precompute (flashe_prepare_* / flashe_*_prepared_dev)
+    PREPARED_ENCRYPT, PREPARED_DECRYPT = 1, 2
+
+    def prepare_encrypt(self, it_next, idx, scheme, num_params, n_jobs):
+        self._prep = getattr(self, "_prep", {})
+        self._prep[1] = (orc.mask_sum(self.key, it_next, [idx], num_params, n_jobs, self.int_bits),
+                         orc.mask_sum(self.key, it_next, [idx + 1], num_params, n_jobs, self.int_bits) if scheme == 1 else None)
+
+    def prepare_decrypt(self, it, num_clients, num_params, n_jobs):
+        self._prep = getattr(self, "_prep", {})
+        self._prep[2] = (orc.mask_sum(self.key, it, [num_clients], num_params, n_jobs, self.int_bits), orc.mask_sum(self.key, it, [0], num_params, n_jobs, self.int_bits))
+
+    def prepared_download(self, which, part):
+        ent = getattr(self, "_prep", {}).get(which)
+        return None if ent is None else ent[0 if part == "add" else 1]
+
+    def prepared_discard(self, which):
+        for w in (1, 2):
+            if which & w:
+                getattr(self, "_prep", {}).pop(w, None)
+
+    def encrypt_prepared_dev(self, n, pt, pt_limbs, ct):
+        add, minus = self._prep[1]                              # KeyError = no cache, as the ABI's FLASHE_EINVAL
+        assert len(add) == n
+        ct.arr = orc.combine(self.int_bits, np.ascontiguousarray(pt.arr).reshape(n, pt_limbs), add, minus)
+        del self._prep[1]                                       # consumed
+
+    def decrypt_prepared_dev(self, it, add_idx, minus_idx, n, n_jobs, inp, out):
+        add, minus = self._prep[2]
+        assert len(add) == n
+        v = orc.combine(self.int_bits, np.ascontiguousarray(inp.arr).reshape(n, self.limbs), add, minus)
+        if add_idx or minus_idx:
+            v = orc.decrypt(self.key, it, add_idx, minus_idx, n_jobs, self.int_bits, v)
+        out.arr = v
+        del self._prep[2]
+
     def combine_dev(self, n, inp, in_limbs, add, minus, out):
         a = np.ascontiguousarray(inp.arr).reshape(n, in_limbs)
         out.arr = orc.combine(self.int_bits, a, add.arr if add is not None else None,

@@ -482,3 +482,47 @@ def test_numpy_random_on_the_device_full_pass_from_an_odd_position():
     st_got = np.random.get_state()
     assert st_got[2] == st_want[2] and np.array_equal(st_got[1], st_want[1])
     assert np.random.random(3).tobytes() == follow_want.tobytes()
+
+
+def test_dynamic_masking_on_the_device():
+    """Arbiter.dynamic_masking's decision (jzf_flashe_block.py:92-112) from location lists that already live in HBM: the cases recorded
+    from the reference (block.json, produced by calling RB.Arbiter.dynamic_masking), random lists against the one-hot formulation the
+    reference uses, more clients than one launch's table holds, and a config-5-sized decision (50 clients x 255,570 of 25,557,032
+    positions) without any `total`-sized host array, in well under a millisecond of device time."""
+    import time
+    from flashe_amd.block import dynamic_masking_choice
+    from flashe_amd.engine import Engine
+    eng = Engine(KEY, 128, device=0)
+
+    def on_device(masks):
+        return [(eng.upload(np.asarray(m, dtype=np.uint32)) if len(m) else eng.alloc(16), len(m)) for m in masks]
+
+    for case in load_golden("block.json")["dynamic_masking"]:
+        masks = [sorted(set(m)) for m in case["masks"]]
+        if [list(m) for m in case["masks"]] != masks:
+            continue                                                   # (the device form takes strictly increasing lists)
+        assert dynamic_masking_choice(on_device(masks), case["total"], engine=eng) == case["choice"], case
+        assert dynamic_masking_choice(case["masks"], case["total"]) == case["choice"]
+    rng = np.random.Generator(np.random.PCG64(11))
+    for C, total, k in [(3, 1000, 400), (70, 5000, 900), (130, 3000, 2000), (2, 64, 64), (5, 100, 0)]:
+        masks = [np.sort(rng.choice(total, k, replace=False)).astype(np.uint32) for _ in range(C)]
+        ohs = []
+        for m in masks:
+            oh = np.zeros(total, dtype=np.uint8)
+            oh[m] = 1
+            ohs.append(oh)
+        canceled = sum(int((ohs[i] & ohs[i + 1]).sum()) for i in range(C - 1))
+        single, double = eng.dynamic_masking_cost_dev([d for d, _k in on_device(masks)], [k] * C)
+        assert single == 2 * C * k and double == 4 * C * k - 2 * canceled, (C, total, k)
+    total, k, C = 25_557_032, 255_570, 50
+    masks = [np.sort(rng.choice(total, k, replace=False)).astype(np.uint32) for _ in range(C)]
+    dev = on_device(masks)
+    eng.dynamic_masking_cost_dev([d for d, _k in dev], [k] * C)           # warm
+    t0 = time.perf_counter()
+    single, double = eng.dynamic_masking_cost_dev([d for d, _k in dev], [k] * C)
+    dt = time.perf_counter() - t0
+    canceled = sum(int(np.intersect1d(masks[i], masks[i + 1], assume_unique=True).size) for i in range(C - 1))
+    assert single == 2 * C * k and double == 2 * single - 2 * canceled
+    assert dynamic_masking_choice(dev, total, engine=eng) == "single"
+    print(f"dynamic_masking at config-5 size on the device: {dt * 1e3:.3f} ms (call incl. the host read-back)")
+    assert dt < 5e-3, dt
