@@ -91,6 +91,7 @@ _SIGNATURES = {
     "flashe_encrypt_batch_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp)]),
     "flashe_encrypt_batch_sum_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp),
                                              c_vp]),
+    "flashe_aggregate_elem_u32_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_dynamic_masking_cost_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64p, c_u64p]),
     "flashe_prepare_encrypt": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32]),
     "flashe_prepare_decrypt": (c_int, [c_vp, c_u32, c_u32, c_u64, c_u32]),

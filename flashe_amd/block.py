@@ -275,6 +275,7 @@ class FlasheClient(object):
             if v.dtype == object:
                 v = v.reshape(-1)
         dv, _kind = c._on_device(v, full_width=True)
+        dv = c._as_wide(dv)                       # (a compact uint32 aggregate: the fused launch reads one-limb vectors)
         n = len(dv)
         sizes = [int(np.prod(shape)) for shape in self.shape_dict.values()]
         if sum(sizes) > n:

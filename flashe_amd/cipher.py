@@ -313,6 +313,19 @@ class FlasheCipher(object):
     def _wants_device(value, device):
         return isinstance(value, DeviceVector) if device is None else bool(device)
 
+    # ---- compact layout (new): int_bits <= 32 keeps device-resident vectors as uint32 arrays ----
+    def _compact_ok(self):
+        """The shipped un-batched jobs run int_bits = 20 (examples/configs/cnn_flashe_q16_b1_pad: quantize.int_bits): one element per
+        uint64 limb moves 8 bytes for 20 useful bits, and the kernels of those widths are bound by exactly those bytes.  With
+        int_bits <= 32 every DeviceVector this class produces is a uint32 array (flashe_encrypt_batch_u32_dev,
+        flashe_aggregate_elem_u32_dev, flashe_aggregate_decrypt_u32_dev), and np.uint32 arrays are accepted and returned as such."""
+        eng = self._engine
+        return (self.int_bits <= 32 and hasattr(eng, "encrypt_batch_u32_dev") and os.environ.get("FLASHE_CHAIN", "1") != "0")
+
+    @staticmethod
+    def _is_u32(value):
+        return isinstance(value, np.ndarray) and value.dtype == np.uint32
+
     def _on_device(self, value, full_width=False):
         """(DeviceVector on this cipher's engine, kind of the host form).  full_width: the operand must have L limbs."""
         eng = self._engine
@@ -322,7 +335,13 @@ class FlasheCipher(object):
             if value.limbs != eng.limbs and (full_width or value.limbs != 1):
                 raise ValueError(f"expected {eng.limbs} limbs per element, got {value.limbs}")
             value.wait_on(eng)
-            return value, "u64_2d"
+            return value, ("u32" if getattr(value, "compact", False) else "u64_2d")
+        if self._is_u32(value):
+            if value.ndim != 1:
+                raise ValueError(f"uint32 input must be [n], got {value.shape}")
+            if self._compact_ok():
+                return DeviceVector.from_host(eng, value), "u32"
+            return DeviceVector.from_host(eng, value.astype(np.uint64)), "u32"
         limbs, kind = _to_limbs(value, eng.limbs)
         if full_width and limbs.shape[1] != eng.limbs:
             limbs = np.concatenate([limbs, np.zeros((limbs.shape[0], eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
@@ -330,15 +349,35 @@ class FlasheCipher(object):
 
     @staticmethod
     def _deliver(out, kind, want_device):
-        return out.mark_ready() if want_device else _from_limbs(out.to_host(), kind)
+        if want_device:
+            return out.mark_ready()
+        host = out.to_host()
+        if getattr(out, "compact", False):                                # uint32 [n] from the device
+            return host if kind == "u32" else _from_limbs(host.astype(np.uint64).reshape(-1, 1), kind)
+        if kind == "u32":
+            return host[:, 0].astype(np.uint32)
+        return _from_limbs(host, kind)
+
+    def _as_compact(self, dv):
+        return dv if dv.compact else dv.narrowed(self._engine)
+
+    def _as_wide(self, dv):
+        return dv.widened(self._engine) if getattr(dv, "compact", False) else dv
 
     def _encrypt_single(self, value, device=None):                       # jzf_flashe.py:431-454
         eng = self._engine
-        if self._wants_device(value, device) or isinstance(value, DeviceVector):
+        if self._wants_device(value, device) or isinstance(value, DeviceVector) or self._is_u32(value):
             dv, kind = self._on_device(value)
-            out = DeviceVector(eng, len(dv))
-            eng.encrypt_dev(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_SINGLE, len(dv), N_JOBS, dv.buf, dv.limbs, out.buf)
-            ct = self._deliver(out, kind, self._wants_device(value, device))
+            want_dev = self._wants_device(value, device)
+            if self._compact_ok() and (dv.compact or want_dev):
+                dv = self._as_compact(dv)
+                out = DeviceVector(eng, len(dv), 1, elem_bytes=4)
+                eng.encrypt_batch_u32_dev(self.iter_index, [self._idx_of(self.index_prefix_for_add)], SCHEME_SINGLE, len(dv), N_JOBS, [dv.buf], [out.buf])
+            else:
+                dv = self._as_wide(dv)
+                out = DeviceVector(eng, len(dv))
+                eng.encrypt_dev(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_SINGLE, len(dv), N_JOBS, dv.buf, dv.limbs, out.buf)
+            ct = self._deliver(out, kind, want_dev)
         else:
             limbs, kind = _to_limbs(value, eng.limbs)
             ct = _from_limbs(eng.encrypt(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_SINGLE, N_JOBS, limbs), kind)
@@ -350,9 +389,16 @@ class FlasheCipher(object):
         eng = self._engine
         want_dev = self._wants_device(value, device)
         prepared = 'add' in self.next_iter_encrypt_prepared
-        if want_dev or prepared or isinstance(value, DeviceVector):
+        if want_dev or prepared or isinstance(value, DeviceVector) or self._is_u32(value):
             dv, kind = self._on_device(value)
             n = len(dv)
+            if not prepared and self._compact_ok() and (dv.compact or want_dev):
+                dv = self._as_compact(dv)
+                out = DeviceVector(eng, n, 1, elem_bytes=4)
+                eng.encrypt_batch_u32_dev(self.iter_index, [self._idx_of(self.index_prefix_for_add)], SCHEME_DOUBLE, n, N_JOBS, [dv.buf], [out.buf])
+                ct = self._deliver(out, kind, want_dev)
+                return ct
+            dv = self._as_wide(dv)
             out = DeviceVector(eng, n)
             if not prepared:
                 eng.encrypt_dev(self.iter_index, self._idx_of(self.index_prefix_for_add), SCHEME_DOUBLE, n, N_JOBS, dv.buf, dv.limbs, out.buf)
@@ -406,8 +452,10 @@ class FlasheCipher(object):
     def _decrypt_single(self, value, device=None):                       # jzf_flashe.py:506-535
         eng = self._engine
         want_dev = self._wants_device(value, device)
-        if want_dev or self.masks is not None or isinstance(value, DeviceVector):
+        if want_dev or self.masks is not None or isinstance(value, DeviceVector) or self._is_u32(value):
             dv, kind = self._on_device(value, full_width=True)
+            was_compact = dv.compact
+            dv = self._as_wide(dv)             # (prefix LISTS and dense masks run in the one-limb layout; the result goes back compact)
             n = len(dv)
             out = DeviceVector(eng, n)
             if self.masks is None:
@@ -417,6 +465,8 @@ class FlasheCipher(object):
                 minus = self.next_iter_decrypt_prepared['minus']
                 self._check_prepared_len(minus, n)
                 eng.combine_dev(n, dv.buf, eng.limbs, None, minus.buf, out.buf)
+            if was_compact and self._compact_ok():
+                out = out.mark_ready().narrowed(eng)
             res = self._deliver(out, kind, want_dev)
         else:
             limbs, kind = _to_limbs(value, eng.limbs)
@@ -441,9 +491,21 @@ class FlasheCipher(object):
         if not prepared and not online:
             _to_limbs(value, eng.limbs) if isinstance(value, np.ndarray) else None      # (conversion errors come first, as in the reference)
             raise KeyError('add')                                         # what the reference raises (:570)
-        if want_dev or prepared or isinstance(value, DeviceVector):
+        if want_dev or prepared or isinstance(value, DeviceVector) or self._is_u32(value):
             dv, kind = self._on_device(value, full_width=True)
             n = len(dv)
+            if dv.compact and not prepared and self._compact_ok() and len(add_idx) == 1 and len(minus_idx) <= 1:
+                # the no-dropout decrypt (and every single telescoped run) on the uint32 vector itself: a one-operand "reduce + decrypt"
+                out = DeviceVector(eng, n, 1, elem_bytes=4)
+                eng.aggregate_decrypt_u32_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, 0, n, [dv.buf], None, out.buf, out_elem_bytes=4)
+                res = self._deliver(out, kind, want_dev)
+                for d in (self.next_iter_decrypt_prepared, self.next_iter_decrypt_prepared_idx):
+                    for k in ('add', 'minus'):
+                        if k in d:
+                            del d[k]
+                return res
+            was_compact = dv.compact
+            dv = self._as_wide(dv)
             out = DeviceVector(eng, n)
             if not prepared:
                 eng.decrypt_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, dv.buf, out.buf)
@@ -458,6 +520,8 @@ class FlasheCipher(object):
                     eng.combine_dev(n, dv.buf, eng.limbs, padd.buf, pminus.buf, out.buf)
                     if online:                                            # extras merged in (:557-564)
                         eng.decrypt_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, out.buf, out.buf)
+            if was_compact and self._compact_ok():
+                out = out.mark_ready().narrowed(eng)
             res = self._deliver(out, kind, want_dev)
         else:
             limbs, kind = _to_limbs(value, eng.limbs)
@@ -528,6 +592,27 @@ def aggregate(ciphertexts, int_bits, packed=False, device=0, _engine=None, keep_
         raise TypeError("reduce() of empty sequence with no initial value")
     eng = _engine or Engine(bytes(32), int_bits, device=device)
     want_dev = isinstance(ciphertexts[0], DeviceVector) if keep_on_device is None else bool(keep_on_device)
+    is_compact = lambda c: (isinstance(c, DeviceVector) and c.compact) or (isinstance(c, np.ndarray) and c.dtype == np.uint32)    # noqa: E731
+    if (int_bits <= 32 and not packed and hasattr(eng, "aggregate_elem_u32_dev") and all(is_compact(c) for c in ciphertexts)):
+        # compact layout: uint32 operands (handles or arrays), uint32 result -- half the bytes of the one-limb reduce
+        ops, held = [], {}
+        for c in ciphertexts:
+            if id(c) not in held:
+                if isinstance(c, DeviceVector):
+                    c.wait_on(eng)
+                    held[id(c)] = c
+                else:
+                    held[id(c)] = DeviceVector.from_host(eng, c.reshape(-1))
+            ops.append(held[id(c)])
+        n = len(ops[0])
+        if any(len(o) != n for o in ops):
+            raise ValueError("operands could not be broadcast together")
+        out = DeviceVector(eng, n, 1, elem_bytes=4)
+        eng.aggregate_elem_u32_dev([o.buf for o in ops], n, out.buf)
+        return out.mark_ready() if want_dev else out.to_host()
+    # (a compact operand among one-limb ones, or the packed reduce: widened on the device)
+    ciphertexts = [c.widened(eng) if (isinstance(c, DeviceVector) and c.compact) else (c.astype(np.uint64) if (isinstance(c, np.ndarray) and c.dtype == np.uint32) else c)
+                   for c in ciphertexts]
     # an operand passed several times (the notebook's `[ct] * num_clients`) is converted and uploaded once
     seen, conv = {}, []
     for c in ciphertexts:

@@ -840,6 +840,27 @@ int flashe_aggregate_decrypt_u32_dev(flashe_ctx *ctx, uint32_t iter, const uint3
     return FLASHE_OK;
 }
 
+int flashe_aggregate_elem_u32_dev(flashe_ctx *ctx, int C, const uint32_t *const *cts_dev, uint64_t n, uint32_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (ctx->int_bits > 32) return fail(ctx, FLASHE_EINVAL, "the uint32 layout needs int_bits <= 32, this ctx has %d", ctx->int_bits);
+    if (C < 1 || !cts_dev || (n && !out_dev)) return fail(ctx, FLASHE_EINVAL, "aggregate_elem_u32: bad arguments");
+    for (int c = 0; c < C; c++)
+        if (n && (!cts_dev[c] || (reinterpret_cast<uintptr_t>(cts_dev[c]) & 3u))) return fail(ctx, FLASHE_EINVAL, "operand %d is null or not 4-byte aligned", c);
+    if (reinterpret_cast<uintptr_t>(out_dev) & 3u) return fail(ctx, FLASHE_EINVAL, "out_dev must be 4-byte aligned");
+    // more operands than one pass holds: partial sums accumulate in out (every pass reads out as one operand)
+    int done = 0;
+    while (done < C) {
+        const int take = std::min(C - done, done ? kMaxOps - 1 : kMaxOps);
+        std::vector<const uint32_t *> ops;
+        if (done) ops.push_back(out_dev);
+        for (int c = 0; c < take; c++) ops.push_back(cts_dev[done + c]);
+        HIP_TRY(ctx, launch_aggregate_elem_u32(ctx->env, static_cast<int>(ops.size()), ops.data(), n, out_dev));
+        done += take;
+    }
+    return FLASHE_OK;
+}
+
 int flashe_widen_u32_dev(flashe_ctx *ctx, uint64_t n, const uint32_t *in_dev, uint64_t *out_dev)
 {
     CHECK_CTX(ctx);

@@ -144,6 +144,8 @@ hipError_t launch_widen_u32(const LaunchEnv &env, uint64_t n, const uint32_t *in
 hipError_t launch_narrow_u32(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint32_t *out_dev);
 hipError_t launch_aggregate_elem(const LaunchEnv &env, int C, const uint64_t *const *ops,
                                  uint64_t n, uint64_t *out_dev);
+// the same on uint32 element arrays (compact layout, int_bits <= 32)
+hipError_t launch_aggregate_elem_u32(const LaunchEnv &env, int C, const uint32_t *const *ops, uint64_t n, uint32_t *out_dev);
 
 // summaries_dev: scratch of at least packed_num_blocks(n_limbs) uint32 words.
 // out must NOT alias an operand (blocks re-read their left neighbour's inputs).

@@ -2743,11 +2743,63 @@ __global__ __launch_bounds__(kStreamThreads) void aggregate_elem8_kernel(int C, 
     }
 }
 
+// compact layout (int_bits <= 32, uint32 elements): four elements per lane in 16-byte accesses; 32-bit sums wrap mod 2^32, which 2^b divides
+template <bool VEC>
+__global__ __launch_bounds__(kStreamThreads) void aggregate_elem_u32_kernel(int C, const PtrTable ops, uint64_t n, uint32_t *out, uint32_t mask)
+{
+    const uint64_t *const *tab = ops.p;
+    if (VEC) {
+        const uint64_t n4 = n / 4;
+        for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; s < n4; s += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+            for (int c = 0; c < C; c++) {
+                const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(tab[c]) + s);
+                a0 += static_cast<uint32_t>(v[0]); a1 += static_cast<uint32_t>(v[0] >> 32);
+                a2 += static_cast<uint32_t>(v[1]); a3 += static_cast<uint32_t>(v[1] >> 32);
+            }
+            u64x2 r;
+            r[0] = (a0 & mask) | (static_cast<uint64_t>(a1 & mask) << 32);
+            r[1] = (a2 & mask) | (static_cast<uint64_t>(a3 & mask) << 32);
+            __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(out) + s);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+            const uint64_t j = n4 * 4 + threadIdx.x;
+            uint32_t a = 0;
+            for (int c = 0; c < C; c++) a += reinterpret_cast<const uint32_t *>(tab[c])[j];
+            out[j] = a & mask;
+        }
+    } else {
+        for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n; j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+            uint32_t a = 0;
+#pragma unroll 4
+            for (int c = 0; c < C; c++) a += __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(tab[c]) + j);
+            __builtin_nontemporal_store(a & mask, out + j);
+        }
+    }
+}
+
 static inline PtrTable make_table(int C, const uint64_t *const *ops)
 {
     PtrTable t;
     for (int c = 0; c < kMaxOps; c++) t.p[c] = c < C ? ops[c] : nullptr;
     return t;
+}
+
+hipError_t launch_aggregate_elem_u32(const LaunchEnv &env, int C, const uint32_t *const *ops, uint64_t n, uint32_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    if (C > kMaxOps || env.b > 32) return hipErrorInvalidValue;
+    const PtrTable tab_dev = make_table(C, reinterpret_cast<const uint64_t *const *>(ops));
+    const uint32_t mask = env.b == 32 ? 0xffffffffu : ((1u << env.b) - 1u);
+    bool a16 = (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0;
+    for (int c = 0; c < C; c++) a16 = a16 && (reinterpret_cast<uintptr_t>(ops[c]) & 15u) == 0;
+    const int bpc = C >= 3 ? 2 : 8;
+    int grid = stream_grid(env, a16 ? n / 4 + 1 : n);
+    if (grid > env.num_cus * bpc) grid = env.num_cus * bpc;
+    if (a16) hipLaunchKernelGGL(aggregate_elem_u32_kernel<true>, dim3(grid), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n, out_dev, mask);
+    else hipLaunchKernelGGL(aggregate_elem_u32_kernel<false>, dim3(grid), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n, out_dev, mask);
+    return hipGetLastError();
 }
 
 hipError_t launch_aggregate_elem(const LaunchEnv &env, int C, const uint64_t *const *ops, uint64_t n, uint64_t *out_dev)

@@ -230,11 +230,21 @@ class DeviceVector:
     The producing engine records an event behind its last write; a consumer on another engine (another FlasheCipher = another
     stream) makes its stream wait for it on the device, the host never blocks."""
 
-    def __init__(self, engine, n, limbs=None, buf=None):
+    def __init__(self, engine, n, limbs=None, buf=None, elem_bytes=8):
+        """elem_bytes = 4: the COMPACT layout of int_bits <= 32 -- the same values as a uint32 array (flashe_*_u32_dev), half the bytes
+        of the one-limb layout in HBM and over PCIe."""
         self.engine, self.n = engine, int(n)
-        self.limbs = int(limbs or engine.limbs)
-        self.buf = buf if buf is not None else engine.alloc_vec(self.n, self.limbs)
+        self.elem_bytes = int(elem_bytes)
+        self.limbs = 1 if self.elem_bytes == 4 else int(limbs or engine.limbs)
+        if buf is not None:
+            self.buf = buf
+        else:
+            self.buf = engine.alloc(max(4 * self.n, 16)) if self.elem_bytes == 4 else engine.alloc_vec(self.n, self.limbs)
         self._ready = None
+
+    @property
+    def compact(self):
+        return self.elem_bytes == 4
 
     def __len__(self):
         return self.n
@@ -253,7 +263,10 @@ class DeviceVector:
 
     @classmethod
     def from_host(cls, engine, arr):
-        """Upload a uint64 array of shape [n] or [n, k]."""
+        """Upload a uint64 array of shape [n] or [n, k] -- or a 1-D uint32 array (compact layout, int_bits <= 32)."""
+        if isinstance(arr, np.ndarray) and arr.dtype == np.uint32:
+            arr = np.ascontiguousarray(arr).reshape(-1)
+            return cls(engine, arr.shape[0], 1, buf=engine.upload(arr), elem_bytes=4)
         arr = np.ascontiguousarray(arr, dtype=np.uint64)
         if arr.ndim == 1:
             arr = arr.reshape(-1, 1)
@@ -273,8 +286,32 @@ class DeviceVector:
             engine.wait_event(self._ready)
 
     def to_host(self):
-        """uint64 array [n, limbs] (from the recycling host pool); blocks until the vector is complete."""
+        """uint64 array [n, limbs] -- uint32 [n] for a compact vector -- (from the recycling host pool); blocks until the vector is
+        complete."""
+        if self.elem_bytes == 4:
+            return self.buf.download(np.uint32, self.n)
         return self.buf.download(np.uint64, self.n * self.limbs).reshape(self.n, self.limbs)
+
+    def widened(self, engine=None):
+        """A compact vector as a one-limb DeviceVector (a device pass, flashe_widen_u32_dev); a one-limb vector as it is."""
+        if self.elem_bytes != 4:
+            return self
+        eng = engine or self.engine
+        self.wait_on(eng)
+        out = DeviceVector(eng, self.n, 1)
+        eng.widen_u32_dev(self.n, self.buf, out.buf)
+        return out.mark_ready()
+
+    def narrowed(self, engine=None):
+        """A one-limb vector in the compact layout (flashe_narrow_u32_dev: the low 32 bits of every element)."""
+        if self.elem_bytes == 4:
+            return self
+        assert self.limbs == 1
+        eng = engine or self.engine
+        self.wait_on(eng)
+        out = DeviceVector(eng, self.n, 1, elem_bytes=4)
+        eng.narrow_u32_dev(self.n, self.buf, out.buf)
+        return out.mark_ready()
 
     def __del__(self):
         try:
@@ -561,6 +598,10 @@ class Engine:
         p, _keep = self._ptr_array(cts)
         self._check(self._lib.flashe_aggregate_decrypt_u32_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, first, count,
                                                                len(cts), p, self._ptr(agg_out), self._ptr(out), int(out_elem_bytes)))
+
+    def aggregate_elem_u32_dev(self, cts, n, out):
+        p, _keep = self._ptr_array(cts)
+        self._check(self._lib.flashe_aggregate_elem_u32_dev(self._h, len(cts), p, n, self._ptr(out)))
 
     def widen_u32_dev(self, n, inp, out):
         self._check(self._lib.flashe_widen_u32_dev(self._h, n, self._ptr(inp), self._ptr(out)))

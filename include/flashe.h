@@ -326,6 +326,9 @@ int flashe_aggregate_decrypt_u32_dev(flashe_ctx *ctx, uint32_t iter,
                                      const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
                                      uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,
                                      int C, const uint32_t *const *cts_dev, void *agg_out_dev, void *out_dev, int out_elem_bytes);
+/* The arbiter's element-wise reduce (jzf_aggregator.py:424-430) on uint32 vectors: out[j] = sum_c cts[c][j] mod 2^b; any C >= 1
+ * (partial sums accumulate in out_dev beyond 64 operands), out_dev may be one of the operands only when C <= 64. */
+int flashe_aggregate_elem_u32_dev(flashe_ctx *ctx, int C, const uint32_t *const *cts_dev, uint64_t n, uint32_t *out_dev);
 int flashe_widen_u32_dev(flashe_ctx *ctx, uint64_t n, const uint32_t *in_dev, uint64_t *out_dev);
 int flashe_narrow_u32_dev(flashe_ctx *ctx, uint64_t n, const uint64_t *in_dev, uint32_t *out_dev);
 /* Packed: each operand is ONE integer of total_bits bits (n_limbs = ceil(total_bits/64)

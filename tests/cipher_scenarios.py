@@ -82,8 +82,13 @@ def run_round_case_with_handles(cm, c):
     d.set_idx_list(raw_idx_list=list(c["uploaded"]), mode="decrypt")
     dec_host = d.decrypt(aggp, device=False)                   # a handle in, a host array out
     assert isinstance(dec_host, np.ndarray) and limbs_to_ints(dec_host) == unhex(c["dec_packed"])
-    h2 = new_cipher(cm, b, scheme, int(c["uploaded"][0]), it, C).encrypt(cm.DeviceVector.from_host(d.engine, handles[int(c["uploaded"][0])].to_host()[:, :1] * 0 + 5))
+    t = handles[int(c["uploaded"][0])].to_host()
+    h2 = new_cipher(cm, b, scheme, int(c["uploaded"][0]), it, C).encrypt(cm.DeviceVector.from_host(d.engine, t.reshape(len(t), -1)[:, :1] * 0 + 5))
     assert isinstance(h2, cm.DeviceVector)                     # a device-resident plaintext gives a device-resident ciphertext
+    if b <= 32 and getattr(d, "_compact_ok", lambda: False)():
+        # int_bits <= 32: the handles this class produces are uint32 arrays in HBM (the compact layout), whatever the input was
+        assert all(h.compact for h in handles.values()) and agg.compact and dec.compact and h2.compact and not aggp.compact
+        assert handles[int(c["uploaded"][0])].to_host().dtype == np.uint32
 
 
 def run_precompute_case(cm, c):

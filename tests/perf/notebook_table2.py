@@ -45,23 +45,28 @@ def main():
         c.set_iter_index(0)
         c.idx = 0
         row = {"n": n, "int_bits": b}
-        for kind, pt in (("object", np.array([int(v) for v in vals], dtype=object)), ("uint64", vals)):
+        for kind, pt in (("object", np.array([int(v) for v in vals], dtype=object)), ("uint64", vals), ("uint32", vals.astype(np.uint32))):
             t_enc, ct = timed(lambda: c.encrypt(pt))
             t_add, agg = timed(lambda: c.aggregate([ct] * C))
             c.set_idx_list(raw_idx_list=[0] * C, mode="decrypt")
             t_dec, dec = timed(lambda: c.decrypt(agg))
             want_ct = orc.encrypt(KEY, 0, 0, "double", 16, b, vals)
-            assert [int(v) for v in ct[:2000]] == [int(v) for v in want_ct[:2000, 0]]
-            assert [int(v) for v in dec[:5000]] == [int(v) * C % (1 << b) for v in vals[:5000]]
+            assert [int(v) for v in np.asarray(ct).reshape(len(ct), -1)[:2000, 0]] == [int(v) for v in want_ct[:2000, 0]]
+            if kind == "uint32":
+                assert ct.dtype == np.uint32 and agg.dtype == np.uint32 and dec.dtype == np.uint32          # the compact layout end to end
+            assert [int(v) for v in np.asarray(dec).reshape(len(dec), -1)[:5000, 0]] == [int(v) * C % (1 << b) for v in vals[:5000]]
             row[kind] = {"encrypt_s": t_enc, "add10_s": t_add, "decrypt_s": t_dec}
         # the same three calls with DeviceVector handles between them (round 3): the plaintext goes up once, the ciphertext and the
         # sum stay in HBM, the decrypted vector comes down once
-        t_enc, h = timed(lambda: c.encrypt(vals, device=True))
+        # (int_bits = 20 <= 32: the handles are uint32 arrays in HBM -- prf_small_chain_kernel<..., uint32> and aggregate_elem_u32_kernel)
+        v32 = vals.astype(np.uint32)
+        t_enc, h = timed(lambda: c.encrypt(v32, device=True))
+        assert h.compact
         t_add, hagg = timed(lambda: c.aggregate([h] * C))
         c.set_idx_list(raw_idx_list=[0] * C, mode="decrypt")
         t_dec, dec = timed(lambda: c.decrypt(hagg, device=False))
         assert [int(v) for v in np.asarray(dec).reshape(-1)[:5000]] == [int(v) * C % (1 << b) for v in vals[:5000]]
-        row["uint64_device_handles"] = {"encrypt_s": t_enc, "add10_s": t_add, "decrypt_s": t_dec,
+        row["uint32_device_handles"] = {"encrypt_s": t_enc, "add10_s": t_add, "decrypt_s": t_dec,
                                         "note": "encrypt includes the upload, decrypt the download; add10 moves nothing"}
         rows.append(row)
     print(json.dumps({"notebook_table2_on_mi355x": rows,

@@ -1484,3 +1484,62 @@ def test_sparse_double_masks_from_location_lists(E, oracle, b, total, C, frac):
         with pytest.raises(E.FlasheError):
             eng.sync()
             da.download(np.uint64, 2)
+
+
+@pytest.mark.parametrize("b,scheme", [(20, "double"), (32, "double"), (8, "single"), (23, "double")])
+def test_flashe_cipher_compact_layout(oracle, b, scheme):
+    """with int_bits <= 32 the drop-in class keeps device-resident vectors as uint32 arrays (half the bytes of the one-limb
+    layout) and takes / returns np.uint32 arrays: encrypt (flashe_encrypt_batch_u32_dev), aggregate (flashe_aggregate_elem_u32_dev),
+    the no-dropout decrypt (flashe_aggregate_decrypt_u32_dev on the vector itself), a dropout decrypt (prefix lists: widened on the
+    device and narrowed back) and the packed reduce -- every value against the oracle, handles and host arrays, mixed operands."""
+    from flashe_amd import cipher as cm
+    cm.N_JOBS = 16
+    n, C, it = 70_001, 4, 5
+    rng = np.random.Generator(np.random.PCG64(b))
+    pts = [rng.integers(0, 2 ** min(b, 16), n, dtype=np.uint64) for _ in range(C)]
+    ciphers = []
+    for c in range(C):
+        ci = cm.FlasheCipher(b, mask=scheme)
+        ci.set_num_clients(C)
+        ci.generate_prp_seed(KEY)
+        ci.set_iter_index(it)
+        ci.idx = c
+        ciphers.append(ci)
+    want_ct = [oracle.encrypt(KEY, it, c, scheme, 16, b, pts[c]) for c in range(C)]
+    hs = []
+    for c in range(C):
+        host32 = ciphers[c].encrypt(pts[c].astype(np.uint32))                        # uint32 in -> uint32 out
+        assert host32.dtype == np.uint32 and np.array_equal(host32.astype(np.uint64), want_ct[c][:, 0])
+        h = ciphers[c].encrypt(pts[c].astype(object) if c % 2 else pts[c], device=True)   # object ints / uint64 in -> compact handle
+        assert h.compact and h.to_host().dtype == np.uint32 and np.array_equal(h.to_host().astype(np.uint64), want_ct[c][:, 0])
+        h2 = ciphers[c].encrypt(h)                                                    # a compact handle as plaintext
+        assert h2.compact
+        hs.append(h)
+    want_agg = oracle.aggregate_elem(want_ct, b)
+    agg = ciphers[0].aggregate(hs)
+    assert agg.compact and np.array_equal(agg.to_host().astype(np.uint64), want_agg[:, 0])
+    agg_host = ciphers[0].aggregate([h.to_host() for h in hs])                        # uint32 arrays in -> uint32 array out
+    assert agg_host.dtype == np.uint32 and np.array_equal(agg_host, agg.to_host())
+    mixed = ciphers[0].aggregate([hs[0], want_ct[1]] + hs[2:], device=False)          # a one-limb host operand among compact handles
+    assert np.array_equal(np.asarray(mixed).reshape(n, -1)[:, 0].astype(np.uint64), want_agg[:, 0])
+    aggp = ciphers[0].aggregate(hs, packed=True)
+    want_aggp = oracle.unpack(oracle.aggregate_packed([oracle.pack(ct, b) for ct in want_ct], n * b), n, b)
+    assert np.array_equal(aggp.to_host().reshape(n, -1)[:, 0], want_aggp[:, 0])
+    # decrypt: everybody uploaded (one add / one minus prefix for the double mask), then client 1 dropped (prefix lists)
+    for up in (list(range(C)), [0, 2, 3]):
+        a = ciphers[0].aggregate([hs[c] for c in up])
+        if scheme == "double":
+            add, minus = cm._engine.telescope(sorted(up))
+        else:
+            add, minus = [], sorted(up)
+        want = oracle.decrypt(KEY, it, add, minus, 16, b, oracle.aggregate_elem([want_ct[c] for c in up], b))
+        ciphers[0].set_idx_list(raw_idx_list=list(up), mode="decrypt")
+        dec = ciphers[0].decrypt(a)
+        assert dec.compact and np.array_equal(dec.to_host().astype(np.uint64), want[:, 0]), (b, scheme, up)
+        ciphers[0].set_idx_list(raw_idx_list=list(up), mode="decrypt")
+        dec_host = ciphers[0].decrypt(a.to_host())                                    # uint32 array in -> uint32 array out
+        assert dec_host.dtype == np.uint32 and np.array_equal(dec_host.astype(np.uint64), want[:, 0])
+        ciphers[0].set_idx_list(raw_idx_list=list(up), mode="decrypt")
+        dec_obj = ciphers[0].decrypt(a, device=False)
+        assert dec_obj.dtype == np.uint32
+    assert np.array_equal(want[:, 0], sum(pts[c] for c in up) & np.uint64((1 << b) - 1))
