@@ -97,6 +97,7 @@ public:
             const Parked v = parked_[oldest];
             parked_.erase(parked_.begin() + oldest);
             held_ -= v.cap;
+            settle_before_wipe(v);
             be_->wipe(v.p, v.cap);
             const int rc = be_->release(v.p);
             if (rc) { (void)be_->release(p); return rc; }
@@ -122,9 +123,21 @@ public:
 
 private:
     struct Parked { void *p; size_t cap; uint64_t epoch; };
+    // A block parked in the CURRENT epoch may still be written by a kernel in flight (callers drop a buffer right after enqueueing
+    // the work that uses it, and the ctx streams are non-blocking: the null-stream memset of wipe() does not wait for them).  Wiping
+    // it now would leave plaintext / ciphertext residue behind the wipe: synchronise the device first, which also opens a new epoch.
+    // (The synchronisation is device-wide, like the one hipFree implies: a stream capture running on ANOTHER ctx of the device is
+    // invalidated by it -- capture sequences are run once beforehand so that no allocation, hence no eviction, happens inside one.)
+    void settle_before_wipe(const Parked &v)
+    {
+        if (v.epoch == epoch_) {
+            (void)be_->sync_all();
+            epoch_++;
+        }
+    }
     void trim_locked()
     {
-        for (const Parked &b : parked_) { be_->wipe(b.p, b.cap); (void)be_->release(b.p); }
+        for (const Parked &b : parked_) { settle_before_wipe(b); be_->wipe(b.p, b.cap); (void)be_->release(b.p); }
         parked_.clear();
         held_ = 0;
     }

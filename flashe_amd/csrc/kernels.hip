@@ -2206,6 +2206,9 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
         }
         return hipSuccess;
     }
+    // the job-table kernels below know only the one-limb layout: a uint32 (compact) launch that the chained path did not take must
+    // fail, not run with the wrong element size (today abi.hip's check_u32 keeps every such condition off)
+    if (env.elem32) return hipErrorInvalidValue;
     if (env.b <= 64) return launch_prf_jobs_small(env, iter, dbl, n_entries, jobs, n, n_jobs);
     if (lone_small_double_job(env, dbl, n_entries, jobs)) {
         constexpr int kLatThreads = 256;

@@ -57,15 +57,30 @@ def deal_clients(total, world):
 # ------------------------------------------------------------------------------------------------------------------
 # process launch and rendezvous (no GPU call happens before the per-GPU processes exist)
 # ------------------------------------------------------------------------------------------------------------------
-def _die_with_parent():
-    """preexec hook of a rank process (runs between fork and exec, before anything GPU): the kernel sends SIGKILL to the rank
-    when the launcher dies, so that even a `kill -9` of the launcher leaves no rank behind holding a GPU."""
+def _resolve_prctl():
+    """libc's prctl, looked up ONCE at import: the preexec hook below runs between fork and exec, where an `import` or a dlopen can
+    deadlock on a lock another thread of the launcher held at the fork (the Python docs' warning about preexec_fn)."""
     try:
         import ctypes
-        import signal
-        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)      # PR_SET_PDEATHSIG
+        fn = ctypes.CDLL("libc.so.6", use_errno=True).prctl
+        fn.argtypes = [ctypes.c_int, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong, ctypes.c_ulong]
+        fn.restype = ctypes.c_int
+        return fn
     except Exception:
-        pass
+        return None
+
+
+_PRCTL = _resolve_prctl()
+_SIGKILL = 9
+
+
+def _die_with_parent():
+    """preexec hook of a rank process (runs between fork and exec, before anything GPU): the kernel sends SIGKILL to the rank
+    when the launcher dies, so that even a `kill -9` of the launcher leaves no rank behind holding a GPU.  One C call, nothing
+    imported or loaded here.  PR_SET_PDEATHSIG is tied to the THREAD that forked: `spawn` must be called from a thread that outlives
+    the ranks (the main thread; `spawn` itself blocks until they are done, so calling it and waiting in the same thread is enough)."""
+    if _PRCTL is not None:
+        _PRCTL(1, _SIGKILL, 0, 0, 0)                   # PR_SET_PDEATHSIG
 
 
 def spawn(n_procs, argv, master_port=None, env=None, deadline_s=None):
@@ -158,13 +173,36 @@ class Watchdog:
         import threading
         self.rank, self.world, self.on_fire = rank, world, on_fire
         self.exit_code = 3                      # what a firing exits with; callers lower it to 0 once a valid result is in hand
-        self.path = os.path.join(rdzv_dir(), f"flashe_abort_{os.getuid()}_{run_tag(world)}")
+        # The flag lives in a directory only this user can write to (0700, ownership checked): in a shared /tmp a predictable flag NAME
+        # could be squatted by another user -- the ranks would then find "a flag" they must not trust, nobody would fire, and the peers
+        # of an aborting rank would sit in their collective until the deadline.  When the directory cannot be had (someone else owns
+        # the name), abort() still fires locally and the peers leave at their deadline.
+        self.dir = self._private_dir(os.path.join(rdzv_dir(), f"flashe_run_{os.getuid()}_{run_tag(world)}"))
+        self.path = os.path.join(self.dir or rdzv_dir(), f"flashe_abort_{os.getuid()}_{run_tag(world)}")
         self._deadline, self._phase = None, ""
         self._lock = threading.Lock()
         self._done = False
         self._poll = poll_s
         self._thread = threading.Thread(target=self._watch, name="flashe-watchdog", daemon=True)
         self._thread.start()
+
+    @staticmethod
+    def _private_dir(path):
+        """`path` as a directory of this user with mode 0700 (created if missing); None when the name is taken by anything else."""
+        import stat
+        try:
+            os.mkdir(path, 0o700)
+        except FileExistsError:
+            pass
+        except OSError:
+            return None
+        try:
+            st = os.lstat(path)
+        except OSError:
+            return None
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            return None
+        return path
 
     def arm(self, seconds, phase):
         self._deadline, self._phase = time.time() + float(seconds), phase
@@ -184,8 +222,12 @@ class Watchdog:
                 f.write(f"rank {self.rank}: {reason}")
             os.link(tmp, self.path)
         except FileExistsError:
-            pass
+            # another rank's flag is already there -- if it really is one of ours; a file of another user (or a stale one nobody of this
+            # launch can read) will never make a watchdog fire: then at least this rank leaves now
+            if not self._flag_is_ours():
+                self._fire(f"rank {self.rank}: {reason} (the abort flag name is taken by a foreign file)")
         except OSError:
+            # (no link() on this filesystem, or the directory is gone: only this rank fires; its peers leave at their deadline)
             self._fire(f"rank {self.rank}: {reason}")
         finally:
             if tmp is not None:
@@ -194,6 +236,26 @@ class Watchdog:
                 except OSError:
                     pass
 
+    def _read_flag(self):
+        """(text, ours?) of the flag file, from ONE open: ownership is checked on the descriptor that is read, not on the name."""
+        try:
+            fd = os.open(self.path, os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+        except OSError:
+            return None, False
+        try:
+            import stat
+            st = os.fstat(fd)
+            ours = st.st_uid == os.getuid() and stat.S_ISREG(st.st_mode)
+            text = os.read(fd, 4096).decode(errors="replace") if ours else ""
+        except OSError:
+            text, ours = None, False
+        finally:
+            os.close(fd)
+        return text, ours
+
+    def _flag_is_ours(self):
+        return self._read_flag()[1]
+
     def finish(self):
         """The normal end: from here on the watchdog never fires (returns False if it already has)."""
         with self._lock:
@@ -201,10 +263,12 @@ class Watchdog:
                 return False
             self._done = True
         if self.rank == 0:
-            try:
-                os.unlink(self.path)
-            except OSError:
-                pass
+            for rm, target in ((os.unlink, self.path), (os.rmdir, self.dir)):
+                try:
+                    if target:
+                        rm(target)
+                except OSError:
+                    pass
         return True
 
     def _fire(self, reason):
@@ -226,14 +290,9 @@ class Watchdog:
             d = self._deadline
             if d is not None and time.time() > d:
                 self._fire(f"deadline of phase '{self._phase}' passed on rank {self.rank}")
-            try:
-                if os.path.exists(self.path):
-                    with open(self.path) as f:
-                        why = f.read()
-                    if os.stat(self.path).st_uid == os.getuid():
-                        self._fire(why or "abort requested")
-            except OSError:
-                pass
+            why, ours = self._read_flag()
+            if ours:
+                self._fire(why or "abort requested")
 
 
 def rendezvous_unique_id(rank, world, make_id, timeout=300.0):

@@ -20,6 +20,10 @@ struct Mock final : Backend {
     std::set<void *> wiped;
     size_t capacity, used = 0;
     uint64_t syncs = 0, allocs = 0, frees = 0;
+    // sync count at the moment the model saw a block parked: a wipe of that block must come AFTER a later synchronisation (a kernel of a
+    // non-blocking stream may still be writing a block parked in the current epoch: wiping first would leave residue behind the wipe)
+    const std::map<void *, uint64_t> *parked_at = nullptr;
+    uint64_t wipes_checked = 0;
     explicit Mock(size_t cap) : capacity(cap) {}
     int alloc(void **p, size_t bytes) override
     {
@@ -37,7 +41,17 @@ struct Mock final : Backend {
         return 0;
     }
     int sync_all() override { syncs++; return 0; }
-    void wipe(void *p, size_t bytes) override { memset(p, 0, real(bytes)); wiped.insert(p); }
+    void wipe(void *p, size_t bytes) override
+    {
+        if (parked_at) {
+            auto it = parked_at->find(p);
+            if (it != parked_at->end()) {
+                if (syncs <= it->second) { fprintf(stderr, "a parked block was wiped before any synchronisation since it was parked\n"); abort(); }
+                wipes_checked++;
+            }
+        }
+        memset(p, 0, real(bytes)); wiped.insert(p);
+    }
     static size_t real(size_t bytes) { return bytes < 4096 ? (bytes ? bytes : 1) : 4096; }
 };
 
@@ -55,6 +69,7 @@ int main()
         struct Live { void *p; size_t want; };
         std::vector<Live> live;
         std::map<void *, uint64_t> parked_at;        // sync count of the mock when the model saw the block freed
+        mock.parked_at = &parked_at;
         const size_t sizes[] = {1, 100, 4096, 5000, 70000, 1u << 20, (3u << 20) + 5, 9u << 20, 17u << 20, 30u << 20};
         for (int step = 0; step < 4000; step++) {
             const int op = rng() % 100;

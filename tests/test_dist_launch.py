@@ -94,3 +94,45 @@ def test_launcher_sigterm_reaches_the_ranks(tmp_path):
     time.sleep(0.3)
     for k in kids:
         assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", k
+
+
+def test_watchdog_flag_in_a_private_directory_and_a_squatted_name(tmp_path):
+    """the abort flag had a predictable name in a shared directory.  It now lives in a 0700 directory of this user; when
+    that NAME is taken by something else (here: a plain file squatting on it) the watchdog falls back to the shared directory, and an
+    abort() that finds a flag it cannot trust fires LOCALLY instead of silently relying on peers that will never see it."""
+    import stat
+    code = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+from flashe_amd.dist import Watchdog
+wd = Watchdog(0, 1, on_fire=lambda why: print("FIRED", why, flush=True))
+wd.exit_code = 0
+print("DIR", wd.dir, flush=True)
+if sys.argv[1] == "squat":
+    assert wd.dir is None
+    # a flag this launch did not write, which a watcher would not trust: a FIFO nobody writes to cannot even be opened for reading
+    # without blocking -- use a directory instead: open() fails, so the flag is "not ours"
+    os.mkdir(wd.path)
+    wd.abort("give up")
+    time.sleep(30)
+else:
+    st = os.lstat(wd.dir)
+    assert (st.st_mode & 0o777) == 0o700 and st.st_uid == os.getuid()
+    wd.abort("give up")
+    time.sleep(30)
+''' % ROOT
+    env = dict(os.environ, FLASHE_RDZV_DIR=str(tmp_path), MASTER_PORT="29888", FLASHE_RUN_ID="t1")
+    r = subprocess.run([sys.executable, "-c", code, "normal"], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 0 and "FIRED rank 0: give up" in r.stdout, r.stdout + r.stderr[-800:]
+    private = [l.split(" ", 1)[1] for l in r.stdout.splitlines() if l.startswith("DIR ")][0]
+    assert private.startswith(str(tmp_path)) and stat.S_ISDIR(os.lstat(private).st_mode)
+    # the same launch name again, the directory's name squatted by a regular file
+    env2 = dict(env, FLASHE_RUN_ID="t2")
+    probe = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import os; from flashe_amd.dist import run_tag, rdzv_dir; "
+                            "print(os.path.join(rdzv_dir(), f'flashe_run_{os.getuid()}_{run_tag(1)}'))" % ROOT],
+                           capture_output=True, text=True, env=env2)
+    # (run_tag contains the parent pid: compute the name the child will use by making this test process the parent of both)
+    name = probe.stdout.strip()
+    open(name, "w").close()
+    r = subprocess.run([sys.executable, "-c", code, "squat"], capture_output=True, text=True, timeout=60, env=env2)
+    assert r.returncode == 0 and "DIR None" in r.stdout and "FIRED" in r.stdout and "foreign file" in r.stdout, r.stdout + r.stderr[-800:]
