@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--calibration-deadline", type=float, default=float(os.environ.get("FLASHE_BENCH_CALIBRATION_DEADLINE_S", "150")),
                     help="N > 1: seconds the optional overlapped schedules (calibration + their timed region) may take; when it passes, or "
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
+    ap.add_argument("--no-span-bounds", action="store_true",
+                    help="config 5: let the sparse aggregate and the sparse decrypt each compute the span bounds of the location lists "
+                         "(the round-3 form) instead of computing them once per round")
     ap.add_argument("--no-element-sharded", action="store_true",
                     help="N > 1: skip the second partition (elements instead of clients sharded over the GPUs, SURVEY.md 8e (i)) that is timed "
                          "after the main line and reported beside it as value_element_sharded")
@@ -1157,6 +1160,10 @@ def bench_sparse(args, total, ops, rank, world, out):
     d_ct = [eng.alloc_vec(k) for _ in range(C)]
     d_agg, d_dec = eng.alloc_vec(total), eng.alloc_vec(total)
     ev = [[eng.event() for _ in range(4)] for _ in range(K)]
+    # the span bounds of the round's location lists (where every list enters every span of the dense vector): computed ONCE per round
+    # and shared by the sparse aggregate and the sparse decrypt (round 4; both used to run that pass on the same lists)
+    use_bounds = L == 2 and not args.no_span_bounds
+    bounds = eng.span_bounds(total, d_loc, [k] * C) if use_bounds else None
 
     def step(it, kk=None):
         if kk is not None:
@@ -1164,10 +1171,12 @@ def bench_sparse(args, total, ops, rank, world, out):
         eng.encrypt_batch_dev(it, list(range(C)), SCHEME_SINGLE, k, J, d_val, 1, d_ct)
         if kk is not None:
             eng.record(ev[kk][1])
-        eng.sparse_aggregate_dev(total, d_loc, [k] * C, d_ct, [zero] * C, d_agg, sorted_lists=True)
+        if bounds is not None:
+            bounds.recompute(d_loc, [k] * C)             # a real job has new lists every round: the pass is part of the step
+        eng.sparse_aggregate_dev(total, d_loc, [k] * C, d_ct, [zero] * C, d_agg, sorted_lists=True, bounds=bounds)
         if kk is not None:
             eng.record(ev[kk][2])
-        eng.sparse_decrypt_dev(it, d_loc, [k] * C, total, J, d_agg, d_dec, sorted_lists=True)    # dense minus-mask built and subtracted in one pass
+        eng.sparse_decrypt_dev(it, d_loc, [k] * C, total, J, d_agg, d_dec, sorted_lists=True, bounds=bounds)    # dense minus-mask built and subtracted in one pass
         if kk is not None:
             eng.record(ev[kk][3])
 
@@ -1187,8 +1196,15 @@ def bench_sparse(args, total, ops, rank, world, out):
         return None
     ph = np.array([[eng.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in ev])
     agg_ms = float(ph[:, 1].mean())
+    enc_ms = float(ph[:, 0].mean())
     alg_bytes = C * k * (4 + 8 * L) + total * 8 * L
     achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
+    # the launch that dominates the round BY TIME is the PRF chain of the compact single-mask streams (the encrypt phase is exactly one
+    # such launch; the decrypt phase contains another one): `roofline` describes it, `roofline_sparse_aggregate` the span reduce
+    m = 1 if L == 2 else 128 // b
+    prf_bytes = C * k * (8 + 8 * L)
+    prf_blocks = C * ((k + m - 1) // m)
+    prf_achieved = prf_bytes / (enc_ms * 1e-3) / 1e9
     out.update({
         "value": world * C * k / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
         "config": {"workload": f"BASELINE config 5: top-1 % sparsified gradient (k={k} of {total} positions, u32 index + {8 * L}-byte value), {C} clients, "
@@ -1197,9 +1213,20 @@ def bench_sparse(args, total, ops, rank, world, out):
                                + ("; independent replicas per GPU" if world > 1 else ""),
                    "n": total, "k": k, "int_bits": b, "clients_total": C, "mask": "single (sparse)",
                    "parity": "bit-exact (dense round trip + one client's ciphertext vs the oracle, checked in-run)"},
-        "roofline": {"kernel": "span_reduce_kernel (fused sparse aggregate: LDS-staged spans, dense vector written once)",
-                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                     "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms, "launches_timed": K},
+        "roofline": {"kernel": (f"prf_chain_kernel<1024> ({C} single-mask streams over compact positions: the {C} clients' encrypts in one launch; "
+                                "the same launch shape generates the decrypt's minus-mask streams)") if L == 2 else
+                               f"prf_small_chain_kernel ({C} single-mask streams over compact positions)",
+                     "kernel_key": "prf_chain_kernel" if L == 2 else "prf_small_chain_kernel",
+                     "bound": "lds", "achieved": prf_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": prf_achieved / HBM_PEAK_GBPS,
+                     "traffic": None, "algorithmic_bytes_per_launch": prf_bytes, "avg_launch_ms": enc_ms, "launches_timed": K,
+                     "aes_blocks_per_launch": prf_blocks, "aes_blocks_per_s": prf_blocks / (enc_ms * 1e-3),
+                     "note": "the round's dominant launch by time (encrypt phase = one such launch, the decrypt phase holds a second one); "
+                             "AES-rate (LDS lookup) bound, `frac` is its HBM fraction as required"},
+        "roofline_sparse_aggregate": {"kernel": "span_reduce_kernel (fused sparse aggregate: LDS-staged spans, dense vector written once)",
+                                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms,
+                                      "note": "phase = span bounds of the round's lists (once, shared with the decrypt) + the span reduce"},
+        "span_bounds": "computed once per round, shared by aggregate and decrypt" if bounds is not None else "computed by each of the two passes",
         "phases_ms": {"encrypt_xC": float(ph[:, 0].mean()), "sparse_aggregate": agg_ms, "minus_mask_plus_decrypt": float(ph[:, 2].mean())},
     })
     return out

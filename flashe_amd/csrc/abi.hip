@@ -1560,10 +1560,98 @@ int flashe_expand_to_dense_dev(flashe_ctx *ctx, uint64_t total, uint64_t k, cons
     return FLASHE_OK;
 }
 
+// ---- span bounds of a round's location lists, computed once (new) ----
+struct flashe_span_bounds {
+    int device = 0, C = 0;
+    uint64_t total = 0;
+    std::vector<const uint32_t *> loc;
+    std::vector<uint64_t> k;
+    uint32_t *start = nullptr;           // per group of kMaxScatter clients: (span_count(total) + 1) * group words
+    size_t group_stride = 0;             // words between two groups' tables
+};
+
+int flashe_span_bounds_create(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k, flashe_span_bounds **out)
+{
+    CHECK_CTX(ctx);
+    if (!out) return fail(ctx, FLASHE_EINVAL, "null output");
+    *out = nullptr;
+    if (C < 1 || !loc_dev || !k) return fail(ctx, FLASHE_EINVAL, "span_bounds_create: bad arguments");
+    if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "span_bounds_create allocates: not capturable");
+    for (int c = 0; c < C; c++) {
+        if (k[c] && !loc_dev[c]) return fail(ctx, FLASHE_EINVAL, "client %d: null list", c);
+        if (k[c] > total || k[c] >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "client %d: more locations than positions", c);
+    }
+    auto *b = new flashe_span_bounds;
+    b->device = ctx->device; b->C = C; b->total = total;
+    b->loc.assign(loc_dev, loc_dev + C); b->k.assign(k, k + C);
+    const int group = std::min(C, kMaxScatter), groups = (C + kMaxScatter - 1) / kMaxScatter;
+    b->group_stride = (span_count(total) + 1) * static_cast<size_t>(group);
+    const hipError_t e = hipMalloc(&b->start, std::max<size_t>(b->group_stride * groups * sizeof(uint32_t), 16));
+    if (e != hipSuccess) { delete b; return fail(ctx, e == hipErrorOutOfMemory ? FLASHE_ENOMEM : FLASHE_EIO, "hipMalloc: %s", hipGetErrorString(e)); }
+    for (int g = 0; g < groups; g++) {
+        const int c0 = g * kMaxScatter, nc = std::min(kMaxScatter, C - c0);
+        const hipError_t le = launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, b->start + g * b->group_stride);
+        if (le != hipSuccess) { (void)hipFree(b->start); delete b; HIP_TRY(ctx, le); }
+    }
+    *out = b;
+    return FLASHE_OK;
+}
+
+// the same handle for the NEXT round's lists (same total and C: a job's shape): recomputes the table in place, no allocation
+int flashe_span_bounds_recompute(flashe_ctx *ctx, flashe_span_bounds *b, const uint32_t *const *loc_dev, const uint64_t *k)
+{
+    CHECK_CTX(ctx);
+    if (!b || !loc_dev || !k) return fail(ctx, FLASHE_EINVAL, "span_bounds_recompute: bad arguments");
+    if (b->device != ctx->device) return fail(ctx, FLASHE_EINVAL, "the handle belongs to another device");
+    for (int c = 0; c < b->C; c++) {
+        if (k[c] && !loc_dev[c]) return fail(ctx, FLASHE_EINVAL, "client %d: null list", c);
+        if (k[c] > b->total || k[c] >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "client %d: more locations than positions", c);
+    }
+    b->loc.assign(loc_dev, loc_dev + b->C); b->k.assign(k, k + b->C);
+    for (int c0 = 0, g = 0; c0 < b->C; c0 += kMaxScatter, g++)
+        HIP_TRY(ctx, launch_span_bounds(ctx->env, std::min(kMaxScatter, b->C - c0), loc_dev + c0, k + c0, b->total, b->start + g * b->group_stride));
+    return FLASHE_OK;
+}
+
+void flashe_span_bounds_destroy(flashe_span_bounds *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->start) (void)hipFree(b->start);
+    delete b;
+}
+
+// the handle must describe exactly the lists of this call
+static int check_bounds(flashe_ctx *ctx, const flashe_span_bounds *b, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k)
+{
+    if (!b) return FLASHE_OK;
+    if (b->device != ctx->device || b->total != total || b->C != C) return fail(ctx, FLASHE_EINVAL, "the span bounds were computed for another set of lists (total / C differ)");
+    for (int c = 0; c < C; c++)
+        if (b->loc[c] != loc_dev[c] || b->k[c] != k[c]) return fail(ctx, FLASHE_EINVAL, "the span bounds were computed for another list of client %d", c);
+    return FLASHE_OK;
+}
+
+static int sparse_aggregate_impl(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                 const uint64_t *const *vals_dev, const uint64_t *zeros, int sorted, const flashe_span_bounds *bounds, uint64_t *out_dev);
+
 int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                                 const uint64_t *const *vals_dev, const uint64_t *zeros, int sorted, uint64_t *out_dev)
 {
+    return sparse_aggregate_impl(ctx, total, C, loc_dev, k, vals_dev, zeros, sorted, nullptr, out_dev);
+}
+
+int flashe_sparse_aggregate_bounds_dev(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                       const uint64_t *const *vals_dev, const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t *out_dev)
+{
+    if (!bounds) return ctx ? fail(ctx, FLASHE_EINVAL, "null bounds handle") : FLASHE_EINVAL;
+    return sparse_aggregate_impl(ctx, total, C, loc_dev, k, vals_dev, zeros, 1, bounds, out_dev);
+}
+
+static int sparse_aggregate_impl(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                 const uint64_t *const *vals_dev, const uint64_t *zeros, int sorted, const flashe_span_bounds *bounds, uint64_t *out_dev)
+{
     CHECK_CTX(ctx);
+    { const int brc = C > 0 && loc_dev && k ? check_bounds(ctx, bounds, total, C, loc_dev, k) : FLASHE_OK; if (brc) return brc; }
     if (C < 0 || (C && (!loc_dev || !k || !vals_dev || !zeros)) || (total && !out_dev)) return fail(ctx, FLASHE_EINVAL, "bad arguments");
     if (ctx->limbs == 2 && !aligned16(out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
     const int L = ctx->limbs;
@@ -1580,13 +1668,14 @@ int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const ui
     // after the other because their location sets overlap
     if (sorted && C > 0) {
         // strictly increasing location lists: LDS-staged span reduce, the dense output is written exactly once
-        int rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(std::min(C, kMaxScatter)) * sizeof(uint32_t));
+        int rc = bounds ? FLASHE_OK : ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(std::min(C, kMaxScatter)) * sizeof(uint32_t));
         if (rc) return rc;
         for (int c0 = 0; c0 < C; c0 += kMaxScatter) {
             const int nc = std::min(kMaxScatter, C - c0);
+            uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
             HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, vals_dev + c0, k + c0, zeros + static_cast<size_t>(L) * c0,
                                             c0 ? 0 : static_cast<uint64_t>(zsum), c0 ? 0 : static_cast<uint64_t>(zsum >> 64), total,
-                                            static_cast<uint32_t *>(ctx->bounds.p), c0 != 0 ? out_dev : nullptr, false, out_dev));
+                                            start, c0 != 0 ? out_dev : nullptr, false, out_dev, bounds != nullptr));
         }
         return FLASHE_OK;
     }
@@ -1600,10 +1689,12 @@ int flashe_sparse_aggregate_dev(flashe_ctx *ctx, uint64_t total, int C, const ui
 // agg_dev == nullptr: out = the dense minus-mask.  agg_dev given: out = (agg - minus-mask) mod 2^b, the single-mask decrypt
 // (jzf_flashe.py:531-532) in the pass that builds the mask.
 static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
-                                  uint64_t total, uint32_t n_jobs, bool sorted, const uint64_t *agg_dev, uint64_t *out_dev)
+                                  uint64_t total, uint32_t n_jobs, bool sorted, const uint64_t *agg_dev, uint64_t *out_dev,
+                                  const flashe_span_bounds *bounds = nullptr)
 {
     CHECK_CTX(ctx);
     if (C < 0 || (C && (!loc_dev || !k)) || (total && !out_dev) || n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "bad arguments");
+    { const int brc = C > 0 ? check_bounds(ctx, bounds, total, C, loc_dev, k) : FLASHE_OK; if (brc) return brc; }
     if (ctx->limbs == 2 && (!aligned16(out_dev) || !aligned16(agg_dev))) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
     uint64_t kmax = 0;
     for (int c = 0; c < C; c++) {
@@ -1621,7 +1712,7 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
         const int group = std::min(C, kMaxScatter);          // clients whose streams are held at once
         int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kpad) * static_cast<size_t>(std::max(group, 1)));
         if (rc) return rc;
-        if (sorted && C > 0 && (rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(group) * sizeof(uint32_t)))) return rc;
+        if (sorted && C > 0 && !bounds && (rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(group) * sizeof(uint32_t)))) return rc;
         uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
         for (int c0 = 0; c0 < C; c0 += group) {
             const int nc = std::min(group, C - c0);
@@ -1633,8 +1724,9 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
             }
             HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nc, jobs, kmax, n_jobs));
             if (sorted) {
+                uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
                 HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, streams, k + c0, nullptr, 0, 0, total,
-                                                static_cast<uint32_t *>(ctx->bounds.p), c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev));
+                                                start, c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev, bounds != nullptr));
             } else {
                 for (int e = 0; e < nc; e++)
                     HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c0 + e], loc_dev[c0 + e], streams[e], out_dev, true));
@@ -1674,6 +1766,17 @@ int flashe_sparse_decrypt_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint3
     CHECK_CTX(ctx);
     if (total && (!agg_dev || agg_dev == out_dev)) return fail(ctx, FLASHE_EINVAL, "the aggregate must be given and must not be the output vector");
     return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, sorted != 0, agg_dev, out_dev);
+}
+
+int flashe_sparse_decrypt_bounds_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total,
+                                     uint32_t n_jobs, const flashe_span_bounds *bounds, const uint64_t *agg_dev, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (!bounds) return fail(ctx, FLASHE_EINVAL, "null bounds handle");
+    if (total && (!agg_dev || agg_dev == out_dev)) return fail(ctx, FLASHE_EINVAL, "the aggregate must be given and must not be the output vector");
+    if (!(ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE)) || std::min(C, kMaxScatter) != std::min(bounds->C, kMaxScatter))
+        return fail(ctx, FLASHE_EINVAL, "sparse_decrypt_bounds needs int_bits > 64 on the table PRF (the span reduce is what consumes the bounds)");
+    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, true, agg_dev, out_dev, bounds);
 }
 
 int flashe_sparse_double_masks_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total,

@@ -179,9 +179,12 @@ hipError_t launch_scatter(const LaunchEnv &env, uint64_t total, uint64_t k, cons
 // start_dev = (span_count(total) + 1) * C words of scratch.
 constexpr int kMaxScatter = 64;
 uint64_t span_count(uint64_t total);
+// (bounds_ready: start_dev already holds the bounds of exactly these lists -- launch_span_bounds -- and the pass that computes them is skipped)
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
-                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev);
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready = false);
+// the first list entry of each of the C <= kMaxScatter clients in every span: (span_count(total) + 1) * C words
+hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev);
 // Sparse + double mask (jzf_flashe.py:388-426, :155-225): compact (add, minus) mask values of a group of nc <= kMaxScatter clients
 // c0 .. c0 + nc - 1 at their own sorted locations -- entry q of client c gets term(c + 1, p) unless client c + 1 holds p, and
 // term(c, p) unless client c - 1 holds p (dense-position counters, one chunk).  loc / k carry nc + 2 entries: the group's lists

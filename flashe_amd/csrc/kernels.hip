@@ -3337,9 +3337,25 @@ uint64_t span_count(uint64_t total) { return (total + kSpan - 1) / kSpan; }
 // out[p] = from[p] +/- sum over clients c and entries q with loc[c][q] == p of (vals[c][q] - sub[c])   (mod 2^b), every p < total,
 // from = src_dev when given (may be out_dev), the constant base otherwise; loc[c] strictly increasing.
 // start_dev: (span_count(total) + 1) * C words of scratch.
+hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev)
+{
+    if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    ScatterTable tb{};
+    uint64_t kmax = 0;
+    for (int c = 0; c < C; c++) {
+        if (k[c] >= (1ull << 32)) return hipErrorInvalidValue;
+        tb.loc[c] = loc_dev[c]; tb.k[c] = k[c];
+        kmax = std::max(kmax, k[c]);
+    }
+    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0,
+                       env.stream, tb, C, span_count(total), total, start_dev, env.err_flag);
+    return hipGetLastError();
+}
+
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
-                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev)
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready)
 {
     if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
     if (total == 0) return hipSuccess;
@@ -3356,8 +3372,9 @@ hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
     const uint64_t n_spans = span_count(total);
-    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0,
-                       env.stream, tb, C, n_spans, total, start_dev, env.err_flag);
+    if (!bounds_ready)
+        hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0,
+                           env.stream, tb, C, n_spans, total, start_dev, env.err_flag);
     hipLaunchKernelGGL((span_reduce_kernel<kSpan, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
                        start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
     return hipGetLastError();

@@ -375,6 +375,35 @@ class Graph:
             pass
 
 
+class SpanBounds:
+    """flashe_span_bounds: where every client's strictly increasing location list enters every span of the dense vector, computed once
+    per round's lists (the lists must stay as they are while the handle is used; it keeps them alive)."""
+
+    def __init__(self, engine, total, locs, ks):
+        self.engine, self._keep = engine, list(locs)
+        p, _k = engine._ptr_array(locs)
+        kk = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        h = c_vp()
+        engine._check(engine._lib.flashe_span_bounds_create(engine._h, int(total), len(locs), p, ctypes.cast(kk, c_u64p), ctypes.byref(h)))
+        self._h = h.value
+
+    def recompute(self, locs, ks):
+        """The table for the next round's lists (same number of clients, same total), in place."""
+        p, _k = self.engine._ptr_array(locs)
+        kk = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        self.engine._check(self.engine._lib.flashe_span_bounds_recompute(self.engine._h, self._h, p, ctypes.cast(kk, c_u64p)))
+        self._keep = list(locs)
+        return self
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.engine._lib.flashe_span_bounds_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 class Engine:
     """One device context of the cipher engine (wraps flashe_ctx)."""
 
@@ -672,10 +701,15 @@ class Engine:
         self._check(self._lib.flashe_expand_to_dense_dev(self._h, total, k, self._ptr(loc), self._ptr(vals),
                                                          ctypes.cast(z, c_u64p), self._ptr(out)))
 
-    def sparse_aggregate_dev(self, total, locs, ks, vals, zeros, out, sorted_lists=False):
+    def span_bounds(self, total, locs, ks):
+        """The span bounds of a round's strictly increasing location lists, computed once: a SpanBounds handle that
+        sparse_aggregate_dev / sparse_decrypt_dev take (bounds=...) instead of recomputing the table for the same lists."""
+        return SpanBounds(self, total, locs, ks)
+
+    def sparse_aggregate_dev(self, total, locs, ks, vals, zeros, out, sorted_lists=False, bounds=None):
         """out = sum over clients of expand_to_dense(total, locs[c], vals[c], zeros[c]) mod 2^b, without the dense
         intermediates.  zeros: per client a sequence of L limbs (or an int).  sorted_lists: every location list is
-        strictly increasing (one-pass LDS-staged form)."""
+        strictly increasing (one-pass LDS-staged form).  bounds: a SpanBounds of exactly these lists (implies sorted_lists)."""
         pl, _kl = self._ptr_array(locs)
         pv, _kv = self._ptr_array(vals)
         k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
@@ -684,6 +718,10 @@ class Engine:
             z = [int(z) & (2 ** 64 - 1), int(z) >> 64] if isinstance(z, int) else [int(v) for v in z] + [0]
             flat += z[:self.limbs]
         zz = (c_u64 * max(len(flat), 1))(*flat)
+        if bounds is not None:
+            self._check(self._lib.flashe_sparse_aggregate_bounds_dev(self._h, total, len(locs), pl, ctypes.cast(k, c_u64p), pv,
+                                                                     ctypes.cast(zz, c_u64p), bounds._h, self._ptr(out)))
+            return
         self._check(self._lib.flashe_sparse_aggregate_dev(self._h, total, len(locs), pl, ctypes.cast(k, c_u64p), pv,
                                                           ctypes.cast(zz, c_u64p), 1 if sorted_lists else 0, self._ptr(out)))
 
@@ -693,10 +731,14 @@ class Engine:
         fn = self._lib.flashe_sparse_minus_mask_sorted_dev if sorted_lists else self._lib.flashe_sparse_minus_mask_dev
         self._check(fn(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, self._ptr(out)))
 
-    def sparse_decrypt_dev(self, it, locs, ks, total, n_jobs, agg, out, sorted_lists=False):
+    def sparse_decrypt_dev(self, it, locs, ks, total, n_jobs, agg, out, sorted_lists=False, bounds=None):
         """out = (agg - dense minus-mask of the location lists) mod 2^b in the pass that builds the mask."""
         p, _keep = self._ptr_array(locs)
         k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        if bounds is not None:
+            self._check(self._lib.flashe_sparse_decrypt_bounds_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, bounds._h,
+                                                                   self._ptr(agg), self._ptr(out)))
+            return
         self._check(self._lib.flashe_sparse_decrypt_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs,
                                                         1 if sorted_lists else 0, self._ptr(agg), self._ptr(out)))
 

@@ -403,6 +403,24 @@ int flashe_sparse_minus_mask_sorted_dev(flashe_ctx *ctx, uint32_t iter, int C, c
  * new: fusion of two reference steps. */
 int flashe_sparse_decrypt_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                               uint64_t total, uint32_t n_jobs, int sorted, const uint64_t *agg_dev, uint64_t *out_dev);
+/* Span bounds of a round's location lists, computed ONCE (new).  The LDS-staged sparse reduce cuts the dense vector into spans and
+ * first finds, for every span, where each client's (strictly increasing) list enters it -- a pass over all lists that the sparse
+ * aggregate and the sparse decrypt of one round would otherwise both run on the same lists.  flashe_span_bounds_create computes the
+ * table for C lists (any C) asynchronously on the ctx stream; the *_bounds_dev calls take it instead of recomputing; the handle is valid
+ * for exactly these list pointers / lengths / total (checked) and until flashe_span_bounds_destroy.  The lists must not change
+ * while a handle built on them is in use. */
+typedef struct flashe_span_bounds flashe_span_bounds;
+int flashe_span_bounds_create(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                              flashe_span_bounds **out);
+/* the same handle for the next round's lists (same total and C): recomputed in place, asynchronously, without an allocation */
+int flashe_span_bounds_recompute(flashe_ctx *ctx, flashe_span_bounds *bounds, const uint32_t *const *loc_dev, const uint64_t *k);
+void flashe_span_bounds_destroy(flashe_span_bounds *bounds);
+int flashe_sparse_aggregate_bounds_dev(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                       const uint64_t *const *vals_dev, const uint64_t *zeros, const flashe_span_bounds *bounds,
+                                       uint64_t *out_dev);
+int flashe_sparse_decrypt_bounds_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                     uint64_t total, uint32_t n_jobs, const flashe_span_bounds *bounds, const uint64_t *agg_dev,
+                                     uint64_t *out_dev);
 int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc,
                              const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out);
 /* Dense-position selected masks -- _static_prepare_decrypt_spar as ONE chunk

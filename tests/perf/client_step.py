@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""A client's step on a ResNet-50-sized model (25.5 M fp32 parameters as 161 layers of realistic sizes): the reference's call chain
-quantize(weights) -> weights.encrypted(cipher) through the mirror (object arrays between the two calls, as the reference has them)
-against FlasheClient.quantize_encrypt (layer up once, draws on the device, one launch per layer), and the way back."""
+"""A client's step on a ResNet-50-sized model (25.5 M fp32 parameters as 56 layers of realistic sizes): the reference JOB's call chain
+quantize(weights) -> flatten_weights -> weights.encrypted(cipher) (jzf_aggregator.py:721-741) through the mirror call by call (object
+arrays between the calls, as the reference has them) against FlasheClient.quantize_encrypt (every layer up once into one flat device
+buffer, draws on the device, ONE launch over the flattened model with a per-layer alpha table), and the way back.  Also counts the
+kernel launches of the fused step (rocprofv3 --kernel-trace --stats -- python3 tests/perf/client_step.py fused-only)."""
 import os
 import sys
 import time
@@ -35,7 +37,10 @@ def client():
     return cl
 
 
-for name in ("fused, device handles", "fused, host arrays", "two calls (object arrays in between, the reference's format)"):
+names = ("fused, device handles", "fused, host arrays", "call by call (object arrays in between, the reference's format)")
+if "fused-only" in sys.argv:
+    names = names[:1]
+for name in names:
     cl = client()
     best = 1e9
     for rep in range(3 if name.startswith("fused") else 1):
@@ -46,9 +51,9 @@ for name in ("fused, device handles", "fused, host arrays", "two calls (object a
             out = cl.quantize_encrypt(w, device=name.endswith("handles"))
             cl.cipher.engine.sync()
         else:
-            out = cl.quantize(w)
-            for k in out.walking_order:
-                out._weights[k] = cl.encrypt(np.asarray(out._weights[k]).reshape(-1))
+            out = cl.flatten_weights(cl.quantize(w))
+            k0 = out.walking_order[0]
+            out._weights[k0] = cl.encrypt(out._weights[k0])
         best = min(best, time.perf_counter() - t0)
         del out
     print(f"{name:62s}: {best * 1e3:9.1f} ms for {len(sizes)} layers, {total} parameters", flush=True)
@@ -67,17 +72,19 @@ if "--profile" in sys.argv:                 # where the host time of the fused s
     pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(14)
 
-# the way back: the aggregate of C such models (here: C copies of this client's ciphertexts) decrypted and unquantised
+# the way back: the aggregate of C such models (here: C copies of this client's flattened ciphertext) decrypted and unquantised
 cl = client()
 w = W({k: v.copy() for k, v in layers.items()})
 np.random.seed(1)
 enc = cl.quantize_encrypt(w, device=True)
-agg = W({k: cl.cipher.aggregate([enc._weights[k]] * C) for k in enc.walking_order})
+k0 = enc.walking_order[0]
+agg = cl.cipher.aggregate([enc._weights[k0]] * C)
 cl.cipher.set_idx_list(raw_idx_list=list(range(1)) * C, mode="decrypt")
 best = 1e9
 for rep in range(3):
-    a2 = W(dict(agg._weights))
+    a2 = W({k0: agg})
     t0 = time.perf_counter()
     back = cl.decrypt_unquantize(a2)
     best = min(best, time.perf_counter() - t0)
-print(f"{'decrypt_unquantize of the aggregate (handles in, float64 layers out)':62s}: {best * 1e3:9.1f} ms", flush=True)
+assert sorted(back._weights) == sorted(layers) and all(back._weights[k].shape == layers[k].shape for k in layers)
+print(f"{'decrypt_unquantize of the aggregate (handle in, float64 layers out)':62s}: {best * 1e3:9.1f} ms", flush=True)

@@ -1587,3 +1587,37 @@ def test_arbiter_reduce_runs_unchanged_on_device_handles(oracle, b):
     assert sum(m._weights["flat"] for m in models) is not None            # sum() starts from 0
     with pytest.raises(ValueError):
         _ = got % (mod + 2)
+
+
+def test_span_bounds_handle_shared_by_aggregate_and_decrypt(E, oracle):
+    """flashe_span_bounds_*: the span bounds of a round's location lists computed once and handed to the sparse aggregate AND the sparse
+    decrypt -- the same dense vectors as when each pass computes them itself; more clients than one group holds; recompute for the next
+    round's lists; a handle used with other lists is refused."""
+    from flashe_amd._lib import FlasheError
+    eng = make(E, 128)
+    rng = np.random.Generator(np.random.PCG64(4))
+    for C, total, k in [(5, 100_003, 2_000), (70, 50_000, 300), (1, 9_000, 9_000)]:
+        locs = [np.sort(rng.choice(total, k, replace=False)).astype(np.uint32) for _ in range(C)]
+        vals = [rng.integers(0, 2 ** 63, (k, 2), dtype=np.uint64) for _ in range(C)]
+        dl, dv = [eng.upload(l) for l in locs], [eng.upload(v) for v in vals]
+        zeros = [7 + c for c in range(C)]
+        a0, a1, d0, d1 = (eng.alloc_vec(total) for _ in range(4))
+        eng.sparse_aggregate_dev(total, dl, [k] * C, dv, zeros, a0, sorted_lists=True)
+        eng.sparse_decrypt_dev(3, dl, [k] * C, total, 16, a0, d0, sorted_lists=True)
+        bnd = eng.span_bounds(total, dl, [k] * C)
+        eng.sparse_aggregate_dev(total, dl, [k] * C, dv, zeros, a1, bounds=bnd)
+        eng.sparse_decrypt_dev(3, dl, [k] * C, total, 16, a1, d1, bounds=bnd)
+        assert np.array_equal(a0.download(np.uint64, 2 * total), a1.download(np.uint64, 2 * total)), (C, total, k, "aggregate")
+        assert np.array_equal(d0.download(np.uint64, 2 * total), d1.download(np.uint64, 2 * total)), (C, total, k, "decrypt")
+        want = oracle.sparse_minus_mask(KEY, 3, locs, total, 16, 128)
+        agg = a0.download(np.uint64, 2 * total).reshape(total, 2)
+        assert np.array_equal(d1.download(np.uint64, 2 * total).reshape(total, 2), oracle.combine(128, agg, None, want))
+        # next round: other lists, the handle recomputed in place
+        locs2 = [np.sort(rng.choice(total, k, replace=False)).astype(np.uint32) for _ in range(C)]
+        dl2 = [eng.upload(l) for l in locs2]
+        with pytest.raises(FlasheError):
+            eng.sparse_aggregate_dev(total, dl2, [k] * C, dv, zeros, a1, bounds=bnd)       # bounds of OTHER lists: refused
+        bnd.recompute(dl2, [k] * C)
+        eng.sparse_aggregate_dev(total, dl2, [k] * C, dv, zeros, a1, bounds=bnd)
+        eng.sparse_aggregate_dev(total, dl2, [k] * C, dv, zeros, a0, sorted_lists=True)
+        assert np.array_equal(a0.download(np.uint64, 2 * total), a1.download(np.uint64, 2 * total)), (C, "recomputed")
