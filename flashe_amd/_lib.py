@@ -39,6 +39,12 @@ class CodecLayer(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class BatchLayer(ctypes.Structure):
+    """flashe_batch_layer of include/flashe.h."""
+    _fields_ = [("size", ctypes.c_uint64), ("x_dev", ctypes.c_void_p), ("alpha", ctypes.c_double), ("x_is_f64", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
 class FlasheError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"flashe error {code}: {msg}")
@@ -148,6 +154,8 @@ _SIGNATURES = {
     "flashe_sparse_dense_mask": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_quantize_encrypt_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_vp, c_int, ctypes.c_double, c_int, c_vp, c_vp]),
     "flashe_decrypt_unquantize_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_vp, ctypes.c_double, c_int, c_int, c_vp]),
+    "flashe_quantize_batch_model_dev": (c_int, [c_vp, ctypes.POINTER(BatchLayer), c_int, c_int, c_int, c_vp, c_u64, c_vp]),
+    "flashe_unbatch_unquantize_model_dev": (c_int, [c_vp, ctypes.POINTER(BatchLayer), c_int, c_int, c_int, c_int, c_vp, c_u64, c_vp]),
     "flashe_quantize_encrypt_model_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_u64, c_u64, ctypes.POINTER(CodecLayer), c_int, c_int, c_vp, c_vp]),
     "flashe_decrypt_unquantize_model_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_vp,
                                                     ctypes.POINTER(CodecLayer), c_int, c_int, c_int, c_vp]),

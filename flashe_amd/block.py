@@ -62,6 +62,7 @@ class FlasheClient(object):
         self.cipher = None
         self.quantizer = None
         self.shape_dict = None           # layer shapes of the flattened model (what the aggregator-side Client keeps, jzf_aggregator.py:648)
+        self.fuse = True                 # False: quantize_encrypt / decrypt_unquantize run the reference's sequence call by call
         self._device = device
 
     def create_cipher(self, idx, num_clients, prp_seed):
@@ -155,7 +156,7 @@ class FlasheClient(object):
     # ---- the client step with nothing on the host in between (new) ------------------------------------------------------------
     def _fusable(self, weights=None):
         c = self.cipher
-        return (not self.batch and c.masks is None and c.prp_seed is not None and not c.next_iter_encrypt_prepared
+        return (self.fuse and c.masks is None and c.prp_seed is not None and not c.next_iter_encrypt_prepared
                 and hasattr(c.engine, "quantize_encrypt_model_dev") and (weights is None or "zzz" not in weights._weights))
 
     def quantize_encrypt(self, weights, device=True):
@@ -169,8 +170,10 @@ class FlasheClient(object):
         device table).  Bit-identical to the reference's sequence with the same seed (tests/golden/clientstep.json).
         The result has the reference's form: one key (the first of the walking order) holding the flattened ciphertext -- a
         DeviceVector (device=True: it stays in HBM for `aggregate`) or uint64 limbs [n, L]; `self.shape_dict` keeps the shapes for
-        `decrypt_unquantize`.  Batched quantisation, sparse jobs (masks, the 'zzz' layer) and precomputed encrypt masks take the same
-        sequence call by call on the host and return object arrays like the reference."""
+        `decrypt_unquantize`.  BATCHED jobs ("batch": true, several quantised values per ciphertext element, every layer padded to whole
+        elements on its own: jzf_quantize.py:436-451, :162-185) are two launches: quantise + batch of the whole model
+        (flashe_quantize_batch_model_dev), then the encrypt of the flattened batched vector.  Sparse jobs (masks, the 'zzz' layer) and
+        precomputed encrypt masks take the same sequence call by call on the host and return object arrays like the reference."""
         from . import cipher as _cipher_mod
         from .engine import DeviceVector
         from .quantize import ACIQ, DEVICE_RNG_MIN, _loop_dtype
@@ -219,12 +222,34 @@ class FlasheClient(object):
         xbuf = eng.alloc(max(nbytes, 16))
         for flat, off in zip(host, offs):
             xbuf.upload_at(off, flat)
+        dev_rng = os.environ.get("FLASHE_DEVICE_RNG", "1") != "0" and np.random.get_state()[0] == "MT19937"
+        if self.batch:
+            # quantise + batch of the whole model in ONE launch (per-layer alpha, per-layer zero padding), then the encrypt of the flattened
+            # batched vector: the draws are one stretch of NumPy's stream over all VALUES in walking order
+            factor = int(np.ceil(np.log2(q.num_clients)))
+            field_bits = q.element_bits + factor
+            bs = self.int_bits // field_bits
+            q.shape_list = [shape_dict[k] for k in order]
+            n_elems = sum((int(h.size) + bs - 1) // bs for h in host)
+            du = (eng.numpy_random_dev(n) if dev_rng and n >= DEVICE_RNG_MIN else eng.upload(np.random.random(n))) if n else eng.alloc(16)
+            pt = eng.alloc_vec(max(n_elems, 1))
+            eng.quantize_batch_model_dev([(int(host[li].size), xbuf.ptr + offs[li], q.alpha_list[li], host[li].dtype == np.float64)
+                                          for li in range(len(order))], q.element_bits, field_bits, du, n_elems, pt)
+            ct = DeviceVector(eng, n_elems)
+            if n_elems:
+                eng.encrypt_dev(c.iter_index, c.idx, scheme, n_elems, _cipher_mod.N_JOBS, pt, eng.limbs, ct.buf)
+            for k in order:
+                del weights._weights[k]
+            self.shape_dict = {k: ((int(h.size) + bs - 1) // bs,) for k, h in zip(order, host)}      # the batched layers are 1-D (:448)
+            if order:
+                weights._weights[order[0]] = ct.mark_ready() if device else ct.to_host()
+            weights.walking_order = sorted(weights._weights.keys(), key=str)
+            return weights
         table = [(starts[li], xbuf.ptr + offs[li], q.alpha_list[li], host[li].dtype == np.float64) for li in range(len(order))]
         ct = DeviceVector(eng, n)
         # the draws of consecutive layers are ONE stretch of NumPy's stream (np.random.random(layer.shape) per layer in walking order,
         # jzf_quantize.py:55-67 under :417-462), i.e. flat element j takes draw j: a run of whole layers is drawn by one device call and
         # quantised + encrypted by one launch over its range.  Runs are capped so the draws of a huge model stay bounded.
-        dev_rng = os.environ.get("FLASHE_DEVICE_RNG", "1") != "0" and np.random.get_state()[0] == "MT19937"
         at = 0
         while at < len(order):
             end, tot = at, 0
@@ -255,7 +280,7 @@ class FlasheClient(object):
         from . import cipher as _cipher_mod
         from .engine import DeviceVector
         q, c = self.quantizer, self.cipher
-        fus = (not self.batch and c.masks is None and c.prp_seed is not None and not c.next_iter_decrypt_prepared
+        fus = (self.fuse and c.masks is None and c.prp_seed is not None and not c.next_iter_decrypt_prepared
                and hasattr(c.engine, "decrypt_unquantize_model_dev"))
         k0 = weights.walking_order[0]
         if not fus:
@@ -277,6 +302,30 @@ class FlasheClient(object):
         dv, _kind = c._on_device(v, full_width=True)
         dv = c._as_wide(dv)                       # (a compact uint32 aggregate: the fused launch reads one-limb vectors)
         n = len(dv)
+        if self.batch:
+            # decrypt of the flattened batched vector, then unbatch + `[:size]` + unquantise of every layer in ONE launch
+            factor = int(np.ceil(np.log2(q.num_clients)))
+            field_bits = q.element_bits + factor
+            bs = self.int_bits // field_bits
+            names = list(self.shape_dict)
+            sizes = [int(np.prod(shape)) for shape in q.shape_list]
+            if sum((s_ + bs - 1) // bs for s_ in sizes) != n:
+                raise ValueError(f"the aggregate has {n} elements, the batched layers describe {sum((s_ + bs - 1) // bs for s_ in sizes)}")
+            dec = eng.alloc_vec(max(n, 1))
+            if n:
+                eng.decrypt_dev(c.iter_index, add_idx, minus_idx, n, _cipher_mod.N_JOBS, dv.buf, dec)
+            n_values = sum(sizes)
+            dout = eng.alloc(max(8 * n_values, 16))
+            eng.unbatch_unquantize_model_dev([(s_, None, q.alpha_list[li], False) for li, s_ in enumerate(sizes)], q.element_bits, field_bits,
+                                             q.num_clients, dec, n, dout)
+            out = dout.download(np.float64, n_values)
+            del weights._weights[k0]
+            at = 0
+            for name, shape, s_ in zip(names, q.shape_list, sizes):
+                weights._weights[name] = out[at:at + s_].reshape(shape)
+                at += s_
+            weights.walking_order = sorted(weights._weights.keys(), key=str)
+            return weights
         sizes = [int(np.prod(shape)) for shape in self.shape_dict.values()]
         if sum(sizes) > n:
             raise ValueError(f"the aggregate has {n} elements, shape_dict describes {sum(sizes)}")

@@ -1126,6 +1126,76 @@ int flashe_decrypt_unquantize_model_dev(flashe_ctx *ctx, uint32_t iter, const ui
     return FLASHE_OK;
 }
 
+// ---- the BATCHED codec over a flattened model (the paper's main job configuration, "batch": true) ----
+static int stage_batch_layers(flashe_ctx *ctx, const flashe_batch_layer *layers, int n_layers, bool front, int element_bits, int field_bits,
+                              int num_clients, uint64_t *n_elems, uint64_t *n_values, const BatchLayer **tab_dev, int *n_tab)
+{
+    if (n_layers < 1 || !layers) return fail(ctx, FLASHE_EINVAL, "the layer table needs at least one entry");
+    if (ctx->capturing) return fail(ctx, FLASHE_EINVAL, "the model-wide codec calls stage their layer table per call and cannot be captured into a graph");
+    if (element_bits < 1 || element_bits > 62 || field_bits < element_bits || field_bits > ctx->int_bits)
+        return fail(ctx, FLASHE_EINVAL, "need 1 <= element_bits <= field_bits <= int_bits (element_bits <= 62)");
+    const uint64_t bs = static_cast<uint64_t>(ctx->int_bits / field_bits);
+    std::vector<BatchLayer> tab;
+    uint64_t e = 0, v = 0;
+    for (int l = 0; l < n_layers; l++) {
+        const flashe_batch_layer &y = layers[l];
+        if (y.reserved) return fail(ctx, FLASHE_EINVAL, "layer %d: reserved field must be 0", l);
+        if (y.size == 0) continue;
+        if (!(y.alpha > 0)) return fail(ctx, FLASHE_EINVAL, "layer %d: alpha must be positive", l);
+        if (front && (!y.x_dev || (reinterpret_cast<uintptr_t>(y.x_dev) & (y.x_is_f64 ? 7u : 3u)))) return fail(ctx, FLASHE_EINVAL, "layer %d: null or misaligned x_dev", l);
+        tab.push_back(front ? batch_layer_front(e, v, y.size, y.x_dev, y.x_is_f64 != 0, y.alpha, element_bits)
+                            : batch_layer_back(e, v, y.size, y.alpha, element_bits, num_clients));
+        e += (y.size + bs - 1) / bs;                       // every layer is padded to whole elements on its own (jzf_quantize.py:166-171)
+        v += y.size;
+    }
+    *n_elems = e; *n_values = v;
+    if (tab.empty()) { *tab_dev = nullptr; *n_tab = 0; return FLASHE_OK; }
+    int rc = ensure(ctx, ctx->codec_tab, tab.size() * sizeof(BatchLayer));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->codec_tab.p, tab.data(), tab.size() * sizeof(BatchLayer), hipMemcpyHostToDevice, ctx->env.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
+    *tab_dev = static_cast<const BatchLayer *>(ctx->codec_tab.p);
+    *n_tab = static_cast<int>(tab.size());
+    return FLASHE_OK;
+}
+
+int flashe_quantize_batch_model_dev(flashe_ctx *ctx, const flashe_batch_layer *layers, int n_layers, int element_bits, int field_bits,
+                                    const double *u_dev, uint64_t n_elems, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    const BatchLayer *tab = nullptr;
+    int n_tab = 0;
+    uint64_t e = 0, v = 0;
+    int rc = stage_batch_layers(ctx, layers, n_layers, true, element_bits, field_bits, 1, &e, &v, &tab, &n_tab);
+    if (rc) return rc;
+    if (e != n_elems) return fail(ctx, FLASHE_EINVAL, "the layers batch into %llu elements, n_elems says %llu", static_cast<unsigned long long>(e),
+                                  static_cast<unsigned long long>(n_elems));
+    if (n_elems && (!u_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if ((ctx->limbs == 2 && !aligned16(out_dev)) || (reinterpret_cast<uintptr_t>(out_dev) & 7u) || (reinterpret_cast<uintptr_t>(u_dev) & 7u))
+        return fail(ctx, FLASHE_EINVAL, "misaligned vector");
+    if (n_elems) HIP_TRY(ctx, launch_quantize_batch_model(ctx->env, tab, n_tab, field_bits, u_dev, n_elems, out_dev));
+    return FLASHE_OK;
+}
+
+int flashe_unbatch_unquantize_model_dev(flashe_ctx *ctx, const flashe_batch_layer *layers, int n_layers, int element_bits, int field_bits,
+                                        int num_clients, const uint64_t *in_dev, uint64_t n_elems, double *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (num_clients < 1) return fail(ctx, FLASHE_EINVAL, "num_clients must be >= 1");
+    const BatchLayer *tab = nullptr;
+    int n_tab = 0;
+    uint64_t e = 0, v = 0;
+    int rc = stage_batch_layers(ctx, layers, n_layers, false, element_bits, field_bits, num_clients, &e, &v, &tab, &n_tab);
+    if (rc) return rc;
+    if (e != n_elems) return fail(ctx, FLASHE_EINVAL, "the layers batch into %llu elements, n_elems says %llu", static_cast<unsigned long long>(e),
+                                  static_cast<unsigned long long>(n_elems));
+    if (v && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if ((ctx->limbs == 2 && !aligned16(in_dev)) || (reinterpret_cast<uintptr_t>(in_dev) & 7u) || (reinterpret_cast<uintptr_t>(out_dev) & 7u))
+        return fail(ctx, FLASHE_EINVAL, "misaligned vector");
+    if (v) HIP_TRY(ctx, launch_unbatch_unquantize_model(ctx->env, tab, n_tab, field_bits, in_dev, v, out_dev));
+    return FLASHE_OK;
+}
+
 // ---- normalise / unnormalise (QuantizingClient.normalize / unnormalize, jzf_quantize.py:542-564) ----
 int flashe_shift_dev(flashe_ctx *ctx, uint64_t n, void *x_dev, int x_is_f64, double shift, int wide)
 {

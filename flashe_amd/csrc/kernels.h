@@ -217,6 +217,25 @@ hipError_t launch_quantize(const LaunchEnv &env, uint64_t n, const void *x_dev, 
 hipError_t launch_unquantize(const LaunchEnv &env, uint64_t n, const uint64_t *v_dev, int v_limbs, double alpha, int bits,
                              int num_clients, double *out_dev);
 hipError_t launch_batch(const LaunchEnv &env, uint64_t n, const uint64_t *vals_dev, int field_bits, uint64_t *out_dev);
+// The BATCHED codec over a whole model (jzf_quantize.py:436-451 under :417-462, then jzf_aggregator.py:723): every layer is quantised
+// with its own alpha and batched ON ITS OWN (zero padded to whole elements), the batched layers lie back to back in the flattened
+// vector.  Device table, one entry per non-empty layer, ascending elem_start.
+struct BatchLayer {
+    uint64_t elem_start;       // first batched element of the layer in the flattened vector
+    uint64_t value_start;      // index of the layer's first value among all values of the model (its draw / its float output)
+    uint64_t size;             // values in the layer
+    const void *x;             // front end: the layer's float32 / float64 values
+    double p0, p1, p2;         // front end: alpha, scale, den; back end: ac, two_a, uden
+    int x_is_f64, pad_;
+};
+// out[e] = sum_t quantize(value bs * e_local + t) << (field_bits * (bs - 1 - t)) for the n_elems batched elements (bs = int_bits / field_bits)
+hipError_t launch_quantize_batch_model(const LaunchEnv &env, const BatchLayer *layers_dev, int n_layers, int field_bits, const double *u_dev,
+                                       uint64_t n_elems, uint64_t *out_dev);
+// out[value_start + j] = unquantize(field t of element elem_start + j / bs), the inverse walk, for the n_values values of the model
+hipError_t launch_unbatch_unquantize_model(const LaunchEnv &env, const BatchLayer *layers_dev, int n_layers, int field_bits, const uint64_t *in_dev,
+                                           uint64_t n_values, double *out_dev);
+BatchLayer batch_layer_front(uint64_t elem_start, uint64_t value_start, uint64_t size, const void *x_dev, bool is_f64, double alpha, int bits);
+BatchLayer batch_layer_back(uint64_t elem_start, uint64_t value_start, uint64_t size, double alpha, int bits, int num_clients);
 hipError_t launch_unbatch(const LaunchEnv &env, uint64_t nb, const uint64_t *in_dev, int field_bits, uint64_t *out_dev);
 
 // Top-k of every layer of a model in one set of launches: the layers lie back to back in flat buffers.  The caller fills the host

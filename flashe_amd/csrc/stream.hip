@@ -1,0 +1,964 @@
+// gfx950 kernels of the FLASHE cipher engine that are bound by HBM streaming: combine (precomputed masks), the arbiter's element-wise
+// and packed reduces with their multi-GPU slice helpers, the bit-packing codec, and the sparse passes (span bounds / span reduce,
+// scatter, run-edge masks, shared positions).  The AES core they need comes from device_common.h.
+#include "device_common.h"
+
+namespace flashe {
+
+// ------------------------------------------------------------------------------------------
+// Streaming kernels (HBM-bound)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kStreamThreads) void widen_u32_kernel(uint64_t n, const uint32_t *in, uint64_t *out)
+{
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n; j += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        out[j] = in[j];
+}
+__global__ __launch_bounds__(kStreamThreads) void narrow_u32_kernel(uint64_t n, const uint64_t *in, uint32_t *out)
+{
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n; j += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        out[j] = static_cast<uint32_t>(in[j]);
+}
+hipError_t launch_widen_u32(const LaunchEnv &env, uint64_t n, const uint32_t *in_dev, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(widen_u32_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, in_dev, out_dev);
+    return hipGetLastError();
+}
+hipError_t launch_narrow_u32(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint32_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(narrow_u32_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, in_dev, out_dev);
+    return hipGetLastError();
+}
+
+// out = (in + add - minus) & mask.  L = 2: one 16-B element per lane-iteration.
+__global__ __launch_bounds__(kStreamThreads) void combine_wide_kernel(uint64_t n, const uint64_t *in, int in_limbs,
+                                                                      const uint64_t *add, const uint64_t *minus,
+                                                                      uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        u128 v = in_limbs == 2 ? ld128_nt(in + 2 * j) : static_cast<u128>(__builtin_nontemporal_load(in + j));
+        if (add) v += ld128_nt(add + 2 * j);
+        if (minus) v -= ld128_nt(minus + 2 * j);
+        st128_nt(out + 2 * j, v & mask);
+    }
+}
+
+__global__ __launch_bounds__(kStreamThreads) void combine_small_kernel(uint64_t n, const uint64_t *in, const uint64_t *add,
+                                                                       const uint64_t *minus, uint64_t *out, uint64_t mask)
+{
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        uint64_t v = in[j];
+        if (add) v += add[j];
+        if (minus) v -= minus[j];
+        out[j] = v & mask;
+    }
+}
+
+// Several combines of equal length in one launch (the online encrypts of the clients a process hosts when their masks were
+// precomputed: a hundred LeNet-sized vectors are launch-bound one by one).  blockIdx.y = vector.
+constexpr int kMaxCombine = 64;
+struct CombineTable {
+    const uint64_t *in[kMaxCombine], *add[kMaxCombine], *minus[kMaxCombine];
+    uint64_t *out[kMaxCombine];
+};
+
+template <bool WIDE>
+__global__ __launch_bounds__(kStreamThreads) void combine_batch_kernel(uint64_t n, const CombineTable tb, int in_limbs, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const int v = blockIdx.y;
+    const uint64_t *in = tb.in[v], *add = tb.add[v], *minus = tb.minus[v];
+    uint64_t *out = tb.out[v];
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        if (WIDE) {
+            u128 x = in_limbs == 2 ? ld128_nt(in + 2 * j) : static_cast<u128>(__builtin_nontemporal_load(in + j));
+            if (add) x += ld128_nt(add + 2 * j);
+            if (minus) x -= ld128_nt(minus + 2 * j);
+            st128_nt(out + 2 * j, x & mask);
+        } else {
+            uint64_t x = in[j];
+            if (add) x += add[j];
+            if (minus) x -= minus[j];
+            out[j] = x & mask_lo;
+        }
+    }
+}
+
+hipError_t launch_combine_batch(const LaunchEnv &env, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev)
+{
+    if (n == 0 || n_vec == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    for (int v0 = 0; v0 < n_vec; v0 += kMaxCombine) {
+        const int nv = std::min(kMaxCombine, n_vec - v0);
+        CombineTable tb{};
+        for (int v = 0; v < nv; v++) {
+            tb.in[v] = in_dev[v0 + v]; tb.add[v] = add_dev ? add_dev[v0 + v] : nullptr;
+            tb.minus[v] = minus_dev ? minus_dev[v0 + v] : nullptr; tb.out[v] = out_dev[v0 + v];
+        }
+        // enough blocks per vector to fill the chip together, at most 8 x 256 threads per CU in all
+        uint64_t bx = (n + kStreamThreads - 1) / kStreamThreads;
+        const uint64_t cap = std::max<uint64_t>(1, static_cast<uint64_t>(env.num_cus) * 8 / nv);
+        if (bx > cap) bx = cap;
+        const dim3 grid(static_cast<unsigned>(bx), static_cast<unsigned>(nv));
+        if (env.b > 64) hipLaunchKernelGGL(combine_batch_kernel<true>, grid, dim3(kStreamThreads), 0, env.stream, n, tb, in_limbs, lo, hi);
+        else hipLaunchKernelGGL(combine_batch_kernel<false>, grid, dim3(kStreamThreads), 0, env.stream, n, tb, in_limbs, lo, hi);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
+                          const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const int grid = stream_grid(env, n);
+    if (env.b > 64)
+        hipLaunchKernelGGL(combine_wide_kernel, dim3(grid), dim3(kStreamThreads), 0, env.stream, n, in_dev, in_limbs,
+                           add_dev, minus_dev, out_dev, lo, hi);
+    else
+        hipLaunchKernelGGL(combine_small_kernel, dim3(grid), dim3(kStreamThreads), 0, env.stream, n, in_dev, add_dev,
+                           minus_dev, out_dev, lo);
+    return hipGetLastError();
+}
+
+// C-way element-wise mod-add.  WIDE: 128-bit elements (carry between the two limbs);
+// otherwise each limb is its own element and a 16-B slot simply carries two of them.
+template <bool WIDE>
+__global__ __launch_bounds__(kStreamThreads) void aggregate_elem_kernel(int C, const PtrTable ops, uint64_t n_limbs,
+                                                                        uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const uint64_t *const *tab = ops.p;
+    const uint64_t n_slots = n_limbs / 2;
+    for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; s < n_slots;
+         s += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        uint64_t a0 = 0, a1 = 0;
+        u128 acc = 0;
+#pragma unroll 4
+        for (int c = 0; c < C; c++) {
+            // every operand byte is read exactly once: stream past the caches
+            const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(tab[c] + 2 * s));
+            if (WIDE) acc += (static_cast<u128>(v[1]) << 64) | v[0];
+            else { a0 += v[0]; a1 += v[1]; }
+        }
+        if (WIDE) { a0 = static_cast<uint64_t>(acc); a1 = static_cast<uint64_t>(acc >> 64); }
+        u64x2 r;
+        r[0] = a0 & mask_lo; r[1] = a1 & (WIDE ? mask_hi : mask_lo);
+        __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(out + 2 * s));
+    }
+    if (!WIDE && (n_limbs & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        uint64_t a = 0;
+        for (int c = 0; c < C; c++) a += tab[c][n_limbs - 1];
+        out[n_limbs - 1] = a & mask_lo;
+    }
+}
+
+// one-limb vectors whose operands are only 8-byte aligned (a sub-range that starts at an odd element): one element per lane
+__global__ __launch_bounds__(kStreamThreads) void aggregate_elem8_kernel(int C, const PtrTable ops, uint64_t n, uint64_t *out, uint64_t mask_lo)
+{
+    const uint64_t *const *tab = ops.p;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n; j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        uint64_t a = 0;
+#pragma unroll 4
+        for (int c = 0; c < C; c++) a += __builtin_nontemporal_load(tab[c] + j);
+        __builtin_nontemporal_store(a & mask_lo, out + j);
+    }
+}
+
+// compact layout (int_bits <= 32, uint32 elements): four elements per lane in 16-byte accesses; 32-bit sums wrap mod 2^32, which 2^b divides
+template <bool VEC>
+__global__ __launch_bounds__(kStreamThreads) void aggregate_elem_u32_kernel(int C, const PtrTable ops, uint64_t n, uint32_t *out, uint32_t mask)
+{
+    const uint64_t *const *tab = ops.p;
+    if (VEC) {
+        const uint64_t n4 = n / 4;
+        for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; s < n4; s += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 4
+            for (int c = 0; c < C; c++) {
+                const u64x2 v = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(tab[c]) + s);
+                a0 += static_cast<uint32_t>(v[0]); a1 += static_cast<uint32_t>(v[0] >> 32);
+                a2 += static_cast<uint32_t>(v[1]); a3 += static_cast<uint32_t>(v[1] >> 32);
+            }
+            u64x2 r;
+            r[0] = (a0 & mask) | (static_cast<uint64_t>(a1 & mask) << 32);
+            r[1] = (a2 & mask) | (static_cast<uint64_t>(a3 & mask) << 32);
+            __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(out) + s);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+            const uint64_t j = n4 * 4 + threadIdx.x;
+            uint32_t a = 0;
+            for (int c = 0; c < C; c++) a += reinterpret_cast<const uint32_t *>(tab[c])[j];
+            out[j] = a & mask;
+        }
+    } else {
+        for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n; j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+            uint32_t a = 0;
+#pragma unroll 4
+            for (int c = 0; c < C; c++) a += __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(tab[c]) + j);
+            __builtin_nontemporal_store(a & mask, out + j);
+        }
+    }
+}
+
+static inline PtrTable make_table(int C, const uint64_t *const *ops)
+{
+    PtrTable t;
+    for (int c = 0; c < kMaxOps; c++) t.p[c] = c < C ? ops[c] : nullptr;
+    return t;
+}
+
+hipError_t launch_aggregate_elem_u32(const LaunchEnv &env, int C, const uint32_t *const *ops, uint64_t n, uint32_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    if (C > kMaxOps || env.b > 32) return hipErrorInvalidValue;
+    const PtrTable tab_dev = make_table(C, reinterpret_cast<const uint64_t *const *>(ops));
+    const uint32_t mask = env.b == 32 ? 0xffffffffu : ((1u << env.b) - 1u);
+    bool a16 = (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0;
+    for (int c = 0; c < C; c++) a16 = a16 && (reinterpret_cast<uintptr_t>(ops[c]) & 15u) == 0;
+    const int bpc = C >= 3 ? 2 : 8;
+    int grid = stream_grid(env, a16 ? n / 4 + 1 : n);
+    if (grid > env.num_cus * bpc) grid = env.num_cus * bpc;
+    if (a16) hipLaunchKernelGGL(aggregate_elem_u32_kernel<true>, dim3(grid), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n, out_dev, mask);
+    else hipLaunchKernelGGL(aggregate_elem_u32_kernel<false>, dim3(grid), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n, out_dev, mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_aggregate_elem(const LaunchEnv &env, int C, const uint64_t *const *ops, uint64_t n, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    if (C > kMaxOps) return hipErrorInvalidValue;
+    const PtrTable tab_dev = make_table(C, ops);
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_limbs = env.b > 64 ? 2 * n : n;
+    bool a16 = (reinterpret_cast<uintptr_t>(out_dev) & 15u) == 0;
+    for (int c = 0; c < C; c++) a16 = a16 && (reinterpret_cast<uintptr_t>(ops[c]) & 15u) == 0;
+    if (!a16) {
+        if (env.b > 64) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(aggregate_elem8_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n, out_dev, lo);
+        return hipGetLastError();
+    }
+    // a lane has C 16-byte loads in flight per slot: with many operands FEWER resident waves stream faster (measured at
+    // C = 10, n = 1e7: 8 / 4 / 2 / 1 blocks per CU -> 5.5 / 5.9 / 6.0 / 4.4 TB/s; two operands want 4-8)
+    const int bpc = C >= 3 ? 2 : 8;
+    int grid = stream_grid(env, n_limbs / 2 + 1);
+    if (grid > env.num_cus * bpc) grid = env.num_cus * bpc;
+    if (env.b > 64)
+        hipLaunchKernelGGL(aggregate_elem_kernel<true>, dim3(grid), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n_limbs,
+                           out_dev, lo, hi);
+    else
+        hipLaunchKernelGGL(aggregate_elem_kernel<false>, dim3(grid), dim3(kStreamThreads), 0, env.stream, C, tab_dev, n_limbs,
+                           out_dev, lo, hi);
+    return hipGetLastError();
+}
+
+// ---- packed aggregate: C-way add of n_limbs-limb integers with full carry propagation ----
+// Stage 1 (this kernel): per 16-B slot the C-way column sums (lo, hi = overflow count), the
+// fold hi -> next limb, and a (generate, propagate) carry scan inside the 256-slot block via
+// wave ballots + the integer-add trick; the block is resolved with carry-in 0 and publishes
+// (G, P).  Stage 2 (packed_fixup_kernel): look-back over the block summaries and ripple the
+// (rare) +1 into blocks whose carry-in is 1.
+constexpr int kPackedThreads = 256;
+uint64_t packed_num_blocks(uint64_t n_limbs) { return ((n_limbs + 1) / 2 + kPackedThreads - 1) / kPackedThreads; }
+
+__device__ __forceinline__ void column_sums(int C, const PtrTable &ops, uint64_t slot, uint64_t n_limbs,
+                                            uint64_t &lo0, uint64_t &hi0, uint64_t &lo1, uint64_t &hi1)
+{
+    const uint64_t *const *tab = ops.p;
+    u128 a0 = 0, a1 = 0;
+    const bool full = 2 * slot + 1 < n_limbs;
+    if (full) {
+#pragma unroll 4
+        for (int c = 0; c < C; c++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(tab[c] + 2 * slot);
+            a0 += v.x; a1 += v.y;
+        }
+    } else {
+        for (int c = 0; c < C; c++) a0 += tab[c][2 * slot];
+    }
+    lo0 = static_cast<uint64_t>(a0); hi0 = static_cast<uint64_t>(a0 >> 64);
+    lo1 = static_cast<uint64_t>(a1); hi1 = static_cast<uint64_t>(a1 >> 64);
+}
+
+__global__ __launch_bounds__(kPackedThreads) void aggregate_packed_kernel(int C, const PtrTable tab, uint64_t n_limbs,
+                                                                          uint64_t top_mask, uint64_t *out, uint32_t *summaries)
+{
+    __shared__ uint64_t sh_hi[kPackedThreads];
+    __shared__ uint32_t sh_zc[kPackedThreads];
+    __shared__ uint32_t sh_wg[kPackedThreads / 64], sh_wp[kPackedThreads / 64];
+    const uint64_t n_slots = (n_limbs + 1) / 2;
+    const uint64_t slot = static_cast<uint64_t>(blockIdx.x) * kPackedThreads + threadIdx.x;
+    const bool live = slot < n_slots;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    uint64_t lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+    if (live) column_sums(C, tab, slot, n_limbs, lo0, hi0, lo1, hi1);
+    // limb 2s+1: z1 = lo1 + hi0
+    const uint64_t zl1 = lo1 + hi0;
+    const uint32_t zc1 = zl1 < lo1;
+    sh_hi[tid] = hi1;
+    sh_zc[tid] = zc1;
+    __syncthreads();
+    uint64_t hi_prev = 0; uint32_t zc_prev = 0;
+    if (tid > 0) { hi_prev = sh_hi[tid - 1]; zc_prev = sh_zc[tid - 1]; }
+    else if (slot > 0 && live) {
+        uint64_t pl0, ph0, pl1, ph1;
+        column_sums(C, tab, slot - 1, n_limbs, pl0, ph0, pl1, ph1);
+        const uint64_t pz = pl1 + ph0;
+        hi_prev = ph1; zc_prev = pz < pl1;
+    }
+    // limb 2s: z0 = lo0 + hi_prev
+    const uint64_t zl0 = lo0 + hi_prev;
+    const uint32_t zc0 = zl0 < lo0;
+    // X + Y with Y = z-carry of the previous limb
+    const uint64_t s0 = zl0 + zc_prev;
+    const uint32_t g0 = s0 < zl0, p0 = s0 == ~0ull;
+    const uint64_t s1 = zl1 + zc0;
+    const uint32_t g1 = s1 < zl1, p1 = s1 == ~0ull;
+    const uint32_t Gt = live ? (g1 | (p1 & g0)) : 0u;
+    const uint32_t Pt = live ? (p1 & p0) : 1u;      // dead lanes are transparent
+    const uint64_t Gm = __ballot(Gt), Pm = __ballot(Pt);
+    const uint64_t a = Gm | Pm, bb = Gm;
+    const uint64_t sum0 = a + bb;
+    if (lane == 0) { sh_wg[wave] = sum0 < a; sh_wp[wave] = Pm == ~0ull; }
+    __syncthreads();
+    uint32_t cin = 0;
+    for (int v = 0; v < wave; v++) cin = sh_wg[v] | (sh_wp[v] & cin);
+    const uint64_t cv = (a + bb + cin) ^ Pm;
+    const uint32_t ct = (cv >> lane) & 1u;
+    const uint64_t r0 = s0 + ct;
+    const uint32_t k0 = g0 | (p0 & ct);
+    const uint64_t r1 = s1 + k0;
+    if (live) {
+        const uint64_t i0 = 2 * slot, i1 = i0 + 1;
+        if (i1 < n_limbs) {
+            *reinterpret_cast<ulonglong2 *>(out + i0) =
+                make_ulonglong2(r0, i1 == n_limbs - 1 ? (r1 & top_mask) : r1);
+        } else {
+            out[i0] = r0 & top_mask;
+        }
+    }
+    if (tid == 0) {
+        uint32_t c = 0, pall = 1;
+        for (int v = 0; v < kPackedThreads / 64; v++) { c = sh_wg[v] | (sh_wp[v] & c); pall &= sh_wp[v]; }
+        summaries[blockIdx.x] = c | (pall << 1);
+    }
+}
+
+__global__ void packed_fixup_kernel(uint64_t n_blocks, uint64_t n_limbs, uint64_t top_mask, const uint32_t *summaries, uint64_t *out)
+{
+    const uint64_t B = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x + 1;
+    if (B >= n_blocks) return;
+    uint32_t cin = 0;
+    for (uint64_t v = B; v-- > 0;) {
+        const uint32_t s = summaries[v];
+        if (s & 1u) { cin = 1; break; }
+        if (!(s & 2u)) break;
+    }
+    if (!cin) return;
+    const uint64_t first = B * kPackedThreads * 2;
+    uint64_t last = first + kPackedThreads * 2;
+    if (last > n_limbs) last = n_limbs;
+    for (uint64_t i = first; i < last; i++) {
+        uint64_t v = out[i] + 1;
+        if (i == n_limbs - 1) v &= top_mask;
+        out[i] = v;
+        if (v != 0) break;
+    }
+}
+
+hipError_t launch_aggregate_packed(const LaunchEnv &env, int C, const uint64_t *const *ops, uint64_t n_limbs,
+                                   uint64_t total_bits, uint64_t *out_dev, uint32_t *summaries_dev)
+{
+    if (n_limbs == 0) return hipSuccess;
+    if (C > kMaxOps) return hipErrorInvalidValue;
+    const PtrTable tab_dev = make_table(C, ops);
+    const unsigned top = static_cast<unsigned>(total_bits % 64);
+    const uint64_t top_mask = top ? ((1ull << top) - 1) : ~0ull;
+    const uint64_t nb = packed_num_blocks(n_limbs);
+    hipLaunchKernelGGL(aggregate_packed_kernel, dim3(static_cast<unsigned>(nb)), dim3(kPackedThreads), 0, env.stream, C, tab_dev,
+                       n_limbs, top_mask, out_dev, summaries_dev);
+    if (nb > 1) {
+        const unsigned fb = static_cast<unsigned>((nb - 1 + 255) / 256);
+        hipLaunchKernelGGL(packed_fixup_kernel, dim3(fb), dim3(256), 0, env.stream, nb, n_limbs, top_mask, summaries_dev, out_dev);
+    }
+    return hipGetLastError();
+}
+
+// ---- slice helpers for a packed reduce that is cut across GPUs (flashe_amd/dist.py run_packed) ----
+// probe: x holds a slice sum as n_limbs - 1 body limbs plus one carry limb on top.
+// info[0] = x[0], info[1] = 1 iff body limbs [1, n_limbs - 1) are all ~0, info[2] = x[n_limbs - 1].
+__global__ __launch_bounds__(kStreamThreads) void packed_probe_kernel(uint64_t n_limbs, const uint64_t *x, uint64_t *info)
+{
+    bool ones = true;
+    for (uint64_t i = 1 + static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; i + 1 < n_limbs;
+         i += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        ones &= __builtin_nontemporal_load(x + i) == ~0ull;
+    if (!__all(ones) && (threadIdx.x & 63) == 0) info[1] = 0;     // every writer stores the same value
+    if (blockIdx.x == 0 && threadIdx.x == 0) { info[0] = x[0]; info[2] = x[n_limbs - 1]; }
+}
+__global__ void packed_probe_init_kernel(uint64_t *info) { info[0] = 0; info[1] = 1; info[2] = 0; }
+
+// x = (x + cin) mod 2^total_bits in place, one workgroup: the ripple stops at the first limb that is
+// not all ones, which is limb 0 or 1 for anything but adversarial data.
+constexpr int kRippleThreads = 1024;
+// infos != null: the carry-in is derived on the device from the (low limb, body-all-ones, carry-out) triples of the limb
+// slices below this one (ranks 0 .. n_below - 1 of a packed reduce cut across GPUs): a slice passes its carry-in on when all its
+// body limbs are ones and the low limb overflows, on top of its own carry-out.
+// stride: words from one slice's triple to the next more significant one's (3 = slice 0 first; -3 = the lowest slice's triple is the
+// LAST of the gathered ones and infos points at it: slices numbered from the most significant end, as element slices of a packed
+// vector are -- element 0 is the most significant, jzf_weights.py:59-62).
+__global__ __launch_bounds__(kRippleThreads) void packed_add_carry_kernel(uint64_t n_limbs, uint64_t top_mask, uint64_t cin, uint64_t *x,
+                                                                          const uint64_t *__restrict__ infos, int n_below, int stride)
+{
+    __shared__ int first_stop;
+    const int tid = threadIdx.x;
+    if (infos) {
+        uint64_t carry = 0;
+        for (int g = 0; g < n_below; g++) {
+            const uint64_t *t = infos + static_cast<int64_t>(g) * stride;
+            const uint64_t low = t[0], ones = t[1], cout = t[2];
+            carry = cout + ((ones && low + carry < low) ? 1ull : 0ull);
+        }
+        cin = carry;
+    }
+    const uint64_t x0 = x[0];
+    __syncthreads();
+    const uint64_t s0 = x0 + cin;
+    if (tid == 0) x[0] = s0;
+    if (s0 < x0) {
+        for (uint64_t base = 1; base < n_limbs; base += kRippleThreads) {
+            const uint64_t i = base + tid;
+            const uint64_t v = i < n_limbs ? x[i] : 0;
+            if (tid == 0) first_stop = kRippleThreads;
+            __syncthreads();
+            if (v != ~0ull) atomicMin(&first_stop, tid);
+            __syncthreads();
+            const int f = first_stop;
+            if (tid < f) x[i] = 0;
+            else if (tid == f && i < n_limbs) x[i] = v + 1;
+            __syncthreads();
+            if (f < kRippleThreads) break;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) x[n_limbs - 1] &= top_mask;
+}
+
+hipError_t launch_packed_probe(const LaunchEnv &env, uint64_t n_limbs, const uint64_t *x_dev, uint64_t *info_dev)
+{
+    hipLaunchKernelGGL(packed_probe_init_kernel, dim3(1), dim3(1), 0, env.stream, info_dev);
+    if (n_limbs == 0) return hipGetLastError();
+    hipLaunchKernelGGL(packed_probe_kernel, dim3(stream_grid(env, n_limbs)), dim3(kStreamThreads), 0, env.stream, n_limbs, x_dev, info_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_packed_add_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, uint64_t cin, uint64_t *x_dev)
+{
+    if (n_limbs == 0) return hipSuccess;
+    const unsigned top = static_cast<unsigned>(total_bits % 64);
+    const uint64_t top_mask = top ? ((1ull << top) - 1) : ~0ull;
+    hipLaunchKernelGGL(packed_add_carry_kernel, dim3(1), dim3(kRippleThreads), 0, env.stream, n_limbs, top_mask, cin, x_dev,
+                       static_cast<const uint64_t *>(nullptr), 0, 3);
+    return hipGetLastError();
+}
+
+hipError_t launch_packed_resolve_carry(const LaunchEnv &env, uint64_t n_limbs, uint64_t total_bits, const uint64_t *infos_dev, int n_below,
+                                       uint64_t *x_dev, int stride_words)
+{
+    if (n_limbs == 0) return hipSuccess;
+    const unsigned top = static_cast<unsigned>(total_bits % 64);
+    const uint64_t top_mask = top ? ((1ull << top) - 1) : ~0ull;
+    hipLaunchKernelGGL(packed_add_carry_kernel, dim3(1), dim3(kRippleThreads), 0, env.stream, n_limbs, top_mask, 0ull, x_dev, infos_dev, n_below,
+                       stride_words);
+    return hipGetLastError();
+}
+
+// ---- bit-packing codec ----
+// pack: one output limb per lane, gathering every element that overlaps bits [64w, 64w + 64).
+__global__ __launch_bounds__(kStreamThreads) void pack_kernel(uint64_t n, int b, int L, const uint64_t *in, uint64_t *out,
+                                                              uint64_t n_limbs, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t w = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; w < n_limbs;
+         w += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const uint64_t bit0 = 64 * w;
+        uint64_t e = bit0 / b;
+        uint64_t e_last = (bit0 + 63) / b;
+        if (e_last >= n) e_last = n - 1;
+        uint64_t acc = 0;
+        for (; e <= e_last; e++) {
+            const uint64_t j = n - 1 - e;
+            const u128 v = (L == 2 ? ld128(in + 2 * j) : static_cast<u128>(in[j])) & mask;
+            const uint64_t pos = e * b;
+            if (pos >= bit0) acc |= static_cast<uint64_t>(v) << (pos - bit0);
+            else acc |= static_cast<uint64_t>(v >> (bit0 - pos));
+        }
+        out[w] = acc;
+    }
+}
+
+__global__ __launch_bounds__(kStreamThreads) void unpack_kernel(uint64_t n, int b, int L, const uint64_t *in, uint64_t *out,
+                                                                uint64_t n_limbs, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const uint64_t pos = (n - 1 - j) * b;
+        const uint64_t w = pos / 64;
+        const unsigned s = static_cast<unsigned>(pos % 64);
+        const u128 l0 = in[w];
+        const u128 l1 = w + 1 < n_limbs ? in[w + 1] : 0;
+        const u128 l2 = w + 2 < n_limbs ? in[w + 2] : 0;
+        u128 v = l0 >> s;
+        if (s) { v |= l1 << (64 - s); v |= l2 << (128 - s); }
+        else v |= l1 << 64;
+        v &= mask;
+        if (L == 2) st128(out + 2 * j, v);
+        else out[j] = static_cast<uint64_t>(v);
+    }
+}
+
+// b = 128: the packed integer is the element order reversed (element 0 most significant) -- one 16-byte move per lane,
+// the same kernel packs and unpacks.
+__global__ __launch_bounds__(kStreamThreads) void reverse128_kernel(uint64_t n, const uint64_t *in, uint64_t *out)
+{
+    for (uint64_t e = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; e < n;
+         e += static_cast<uint64_t>(gridDim.x) * kStreamThreads)
+        st128_nt(out + 2 * e, ld128_nt(in + 2 * (n - 1 - e)));
+}
+
+hipError_t launch_pack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    if (env.b == 128) {
+        hipLaunchKernelGGL(reverse128_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, in_dev, out_dev);
+        return hipGetLastError();
+    }
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_limbs = (n * static_cast<uint64_t>(env.b) + 63) / 64;
+    hipLaunchKernelGGL(pack_kernel, dim3(stream_grid(env, n_limbs)), dim3(kStreamThreads), 0, env.stream, n, env.b,
+                       env.b > 64 ? 2 : 1, in_dev, out_dev, n_limbs, lo, hi);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    if (env.b == 128) {
+        hipLaunchKernelGGL(reverse128_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, in_dev, out_dev);
+        return hipGetLastError();
+    }
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_limbs = (n * static_cast<uint64_t>(env.b) + 63) / 64;
+    hipLaunchKernelGGL(unpack_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, env.b,
+                       env.b > 64 ? 2 : 1, in_dev, out_dev, n_limbs, lo, hi);
+    return hipGetLastError();
+}
+
+// ---- sparse helpers ----
+__global__ __launch_bounds__(kStreamThreads) void fill_kernel(uint64_t n, int L, uint64_t lo, uint64_t hi, uint64_t *out)
+{
+    for (uint64_t j = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; j < n;
+         j += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        if (L == 2) *reinterpret_cast<ulonglong2 *>(out + 2 * j) = make_ulonglong2(lo, hi);
+        else out[j] = lo;
+    }
+}
+
+// out[loc[q]] = vals[q]  or  out[loc[q]] = (out[loc[q]] + vals[q]) mod 2^b.  loc must hold
+// distinct positions within one launch (the reference's location lists are sets).
+// sub (a constant, < 2^b) is subtracted from every value first: the sparse reduce adds vals[q] - zero.
+__global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t total, uint64_t k, int L, const uint32_t *loc, const uint64_t *vals,
+                                                                 uint64_t *out, bool accumulate, uint64_t mask_lo, uint64_t mask_hi,
+                                                                 uint64_t sub_lo, uint64_t sub_hi, uint32_t *err_flag)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const u128 sub = (static_cast<u128>(sub_hi) << 64) | sub_lo;
+    for (uint64_t q = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; q < k;
+         q += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const uint64_t p = loc[q];
+        if (p >= total) { *err_flag = 1; continue; }       // never write outside the dense vector: skip and report
+        if (L == 2) {
+            u128 v = ld128(vals + 2 * q) - sub;
+            if (accumulate) v += ld128(out + 2 * p);
+            st128(out + 2 * p, v & mask);
+        } else {
+            uint64_t v = vals[q] - sub_lo;
+            if (accumulate) v += out[p];
+            out[p] = v & mask_lo;
+        }
+    }
+}
+
+// Sparse reduce over SORTED location lists, two launches for any number of clients.
+// The dense vector is cut into spans of kSpan positions, one workgroup each.  Kernel A: start[s][c] = first entry of
+// client c at or beyond position s * kSpan -- one thread per ENTRY: entry q opens every span between the span of entry
+// q - 1 and its own (most entries open none), one coalesced pass over the location lists instead of a binary search per
+// (span, client); it also reports lists that are not strictly increasing or reach beyond the vector.  Kernel B: the
+// workgroup (1,024 threads: the gathers are the slow part, measured against 256 / 512 threads and 1 K ... 8 K spans) clears a
+// span-sized accumulator in LDS, adds every client's entries that fall into its span (128-bit add =
+// two LDS atomics; the low one returns the old value, which tells the lane exactly whether ITS add wrapped -- integer
+// adds commute, so the sum does not depend on the order), then writes src + accumulator (or src - accumulator, base
+// instead of src when there is none) for the WHOLE span: the dense output is written exactly once, coalesced.
+#ifndef FLASHE_SPAN
+#define FLASHE_SPAN 4096
+#endif
+constexpr int kSpan = FLASHE_SPAN;  // positions per span: 64 KiB of 128-bit accumulators, two workgroups per CU (8,192 = 128 KiB, one workgroup per CU,
+                                    // twice as long slices per client: aggregate 0.171 against 0.169 ms, fused decrypt 0.442 against 0.420 -- config 5)
+constexpr int kSpanThreads = 1024;
+constexpr int kSpanBatch = 2;       // entries whose loads a lane keeps in flight at once (config 5, aggregate / fused decrypt: 8: 0.256 / 0.484 ms,
+                                    // 4: 0.171 / 0.416, 2: 0.163 / 0.407, 1: 0.167 / 0.407 -- fewer gathers in flight stream faster here too)
+struct ScatterTable {
+    const uint32_t *loc[kMaxScatter];
+    const uint64_t *vals[kMaxScatter];
+    uint64_t k[kMaxScatter], sub_lo[kMaxScatter], sub_hi[kMaxScatter];
+};
+
+constexpr int kBoundsPerThread = 8;
+__global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const ScatterTable tb, int C, uint64_t n_spans, uint64_t total, uint32_t *start,
+                                                                     uint32_t *err_flag)
+{
+    const int c = blockIdx.y;
+    const uint64_t k = tb.k[c];
+    const uint32_t *loc = tb.loc[c];
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int i = 0; i < kBoundsPerThread; i++) {
+        const uint64_t q = (static_cast<uint64_t>(blockIdx.x) * kBoundsPerThread + i) * kStreamThreads + threadIdx.x;
+        // q == k closes the list (the spans behind the last entry); lanes beyond it open nothing
+        const bool live = q <= k;
+        const uint64_t prev = live && q ? loc[q - 1] : 0, cur = live && q < k ? loc[q] : 0;
+        if (live && q < k && (cur >= total || (q && cur <= prev))) *err_flag = 1;
+        const uint64_t s_last = q < k ? std::min<uint64_t>(cur / kSpan, n_spans) : n_spans;
+        const uint64_t s_first = !live ? s_last + 1 : q ? std::min<uint64_t>(prev / kSpan, n_spans) + 1 : 0;
+        const bool is_long = s_first + 16 <= s_last;
+        if (!is_long)
+            for (uint64_t sp = s_first; sp <= s_last; sp++) start[sp * C + c] = static_cast<uint32_t>(q);
+        // a long run of empty spans (a short list over a long vector, an empty client): the wave fills it together instead of one
+        // lane storing span after span
+        uint64_t pending = __ballot(is_long);
+        while (pending) {
+            const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
+            const uint64_t a = __shfl(s_first, src, 64), b = __shfl(s_last, src, 64);
+            const uint32_t qq = static_cast<uint32_t>(__shfl(q, src, 64));
+            for (uint64_t x = a + lane; x <= b; x += 64u) start[x * C + c] = qq;
+            pending &= pending - 1;
+        }
+    }
+}
+
+// One batch of a span's entries, gathered into registers: flat entry f belongs to the client c with prefix[c] <= f < prefix[c + 1].
+struct SpanBatch { uint32_t r[kSpanBatch]; int own[kSpanBatch]; u128 v[kSpanBatch]; };
+
+template <int THREADS>
+__device__ __forceinline__ void span_gather(SpanBatch &g, uint32_t f0, uint32_t n_entries, const uint32_t *prefix, const uint32_t *begin,
+                                            const uint32_t *const *s_loc, const uint64_t *const *s_vals, int L, uint32_t p0)
+{
+#pragma unroll
+    for (int e = 0; e < kSpanBatch; e++) {
+        const uint32_t fe = f0 + e * THREADS;
+        const uint32_t f = fe < n_entries ? fe : f0;     // surplus slots re-read the first entry (f0 < n_entries) and are not added
+        int c = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (prefix[c + step] <= f) c += step;
+        g.own[e] = c;
+        const uint64_t q = static_cast<uint64_t>(begin[c]) + (f - prefix[c]);
+        g.r[e] = s_loc[c][q] - p0;
+        g.v[e] = L == 2 ? ld128(s_vals[c] + 2 * q) : static_cast<u128>(s_vals[c][q]);
+    }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void span_add(const SpanBatch &g, uint32_t f0, uint32_t n_entries, unsigned long long *acc, const uint64_t *s_sub, int L,
+                                         uint64_t span_len, uint32_t *err_flag)
+{
+#pragma unroll
+    for (int e = 0; e < kSpanBatch; e++) {
+        if (f0 + e * THREADS >= n_entries) break;
+        if (g.r[e] >= span_len) { *err_flag = 1; continue; }      // position >= total, or a list that is not strictly increasing
+        const u128 w = g.v[e] - ((static_cast<u128>(s_sub[2 * g.own[e] + 1]) << 64) | s_sub[2 * g.own[e]]);
+        const unsigned long long wlo = static_cast<unsigned long long>(w), whi = static_cast<unsigned long long>(w >> 64);
+        if (L == 2) {
+            const unsigned long long old = atomicAdd(&acc[2 * g.r[e]], wlo);
+            atomicAdd(&acc[2 * g.r[e] + 1], whi + (old + wlo < old ? 1ull : 0ull));
+        } else {
+            atomicAdd(&acc[g.r[e]], wlo);
+        }
+    }
+}
+
+template <int SPAN, int THREADS>
+__global__ __launch_bounds__(THREADS) void span_reduce_kernel(const ScatterTable tb, int C, int L, uint64_t total, const uint32_t *start,
+                                                              uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo, uint64_t mask_hi,
+                                                              const uint64_t *src, bool negate, uint64_t *out, uint32_t *err_flag)
+{
+    __shared__ unsigned long long acc[2 * SPAN];
+    __shared__ uint32_t s_begin[kMaxScatter], s_prefix[2 * kMaxScatter + 2];
+    __shared__ const uint32_t *s_loc[kMaxScatter];
+    __shared__ const uint64_t *s_vals[kMaxScatter];
+    __shared__ uint64_t s_sub[2 * kMaxScatter];
+    const uint64_t span = blockIdx.x, p0 = span * SPAN;
+    const uint64_t span_len = total - p0 < SPAN ? total - p0 : SPAN;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (L == 2 ? 2 : 1) * SPAN; i += THREADS) acc[i] = 0;
+    // this span's slice [begin, begin + count) of every client's list (clamped: a malformed list was reported by kernel A and
+    // must not turn into reads outside the lists) and the running total of the counts, by a shuffle scan in the first wave:
+    // the entries of ALL clients are then walked as one flat index space -- consecutive lanes read consecutive entries
+    if (tid < 64) {
+        uint32_t cnt = 0;
+        if (tid < C) {
+            const uint32_t kc = static_cast<uint32_t>(tb.k[tid]);
+            const uint32_t b0 = min(start[span * C + tid], kc), b1 = min(start[(span + 1) * C + tid], kc);
+            cnt = b1 > b0 ? b1 - b0 : 0;
+            s_begin[tid] = b0;
+            s_loc[tid] = tb.loc[tid]; s_vals[tid] = tb.vals[tid];
+            s_sub[2 * tid] = tb.sub_lo[tid]; s_sub[2 * tid + 1] = tb.sub_hi[tid];
+        }
+        uint32_t run = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(run, d, 64);
+            if (tid >= d) run += up;
+        }
+        if (tid == 0) s_prefix[0] = 0;
+        s_prefix[tid + 1] = tid < C ? run : 0xffffffffu;        // sentinels: the owner search needs no bounds
+        s_prefix[tid + 65] = 0xffffffffu;
+    }
+    __syncthreads();
+    const uint32_t n_entries = s_prefix[C];
+    for (uint32_t f0 = tid; f0 < n_entries; f0 += kSpanBatch * THREADS) {
+        SpanBatch g;
+        span_gather<THREADS>(g, f0, n_entries, s_prefix, s_begin, s_loc, s_vals, L, static_cast<uint32_t>(p0));
+        span_add<THREADS>(g, f0, n_entries, acc, s_sub, L, span_len, err_flag);
+    }
+    __syncthreads();
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const u128 base = (static_cast<u128>(base_hi) << 64) | base_lo;
+    for (uint64_t r = tid; r < span_len; r += THREADS) {
+        if (L == 2) {
+            const u128 a = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
+            const u128 from = src ? ld128_nt(src + 2 * (p0 + r)) : base;
+            st128_nt(out + 2 * (p0 + r), (negate ? from - a : from + a) & mask);
+        } else {
+            const uint64_t from = src ? __builtin_nontemporal_load(src + p0 + r) : base_lo;
+            __builtin_nontemporal_store((negate ? from - acc[r] : from + acc[r]) & mask_lo, out + p0 + r);
+        }
+    }
+}
+
+uint64_t span_count(uint64_t total) { return (total + kSpan - 1) / kSpan; }
+
+// out[p] = from[p] +/- sum over clients c and entries q with loc[c][q] == p of (vals[c][q] - sub[c])   (mod 2^b), every p < total,
+// from = src_dev when given (may be out_dev), the constant base otherwise; loc[c] strictly increasing.
+// start_dev: (span_count(total) + 1) * C words of scratch.
+hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev)
+{
+    if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    ScatterTable tb{};
+    uint64_t kmax = 0;
+    for (int c = 0; c < C; c++) {
+        if (k[c] >= (1ull << 32)) return hipErrorInvalidValue;
+        tb.loc[c] = loc_dev[c]; tb.k[c] = k[c];
+        kmax = std::max(kmax, k[c]);
+    }
+    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0,
+                       env.stream, tb, C, span_count(total), total, start_dev, env.err_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
+                              const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready)
+{
+    if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    const int L = env.b > 64 ? 2 : 1;
+    ScatterTable tb{};
+    uint64_t kmax = 0;
+    for (int c = 0; c < C; c++) {
+        if (k[c] >= (1ull << 32)) return hipErrorInvalidValue;
+        tb.loc[c] = loc_dev[c]; tb.vals[c] = vals_dev[c]; tb.k[c] = k[c];
+        tb.sub_lo[c] = sub ? sub[static_cast<size_t>(L) * c] : 0;
+        tb.sub_hi[c] = sub && L == 2 ? sub[2 * c + 1] : 0;
+        kmax = std::max(kmax, k[c]);
+    }
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_spans = span_count(total);
+    if (!bounds_ready)
+        hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0,
+                           env.stream, tb, C, n_spans, total, start_dev, env.err_flag);
+    hipLaunchKernelGGL((span_reduce_kernel<kSpan, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
+                       start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
+    return hipGetLastError();
+}
+
+// ---- sparse + double mask: the masks of the run EDGES, computed only where they are needed -------------------------------------
+// set_idx_list's sparse branch of the double mask (jzf_flashe.py:388-426) runs a per-position analysis of the clients' one-hot
+// location vectors: position p of client c needs term(c + 1, p) on the ADD side unless client c + 1 holds p too (the masks of
+// neighbouring clients telescope), and term(c, p) on the MINUS side unless client c - 1 holds p -- _static_prepare_decrypt_spar
+// (:155-225) then evaluates the PRF at exactly the selected dense positions (a block without a selected slot costs no AES).  Here
+// the work items are the clients' own list entries: entry q of client c looks its position up in the two neighbouring (sorted)
+// lists and computes at most two AES blocks with the counter of the DENSE position (one chunk, begin = 0: counter = p / m, slot
+// p % m), writing compact (add, minus) values that the span reduce then scatters -- sum_c k_c block pairs instead of
+// (C + 1) x total blocks and no per-list one-hot of `total` bytes.
+struct EdgeTable {
+    const uint32_t *loc[kMaxScatter + 2];     // entry e + 1 = client c0 + e; entries 0 and nc + 1 = the neighbours outside the group (or null)
+    uint64_t k[kMaxScatter + 2];
+    uint64_t *va[kMaxScatter], *vm[kMaxScatter];
+    uint64_t end[kMaxScatter];                // running total of the group's entries
+};
+
+__device__ __forceinline__ bool sorted_contains(const uint32_t *__restrict__ a, uint64_t n, uint32_t x)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && a[lo] == x;
+}
+
+__global__ __launch_bounds__(kPrfThreads) void sparse_edge_prf_kernel(const RoundKeys rk, const EdgeTable tb, int nc, uint32_t c0, uint32_t iter0, int b,
+                                                                      uint64_t mask_lo, uint64_t mask_hi, const uint32_t *__restrict__ te0)
+{
+    const uint32_t iter = iter0 + te0[kIterShiftWord];
+    __shared__ uint32_t tab[kTabWords];
+    fill_tables(tab, te0);
+    const LaneRegs lr = lane_regs(tab);
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const uint32_t m = b > 64 ? 1u : 128u / static_cast<uint32_t>(b);
+    const uint64_t n_items = tb.end[nc - 1];
+    for (uint64_t f = static_cast<uint64_t>(blockIdx.x) * kPrfThreads + threadIdx.x; f < n_items; f += static_cast<uint64_t>(gridDim.x) * kPrfThreads) {
+        int e = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (e + step < nc && tb.end[e + step - 1] <= f) e += step;
+        const uint64_t q = f - (e ? tb.end[e - 1] : 0);
+        const uint32_t p = tb.loc[e + 1][q];
+        const bool in_prev = tb.loc[e] && sorted_contains(tb.loc[e], tb.k[e], p);
+        const bool in_next = tb.loc[e + 2] && sorted_contains(tb.loc[e + 2], tb.k[e + 2], p);
+        const uint32_t c = c0 + static_cast<uint32_t>(e);
+        const uint64_t ctr = p / m;
+        uint32_t s[2][4];
+        set_block(s[0], iter, c + 1u, ctr);            // add side: list (prefix) c + 1
+        set_block(s[1], iter, c, ctr);                 // minus side: list c
+        aes256_encrypt<2>(rk, lr, s);
+        const int sh = static_cast<int>(static_cast<uint32_t>(b) * (p - static_cast<uint32_t>(ctr) * m));
+        const u128 A = in_next ? static_cast<u128>(0) : (words_to_u128(s[0]) >> sh) & mask;
+        const u128 M = in_prev ? static_cast<u128>(0) : (words_to_u128(s[1]) >> sh) & mask;
+        if (b > 64) { st128(tb.va[e] + 2 * q, A); st128(tb.vm[e] + 2 * q, M); }
+        else { tb.va[e][q] = static_cast<uint64_t>(A); tb.vm[e][q] = static_cast<uint64_t>(M); }
+    }
+}
+
+hipError_t launch_sparse_edge_prf(const LaunchEnv &env, uint32_t iter, int nc, uint32_t c0, const uint32_t *const *loc_with_neighbours,
+                                  const uint64_t *k_with_neighbours, uint64_t *const *va_dev, uint64_t *const *vm_dev)
+{
+    if (nc < 1 || nc > kMaxScatter) return hipErrorInvalidValue;
+    EdgeTable tb{};
+    uint64_t total = 0;
+    for (int e = 0; e < nc + 2; e++) { tb.loc[e] = loc_with_neighbours[e]; tb.k[e] = k_with_neighbours[e]; }
+    for (int e = 0; e < nc; e++) { tb.va[e] = va_dev[e]; tb.vm[e] = vm_dev[e]; total += tb.k[e + 1]; tb.end[e] = total; }
+    if (total == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    hipLaunchKernelGGL(sparse_edge_prf_kernel, dim3(grid_for(env, total, kPrfThreads)), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc, c0, iter, env.b, lo,
+                       hi, env.te0_dev);
+    return hipGetLastError();
+}
+
+// ---- Arbiter.dynamic_masking's cost model on the device (jzf_flashe_block.py:92-112) -----------------------------------------------
+// canceled_out_pairs = sum over consecutive clients (c, c + 1) of the positions both hold (the reference ANDs one-hot vectors of
+// `total` entries): every list entry of client c looks its position up in client c + 1's sorted list -- the neighbour lookup of
+// sparse_edge_prf_kernel without the AES -- and the hits are counted (wave ballot, one atomic per wave).
+__global__ __launch_bounds__(kStreamThreads) void shared_positions_kernel(const EdgeTable tb, int nc, unsigned long long *count)
+{
+    const uint64_t n_items = tb.end[nc - 1];
+    unsigned long long mine = 0;
+    for (uint64_t f = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; f < n_items; f += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        int e = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (e + step < nc && tb.end[e + step - 1] <= f) e += step;
+        const uint64_t q = f - (e ? tb.end[e - 1] : 0);
+        const uint32_t p = tb.loc[e + 1][q];
+        if (tb.loc[e + 2] && sorted_contains(tb.loc[e + 2], tb.k[e + 2], p)) mine++;
+    }
+    for (int off = 32; off; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(count, mine);
+}
+
+hipError_t launch_shared_positions(const LaunchEnv &env, int nc, const uint32_t *const *loc_with_next, const uint64_t *k_with_next,
+                                   unsigned long long *count_dev)
+{
+    if (nc < 1 || nc > kMaxScatter) return hipErrorInvalidValue;
+    EdgeTable tb{};
+    uint64_t total = 0;
+    for (int e = 0; e < nc; e++) { tb.loc[e + 1] = loc_with_next[e]; tb.k[e + 1] = k_with_next[e]; total += k_with_next[e]; tb.end[e] = total; }
+    tb.loc[nc + 1] = loc_with_next[nc]; tb.k[nc + 1] = k_with_next[nc];
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(shared_positions_kernel, dim3(stream_grid(env, total)), dim3(kStreamThreads), 0, env.stream, tb, nc, count_dev);
+    return hipGetLastError();
+}
+
+// out[p] = (out[p] + (sel[p] ? stream[p] : 0)) mod 2^b
+__global__ __launch_bounds__(kStreamThreads) void sel_accumulate_kernel(uint64_t n, int L, const uint8_t *sel, const uint64_t *stream,
+                                                                        uint64_t *out, uint64_t mask_lo, uint64_t mask_hi)
+{
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    for (uint64_t p = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; p < n;
+         p += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        if (!sel[p]) continue;
+        if (L == 2) st128(out + 2 * p, (ld128(out + 2 * p) + ld128(stream + 2 * p)) & mask);
+        else out[p] = (out[p] + stream[p]) & mask_lo;
+    }
+}
+
+hipError_t launch_fill(const LaunchEnv &env, uint64_t n, uint64_t lo, uint64_t hi, uint64_t *out_dev)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(env, n)), dim3(kStreamThreads), 0, env.stream, n, env.b > 64 ? 2 : 1, lo, hi, out_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter(const LaunchEnv &env, uint64_t total, uint64_t k, const uint32_t *loc_dev, const uint64_t *vals_dev,
+                          uint64_t *out_dev, bool accumulate, uint64_t sub_lo, uint64_t sub_hi)
+{
+    if (k == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    hipLaunchKernelGGL(scatter_kernel, dim3(stream_grid(env, k)), dim3(kStreamThreads), 0, env.stream, total, k, env.b > 64 ? 2 : 1,
+                       loc_dev, vals_dev, out_dev, accumulate, lo, hi, sub_lo, sub_hi, env.err_flag);
+    return hipGetLastError();
+}
+
+// One list entry of _static_prepare_decrypt_spar: the whole-vector stream for prefix iter|list_idx
+// (one chunk, begin = 0) must already be in stream_dev; selected positions are accumulated.
+hipError_t launch_sel_accumulate(const LaunchEnv &env, uint64_t total, const uint8_t *sel_dev, const uint64_t *stream_dev,
+                                 uint64_t *out_dev)
+{
+    if (total == 0) return hipSuccess;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    hipLaunchKernelGGL(sel_accumulate_kernel, dim3(stream_grid(env, total)), dim3(kStreamThreads), 0, env.stream, total,
+                       env.b > 64 ? 2 : 1, sel_dev, stream_dev, out_dev, lo, hi);
+    return hipGetLastError();
+}
+
+}  // namespace flashe

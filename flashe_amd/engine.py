@@ -936,6 +936,27 @@ class Engine:
         self._check(self._lib.flashe_decrypt_unquantize_model_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, first, count,
                                                                   self._ptr(inp), arr, nl, element_bits, num_clients, self._ptr(out)))
 
+    @staticmethod
+    def _batch_layers(layers):
+        """layers: iterable of (size, x device pointer or None, alpha, x_is_f64) -> ctypes array of flashe_batch_layer."""
+        layers = list(layers)
+        arr = (_lib.BatchLayer * max(len(layers), 1))()
+        for i, (size, x, alpha, is_f64) in enumerate(layers):
+            arr[i].size, arr[i].x_dev, arr[i].alpha, arr[i].x_is_f64, arr[i].reserved = int(size), x, float(alpha), 1 if is_f64 else 0, 0
+        return arr, len(layers)
+
+    def quantize_batch_model_dev(self, layers, element_bits, field_bits, u, n_elems, out):
+        """The batched plaintext of a whole model in one launch: every layer quantised with its own alpha and batched on its own
+        (int_bits // field_bits values per element, zero padded), the batched layers back to back in `out` (n_elems x L limbs)."""
+        arr, nl = self._batch_layers(layers)
+        self._check(self._lib.flashe_quantize_batch_model_dev(self._h, arr, nl, element_bits, field_bits, self._ptr(u), n_elems, self._ptr(out)))
+
+    def unbatch_unquantize_model_dev(self, layers, element_bits, field_bits, num_clients, inp, n_elems, out):
+        """The way back: the decrypted flattened batched vector -> the model's float64 values in walking order, one launch."""
+        arr, nl = self._batch_layers(layers)
+        self._check(self._lib.flashe_unbatch_unquantize_model_dev(self._h, arr, nl, element_bits, field_bits, num_clients, self._ptr(inp), n_elems,
+                                                                  self._ptr(out)))
+
     def shift_dev(self, n, x, x_is_f64, shift, wide=False):
         """x <- x + shift in place (normalize: shift = -mean)."""
         self._check(self._lib.flashe_shift_dev(self._h, n, self._ptr(x), 1 if x_is_f64 else 0, float(shift), 1 if wide else 0))

@@ -487,6 +487,26 @@ int flashe_decrypt_unquantize_model_dev(flashe_ctx *ctx, uint32_t iter, const ui
                                         const uint32_t *minus_idx, int n_minus, uint64_t n, uint32_t n_jobs, uint64_t first,
                                         uint64_t count, const uint64_t *in_dev, const flashe_codec_layer *layers, int n_layers,
                                         int element_bits, int num_clients, double *out_dev);
+/* The BATCHED form of the same job (the paper's main configuration, "batch": true): QuantizingClient.quantize packs
+ * batch_size = int_bits / field_bits quantised values (field_bits = element_bits + ceil(log2(num_clients))) into every ciphertext element,
+ * first value most significant, EVERY LAYER padded with zeros to whole elements on its own (_static_batching_padding_asymmetric,
+ * jzf_quantize.py:162-185 under :436-451); flatten_weights then concatenates the batched layers and the cipher encrypts that vector.
+ * quantize_batch_model: one launch from the layers' float values (x_dev per layer) and the model's uniform draws (u_dev[j] = draw of the
+ * j-th value in walking order) to the flattened batched plaintext out_dev[n_elems][L] (then flashe_encrypt_dev); unbatch_unquantize_model:
+ * one launch from the decrypted flattened vector to the model's float64 values in walking order (_static_unbatching_padding_asymmetric
+ * :234-251, the `[:size]` cut of QuantizingClient.unquantize :509-513, _static_unquantize_padding_asymmetric :102-107).
+ * n_elems must equal sum over layers of ceil(size / batch_size).  layers is a HOST array. */
+typedef struct flashe_batch_layer {
+    uint64_t size;         /* values in the layer */
+    const void *x_dev;     /* quantize_batch_model: the layer's float32 / float64 values; ignored on the way back */
+    double alpha;
+    int32_t x_is_f64;
+    int32_t reserved;      /* 0 */
+} flashe_batch_layer;
+int flashe_quantize_batch_model_dev(flashe_ctx *ctx, const flashe_batch_layer *layers, int n_layers, int element_bits, int field_bits,
+                                    const double *u_dev, uint64_t n_elems, uint64_t *out_dev);
+int flashe_unbatch_unquantize_model_dev(flashe_ctx *ctx, const flashe_batch_layer *layers, int n_layers, int element_bits,
+                                        int field_bits, int num_clients, const uint64_t *in_dev, uint64_t n_elems, double *out_dev);
 /* QuantizingClient.normalize / unnormalize (jzf_quantize.py:542-564): x <- x + shift in place (normalize passes -mean).  wide: for
  * float32 arrays the addition runs in float64 and is rounded once -- NumPy's loop when the scalar is a float64 (np.mean / np.std
  * results), as opposed to a Python float; bit-exact either way.  mean_std: the per-layer statistics unnormalize records for the next

@@ -782,7 +782,13 @@ def gen_clientstep():
             (20, 12, 3, 5, "double", 6, [("l0", (13, 3), "float32", 1.0), ("l1", (1,), "float32", 1.0), ("l2", (4, 5), "float64", 4.0)]),
             (64, 32, 2, 8, "single", 1, [("w", (10, 10), "float32", 1.0), ("x", (3,), "float32", 1.0)]),
             (23, 16, 4, 16, "double", 3, [("only", (61,), "float32", 1.0)])]
-    for b, eb, C, n_jobs, scheme, it, layer_specs in grid:
+    # BATCHED jobs (the paper's main configuration, "batch": true): several quantised values per ciphertext element
+    # (_static_batching_padding_asymmetric, jzf_quantize.py:162-185, every layer padded to whole elements on its own), then flattened
+    batched = [(128, 16, 10, 8, "double", 4, [("a_conv", (7, 5), "float32", 0.8), ("b_bias", (11,), "float32", 3.0), ("c_dense", (3, 4), "float64", 1.0)]),
+               (120, 16, 3, 16, "double", 1, [("l0", (13,), "float32", 1.0), ("l1", (6, 1), "float32", 2.0)]),
+               (64, 12, 3, 5, "double", 7, [("w", (10, 10), "float32", 1.0), ("x", (3,), "float64", 1.0), ("y", (4,), "float32", 1.0)])]
+    for spec in [g + (False,) for g in grid] + [g + (True,) for g in batched]:
+        b, eb, C, n_jobs, scheme, it, layer_specs, batch = spec
         RF.N_JOBS = n_jobs
         mod = 1 << b
         clients = []
@@ -791,7 +797,7 @@ def gen_clientstep():
             ci.idx = c
             ci.generate_prp_seed(KEY)
             ci.set_num_clients(C)
-            qc = RQ.QuantizingClient(b, None, None, False, eb, True, True)
+            qc = RQ.QuantizingClient(b, None, None, batch, eb, True, True)
             qc.num_clients = C
             st = types.SimpleNamespace(cipher=ci, quantizer=qc, precompute=False, mask=scheme)
             st.encrypt = lambda x, st=st: RB._Client.encrypt(st, x)            # what JZFWeights.encrypted / decrypted call on the "cipher"
@@ -832,7 +838,7 @@ def gen_clientstep():
             w = RB._Client.unquantize(st, w)                                       # :899
             outs[nm] = {"dec": hxl(dec), "unquantized": {k: _fhex(np.array([float(v) for v in np.asarray(w._weights[k]).flatten()], dtype=np.float64))
                                                          for k in agg_client.shape_dict}}
-        cases.append({"b": b, "element_bits": eb, "num_clients": C, "n_jobs": n_jobs, "scheme": scheme, "iter": it, "n": n,
+        cases.append({"b": b, "element_bits": eb, "num_clients": C, "n_jobs": n_jobs, "scheme": scheme, "iter": it, "n": n, "batch": batch,
                       "layers": [[nm, list(sh), dt] for nm, sh, dt, _sc in layer_specs], "clients": rec_clients,
                       "agg_elem": hxl(agg_elem), "agg_packed": hxl(agg_packed), "out_elem": outs["elem"], "out_packed": outs["packed"]})
 

@@ -72,6 +72,34 @@ if "--profile" in sys.argv:                 # where the host time of the fused s
     pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(14)
 
+# the BATCHED job (the paper's main configuration: several quantised values per 128-bit ciphertext element): two launches
+bargs = {"quantize": {"int_bits": 128, "batch": True, "element_bits": 16, "padding": True, "secure": True}, "precompute": {"enable": False}}
+for name in ("batched, fused, device handles", "batched, call by call (object arrays in between)"):
+    cl = FlasheClient(bargs)
+    cl.create_cipher(3, C, bytes(range(32)))
+    cl.set_iter_index(1)
+    cl.fuse = name.startswith("batched, fused")
+    best = 1e9
+    for rep in range(3 if cl.fuse else 1):
+        w = W({k: v.copy() for k, v in layers.items()})
+        np.random.seed(1)
+        t0 = time.perf_counter()
+        out = cl.quantize_encrypt(w, device=cl.fuse)
+        cl.cipher.engine.sync()
+        best = min(best, time.perf_counter() - t0)
+    k0b = out.walking_order[0]
+    print(f"{name:62s}: {best * 1e3:9.1f} ms ({len(out._weights[k0b])} ciphertext elements of 6 values)", flush=True)
+    if cl.fuse:
+        aggb = cl.cipher.aggregate([out._weights[k0b]] * C)
+        cl.cipher.set_idx_list(raw_idx_list=list(range(1)) * C, mode="decrypt")
+        best = 1e9
+        for rep in range(3):
+            t0 = time.perf_counter()
+            backb = cl.decrypt_unquantize(W({k0b: aggb}))
+            best = min(best, time.perf_counter() - t0)
+        assert all(backb._weights[k].shape == layers[k].shape for k in layers)
+        print(f"{'batched, decrypt_unquantize (handle in, float64 layers out)':62s}: {best * 1e3:9.1f} ms", flush=True)
+
 # the way back: the aggregate of C such models (here: C copies of this client's flattened ciphertext) decrypted and unquantised
 cl = client()
 w = W({k: v.copy() for k, v in layers.items()})

@@ -241,17 +241,20 @@ def test_client_step_flatten_semantics_from_reference_fixture(cipher_cls):
     for case in g["dense"]:
         b, C = case["b"], case["num_clients"]
         cm.N_JOBS = case["n_jobs"]
-        args = {"quantize": {"int_bits": b, "batch": False, "element_bits": case["element_bits"], "padding": True, "secure": True},
+        args = {"quantize": {"int_bits": b, "batch": case["batch"], "element_bits": case["element_bits"], "padding": True, "secure": True},
                 "precompute": {"enable": False}}
-        sizes = [int(np.prod(sh)) for _nm, sh, _dt in case["layers"]]
         for c, rec in enumerate(case["clients"]):
+            # what the quantiser leaves per layer: the layer's own shape -- or, batched job, a 1-D array of batched elements (shape_dict
+            # records exactly these shapes, jzf_aggregator.py:641-642)
+            shapes = [(nm, tuple(rec["shape_dict"][nm])) for nm, _sh, _dt in case["layers"]]
+            sizes = [int(np.prod(sh)) for _nm, sh in shapes]
             cl = FlasheClient(args)
             cl.create_cipher(c, C, bytes(range(32)))
             cl.cipher.masking_scheme = case["scheme"]
             cl.set_iter_index(case["iter"])
             flat_q = unhex(rec["flat_quantized"])
             per_layer, at = {}, 0
-            for (nm, sh, _dt), size in zip(case["layers"], sizes):
+            for (nm, sh), size in zip(shapes, sizes):
                 per_layer[nm] = np.array(flat_q[at:at + size], dtype=object).reshape(sh)
                 at += size
             cl.quantizer.layer_size_list = sizes
@@ -267,7 +270,7 @@ def test_client_step_flatten_semantics_from_reference_fixture(cipher_cls):
                     w._weights[rec["flat_key"]] = cl.decrypt(w._weights[rec["flat_key"]])
                     assert [int(v) for v in w._weights[rec["flat_key"]]] == unhex(case[out_name]["dec"]), (b, agg_name)
                     w = cl.unflatten_weights(w)
-                    assert w.walking_order == sorted(per_layer) and all(w._weights[nm].shape == tuple(sh) for nm, sh, _dt in case["layers"])
+                    assert w.walking_order == sorted(per_layer) and all(w._weights[nm].shape == sh for nm, sh in shapes)
                     assert [int(v) for nm in w.walking_order for v in w._weights[nm].flatten()] == unhex(case[out_name]["dec"])
     for case in g["sparse"]:
         b, C = case["b"], case["num_clients"]

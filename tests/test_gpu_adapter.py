@@ -281,7 +281,7 @@ class _W:
 
 
 def _client_args(case, **extra):
-    d = {"quantize": {"int_bits": case["b"], "batch": False, "element_bits": case["element_bits"], "padding": True, "secure": True},
+    d = {"quantize": {"int_bits": case["b"], "batch": bool(case.get("batch")), "element_bits": case["element_bits"], "padding": True, "secure": True},
          "precompute": {"enable": False}}
     d.update(extra)
     return d
@@ -291,9 +291,9 @@ def _layers_of(case_layers, rec):
     return {nm: _arr(rec["layers"][nm], np.dtype(dt), sh) for nm, sh, dt in case_layers}
 
 
-@pytest.mark.parametrize("case_i", range(5))
+@pytest.mark.parametrize("case_i", range(8))
 @pytest.mark.parametrize("mode", ["fused-handles", "fused-host", "call-by-call"])
-def test_client_step_is_the_reference_jobs(case_i, mode, monkeypatch):
+def test_client_step_is_the_reference_jobs(case_i, mode):
     """The client step of a reference JOB against tests/golden/clientstep.json -- recorded by CALLING the reference:
     QuantizingClient.quantize -> Client.flatten_weights (jzf_aggregator.py:625-650) -> JZFOrderDictWeights.encrypted(_Client), the arbiter's
     two reduces, then decrypted -> Client.unflatten_weights (:652-671) -> unquantize.  The layers are flattened BEFORE the encrypt, so PRF
@@ -301,7 +301,9 @@ def test_client_step_is_the_reference_jobs(case_i, mode, monkeypatch):
     step that encrypts layer by layer.  FlasheClient.quantize_encrypt (one launch over the flattened model, per-layer alpha from a device
     table) and the same sequence call by call must both give the fixture's flat ciphertext bit for bit with the fixture's seed, leave
     NumPy's generator where the reference left it, and decrypt_unquantize must return the fixture's floats byte for byte from the
-    element-wise AND the packed aggregate."""
+    element-wise AND the packed aggregate.  Cases 5-7 are BATCHED jobs ("batch": true: several quantised values per ciphertext element,
+    every layer padded to whole elements on its own before the flatten): quantise + batch of the whole model in one launch, the encrypt
+    in a second one; back: decrypt, then unbatch + cut + unquantise in one launch."""
     from flashe_amd import cipher as cm
     from flashe_amd.block import FlasheClient
     from flashe_amd.engine import DeviceVector
@@ -315,13 +317,12 @@ def test_client_step_is_the_reference_jobs(case_i, mode, monkeypatch):
         cl.create_cipher(c, C, KEY)
         cl.cipher.masking_scheme = case["scheme"]
         cl.set_iter_index(case["iter"])
-        if mode == "call-by-call":
-            monkeypatch.setattr(cl, "_fusable", lambda *a: False)
+        cl.fuse = mode != "call-by-call"
         np.random.seed(rec["seed"])
         out = cl.quantize_encrypt(_W(_layers_of(case["layers"], rec)), device=(mode == "fused-handles"))
         st = np.random.get_state()
         np.random.seed(rec["seed"])
-        np.random.random(n)
+        np.random.random(sum(int(np.prod(sh)) for _nm, sh, _dt in case["layers"]))          # one draw per VALUE of the model
         st_want = np.random.get_state()
         assert st[2] == st_want[2] and np.array_equal(st[1], st_want[1]), "the NumPy stream must be consumed as the reference consumes it"
         assert out.walking_order == [rec["flat_key"]] and list(out._weights) == [rec["flat_key"]]
@@ -526,3 +527,76 @@ def test_dynamic_masking_on_the_device():
     assert dynamic_masking_choice(dev, total, engine=eng) == "single"
     print(f"dynamic_masking at config-5 size on the device: {dt * 1e3:.3f} ms (call incl. the host read-back)")
     assert dt < 5e-3, dt
+
+
+@pytest.mark.parametrize("b,eb,C,n_jobs", [(128, 16, 10, 16), (120, 16, 3, 7), (64, 12, 3, 16)])
+def test_batched_client_step_of_a_large_model_vs_oracle(oracle, b, eb, C, n_jobs):
+    """The BATCHED client step at a size that takes the device-side draws (90,000 + 1,000 + 350 + 0 + 70,001 values): quantise + batch of
+    the whole model in one launch, the encrypt of the flattened batched vector in a second one -- against the fixture-pinned quantiser
+    with host draws, the reference's batching arithmetic on Python ints (jzf_quantize.py:162-185: every layer padded to whole elements
+    on its own, first value most significant) and the ORACLE's encrypt of the flattened vector; back: decrypt_unquantize of the
+    aggregate against the oracle's decrypt, the unbatching (:234-251) and NumPy's unquantise arithmetic."""
+    from flashe_amd import cipher as cm
+    from flashe_amd import quantize as qz
+    from flashe_amd.block import FlasheClient
+    cm.N_JOBS = n_jobs
+    it = 3
+    factor = int(np.ceil(np.log2(C)))
+    fb, bs = eb + factor, b // (eb + factor)
+    case = {"b": b, "element_bits": eb, "batch": True}
+    rng = np.random.Generator(np.random.PCG64(b + eb))
+    shapes = {"a_conv": ((300, 300), np.float32), "b_bias": ((1000,), np.float32), "c_dense": ((50, 7), np.float64), "d_empty": ((0,), np.float32),
+              "e_fc": ((70001,), np.float32)}
+    handles, want_cts, clients = [], [], []
+    for c in range(C if C <= 3 else 3):
+        layers = {k: (rng.standard_normal(sh) * 0.7).astype(dt) for k, (sh, dt) in shapes.items()}
+        cl = FlasheClient(_client_args(case))
+        cl.create_cipher(c, C, KEY)
+        cl.set_iter_index(it)
+        np.random.seed(4321 + c)
+        np.random.random(1)
+        st0 = np.random.get_state()
+        handles.append(cl.quantize_encrypt(_W({k: v.copy() for k, v in layers.items()}), device=True))
+        st_got = np.random.get_state()
+        np.random.set_state(st0)
+        flat = []
+        for li, k in enumerate(sorted(layers)):
+            x = layers[k].reshape(-1)
+            u = np.random.random(x.size)
+            if not x.size:
+                continue
+            qv = qz._static_quantize_padding_asymmetric(x, float(cl.quantizer.alpha_list[li]), eb, uniforms=u, as_object=False).astype(np.uint64)
+            pad = (-len(qv)) % bs
+            qo = np.concatenate([qv, np.zeros(pad, dtype=np.uint64)]).astype(object).reshape(-1, bs)
+            elems = np.zeros(len(qo), dtype=object)
+            for t in range(bs):
+                elems = elems * (1 << fb) + qo[:, t]                          # temp *= mod; temp += value
+            flat.append(elems)
+        st_want = np.random.get_state()
+        assert st_got[2] == st_want[2] and np.array_equal(st_got[1], st_want[1])
+        flat = np.concatenate(flat)
+        want = oracle.encrypt(KEY, it, c, "double", n_jobs, b, oracle.ints_to_limbs([int(v) for v in flat], b))
+        k0 = handles[-1].walking_order[0]
+        assert np.array_equal(handles[-1]._weights[k0].to_host().reshape(want.shape), want), (b, c)
+        assert cl.shape_dict["a_conv"] == ((90000 + bs - 1) // bs,) and cl.quantizer.shape_list[0] == (300, 300)
+        want_cts.append(want)
+        clients.append(cl)
+    up = list(range(len(clients)))
+    agg = clients[0].cipher.aggregate([h._weights[h.walking_order[0]] for h in handles])
+    clients[0].set_idx_list(list(up))
+    back = clients[0].decrypt_unquantize(_W({"a_conv": agg}))
+    add, minus = cm._engine.telescope(sorted(up))
+    dec = oracle.limbs_to_ints(oracle.decrypt(KEY, it, add, minus, n_jobs, b, oracle.aggregate_elem(want_cts, b)))
+    at = 0
+    for li, k in enumerate(sorted(shapes)):
+        sh, _dt = shapes[k]
+        size = int(np.prod(sh))
+        nb = (size + bs - 1) // bs
+        vals = []
+        for item in dec[at:at + nb]:
+            vals += [(item >> (fb * (bs - 1 - t))) & ((1 << fb) - 1) for t in range(bs)]
+        at += nb
+        alpha = clients[0].quantizer.alpha_list[li] * C
+        v = np.array(vals[:size], dtype=np.float64) if size else np.zeros(0)
+        want = v * (2 * alpha) / (((1 << eb) - 1) * C) - alpha
+        assert back._weights[k].shape == sh and np.asarray(back._weights[k]).tobytes() == want.reshape(sh).tobytes(), (b, k)
