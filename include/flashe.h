@@ -49,8 +49,11 @@ typedef struct flashe_ctx flashe_ctx;
  *   1  rounds 1-3 (entry points and flashe_prf_job fields were added without a bump: n_in / in_stride / sum_out_dev, the *_u32_dev,
  *      *_sum_dev, sparse_double_masks, mt19937 and sparsify_batch calls -- a round-1 binding of flashe_prf_job is NOT compatible)
  *   2  round 4: flashe_codec_layer + flashe_quantize_encrypt_model_dev / flashe_decrypt_unquantize_model_dev (the fused codec over a
- *      flattened model); ctx-resident mask precompute (flashe_prepare_* / flashe_*_prepared_dev); flashe_span_bounds handles;
- *      flashe_dynamic_masking_cost_dev; timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only) */
+ *      flattened model), flashe_batch_layer + flashe_quantize_batch_model_dev / flashe_unbatch_unquantize_model_dev (batched jobs);
+ *      ctx-resident mask precompute (flashe_prepare_* / flashe_*_prepared[_dev] / flashe_prepared_query / _discard); flashe_span_bounds
+ *      handles (+ flashe_sparse_*_bounds_dev); flashe_dynamic_masking_cost_dev; flashe_encrypt_batch_range_dev and
+ *      flashe_packed_resolve_carry_strided_dev (element-sharded multi-GPU round); flashe_aggregate_elem_u32_dev; flashe_mt19937_plan;
+ *      timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only) */
 #define FLASHE_ABI_VERSION 2
 int flashe_abi_version(void);
 int flashe_device_count(int *count);

@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$SCRIPT" "$@" > "$OUT/run.log" 2>&1 < /dev/null
 f=$(ls "$OUT"/trace/*/*kernel_stats.csv 2>/dev/null | head -1)
 if [ -n "$f" ]; then
+  cp "$f" "$OUT/kernel_stats.csv"
   python3 - "$f" <<'PY'
 import csv, sys
 for r in list(csv.DictReader(open(sys.argv[1])))[:8]:
