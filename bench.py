@@ -353,7 +353,9 @@ def main(comm_factory=None, device_override=None):
             if rank != 0:
                 return
             line = state["fallback"]
-            if line is not None:
+            if line is not None and state.get("reason_key"):
+                line[state["reason_key"]] = reason             # (the main line is complete: the phase that failed came after it)
+            elif line is not None:
                 line["config"]["schedule_fallback_reason"] = reason
             else:
                 line = dict(out, value=None, ms_per_step=None, error=f"no round completed: {reason}")
@@ -729,6 +731,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
     if (world > 1 or args.force_dist) and not args.no_element_sharded:                # (the same decision on every rank)
         if rank == 0:
             state["fallback"] = line
+        state["reason_key"] = "element_sharded_error"
         wd.arm(args.calibration_deadline, "element-sharded round")
         try:
             extra = element_sharded_round(args, n, b, J, ops, rank, world, total, K, W, (lo, hi), orc)
@@ -737,6 +740,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
             wd.abort(f"element-sharded round raised on rank {rank}: {e}")
         if rank == 0 and line is not None:
             line.update(extra)
+        state["reason_key"] = None
     wd.arm(args.deadline, "closing")
     if rank != 0:
         return None

@@ -4,7 +4,8 @@ test seams: a file-based double of RcclComm (tests/shm_comm.py, directory from B
 every rank.  The printed figure is meaningless and labelled so.
 
 BENCH_SHM_INJECT=raise:R | hang:R makes rank R raise / block forever inside the first overlapped (fused) round -- what a first
-multi-GPU run may meet -- so that the tests can check the fallback: a valid sequential line within the deadline, exit code 0."""
+multi-GPU run may meet -- so that the tests can check the fallback: a valid sequential line within the deadline, exit code 0.
+raise_elements:R | hang_elements:R do the same inside the element-sharded phase that follows the main line."""
 import os
 import sys
 import time
@@ -27,7 +28,11 @@ def main():
                 if kind == "raise":
                     raise RuntimeError("injected failure of an optional schedule")
                 time.sleep(10 ** 6)
-            ShardedRound.run_fused = broken
+            if kind.endswith("_elements"):                       # the element-sharded phase, timed AFTER the main line exists
+                kind = kind[:-len("_elements")]
+                ShardedRound.run_elements = broken
+            else:
+                ShardedRound.run_fused = broken
     bench.main(comm_factory=lambda rank, world: ShmComm(rank, world, os.environ["BENCH_SHM_DIR"]), device_override=0)
 
 

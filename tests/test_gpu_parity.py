@@ -727,6 +727,21 @@ def test_bench_multi_rank_falls_back_to_the_sequential_line(inject, tmp_path):
     assert took < 200, took
 
 
+@pytest.mark.parametrize("inject", ["raise_elements:1", "hang_elements:2"])
+def test_bench_multi_rank_keeps_its_line_when_the_element_sharded_phase_fails(inject, tmp_path):
+    """The element-sharded partition is timed AFTER the client-sharded line exists: a rank that raises or hangs there (the others
+    then sit in a collective) must not cost the run its result -- rank 0 prints the main line, exit code 0, within the deadline."""
+    r, lines, took = _bench_shm(tmp_path, ["--config", "4", "--clients", "5", "--schedule", "sequential", "--calibration-deadline", "25"],
+                                {"BENCH_SHM_INJECT": inject}, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = lines[0]
+    assert d["value"] > 0 and d["n_gpus"] == 3 and d["config"]["ranks_parity_ok"] is True
+    assert "value_element_sharded" not in d and d["config"]["schedule_fallback_reason"] is None
+    assert "element_sharded_error" in d and (("injected failure" in d["element_sharded_error"]) if inject.startswith("raise") else ("deadline" in d["element_sharded_error"]))
+    assert took < 200, took
+
+
 def test_bench_partial_agg_schedule_multi_rank(tmp_path):
     """--schedule partial-agg with 3 ranks: the encrypt launch writes each rank's partial aggregate, which is what the exchange sends."""
     r, lines, _ = _bench_shm(tmp_path, ["--config", "2", "--clients", "3", "--schedule", "partial-agg"])
