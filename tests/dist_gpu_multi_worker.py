@@ -73,7 +73,9 @@ def main():
     # ---- element sharding: every rank plays EVERY client on its own slice of the vectors; real kernels on ranges with
     # non-zero `first`, the chained launch with the slice of the partial aggregate, the backward carry walk of the packed reduce
     for b, n, C, J, scheme in [(128, 300_007, 10, 16, SCHEME_DOUBLE), (128, 70_001, 3, 16, SCHEME_DOUBLE), (20, 50_001, 4, 16, SCHEME_DOUBLE),
-                               (64, 7777, 3, 4, SCHEME_SINGLE), (128, 999, 2, 1, SCHEME_DOUBLE), (33, 2_100_003, 2, 8, SCHEME_DOUBLE)]:
+                               (64, 7777, 3, 4, SCHEME_SINGLE), (128, 999, 2, 1, SCHEME_DOUBLE), (33, 2_100_003, 2, 8, SCHEME_DOUBLE),
+                               # 80 clients on every rank's slice: what `bench.py --gpus 8` (config 2, ten clients per GPU) runs in its element-sharded phase
+                               (128, 50_001, 80, 16, SCHEME_DOUBLE), (20, 30_001, 130, 16, SCHEME_DOUBLE)]:
         L = 2 if b > 64 else 1
         eng = Engine(KEY, b, device=0)
         ops = HipOps(eng, None, comm)
