@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One-off fuzz of the sharded round with real kernels: random world sizes (ranks share GPU 0, exchange through tests/shm_comm.py),
-vector lengths, bit widths, dealings and chunk counts; every schedule against the oracle.  usage: fuzz_dist.py [cases] [seed]"""
+vector lengths, bit widths, dealings and chunk counts; every schedule of the client-sharded round and -- round 4 -- the element-sharded round
+(element-wise with / without the partial aggregate, and packed) against the oracle.  usage: fuzz_dist.py [cases] [seed]"""
 import json
 import os
 import subprocess
@@ -45,6 +46,17 @@ for b, n, C, J, dbl, chunks in json.loads(os.environ["CASES"]):
                else rnd.run_fused(2, pts, 1, chunks=chunks) if mode == "fused" else rnd.run_packed(2, pts, 1))
         got = ops.read((out, 0), n * L).reshape(n, L)
         assert np.array_equal(got, wantp if mode == "packed" else want), (rank, world, b, n, C, J, dbl, chunks, mode)
+    # the other partition (round 4): elements instead of clients sharded -- every rank plays every client on its slice
+    ernd = ShardedRound(ops, n, b, C, J, rank=rank, world=world, scheme=scheme, shard="elements")
+    first, count = ernd.element_range()
+    epts = [(ops.upload(host[c][first:first + count]) if count else ops.alloc(2), 0) for c in range(C)]
+    for partial in (True, False):
+        got = ops.read((ernd.run(2, epts, 1, partial_agg=partial), 0), n * L).reshape(n, L)
+        assert np.array_equal(got, want), (rank, world, b, n, C, J, dbl, "elements", partial)
+    lo, cnt = ernd.element_range(packed=True)
+    ppts = [(ops.upload(host[c][lo:lo + cnt]) if cnt else ops.alloc(2), 0) for c in range(C)]
+    got = ops.read((ernd.run_packed(2, ppts, 1), 0), n * L).reshape(n, L)
+    assert np.array_equal(got, wantp), (rank, world, b, n, C, J, dbl, "elements packed")
 comm.barrier(eng)
 print("OK")
 ''' % (ROOT, ROOT)
