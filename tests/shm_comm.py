@@ -22,6 +22,30 @@ class ShmComm:
         with open(tmp, "wb") as f:
             f.write(data)
         os.replace(tmp, os.path.join(self.dir, name))
+        self.__dict__.setdefault("_mine", []).append((self.seq, name))
+
+    def _sweep(self):
+        """Drop this rank's files of collectives <= seq - 2: a rank that has finished collective s - 1 has read every peer's s - 1 file, so
+        every peer had started s - 1, i.e. finished reading s - 2 (full-size vectors would otherwise pile up gigabytes in the directory)."""
+        keep = []
+        for seq, name in self.__dict__.get("_mine", []):
+            if seq <= self.seq - 2:
+                try:
+                    os.unlink(os.path.join(self.dir, name))
+                except OSError:
+                    pass
+            else:
+                keep.append((seq, name))
+        self._mine = keep
+
+    def _take(self, name):
+        """A file only this rank reads (its piece of an all-to-all): read, then removed."""
+        data = self._get(name)
+        try:
+            os.unlink(os.path.join(self.dir, name))
+        except OSError:
+            pass
+        return data
 
     def _get(self, name, timeout=60.0):
         path = os.path.join(self.dir, name)
@@ -47,19 +71,23 @@ class ShmComm:
     # ---- RcclComm surface ----
     def all_to_all(self, engine, send_ptr, send_stride, recv_ptr, recv_stride, nbytes):
         s = self.seq = self.seq + 1
+        self._sweep()
         for p in range(self.world):
             self._put(f"a2a_{s}_{self.rank}_{p}", self._d2h(engine, send_ptr + p * send_stride, nbytes).tobytes())
+        self._mine = [(q, nm) for q, nm in self._mine if not nm.startswith(f"a2a_{s}_")]      # (the receivers remove these)
         for p in range(self.world):
-            self._h2d(engine, recv_ptr + p * recv_stride, np.frombuffer(self._get(f"a2a_{s}_{p}_{self.rank}"), dtype=np.uint8))
+            self._h2d(engine, recv_ptr + p * recv_stride, np.frombuffer(self._take(f"a2a_{s}_{p}_{self.rank}"), dtype=np.uint8))
 
     def all_gather(self, engine, send_ptr, recv_ptr, nbytes):
         s = self.seq = self.seq + 1
+        self._sweep()
         self._put(f"ag_{s}_{self.rank}", self._d2h(engine, send_ptr, nbytes).tobytes())
         for p in range(self.world):
             self._h2d(engine, recv_ptr + p * nbytes, np.frombuffer(self._get(f"ag_{s}_{p}"), dtype=np.uint8))
 
     def allreduce_modadd(self, engine, ptr, count):
         s = self.seq = self.seq + 1
+        self._sweep()
         self._put(f"arm_{s}_{self.rank}", self._d2h(engine, ptr, 8 * count).tobytes())
         tot = np.zeros(count, dtype=np.uint64)
         for p in range(self.world):

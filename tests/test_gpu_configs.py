@@ -230,3 +230,22 @@ def test_bench_lines_on_one_gpu(args, keys):
     if "--schedule" in args:
         want = args[args.index("--schedule") + 1]
         assert d["config"]["schedule_name"] == want or want == "auto"
+
+
+def test_config4_full_size_eight_way_both_partitions(tmp_path):
+    """BASELINE config 4 (25,557,032 elements, 10 clients, b = 128) in its 8-way shape with REAL kernels: eight ranks share this GPU and
+    exchange through the file-based comm double.  Both partitions of SURVEY 8e: clients dealt 2, 2, 1, 1, 1, 1, 1, 1 (all-to-all +
+    sliced decrypt + all-gather) and elements sharded (every rank the whole client chain on its eighth, no exchange for the aggregate):
+    decrypted aggregate == plaintext sum at full size, ciphertext slices == the oracle's."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="8", FLASHE_TEST_SHM_DIR=str(tmp_path), OMP_WAIT_POLICY="passive")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_config4_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: {so[-1500:]}{se[-3000:]}"
+    assert "CONFIG4_8WAY_OK" in outs[0][0]
