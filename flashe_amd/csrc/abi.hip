@@ -2534,4 +2534,16 @@ int flashe_sparsify_batch(flashe_ctx *ctx, int n_layers, const uint64_t *n, cons
     return FLASHE_OK;
 }
 
+#ifdef FLASHE_TUNING
+// tuning build only (not in include/flashe.h): the two-workgroups-per-CU experiment, tests/perf/ab_reduce_2wg.py
+int flashe_tune_reduce_decrypt_probe(flashe_ctx *ctx, int variant, uint32_t iter, uint32_t add_idx, uint32_t minus_idx, int C,
+                                     const uint64_t *const *cts_dev, uint64_t n, uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (!cts_dev || !out_dev) return fail(ctx, FLASHE_EINVAL, "null vector");
+    HIP_TRY(ctx, launch_reduce_decrypt_probe(ctx->env, variant, iter, add_idx, minus_idx, C, cts_dev, n, out_dev));
+    return FLASHE_OK;
+}
+#endif
+
 }  // extern "C"

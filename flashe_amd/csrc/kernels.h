@@ -255,4 +255,11 @@ hipError_t launch_sparsify(const LaunchEnv &env, uint64_t n, uint64_t k, const v
 hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t *in_words_dev,
                              uint32_t *out_words_dev);
 
+#ifdef FLASHE_TUNING
+// tuning build only: the two-workgroups-per-CU experiment on the reduce fused with the decrypt (kernels.hip); variant 0 = 1024 threads,
+// full tables (correct results); 1 = 2 x 512 threads on half-size aliased tables (timing probe, wrong results); 2 = 1024 threads on them
+hipError_t launch_reduce_decrypt_probe(const LaunchEnv &env, int variant, uint32_t iter, uint32_t add_idx, uint32_t minus_idx, int C,
+                                       const uint64_t *const *ops, uint64_t n, uint64_t *out_dev);
+#endif
+
 }  // namespace flashe

@@ -2168,4 +2168,74 @@ hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t
     return hipGetLastError();
 }
 
+#ifdef FLASHE_TUNING
+// ---- experiment (tuning build only): does the reduce fused with the decrypt gain from TWO workgroups per CU? ----
+// The same simplified loop -- one element per lane per trip, all C operands requested before the two-block AES pass, result stored
+// non-temporally -- in two shapes: THREADS = 1024 with the full 128-KiB tables (one workgroup per CU, the product's shape) and
+// THREADS = 512 with HALF-size tables (64 KiB: two workgroups fit a CU).  The half-size form is a TIMING PROBE: tables 2 / 3 alias
+// tables 0 / 1, so its results are wrong -- what a real two-table AES would add on top (one rotate per aliased lookup) is NOT in it,
+// i.e. it measures an upper bound of what the split could buy.
+template <int THREADS, bool HALF>
+__global__ __launch_bounds__(THREADS) void reduce_decrypt_probe_kernel(const RoundKeys rk, const PtrTable ops, int C, uint64_t n, uint32_t iter0,
+                                                                       uint32_t add_idx, uint32_t minus_idx, uint64_t mask_lo, uint64_t mask_hi,
+                                                                       const uint32_t *__restrict__ te0, uint64_t *out)
+{
+    const uint32_t iter = iter0 + te0[kIterShiftWord];
+    __shared__ uint32_t tab[HALF ? kTabWords / 2 : kTabWords];
+    for (int e = threadIdx.x; e < (HALF ? 512 : 1024); e += THREADS) {
+        const int t = e >> 8, x = e & 255;
+        const uint32_t v = rotr32(te0[x], 8 * t);
+        uint4 vv = make_uint4(v, v, v, v);
+        uint4 *dst = reinterpret_cast<uint4 *>(tab + ((t >> 1) * 16384 + x * 64 + (t & 1) * 32));
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = vv;
+    }
+    __syncthreads();
+    LaneRegs lr = lane_regs(tab);
+    if (HALF) lr.b = lr.a;
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const CtrPrefix pre_a = scalar_prefix(ctr_prefix(rk, lr, iter, add_idx, 0u)), pre_b = scalar_prefix(ctr_prefix(rk, lr, iter, minus_idx, 0u));
+    const uint64_t *const *tab_ops = ops.p;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * THREADS + threadIdx.x; k < n; k += static_cast<uint64_t>(gridDim.x) * THREADS) {
+        u64x2 held[kSumRegs];
+#pragma unroll
+        for (int c = 0; c < kSumRegs; c++) held[c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(tab_ops[c < C ? c : 0] + 2 * k));
+        const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(k));
+        uint32_t s[2][4];
+        ctr_round1(pre_a, x, s[0]);
+        ctr_round1(pre_b, x, s[1]);
+        aes256_rounds<2, 2>(rk, lr, s);
+        u128 acc = 0;
+#pragma unroll
+        for (int c = 0; c < kSumRegs; c++)
+            if (c < C) acc += (static_cast<u128>(held[c][1]) << 64) | held[c][0];
+        acc += words_to_u128(s[0]);
+        acc -= words_to_u128(s[1]);
+        st128_nt(out + 2 * k, acc & mask);
+    }
+}
+
+hipError_t launch_reduce_decrypt_probe(const LaunchEnv &env, int variant, uint32_t iter, uint32_t add_idx, uint32_t minus_idx, int C,
+                                       const uint64_t *const *ops, uint64_t n, uint64_t *out_dev)
+{
+    if (C < 1 || C > kSumRegs || env.b <= 64) return hipErrorInvalidValue;
+    PtrTable t;
+    for (int c = 0; c < kMaxOps; c++) t.p[c] = c < C ? ops[c] : nullptr;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    if (variant == 0)
+        hipLaunchKernelGGL((reduce_decrypt_probe_kernel<1024, false>), dim3(env.num_cus), dim3(1024), 0, env.stream, env.rk, t, C, n, iter, add_idx,
+                           minus_idx, lo, hi, env.te0_dev, out_dev);
+    else if (variant == 1)
+        hipLaunchKernelGGL((reduce_decrypt_probe_kernel<512, true>), dim3(2 * env.num_cus), dim3(512), 0, env.stream, env.rk, t, C, n, iter, add_idx,
+                           minus_idx, lo, hi, env.te0_dev, out_dev);
+    else if (variant == 2)          // the half-size tables with ONE 1024-thread workgroup per CU: separates "two workgroups" from "smaller tables"
+        hipLaunchKernelGGL((reduce_decrypt_probe_kernel<1024, true>), dim3(env.num_cus), dim3(1024), 0, env.stream, env.rk, t, C, n, iter, add_idx,
+                           minus_idx, lo, hi, env.te0_dev, out_dev);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+#endif
+
 }  // namespace flashe
