@@ -1499,6 +1499,17 @@ int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, const uin
         HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, n_minus == 1, 1, &job, n, n_jobs));
         return FLASHE_OK;
     }
+    if (ctx->limbs == 2 && n_add == 1 && n_minus <= 1 && aligned16(out_dev) && aligned16(agg_out_dev)) {
+        // operands that are NOT equally spaced (separately allocated ciphertexts), or a short vector: still one launch
+        bool ok = true;
+        for (int c = 0; c < C && ok; c++) ok = aligned16(cts_dev[c]);
+        if (ok) {
+            const hipError_t e = launch_reduce_decrypt_ptrs(ctx->env, iter, add_idx[0], n_minus == 1, n_minus ? minus_idx[0] : 0u, first, count, C, cts_dev,
+                                                            agg_out_dev, out_dev);
+            if (e == hipSuccess) return FLASHE_OK;
+            if (e != hipErrorNotSupported) HIP_TRY(ctx, e);
+        }
+    }
     if (ctx->limbs == 1 && n_add == 1 && n_minus <= 1) {
         // b <= 64: the same fusion in the small-modulus form (FLASHE_SMALL_FUSED_REDUCE=0: two launches, the A/B switch)
 #ifdef FLASHE_TUNING

@@ -255,6 +255,11 @@ hipError_t launch_sparsify(const LaunchEnv &env, uint64_t n, uint64_t k, const v
 hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t *in_words_dev,
                              uint32_t *out_words_dev);
 
+// b > 64, one add and at most one minus prefix, C <= kMaxOps operands ANYWHERE in HBM (pointers address element `first`): out = sum of the
+// operands + term(add) - term(minus) on [first, first + count) in ONE launch; agg_out_dev (may be null) receives the sum.
+// hipErrorNotSupported (nothing launched): b <= 64, too many operands, a range across a 2^32 counter boundary, another PRF backend.
+hipError_t launch_reduce_decrypt_ptrs(const LaunchEnv &env, uint32_t iter, uint32_t add_idx, bool has_minus, uint32_t minus_idx, uint64_t first,
+                                      uint64_t count, int C, const uint64_t *const *ops, uint64_t *agg_out_dev, uint64_t *out_dev);
 #ifdef FLASHE_TUNING
 // tuning build only: the two-workgroups-per-CU experiment on the reduce fused with the decrypt (kernels.hip); variant 0 = 1024 threads,
 // full tables (correct results); 1 = 2 x 512 threads on half-size aliased tables (timing probe, wrong results); 2 = 1024 threads on them

@@ -2168,6 +2168,71 @@ hipError_t launch_aes_blocks(const LaunchEnv &env, uint32_t nblk, const uint32_t
     return hipGetLastError();
 }
 
+// ---- the arbiter's reduce fused with the decrypt of its result, operands ANYWHERE in HBM (b > 64, one add / at most one minus prefix) ----
+// out[k] = (sum_c ops[c][k] + term(add, first + k) - [DBL] term(minus, first + k)) mod 2^b for k < count.  The job-table form of this
+// fusion (prf_wide_batch_kernel<..., 2>) wants the operands equally spaced in one allocation; separately allocated ciphertexts used to
+// fall back to two launches (reduce, then decrypt: 0.61 ms for ten 1e7-element operands).  A plain grid-stride loop -- one element per
+// lane per trip, the first kSumRegs operands requested before the element's AES pass and added after it, further operands summed up
+// front -- measured the same as the tiled form on equally spaced operands (0.346 against 0.352 ms, tests/perf/ab_reduce_2wg.py), so
+// this is the one-launch form for operand lists of any layout.
+template <bool DBL>
+__global__ __launch_bounds__(kPrfThreads) void reduce_decrypt_ptrs_kernel(const RoundKeys rk, const PtrTable ops, int C, uint64_t first, uint64_t count,
+                                                                          uint32_t iter0, uint32_t add_idx, uint32_t minus_idx, uint64_t mask_lo,
+                                                                          uint64_t mask_hi, const uint32_t *__restrict__ te0, uint64_t *agg_out,
+                                                                          uint64_t *out)
+{
+    const uint32_t iter = iter0 + te0[kIterShiftWord];
+    __shared__ uint32_t tab[kTabWords];
+    fill_tables(tab, te0);
+    const LaneRegs lr = lane_regs(tab);
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const uint32_t ctr_hi = static_cast<uint32_t>(first >> 32);                 // (host-checked: the range stays inside one 2^32 window)
+    const CtrPrefix pre_a = scalar_prefix(ctr_prefix(rk, lr, iter, add_idx, ctr_hi));
+    CtrPrefix pre_b{};
+    if (DBL) pre_b = scalar_prefix(ctr_prefix(rk, lr, iter, minus_idx, ctr_hi));
+    const uint64_t *const *tab_ops = ops.p;
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * kPrfThreads + threadIdx.x; k < count; k += static_cast<uint64_t>(gridDim.x) * kPrfThreads) {
+        u64x2 held[kSumRegs];
+#pragma unroll
+        for (int c = 0; c < kSumRegs; c++) held[c] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(tab_ops[c < C ? c : 0] + 2 * k));
+        u128 acc = 0;
+        for (int c = kSumRegs; c < C; c++) acc += ld128_nt(tab_ops[c] + 2 * k);
+        const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(first + k));
+        uint32_t s[DBL ? 2 : 1][4];
+        ctr_round1(pre_a, x, s[0]);
+        if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
+        aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
+#pragma unroll
+        for (int c = 0; c < kSumRegs; c++)
+            if (c < C) acc += (static_cast<u128>(held[c][1]) << 64) | held[c][0];
+        acc &= mask;
+        if (agg_out) st128_nt(agg_out + 2 * k, acc);
+        acc += words_to_u128(s[0]);
+        if (DBL) acc -= words_to_u128(s[DBL ? 1 : 0]);
+        st128_nt(out + 2 * k, acc & mask);
+    }
+}
+
+hipError_t launch_reduce_decrypt_ptrs(const LaunchEnv &env, uint32_t iter, uint32_t add_idx, bool has_minus, uint32_t minus_idx, uint64_t first,
+                                      uint64_t count, int C, const uint64_t *const *ops, uint64_t *agg_out_dev, uint64_t *out_dev)
+{
+    if (count == 0) return hipSuccess;
+    if (env.b <= 64 || C < 1 || C > kMaxOps || ((first + count - 1) >> 32) != (first >> 32)) return hipErrorNotSupported;
+    if (env.prf_backend != PRF_AUTO && env.prf_backend != PRF_TABLE) return hipErrorNotSupported;
+    PtrTable t;
+    for (int c = 0; c < kMaxOps; c++) t.p[c] = c < C ? ops[c] : nullptr;
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const int grid = grid_for(env, count, kPrfThreads);
+    if (has_minus)
+        hipLaunchKernelGGL(reduce_decrypt_ptrs_kernel<true>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, t, C, first, count, iter, add_idx,
+                           minus_idx, lo, hi, env.te0_dev, agg_out_dev, out_dev);
+    else
+        hipLaunchKernelGGL(reduce_decrypt_ptrs_kernel<false>, dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, t, C, first, count, iter, add_idx,
+                           0u, lo, hi, env.te0_dev, agg_out_dev, out_dev);
+    return hipGetLastError();
+}
+
 #ifdef FLASHE_TUNING
 // ---- experiment (tuning build only): does the reduce fused with the decrypt gain from TWO workgroups per CU? ----
 // The same simplified loop -- one element per lane per trip, all C operands requested before the two-block AES pass, result stored

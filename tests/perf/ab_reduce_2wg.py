@@ -32,8 +32,13 @@ orc.build()
 for C in (10, 4):
     rng = np.random.Generator(np.random.PCG64(C))
     cts = [rng.integers(0, 2 ** 64, (n, 2), dtype=np.uint64) for _ in range(C)]
-    dev = [eng.upload(c) for c in cts]
-    ptrs = (ctypes.c_void_p * C)(*[d.ptr for d in dev])
+    # equally spaced in ONE allocation: the shape the product's one-launch form takes (ShardedRound lays its ciphertexts out like this)
+    stride = (2 * n + 1) // 2 * 2
+    big = eng.alloc(C * stride * 8)
+    for c in range(C):
+        big.upload_at(c * stride * 8, cts[c])
+    dev = [big.ptr + c * stride * 8 for c in range(C)]
+    ptrs = (ctypes.c_void_p * C)(*dev)
     out = eng.alloc_vec(n)
     it = 5
 

@@ -8,6 +8,7 @@
   bounds   flashe_span_bounds_* + sparse aggregate / decrypt through the handle, recompute for new lists
   masking  flashe_dynamic_masking_cost_dev  (positions shared by consecutive clients)
   strided  flashe_packed_resolve_carry_strided_dev (carry-in from triples walked backwards)
+  rdptrs   flashe_aggregate_decrypt_range_dev at b > 64 on operands in separate allocations (the pointer-table one-launch form)
 usage: fuzz_round4.py [cases per family] [seed] [families, comma separated]"""
 import os
 import sys
@@ -245,7 +246,38 @@ def fuzz_strided(rng, case):
     return f"W={W} rank={g} limbs={n_limbs} bits={total_bits} carry={carry}"
 
 
-FAMILIES = {"range": fuzz_range, "model": fuzz_model, "prepared": fuzz_prepared, "agg32": fuzz_agg32, "bounds": fuzz_bounds, "masking": fuzz_masking,
+def fuzz_rdptrs(rng, case):
+    """flashe_aggregate_decrypt_range_dev at b > 64 with operands scattered over separate allocations: the pointer-table one-launch form
+    (up to 64 operands; beyond, or with prefix lists, the two-launch form), sub-ranges, with / without the stored aggregate."""
+    b = int(rng.choice([128, 128, 127, 100, 65]))
+    C = int(rng.choice([1, 2, 3, 10, 11, 12, 33, 64, 65, 70]))
+    n = pick_n(rng, 12_000_000 // C + 1)
+    first = int(rng.integers(0, n)) if rng.random() < 0.6 else 0
+    count = int(rng.integers(0, n - first + 1)) if rng.random() < 0.6 else n - first
+    it, n_jobs = int(rng.integers(0, 2 ** 32)), int(rng.choice([1, 16]))
+    kind = rng.integers(0, 4)
+    add, minus = ([C], [0]) if kind < 2 else ([int(rng.integers(0, 99))], []) if kind == 2 else ([3, 7], [0, 5])
+    eng = E.Engine(KEY, b, device=0)
+    cts = []
+    for _ in range(C):
+        a = rng.integers(0, 2 ** 64, (n, 2), dtype=np.uint64)
+        if b < 128:
+            a[:, 1] &= np.uint64((1 << (b - 64)) - 1)
+        cts.append(a)
+    dev = [eng.upload(c) for c in cts]
+    keep = rng.random() < 0.5
+    out, ao = eng.alloc_vec(max(count, 1)), eng.alloc_vec(max(count, 1))
+    eng.aggregate_decrypt_range_dev(it, add, minus, n, n_jobs, first, count, [d.ptr + 16 * first for d in dev], ao if keep else None, out)
+    if count:
+        agg = orc.aggregate_elem([c[first:first + count] for c in cts], b)
+        want = orc.combine(b, agg, orc.mask_sum(KEY, it, add, n, n_jobs, b)[first:first + count], orc.mask_sum(KEY, it, minus, n, n_jobs, b)[first:first + count])
+        assert np.array_equal(out.download(np.uint64, 2 * count).reshape(count, 2), want), ("rdptrs", case, b, C, n, first, count, add, minus)
+        if keep:
+            assert np.array_equal(ao.download(np.uint64, 2 * count).reshape(count, 2), agg), ("rdptrs/agg", case, b, C, n, first, count)
+    return f"b={b} C={C} n={n} [{first}, +{count}) add={add} minus={minus} keep={keep}"
+
+
+FAMILIES = {"rdptrs": fuzz_rdptrs, "range": fuzz_range, "model": fuzz_model, "prepared": fuzz_prepared, "agg32": fuzz_agg32, "bounds": fuzz_bounds, "masking": fuzz_masking,
             "strided": fuzz_strided}
 
 
