@@ -23,8 +23,22 @@ def _engine(bits, device=0):
 
 
 def to_big_int(flatten_array, num_bits, device=0):
-    """`_to_bytes(flatten_array, num_bits)` / `_to_bytes_old` (jzf_weights.py:36-84) -> (int, length)."""
+    """`_to_bytes(flatten_array, num_bits)` / `_to_bytes_old` (jzf_weights.py:36-84) -> (int, length).  A `DeviceVector` (a ciphertext
+    that stayed in HBM) is packed where it lies: only the n * num_bits / 8 packed bytes come down."""
+    from .engine import DeviceVector
     eng = _engine(num_bits, device)
+    if isinstance(flatten_array, DeviceVector):
+        dv = flatten_array.widened(eng) if flatten_array.compact else flatten_array
+        n = len(dv)
+        if n == 0:
+            return 0, 0
+        if dv.limbs != eng.limbs:
+            raise ValueError(f"expected {eng.limbs} limbs per element for {num_bits}-bit fields, got {dv.limbs}")
+        dv.wait_on(eng)
+        n_limbs = (n * num_bits + 63) // 64
+        packed = eng.alloc(max(8 * n_limbs, 16))
+        eng.pack_dev(n, dv.buf, packed)
+        return int.from_bytes(packed.download(np.uint64, n_limbs).tobytes(), "little"), n
     arr = np.asarray(flatten_array)
     if arr.dtype != object and arr.dtype != np.uint64:
         arr = arr.astype(object)
@@ -38,14 +52,19 @@ def to_big_int(flatten_array, num_bits, device=0):
     return int.from_bytes(packed.tobytes(), "little"), n
 
 
-def from_big_int(big_int, length, num_bits, device=0, as_object=True):
+def from_big_int(big_int, length, num_bits, device=0, as_object=True, as_device=False):
     """`_from_bytes(...)` followed by `reverse()` (jzf_weights.py:87-137, :225-228): the values in their
-    original order."""
+    original order.  as_device: unpacked in HBM and returned as a `DeviceVector` (the arbiter's operands of `aggregate`)."""
+    from .engine import DeviceVector
     eng = _engine(num_bits, device)
     if length == 0:
-        return np.array([], dtype=object if as_object else np.uint64)
+        return DeviceVector(eng, 0) if as_device else np.array([], dtype=object if as_object else np.uint64)
     n_limbs = (length * num_bits + 63) // 64
     packed = np.frombuffer(int(big_int).to_bytes(n_limbs * 8, "little"), dtype=np.uint64)
+    if as_device:
+        out = DeviceVector(eng, length)
+        eng.unpack_dev(length, eng.upload(packed), out.buf)
+        return out.mark_ready()
     out = eng.unpack(packed, length)
     return _from_limbs(out, "object") if as_object else out
 

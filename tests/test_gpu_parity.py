@@ -1083,6 +1083,12 @@ def test_wire_format_mirror(E):
         big, n = wz.to_big_int(np.array(vals, dtype=object), c["b"])
         assert n == c["n"] and big == int(c["packed_int"], 16)
         assert [int(v) for v in wz.from_big_int(big, n, c["b"])] == vals
+        # device-resident ends of the wire format: a handle is packed where it lies, a received integer is unpacked into HBM
+        if n:
+            from oracle.flashe_oracle import limbs_to_ints
+            dv = wz.from_big_int(big, n, c["b"], as_device=True)
+            assert isinstance(dv, E.DeviceVector) and limbs_to_ints(dv.to_host()) == vals
+            assert wz.to_big_int(dv, c["b"]) == (big, n)
     layer = np.array([[3, 1, 4], [1, 5, 9]], dtype=object)
     tw = wz.TransferableWeights({"w": layer, "b": np.array([7], dtype=object)}, bits=20)
     assert tw.unboxed["w"] == sum(int(v) << (20 * (5 - j)) for j, v in enumerate(layer.flatten()))
