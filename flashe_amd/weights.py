@@ -80,18 +80,25 @@ class TransferableWeights(object):
 
     def compress(self):
         res, self._shape = {}, {}
+        from .engine import DeviceVector
         for k, w in self._weights.items():
+            if isinstance(w, DeviceVector):                  # a ciphertext that stayed in HBM: packed there, only the packed bytes come down
+                self._shape[k] = (len(w),)
+                res[k] = to_big_int(w, self._bits, self._device)[0]
+                continue
             w = np.asarray(w)
             self._shape[k] = w.shape
             res[k] = to_big_int(w.flatten(), self._bits, self._device)[0]
         self._weights = res
 
-    def decompress(self):
+    def decompress(self, as_device=False):
+        """as_device: every layer comes back as a flat `DeviceVector` in HBM (the arbiter's operands of `aggregate`) instead of an object array."""
         out = {}
         for k, big in self._weights.items():
             shape = self._shape[k]
             n = int(np.prod(shape))
-            out[k] = from_big_int(big, n, self._bits, self._device).reshape(shape)
+            v = from_big_int(big, n, self._bits, self._device, as_device=as_device)
+            out[k] = v if as_device else v.reshape(shape)
         return out
 
     @property

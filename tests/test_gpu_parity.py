@@ -1094,6 +1094,10 @@ def test_wire_format_mirror(E):
     assert tw.unboxed["w"] == sum(int(v) << (20 * (5 - j)) for j, v in enumerate(layer.flatten()))
     back = tw.decompress()
     assert back["w"].shape == (2, 3) and [int(v) for v in back["w"].flatten()] == [3, 1, 4, 1, 5, 9] and int(back["b"][0]) == 7
+    dev_layers = wz.TransferableWeights({"w": tw.unboxed["w"]}, bits=20, need_compress=False, shape={"w": (2, 3)}).decompress(as_device=True)
+    assert isinstance(dev_layers["w"], E.DeviceVector)
+    again = wz.TransferableWeights({"w": dev_layers["w"]}, bits=20)                     # a handle compresses to the same integer
+    assert again.unboxed["w"] == tw.unboxed["w"]
     # sparse location coding: _to_bytes(locations, total.bit_length())
     total = 25_557_032
     locs = np.sort(np.random.Generator(np.random.PCG64(1)).choice(total, size=5000, replace=False))
