@@ -1648,9 +1648,16 @@ struct flashe_span_bounds {
     uint64_t total = 0;
     std::vector<const uint32_t *> loc;
     std::vector<uint64_t> k;
-    uint32_t *start = nullptr;           // per group of kMaxScatter clients: (span_count(total) + 1) * group words
+    int span = kSpanReduce;              // positions per span the table was computed for (kSpanFused on a ctx whose sparse passes run the PRF inside the reduce)
+    uint32_t *start = nullptr;           // per group of kMaxScatter clients: (span_count(total, span) + 1) * group words
     size_t group_stride = 0;             // words between two groups' tables
 };
+
+// int_bits > 64 on the table PRF: the sparse single-mask passes run as launch_span_prf
+static bool span_prf_ok(const flashe_ctx *ctx)
+{
+    return ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE);
+}
 
 int flashe_span_bounds_create(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k, flashe_span_bounds **out)
 {
@@ -1665,14 +1672,15 @@ int flashe_span_bounds_create(flashe_ctx *ctx, uint64_t total, int C, const uint
     }
     auto *b = new flashe_span_bounds;
     b->device = ctx->device; b->C = C; b->total = total;
+    b->span = span_prf_ok(ctx) ? kSpanFused : kSpanReduce;
     b->loc.assign(loc_dev, loc_dev + C); b->k.assign(k, k + C);
     const int group = std::min(C, kMaxScatter), groups = (C + kMaxScatter - 1) / kMaxScatter;
-    b->group_stride = (span_count(total) + 1) * static_cast<size_t>(group);
+    b->group_stride = (span_count(total, b->span) + 1) * static_cast<size_t>(group);
     const hipError_t e = hipMalloc(&b->start, std::max<size_t>(b->group_stride * groups * sizeof(uint32_t), 16));
     if (e != hipSuccess) { delete b; return fail(ctx, e == hipErrorOutOfMemory ? FLASHE_ENOMEM : FLASHE_EIO, "hipMalloc: %s", hipGetErrorString(e)); }
     for (int g = 0; g < groups; g++) {
         const int c0 = g * kMaxScatter, nc = std::min(kMaxScatter, C - c0);
-        const hipError_t le = launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, b->start + g * b->group_stride);
+        const hipError_t le = launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, b->start + g * b->group_stride, b->span);
         if (le != hipSuccess) { (void)hipFree(b->start); delete b; HIP_TRY(ctx, le); }
     }
     *out = b;
@@ -1691,7 +1699,7 @@ int flashe_span_bounds_recompute(flashe_ctx *ctx, flashe_span_bounds *b, const u
     }
     b->loc.assign(loc_dev, loc_dev + b->C); b->k.assign(k, k + b->C);
     for (int c0 = 0, g = 0; c0 < b->C; c0 += kMaxScatter, g++)
-        HIP_TRY(ctx, launch_span_bounds(ctx->env, std::min(kMaxScatter, b->C - c0), loc_dev + c0, k + c0, b->total, b->start + g * b->group_stride));
+        HIP_TRY(ctx, launch_span_bounds(ctx->env, std::min(kMaxScatter, b->C - c0), loc_dev + c0, k + c0, b->total, b->start + g * b->group_stride, b->span));
     return FLASHE_OK;
 }
 
@@ -1750,14 +1758,14 @@ static int sparse_aggregate_impl(flashe_ctx *ctx, uint64_t total, int C, const u
     // after the other because their location sets overlap
     if (sorted && C > 0) {
         // strictly increasing location lists: LDS-staged span reduce, the dense output is written exactly once
-        int rc = bounds ? FLASHE_OK : ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(std::min(C, kMaxScatter)) * sizeof(uint32_t));
+        int rc = bounds ? FLASHE_OK : ensure(ctx, ctx->bounds, span_table_words(total, std::min(C, kMaxScatter)) * sizeof(uint32_t));
         if (rc) return rc;
         for (int c0 = 0; c0 < C; c0 += kMaxScatter) {
             const int nc = std::min(kMaxScatter, C - c0);
             uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
             HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, vals_dev + c0, k + c0, zeros + static_cast<size_t>(L) * c0,
                                             c0 ? 0 : static_cast<uint64_t>(zsum), c0 ? 0 : static_cast<uint64_t>(zsum >> 64), total,
-                                            start, c0 != 0 ? out_dev : nullptr, false, out_dev, bounds != nullptr));
+                                            start, c0 != 0 ? out_dev : nullptr, false, out_dev, bounds != nullptr, bounds ? bounds->span : kSpanReduce));
         }
         return FLASHE_OK;
     }
@@ -1765,6 +1773,53 @@ static int sparse_aggregate_impl(flashe_ctx *ctx, uint64_t total, int C, const u
     for (int c = 0; c < C; c++)
         HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c], loc_dev[c], vals_dev[c], out_dev, true, zeros[static_cast<size_t>(L) * c],
                                     L == 2 ? zeros[2 * c + 1] : 0));
+    return FLASHE_OK;
+}
+
+// The sparse twin of flashe_encrypt_batch_sum_dev: the C clients this device plays encrypt their compact uploads (single mask over the
+// compact positions, jzf_flashe.py:471-478 on the values Client.sparsify kept) and the sum of the C expanded uploads -- what
+// Arbiter.expand_to_dense + the reduce make of them (jzf_aggregator.py:150-165, :419-430) -- is written in the same pass.
+int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t n_jobs, uint64_t total, int C, const uint32_t *idx,
+                                        const uint32_t *const *loc_dev, const uint64_t *k, const uint64_t *const *pt_dev, int pt_limbs,
+                                        const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t *const *ct_dev, uint64_t *agg_out_dev)
+{
+    CHECK_CTX(ctx);
+    if (C < 1 || !idx || !loc_dev || !k || !pt_dev || !zeros || !ct_dev || (total && !agg_out_dev) || n_jobs == 0)
+        return fail(ctx, FLASHE_EINVAL, "flashe_sparse_encrypt_aggregate_dev: bad arguments");
+    { const int brc = check_bounds(ctx, bounds, total, C, loc_dev, k); if (brc) return brc; }
+    if (ctx->limbs == 2 && !aligned16(agg_out_dev)) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
+    const int L = ctx->limbs;
+    using u128 = unsigned __int128;
+    const u128 mask = ctx->int_bits == 128 ? ~static_cast<u128>(0) : ((static_cast<u128>(1) << ctx->int_bits) - 1);
+    u128 zsum = 0;
+    for (int c = 0; c < C; c++) {
+        if (k[c] > total || k[c] >= (1ull << 32)) return fail(ctx, FLASHE_EINVAL, "client %d: more locations than positions", c);
+        if (k[c] && (!loc_dev[c] || !pt_dev[c] || !ct_dev[c])) return fail(ctx, FLASHE_EINVAL, "client %d: null vector", c);
+        if (ct_dev[c] == agg_out_dev && k[c]) return fail(ctx, FLASHE_EINVAL, "the aggregate must not be one of the ciphertext vectors");
+        if (k[c]) { const int rc = check_prf_args(ctx, 1, FLASHE_SCHEME_SINGLE, n_jobs, ct_dev[c], pt_dev[c], pt_limbs); if (rc) return rc; }
+        const u128 z = (L == 2 ? static_cast<u128>(zeros[2 * c + 1]) << 64 : 0) | zeros[static_cast<size_t>(L) * c];
+        if (z & ~mask) return fail(ctx, FLASHE_EINVAL, "zero value of client %d exceeds int_bits", c);
+        zsum = (zsum + z) & mask;
+    }
+    if (!span_prf_ok(ctx) || (bounds && bounds->span != kSpanFused)) {
+        // int_bits <= 64 / another PRF backend: the encrypts, then the sparse reduce of what they wrote
+        for (int c = 0; c < C; c++) {
+            if (!k[c]) continue;
+            const int rc = flashe_encrypt_dev(ctx, iter, idx[c], FLASHE_SCHEME_SINGLE, k[c], n_jobs, pt_dev[c], pt_limbs, ct_dev[c]);
+            if (rc) return rc;
+        }
+        return sparse_aggregate_impl(ctx, total, C, loc_dev, k, ct_dev, zeros, 1, bounds, agg_out_dev);
+    }
+    int rc = bounds ? FLASHE_OK : ensure(ctx, ctx->bounds, span_table_words(total, std::min(C, kMaxScatter)) * sizeof(uint32_t));
+    if (rc) return rc;
+    for (int c0 = 0; c0 < C; c0 += kMaxScatter) {
+        const int nc = std::min(kMaxScatter, C - c0);
+        uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
+        if (!bounds) HIP_TRY(ctx, launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, start, kSpanFused));
+        HIP_TRY(ctx, launch_span_prf(ctx->env, iter, nc, idx + c0, loc_dev + c0, k + c0, pt_dev + c0, pt_limbs, ct_dev + c0, zeros + 2 * static_cast<size_t>(c0),
+                                     c0 ? 0 : static_cast<uint64_t>(zsum), c0 ? 0 : static_cast<uint64_t>(zsum >> 64), total, start,
+                                     c0 != 0 ? agg_out_dev : nullptr, false, agg_out_dev));
+    }
     return FLASHE_OK;
 }
 
@@ -1784,8 +1839,31 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
                                       static_cast<unsigned long long>(k[c]), static_cast<unsigned long long>(total));
         kmax = std::max(kmax, k[c]);
     }
-    const bool jobs_path = ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE);
+    const bool jobs_path = span_prf_ok(ctx);
     const bool fused = sorted && jobs_path && C > 0;      // the span reduce writes (or subtracts from agg) the whole vector itself
+#ifdef FLASHE_TUNING
+    const char *two_pass = getenv("FLASHE_SPAN_PRF");     // "0" = compact streams through HBM, then the plain span reduce (the round-2 .. 4 form; A/B runs)
+    const bool prf_inside = fused && !(two_pass && two_pass[0] == '0' && !bounds);
+#else
+    const bool prf_inside = fused;
+#endif
+    if (prf_inside) {
+        // strictly increasing lists: ONE persistent launch per group of clients generates the mask blocks inside the span reduce
+        // (launch_span_prf) -- no compact streams in HBM, the AES rounds run under the dense read / write
+        if (bounds && bounds->span != kSpanFused) return fail(ctx, FLASHE_EINVAL, "the span bounds were computed by a ctx of another int_bits / PRF backend");
+        int rc = bounds ? FLASHE_OK : ensure(ctx, ctx->bounds, span_table_words(total, std::min(C, kMaxScatter)) * sizeof(uint32_t));
+        if (rc) return rc;
+        for (int c0 = 0; c0 < C; c0 += kMaxScatter) {
+            const int nc = std::min(kMaxScatter, C - c0);
+            uint32_t idx[kMaxScatter];
+            for (int e = 0; e < nc; e++) idx[e] = static_cast<uint32_t>(c0 + e);
+            uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
+            if (!bounds) HIP_TRY(ctx, launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, start, kSpanFused));
+            HIP_TRY(ctx, launch_span_prf(ctx->env, iter, nc, idx, loc_dev + c0, k + c0, nullptr, 2, nullptr, nullptr, 0, 0, total, start,
+                                         c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev));
+        }
+        return FLASHE_OK;
+    }
     if (!fused && total) HIP_TRY(ctx, hipMemsetAsync(out_dev, 0, vec_bytes(ctx, total), ctx->env.stream));
     if (jobs_path) {
         // m = 1: the compact streams do not depend on their length, so every client's stream comes from one job-list
@@ -1794,7 +1872,7 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
         const int group = std::min(C, kMaxScatter);          // clients whose streams are held at once
         int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kpad) * static_cast<size_t>(std::max(group, 1)));
         if (rc) return rc;
-        if (sorted && C > 0 && !bounds && (rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(group) * sizeof(uint32_t)))) return rc;
+        if (fused && (rc = ensure(ctx, ctx->bounds, span_table_words(total, group) * sizeof(uint32_t)))) return rc;
         uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
         for (int c0 = 0; c0 < C; c0 += group) {
             const int nc = std::min(group, C - c0);
@@ -1805,14 +1883,13 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
                 jobs[e] = PrfJob{static_cast<uint32_t>(c0 + e), 0u, 0, k[c0 + e], nullptr, 0, tmp + 2 * kpad * static_cast<uint64_t>(e)};
             }
             HIP_TRY(ctx, launch_prf_jobs(ctx->env, iter, false, nc, jobs, kmax, n_jobs));
-            if (sorted) {
-                uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
-                HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, streams, k + c0, nullptr, 0, 0, total,
-                                                start, c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev, bounds != nullptr));
-            } else {
-                for (int e = 0; e < nc; e++)
-                    HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c0 + e], loc_dev[c0 + e], streams[e], out_dev, true));
+            if (fused) {
+                HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, streams, k + c0, nullptr, 0, 0, total, static_cast<uint32_t *>(ctx->bounds.p),
+                                                c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev));
+                continue;
             }
+            for (int e = 0; e < nc; e++)           // unsorted lists
+                HIP_TRY(ctx, launch_scatter(ctx->env, total, k[c0 + e], loc_dev[c0 + e], streams[e], out_dev, true));
         }
     } else {
         int rc = ensure(ctx, ctx->stream_tmp, vec_bytes(ctx, kmax));
@@ -1856,7 +1933,7 @@ int flashe_sparse_decrypt_bounds_dev(flashe_ctx *ctx, uint32_t iter, int C, cons
     CHECK_CTX(ctx);
     if (!bounds) return fail(ctx, FLASHE_EINVAL, "null bounds handle");
     if (total && (!agg_dev || agg_dev == out_dev)) return fail(ctx, FLASHE_EINVAL, "the aggregate must be given and must not be the output vector");
-    if (!(ctx->limbs == 2 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE)) || std::min(C, kMaxScatter) != std::min(bounds->C, kMaxScatter))
+    if (!span_prf_ok(ctx) || std::min(C, kMaxScatter) != std::min(bounds->C, kMaxScatter))
         return fail(ctx, FLASHE_EINVAL, "sparse_decrypt_bounds needs int_bits > 64 on the table PRF (the span reduce is what consumes the bounds)");
     return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, true, agg_dev, out_dev, bounds);
 }
@@ -1886,7 +1963,7 @@ int flashe_sparse_double_masks_dev(flashe_ctx *ctx, uint32_t iter, int C, const 
     const int group = std::min(C, kMaxScatter);
     int rc = ensure(ctx, ctx->stream_tmp, 2 * vec_bytes(ctx, kpad) * static_cast<size_t>(group));
     if (rc) return rc;
-    if ((rc = ensure(ctx, ctx->bounds, (span_count(total) + 1) * static_cast<size_t>(group) * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->bounds, span_table_words(total, group) * sizeof(uint32_t)))) return rc;
     uint64_t *tmp = static_cast<uint64_t *>(ctx->stream_tmp.p);
     const uint64_t stride = kpad * static_cast<uint64_t>(ctx->limbs);
     for (int c0 = 0; c0 < C; c0 += group) {
@@ -2547,6 +2624,14 @@ int flashe_sparsify_batch(flashe_ctx *ctx, int n_layers, const uint64_t *n, cons
 }
 
 #ifdef FLASHE_TUNING
+// tuning build only: phase cycle sums of span_prf_kernel's workgroup 0 (FLASHE_SPAN_PROBE=9), tests/perf/sparse_phases.py
+int flashe_tune_span_prf_cycles(flashe_ctx *ctx, unsigned long long *out8, int reset)
+{
+    CHECK_CTX(ctx);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream));
+    HIP_TRY(ctx, flashe::span_prf_cycles(out8, reset != 0));
+    return FLASHE_OK;
+}
 // tuning build only (not in include/flashe.h): the two-workgroups-per-CU experiment, tests/perf/ab_reduce_2wg.py
 int flashe_tune_reduce_decrypt_probe(flashe_ctx *ctx, int variant, uint32_t iter, uint32_t add_idx, uint32_t minus_idx, int C,
                                      const uint64_t *const *cts_dev, uint64_t n, uint64_t *out_dev)

@@ -208,6 +208,23 @@ __device__ __forceinline__ void aes256_rounds2_swp(const RoundKeys &rk, const La
     finish_final(rk, kb, s[1]);
 }
 
+// One block per lane where there is no second one to pipeline against: all sixteen lookups of a round are issued as their state
+// words become final, nothing of the next round moves up (left to itself the compiler interleaves the rounds with two or three
+// lookups in flight per wave, and the LDS pipe idles: the span reduce with the PRF inside ran at 46 % of the lookup rate that way).
+template <int FIRST>
+__device__ __forceinline__ void aes256_rounds1_deep(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[4])
+{
+    Lk16 k = issue_main(lr, s);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = FIRST; r < 14; r++) {
+        finish_main(rk, r, k, s);
+        k = r < 13 ? issue_main(lr, s) : issue_final(lr, s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    finish_final(rk, k, s);
+}
+
 // NB independent blocks; s holds the plaintext blocks.
 template <int NB>
 __device__ __forceinline__ void aes256_encrypt(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4])

@@ -176,15 +176,32 @@ hipError_t launch_scatter(const LaunchEnv &env, uint64_t total, uint64_t k, cons
 // out[p] = from[p] +/- sum_{c, q: loc[c][q] == p} (vals[c][q] - sub[c]) mod 2^b for every p < total, where from = src_dev when it
 // is given (it may be out_dev: accumulate in place) and the constant base otherwise; negate subtracts the sum (a decrypt:
 // aggregate - minus-mask in the pass that builds the mask).  At most kMaxScatter clients per call;
-// start_dev = (span_count(total) + 1) * C words of scratch.
+// start_dev = (span_count(total, span) + 1) * C words of scratch.
 constexpr int kMaxScatter = 64;
-uint64_t span_count(uint64_t total);
+// positions per span: the plain reduce keeps 64 KiB of accumulators per workgroup, the passes with the PRF inside (launch_span_prf)
+// what the AES tables leave of a CU's LDS.  A table of span bounds serves the kernels of ONE of the two sizes.
+constexpr int kSpanReduce = 4096, kSpanFused = 1760;
+uint64_t span_count(uint64_t total, int span);
+// words of a bounds table that is large enough for either span size
+inline size_t span_table_words(uint64_t total, int C) { return static_cast<size_t>(span_count(total, kSpanFused) + 1) * static_cast<size_t>(C); }
 // (bounds_ready: start_dev already holds the bounds of exactly these lists -- launch_span_bounds -- and the pass that computes them is skipped)
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
-                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready = false);
-// the first list entry of each of the C <= kMaxScatter clients in every span: (span_count(total) + 1) * C words
-hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev);
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready = false,
+                              int span = kSpanReduce);
+// the first list entry of each of the C <= kMaxScatter clients in every span: (span_count(total, span) + 1) * C words
+hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev,
+                              int span = kSpanReduce);
+// The span reduce with the PRF inside (int_bits > 64, table PRF; one persistent launch): entry q of client c contributes
+// term(iter, idx[c], q) -- pt_dev null: out[p] = from[p] +/- the sum of the masks at p (sparse minus-mask / decrypt); pt_dev given:
+// ct_dev[c][q] = (pt_dev[c][q] + mask) mod 2^b is stored (where ct_dev[c] is not null) and out[p] = from[p] + sum (ct - sub[c]);
+// pt_limbs = 1: the plaintexts are uint64 arrays.  start_dev: bounds of exactly these lists at kSpanFused.
+hipError_t launch_span_prf(const LaunchEnv &env, uint32_t iter, int C, const uint32_t *idx, const uint32_t *const *loc_dev, const uint64_t *k,
+                           const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi,
+                           uint64_t total, const uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev);
+#ifdef FLASHE_TUNING
+hipError_t span_prf_cycles(unsigned long long *out8, bool reset);      // phase cycle sums of span_prf_kernel's workgroup 0 (FLASHE_SPAN_PROBE=9)
+#endif
 // Sparse + double mask (jzf_flashe.py:388-426, :155-225): compact (add, minus) mask values of a group of nc <= kMaxScatter clients
 // c0 .. c0 + nc - 1 at their own sorted locations -- entry q of client c gets term(c + 1, p) unless client c + 1 holds p, and
 // term(c, p) unless client c - 1 holds p (dense-position counters, one chunk).  loc / k carry nc + 2 entries: the group's lists

@@ -613,10 +613,7 @@ __global__ __launch_bounds__(kStreamThreads) void scatter_kernel(uint64_t total,
 // two LDS atomics; the low one returns the old value, which tells the lane exactly whether ITS add wrapped -- integer
 // adds commute, so the sum does not depend on the order), then writes src + accumulator (or src - accumulator, base
 // instead of src when there is none) for the WHOLE span: the dense output is written exactly once, coalesced.
-#ifndef FLASHE_SPAN
-#define FLASHE_SPAN 4096
-#endif
-constexpr int kSpan = FLASHE_SPAN;  // positions per span: 64 KiB of 128-bit accumulators, two workgroups per CU (8,192 = 128 KiB, one workgroup per CU,
+constexpr int kSpan = kSpanReduce;  // positions per span: 64 KiB of 128-bit accumulators, two workgroups per CU (8,192 = 128 KiB, one workgroup per CU,
                                     // twice as long slices per client: aggregate 0.171 against 0.169 ms, fused decrypt 0.442 against 0.420 -- config 5)
 constexpr int kSpanThreads = 1024;
 constexpr int kSpanBatch = 2;       // entries whose loads a lane keeps in flight at once (config 5, aggregate / fused decrypt: 8: 0.256 / 0.484 ms,
@@ -628,6 +625,7 @@ struct ScatterTable {
 };
 
 constexpr int kBoundsPerThread = 8;
+template <int SPAN>
 __global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const ScatterTable tb, int C, uint64_t n_spans, uint64_t total, uint32_t *start,
                                                                      uint32_t *err_flag)
 {
@@ -642,8 +640,8 @@ __global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const Scatt
         const bool live = q <= k;
         const uint64_t prev = live && q ? loc[q - 1] : 0, cur = live && q < k ? loc[q] : 0;
         if (live && q < k && (cur >= total || (q && cur <= prev))) *err_flag = 1;
-        const uint64_t s_last = q < k ? std::min<uint64_t>(cur / kSpan, n_spans) : n_spans;
-        const uint64_t s_first = !live ? s_last + 1 : q ? std::min<uint64_t>(prev / kSpan, n_spans) + 1 : 0;
+        const uint64_t s_last = q < k ? std::min<uint64_t>(static_cast<uint32_t>(cur) / static_cast<uint32_t>(SPAN), n_spans) : n_spans;
+        const uint64_t s_first = !live ? s_last + 1 : q ? std::min<uint64_t>(static_cast<uint32_t>(prev) / static_cast<uint32_t>(SPAN), n_spans) + 1 : 0;
         const bool is_long = s_first + 16 <= s_last;
         if (!is_long)
             for (uint64_t sp = s_first; sp <= s_last; sp++) start[sp * C + c] = static_cast<uint32_t>(q);
@@ -760,14 +758,14 @@ __global__ __launch_bounds__(THREADS) void span_reduce_kernel(const ScatterTable
     }
 }
 
-uint64_t span_count(uint64_t total) { return (total + kSpan - 1) / kSpan; }
+uint64_t span_count(uint64_t total, int span) { return (total + static_cast<uint64_t>(span) - 1) / static_cast<uint64_t>(span); }
 
 // out[p] = from[p] +/- sum over clients c and entries q with loc[c][q] == p of (vals[c][q] - sub[c])   (mod 2^b), every p < total,
 // from = src_dev when given (may be out_dev), the constant base otherwise; loc[c] strictly increasing.
-// start_dev: (span_count(total) + 1) * C words of scratch.
-hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev)
+// start_dev: (span_count(total, span) + 1) * C words of scratch.
+hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev, int span)
 {
-    if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
+    if (C > kMaxScatter || C < 1 || (span != kSpanReduce && span != kSpanFused)) return hipErrorInvalidValue;
     if (total == 0) return hipSuccess;
     ScatterTable tb{};
     uint64_t kmax = 0;
@@ -776,35 +774,259 @@ hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const
         tb.loc[c] = loc_dev[c]; tb.k[c] = k[c];
         kmax = std::max(kmax, k[c]);
     }
-    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0,
-                       env.stream, tb, C, span_count(total), total, start_dev, env.err_flag);
+    const dim3 grid(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C);
+    if (span == kSpanFused)
+        hipLaunchKernelGGL(span_bounds_kernel<kSpanFused>, grid, dim3(kStreamThreads), 0, env.stream, tb, C, span_count(total, span), total, start_dev, env.err_flag);
+    else
+        hipLaunchKernelGGL(span_bounds_kernel<kSpanReduce>, grid, dim3(kStreamThreads), 0, env.stream, tb, C, span_count(total, span), total, start_dev, env.err_flag);
     return hipGetLastError();
 }
 
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
-                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready)
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready, int span)
 {
-    if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
+    if (C > kMaxScatter || C < 1 || (span != kSpanReduce && span != kSpanFused)) return hipErrorInvalidValue;
     if (total == 0) return hipSuccess;
     const int L = env.b > 64 ? 2 : 1;
     ScatterTable tb{};
-    uint64_t kmax = 0;
     for (int c = 0; c < C; c++) {
         if (k[c] >= (1ull << 32)) return hipErrorInvalidValue;
         tb.loc[c] = loc_dev[c]; tb.vals[c] = vals_dev[c]; tb.k[c] = k[c];
         tb.sub_lo[c] = sub ? sub[static_cast<size_t>(L) * c] : 0;
         tb.sub_hi[c] = sub && L == 2 ? sub[2 * c + 1] : 0;
-        kmax = std::max(kmax, k[c]);
     }
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
-    const uint64_t n_spans = span_count(total);
-    if (!bounds_ready)
-        hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0,
-                           env.stream, tb, C, n_spans, total, start_dev, env.err_flag);
-    hipLaunchKernelGGL((span_reduce_kernel<kSpan, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
-                       start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
+    const uint64_t n_spans = span_count(total, span);
+    if (!bounds_ready) {
+        const hipError_t e = launch_span_bounds(env, C, loc_dev, k, total, start_dev, span);
+        if (e != hipSuccess) return e;
+    }
+    if (span == kSpanFused)       // a bounds handle laid out for the fused PRF passes (their accumulators share the LDS with the AES tables)
+        hipLaunchKernelGGL((span_reduce_kernel<kSpanFused, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
+                           start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
+    else
+        hipLaunchKernelGGL((span_reduce_kernel<kSpan, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
+                           start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
+    return hipGetLastError();
+}
+
+// ---- the span reduce with the PRF inside (int_bits > 64, table PRF) ---------------------------------------------------------------
+// The sparse single-mask passes spend more time generating their compact mask streams (one AES block per list entry, LDS-lookup bound)
+// than reducing them (HBM bound), and the streams make a round trip through HBM in between.  Here the two run in ONE persistent kernel,
+// one workgroup per CU: the AES tables (128 KiB) and the accumulators of a span (kSpanFused positions, 27.5 KiB) share the CU's 160 KiB,
+// entry q of client c gets its block term(iter, idx[c], q) computed where the span reduce would have gathered a stored value -- the
+// block needs (c, q) only, so the load of the entry's POSITION (and, ENC, of its plaintext) is in flight under the 14 rounds -- and the
+// dense read / write of the span (prefetched before the entries, written after them) overlaps with the next span's rounds.
+//   ENC = false: out[p] = from[p] +/- sum of the masks of the entries at p   (sparse minus-mask / sparse decrypt, a-13)
+//   ENC = true : ct[c][q] = (pt[c][q] + mask) mod 2^b is stored AND out[p] = base + sum (ct[c][q] - sub[c]): the clients a GPU plays
+//                encrypt and their uploads are summed in the same pass (the sparse twin of the chained encrypt's partial aggregate)
+struct SpanPrfTable {
+    const uint32_t *loc[kMaxScatter];
+    const uint64_t *pt[kMaxScatter];
+    uint64_t *ct[kMaxScatter];
+    uint32_t k[kMaxScatter], idx[kMaxScatter];
+    uint64_t sub_lo[kMaxScatter], sub_hi[kMaxScatter];
+};
+
+#ifdef FLASHE_TUNING
+__device__ unsigned long long g_span_prf_cycles[8];      // phase cycle sums of workgroup 0, wave 0 (FLASHE_SPAN_PROBE=9)
+#define SPAN_PRF_TICK(i) do { if (probe == 9 && blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                                                                                g_span_prf_cycles[i] += t_ - tick_; tick_ = t_; } } while (0)
+#else
+#define SPAN_PRF_TICK(i) do { } while (0)
+#endif
+template <bool ENC>
+__global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys rk, const SpanPrfTable tb, int C, uint32_t iter0, uint64_t total, uint32_t n_spans,
+                                                               const uint32_t *__restrict__ start, uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo,
+                                                               uint64_t mask_hi, const uint64_t *src, bool negate, uint64_t *out,
+                                                               const uint32_t *__restrict__ te0, uint32_t *err_flag, int pt_limbs, int probe)
+{
+    constexpr int SPAN = kSpanFused, THREADS = kPrfThreads, PER = (SPAN + THREADS - 1) / THREADS;
+    const uint32_t iter = iter0 + te0[kIterShiftWord];
+    __shared__ uint32_t tab[kTabWords];
+    __shared__ unsigned long long acc[2 * SPAN];
+    __shared__ uint32_t s_begin[kMaxScatter], s_prefix[2 * kMaxScatter + 2];
+    __shared__ uint4 s_pref[kMaxScatter];                     // CtrPrefix of (iter, idx[c], counter high word 0): round 1 costs 4 lookups
+    __shared__ const uint32_t *s_loc[kMaxScatter];
+    __shared__ const uint64_t *s_pt[ENC ? kMaxScatter : 1];
+    __shared__ uint64_t *s_ct[ENC ? kMaxScatter : 1];
+    __shared__ uint64_t s_sub[ENC ? 2 * kMaxScatter : 2];
+    fill_tables(tab, te0);
+    const LaneRegs lr = lane_regs(tab);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * SPAN; i += THREADS) acc[i] = 0;
+    uint32_t kc = 0;
+    if (tid < C) {
+        const CtrPrefix p = ctr_prefix(rk, lr, iter, tb.idx[tid], 0u);
+        s_pref[tid] = make_uint4(p.u[0], p.u[1], p.u[2], p.u[3]);
+        s_loc[tid] = tb.loc[tid];
+        kc = tb.k[tid];
+        if (ENC) { s_pt[tid] = tb.pt[tid]; s_ct[tid] = tb.ct[tid]; s_sub[2 * tid] = tb.sub_lo[tid]; s_sub[2 * tid + 1] = tb.sub_hi[tid]; }
+    }
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    const u128 base = (static_cast<u128>(base_hi) << 64) | base_lo;
+    // first wave: this span's slice [b0, b1) of client `tid`'s list (clamped like span_reduce_kernel's), loaded one span AHEAD of its
+    // use; SPAN_PRF_PUBLISH turns the 64 counts into the flat entry index space of the span
+    // (the loads are unconditional -- clamped indices -- and their values are not touched before SPAN_PRF_PUBLISH, so that nothing
+    // waits for them under the rounds; PUBLISH comes BEFORE the wave's stores of the finished span: the memory counter is in order, a
+    // wait for these loads behind the stores would wait for the stores)
+    uint32_t f0 = 0, f1 = 0;
+    bool f_live = false;
+    const uint32_t tid_c = static_cast<uint32_t>(min(tid, C - 1));
+#define SPAN_PRF_FETCH(spx)                                                                                              \
+    do {                                                                                                                 \
+        const uint64_t sp_ = (spx), sc_ = sp_ < n_spans ? sp_ : n_spans - 1;                                             \
+        f_live = tid < C && sp_ < n_spans;                                                                               \
+        f0 = start[sc_ * C + tid_c]; f1 = start[(sc_ + 1) * C + tid_c];                                                  \
+    } while (0)
+#define SPAN_PRF_PUBLISH()                                                                                               \
+    do {                                                                                                                 \
+        const uint32_t b0_ = min(f0, kc), b1_ = min(f1, kc);                                                             \
+        uint32_t run_ = f_live && b1_ > b0_ ? b1_ - b0_ : 0;                                                             \
+        _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {                                                             \
+            const uint32_t up_ = __shfl_up(run_, d, 64);                                                                 \
+            if (tid >= d) run_ += up_;                                                                                   \
+        }                                                                                                                \
+        if (tid < C) s_begin[tid] = b0_;                                                                                 \
+        if (tid == 0) s_prefix[0] = 0;                                                                                   \
+        s_prefix[tid + 1] = tid < C ? run_ : 0xffffffffu;                                                                \
+        s_prefix[tid + 65] = 0xffffffffu;                                                                                \
+    } while (0)
+    uint64_t sp = blockIdx.x;
+    if (tid < 64) { SPAN_PRF_FETCH(sp); SPAN_PRF_PUBLISH(); }
+    __syncthreads();
+#ifdef FLASHE_TUNING
+    unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
+    for (; sp < n_spans; sp += gridDim.x) {
+        const uint64_t p0 = sp * SPAN;
+        const uint32_t span_len = static_cast<uint32_t>(total - p0 < SPAN ? total - p0 : SPAN);
+        SPAN_PRF_TICK(7);
+        if (tid < 64) SPAN_PRF_FETCH(sp + gridDim.x);
+        u128 from[PER];
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const uint32_t r = tid + e * THREADS;
+#ifdef FLASHE_TUNING
+            from[e] = src && r < span_len && probe != 4 ? ld128_nt(src + 2 * (p0 + r)) : base;      // 4 = no dense read / write
+#else
+            from[e] = src && r < span_len ? ld128_nt(src + 2 * (p0 + r)) : base;
+#endif
+        }
+#ifdef FLASHE_TUNING
+        const uint32_t n_entries = probe == 2 ? 0u : s_prefix[C];     // timing probes (wrong results): 1 = no rounds, 2 = no entries, 3 = no position load / atomics
+#else
+        const uint32_t n_entries = s_prefix[C];
+#endif
+        for (uint32_t f = tid; f < n_entries; f += THREADS) {
+            int c = 0;
+#pragma unroll
+            for (int step = 32; step; step >>= 1)
+                if (s_prefix[c + step] <= f) c += step;
+            const uint32_t q = s_begin[c] + (f - s_prefix[c]);
+#ifdef FLASHE_TUNING
+            const uint32_t pos = probe == 3 ? static_cast<uint32_t>(p0) + (f % span_len) : s_loc[c][q];
+#else
+            const uint32_t pos = s_loc[c][q];                                  // needed after the rounds only
+#endif
+            u128 pt = 0;
+            if (ENC) pt = pt_limbs == 2 ? ld128_nt(s_pt[c] + 2 * static_cast<uint64_t>(q)) : static_cast<u128>(__builtin_nontemporal_load(s_pt[c] + q));
+            const uint4 pw = s_pref[c];
+            const CtrPrefix pre{{pw.x, pw.y, pw.z, pw.w}};
+            uint32_t s[4];
+            ctr_round1(pre, ctr_var(rk, lr, q), s);
+            __builtin_amdgcn_sched_barrier(0);
+            SPAN_PRF_TICK(0);                                                  // owner search, table reads, round 1
+#ifdef FLASHE_TUNING
+            if (probe != 1)
+#endif
+            aes256_rounds1_deep<2>(rk, lr, s);
+            __builtin_amdgcn_sched_barrier(0);
+            SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14                                 // the position (and plaintext) loads are waited for HERE, not under round 1
+            const uint32_t r = pos - static_cast<uint32_t>(p0);
+            u128 w = words_to_u128(s) & mask;
+            if (ENC) {
+                w = (pt + w) & mask;
+                if (s_ct[c]) st128_nt(s_ct[c] + 2 * static_cast<uint64_t>(q), w);
+                w -= (static_cast<u128>(s_sub[2 * c + 1]) << 64) | s_sub[2 * c];
+            }
+            if (r >= span_len) { *err_flag = 1; continue; }      // a list that is not strictly increasing or reaches beyond the vector
+            const unsigned long long wlo = static_cast<unsigned long long>(w), whi = static_cast<unsigned long long>(w >> 64);
+#ifdef FLASHE_TUNING
+            if (probe == 3) { if (wlo == 0x1234567ull) acc[2 * r] = whi; continue; }
+#endif
+            const unsigned long long old = atomicAdd(&acc[2 * r], wlo);
+            atomicAdd(&acc[2 * r + 1], whi + (old + wlo < old ? 1ull : 0ull));
+            SPAN_PRF_TICK(2);                                                  // wait for the position, accumulate
+        }
+        SPAN_PRF_TICK(3);
+        __syncthreads();
+        SPAN_PRF_TICK(4);                                                      // barrier: the slowest wave's entries
+        // every load of this span has long returned (the entries waited for theirs): saying so HERE, on every wave's path, keeps the
+        // compiler from guarding the reuse of the prefetch registers with waits that would also cover the stores below
+        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+        if (tid < 64) SPAN_PRF_PUBLISH();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const uint32_t r = tid + e * THREADS;
+            if (r < span_len) {
+                const u128 a = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
+                acc[2 * r] = 0; acc[2 * r + 1] = 0;
+#ifdef FLASHE_TUNING
+                if (probe == 4 && static_cast<uint64_t>(a) != 0x1234567ull) continue;
+#endif
+                st128_nt(out + 2 * (p0 + r), (negate ? from[e] - a : from[e] + a) & mask);
+            }
+        }
+        SPAN_PRF_TICK(5);                                                      // publish + write-out
+        __syncthreads();
+        SPAN_PRF_TICK(6);
+    }
+#undef SPAN_PRF_FETCH
+#undef SPAN_PRF_PUBLISH
+}
+
+#ifdef FLASHE_TUNING
+hipError_t span_prf_cycles(unsigned long long *out8, bool reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_span_prf_cycles), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { const unsigned long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_span_prf_cycles), z, sizeof z); }
+    return e;
+}
+#endif
+
+// start_dev: the bounds of exactly these lists at kSpanFused positions per span (launch_span_bounds(..., kSpanFused)).
+hipError_t launch_span_prf(const LaunchEnv &env, uint32_t iter, int C, const uint32_t *idx, const uint32_t *const *loc_dev, const uint64_t *k,
+                           const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi,
+                           uint64_t total, const uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev)
+{
+    if (C > kMaxScatter || C < 1 || env.b <= 64 || (pt_dev && pt_limbs != 1 && pt_limbs != 2)) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    SpanPrfTable tb{};
+    for (int c = 0; c < C; c++) {
+        if (k[c] >= (1ull << 32)) return hipErrorInvalidValue;
+        tb.loc[c] = loc_dev[c]; tb.k[c] = static_cast<uint32_t>(k[c]); tb.idx[c] = idx[c];
+        if (pt_dev) {
+            tb.pt[c] = pt_dev[c]; tb.ct[c] = ct_dev ? ct_dev[c] : nullptr;
+            tb.sub_lo[c] = sub ? sub[2 * c] : 0; tb.sub_hi[c] = sub ? sub[2 * c + 1] : 0;
+        }
+    }
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    const uint64_t n_spans = span_count(total, kSpanFused);
+    if (n_spans >= (1ull << 32)) return hipErrorInvalidValue;
+    const dim3 grid(static_cast<unsigned>(std::min<uint64_t>(n_spans, static_cast<uint64_t>(std::max(env.num_cus, 1)))));
+    const char *pe = FLASHE_TUNE_ENV("FLASHE_SPAN_PROBE");
+    const int probe = pe ? atoi(pe) : 0;
+    if (pt_dev)
+        hipLaunchKernelGGL(span_prf_kernel<true>, grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), start_dev,
+                           base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.te0_dev, env.err_flag, pt_limbs, probe);
+    else
+        hipLaunchKernelGGL(span_prf_kernel<false>, grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), start_dev,
+                           base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.te0_dev, env.err_flag, 2, probe);
     return hipGetLastError();
 }
 

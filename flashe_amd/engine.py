@@ -725,6 +725,25 @@ class Engine:
         self._check(self._lib.flashe_sparse_aggregate_dev(self._h, total, len(locs), pl, ctypes.cast(k, c_u64p), pv,
                                                           ctypes.cast(zz, c_u64p), 1 if sorted_lists else 0, self._ptr(out)))
 
+    def sparse_encrypt_aggregate_dev(self, it, idx, locs, ks, pts, pt_limbs, zeros, total, n_jobs, cts, agg, bounds=None):
+        """The clients this device plays encrypt their compact uploads (single mask) and the sum of the expanded uploads is written in
+        the same pass: cts[c] = encrypt(it, idx[c], SINGLE) of pts[c], agg = sparse_aggregate_dev(locs, cts, zeros).  Strictly increasing
+        location lists.  int_bits > 64: one persistent launch per 64 clients with the PRF inside the span reduce."""
+        pl, _kl = self._ptr_array(locs)
+        pp, _kp = self._ptr_array(pts)
+        pc, _kc = self._ptr_array(cts)
+        C = len(locs)
+        k = (c_u64 * max(C, 1))(*[int(v) for v in ks])
+        ii = (ctypes.c_uint32 * max(C, 1))(*[int(v) for v in idx])
+        flat = []
+        for z in zeros:
+            z = [int(z) & (2 ** 64 - 1), int(z) >> 64] if isinstance(z, int) else [int(v) for v in z] + [0]
+            flat += z[:self.limbs]
+        zz = (c_u64 * max(len(flat), 1))(*flat)
+        self._check(self._lib.flashe_sparse_encrypt_aggregate_dev(self._h, it, n_jobs, total, C, ii, pl, ctypes.cast(k, c_u64p), pp, pt_limbs,
+                                                                  ctypes.cast(zz, c_u64p), bounds._h if bounds is not None else None, pc,
+                                                                  self._ptr(agg)))
+
     def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out, sorted_lists=False):
         p, _keep = self._ptr_array(locs)
         k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])

@@ -424,6 +424,16 @@ int flashe_sparse_aggregate_bounds_dev(flashe_ctx *ctx, uint64_t total, int C, c
 int flashe_sparse_decrypt_bounds_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                                      uint64_t total, uint32_t n_jobs, const flashe_span_bounds *bounds, const uint64_t *agg_dev,
                                      uint64_t *out_dev);
+/* The sparse twin of flashe_encrypt_batch_sum_dev (new): the C clients this device plays encrypt their compact uploads with the single
+ * mask -- ct_dev[c] = flashe_encrypt_dev(iter, idx[c], SINGLE, k[c], n_jobs) of pt_dev[c] (jzf_flashe.py:471-478) -- AND the sum of
+ * their expanded uploads, flashe_sparse_aggregate_dev(loc_dev, ct_dev, zeros) (jzf_aggregator.py:150-165, :419-430), is written to
+ * agg_out_dev in the same pass.  int_bits > 64 on the table PRF: ONE persistent launch per 64 clients computes every entry's mask block
+ * inside the LDS-staged span reduce (the ciphertexts are stored on the way, the compact values never travel twice); otherwise the two
+ * calls it stands for.  loc_dev[c] strictly increasing; bounds: NULL or the handle of exactly these lists. */
+int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t n_jobs, uint64_t total, int C, const uint32_t *idx,
+                                        const uint32_t *const *loc_dev, const uint64_t *k, const uint64_t *const *pt_dev, int pt_limbs,
+                                        const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t *const *ct_dev,
+                                        uint64_t *agg_out_dev);
 int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc,
                              const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out);
 /* Dense-position selected masks -- _static_prepare_decrypt_spar as ONE chunk

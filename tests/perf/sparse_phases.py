@@ -27,7 +27,7 @@ else:
     d_ct = [eng.alloc_vec(k) for _ in range(C)]
 d_agg, d_dec = eng.alloc_vec(total), eng.alloc_vec(total)
 evs = [eng.event() for _ in range(3)]
-for fused in (0, 1):
+for fused in ((1,) if os.environ.get("DECRYPT_ONLY") else (0, 1)):
     for rep in range(3):
         eng.record(evs[0])
         for _ in range(10):
@@ -41,3 +41,14 @@ for fused in (0, 1):
         except Exception as e:
             print("flag", e)
     print("fused decrypt" if fused else "aggregate", "probe", os.environ.get("FLASHE_SPAN_PROBE", "0"), "us per call", eng.elapsed_ms(evs[0], evs[1]) * 100)
+
+if os.environ.get("FLASHE_SPAN_PROBE") == "9":              # tuning build: where workgroup 0 / wave 0 of span_prf_kernel spends its cycles
+    import ctypes
+    out = (ctypes.c_ulonglong * 8)()
+    fn = eng._lib.flashe_tune_span_prf_cycles
+    fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int], ctypes.c_int
+    fn(eng._h, out, 1)
+    names = ["search + round 1", "rounds 2..14", "position wait + atomics", "loop exit", "barrier 1", "publish + write-out", "barrier 2", "loop head"]
+    tot = sum(out)
+    for n, v in zip(names, out):
+        print(f"  {n:28s} {v:14d} ticks  {100.0 * v / max(tot, 1):5.1f} %")

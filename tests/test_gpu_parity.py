@@ -1646,3 +1646,48 @@ def test_span_bounds_handle_shared_by_aggregate_and_decrypt(E, oracle):
         eng.sparse_aggregate_dev(total, dl2, [k] * C, dv, zeros, a1, bounds=bnd)
         eng.sparse_aggregate_dev(total, dl2, [k] * C, dv, zeros, a0, sorted_lists=True)
         assert np.array_equal(a0.download(np.uint64, 2 * total), a1.download(np.uint64, 2 * total)), (C, "recomputed")
+
+
+@pytest.mark.parametrize("b,C,total,k,pt_limbs", [(128, 5, 100_003, 2_000, 1), (128, 70, 50_000, 300, 2), (100, 9, 30_011, 1_234, 1), (128, 1, 9_000, 9_000, 2),
+                                                  (128, 3, 1_759, 40, 1), (128, 3, 1_761, 1_761, 2), (64, 4, 20_000, 700, 1), (20, 3, 20_000, 700, 1)])
+def test_sparse_encrypt_aggregate_in_one_pass(E, oracle, b, C, total, k, pt_limbs):
+    """flashe_sparse_encrypt_aggregate_dev (the span reduce with the PRF inside): every client's compact ciphertext against the oracle's
+    single-mask encrypt, the aggregate against the sum of the oracle's expand_to_dense of those ciphertexts; client indices that are not
+    0 .. C-1, clients with ragged list lengths and an empty one, more clients than one group holds, a vector a few positions around one
+    span, with and without the bounds handle; int_bits <= 64 takes the two calls it stands for."""
+    eng = make(E, b)
+    L = 2 if b > 64 else 1
+    if L == 1 and pt_limbs == 2:
+        pytest.skip("one-limb ctx")
+    rng = np.random.Generator(np.random.PCG64(b * 1000 + C))
+    ks = [k] * C
+    if C >= 3:
+        ks[1] = max(k // 3, 1)
+        ks[2] = 0
+    idx = [(3 * c + 1) % 97 for c in range(C)]
+    locs = [np.sort(rng.choice(total, kc, replace=False)).astype(np.uint32) for kc in ks]
+    top = 2 ** 63 if b >= 64 else 2 ** (b - 2)
+    pts = [rng.integers(0, top, (kc, pt_limbs), dtype=np.uint64) for kc in ks]
+    if b < 128 and pt_limbs == 2:
+        for p in pts:
+            p[:, 1] &= np.uint64((1 << (b - 64)) - 1)
+    zeros = [(1 << min(b - 4, 20)) + c for c in range(C)]
+    dl = [eng.upload(l) if l.size else eng.alloc(16) for l in locs]
+    dp = [eng.upload(p) if p.size else eng.alloc(16) for p in pts]
+    want_ct = []
+    for c in range(C):
+        p = pts[c] if pt_limbs == L else np.concatenate([pts[c], np.zeros((ks[c], 1), dtype=np.uint64)], axis=1)
+        want_ct.append(oracle.encrypt(KEY, 5, idx[c], "single", 16, b, p) if ks[c] else np.zeros((0, L), dtype=np.uint64))
+    want = np.zeros((total, L), dtype=np.uint64)
+    for c in range(C):
+        z = np.array([[zeros[c]] + [0] * (L - 1)], dtype=np.uint64)
+        want = oracle.aggregate_elem([want, oracle.expand_to_dense(total, locs[c], want_ct[c], z, b)], b)
+    for with_bounds in (False, True):
+        bnd = eng.span_bounds(total, dl, ks) if with_bounds else None
+        cts = [eng.alloc_vec(max(kc, 1)) for kc in ks]
+        agg = eng.alloc_vec(total)
+        eng.sparse_encrypt_aggregate_dev(5, idx, dl, ks, dp, pt_limbs, zeros, total, 16, cts, agg, bounds=bnd)
+        for c in range(C):
+            if ks[c]:
+                assert np.array_equal(cts[c].download(np.uint64, ks[c] * L).reshape(ks[c], L), want_ct[c]), (b, C, c, with_bounds, "ciphertext")
+        assert np.array_equal(agg.download(np.uint64, total * L).reshape(total, L), want), (b, C, with_bounds, "aggregate")
