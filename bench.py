@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--calibration-deadline", type=float, default=float(os.environ.get("FLASHE_BENCH_CALIBRATION_DEADLINE_S", "150")),
                     help="N > 1: seconds the optional overlapped schedules (calibration + their timed region) may take; when it passes, or "
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
+    ap.add_argument("--sparse-separate", action="store_true", help="config 5: the encrypts and the sparse aggregate as separate launches (the round-2 .. 4 form) as `value`")
     ap.add_argument("--no-span-bounds", action="store_true",
                     help="config 5: let the sparse aggregate and the sparse decrypt each compute the span bounds of the location lists "
                          "(the round-3 form) instead of computing them once per round")
@@ -1167,47 +1168,109 @@ def bench_sparse(args, total, ops, rank, world, out):
     # the span bounds of the round's location lists (where every list enters every span of the dense vector): computed ONCE per round
     # and shared by the sparse aggregate and the sparse decrypt (round 4; both used to run that pass on the same lists)
     use_bounds = L == 2 and not args.no_span_bounds
-    bounds = eng.span_bounds(total, d_loc, [k] * C) if use_bounds else None
+    bounds = None
 
-    def step(it, kk=None):
+    fused_ok = L == 2 and not args.sparse_separate
+    # the per-round argument tables, built once: the same 50 clients' buffers go into every round's calls, and building the ctypes arrays
+    # costs about as much host time as the launches they describe take on the device
+    t_loc, t_val, t_ct, t_k = eng.ptr_table(d_loc), eng.ptr_table(d_val), eng.ptr_table(d_ct), eng.u64_table([k] * C)
+    t_zero, idx_all = eng.zeros_table([zero] * C), list(range(C))
+
+    def step_separate(it, kk=None):
+        """Round-2 .. 4 form: the encrypts (one chained launch), the arbiter's sparse aggregate, the sparse decrypt."""
         if kk is not None:
             eng.record(ev[kk][0])
-        eng.encrypt_batch_dev(it, list(range(C)), SCHEME_SINGLE, k, J, d_val, 1, d_ct)
+        eng.encrypt_batch_dev(it, idx_all, SCHEME_SINGLE, k, J, t_val, 1, t_ct)
         if kk is not None:
             eng.record(ev[kk][1])
         if bounds is not None:
-            bounds.recompute(d_loc, [k] * C)             # a real job has new lists every round: the pass is part of the step
-        eng.sparse_aggregate_dev(total, d_loc, [k] * C, d_ct, [zero] * C, d_agg, sorted_lists=True, bounds=bounds)
+            bounds.recompute(t_loc, t_k)             # a real job has new lists every round: the pass is part of the step
+        eng.sparse_aggregate_dev(total, t_loc, t_k, t_ct, t_zero, d_agg, sorted_lists=True, bounds=bounds)
         if kk is not None:
             eng.record(ev[kk][2])
-        eng.sparse_decrypt_dev(it, d_loc, [k] * C, total, J, d_agg, d_dec, sorted_lists=True, bounds=bounds)    # dense minus-mask built and subtracted in one pass
+        eng.sparse_decrypt_dev(it, t_loc, t_k, total, J, d_agg, d_dec, sorted_lists=True, bounds=bounds)    # dense minus-mask built and subtracted in one pass
         if kk is not None:
             eng.record(ev[kk][3])
 
-    step(0)
-    # parity: the decrypted dense vector == sum over clients of (value at its locations, zero elsewhere)
-    got = d_dec.download(np.uint64, total * L).reshape(total, L)
+    def step_fused(it, kk=None):
+        """The clients this GPU plays encrypt AND their uploads are summed in one persistent launch (flashe_sparse_encrypt_aggregate_dev,
+        the sparse twin of the dense round's partial aggregate); the ciphertexts are still written, the decrypt is the other party's pass."""
+        if kk is not None:
+            eng.record(ev[kk][0])
+        if bounds is not None:
+            bounds.recompute(t_loc, t_k)
+        if kk is not None:
+            eng.record(ev[kk][1])
+        eng.sparse_encrypt_aggregate_dev(it, idx_all, t_loc, t_k, t_val, 1, t_zero, total, J, t_ct, d_agg, bounds=bounds)
+        if kk is not None:
+            eng.record(ev[kk][2])
+        eng.sparse_decrypt_dev(it, t_loc, t_k, total, J, d_agg, d_dec, sorted_lists=True, bounds=bounds)
+        if kk is not None:
+            eng.record(ev[kk][3])
+
+    bounds = eng.span_bounds(total, t_loc, t_k) if use_bounds else None
+    step = step_fused if fused_ok else step_separate
+    orc.build()
     want = np.full(total, np.uint64((C * zero) & (2 ** 64 - 1)), dtype=np.uint64)
     for c in range(C):
         want[locs[c]] += vals[c] - np.uint64(zero)
-    assert np.array_equal(got[:, 0], want if b >= 64 else want & np.uint64((1 << b) - 1)), "PARITY FAILURE (sparse round trip)"
-    orc.build()
-    assert np.array_equal(d_ct[3].download(np.uint64, k * L).reshape(k, L), orc.encrypt(KEY, 0, 3, "single", J, b, vals[3])), "PARITY FAILURE client 3"
+    for st in ([step_fused, step_separate] if fused_ok else [step_separate]):
+        d_dec.upload(np.zeros(16, dtype=np.uint64))
+        st(0)
+        # parity: the decrypted dense vector == sum over clients of (value at its locations, zero elsewhere)
+        got = d_dec.download(np.uint64, total * L).reshape(total, L)
+        assert np.array_equal(got[:, 0], want if b >= 64 else want & np.uint64((1 << b) - 1)), "PARITY FAILURE (sparse round trip)"
+        for c in (3, C - 1):
+            assert np.array_equal(d_ct[c].download(np.uint64, k * L).reshape(k, L), orc.encrypt(KEY, 0, c, "single", J, b, vals[c])), f"PARITY FAILURE client {c}"
+    sep_ms = None
+    if fused_ok:                                         # the other schedule beside it, same buffers
+        for it in range(max(W, 2)):
+            step_separate(it)
+        sep_ms = timed_region(ops, K, lambda kk: step_separate(kk)) * 1e3 / K
     for it in range(max(W, 2)):
         step(it)
     elapsed = timed_region(ops, K, lambda kk: step(kk, kk))
     if rank != 0:
         return None
     ph = np.array([[eng.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in ev])
+    m = 1 if L == 2 else 128 // b
+    prf_blocks = C * ((k + m - 1) // m)
+    if fused_ok:
+        enc_ms, dec_ms = float(ph[:, 1].mean()), float(ph[:, 2].mean())
+        enc_bytes = C * k * (4 + 8 + 8 * L) + total * 8 * L          # locations + plaintexts + ciphertexts, the dense aggregate written once
+        dec_bytes = C * k * 4 + 2 * total * 8 * L                     # locations, the dense aggregate read and the result written
+        achieved = enc_bytes / (enc_ms * 1e-3) / 1e9
+        out.update({
+            "value": world * C * k / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
+            "value_separate_launches": world * C * k / (sep_ms * 1e-3), "ms_per_step_separate_launches": sep_ms,
+            "config": {"workload": f"BASELINE config 5: top-1 % sparsified gradient (k={k} of {total} positions, u32 index + {8 * L}-byte value), {C} clients, "
+                                   f"{b}-bit modulus, single mask over compact positions (the sparse path the reference runs; dynamic masking picks it), "
+                                   f"n_jobs={J}; step = span bounds of the round's lists + {C} compact encrypts with the sum of the expanded uploads written "
+                                   "in the same persistent launch + sparse decrypt (mask blocks computed inside the span reduce)"
+                                   + ("; independent replicas per GPU" if world > 1 else ""),
+                       "n": total, "k": k, "int_bits": b, "clients_total": C, "mask": "single (sparse)", "schedule": "encrypt+aggregate fused",
+                       "parity": "bit-exact (dense round trip + two clients' ciphertexts vs the oracle, both schedules, checked in-run)"},
+            "roofline": {"kernel": f"span_prf_kernel<1> ({C} clients' single-mask encrypts over compact positions + the sparse aggregate of their uploads: one "
+                                   "persistent launch, one workgroup per CU, AES tables and span accumulators in the same 160 KiB of LDS)",
+                         "kernel_key": "span_prf_kernel", "bound": "lds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": enc_bytes, "avg_launch_ms": enc_ms,
+                         "launches_timed": K, "aes_blocks_per_launch": prf_blocks, "aes_blocks_per_s": prf_blocks / (enc_ms * 1e-3),
+                         "note": "the round's two dominant launches are this one and its decrypt twin; one AES block per list entry, LDS-lookup / "
+                                 "VALU-issue bound, `frac` is its HBM fraction as required"},
+            "roofline_sparse_decrypt": {"kernel": "span_prf_kernel<0> (dense minus-mask built inside the span reduce and subtracted from the aggregate)",
+                                        "bound": "lds", "achieved": dec_bytes / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                        "frac": dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": dec_bytes,
+                                        "avg_launch_ms": dec_ms, "aes_blocks_per_s": prf_blocks / (dec_ms * 1e-3)},
+            "span_bounds": "computed once per round (both span sizes in one pass), shared by the two passes" if bounds is not None else "computed by each pass",
+            "phases_ms": {"span_bounds": float(ph[:, 0].mean()), "encrypt_xC_plus_sparse_aggregate": enc_ms, "minus_mask_plus_decrypt": dec_ms},
+        })
+        return out
     agg_ms = float(ph[:, 1].mean())
     enc_ms = float(ph[:, 0].mean())
     alg_bytes = C * k * (4 + 8 * L) + total * 8 * L
     achieved = alg_bytes / (agg_ms * 1e-3) / 1e9
-    # the launch that dominates the round BY TIME is the PRF chain of the compact single-mask streams (the encrypt phase is exactly one
-    # such launch; the decrypt phase contains another one): `roofline` describes it, `roofline_sparse_aggregate` the span reduce
-    m = 1 if L == 2 else 128 // b
+    # the launch that dominates the round BY TIME is the PRF chain of the compact single-mask streams
     prf_bytes = C * k * (8 + 8 * L)
-    prf_blocks = C * ((k + m - 1) // m)
     prf_achieved = prf_bytes / (enc_ms * 1e-3) / 1e9
     out.update({
         "value": world * C * k / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
@@ -1215,17 +1278,15 @@ def bench_sparse(args, total, ops, rank, world, out):
                                f"{b}-bit modulus, single mask over compact positions (the sparse path the reference runs; dynamic masking picks it), "
                                f"n_jobs={J}; step = {C} compact encrypts + fused sparse aggregate + decrypt (dense minus-mask built and subtracted in one pass)"
                                + ("; independent replicas per GPU" if world > 1 else ""),
-                   "n": total, "k": k, "int_bits": b, "clients_total": C, "mask": "single (sparse)",
-                   "parity": "bit-exact (dense round trip + one client's ciphertext vs the oracle, checked in-run)"},
-        "roofline": {"kernel": (f"prf_chain_kernel<1024> ({C} single-mask streams over compact positions: the {C} clients' encrypts in one launch; "
-                                "the same launch shape generates the decrypt's minus-mask streams)") if L == 2 else
+                   "n": total, "k": k, "int_bits": b, "clients_total": C, "mask": "single (sparse)", "schedule": "separate launches",
+                   "parity": "bit-exact (dense round trip + two clients' ciphertexts vs the oracle, checked in-run)"},
+        "roofline": {"kernel": (f"prf_chain_kernel<1024> ({C} single-mask streams over compact positions: the {C} clients' encrypts in one launch)") if L == 2 else
                                f"prf_small_chain_kernel ({C} single-mask streams over compact positions)",
                      "kernel_key": "prf_chain_kernel" if L == 2 else "prf_small_chain_kernel",
                      "bound": "lds", "achieved": prf_achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": prf_achieved / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": prf_bytes, "avg_launch_ms": enc_ms, "launches_timed": K,
                      "aes_blocks_per_launch": prf_blocks, "aes_blocks_per_s": prf_blocks / (enc_ms * 1e-3),
-                     "note": "the round's dominant launch by time (encrypt phase = one such launch, the decrypt phase holds a second one); "
-                             "AES-rate (LDS lookup) bound, `frac` is its HBM fraction as required"},
+                     "note": "AES-rate (LDS lookup) bound, `frac` is its HBM fraction as required"},
         "roofline_sparse_aggregate": {"kernel": "span_reduce_kernel (fused sparse aggregate: LDS-staged spans, dense vector written once)",
                                       "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                                       "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": agg_ms,

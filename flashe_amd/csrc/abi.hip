@@ -1648,9 +1648,10 @@ struct flashe_span_bounds {
     uint64_t total = 0;
     std::vector<const uint32_t *> loc;
     std::vector<uint64_t> k;
-    int span = kSpanReduce;              // positions per span the table was computed for (kSpanFused on a ctx whose sparse passes run the PRF inside the reduce)
-    uint32_t *start = nullptr;           // per group of kMaxScatter clients: (span_count(total, span) + 1) * group words
+    uint32_t *start = nullptr;           // per group of kMaxScatter clients: (span_count(total, kSpanReduce) + 1) * group words (the plain span reduce)
     size_t group_stride = 0;             // words between two groups' tables
+    uint32_t *start_fused = nullptr;     // the same at kSpanFused positions per span (the passes with the PRF inside; null on a ctx that has none)
+    size_t group_stride_fused = 0;
 };
 
 // int_bits > 64 on the table PRF: the sparse single-mask passes run as launch_span_prf
@@ -1672,15 +1673,17 @@ int flashe_span_bounds_create(flashe_ctx *ctx, uint64_t total, int C, const uint
     }
     auto *b = new flashe_span_bounds;
     b->device = ctx->device; b->C = C; b->total = total;
-    b->span = span_prf_ok(ctx) ? kSpanFused : kSpanReduce;
     b->loc.assign(loc_dev, loc_dev + C); b->k.assign(k, k + C);
     const int group = std::min(C, kMaxScatter), groups = (C + kMaxScatter - 1) / kMaxScatter;
-    b->group_stride = (span_count(total, b->span) + 1) * static_cast<size_t>(group);
-    const hipError_t e = hipMalloc(&b->start, std::max<size_t>(b->group_stride * groups * sizeof(uint32_t), 16));
+    b->group_stride = (span_count(total, kSpanReduce) + 1) * static_cast<size_t>(group);
+    b->group_stride_fused = span_prf_ok(ctx) ? (span_count(total, kSpanFused) + 1) * static_cast<size_t>(group) : 0;
+    const hipError_t e = hipMalloc(&b->start, std::max<size_t>((b->group_stride + b->group_stride_fused) * groups * sizeof(uint32_t), 16));
     if (e != hipSuccess) { delete b; return fail(ctx, e == hipErrorOutOfMemory ? FLASHE_ENOMEM : FLASHE_EIO, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (b->group_stride_fused) b->start_fused = b->start + b->group_stride * groups;
     for (int g = 0; g < groups; g++) {
         const int c0 = g * kMaxScatter, nc = std::min(kMaxScatter, C - c0);
-        const hipError_t le = launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, b->start + g * b->group_stride, b->span);
+        const hipError_t le = launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, b->start + g * b->group_stride,
+                                                 b->start_fused ? b->start_fused + g * b->group_stride_fused : nullptr);
         if (le != hipSuccess) { (void)hipFree(b->start); delete b; HIP_TRY(ctx, le); }
     }
     *out = b;
@@ -1699,7 +1702,8 @@ int flashe_span_bounds_recompute(flashe_ctx *ctx, flashe_span_bounds *b, const u
     }
     b->loc.assign(loc_dev, loc_dev + b->C); b->k.assign(k, k + b->C);
     for (int c0 = 0, g = 0; c0 < b->C; c0 += kMaxScatter, g++)
-        HIP_TRY(ctx, launch_span_bounds(ctx->env, std::min(kMaxScatter, b->C - c0), loc_dev + c0, k + c0, b->total, b->start + g * b->group_stride, b->span));
+        HIP_TRY(ctx, launch_span_bounds(ctx->env, std::min(kMaxScatter, b->C - c0), loc_dev + c0, k + c0, b->total, b->start + g * b->group_stride,
+                                        b->start_fused ? b->start_fused + g * b->group_stride_fused : nullptr));
     return FLASHE_OK;
 }
 
@@ -1765,7 +1769,7 @@ static int sparse_aggregate_impl(flashe_ctx *ctx, uint64_t total, int C, const u
             uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
             HIP_TRY(ctx, launch_span_reduce(ctx->env, nc, loc_dev + c0, vals_dev + c0, k + c0, zeros + static_cast<size_t>(L) * c0,
                                             c0 ? 0 : static_cast<uint64_t>(zsum), c0 ? 0 : static_cast<uint64_t>(zsum >> 64), total,
-                                            start, c0 != 0 ? out_dev : nullptr, false, out_dev, bounds != nullptr, bounds ? bounds->span : kSpanReduce));
+                                            start, c0 != 0 ? out_dev : nullptr, false, out_dev, bounds != nullptr));
         }
         return FLASHE_OK;
     }
@@ -1801,7 +1805,7 @@ int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t
         if (z & ~mask) return fail(ctx, FLASHE_EINVAL, "zero value of client %d exceeds int_bits", c);
         zsum = (zsum + z) & mask;
     }
-    if (!span_prf_ok(ctx) || (bounds && bounds->span != kSpanFused)) {
+    if (!span_prf_ok(ctx) || (bounds && !bounds->start_fused)) {
         // int_bits <= 64 / another PRF backend: the encrypts, then the sparse reduce of what they wrote
         for (int c = 0; c < C; c++) {
             if (!k[c]) continue;
@@ -1814,8 +1818,8 @@ int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t
     if (rc) return rc;
     for (int c0 = 0; c0 < C; c0 += kMaxScatter) {
         const int nc = std::min(kMaxScatter, C - c0);
-        uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
-        if (!bounds) HIP_TRY(ctx, launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, start, kSpanFused));
+        uint32_t *start = bounds ? bounds->start_fused + (c0 / kMaxScatter) * bounds->group_stride_fused : static_cast<uint32_t *>(ctx->bounds.p);
+        if (!bounds) HIP_TRY(ctx, launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, nullptr, start));
         HIP_TRY(ctx, launch_span_prf(ctx->env, iter, nc, idx + c0, loc_dev + c0, k + c0, pt_dev + c0, pt_limbs, ct_dev + c0, zeros + 2 * static_cast<size_t>(c0),
                                      c0 ? 0 : static_cast<uint64_t>(zsum), c0 ? 0 : static_cast<uint64_t>(zsum >> 64), total, start,
                                      c0 != 0 ? agg_out_dev : nullptr, false, agg_out_dev));
@@ -1850,15 +1854,15 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
     if (prf_inside) {
         // strictly increasing lists: ONE persistent launch per group of clients generates the mask blocks inside the span reduce
         // (launch_span_prf) -- no compact streams in HBM, the AES rounds run under the dense read / write
-        if (bounds && bounds->span != kSpanFused) return fail(ctx, FLASHE_EINVAL, "the span bounds were computed by a ctx of another int_bits / PRF backend");
+        if (bounds && !bounds->start_fused) return fail(ctx, FLASHE_EINVAL, "the span bounds were computed by a ctx of another int_bits / PRF backend");
         int rc = bounds ? FLASHE_OK : ensure(ctx, ctx->bounds, span_table_words(total, std::min(C, kMaxScatter)) * sizeof(uint32_t));
         if (rc) return rc;
         for (int c0 = 0; c0 < C; c0 += kMaxScatter) {
             const int nc = std::min(kMaxScatter, C - c0);
             uint32_t idx[kMaxScatter];
             for (int e = 0; e < nc; e++) idx[e] = static_cast<uint32_t>(c0 + e);
-            uint32_t *start = bounds ? bounds->start + (c0 / kMaxScatter) * bounds->group_stride : static_cast<uint32_t *>(ctx->bounds.p);
-            if (!bounds) HIP_TRY(ctx, launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, start, kSpanFused));
+            uint32_t *start = bounds ? bounds->start_fused + (c0 / kMaxScatter) * bounds->group_stride_fused : static_cast<uint32_t *>(ctx->bounds.p);
+            if (!bounds) HIP_TRY(ctx, launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, nullptr, start));
             HIP_TRY(ctx, launch_span_prf(ctx->env, iter, nc, idx, loc_dev + c0, k + c0, nullptr, 2, nullptr, nullptr, 0, 0, total, start,
                                          c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev));
         }

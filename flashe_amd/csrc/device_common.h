@@ -329,6 +329,30 @@ __device__ __forceinline__ void st128(uint64_t *p, u128 v)
     *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(static_cast<uint64_t>(v), static_cast<uint64_t>(v >> 64));
 }
 
+// A device pointer that was itself LOADED from the LDS (per-client tables of list / value pointers) is a generic pointer to the
+// compiler: it is dereferenced with flat_load / flat_store, which count on the LDS counter as well as on the memory counter -- every
+// later wait for an LDS lookup then waits for that memory access too.  These casts say what such pointers are.
+#define FLASHE_GLOBAL(T, p) (reinterpret_cast<__attribute__((address_space(1))) T *>(reinterpret_cast<uintptr_t>(p)))
+__device__ __forceinline__ uint32_t ld32_g(const uint32_t *p) { return *FLASHE_GLOBAL(const uint32_t, p); }
+__device__ __forceinline__ uint64_t ld64_g(const uint64_t *p) { return *FLASHE_GLOBAL(const uint64_t, p); }
+__device__ __forceinline__ uint64_t ld64_nt_g(const uint64_t *p) { return __builtin_nontemporal_load(FLASHE_GLOBAL(const uint64_t, p)); }
+__device__ __forceinline__ u128 ld128_g(const uint64_t *p)
+{
+    const u64x2 v = *FLASHE_GLOBAL(const u64x2, p);
+    return (static_cast<u128>(v[1]) << 64) | v[0];
+}
+__device__ __forceinline__ u128 ld128_nt_g(const uint64_t *p)
+{
+    const u64x2 v = __builtin_nontemporal_load(FLASHE_GLOBAL(const u64x2, p));
+    return (static_cast<u128>(v[1]) << 64) | v[0];
+}
+__device__ __forceinline__ void st128_nt_g(uint64_t *p, u128 v)
+{
+    u64x2 r;
+    r[0] = static_cast<uint64_t>(v); r[1] = static_cast<uint64_t>(v >> 64);
+    __builtin_nontemporal_store(r, FLASHE_GLOBAL(u64x2, p));
+}
+
 // streaming (read-once / write-once) forms: keep such traffic out of the caches
 __device__ __forceinline__ u128 ld128_nt(const uint64_t *p)
 {

@@ -179,19 +179,19 @@ hipError_t launch_scatter(const LaunchEnv &env, uint64_t total, uint64_t k, cons
 // start_dev = (span_count(total, span) + 1) * C words of scratch.
 constexpr int kMaxScatter = 64;
 // positions per span: the plain reduce keeps 64 KiB of accumulators per workgroup, the passes with the PRF inside (launch_span_prf)
-// what the AES tables leave of a CU's LDS.  A table of span bounds serves the kernels of ONE of the two sizes.
-constexpr int kSpanReduce = 4096, kSpanFused = 1760;
+// what the AES tables leave of a CU's LDS.  A table of span bounds serves the kernels of ONE of the two sizes (launch_span_bounds fills both in one pass).
+constexpr int kSpanReduce = 4096, kSpanFused = 1752;
 uint64_t span_count(uint64_t total, int span);
 // words of a bounds table that is large enough for either span size
 inline size_t span_table_words(uint64_t total, int C) { return static_cast<size_t>(span_count(total, kSpanFused) + 1) * static_cast<size_t>(C); }
 // (bounds_ready: start_dev already holds the bounds of exactly these lists -- launch_span_bounds -- and the pass that computes them is skipped)
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
-                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready = false,
-                              int span = kSpanReduce);
-// the first list entry of each of the C <= kMaxScatter clients in every span: (span_count(total, span) + 1) * C words
-hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev,
-                              int span = kSpanReduce);
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready = false);
+// the first list entry of each of the C <= kMaxScatter clients in every span, at kSpanReduce and / or kSpanFused positions per span
+// (either table may be null): (span_count(total, span) + 1) * C words each, one pass over the lists
+hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_reduce_dev,
+                              uint32_t *start_fused_dev);
 // The span reduce with the PRF inside (int_bits > 64, table PRF; one persistent launch): entry q of client c contributes
 // term(iter, idx[c], q) -- pt_dev null: out[p] = from[p] +/- the sum of the masks at p (sparse minus-mask / decrypt); pt_dev given:
 // ct_dev[c][q] = (pt_dev[c][q] + mask) mod 2^b is stored (where ct_dev[c] is not null) and out[p] = from[p] + sum (ct - sub[c]);

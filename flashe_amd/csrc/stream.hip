@@ -625,8 +625,32 @@ struct ScatterTable {
 };
 
 constexpr int kBoundsPerThread = 8;
+// entry q of client c (prev = the entry before it, cur = itself; q == k closes the list) opens the spans of SPAN positions between them
 template <int SPAN>
-__global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const ScatterTable tb, int C, uint64_t n_spans, uint64_t total, uint32_t *start,
+__device__ __forceinline__ void span_open(uint32_t *start, int C, int c, uint64_t q, bool live, uint64_t k, uint64_t prev, uint64_t cur, uint64_t total,
+                                          uint32_t lane)
+{
+    const uint64_t n_spans = (total + SPAN - 1) / SPAN;
+    const uint64_t s_last = q < k ? std::min<uint64_t>(static_cast<uint32_t>(cur) / static_cast<uint32_t>(SPAN), n_spans) : n_spans;
+    const uint64_t s_first = !live ? s_last + 1 : q ? std::min<uint64_t>(static_cast<uint32_t>(prev) / static_cast<uint32_t>(SPAN), n_spans) + 1 : 0;
+    const bool is_long = s_first + 16 <= s_last;
+    if (!is_long)
+        for (uint64_t sp = s_first; sp <= s_last; sp++) start[sp * C + c] = static_cast<uint32_t>(q);
+    // a long run of empty spans (a short list over a long vector, an empty client): the wave fills it together instead of one
+    // lane storing span after span
+    uint64_t pending = __ballot(is_long);
+    while (pending) {
+        const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
+        const uint64_t a = __shfl(s_first, src, 64), b = __shfl(s_last, src, 64);
+        const uint32_t qq = static_cast<uint32_t>(__shfl(q, src, 64));
+        for (uint64_t x = a + lane; x <= b; x += 64u) start[x * C + c] = qq;
+        pending &= pending - 1;
+    }
+}
+
+// start_reduce / start_fused: the table at kSpanReduce / kSpanFused positions per span (either may be null): one pass over the lists
+// serves the plain reduce and the passes with the PRF inside
+__global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const ScatterTable tb, int C, uint64_t total, uint32_t *start_reduce, uint32_t *start_fused,
                                                                      uint32_t *err_flag)
 {
     const int c = blockIdx.y;
@@ -640,21 +664,8 @@ __global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const Scatt
         const bool live = q <= k;
         const uint64_t prev = live && q ? loc[q - 1] : 0, cur = live && q < k ? loc[q] : 0;
         if (live && q < k && (cur >= total || (q && cur <= prev))) *err_flag = 1;
-        const uint64_t s_last = q < k ? std::min<uint64_t>(static_cast<uint32_t>(cur) / static_cast<uint32_t>(SPAN), n_spans) : n_spans;
-        const uint64_t s_first = !live ? s_last + 1 : q ? std::min<uint64_t>(static_cast<uint32_t>(prev) / static_cast<uint32_t>(SPAN), n_spans) + 1 : 0;
-        const bool is_long = s_first + 16 <= s_last;
-        if (!is_long)
-            for (uint64_t sp = s_first; sp <= s_last; sp++) start[sp * C + c] = static_cast<uint32_t>(q);
-        // a long run of empty spans (a short list over a long vector, an empty client): the wave fills it together instead of one
-        // lane storing span after span
-        uint64_t pending = __ballot(is_long);
-        while (pending) {
-            const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
-            const uint64_t a = __shfl(s_first, src, 64), b = __shfl(s_last, src, 64);
-            const uint32_t qq = static_cast<uint32_t>(__shfl(q, src, 64));
-            for (uint64_t x = a + lane; x <= b; x += 64u) start[x * C + c] = qq;
-            pending &= pending - 1;
-        }
+        if (start_reduce) span_open<kSpanReduce>(start_reduce, C, c, q, live, k, prev, cur, total, lane);
+        if (start_fused) span_open<kSpanFused>(start_fused, C, c, q, live, k, prev, cur, total, lane);
     }
 }
 
@@ -675,8 +686,8 @@ __device__ __forceinline__ void span_gather(SpanBatch &g, uint32_t f0, uint32_t 
             if (prefix[c + step] <= f) c += step;
         g.own[e] = c;
         const uint64_t q = static_cast<uint64_t>(begin[c]) + (f - prefix[c]);
-        g.r[e] = s_loc[c][q] - p0;
-        g.v[e] = L == 2 ? ld128(s_vals[c] + 2 * q) : static_cast<u128>(s_vals[c][q]);
+        g.r[e] = ld32_g(s_loc[c] + q) - p0;
+        g.v[e] = L == 2 ? ld128_g(s_vals[c] + 2 * q) : static_cast<u128>(ld64_g(s_vals[c] + q));
     }
 }
 
@@ -760,12 +771,12 @@ __global__ __launch_bounds__(THREADS) void span_reduce_kernel(const ScatterTable
 
 uint64_t span_count(uint64_t total, int span) { return (total + static_cast<uint64_t>(span) - 1) / static_cast<uint64_t>(span); }
 
-// out[p] = from[p] +/- sum over clients c and entries q with loc[c][q] == p of (vals[c][q] - sub[c])   (mod 2^b), every p < total,
-// from = src_dev when given (may be out_dev), the constant base otherwise; loc[c] strictly increasing.
-// start_dev: (span_count(total, span) + 1) * C words of scratch.
-hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_dev, int span)
+// The first list entry of each of the C <= kMaxScatter clients in every span: start_reduce_dev / start_fused_dev (either may be null)
+// = (span_count(total, kSpanReduce / kSpanFused) + 1) * C words.
+hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total, uint32_t *start_reduce_dev,
+                              uint32_t *start_fused_dev)
 {
-    if (C > kMaxScatter || C < 1 || (span != kSpanReduce && span != kSpanFused)) return hipErrorInvalidValue;
+    if (C > kMaxScatter || C < 1 || (!start_reduce_dev && !start_fused_dev)) return hipErrorInvalidValue;
     if (total == 0) return hipSuccess;
     ScatterTable tb{};
     uint64_t kmax = 0;
@@ -774,19 +785,19 @@ hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const
         tb.loc[c] = loc_dev[c]; tb.k[c] = k[c];
         kmax = std::max(kmax, k[c]);
     }
-    const dim3 grid(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C);
-    if (span == kSpanFused)
-        hipLaunchKernelGGL(span_bounds_kernel<kSpanFused>, grid, dim3(kStreamThreads), 0, env.stream, tb, C, span_count(total, span), total, start_dev, env.err_flag);
-    else
-        hipLaunchKernelGGL(span_bounds_kernel<kSpanReduce>, grid, dim3(kStreamThreads), 0, env.stream, tb, C, span_count(total, span), total, start_dev, env.err_flag);
+    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0, env.stream,
+                       tb, C, total, start_reduce_dev, start_fused_dev, env.err_flag);
     return hipGetLastError();
 }
 
+// out[p] = from[p] +/- sum over clients c and entries q with loc[c][q] == p of (vals[c][q] - sub[c])   (mod 2^b), every p < total,
+// from = src_dev when given (may be out_dev), the constant base otherwise; loc[c] strictly increasing.
+// start_dev: (span_count(total, kSpanReduce) + 1) * C words of scratch.
 hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const *loc_dev, const uint64_t *const *vals_dev,
                               const uint64_t *k, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi, uint64_t total,
-                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready, int span)
+                              uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, bool bounds_ready)
 {
-    if (C > kMaxScatter || C < 1 || (span != kSpanReduce && span != kSpanFused)) return hipErrorInvalidValue;
+    if (C > kMaxScatter || C < 1) return hipErrorInvalidValue;
     if (total == 0) return hipSuccess;
     const int L = env.b > 64 ? 2 : 1;
     ScatterTable tb{};
@@ -798,17 +809,13 @@ hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const
     }
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
-    const uint64_t n_spans = span_count(total, span);
+    const uint64_t n_spans = span_count(total, kSpanReduce);
     if (!bounds_ready) {
-        const hipError_t e = launch_span_bounds(env, C, loc_dev, k, total, start_dev, span);
+        const hipError_t e = launch_span_bounds(env, C, loc_dev, k, total, start_dev, nullptr);
         if (e != hipSuccess) return e;
     }
-    if (span == kSpanFused)       // a bounds handle laid out for the fused PRF passes (their accumulators share the LDS with the AES tables)
-        hipLaunchKernelGGL((span_reduce_kernel<kSpanFused, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
-                           start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
-    else
-        hipLaunchKernelGGL((span_reduce_kernel<kSpan, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
-                           start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
+    hipLaunchKernelGGL((span_reduce_kernel<kSpan, kSpanThreads>), dim3(static_cast<unsigned>(n_spans)), dim3(kSpanThreads), 0, env.stream, tb, C, L, total,
+                       start_dev, base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.err_flag);
     return hipGetLastError();
 }
 
@@ -819,9 +826,10 @@ hipError_t launch_span_reduce(const LaunchEnv &env, int C, const uint32_t *const
 // entry q of client c gets its block term(iter, idx[c], q) computed where the span reduce would have gathered a stored value -- the
 // block needs (c, q) only, so the load of the entry's POSITION (and, ENC, of its plaintext) is in flight under the 14 rounds -- and the
 // dense read / write of the span (prefetched before the entries, written after them) overlaps with the next span's rounds.
-//   ENC = false: out[p] = from[p] +/- sum of the masks of the entries at p   (sparse minus-mask / sparse decrypt, a-13)
-//   ENC = true : ct[c][q] = (pt[c][q] + mask) mod 2^b is stored AND out[p] = base + sum (ct[c][q] - sub[c]): the clients a GPU plays
-//                encrypt and their uploads are summed in the same pass (the sparse twin of the chained encrypt's partial aggregate)
+//   ENC = 0    : out[p] = from[p] +/- sum of the masks of the entries at p   (sparse minus-mask / sparse decrypt, a-13)
+//   ENC = 1, 2 : ct[c][q] = (pt[c][q] + mask) mod 2^b is stored AND out[p] = base + sum (ct[c][q] - sub[c]): the clients a GPU plays
+//                encrypt and their uploads are summed in the same pass (the sparse twin of the chained encrypt's partial aggregate);
+//                the value of ENC is the number of limbs of a plaintext
 struct SpanPrfTable {
     const uint32_t *loc[kMaxScatter];
     const uint64_t *pt[kMaxScatter];
@@ -831,23 +839,49 @@ struct SpanPrfTable {
 };
 
 #ifdef FLASHE_TUNING
-__device__ unsigned long long g_span_prf_cycles[8];      // phase cycle sums of workgroup 0, wave 0 (FLASHE_SPAN_PROBE=9)
+__device__ unsigned long long g_span_prf_cycles[24];      // phase cycle sums of workgroup 0, wave 0 (FLASHE_SPAN_PROBE=9)
 #define SPAN_PRF_TICK(i) do { if (probe == 9 && blockIdx.x == 0 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); \
                                                                                 g_span_prf_cycles[i] += t_ - tick_; tick_ = t_; } } while (0)
 #else
 #define SPAN_PRF_TICK(i) do { } while (0)
 #endif
-template <bool ENC>
+
+// inclusive prefix sum over the 64 lanes without the LDS (row shifts, then the two row broadcasts of the GFX9 DPP set): the shuffle
+// form costs six LDS round trips on the one wave every other wave of the workgroup waits for
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// One list entry on its way through the kernel: which client, which compact position, where it lands, and what round 1 needs.
+struct SpanPrfEntry {
+    bool valid;
+    int c;
+    uint32_t q, pos;
+    uint4 pre;           // CtrPrefix of the client
+    CtrVar x;            // the four round-1 lookups on the counter
+    u128 pt;             // ENC: the plaintext
+};
+
+template <int ENC>
 __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys rk, const SpanPrfTable tb, int C, uint32_t iter0, uint64_t total, uint32_t n_spans,
                                                                const uint32_t *__restrict__ start, uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo,
                                                                uint64_t mask_hi, const uint64_t *src, bool negate, uint64_t *out,
-                                                               const uint32_t *__restrict__ te0, uint32_t *err_flag, int pt_limbs, int probe)
+                                                               const uint32_t *__restrict__ te0, uint32_t *err_flag, int probe)
 {
     constexpr int SPAN = kSpanFused, THREADS = kPrfThreads, PER = (SPAN + THREADS - 1) / THREADS;
     const uint32_t iter = iter0 + te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
     __shared__ unsigned long long acc[2 * SPAN];
-    __shared__ uint32_t s_begin[kMaxScatter], s_prefix[2 * kMaxScatter + 2];
+    // (prefix, begin) per client of the span in flight and of the NEXT one: entry f of a span belongs to the client c with
+    // pb[c].x <= f < pb[c + 1].x and is entry pb[c].y + (f - pb[c].x) of that client's list; pb[C].x = entries in the span
+    __shared__ uint2 s_pb[2][kMaxScatter + 2];
     __shared__ uint4 s_pref[kMaxScatter];                     // CtrPrefix of (iter, idx[c], counter high word 0): round 1 costs 4 lookups
     __shared__ const uint32_t *s_loc[kMaxScatter];
     __shared__ const uint64_t *s_pt[ENC ? kMaxScatter : 1];
@@ -857,117 +891,199 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
     const LaneRegs lr = lane_regs(tab);
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * SPAN; i += THREADS) acc[i] = 0;
-    uint32_t kc = 0;
+    // the LAST wave keeps the span tables: it is the wave with the fewest entries (none at all while a span holds at most 960)
+    const int ln = tid & 63;
+    const bool keeper = tid >= THREADS - 64;
+    const uint32_t kc = keeper && ln < C ? tb.k[ln] : 0u;
     if (tid < C) {
         const CtrPrefix p = ctr_prefix(rk, lr, iter, tb.idx[tid], 0u);
         s_pref[tid] = make_uint4(p.u[0], p.u[1], p.u[2], p.u[3]);
         s_loc[tid] = tb.loc[tid];
-        kc = tb.k[tid];
         if (ENC) { s_pt[tid] = tb.pt[tid]; s_ct[tid] = tb.ct[tid]; s_sub[2 * tid] = tb.sub_lo[tid]; s_sub[2 * tid + 1] = tb.sub_hi[tid]; }
     }
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
     const u128 base = (static_cast<u128>(base_hi) << 64) | base_lo;
-    // first wave: this span's slice [b0, b1) of client `tid`'s list (clamped like span_reduce_kernel's), loaded one span AHEAD of its
-    // use; SPAN_PRF_PUBLISH turns the 64 counts into the flat entry index space of the span
-    // (the loads are unconditional -- clamped indices -- and their values are not touched before SPAN_PRF_PUBLISH, so that nothing
-    // waits for them under the rounds; PUBLISH comes BEFORE the wave's stores of the finished span: the memory counter is in order, a
-    // wait for these loads behind the stores would wait for the stores)
+    const uint32_t stride = gridDim.x;
+    // The keeper wave: the slice [f0, f1) of client `ln`'s list in a span (clamped like span_reduce_kernel's) is loaded THREE spans
+    // ahead and published TWO spans ahead -- at the head of an iteration, into the table of the span in flight, which nobody reads any
+    // more (its entry count travels in a register) unless the span is crowded (more than 1,024 entries: a second pass looks entries up
+    // in it; the table is then published behind the entries' barrier).  Every lane can so look its entry of the next span up under
+    // the rounds of this one, and no wave waits for the keeper.  The loads are unconditional (clamped indices).
     uint32_t f0 = 0, f1 = 0;
     bool f_live = false;
-    const uint32_t tid_c = static_cast<uint32_t>(min(tid, C - 1));
+    const uint32_t ln_c = static_cast<uint32_t>(min(ln, C - 1));
 #define SPAN_PRF_FETCH(spx)                                                                                              \
     do {                                                                                                                 \
         const uint64_t sp_ = (spx), sc_ = sp_ < n_spans ? sp_ : n_spans - 1;                                             \
-        f_live = tid < C && sp_ < n_spans;                                                                               \
-        f0 = start[sc_ * C + tid_c]; f1 = start[(sc_ + 1) * C + tid_c];                                                  \
+        f_live = ln < C && sp_ < n_spans;                                                                                \
+        f0 = start[sc_ * C + ln_c]; f1 = start[(sc_ + 1) * C + ln_c];                                                    \
     } while (0)
-#define SPAN_PRF_PUBLISH()                                                                                               \
+#define SPAN_PRF_PUBLISH(buf)                                                                                            \
     do {                                                                                                                 \
         const uint32_t b0_ = min(f0, kc), b1_ = min(f1, kc);                                                             \
-        uint32_t run_ = f_live && b1_ > b0_ ? b1_ - b0_ : 0;                                                             \
-        _Pragma("unroll") for (int d = 1; d < 64; d <<= 1) {                                                             \
-            const uint32_t up_ = __shfl_up(run_, d, 64);                                                                 \
-            if (tid >= d) run_ += up_;                                                                                   \
-        }                                                                                                                \
-        if (tid < C) s_begin[tid] = b0_;                                                                                 \
-        if (tid == 0) s_prefix[0] = 0;                                                                                   \
-        s_prefix[tid + 1] = tid < C ? run_ : 0xffffffffu;                                                                \
-        s_prefix[tid + 65] = 0xffffffffu;                                                                                \
+        const uint32_t run_ = wave_scan_u32(f_live && b1_ > b0_ ? b1_ - b0_ : 0u);                                       \
+        if (ln == 0) s_pb[buf][0].x = 0;                                                                                 \
+        if (ln < C) s_pb[buf][ln].y = b0_;                                                                               \
+        s_pb[buf][ln + 1].x = ln < C ? run_ : 0xffffffffu;           /* sentinels: the owner search needs no bounds */   \
     } while (0)
+    // entry f of the span whose table is s_pb[buf], without anything to hide behind (first span, entries beyond the first 1,024)
+    auto lookup = [&](int buf, uint32_t f, uint32_t n_in_span) {
+        SpanPrfEntry e;
+        int c = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (s_pb[buf][c + step].x <= f) c += step;
+        const uint2 pb = s_pb[buf][c];
+        e.valid = f < n_in_span;
+        e.c = c;
+        e.q = pb.y + (f - pb.x);
+        e.pos = e.valid ? ld32_g(s_loc[c] + e.q) : 0u;
+        e.pt = 0;
+        if (ENC && e.valid) e.pt = ENC == 2 ? ld128_nt_g(s_pt[c] + 2 * static_cast<uint64_t>(e.q)) : static_cast<u128>(ld64_nt_g(s_pt[c] + e.q));
+        e.pre = s_pref[c];
+        e.x = ctr_var(rk, lr, e.q);
+        return e;
+    };
+    // what an entry's block is worth once the rounds are done: ENC stores the ciphertext on the way
+    // (ENC: the ciphertext goes to *ct_later / *ct_to when the caller stores it itself -- the first 1,024 entries of a span, whose
+    // store must come BEHIND the wait that follows the entries' barrier, not in front of it)
+    auto settle = [&](const SpanPrfEntry &e, const uint32_t (&s)[4], uint32_t p0_lo, uint32_t span_len, u128 *ct_later, uint64_t **ct_to) {
+        if (!e.valid) return;
+        u128 w = words_to_u128(s) & mask;
+        if (ENC) {
+            w = (e.pt + w) & mask;
+            uint64_t *to = s_ct[e.c] ? s_ct[e.c] + 2 * static_cast<uint64_t>(e.q) : nullptr;
+            if (ct_later) { *ct_later = w; *ct_to = to; }
+            else if (to) st128_nt_g(to, w);
+            w -= (static_cast<u128>(s_sub[2 * e.c + 1]) << 64) | s_sub[2 * e.c];
+        }
+        const uint32_t r = e.pos - p0_lo;
+        if (r >= span_len) { *err_flag = 1; return; }            // a list that is not strictly increasing or reaches beyond the vector
+        const unsigned long long wlo = static_cast<unsigned long long>(w), whi = static_cast<unsigned long long>(w >> 64);
+#ifdef FLASHE_TUNING
+        if (probe == 3) { if (wlo == 0x1234567ull) acc[2 * r] = whi; return; }
+#endif
+        const unsigned long long old = atomicAdd(&acc[2 * r], wlo);
+        atomicAdd(&acc[2 * r + 1], whi + (old + wlo < old ? 1ull : 0ull));
+    };
     uint64_t sp = blockIdx.x;
-    if (tid < 64) { SPAN_PRF_FETCH(sp); SPAN_PRF_PUBLISH(); }
+    if (keeper) {
+        SPAN_PRF_FETCH(sp); SPAN_PRF_PUBLISH(0);
+        SPAN_PRF_FETCH(sp + stride); SPAN_PRF_PUBLISH(1);
+        SPAN_PRF_FETCH(sp + 2 * static_cast<uint64_t>(stride));
+    }
     __syncthreads();
+    uint32_t n_entries = s_pb[0][C].x;
+    SpanPrfEntry cur = lookup(0, tid, n_entries);
+    // (the first entry's loads are waited for HERE: left pending into the loop, they make the compiler guard the entry's use in EVERY
+    // iteration with a full wait -- which then also covers the dense prefetch issued a few rounds earlier)
+    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+    __syncthreads();                             // (the keeper's first act in the loop overwrites the table this lookup read)
+    int buf = 0;
 #ifdef FLASHE_TUNING
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
-    for (; sp < n_spans; sp += gridDim.x) {
+    for (; sp < n_spans; sp += stride, buf ^= 1) {
         const uint64_t p0 = sp * SPAN;
         const uint32_t span_len = static_cast<uint32_t>(total - p0 < SPAN ? total - p0 : SPAN);
         SPAN_PRF_TICK(7);
-        if (tid < 64) SPAN_PRF_FETCH(sp + gridDim.x);
+#ifdef FLASHE_TUNING
+        const unsigned long long head_ = __builtin_readcyclecounter();
+        if (probe == 2) n_entries = 0;                                     // timing probes (wrong results): 1 = no rounds, 2 = no entries, 3 = no atomics
+#endif
+        const bool early = n_entries <= THREADS;                           // nobody will look an entry up in this span's table any more
+        if (keeper && early) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
+        // the dense read of the span: requested BEHIND the next entry's loads (the memory counter is in order: what is waited for after
+        // the entries' barrier is everything up to these), still some 4,000 cycles before its use
         u128 from[PER];
-#pragma unroll
-        for (int e = 0; e < PER; e++) {
-            const uint32_t r = tid + e * THREADS;
 #ifdef FLASHE_TUNING
-            from[e] = src && r < span_len && probe != 4 ? ld128_nt(src + 2 * (p0 + r)) : base;      // 4 = no dense read / write
-#else
-            from[e] = src && r < span_len ? ld128_nt(src + 2 * (p0 + r)) : base;
-#endif
+#define SPAN_PRF_FROM()                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < PER; e++) {                                                                 \
+            const uint32_t r_ = tid + e * THREADS;                                                                        \
+            from[e] = src && r_ < span_len && probe != 4 ? ld128_nt(src + 2 * (p0 + r_)) : base;      /* 4 = no dense read / write */ \
         }
-#ifdef FLASHE_TUNING
-        const uint32_t n_entries = probe == 2 ? 0u : s_prefix[C];     // timing probes (wrong results): 1 = no rounds, 2 = no entries, 3 = no position load / atomics
 #else
-        const uint32_t n_entries = s_prefix[C];
+#define SPAN_PRF_FROM()                                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < PER; e++) {                                                                 \
+            const uint32_t r_ = tid + e * THREADS;                                                                        \
+            from[e] = src && r_ < span_len ? ld128_nt(src + 2 * (p0 + r_)) : base;                                        \
+        }
 #endif
-        for (uint32_t f = tid; f < n_entries; f += THREADS) {
-            int c = 0;
+        const int nbuf = buf ^ 1;
+        const uint32_t n_next = sp + stride < n_spans ? s_pb[nbuf][C].x : 0u;
+        // The first 1,024 entries, one per lane: its block's rounds with the lookup of the lane's entry of the NEXT span threaded
+        // through them -- one step of the owner search per round (each a dependent LDS read), then the entry's position (and plaintext)
+        // load and its round-1 lookups: all of it latency that the sixteen lookups per round hide.
+        SpanPrfEntry nxt;
+        nxt.valid = false; nxt.c = 0; nxt.q = 0; nxt.pos = 0; nxt.pt = 0; nxt.pre = make_uint4(0, 0, 0, 0); nxt.x = CtrVar{{0, 0, 0, 0}};
+        const uint32_t f = tid;
+        uint32_t s[4] = {0, 0, 0, 0};
+        if (__builtin_amdgcn_ballot_w64(cur.valid || f < n_next)) {
+            const CtrPrefix pre{{cur.pre.x, cur.pre.y, cur.pre.z, cur.pre.w}};
+            ctr_round1(pre, cur.x, s);
+            int cn = 0;
+            uint32_t pv;
+            uint2 pbn = make_uint2(0, 0);
+            const uint32_t *locn = nullptr;
+            Lk16 k = issue_main(lr, s);
+            pv = s_pb[nbuf][32].x;
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int step = 32; step; step >>= 1)
-                if (s_prefix[c + step] <= f) c += step;
-            const uint32_t q = s_begin[c] + (f - s_prefix[c]);
-#ifdef FLASHE_TUNING
-            const uint32_t pos = probe == 3 ? static_cast<uint32_t>(p0) + (f % span_len) : s_loc[c][q];
-#else
-            const uint32_t pos = s_loc[c][q];                                  // needed after the rounds only
-#endif
-            u128 pt = 0;
-            if (ENC) pt = pt_limbs == 2 ? ld128_nt(s_pt[c] + 2 * static_cast<uint64_t>(q)) : static_cast<u128>(__builtin_nontemporal_load(s_pt[c] + q));
-            const uint4 pw = s_pref[c];
-            const CtrPrefix pre{{pw.x, pw.y, pw.z, pw.w}};
-            uint32_t s[4];
-            ctr_round1(pre, ctr_var(rk, lr, q), s);
-            __builtin_amdgcn_sched_barrier(0);
-            SPAN_PRF_TICK(0);                                                  // owner search, table reads, round 1
-#ifdef FLASHE_TUNING
-            if (probe != 1)
-#endif
-            aes256_rounds1_deep<2>(rk, lr, s);
-            __builtin_amdgcn_sched_barrier(0);
-            SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14                                 // the position (and plaintext) loads are waited for HERE, not under round 1
-            const uint32_t r = pos - static_cast<uint32_t>(p0);
-            u128 w = words_to_u128(s) & mask;
-            if (ENC) {
-                w = (pt + w) & mask;
-                if (s_ct[c]) st128_nt(s_ct[c] + 2 * static_cast<uint64_t>(q), w);
-                w -= (static_cast<u128>(s_sub[2 * c + 1]) << 64) | s_sub[2 * c];
+            for (int r = 2; r < 14; r++) {
+                finish_main(rk, r, k, s);
+                if (r <= 7) {                                        // r = 2 .. 7: the six steps 32, 16, .. 1 of the search
+                    const int step = 32 >> (r - 2);
+                    if (pv <= f) cn += step;
+                    if (r < 7) pv = s_pb[nbuf][cn + (step >> 1)].x;
+                    else { pbn = s_pb[nbuf][cn]; locn = s_loc[cn]; nxt.pre = s_pref[cn]; }
+                } else if (r == 8) {
+                    nxt.valid = f < n_next;
+                    nxt.c = cn;
+                    nxt.q = pbn.y + (f - pbn.x);
+                    if (nxt.valid) {
+                        nxt.pos = ld32_g(locn + nxt.q);
+                        if (ENC) nxt.pt = ENC == 2 ? ld128_nt_g(s_pt[cn] + 2 * static_cast<uint64_t>(nxt.q)) : static_cast<u128>(ld64_nt_g(s_pt[cn] + nxt.q));
+                    }
+                } else if (r == 9) {
+                    nxt.x = ctr_var(rk, lr, nxt.q);
+                } else if (r == 10) {
+                    SPAN_PRF_FROM()
+                }
+                k = r < 13 ? issue_main(lr, s) : issue_final(lr, s);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (r >= span_len) { *err_flag = 1; continue; }      // a list that is not strictly increasing or reaches beyond the vector
-            const unsigned long long wlo = static_cast<unsigned long long>(w), whi = static_cast<unsigned long long>(w >> 64);
-#ifdef FLASHE_TUNING
-            if (probe == 3) { if (wlo == 0x1234567ull) acc[2 * r] = whi; continue; }
-#endif
-            const unsigned long long old = atomicAdd(&acc[2 * r], wlo);
-            atomicAdd(&acc[2 * r + 1], whi + (old + wlo < old ? 1ull : 0ull));
-            SPAN_PRF_TICK(2);                                                  // wait for the position, accumulate
+            finish_final(rk, k, s);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            SPAN_PRF_FROM()
+        }
+#undef SPAN_PRF_FROM
+        SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14 (+ the next entry's lookup)
+        u128 ct_val = 0;
+        uint64_t *ct_to = nullptr;
+        settle(cur, s, static_cast<uint32_t>(p0), span_len, &ct_val, &ct_to);
+        SPAN_PRF_TICK(2);
+        // entries beyond the first 1,024 of a crowded span: looked up and computed one after the other
+        for (uint32_t f2 = tid + THREADS; f2 < n_entries; f2 += THREADS) {
+            const SpanPrfEntry e = lookup(buf, f2, n_entries);
+            const CtrPrefix pre{{e.pre.x, e.pre.y, e.pre.z, e.pre.w}};
+            uint32_t s2[4];
+            ctr_round1(pre, e.x, s2);
+            aes256_rounds1_deep<2>(rk, lr, s2);
+            __builtin_amdgcn_sched_barrier(0);
+            settle(e, s2, static_cast<uint32_t>(p0), span_len, nullptr, nullptr);
         }
         SPAN_PRF_TICK(3);
+#ifdef FLASHE_TUNING
+        if (probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
+#endif
         __syncthreads();
         SPAN_PRF_TICK(4);                                                      // barrier: the slowest wave's entries
-        // every load of this span has long returned (the entries waited for theirs): saying so HERE, on every wave's path, keeps the
-        // compiler from guarding the reuse of the prefetch registers with waits that would also cover the stores below
+        // every load of this span has returned or is about to (the next entry's were issued rounds ago): saying so HERE, on every wave's
+        // path, keeps the compiler from guarding the reuse of the prefetch registers with waits that would also cover the stores below
         __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
-        if (tid < 64) SPAN_PRF_PUBLISH();
+        if (ENC && ct_to) st128_nt_g(ct_to, ct_val);
+        if (keeper && !early) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int e = 0; e < PER; e++) {
@@ -984,6 +1100,8 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         SPAN_PRF_TICK(5);                                                      // publish + write-out
         __syncthreads();
         SPAN_PRF_TICK(6);
+        cur = nxt;
+        n_entries = n_next;
     }
 #undef SPAN_PRF_FETCH
 #undef SPAN_PRF_PUBLISH
@@ -992,8 +1110,8 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
 #ifdef FLASHE_TUNING
 hipError_t span_prf_cycles(unsigned long long *out8, bool reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_span_prf_cycles), 8 * sizeof(unsigned long long));
-    if (e == hipSuccess && reset) { const unsigned long long z[8] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_span_prf_cycles), z, sizeof z); }
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_span_prf_cycles), 24 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) { const unsigned long long z[24] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_span_prf_cycles), z, sizeof z); }
     return e;
 }
 #endif
@@ -1021,12 +1139,13 @@ hipError_t launch_span_prf(const LaunchEnv &env, uint32_t iter, int C, const uin
     const dim3 grid(static_cast<unsigned>(std::min<uint64_t>(n_spans, static_cast<uint64_t>(std::max(env.num_cus, 1)))));
     const char *pe = FLASHE_TUNE_ENV("FLASHE_SPAN_PROBE");
     const int probe = pe ? atoi(pe) : 0;
-    if (pt_dev)
-        hipLaunchKernelGGL(span_prf_kernel<true>, grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), start_dev,
-                           base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.te0_dev, env.err_flag, pt_limbs, probe);
-    else
-        hipLaunchKernelGGL(span_prf_kernel<false>, grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), start_dev,
-                           base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.te0_dev, env.err_flag, 2, probe);
+#define SPAN_PRF_LAUNCH(E)                                                                                                                    \
+    hipLaunchKernelGGL(span_prf_kernel<E>, grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), start_dev, \
+                       base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.te0_dev, env.err_flag, probe)
+    if (!pt_dev) SPAN_PRF_LAUNCH(0);
+    else if (pt_limbs == 1) SPAN_PRF_LAUNCH(1);
+    else SPAN_PRF_LAUNCH(2);
+#undef SPAN_PRF_LAUNCH
     return hipGetLastError();
 }
 

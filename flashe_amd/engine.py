@@ -375,14 +375,55 @@ class Graph:
             pass
 
 
+class PtrTable(object):
+    """A table of device pointers built ONCE (the ctypes array a *_dev call hands to the library): what a per-round call takes in
+    place of a list of buffers when the same clients' vectors are passed round after round -- for 50 clients building the arrays costs
+    as much host time as the launches they describe.  Engine.ptr_table(items); keeps the buffers alive."""
+
+    def __init__(self, engine, items):
+        self.items = list(items)
+        self.arr = (c_vp * max(len(self.items), 1))(*[engine._ptr(x) for x in self.items])
+        self.ptr = ctypes.cast(self.arr, ctypes.POINTER(c_vp))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __iter__(self):
+        return iter(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+class U64Table(object):
+    """The same for a per-client list of lengths (Engine.u64_table(values))."""
+
+    def __init__(self, values):
+        self.values = [int(v) for v in values]
+        self.arr = (c_u64 * max(len(self.values), 1))(*self.values)
+
+    def __len__(self):
+        return len(self.values)
+
+    def __iter__(self):
+        return iter(self.values)
+
+    def __getitem__(self, i):
+        return self.values[i]
+
+
+def _u64_array(vals):
+    return vals.arr if isinstance(vals, U64Table) else (c_u64 * max(len(vals), 1))(*[int(v) for v in vals])
+
+
 class SpanBounds:
     """flashe_span_bounds: where every client's strictly increasing location list enters every span of the dense vector, computed once
     per round's lists (the lists must stay as they are while the handle is used; it keeps them alive)."""
 
     def __init__(self, engine, total, locs, ks):
-        self.engine, self._keep = engine, list(locs)
+        self.engine, self._keep = engine, locs if isinstance(locs, PtrTable) else list(locs)
         p, _k = engine._ptr_array(locs)
-        kk = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        kk = _u64_array(ks)
         h = c_vp()
         engine._check(engine._lib.flashe_span_bounds_create(engine._h, int(total), len(locs), p, ctypes.cast(kk, c_u64p), ctypes.byref(h)))
         self._h = h.value
@@ -390,9 +431,9 @@ class SpanBounds:
     def recompute(self, locs, ks):
         """The table for the next round's lists (same number of clients, same total), in place."""
         p, _k = self.engine._ptr_array(locs)
-        kk = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        kk = _u64_array(ks)
         self.engine._check(self.engine._lib.flashe_span_bounds_recompute(self.engine._h, self._h, p, ctypes.cast(kk, c_u64p)))
-        self._keep = list(locs)
+        self._keep = locs if isinstance(locs, PtrTable) else list(locs)
         return self
 
     def __del__(self):
@@ -629,8 +670,31 @@ class Engine:
         self._check(self._lib.flashe_combine_batch_dev(self._h, n, len(inps), pi, in_limbs, pa, pm, po))
 
     def _ptr_array(self, items):
+        if isinstance(items, PtrTable):
+            return items.ptr, items
         arr = (c_vp * max(len(items), 1))(*[self._ptr(x) for x in items])
         return ctypes.cast(arr, ctypes.POINTER(c_vp)), arr
+
+    def ptr_table(self, items):
+        """A list of device buffers as an argument table built once (PtrTable): accepted wherever a *_dev method takes such a list."""
+        return PtrTable(self, items)
+
+    @staticmethod
+    def u64_table(values):
+        return U64Table(values)
+
+    def _zeros_array(self, zeros):
+        """per client a sequence of L limbs (or an int) -> the flat limb array; a prebuilt ctypes array passes through"""
+        if isinstance(zeros, ctypes.Array):
+            return zeros
+        flat = []
+        for z in zeros:
+            z = [int(z) & (2 ** 64 - 1), int(z) >> 64] if isinstance(z, int) else [int(v) for v in z] + [0]
+            flat += z[:self.limbs]
+        return (c_u64 * max(len(flat), 1))(*flat)
+
+    def zeros_table(self, zeros):
+        return self._zeros_array(zeros)
 
     def aggregate_elem_dev(self, cts, n, out):
         p, _keep = self._ptr_array(cts)
@@ -712,12 +776,8 @@ class Engine:
         strictly increasing (one-pass LDS-staged form).  bounds: a SpanBounds of exactly these lists (implies sorted_lists)."""
         pl, _kl = self._ptr_array(locs)
         pv, _kv = self._ptr_array(vals)
-        k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
-        flat = []
-        for z in zeros:
-            z = [int(z) & (2 ** 64 - 1), int(z) >> 64] if isinstance(z, int) else [int(v) for v in z] + [0]
-            flat += z[:self.limbs]
-        zz = (c_u64 * max(len(flat), 1))(*flat)
+        k = _u64_array(ks)
+        zz = self._zeros_array(zeros)
         if bounds is not None:
             self._check(self._lib.flashe_sparse_aggregate_bounds_dev(self._h, total, len(locs), pl, ctypes.cast(k, c_u64p), pv,
                                                                      ctypes.cast(zz, c_u64p), bounds._h, self._ptr(out)))
@@ -733,27 +793,23 @@ class Engine:
         pp, _kp = self._ptr_array(pts)
         pc, _kc = self._ptr_array(cts)
         C = len(locs)
-        k = (c_u64 * max(C, 1))(*[int(v) for v in ks])
-        ii = (ctypes.c_uint32 * max(C, 1))(*[int(v) for v in idx])
-        flat = []
-        for z in zeros:
-            z = [int(z) & (2 ** 64 - 1), int(z) >> 64] if isinstance(z, int) else [int(v) for v in z] + [0]
-            flat += z[:self.limbs]
-        zz = (c_u64 * max(len(flat), 1))(*flat)
+        k = _u64_array(ks)
+        ii = idx if isinstance(idx, ctypes.Array) else (ctypes.c_uint32 * max(C, 1))(*[int(v) for v in idx])
+        zz = self._zeros_array(zeros)
         self._check(self._lib.flashe_sparse_encrypt_aggregate_dev(self._h, it, n_jobs, total, C, ii, pl, ctypes.cast(k, c_u64p), pp, pt_limbs,
                                                                   ctypes.cast(zz, c_u64p), bounds._h if bounds is not None else None, pc,
                                                                   self._ptr(agg)))
 
     def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out, sorted_lists=False):
         p, _keep = self._ptr_array(locs)
-        k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        k = _u64_array(ks)
         fn = self._lib.flashe_sparse_minus_mask_sorted_dev if sorted_lists else self._lib.flashe_sparse_minus_mask_dev
         self._check(fn(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, self._ptr(out)))
 
     def sparse_decrypt_dev(self, it, locs, ks, total, n_jobs, agg, out, sorted_lists=False, bounds=None):
         """out = (agg - dense minus-mask of the location lists) mod 2^b in the pass that builds the mask."""
         p, _keep = self._ptr_array(locs)
-        k = (c_u64 * max(len(ks), 1))(*[int(v) for v in ks])
+        k = _u64_array(ks)
         if bounds is not None:
             self._check(self._lib.flashe_sparse_decrypt_bounds_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, bounds._h,
                                                                    self._ptr(agg), self._ptr(out)))

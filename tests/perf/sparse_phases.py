@@ -44,11 +44,12 @@ for fused in ((1,) if os.environ.get("DECRYPT_ONLY") else (0, 1)):
 
 if os.environ.get("FLASHE_SPAN_PROBE") == "9":              # tuning build: where workgroup 0 / wave 0 of span_prf_kernel spends its cycles
     import ctypes
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 24)()
     fn = eng._lib.flashe_tune_span_prf_cycles
     fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int], ctypes.c_int
     fn(eng._h, out, 1)
     names = ["search + round 1", "rounds 2..14", "position wait + atomics", "loop exit", "barrier 1", "publish + write-out", "barrier 2", "loop head"]
-    tot = sum(out)
+    tot = sum(out[:8])
+    print("  head -> barrier 1 per wave:", [int(v) // 1710 for v in out[8:24]])
     for n, v in zip(names, out):
         print(f"  {n:28s} {v:14d} ticks  {100.0 * v / max(tot, 1):5.1f} %")
