@@ -83,8 +83,8 @@ __global__ __launch_bounds__(kStreamThreads) void quantize_batch_model_kernel(co
             uint64_t v = 0;
             if (j < Ly->size) {
                 const double draw = u[Ly->value_start + j];
-                v = Ly->x_is_f64 ? quantize_one<double>(static_cast<const double *>(Ly->x)[j], Ly->p0, Ly->p1, Ly->p2, draw)
-                                 : quantize_one<float>(static_cast<const float *>(Ly->x)[j], static_cast<float>(Ly->p0), static_cast<float>(Ly->p1),
+                v = Ly->x_is_f64 ? quantize_one<double>(*FLASHE_GLOBAL(const double, static_cast<const double *>(Ly->x) + j), Ly->p0, Ly->p1, Ly->p2, draw)
+                                 : quantize_one<float>(*FLASHE_GLOBAL(const float, static_cast<const float *>(Ly->x) + j), static_cast<float>(Ly->p0), static_cast<float>(Ly->p1),
                                                        static_cast<float>(Ly->p2), draw);
             }
             t = (field_bits >= 128 ? 0 : t << field_bits) + v;          // temp *= mod; temp += value (jzf_quantize.py:178-181)

@@ -409,9 +409,11 @@ __device__ __forceinline__ uint64_t codec_quantize(const Codec &c, uint64_t k)
         const uint64_t key = c.k0 + k;
         const CodecLayer *L = codec_layer_of(c, key);
         const uint64_t r = key - L->start;
-        return L->x_is_f64 ? quantize_one<double>(static_cast<const double *>(L->x)[r], L->p0, L->p1, L->p2, c.u[k])
-                           : quantize_one<float>(static_cast<const float *>(L->x)[r], static_cast<float>(L->p0), static_cast<float>(L->p1),
-                                                 static_cast<float>(L->p2), c.u[k]);
+        // (the layer's pointer comes out of a table in memory: said to be a global one, its loads do not count on the LDS counter
+        // the AES lookups of the same kernel wait on)
+        return L->x_is_f64 ? quantize_one<double>(*FLASHE_GLOBAL(const double, static_cast<const double *>(L->x) + r), L->p0, L->p1, L->p2, c.u[k])
+                           : quantize_one<float>(*FLASHE_GLOBAL(const float, static_cast<const float *>(L->x) + r), static_cast<float>(L->p0),
+                                                 static_cast<float>(L->p1), static_cast<float>(L->p2), c.u[k]);
     }
     return c.x_is_f64 ? quantize_one<double>(static_cast<const double *>(c.x)[k], c.alpha, c.scale, c.den, c.u[k])
                       : quantize_one<float>(static_cast<const float *>(c.x)[k], static_cast<float>(c.alpha), static_cast<float>(c.scale),
