@@ -649,20 +649,33 @@ __device__ __forceinline__ void span_open(uint32_t *start, int C, int c, uint64_
 }
 
 // start_reduce / start_fused: the table at kSpanReduce / kSpanFused positions per span (either may be null): one pass over the lists
-// serves the plain reduce and the passes with the PRF inside
+// serves the plain reduce and the passes with the PRF inside.  A thread takes kBoundsPerThread CONSECUTIVE entries: two 16-byte loads
+// (VEC: every list 16-byte aligned) and the entry in front of them, instead of two 4-byte loads per entry.
+template <bool VEC>
 __global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const ScatterTable tb, int C, uint64_t total, uint32_t *start_reduce, uint32_t *start_fused,
                                                                      uint32_t *err_flag)
 {
+    static_assert(kBoundsPerThread == 8, "two uint4 loads per thread");
     const int c = blockIdx.y;
     const uint64_t k = tb.k[c];
     const uint32_t *loc = tb.loc[c];
     const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t q0 = (static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x) * kBoundsPerThread;
+    uint32_t v[kBoundsPerThread + 1];                    // v[0] = the entry in front of this thread's, v[1 + i] = entry q0 + i
+    v[0] = q0 && q0 <= k ? loc[q0 - 1] : 0u;
+    if (VEC && q0 + kBoundsPerThread <= k) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(loc + q0), b = *reinterpret_cast<const uint4 *>(loc + q0 + 4);
+        v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w; v[5] = b.x; v[6] = b.y; v[7] = b.z; v[8] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kBoundsPerThread; i++) v[1 + i] = q0 + i < k ? loc[q0 + i] : 0u;
+    }
 #pragma unroll
     for (int i = 0; i < kBoundsPerThread; i++) {
-        const uint64_t q = (static_cast<uint64_t>(blockIdx.x) * kBoundsPerThread + i) * kStreamThreads + threadIdx.x;
+        const uint64_t q = q0 + i;
         // q == k closes the list (the spans behind the last entry); lanes beyond it open nothing
         const bool live = q <= k;
-        const uint64_t prev = live && q ? loc[q - 1] : 0, cur = live && q < k ? loc[q] : 0;
+        const uint64_t prev = live && q ? v[i] : 0, cur = live && q < k ? v[1 + i] : 0;
         if (live && q < k && (cur >= total || (q && cur <= prev))) *err_flag = 1;
         if (start_reduce) span_open<kSpanReduce>(start_reduce, C, c, q, live, k, prev, cur, total, lane);
         if (start_fused) span_open<kSpanFused>(start_fused, C, c, q, live, k, prev, cur, total, lane);
@@ -785,8 +798,13 @@ hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const
         tb.loc[c] = loc_dev[c]; tb.k[c] = k[c];
         kmax = std::max(kmax, k[c]);
     }
-    hipLaunchKernelGGL(span_bounds_kernel, dim3(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C), dim3(kStreamThreads), 0, env.stream,
-                       tb, C, total, start_reduce_dev, start_fused_dev, env.err_flag);
+    bool vec = true;
+    for (int c = 0; c < C; c++) vec = vec && (reinterpret_cast<uintptr_t>(loc_dev[c]) & 15u) == 0;
+    const dim3 grid(static_cast<unsigned>(kmax / (kStreamThreads * kBoundsPerThread) + 1), C);
+    if (vec)
+        hipLaunchKernelGGL(span_bounds_kernel<true>, grid, dim3(kStreamThreads), 0, env.stream, tb, C, total, start_reduce_dev, start_fused_dev, env.err_flag);
+    else
+        hipLaunchKernelGGL(span_bounds_kernel<false>, grid, dim3(kStreamThreads), 0, env.stream, tb, C, total, start_reduce_dev, start_fused_dev, env.err_flag);
     return hipGetLastError();
 }
 

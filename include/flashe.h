@@ -53,6 +53,7 @@ typedef struct flashe_ctx flashe_ctx;
  *      ctx-resident mask precompute (flashe_prepare_* / flashe_*_prepared[_dev] / flashe_prepared_query / _discard); flashe_span_bounds
  *      handles (+ flashe_sparse_*_bounds_dev); flashe_dynamic_masking_cost_dev; flashe_encrypt_batch_range_dev and
  *      flashe_packed_resolve_carry_strided_dev (element-sharded multi-GPU round); flashe_aggregate_elem_u32_dev; flashe_mt19937_plan;
+ *      flashe_sparse_encrypt_aggregate_dev (the clients' sparse encrypts and the aggregate of their uploads in one pass);
  *      timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only) */
 #define FLASHE_ABI_VERSION 2
 int flashe_abi_version(void);

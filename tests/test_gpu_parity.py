@@ -1691,3 +1691,32 @@ def test_sparse_encrypt_aggregate_in_one_pass(E, oracle, b, C, total, k, pt_limb
             if ks[c]:
                 assert np.array_equal(cts[c].download(np.uint64, ks[c] * L).reshape(ks[c], L), want_ct[c]), (b, C, c, with_bounds, "ciphertext")
         assert np.array_equal(agg.download(np.uint64, total * L).reshape(total, L), want), (b, C, with_bounds, "aggregate")
+
+
+def test_span_bounds_with_lists_at_any_alignment(E, oracle):
+    """The bounds pass reads 16 bytes per load when every list is 16-byte aligned and entry by entry otherwise: lists that start 4 / 8 / 12
+    bytes into a buffer give the same sparse aggregate and decrypt as aligned ones (list lengths that are not multiples of eight either way)."""
+    eng = make(E, 128)
+    rng = np.random.Generator(np.random.PCG64(11))
+    total, C = 70_001, 6
+    ks = [3_001, 17, 2_048, 0, 999, 4_097]
+    locs = [np.sort(rng.choice(total, kc, replace=False)).astype(np.uint32) for kc in ks]
+    vals = [rng.integers(0, 2 ** 63, (kc, 2), dtype=np.uint64) for kc in ks]
+    dv = [eng.upload(v) if v.size else eng.alloc(16) for v in vals]
+    outs = []
+    for shift in (0, 4, 8, 12):
+        bufs = [eng.alloc(4 * kc + 32) for kc in ks]
+        for bf, l in zip(bufs, locs):
+            if l.size:
+                bf.upload_at(shift, l)
+        dl = [bf.ptr + shift for bf in bufs]
+        agg, dec = eng.alloc_vec(total), eng.alloc_vec(total)
+        bnd = eng.span_bounds(total, dl, ks)
+        eng.sparse_aggregate_dev(total, dl, ks, dv, [5] * C, agg, bounds=bnd)
+        eng.sparse_decrypt_dev(2, dl, ks, total, 16, agg, dec, bounds=bnd)
+        outs.append((agg.download(np.uint64, 2 * total), dec.download(np.uint64, 2 * total)))
+        del bnd
+    want = oracle.sparse_minus_mask(KEY, 2, locs, total, 16, 128)
+    assert np.array_equal(outs[0][1].reshape(total, 2), oracle.combine(128, outs[0][0].reshape(total, 2), None, want))
+    for a, d in outs[1:]:
+        assert np.array_equal(a, outs[0][0]) and np.array_equal(d, outs[0][1])
