@@ -1240,6 +1240,8 @@ def bench_sparse(args, total, ops, rank, world, out):
         enc_bytes = C * k * (4 + 8 + 8 * L) + total * 8 * L          # locations + plaintexts + ciphertexts, the dense aggregate written once
         dec_bytes = C * k * 4 + 2 * total * 8 * L                     # locations, the dense aggregate read and the result written
         achieved = enc_bytes / (enc_ms * 1e-3) / 1e9
+        ratio, tsrc = traffic_ratio("span_prf_kernel")
+        dratio, _ = traffic_ratio("span_prf_kernel_decrypt")
         out.update({
             "value": world * C * k / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
             "value_separate_launches": world * C * k / (sep_ms * 1e-3), "ms_per_step_separate_launches": sep_ms,
@@ -1253,13 +1255,14 @@ def bench_sparse(args, total, ops, rank, world, out):
             "roofline": {"kernel": f"span_prf_kernel<1> ({C} clients' single-mask encrypts over compact positions + the sparse aggregate of their uploads: one "
                                    "persistent launch, one workgroup per CU, AES tables and span accumulators in the same 160 KiB of LDS)",
                          "kernel_key": "span_prf_kernel", "bound": "lds", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "algorithmic_bytes_per_launch": enc_bytes, "avg_launch_ms": enc_ms,
-                         "launches_timed": K, "aes_blocks_per_launch": prf_blocks, "aes_blocks_per_s": prf_blocks / (enc_ms * 1e-3),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": ratio * enc_bytes if ratio else None, "traffic_source": tsrc if ratio else None,
+                         "algorithmic_bytes_per_launch": enc_bytes, "avg_launch_ms": enc_ms, "launches_timed": K, "aes_blocks_per_launch": prf_blocks, "aes_blocks_per_s": prf_blocks / (enc_ms * 1e-3),
                          "note": "the round's two dominant launches are this one and its decrypt twin; one AES block per list entry, LDS-lookup / "
                                  "VALU-issue bound, `frac` is its HBM fraction as required"},
             "roofline_sparse_decrypt": {"kernel": "span_prf_kernel<0> (dense minus-mask built inside the span reduce and subtracted from the aggregate)",
                                         "bound": "lds", "achieved": dec_bytes / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                        "frac": dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": dec_bytes,
+                                        "frac": dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": dratio * dec_bytes if dratio else None,
+                                        "algorithmic_bytes_per_launch": dec_bytes,
                                         "avg_launch_ms": dec_ms, "aes_blocks_per_s": prf_blocks / (dec_ms * 1e-3)},
             "span_bounds": "computed once per round (both span sizes in one pass), shared by the two passes" if bounds is not None else "computed by each pass",
             "phases_ms": {"span_bounds": float(ph[:, 0].mean()), "encrypt_xC_plus_sparse_aggregate": enc_ms, "minus_mask_plus_decrypt": dec_ms},

@@ -9,6 +9,9 @@
   masking  flashe_dynamic_masking_cost_dev  (positions shared by consecutive clients)
   strided  flashe_packed_resolve_carry_strided_dev (carry-in from triples walked backwards)
   rdptrs   flashe_aggregate_decrypt_range_dev at b > 64 on operands in separate allocations (the pointer-table one-launch form)
+  spenc    flashe_sparse_encrypt_aggregate_dev (the span reduce with the PRF inside): ragged and CLUSTERED lists (spans with thousands of
+           entries next to empty ones), any client indices, one- and two-limb plaintexts, bounds handle or none, argument tables built once,
+           followed by the sparse decrypt of the result
 usage: fuzz_round4.py [cases per family] [seed] [families, comma separated]"""
 import os
 import sys
@@ -277,7 +280,65 @@ def fuzz_rdptrs(rng, case):
     return f"b={b} C={C} n={n} [{first}, +{count}) add={add} minus={minus} keep={keep}"
 
 
-FAMILIES = {"rdptrs": fuzz_rdptrs, "range": fuzz_range, "model": fuzz_model, "prepared": fuzz_prepared, "agg32": fuzz_agg32, "bounds": fuzz_bounds, "masking": fuzz_masking,
+def fuzz_spenc(rng, case):
+    b = int(rng.choice([128, 128, 100, 65, 64, 23]))
+    lim = L(b)
+    total = int(rng.choice([1_751, 1_753, 4_096, 50_000, 300_001, 1_500_000]))
+    C = int(rng.choice([1, 2, 7, 50, 64, 65, 80]))
+    pt_limbs = int(rng.choice([1, lim]))
+    it, n_jobs = int(rng.integers(0, 1000)), int(rng.choice([1, 16]))
+    ks, locs = [], []
+    for c in range(C):
+        style = rng.integers(0, 4)
+        if style == 0:                                     # uniform
+            kc = int(min(total, rng.choice([0, 1, 40, 500, 4000])))
+            l = np.sort(rng.choice(total, kc, replace=False))
+        elif style == 1:                                   # one dense cluster (a layer whose values all made the cut)
+            kc = int(min(total, rng.choice([300, 3000, 20_000])))
+            a = int(rng.integers(0, total - kc + 1))
+            l = np.arange(a, a + kc)
+        elif style == 2:                                   # a cluster plus a sparse tail
+            kc1 = int(min(total // 2, rng.choice([100, 2500])))
+            a = int(rng.integers(0, total // 2 - kc1 + 1))
+            tail = np.sort(rng.choice(np.arange(total // 2, total), int(min(total - total // 2, rng.choice([0, 10, 700]))), replace=False))
+            l = np.concatenate([np.arange(a, a + kc1), tail])
+        else:                                              # every position
+            l = np.arange(total) if total <= 60_000 else np.sort(rng.choice(total, 1000, replace=False))
+        locs.append(l.astype(np.uint32)); ks.append(int(l.size))
+    idx = [int(v) for v in rng.integers(0, 2 ** 20, C)]
+    top = 2 ** 63 if b >= 64 else 2 ** (b - 1)
+    pts = [rng.integers(0, top, (kc, pt_limbs), dtype=np.uint64) for kc in ks]
+    if lim == 2 and pt_limbs == 2 and b < 128:
+        for p_ in pts:
+            p_[:, 1] &= np.uint64((1 << (b - 64)) - 1)
+    zeros = [int(rng.integers(0, 2 ** min(b - 2, 31))) for _ in range(C)]
+    eng = E.Engine(KEY, b, device=0)
+    dl = [eng.upload(l) if l.size else eng.alloc(16) for l in locs]
+    dp = [eng.upload(p_) if p_.size else eng.alloc(16) for p_ in pts]
+    cts = [eng.alloc_vec(max(kc, 1)) for kc in ks]
+    agg, dec = eng.alloc_vec(total), eng.alloc_vec(total)
+    use_tables, use_bounds = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    a_loc, a_k, a_pt, a_ct = (eng.ptr_table(dl), eng.u64_table(ks), eng.ptr_table(dp), eng.ptr_table(cts)) if use_tables else (dl, ks, dp, cts)
+    bnd = eng.span_bounds(total, a_loc, a_k) if use_bounds else None
+    eng.sparse_encrypt_aggregate_dev(it, idx, a_loc, a_k, a_pt, pt_limbs, eng.zeros_table(zeros) if use_tables else zeros, total, n_jobs, a_ct, agg, bounds=bnd)
+    want = np.zeros((total, lim), dtype=np.uint64)
+    for c in range(C):
+        wc = orc.encrypt(KEY, it, idx[c], "single", n_jobs, b, pts[c]) if ks[c] else np.zeros((0, lim), dtype=np.uint64)
+        if ks[c]:
+            assert np.array_equal(cts[c].download(np.uint64, ks[c] * lim).reshape(ks[c], lim), wc), ("spenc/ct", case, b, total, C, c)
+        z = np.array([[zeros[c]] + [0] * (lim - 1)], dtype=np.uint64)
+        want = orc.aggregate_elem([want, orc.expand_to_dense(total, locs[c], wc, z, b)], b)
+    got = agg.download(np.uint64, total * lim).reshape(total, lim)
+    assert np.array_equal(got, want), ("spenc/agg", case, b, total, C, ks[:6])
+    if lim == 2 and len(set(idx)) == C:
+        # the decrypt twin on the same lists (client c's prefix is c there: the minus-mask of lists 0 .. C-1)
+        eng.sparse_decrypt_dev(it, a_loc, a_k, total, n_jobs, agg, dec, sorted_lists=True, bounds=bnd)
+        mask = orc.sparse_minus_mask(KEY, it, locs, total, n_jobs, b)
+        assert np.array_equal(dec.download(np.uint64, 2 * total).reshape(total, 2), orc.combine(b, got, None, mask)), ("spenc/dec", case, b, total, C)
+    return f"b={b} total={total} C={C} pt_limbs={pt_limbs} tables={use_tables} bounds={use_bounds} k={ks[:5]}"
+
+
+FAMILIES = {"spenc": fuzz_spenc, "rdptrs": fuzz_rdptrs, "range": fuzz_range, "model": fuzz_model, "prepared": fuzz_prepared, "agg32": fuzz_agg32, "bounds": fuzz_bounds, "masking": fuzz_masking,
             "strided": fuzz_strided}
 
 

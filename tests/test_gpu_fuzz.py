@@ -37,5 +37,6 @@ def test_fuzz_round3_entry_points():
 def test_fuzz_round4_entry_points():
     """The round-4 entry points on random shapes against the oracle: every client's encrypt on an element slice (+ the slice of the sum),
     the fused codec over a flattened model with a random layer table, the ctx-resident precompute with dropouts, the uint32 reduce, the
-    span-bounds handle, dynamic_masking's cost on the device, the backward carry walk of the element-sharded packed reduce."""
-    assert "FUZZ_R4_OK 64 cases" in _run("fuzz_round4.py", 8, 105)
+    span-bounds handle, dynamic_masking's cost on the device, the backward carry walk of the element-sharded packed reduce, the clients'
+    sparse encrypts + the aggregate of their uploads in one pass (ragged and clustered lists)."""
+    assert "FUZZ_R4_OK 72 cases" in _run("fuzz_round4.py", 8, 105)

@@ -91,6 +91,8 @@ def main(tag):
         short = k.replace("void ", "").replace("flashe::", "").split("<")[0].split("(")[0]
         if short == "prf_chain_kernel" and "prf_chain_kernel<1024, true" in k:
             short = "prf_chain_kernel_sum"          # the instantiation that also writes the local partial aggregate
+        if short == "span_prf_kernel" and "span_prf_kernel<0>" in k:
+            short = "span_prf_kernel_decrypt"       # (the ENC instantiations -- encrypts + aggregate -- keep the plain key)
         ent = {"full_name": k, "hbm_bytes_per_launch": e["hbm_bytes_per_launch_avg"], "fetch_kib_avg": e["FETCH_SIZE"]["avg"],
                "write_kib_avg": e["WRITE_SIZE"]["avg"], "launches": e["FETCH_SIZE"]["launches"]}
         if dom_name and short == dom_name and alg:
@@ -132,6 +134,8 @@ def main(tag):
                 return "prf_chain_kernel<1024, true" in k
             if dom_name == "prf_chain_kernel":
                 return "prf_chain_kernel<1024, false" in k
+            if dom_name == "span_prf_kernel":
+                return "span_prf_kernel<1>" in k or "span_prf_kernel<2>" in k
             return dom_name in k
         d_all = [v for k, vs in dur.items() if is_dom(k) for v in vs]
         if steps and len(d_all) >= steps:
