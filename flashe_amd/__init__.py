@@ -7,6 +7,6 @@ reference's `FlasheCipher` API.  See DESIGN.md / INTEGRATION.md.
 """
 from .cipher import FlasheCipher, aggregate          # noqa: F401
 from .engine import Engine, DeviceBuffer, DeviceVector, FlasheError  # noqa: F401
-from .block import FlasheClient, dynamic_masking_choice  # noqa: F401
+from .block import FlasheClient, aggregate_sparse_uploads, dynamic_masking_choice  # noqa: F401
 
-__all__ = ["FlasheCipher", "aggregate", "Engine", "DeviceBuffer", "DeviceVector", "FlasheError", "FlasheClient", "dynamic_masking_choice"]
+__all__ = ["FlasheCipher", "aggregate", "Engine", "DeviceBuffer", "DeviceVector", "FlasheError", "FlasheClient", "aggregate_sparse_uploads", "dynamic_masking_choice"]

@@ -161,6 +161,7 @@ _SIGNATURES = {
     "flashe_quantize_encrypt_model_dev": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32, c_u64, c_u64, ctypes.POINTER(CodecLayer), c_int, c_int, c_vp, c_vp]),
     "flashe_decrypt_unquantize_model_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_vp,
                                                     ctypes.POINTER(CodecLayer), c_int, c_int, c_int, c_vp]),
+    "flashe_unquantize_model_dev": (c_int, [c_vp, c_u64, c_u64, c_u64, c_vp, ctypes.POINTER(CodecLayer), c_int, c_int, c_int, c_vp]),
     "flashe_shift_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.c_double, c_int]),
     "flashe_mean_std_dev": (c_int, [c_vp, c_u64, c_vp, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "flashe_mt19937_random_dev": (c_int, [c_vp, c_u32p, c_u32p, c_u64, c_vp]),

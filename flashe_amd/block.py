@@ -43,6 +43,50 @@ def dynamic_masking_choice(masks, total, engine=None):
     return "single" if single_cost <= double_cost else "double"
 
 
+def aggregate_sparse_uploads(engine, uploads, locations, total, device=True):
+    """The arbiter's side of a sparse round on the device: what `Arbiter.expand_to_dense` (jzf_aggregator.py:150-165: a dense vector filled
+    with the upload's LAST element -- the un-encrypted quantised zero -- and the other elements at the client's locations) followed by the
+    reduce over the clients (`:419-430`) computes, in one pass without the C dense intermediates (flashe_sparse_aggregate_dev; strictly
+    increasing location lists take the LDS-staged form).
+      uploads   per client: a DeviceVector of k + 1 elements as FlasheClient.quantize_encrypt leaves it (it stays where it is), uint64 limbs
+                [k + 1, L] or object ints [k + 1]
+      locations per client: k sorted positions (host integers, or a device buffer of uint32)
+    Returns the dense aggregate of `total` elements: a DeviceVector (device=True) or uint64 limbs [total, L]."""
+    from .engine import DeviceBuffer, DeviceVector
+    lim = engine.limbs
+    vals, zeros, ks, locs, sorted_all = [], [], [], [], True
+    for up, loc in zip(uploads, locations):
+        if isinstance(up, DeviceVector):
+            dv = up.widened(engine) if up.compact else up
+            k = len(dv) - 1
+            dv.wait_on(engine)
+            z = dv.buf.download(np.uint64, (k + 1) * lim)[k * lim:]
+            vals.append(dv.buf)
+        else:
+            a = np.asarray(up)
+            if a.dtype == object:
+                flat = a.reshape(-1)
+                a = np.stack([(flat & (2 ** 64 - 1)).astype(np.uint64)] + ([((flat >> 64) & (2 ** 64 - 1)).astype(np.uint64)] if lim == 2 else []), axis=1)
+            a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, lim)
+            k = a.shape[0] - 1
+            z = a[k]
+            vals.append(engine.upload(a[:k]) if k else engine.alloc(16))
+        zeros.append([int(v) for v in z])
+        ks.append(k)
+        if isinstance(loc, DeviceBuffer):
+            locs.append(loc)
+        else:
+            la = np.asarray(loc, dtype=np.int64).reshape(-1)
+            if la.size != k:
+                raise ValueError(f"{la.size} locations for an upload of {k} values")
+            sorted_all = sorted_all and bool(np.all(la[1:] > la[:-1]))
+            locs.append(engine.upload(la.astype(np.uint32)) if k else engine.alloc(16))
+    out = DeviceVector(engine, int(total))
+    if total:
+        engine.sparse_aggregate_dev(int(total), locs, ks, vals, zeros, out.buf, sorted_lists=sorted_all)
+    return out.mark_ready() if device else out.to_host()
+
+
 class FlasheClient(object):
     """`jzf_flashe_block._Client` without the transport: holds a FlasheCipher and forwards to it with the
     reference's method names, so `JZFWeights.encrypted(cipher)` / `.decrypted(cipher)`
@@ -156,8 +200,14 @@ class FlasheClient(object):
     # ---- the client step with nothing on the host in between (new) ------------------------------------------------------------
     def _fusable(self, weights=None):
         c = self.cipher
-        return (self.fuse and c.masks is None and c.prp_seed is not None and not c.next_iter_encrypt_prepared
-                and hasattr(c.engine, "quantize_encrypt_model_dev") and (weights is None or "zzz" not in weights._weights))
+        if not (self.fuse and c.prp_seed is not None and not c.next_iter_encrypt_prepared and hasattr(c.engine, "quantize_encrypt_model_dev")):
+            return False
+        if weights is None or "zzz" not in weights._weights:
+            return c.masks is None
+        # the sparse job: compact layers + the sparsifier's trailing one-value layer (the masks a previous round's decrypt left in the
+        # cipher do not touch the encrypt)
+        order = list(weights.walking_order)
+        return not self.batch and len(order) > 1 and order[-1] == "zzz" and np.size(weights._weights["zzz"]) == 1
 
     def quantize_encrypt(self, weights, device=True):
         """What Client.secure_aggregate does between "begin encoding" and "end encryption" (jzf_aggregator.py:721-743):
@@ -172,8 +222,11 @@ class FlasheClient(object):
         DeviceVector (device=True: it stays in HBM for `aggregate`) or uint64 limbs [n, L]; `self.shape_dict` keeps the shapes for
         `decrypt_unquantize`.  BATCHED jobs ("batch": true, several quantised values per ciphertext element, every layer padded to whole
         elements on its own: jzf_quantize.py:436-451, :162-185) are two launches: quantise + batch of the whole model
-        (flashe_quantize_batch_model_dev), then the encrypt of the flattened batched vector.  Sparse jobs (masks, the 'zzz' layer) and
-        precomputed encrypt masks take the same sequence call by call on the host and return object arrays like the reference."""
+        (flashe_quantize_batch_model_dev), then the encrypt of the flattened batched vector.  The SPARSE job (compact layers from
+        `Client.sparsify` plus the one-value 'zzz' layer, jzf_aggregator.py:717-743) is the same one launch over the compact layers; the
+        'zzz' value is quantised on the host with the draw that follows theirs (alpha 1.0, jzf_quantize.py:433-435) and appended
+        UN-encrypted: the result holds n + 1 elements.  Batched sparse jobs and precomputed encrypt masks take the same sequence call by
+        call on the host and return object arrays like the reference."""
         from . import cipher as _cipher_mod
         from .engine import DeviceVector
         from .quantize import ACIQ, DEVICE_RNG_MIN, _loop_dtype
@@ -200,6 +253,10 @@ class FlasheClient(object):
         c.set_idx_list(mode="encrypt")
         scheme = 1 if c.masking_scheme == "double" else 0
         order = list(weights.walking_order)
+        zzz = None
+        if "zzz" in weights._weights:                       # (_fusable: it closes the walking order)
+            zzz = np.asarray(weights._weights["zzz"])
+            order = order[:-1]
         host, starts, offs, shape_dict = [], [], [], {}
         n, nbytes = 0, 0
         for li, k in enumerate(order):
@@ -246,7 +303,7 @@ class FlasheClient(object):
             weights.walking_order = sorted(weights._weights.keys(), key=str)
             return weights
         table = [(starts[li], xbuf.ptr + offs[li], q.alpha_list[li], host[li].dtype == np.float64) for li in range(len(order))]
-        ct = DeviceVector(eng, n)
+        ct = DeviceVector(eng, n + (1 if zzz is not None else 0))
         # the draws of consecutive layers are ONE stretch of NumPy's stream (np.random.random(layer.shape) per layer in walking order,
         # jzf_quantize.py:55-67 under :417-462), i.e. flat element j takes draw j: a run of whole layers is drawn by one device call and
         # quantised + encrypted by one launch over its range.  Runs are capped so the draws of a huge model stay bounded.
@@ -262,6 +319,16 @@ class FlasheClient(object):
                 eng.quantize_encrypt_model_dev(c.iter_index, c.idx, scheme, n, _cipher_mod.N_JOBS, first, tot, table, q.element_bits, du,
                                                ct.ptr + first * eng.limbs * 8)
             at = end
+        if zzz is not None:
+            # the trailing layer: the next draw of the stream, alpha 1.0, not encrypted (:735-743 strips it before and re-appends it after)
+            from .quantize import _as_object, _static_quantize_padding_asymmetric
+            flat = zzz.flatten()
+            want = _loop_dtype(flat.dtype, 1.0)
+            if flat.dtype != want:
+                flat = flat.astype(want)
+            zq = int(_as_object(_static_quantize_padding_asymmetric(flat, 1.0, q.element_bits, device=q._device, as_object=False)).reshape(-1)[0])
+            ct.buf.upload_at(n * eng.limbs * 8, np.array([zq & (2 ** 64 - 1), zq >> 64][:eng.limbs], dtype=np.uint64))
+            del weights._weights["zzz"]
         for k in order:
             del weights._weights[k]
         self.shape_dict = shape_dict
@@ -275,16 +342,43 @@ class FlasheClient(object):
         (jzf_weights.py:334-335 -> _Client.decrypt) of the ONE flattened aggregate, `unflatten_weights` by `self.shape_dict`, then
         QuantizingClient.unquantize layer by layer (jzf_quantize.py:493-540) -- as ONE launch (flashe_decrypt_unquantize_model_dev): the
         aggregate -- a DeviceVector, uint64 limbs or object ints -- is decrypted with the prefixes `set_idx_list` left behind and comes
-        back as unquantised float64 layers.  Precomputed decrypt masks, sparse masks and batched values take the same sequence call by
-        call (the sparse job sets `self.shape_dict = shape_dict_used_for_sparsification` first, :893-894)."""
+        back as unquantised float64 layers.  The SPARSE job (location lists in `cipher.masks`; it sets `self.shape_dict =
+        shape_dict_used_for_sparsification` first, :893-894) decrypts on the device with the sparse minus-mask pass and unquantises the
+        dense result in a second launch (flashe_unquantize_model_dev).  Precomputed decrypt masks take the same sequence call by call."""
         from . import cipher as _cipher_mod
         from .engine import DeviceVector
         q, c = self.quantizer, self.cipher
         fus = (self.fuse and c.masks is None and c.prp_seed is not None and not c.next_iter_decrypt_prepared
                and hasattr(c.engine, "decrypt_unquantize_model_dev"))
         k0 = weights.walking_order[0]
+        from .cipher import _SparseMinus
+        prep = c.next_iter_decrypt_prepared
+        sparse_dev = (self.fuse and c.masks is not None and c.masking_scheme == "single" and not self.batch and c.prp_seed is not None
+                      and set(prep) == {"minus"} and isinstance(prep["minus"], _SparseMinus) and hasattr(c.engine, "unquantize_model_dev"))
+        if sparse_dev:
+            eng = c.engine
+            dec = self.cipher.decrypt(weights._weights[k0], device=True)                 # the sparse minus-mask pass, result in HBM
+            dec = c._as_wide(dec)
+            n = len(dec)
+            sizes = [int(np.prod(shape)) for shape in self.shape_dict.values()]
+            if sum(sizes) > n:
+                raise ValueError(f"the aggregate has {n} elements, shape_dict describes {sum(sizes)}")
+            table, at = [], 0
+            for li, size in enumerate(sizes):
+                table.append((at, None, q.alpha_list[li], False))
+                at += size
+            dout = eng.alloc(max(8 * n, 16))
+            if n:
+                dec.wait_on(eng)
+                eng.unquantize_model_dev(n, 0, n, dec.buf, table, q.element_bits, q.num_clients, dout)
+            weights._weights[k0] = dout.download(np.float64, n)
+            return self.unflatten_weights(weights)
         if not fus:
-            weights._weights[k0] = self.cipher.decrypt(weights._weights[k0], device=False)
+            res = self.cipher.decrypt(weights._weights[k0], device=False)
+            if isinstance(res, np.ndarray) and res.dtype == np.uint64 and res.ndim == 2:
+                from .cipher import _from_limbs
+                res = _from_limbs(res, "object")          # (limbs in, limbs out: the layer-by-layer sequence works on the reference's object ints)
+            weights._weights[k0] = res
             return self.unquantize(self.unflatten_weights(weights))
         eng = c.engine
         if c.masking_scheme == "double":

@@ -147,6 +147,36 @@ class _DevVec:
         return self.buf.download(np.uint64, self.n * eng.limbs).reshape(self.n, eng.limbs)
 
 
+class _SparseMinus:
+    """The single-mask sparse branch of set_idx_list (jzf_flashe.py:316-343) as a promise: the clients' location lists are on the
+    device, the dense minus-mask itself is not built unless somebody asks for it (`buf` / `to_host`).  The decrypt that follows
+    subtracts the mask from the aggregate in the pass that computes it (flashe_sparse_decrypt_dev: one read and one write of the dense
+    vector instead of building 16 B x total, reading it back and combining)."""
+
+    def __init__(self, eng, it, dloc, ks, total, sorted_lists):
+        self.eng, self.it, self.dloc, self.ks, self.n, self.sorted_lists = eng, it, dloc, ks, total, sorted_lists
+        self._vec = None
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def buf(self):
+        if self._vec is None:
+            self._vec = _DevVec(self.eng, self.n)
+            self.eng.sparse_minus_mask_dev(self.it, self.dloc, self.ks, self.n, N_JOBS, self._vec.buf, sorted_lists=self.sorted_lists)
+            self.eng.sync()
+        return self._vec.buf
+
+    @property
+    def materialized(self):
+        return self._vec is not None
+
+    def to_host(self, eng):
+        _ = self.buf
+        return self._vec.to_host(eng)
+
+
 class _CtxMask:
     """A precomputed mask held INSIDE the engine's ctx (flashe_prepare_encrypt / flashe_prepare_decrypt): the entry the reference keeps
     in next_iter_encrypt_prepared / next_iter_decrypt_prepared, as a handle.  The C ABI owns the vector and the consume-once rule; this
@@ -259,11 +289,9 @@ class FlasheCipher(object):
                 for c, l in enumerate(locs):
                     if len(l) and int(l.max()) >= self.total:
                         raise IndexError(f"index {int(l.max())} is out of bounds for axis 0 with size {self.total}")
-                dloc = [eng.upload(l) for l in locs]
-                vec = _DevVec(eng, self.total)
-                eng.sparse_minus_mask_dev(self.iter_index, dloc, [len(l) for l in locs], self.total, N_JOBS, vec.buf)
-                eng.sync()
-                self.next_iter_decrypt_prepared["minus"] = vec
+                dloc = [eng.upload(l) if len(l) else eng.alloc(16) for l in locs]
+                strictly_up = all(len(l) < 2 or bool(np.all(l[1:] > l[:-1])) for l in locs)        # (what Client.sparsify emits)
+                self.next_iter_decrypt_prepared["minus"] = _SparseMinus(eng, self.iter_index, dloc, [len(l) for l in locs], self.total, strictly_up)
 
     def set_idx_list(self, raw_idx_list=None, mode="encrypt"):          # jzf_flashe.py:345-426
         if self.masking_scheme == "single":
@@ -464,7 +492,10 @@ class FlasheCipher(object):
             else:
                 minus = self.next_iter_decrypt_prepared['minus']
                 self._check_prepared_len(minus, n)
-                eng.combine_dev(n, dv.buf, eng.limbs, None, minus.buf, out.buf)
+                if isinstance(minus, _SparseMinus) and not minus.materialized and minus.it == self.iter_index:
+                    eng.sparse_decrypt_dev(minus.it, minus.dloc, minus.ks, n, N_JOBS, dv.buf, out.buf, sorted_lists=minus.sorted_lists)
+                else:
+                    eng.combine_dev(n, dv.buf, eng.limbs, None, minus.buf, out.buf)
             if was_compact and self._compact_ok():
                 out = out.mark_ready().narrowed(eng)
             res = self._deliver(out, kind, want_dev)

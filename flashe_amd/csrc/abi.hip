@@ -1126,6 +1126,28 @@ int flashe_decrypt_unquantize_model_dev(flashe_ctx *ctx, uint32_t iter, const ui
     return FLASHE_OK;
 }
 
+// unflatten_weights + QuantizingClient.unquantize (jzf_aggregator.py:652-671, jzf_quantize.py:493-540) of a flattened vector that is
+// already decrypted -- the sparse job's way back, whose decrypt is the sparse minus-mask pass, not a prefix list
+int flashe_unquantize_model_dev(flashe_ctx *ctx, uint64_t n, uint64_t first, uint64_t count, const uint64_t *in_dev,
+                                const flashe_codec_layer *layers, int n_layers, int element_bits, int num_clients, double *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (count && (!in_dev || !out_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
+    if (num_clients < 1) return fail(ctx, FLASHE_EINVAL, "num_clients must be >= 1");
+    int rc = check_codec_bits(ctx, element_bits);
+    if (rc || (rc = check_range(ctx, n, first, count))) return rc;
+    if ((ctx->limbs == 2 && !aligned16(in_dev)) || (reinterpret_cast<uintptr_t>(in_dev) & 7u) || (reinterpret_cast<uintptr_t>(out_dev) & 7u))
+        return fail(ctx, FLASHE_EINVAL, "misaligned vector");
+    const CodecLayer *tab = nullptr;
+    int n_tab = 0;
+    rc = stage_codec_layers(ctx, n, layers, n_layers, false, element_bits, num_clients, first, count, &tab, &n_tab);
+    if (rc || count == 0) return rc;
+    Codec cq{};
+    cq.fout = out_dev; cq.layers = tab; cq.n_layers = n_tab; cq.k0 = first;
+    HIP_TRY(ctx, launch_unquantize_model(ctx->env, count, in_dev, cq, out_dev));
+    return FLASHE_OK;
+}
+
 // ---- the BATCHED codec over a flattened model (the paper's main job configuration, "batch": true) ----
 static int stage_batch_layers(flashe_ctx *ctx, const flashe_batch_layer *layers, int n_layers, bool front, int element_bits, int field_bits,
                               int num_clients, uint64_t *n_elems, uint64_t *n_values, const BatchLayer **tab_dev, int *n_tab)

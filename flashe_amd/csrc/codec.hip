@@ -243,6 +243,24 @@ hipError_t launch_quantize(const LaunchEnv &env, uint64_t n, const void *x_dev, 
     return hipGetLastError();
 }
 
+// the back end of a flattened model alone (the values are already plaintext sums, e.g. after the sparse decrypt): element k of
+// [first, first + count) comes back as float64 with its layer's parameters
+__global__ __launch_bounds__(kStreamThreads) void unquantize_model_kernel(uint64_t count, const uint64_t *v, int v_limbs, const Codec cq, double *out)
+{
+    for (uint64_t k = static_cast<uint64_t>(blockIdx.x) * kStreamThreads + threadIdx.x; k < count; k += static_cast<uint64_t>(gridDim.x) * kStreamThreads) {
+        const u128 x = v_limbs == 2 ? ld128_nt(v + 2 * k) : static_cast<u128>(__builtin_nontemporal_load(v + k));
+        __builtin_nontemporal_store(codec_unquantize(cq, k, x), out + k);
+    }
+}
+
+hipError_t launch_unquantize_model(const LaunchEnv &env, uint64_t count, const uint64_t *v_dev, const Codec &cq, double *out_dev)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(unquantize_model_kernel, dim3(stream_grid(env, count)), dim3(kStreamThreads), 0, env.stream, count, v_dev, env.b > 64 ? 2 : 1, cq,
+                       out_dev);
+    return hipGetLastError();
+}
+
 hipError_t launch_unquantize(const LaunchEnv &env, uint64_t n, const uint64_t *v_dev, int v_limbs, double alpha, int bits,
                              int num_clients, double *out_dev)
 {

@@ -231,6 +231,8 @@ int moments_grid(const LaunchEnv &env, uint64_t n);
 hipError_t launch_moment(const LaunchEnv &env, uint64_t n, const void *x_dev, bool is_f64, double center, int pow, double *part_dev);
 hipError_t launch_quantize(const LaunchEnv &env, uint64_t n, const void *x_dev, bool is_f64, double alpha, int bits,
                            const double *u_dev, uint64_t *q_dev);
+// the codec back end over a flattened model without a PRF stream: out[k] = unquantise(v[k]) with the layer table of cq (k0 = first element)
+hipError_t launch_unquantize_model(const LaunchEnv &env, uint64_t count, const uint64_t *v_dev, const Codec &cq, double *out_dev);
 hipError_t launch_unquantize(const LaunchEnv &env, uint64_t n, const uint64_t *v_dev, int v_limbs, double alpha, int bits,
                              int num_clients, double *out_dev);
 hipError_t launch_batch(const LaunchEnv &env, uint64_t n, const uint64_t *vals_dev, int field_bits, uint64_t *out_dev);

@@ -514,6 +514,10 @@ class Engine:
     def sync(self):
         self._check(self._lib.flashe_sync(self._h))
 
+    def memset_dev(self, buf, byte, nbytes):
+        """Fills the first nbytes of a device buffer with `byte` (asynchronous on the ctx stream)."""
+        self._check(self._lib.flashe_memset_dev(self._h, self._ptr(buf), int(byte), int(nbytes)))
+
     # -- HIP graph capture / replay of a sequence of *_dev calls ---------------------------------
     def graph_begin(self):
         self._check(self._lib.flashe_graph_begin(self._h))
@@ -1010,6 +1014,11 @@ class Engine:
         arr, nl = self._codec_layers(layers)
         self._check(self._lib.flashe_decrypt_unquantize_model_dev(self._h, it, pa, len(add_idx), pm, len(minus_idx), n, n_jobs, first, count,
                                                                   self._ptr(inp), arr, nl, element_bits, num_clients, self._ptr(out)))
+
+    def unquantize_model_dev(self, n, first, count, inp, layers, element_bits, num_clients, out):
+        """The codec back end alone over elements [first, first + count) of a flattened, already decrypted vector (the sparse job's way back)."""
+        arr, nl = self._codec_layers(layers)
+        self._check(self._lib.flashe_unquantize_model_dev(self._h, n, first, count, self._ptr(inp), arr, nl, element_bits, num_clients, self._ptr(out)))
 
     @staticmethod
     def _batch_layers(layers):

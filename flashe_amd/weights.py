@@ -159,9 +159,15 @@ class Sparsifier(object):
             dev = self._remain_dev
             if dev is None or dev[1] != order or dev[2] != sizes or dev[3] != dt:
                 host = self.remain_weights or {}            # (downloads what a differently shaped earlier round left on the device)
-                flat = np.concatenate([np.ascontiguousarray(host[k], dtype=dt).reshape(-1) if host.get(k) is not None else np.zeros(n, dtype=dt)
-                                       for k, n in zip(order, sizes)]) if sizes else np.zeros(0, dtype=dt)
-                dev = (eng.upload(flat) if flat.size else eng.alloc(16), order, sizes, dt)
+                if not any(host.get(k) is not None for k in order):
+                    # the first round: no residual yet -- zeroed where it will live, not 4 or 8 bytes per value of zeros over PCIe
+                    buf = eng.alloc(max(sum(sizes) * np.dtype(dt).itemsize, 16))
+                    eng.memset_dev(buf, 0, buf.nbytes)
+                    dev = (buf, order, sizes, dt)
+                else:
+                    flat = np.concatenate([np.ascontiguousarray(host[k], dtype=dt).reshape(-1) if host.get(k) is not None else np.zeros(n, dtype=dt)
+                                           for k, n in zip(order, sizes)]) if sizes else np.zeros(0, dtype=dt)
+                    dev = (eng.upload(flat) if flat.size else eng.alloc(16), order, sizes, dt)
             results = eng.sparsify_model(layers, ks, dev[0], dt)
             self._remain_dev, self._remain_host = dev, None
         else:

@@ -54,6 +54,7 @@ typedef struct flashe_ctx flashe_ctx;
  *      handles (+ flashe_sparse_*_bounds_dev); flashe_dynamic_masking_cost_dev; flashe_encrypt_batch_range_dev and
  *      flashe_packed_resolve_carry_strided_dev (element-sharded multi-GPU round); flashe_aggregate_elem_u32_dev; flashe_mt19937_plan;
  *      flashe_sparse_encrypt_aggregate_dev (the clients' sparse encrypts and the aggregate of their uploads in one pass);
+ *      flashe_unquantize_model_dev (the model-wide codec back end without a decrypt: the sparse job's way back);
  *      timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only) */
 #define FLASHE_ABI_VERSION 2
 int flashe_abi_version(void);
@@ -501,6 +502,10 @@ int flashe_decrypt_unquantize_model_dev(flashe_ctx *ctx, uint32_t iter, const ui
                                         const uint32_t *minus_idx, int n_minus, uint64_t n, uint32_t n_jobs, uint64_t first,
                                         uint64_t count, const uint64_t *in_dev, const flashe_codec_layer *layers, int n_layers,
                                         int element_bits, int num_clients, double *out_dev);
+/* The same back end WITHOUT a decrypt (new): in_dev holds plaintext sums already -- the sparse job's way back, whose decrypt is the
+ * sparse minus-mask pass (flashe_sparse_decrypt_dev), not a prefix list; element first + k of the flattened model -> out_dev[k]. */
+int flashe_unquantize_model_dev(flashe_ctx *ctx, uint64_t n, uint64_t first, uint64_t count, const uint64_t *in_dev,
+                                const flashe_codec_layer *layers, int n_layers, int element_bits, int num_clients, double *out_dev);
 /* The BATCHED form of the same job (the paper's main configuration, "batch": true): QuantizingClient.quantize packs
  * batch_size = int_bits / field_bits quantised values (field_bits = element_bits + ceil(log2(num_clients))) into every ciphertext element,
  * first value most significant, EVERY LAYER padded with zeros to whole elements on its own (_static_batching_padding_asymmetric,

@@ -122,8 +122,12 @@ class OracleEngine:
     def aggregate_packed_dev(self, packed, n_limbs, total_bits, out):
         out.arr = orc.aggregate_packed([p.arr[:n_limbs] for p in packed], total_bits)
 
-    def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out):
-        out.arr = orc.sparse_minus_mask(self.key, it, [l.arr for l in locs], total, n_jobs, self.int_bits)
+    def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out, sorted_lists=False):
+        out.arr = orc.sparse_minus_mask(self.key, it, [np.asarray(l.arr)[:k] for l, k in zip(locs, ks)], total, n_jobs, self.int_bits)
+
+    def sparse_decrypt_dev(self, it, locs, ks, total, n_jobs, agg, out, sorted_lists=False, bounds=None):
+        mask = orc.sparse_minus_mask(self.key, it, [np.asarray(l.arr)[:k] for l, k in zip(locs, ks)], total, n_jobs, self.int_bits)
+        out.arr = orc.combine(self.int_bits, np.asarray(agg.arr).reshape(total, -1), None, mask)
 
     def sparse_double_masks_dev(self, it, locs, ks, total, add_out, minus_out):
         # the reference's own formulation: one-hot vectors, run analysis (jzf_flashe.py:388-407), dense-position masks

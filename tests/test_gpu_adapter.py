@@ -360,18 +360,23 @@ def test_client_step_is_the_reference_jobs(case_i, mode):
         assert np.asarray(back._weights[nm], dtype=np.float64).tobytes() == bytes.fromhex(case["out_elem"]["unquantized"][nm])
 
 
+@pytest.mark.parametrize("mode", ["fused-handles", "fused-host", "call-by-call"])
 @pytest.mark.parametrize("case_i", range(2))
-def test_client_step_of_the_sparse_job(case_i):
+def test_client_step_of_the_sparse_job(case_i, mode):
     """The sparse job's client step against the fixture recorded from the reference (jzf_aggregator.py:717-743, :881-899): compact layers
     plus the 'zzz' layer, quantised, flattened, the trailing quantised zero stripped before and re-appended un-encrypted after the
-    (dynamic -> single mask, compact positions) encrypt; back: the dense aggregate decrypted with the sparse minus-mask, unflattened by
-    the DENSE shapes and unquantised."""
+    (dynamic -> single mask, compact positions) encrypt -- as ONE launch over the compact layers with the 'zzz' value quantised beside it
+    (handles or uint64 limbs out) and call by call (object ints out), the NumPy stream left where the reference leaves it; the arbiter's
+    expand_to_dense + reduce on those uploads (aggregate_sparse_uploads) against the fixture's dense aggregate; back: the dense aggregate
+    decrypted with the sparse minus-mask, unflattened by the DENSE shapes and unquantised."""
     from flashe_amd import cipher as cm
-    from flashe_amd.block import FlasheClient
+    from flashe_amd.block import FlasheClient, aggregate_sparse_uploads
+    from flashe_amd.engine import DeviceVector
+    from oracle.flashe_oracle import limbs_to_ints
     case = load_golden("clientstep.json")["sparse"][case_i]
     b, C = case["b"], case["num_clients"]
     cm.N_JOBS = case["n_jobs"]
-    cl0 = None
+    cl0, uploads = None, []
     for c, rec in enumerate(case["clients"]):
         cl = FlasheClient(_client_args(case, mask="dynamic"))
         cl.create_cipher(c, C, KEY)
@@ -379,25 +384,45 @@ def test_client_step_of_the_sparse_job(case_i):
         cl.cipher.total = case["total"]
         cl.dynamic_masking(case["choice"], case["masks"])
         assert cl.cipher.masking_scheme == "single"
+        cl.fuse = mode != "call-by-call"
         layers = {nm: _arr(rec["layers"][nm], np.dtype(dt)) for nm, _sh, dt in case["dense_layers"]}
         w = _W(layers)
         cl.quantizer.set_layer_size_list(w)                      # (normalize's first call, before 'zzz' exists)
         w._weights["zzz"] = np.array([0.0])
         w.walking_order = sorted(w._weights, key=str)
         np.random.seed(rec["seed"])
-        out = cl.quantize_encrypt(w)
+        out = cl.quantize_encrypt(w, device=(mode == "fused-handles"))
+        st = np.random.get_state()
+        np.random.seed(rec["seed"])
+        np.random.random(sum(int(np.asarray(v).size) for v in layers.values()) + 1)          # one draw per value, 'zzz' included
+        st_want = np.random.get_state()
+        assert st[2] == st_want[2] and np.array_equal(st[1], st_want[1]), "the NumPy stream must be consumed as the reference consumes it"
         k0 = rec["flat_key"]
         assert out.walking_order == [k0]
-        assert [int(v) for v in out._weights[k0]] == unhex(rec["upload"]), (b, c)
+        v = out._weights[k0]
+        if mode == "fused-handles":
+            assert isinstance(v, DeviceVector)
+            got = limbs_to_ints(v.to_host())
+        elif mode == "fused-host":
+            assert isinstance(v, np.ndarray) and v.dtype == np.uint64
+            got = limbs_to_ints(v)
+        else:
+            got = [int(x) for x in v]
+        assert got == unhex(rec["upload"]), (b, c, mode)
         assert [float(a).hex() for a in cl.quantizer.alpha_list] == rec["alpha"]
+        uploads.append(v)
         cl0 = cl0 or cl
-    cl0.set_idx_list(list(range(C)))
-    cl0.shape_dict = {nm: tuple(sh) for nm, sh, _dt in case["dense_layers"]}         # shape_dict_used_for_sparsification (:893-894)
-    back = cl0.decrypt_unquantize(_W({case["clients"][0]["flat_key"]: np.array(unhex(case["agg"]), dtype=object)}))
-    for nm, sh, _dt in case["dense_layers"]:
-        a = np.asarray(back._weights[nm])
-        assert a.shape == tuple(sh)
-        assert np.array([float(v) for v in a.flatten()], dtype=np.float64).tobytes() == bytes.fromhex(case["unquantized"][nm]), (b, nm)
+    # the arbiter: expand_to_dense of every upload + the reduce, on what the clients produced
+    agg = aggregate_sparse_uploads(cl0.cipher.engine, uploads, case["masks"], case["total"], device=(mode == "fused-handles"))
+    assert limbs_to_ints(agg.to_host() if mode == "fused-handles" else agg) == unhex(case["agg"]), (b, mode)
+    for given in (agg, np.array(unhex(case["agg"]), dtype=object)):
+        cl0.set_idx_list(list(range(C)))
+        cl0.shape_dict = {nm: tuple(sh) for nm, sh, _dt in case["dense_layers"]}         # shape_dict_used_for_sparsification (:893-894)
+        back = cl0.decrypt_unquantize(_W({case["clients"][0]["flat_key"]: given}))
+        for nm, sh, _dt in case["dense_layers"]:
+            a = np.asarray(back._weights[nm])
+            assert a.shape == tuple(sh)
+            assert np.array([float(v) for v in a.flatten()], dtype=np.float64).tobytes() == bytes.fromhex(case["unquantized"][nm]), (b, nm, mode)
 
 
 @pytest.mark.parametrize("b,scheme,n_jobs", [(128, "double", 16), (64, "double", 7), (20, "double", 16), (64, "single", 5)])
