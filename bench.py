@@ -1143,6 +1143,37 @@ def bench_compact(args, n, ops, rank, world, out):
     return out
 
 
+def cpu_baseline_sparse(n_jobs, b, C, locs, vals, zero, total):
+    """The sparse round through the oracle on the host cores, in the reference's own structure: C compact single-mask encrypts, one
+    expand_to_dense per upload + the running mod-add (jzf_aggregator.py:150-165, :419-430), the dense minus-mask from the location lists
+    and its subtraction (jzf_flashe.py:316-343, :531-532).  Bounded: the expand + reduce is timed on the first uploads and scaled."""
+    import numpy as np
+    from oracle import flashe_oracle as orc
+    orc.build()
+    cores = min(orc.num_threads(), usable_cpus())
+    orc.set_num_threads(cores)
+    orc.mask(KEY, 0, 0, 1000, 1, b)          # table init outside the clock
+    L = 2 if b > 64 else 1
+    t0 = time.perf_counter()
+    cts = [orc.encrypt(KEY, 0, c, "single", n_jobs, b, vals[c]) for c in range(C)]
+    t1 = time.perf_counter()
+    ns = min(C, 8)
+    z = np.array([[zero] + [0] * (L - 1)], dtype=np.uint64)
+    agg = np.zeros((total, L), dtype=np.uint64)
+    for c in range(ns):
+        agg = orc.aggregate_elem([agg, orc.expand_to_dense(total, locs[c], cts[c], z, b)], b, out=agg)
+    t2 = time.perf_counter()
+    mask = orc.sparse_minus_mask(KEY, 0, locs, total, n_jobs, b)
+    orc.combine(b, agg, None, mask)
+    t3 = time.perf_counter()
+    t_round = (t1 - t0) + (t2 - t1) * C / ns + (t3 - t2)
+    k = len(locs[0])
+    return {"value": C * k / t_round, "unit": "ciphertexts/s", "cores": cores, "kind": "port", "ms_per_round": t_round * 1e3,
+            "sample": f"one round through oracle/flashe_oracle.c: all {C} encrypts and the dense minus-mask + subtraction in full, expand_to_dense + "
+                      f"running reduce timed on the first {ns} uploads and scaled to {C}",
+            "phases_ms": {"encrypt_xC": (t1 - t0) * 1e3, f"expand_plus_reduce_x{C}_scaled": (t2 - t1) * C / ns * 1e3, "minus_mask_plus_decrypt": (t3 - t2) * 1e3}}
+
+
 # ---- config 5: top-1 % sparse uploads, 50 clients, single mask (the sparse path the reference can run) --------------------
 def bench_sparse(args, total, ops, rank, world, out):
     """Per round (SURVEY.md 8 a-13, a-15, a-10): every client encrypts its compact k-vector (single mask, compact positions);
@@ -1267,6 +1298,8 @@ def bench_sparse(args, total, ops, rank, world, out):
             "span_bounds": "computed once per round (both span sizes in one pass), shared by the two passes" if bounds is not None else "computed by each pass",
             "phases_ms": {"span_bounds": float(ph[:, 0].mean()), "encrypt_xC_plus_sparse_aggregate": enc_ms, "minus_mask_plus_decrypt": dec_ms},
         })
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_sparse(J, b, C, locs, vals, zero, total)
         return out
     agg_ms = float(ph[:, 1].mean())
     enc_ms = float(ph[:, 0].mean())
@@ -1297,6 +1330,8 @@ def bench_sparse(args, total, ops, rank, world, out):
         "span_bounds": "computed once per round, shared by aggregate and decrypt" if bounds is not None else "computed by each of the two passes",
         "phases_ms": {"encrypt_xC": float(ph[:, 0].mean()), "sparse_aggregate": agg_ms, "minus_mask_plus_decrypt": float(ph[:, 2].mean())},
     })
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_sparse(J, b, C, locs, vals, zero, total)
     return out
 
 
