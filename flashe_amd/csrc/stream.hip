@@ -984,6 +984,14 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         const unsigned long long old = atomicAdd(&acc[2 * r], wlo);
         atomicAdd(&acc[2 * r + 1], whi + (old + wlo < old ? 1ull : 0ull));
     };
+    // The last five round keys live in VGPRs: sixty key words + the kernel's pointers do not fit the SGPR file, and what the compiler
+    // spills it re-reads with v_readlane inside the rounds (VALU issue is what bounds them)
+    uint32_t rkv[20];
+#pragma unroll
+    for (int i = 0; i < 20; i++) {
+        rkv[i] = rk.w[40 + i];
+        asm volatile("" : "+v"(rkv[i]));
+    }
     uint64_t sp = blockIdx.x;
     if (keeper) {
         SPAN_PRF_FETCH(sp); SPAN_PRF_PUBLISH(0);
@@ -1048,7 +1056,11 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 2; r < 14; r++) {
-                finish_main(rk, r, k, s);
+                if (r < 10) finish_main(rk, r, k, s);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) s[j] = xor3(xor3(k.v[4 * j], k.v[4 * j + 1], k.v[4 * j + 2]), k.v[4 * j + 3], rkv[4 * (r - 10) + j]);
+                }
                 if (r <= 7) {                                        // r = 2 .. 7: the six steps 32, 16, .. 1 of the search
                     const int step = 32 >> (r - 2);
                     if (pv <= f) cn += step;
@@ -1070,7 +1082,9 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                 k = r < 13 ? issue_main(lr, s) : issue_final(lr, s);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            finish_final(rk, k, s);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                s[j] = bfi(0xff000000u, k.v[4 * j], bfi(0x00ff0000u, k.v[4 * j + 1], bfi(0x0000ff00u, k.v[4 * j + 2], k.v[4 * j + 3]))) ^ rkv[16 + j];
             __builtin_amdgcn_sched_barrier(0);
         } else {
             SPAN_PRF_FROM()
