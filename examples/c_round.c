@@ -165,5 +165,57 @@ int main(void)
            " prepared_vs_online_differences=%" PRIu64 "\n",
            bad3 == 0 && bad3d == 0 && differ == 0 ? "OK" : "FAILED", n3, C3, bad3, runs3, na, nm, bad3d, differ);
     flashe_ctx_destroy(ctx);
-    return bad3 == 0 && bad3d == 0 && differ == 0 ? 0 : 1;
+    if (!(bad3 == 0 && bad3d == 0 && differ == 0)) return 1;
+
+    /* BASELINE config 5's path from plain C, device resident: CS clients upload their top-k values (sorted positions + compact values,
+     * what Client.sparsify leaves), single mask over the COMPACT positions.  One call encrypts all of them and writes the sum of their
+     * expanded uploads (Arbiter.expand_to_dense + reduce: the plain `zero` everywhere, value - zero at the locations); the decrypt
+     * rebuilds the dense minus-mask from the location lists and subtracts it in the same pass.  The span bounds of the round's lists are
+     * computed once and shared by both. */
+    enum { CS = 6 };
+    const uint64_t total = 300007, ks = 3000, zero = 1ull << 31;
+    const uint32_t its = 5;
+    if (flashe_ctx_create(&ctx, key, 128, 0, NULL) != FLASHE_OK) {
+        fprintf(stderr, "flashe_ctx_create: %s\n", flashe_last_error(NULL));
+        return 1;
+    }
+    uint64_t *wants = malloc(total * sizeof *wants), *got = malloc(total * 16), *hv = malloc(ks * sizeof *hv);
+    uint32_t *hl = malloc(ks * sizeof *hl), idxs[CS];
+    const uint32_t *dloc[CS];
+    const uint64_t *dval[CS];
+    uint64_t *dcts[CS], kk[CS], zeros[2 * CS], *dagg = NULL, *ddec = NULL;
+    for (uint64_t p = 0; p < total; p++) wants[p] = CS * zero;
+    for (int c = 0; c < CS; c++) {
+        uint32_t pos = (uint32_t)(c * 7);
+        for (uint64_t q = 0; q < ks; q++) {                      /* strictly increasing positions, gaps of 1 .. 89 */
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            pos += 1 + (uint32_t)(x % 89);
+            hl[q] = pos;
+            hv[q] = x >> 12;
+            wants[pos] += hv[q] - zero;
+        }
+        void *p1 = NULL, *p2 = NULL, *p3 = NULL;
+        CHECK(flashe_dev_alloc(ctx, ks * 4, &p1)); CHECK(flashe_dev_alloc(ctx, ks * 8, &p2)); CHECK(flashe_dev_alloc(ctx, ks * 16, &p3));
+        CHECK(flashe_memcpy_h2d(ctx, p1, hl, ks * 4)); CHECK(flashe_memcpy_h2d(ctx, p2, hv, ks * 8));
+        dloc[c] = p1; dval[c] = p2; dcts[c] = p3; kk[c] = ks; idxs[c] = (uint32_t)c; zeros[2 * c] = zero; zeros[2 * c + 1] = 0;
+    }
+    CHECK(flashe_dev_alloc(ctx, total * 16, (void **)&dagg)); CHECK(flashe_dev_alloc(ctx, total * 16, (void **)&ddec));
+    flashe_span_bounds *bounds = NULL;
+    CHECK(flashe_span_bounds_create(ctx, total, CS, dloc, kk, &bounds));
+    CHECK(flashe_sparse_encrypt_aggregate_dev(ctx, its, N_JOBS, total, CS, idxs, dloc, kk, dval, 1, zeros, bounds, dcts, dagg));
+    CHECK(flashe_sparse_decrypt_bounds_dev(ctx, its, CS, dloc, kk, total, N_JOBS, bounds, dagg, ddec));
+    CHECK(flashe_memcpy_d2h(ctx, got, ddec, total * 16));
+    uint64_t bads = 0;
+    for (uint64_t p = 0; p < total; p++) bads += got[2 * p] != wants[p] || got[2 * p + 1] != 0;
+    /* and the ciphertexts are what a lone client's encrypt gives */
+    uint64_t *lone = malloc(ks * 16), *both = malloc(ks * 16), differs = 0;
+    CHECK(flashe_memcpy_d2h(ctx, hv, dval[CS - 1], ks * 8));
+    CHECK(flashe_encrypt(ctx, its, CS - 1, FLASHE_SCHEME_SINGLE, ks, N_JOBS, hv, 1, lone));
+    CHECK(flashe_memcpy_d2h(ctx, both, dcts[CS - 1], ks * 16));
+    for (uint64_t j = 0; j < 2 * ks; j++) differs += lone[j] != both[j];
+    printf("C_ROUND_SPARSE %s: total=%" PRIu64 " k=%" PRIu64 " clients=%d mismatches=%" PRIu64 " ciphertext_differences=%" PRIu64 "\n",
+           bads == 0 && differs == 0 ? "OK" : "FAILED", total, ks, CS, bads, differs);
+    flashe_span_bounds_destroy(bounds);
+    flashe_ctx_destroy(ctx);
+    return bads == 0 && differs == 0 ? 0 : 1;
 }

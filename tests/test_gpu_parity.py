@@ -819,6 +819,8 @@ def test_c_example_round_runs(tmp_path):
     # third round: BASELINE config 3's shape (LeNet-sized vector, 100 clients, mask precompute held and consumed inside the ctx; a
     # dropout whose two uncovered prefixes are computed online) -- VERDICT r3 #9
     assert "C_ROUND_PRECOMPUTE OK" in r.stdout and "clients=100" in r.stdout and "extra_prefixes=1+1" in r.stdout, r.stdout[-800:]
+    # fourth round: config 5's path, device resident -- six sparse clients encrypted and summed in one call, the sparse decrypt, shared span bounds
+    assert "C_ROUND_SPARSE OK" in r.stdout and "ciphertext_differences=0" in r.stdout, r.stdout[-800:]
 
 
 @pytest.mark.parametrize("b,n,J", [(128, 61_706, 16), (23, 61_706, 16), (64, 5_001, 3), (128, 0, 1), (20, 7, 16)])
