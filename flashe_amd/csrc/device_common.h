@@ -86,10 +86,26 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
 #ifndef FLASHE_SWP
 #define FLASHE_SWP 1   // two-block calls run software pipelined (measured 4.6 % faster than the compiler's own order)
 #endif
+#ifndef FLASHE_ADDR_BITOP
+#define FLASHE_ADDR_BITOP 0   // 1 = lookup addresses by shift + v_bitop3 instead of v_perm_b32 (round 4 A/B builds: measured SLOWER in the kernels, see below)
+#endif
 template <int OFF>
 __device__ __forceinline__ uint32_t lut(const lds_u8 *base, uint32_t w, uint32_t lanereg, uint32_t sel)
 {
+#if FLASHE_ADDR_BITOP
+    // address = (byte k of w) << 8 | lane register.  v_perm_b32 builds it in one instruction, but every three-source VALU op except
+    // v_bitop3_b32 issues at ~4.3 cycles per wave here and the rounds are bound by VALU issue as much as by the LDS; a shift that brings
+    // byte k to bits 8..15 (a two-source op, 1.9 cycles; none for k = 1) and one v_bitop3 ((x & 0xff00) | lane register, 2.5 cycles)
+    // cost 12 x 1.9 + 16 x 2.5 = 63 cycles per block-round instead of 69 (tools/ubench_lds.hip: 23.2 -> 25.1 lookups per clock per CU
+    // with one block per lane, 24.1 -> 25.2 with two).  In the KERNELS the two builds alternated in one process say the opposite:
+    // ten chained 1e7-element encrypts 1.575 ms against 1.429 with v_perm, b = 64 0.882 / 0.799, config 5 0.655 / 0.62 -- twelve more
+    // instructions per block-round and a two-deep dependent chain in front of every lookup cost more than the cycles they save once the
+    // software-pipelined rounds compete for issue slots.  Kept as a build option, off.  `sel` is a compile-time constant at every call site.
+    const uint32_t x = sel == SEL_B1 ? w : sel == SEL_B0 ? w << 8 : sel == SEL_B2 ? w >> 8 : w >> 16;
+    const uint32_t addr = __builtin_amdgcn_bitop3_b32(x, 0xff00u, lanereg, 0xea);
+#else
     const uint32_t addr = __builtin_amdgcn_perm(w, lanereg, sel);
+#endif
     return *reinterpret_cast<const lds_u32 *>(base + addr + OFF);
 }
 
