@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kern
 #ifdef FLASHE_TUNING
         if (!(has_minus & 0x100))                                        // (0x100: timing probe without the rounds)
 #endif
-        aes256_rounds<1, 2>(rk, lr, s);
+        aes256_rounds1_deep<2>(rk, lr, s[0]);                            // (one block per lane: all sixteen lookups of a round in flight)
         // row word order = little-endian words of the 128-bit block value (word 0 = bits 0..31)
         *reinterpret_cast<uint4 *>(row0 + 4 * lane) = drop ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(s[0][3], s[0][2], s[0][1], s[0][0]);
         __builtin_amdgcn_wave_barrier();
@@ -1442,6 +1442,50 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kern
         const int n_valid = __popc(valid_mask);
         const uint32_t j0_lo = static_cast<uint32_t>(j0), j0_hi = static_cast<uint32_t>(j0 >> 32);
         int lane_base = 0;
+        if constexpr (sizeof(IT) == 4 && sizeof(OT) == 4) {
+            // The compact layout's regular tile -- 32 whole blocks inside the range, its 32 m elements a 16-byte aligned run of every
+            // operand (0x200: the host checked the pointers): a lane takes FOUR consecutive elements, one 16-byte load per operand and
+            // one 16-byte store, up to four operands in flight -- a quarter of the memory instructions of the element-per-lane walk
+            // and four times the bytes in flight per lane, which is what this HBM-bound pass was short of.
+            const uint64_t e0t = static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_lo, 0)) |
+                                 (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_hi, 0))) << 32);
+            if ((has_minus & 0x200) && valid_mask == 0xffffffffu && partial_mask == 0 && e0t >= first && e0t + 32u * m32 <= range_end &&
+                ((e0t - first) & 3u) == 0) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                constexpr int QB = 8;                                  // operands in flight per lane (C is wave-uniform: surplus slots issue nothing)
+                const uint64_t k0 = e0t - first;
+                for (uint32_t qd = lane; qd < 8u * m32; qd += 64u) {
+                    const uint64_t kq = k0 + 4u * qd;
+                    u32x4 sum = {0u, 0u, 0u, 0u};
+                    for (int c = 0; c < C; c += QB) {
+                        u32x4 v[QB];
+#pragma unroll
+                        for (int u = 0; u < QB; u++) {
+                            v[u] = u32x4{0u, 0u, 0u, 0u};
+                            if (c + u < C) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tab_ops[c + u]) + kq));
+                        }
+#pragma unroll
+                        for (int u = 0; u < QB; u++) sum += v[u];
+                    }
+                    u32x4 res;
+#pragma unroll
+                    for (uint32_t tq = 0; tq < 4; tq++) {
+                        const uint32_t xx = 4u * qd + tq;
+                        const uint32_t blk = static_cast<uint32_t>((static_cast<uint64_t>(xx) * p.m_magic) >> 32);
+                        const uint32_t o = static_cast<uint32_t>(p.b) * (xx - blk * m32);
+                        const uint32_t *wa = row0 + 4 * blk + (o >> 5), *wm = wa + 128;
+                        res[tq] = (sum[tq] + __builtin_amdgcn_alignbit(wa[1], wa[0], o & 31u) - __builtin_amdgcn_alignbit(wm[1], wm[0], o & 31u)) & mask;
+                    }
+                    if (agg_out) {
+                        const u32x4 ag = {sum[0] & mask, sum[1] & mask, sum[2] & mask, sum[3] & mask};
+                        __builtin_nontemporal_store(ag, reinterpret_cast<u32x4 *>(reinterpret_cast<uint32_t *>(agg_out) + kq));
+                    }
+                    __builtin_nontemporal_store(res, reinterpret_cast<u32x4 *>(reinterpret_cast<uint32_t *>(out) + kq));
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+        }
         while (lane_base < n_valid) {
             const int P = partial_mask ? static_cast<int>(__ffs(partial_mask)) - 1 : -1;
             const uint64_t e0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_lo, lane_base)) |
@@ -2050,9 +2094,14 @@ hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint
         // 32-block tiles, the two streams in the two halves of the wave (see small_reduce_decrypt_split_kernel)
         const uint64_t tiles32 = (bc + 31) / 32, groups32 = (tiles32 + kSmallThreads / 64 - 1) / (kSmallThreads / 64);
         const int grid32 = static_cast<int>(groups32 < cus ? groups32 : cus);
+        // 0x200: every operand and both outputs 16-byte aligned -- the compact layout's regular tiles take 16-byte accesses
+        uintptr_t low_bits = reinterpret_cast<uintptr_t>(out_dev) | reinterpret_cast<uintptr_t>(agg_out_dev);
+        for (int c = 0; c < C; c++) low_bits |= reinterpret_cast<uintptr_t>(ops[c]);
+        static const bool quad_off = FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_QUAD") && atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_QUAD")) == 0;
+        const int quad = (low_bits & 15u) == 0 && !quad_off ? 0x200 : 0;
 #define SRDS_LAUNCH(CB, IT, OT)                                                                                                               \
     hipLaunchKernelGGL((small_reduce_decrypt_split_kernel<CB, IT, OT>), dim3(grid32), dim3(kSmallThreads), 0, env.stream, env.rk, p, add_idx,  \
-                       minus_idx, (has_minus ? 1 : 0) | probe, first, count, bf, bc, C, t, agg_out_dev, out_dev)
+                       minus_idx, (has_minus ? 1 : 0) | probe | quad, first, count, bf, bc, C, t, agg_out_dev, out_dev)
 #define SRDS_PICK(CB)                                                                                                                          \
     do {                                                                                                                                        \
         if (!env.elem32) SRDS_LAUNCH(CB, uint64_t, uint64_t);                                                                                   \
