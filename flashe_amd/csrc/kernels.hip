@@ -1442,45 +1442,46 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kern
         const int n_valid = __popc(valid_mask);
         const uint32_t j0_lo = static_cast<uint32_t>(j0), j0_hi = static_cast<uint32_t>(j0 >> 32);
         int lane_base = 0;
-        if constexpr (sizeof(IT) == 4 && sizeof(OT) == 4) {
-            // The compact layout's regular tile -- 32 whole blocks inside the range, its 32 m elements a 16-byte aligned run of every
-            // operand (0x200: the host checked the pointers): a lane takes FOUR consecutive elements, one 16-byte load per operand and
-            // one 16-byte store, up to four operands in flight -- a quarter of the memory instructions of the element-per-lane walk
-            // and four times the bytes in flight per lane, which is what this HBM-bound pass was short of.
+        if constexpr (sizeof(IT) == 4 && sizeof(OT) == 4) {      // (measured without gain in the one-limb layout: 0.212 against 0.208 ms at b = 20 -- that walk streams 880 MB at 4.2 TB/s as it is)
+            // The regular tile -- 32 whole blocks inside the range, its 32 m elements a 16-byte aligned run of every operand (0x200: the
+            // host checked the pointers): a lane takes 16 BYTES of consecutive elements (four in the compact layout, two one-limb
+            // elements), one 16-byte load per operand and one 16-byte store, up to eight operands in flight -- a quarter / half of the
+            // memory instructions of the element-per-lane walk and more bytes in flight per lane, which is what this HBM-bound pass was
+            // short of (b <= 32: the sums and the slots are 32-bit, only the low word of a one-limb element takes part).
+            constexpr uint32_t EPQ = 16 / sizeof(IT);
             const uint64_t e0t = static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_lo, 0)) |
                                  (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_hi, 0))) << 32);
             if ((has_minus & 0x200) && valid_mask == 0xffffffffu && partial_mask == 0 && e0t >= first && e0t + 32u * m32 <= range_end &&
-                ((e0t - first) & 3u) == 0) {
+                ((e0t - first) & (EPQ - 1u)) == 0) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 constexpr int QB = 8;                                  // operands in flight per lane (C is wave-uniform: surplus slots issue nothing)
                 const uint64_t k0 = e0t - first;
-                for (uint32_t qd = lane; qd < 8u * m32; qd += 64u) {
-                    const uint64_t kq = k0 + 4u * qd;
+                for (uint32_t qd = lane; qd < (32u / EPQ) * m32; qd += 64u) {
+                    const uint64_t kq = k0 + EPQ * qd;
                     u32x4 sum = {0u, 0u, 0u, 0u};
                     for (int c = 0; c < C; c += QB) {
                         u32x4 v[QB];
 #pragma unroll
                         for (int u = 0; u < QB; u++) {
                             v[u] = u32x4{0u, 0u, 0u, 0u};
-                            if (c + u < C) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint32_t *>(tab_ops[c + u]) + kq));
+                            if (c + u < C) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const IT *>(tab_ops[c + u]) + kq));
                         }
 #pragma unroll
                         for (int u = 0; u < QB; u++) sum += v[u];
                     }
-                    u32x4 res;
+                    u32x4 res = {0u, 0u, 0u, 0u}, ag = {0u, 0u, 0u, 0u};
 #pragma unroll
-                    for (uint32_t tq = 0; tq < 4; tq++) {
-                        const uint32_t xx = 4u * qd + tq;
+                    for (uint32_t tq = 0; tq < EPQ; tq++) {
+                        const uint32_t xx = EPQ * qd + tq;
                         const uint32_t blk = static_cast<uint32_t>((static_cast<uint64_t>(xx) * p.m_magic) >> 32);
                         const uint32_t o = static_cast<uint32_t>(p.b) * (xx - blk * m32);
                         const uint32_t *wa = row0 + 4 * blk + (o >> 5), *wm = wa + 128;
-                        res[tq] = (sum[tq] + __builtin_amdgcn_alignbit(wa[1], wa[0], o & 31u) - __builtin_amdgcn_alignbit(wm[1], wm[0], o & 31u)) & mask;
+                        const uint32_t w = (4u / EPQ) * tq;            // the element's (low) word in the 16 bytes
+                        res[w] = (sum[w] + __builtin_amdgcn_alignbit(wa[1], wa[0], o & 31u) - __builtin_amdgcn_alignbit(wm[1], wm[0], o & 31u)) & mask;
+                        ag[w] = sum[w] & mask;
                     }
-                    if (agg_out) {
-                        const u32x4 ag = {sum[0] & mask, sum[1] & mask, sum[2] & mask, sum[3] & mask};
-                        __builtin_nontemporal_store(ag, reinterpret_cast<u32x4 *>(reinterpret_cast<uint32_t *>(agg_out) + kq));
-                    }
-                    __builtin_nontemporal_store(res, reinterpret_cast<u32x4 *>(reinterpret_cast<uint32_t *>(out) + kq));
+                    if (agg_out) __builtin_nontemporal_store(ag, reinterpret_cast<u32x4 *>(agg_out + kq));
+                    __builtin_nontemporal_store(res, reinterpret_cast<u32x4 *>(out + kq));
                 }
                 __builtin_amdgcn_wave_barrier();
                 continue;
