@@ -408,9 +408,10 @@ int flashe_sparse_minus_mask_sorted_dev(flashe_ctx *ctx, uint32_t iter, int C, c
  * new: fusion of two reference steps. */
 int flashe_sparse_decrypt_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                               uint64_t total, uint32_t n_jobs, int sorted, const uint64_t *agg_dev, uint64_t *out_dev);
-/* Span bounds of a round's location lists, computed ONCE (new).  The LDS-staged sparse reduce cuts the dense vector into spans and
- * first finds, for every span, where each client's (strictly increasing) list enters it -- a pass over all lists that the sparse
- * aggregate and the sparse decrypt of one round would otherwise both run on the same lists.  flashe_span_bounds_create computes the
+/* Span bounds of a round's location lists, computed ONCE (new).  The LDS-staged sparse passes cut the dense vector into spans and
+ * first find, for every span, where each client's (strictly increasing) list enters it -- a pass over all lists that the sparse
+ * aggregate and the sparse decrypt of one round would otherwise both run on the same lists.  (The handle carries the table for both
+ * span sizes in use -- the plain reduce's and that of the passes with the PRF inside -- filled by one pass over the lists.)  flashe_span_bounds_create computes the
  * table for C lists (any C) asynchronously on the ctx stream; the *_bounds_dev calls take it instead of recomputing; the handle is valid
  * for exactly these list pointers / lengths / total (checked) and until flashe_span_bounds_destroy.  The lists must not change
  * while a handle built on them is in use. */
