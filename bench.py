@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--calibration-deadline", type=float, default=float(os.environ.get("FLASHE_BENCH_CALIBRATION_DEADLINE_S", "150")),
                     help="N > 1: seconds the optional overlapped schedules (calibration + their timed region) may take; when it passes, or "
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
+    ap.add_argument("--no-position-sharded", action="store_true", help="config 5, N > 1: skip the round sharded by position ranges (timed beside the replicas)")
     ap.add_argument("--sparse-separate", action="store_true", help="config 5: the encrypts and the sparse aggregate as separate launches (the round-2 .. 4 form) as `value`")
     ap.add_argument("--no-span-bounds", action="store_true",
                     help="config 5: let the sparse aggregate and the sparse decrypt each compute the span bounds of the location lists "
@@ -1261,8 +1262,29 @@ def bench_sparse(args, total, ops, rank, world, out):
     for it in range(max(W, 2)):
         step(it)
     elapsed = timed_region(ops, K, lambda kk: step(kk, kk))
+    # several GPUs: `value` above is every rank running the whole round on its own data (replicas, weak scaling).  Beside it, ONE round
+    # shared by all ranks: the dense vector cut into position ranges of whole spans, every rank plays every client on the range it owns
+    # (SparseShardedRound: no exchange for the aggregate, the decrypted ranges all-gathered) -- strong scaling of the same 50-client round.
+    shard_ms = shard_ms_no_gather = None
+    if world > 1 and L == 2 and not args.no_position_sharded:
+        from flashe_amd.dist import SparseShardedRound
+        srnd = SparseShardedRound(ops, total, b, C, J, rank=rank, world=world)
+        refs = lambda bufs: [(bf, 0) for bf in bufs]                      # noqa: E731
+        r_loc, r_val, r_ct = refs(d_loc), refs(d_val), refs(d_ct)
+        out_ref = srnd.run(0, r_loc, [k] * C, r_val, 1, [zero] * C, r_ct)
+        got = ops.read((out_ref, 0), total * L).reshape(total, L)
+        assert np.array_equal(got[:, 0], want), "PARITY FAILURE (position-sharded sparse round)"
+        for it in range(max(W, 2)):
+            srnd.run(it, r_loc, [k] * C, r_val, 1, [zero] * C, r_ct)
+        shard_ms = timed_region(ops, K, lambda kk: srnd.run(kk, r_loc, [k] * C, r_val, 1, [zero] * C, r_ct)) * 1e3 / K
+        shard_ms_no_gather = timed_region(ops, K, lambda kk: srnd.run(kk, r_loc, [k] * C, r_val, 1, [zero] * C, r_ct, gather=False)) * 1e3 / K
     if rank != 0:
         return None
+    if shard_ms is not None:
+        out.update({"value_position_sharded": C * k / (shard_ms * 1e-3), "ms_per_step_position_sharded": shard_ms,
+                    "value_position_sharded_no_gather": C * k / (shard_ms_no_gather * 1e-3),
+                    "position_sharded_note": f"ONE {C}-client round over {world} GPUs: position ranges of whole spans, no exchange for the "
+                                             "aggregate; all-gather of the decrypted ranges included in the first figure (strong scaling)"})
     ph = np.array([[eng.elapsed_ms(e[i], e[i + 1]) for i in range(3)] for e in ev])
     m = 1 if L == 2 else 128 // b
     prf_blocks = C * ((k + m - 1) // m)

@@ -104,6 +104,10 @@ _SIGNATURES = {
     "flashe_sparse_decrypt_bounds_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp, c_vp, c_vp]),
     "flashe_sparse_encrypt_aggregate_dev": (c_int, [c_vp, c_u32, c_u32, c_u64, c_int, c_u32p, ctypes.POINTER(c_vp), c_u64p, ctypes.POINTER(c_vp), c_int,
                                                     c_u64p, c_vp, ctypes.POINTER(c_vp), c_vp]),
+    "flashe_sparse_span": (c_int, []),
+    "flashe_sparse_encrypt_aggregate_range_dev": (c_int, [c_vp, c_u32, c_u32, c_u64, c_int, c_u32p, ctypes.POINTER(c_vp), c_u64p, ctypes.POINTER(c_vp), c_int,
+                                                          c_u64p, c_vp, c_u64, c_u64, ctypes.POINTER(c_vp), c_vp]),
+    "flashe_sparse_decrypt_range_dev": (c_int, [c_vp, c_u32, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64, c_u32, c_vp, c_u64, c_u64, c_vp, c_vp]),
     "flashe_aggregate_elem_u32_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_dynamic_masking_cost_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64p, c_u64p, c_u64p]),
     "flashe_prepare_encrypt": (c_int, [c_vp, c_u32, c_u32, c_int, c_u64, c_u32]),

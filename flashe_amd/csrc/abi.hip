@@ -1805,9 +1805,10 @@ static int sparse_aggregate_impl(flashe_ctx *ctx, uint64_t total, int C, const u
 // The sparse twin of flashe_encrypt_batch_sum_dev: the C clients this device plays encrypt their compact uploads (single mask over the
 // compact positions, jzf_flashe.py:471-478 on the values Client.sparsify kept) and the sum of the C expanded uploads -- what
 // Arbiter.expand_to_dense + the reduce make of them (jzf_aggregator.py:150-165, :419-430) -- is written in the same pass.
-int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t n_jobs, uint64_t total, int C, const uint32_t *idx,
-                                        const uint32_t *const *loc_dev, const uint64_t *k, const uint64_t *const *pt_dev, int pt_limbs,
-                                        const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t *const *ct_dev, uint64_t *agg_out_dev)
+static int sparse_encrypt_aggregate_impl(flashe_ctx *ctx, uint32_t iter, uint32_t n_jobs, uint64_t total, int C, const uint32_t *idx,
+                                         const uint32_t *const *loc_dev, const uint64_t *k, const uint64_t *const *pt_dev, int pt_limbs,
+                                         const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t *const *ct_dev, uint64_t *agg_out_dev,
+                                         uint64_t first, uint64_t count, bool whole)
 {
     CHECK_CTX(ctx);
     if (C < 1 || !idx || !loc_dev || !k || !pt_dev || !zeros || !ct_dev || (total && !agg_out_dev) || n_jobs == 0)
@@ -1827,6 +1828,8 @@ int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t
         if (z & ~mask) return fail(ctx, FLASHE_EINVAL, "zero value of client %d exceeds int_bits", c);
         zsum = (zsum + z) & mask;
     }
+    if (!whole && (!span_prf_ok(ctx) || !bounds || !bounds->start_fused))
+        return fail(ctx, FLASHE_EINVAL, "the position-range form needs int_bits > 64 on the table PRF and a bounds handle");
     if (!span_prf_ok(ctx) || (bounds && !bounds->start_fused)) {
         // int_bits <= 64 / another PRF backend: the encrypts, then the sparse reduce of what they wrote
         for (int c = 0; c < C; c++) {
@@ -1844,18 +1847,53 @@ int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t
         if (!bounds) HIP_TRY(ctx, launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, nullptr, start));
         HIP_TRY(ctx, launch_span_prf(ctx->env, iter, nc, idx + c0, loc_dev + c0, k + c0, pt_dev + c0, pt_limbs, ct_dev + c0, zeros + 2 * static_cast<size_t>(c0),
                                      c0 ? 0 : static_cast<uint64_t>(zsum), c0 ? 0 : static_cast<uint64_t>(zsum >> 64), total, start,
-                                     c0 != 0 ? agg_out_dev : nullptr, false, agg_out_dev));
+                                     c0 != 0 ? agg_out_dev : nullptr, false, agg_out_dev, first, count));
     }
     return FLASHE_OK;
 }
+
+int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t n_jobs, uint64_t total, int C, const uint32_t *idx,
+                                        const uint32_t *const *loc_dev, const uint64_t *k, const uint64_t *const *pt_dev, int pt_limbs,
+                                        const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t *const *ct_dev, uint64_t *agg_out_dev)
+{
+    return sparse_encrypt_aggregate_impl(ctx, iter, n_jobs, total, C, idx, loc_dev, k, pt_dev, pt_limbs, zeros, bounds, ct_dev, agg_out_dev, 0, total, true);
+}
+
+// ---- the sparse round sharded by POSITION ranges (SURVEY 8e (i) for the sparse path): GPU g owns the positions [first, first + count) of
+// the dense vector and runs every client's entries that fall into them -- counters and list indices stay global, nothing is exchanged
+// for the aggregate.  Ranges start at multiples of flashe_sparse_span() and end at one or at the end of the vector. ----
+int flashe_sparse_span(void) { return kSpanFused; }
+
+static int check_span_range(flashe_ctx *ctx, uint64_t total, uint64_t first, uint64_t count)
+{
+    if (first > total || count > total - first) return fail(ctx, FLASHE_EINVAL, "position range outside the vector");
+    if (first % kSpanFused || (first + count != total && (first + count) % kSpanFused))
+        return fail(ctx, FLASHE_EINVAL, "position ranges start and end at multiples of flashe_sparse_span() = %d (or at the end of the vector)", kSpanFused);
+    return FLASHE_OK;
+}
+
+int flashe_sparse_encrypt_aggregate_range_dev(flashe_ctx *ctx, uint32_t iter, uint32_t n_jobs, uint64_t total, int C, const uint32_t *idx,
+                                              const uint32_t *const *loc_dev, const uint64_t *k, const uint64_t *const *pt_dev, int pt_limbs,
+                                              const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t first, uint64_t count,
+                                              uint64_t *const *ct_dev, uint64_t *agg_out_dev)
+{
+    CHECK_CTX(ctx);
+    const int rc = check_span_range(ctx, total, first, count);
+    if (rc) return rc;
+    if (count == 0) return FLASHE_OK;
+    return sparse_encrypt_aggregate_impl(ctx, iter, n_jobs, total, C, idx, loc_dev, k, pt_dev, pt_limbs, zeros, bounds, ct_dev, agg_out_dev, first, count, false);
+}
+
 
 // agg_dev == nullptr: out = the dense minus-mask.  agg_dev given: out = (agg - minus-mask) mod 2^b, the single-mask decrypt
 // (jzf_flashe.py:531-532) in the pass that builds the mask.
 static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                                   uint64_t total, uint32_t n_jobs, bool sorted, const uint64_t *agg_dev, uint64_t *out_dev,
-                                  const flashe_span_bounds *bounds = nullptr)
+                                  const flashe_span_bounds *bounds = nullptr, uint64_t first = 0, uint64_t count = ~0ull)
 {
     CHECK_CTX(ctx);
+    const bool whole = count == ~0ull;                 // (a position range [first, first + count) is the *_range_dev form: the fused pass only)
+    if (whole) count = total;
     if (C < 0 || (C && (!loc_dev || !k)) || (total && !out_dev) || n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "bad arguments");
     { const int brc = C > 0 ? check_bounds(ctx, bounds, total, C, loc_dev, k) : FLASHE_OK; if (brc) return brc; }
     if (ctx->limbs == 2 && (!aligned16(out_dev) || !aligned16(agg_dev))) return fail(ctx, FLASHE_EINVAL, "device vectors must be 16-byte aligned");
@@ -1867,6 +1905,7 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
     }
     const bool jobs_path = span_prf_ok(ctx);
     const bool fused = sorted && jobs_path && C > 0;      // the span reduce writes (or subtracts from agg) the whole vector itself
+    if (!whole && !(fused && bounds)) return fail(ctx, FLASHE_EINVAL, "the position-range form needs int_bits > 64 on the table PRF, sorted lists and a bounds handle");
 #ifdef FLASHE_TUNING
     const char *two_pass = getenv("FLASHE_SPAN_PRF");     // "0" = compact streams through HBM, then the plain span reduce (the round-2 .. 4 form; A/B runs)
     const bool prf_inside = fused && !(two_pass && two_pass[0] == '0' && !bounds);
@@ -1886,7 +1925,7 @@ static int sparse_minus_mask_impl(flashe_ctx *ctx, uint32_t iter, int C, const u
             uint32_t *start = bounds ? bounds->start_fused + (c0 / kMaxScatter) * bounds->group_stride_fused : static_cast<uint32_t *>(ctx->bounds.p);
             if (!bounds) HIP_TRY(ctx, launch_span_bounds(ctx->env, nc, loc_dev + c0, k + c0, total, nullptr, start));
             HIP_TRY(ctx, launch_span_prf(ctx->env, iter, nc, idx, loc_dev + c0, k + c0, nullptr, 2, nullptr, nullptr, 0, 0, total, start,
-                                         c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev));
+                                         c0 != 0 ? out_dev : agg_dev, agg_dev != nullptr, out_dev, first, count));
         }
         return FLASHE_OK;
     }
@@ -1962,6 +2001,20 @@ int flashe_sparse_decrypt_bounds_dev(flashe_ctx *ctx, uint32_t iter, int C, cons
     if (!span_prf_ok(ctx) || std::min(C, kMaxScatter) != std::min(bounds->C, kMaxScatter))
         return fail(ctx, FLASHE_EINVAL, "sparse_decrypt_bounds needs int_bits > 64 on the table PRF (the span reduce is what consumes the bounds)");
     return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, true, agg_dev, out_dev, bounds);
+}
+
+int flashe_sparse_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total,
+                                    uint32_t n_jobs, const flashe_span_bounds *bounds, uint64_t first, uint64_t count, const uint64_t *agg_dev,
+                                    uint64_t *out_dev)
+{
+    CHECK_CTX(ctx);
+    if (!bounds) return fail(ctx, FLASHE_EINVAL, "null bounds handle");
+    const int rc = check_span_range(ctx, total, first, count);
+    if (rc) return rc;
+    if (count == 0) return FLASHE_OK;
+    if (!agg_dev || agg_dev == out_dev) return fail(ctx, FLASHE_EINVAL, "the aggregate must be given and must not be the output vector");
+    if (std::min(C, kMaxScatter) != std::min(bounds->C, kMaxScatter)) return fail(ctx, FLASHE_EINVAL, "the bounds handle describes other lists");
+    return sparse_minus_mask_impl(ctx, iter, C, loc_dev, k, total, n_jobs, true, agg_dev, out_dev, bounds, first, count);
 }
 
 int flashe_sparse_double_masks_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k, uint64_t total,

@@ -195,10 +195,12 @@ hipError_t launch_span_bounds(const LaunchEnv &env, int C, const uint32_t *const
 // The span reduce with the PRF inside (int_bits > 64, table PRF; one persistent launch): entry q of client c contributes
 // term(iter, idx[c], q) -- pt_dev null: out[p] = from[p] +/- the sum of the masks at p (sparse minus-mask / decrypt); pt_dev given:
 // ct_dev[c][q] = (pt_dev[c][q] + mask) mod 2^b is stored (where ct_dev[c] is not null) and out[p] = from[p] + sum (ct - sub[c]);
-// pt_limbs = 1: the plaintexts are uint64 arrays.  start_dev: bounds of exactly these lists at kSpanFused.
+// pt_limbs = 1: the plaintexts are uint64 arrays.  start_dev: bounds of exactly these lists at kSpanFused.  [first, first + count):
+// the positions this launch covers (span-aligned, see stream.hip) -- src_dev / out_dev address position `first`; entries outside it
+// are left alone (their ciphertexts are not written).
 hipError_t launch_span_prf(const LaunchEnv &env, uint32_t iter, int C, const uint32_t *idx, const uint32_t *const *loc_dev, const uint64_t *k,
                            const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi,
-                           uint64_t total, const uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev);
+                           uint64_t total, const uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, uint64_t first, uint64_t count);
 #ifdef FLASHE_TUNING
 hipError_t span_prf_cycles(unsigned long long *out8, bool reset);      // phase cycle sums of span_prf_kernel's workgroup 0 (FLASHE_SPAN_PROBE=9)
 #endif

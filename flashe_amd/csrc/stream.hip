@@ -889,7 +889,7 @@ struct SpanPrfEntry {
 
 template <int ENC>
 __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys rk, const SpanPrfTable tb, int C, uint32_t iter0, uint64_t total, uint32_t n_spans,
-                                                               const uint32_t *__restrict__ start, uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo,
+                                                               uint32_t sp_first, uint32_t sp_end, const uint32_t *__restrict__ start, uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo,
                                                                uint64_t mask_hi, const uint64_t *src, bool negate, uint64_t *out,
                                                                const uint32_t *__restrict__ te0, uint32_t *err_flag, int probe)
 {
@@ -933,7 +933,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
 #define SPAN_PRF_FETCH(spx)                                                                                              \
     do {                                                                                                                 \
         const uint64_t sp_ = (spx), sc_ = sp_ < n_spans ? sp_ : n_spans - 1;                                             \
-        f_live = ln < C && sp_ < n_spans;                                                                                \
+        f_live = ln < C && sp_ < sp_end;                                                                                 \
         f0 = start[sc_ * C + ln_c]; f1 = start[(sc_ + 1) * C + ln_c];                                                    \
     } while (0)
 #define SPAN_PRF_PUBLISH(buf)                                                                                            \
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         rkv[i] = rk.w[40 + i];
         asm volatile("" : "+v"(rkv[i]));
     }
-    uint64_t sp = blockIdx.x;
+    uint64_t sp = static_cast<uint64_t>(sp_first) + blockIdx.x;        // (a launch covers the spans [sp_first, sp_end): the whole vector, or one GPU's position range)
     if (keeper) {
         SPAN_PRF_FETCH(sp); SPAN_PRF_PUBLISH(0);
         SPAN_PRF_FETCH(sp + stride); SPAN_PRF_PUBLISH(1);
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
 #ifdef FLASHE_TUNING
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
-    for (; sp < n_spans; sp += stride, buf ^= 1) {
+    for (; sp < sp_end; sp += stride, buf ^= 1) {
         const uint64_t p0 = sp * SPAN;
         const uint32_t span_len = static_cast<uint32_t>(total - p0 < SPAN ? total - p0 : SPAN);
         SPAN_PRF_TICK(7);
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         }
 #endif
         const int nbuf = buf ^ 1;
-        const uint32_t n_next = sp + stride < n_spans ? s_pb[nbuf][C].x : 0u;
+        const uint32_t n_next = sp + stride < sp_end ? s_pb[nbuf][C].x : 0u;
         // The first 1,024 entries, one per lane: its block's rounds with the lookup of the lane's entry of the NEXT span threaded
         // through them -- one step of the owner search per round (each a dependent LDS read), then the entry's position (and plaintext)
         // load and its round-1 lookups: all of it latency that the sixteen lookups per round hide.
@@ -1148,13 +1148,16 @@ hipError_t span_prf_cycles(unsigned long long *out8, bool reset)
 }
 #endif
 
-// start_dev: the bounds of exactly these lists at kSpanFused positions per span (launch_span_bounds(..., kSpanFused)).
+// start_dev: the bounds of exactly these lists at kSpanFused positions per span (launch_span_bounds).  first / count: the position
+// range the launch covers -- first a multiple of kSpanFused, first + count a multiple of it or the end of the vector; src_dev / out_dev
+// address position `first`.
 hipError_t launch_span_prf(const LaunchEnv &env, uint32_t iter, int C, const uint32_t *idx, const uint32_t *const *loc_dev, const uint64_t *k,
                            const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev, const uint64_t *sub, uint64_t base_lo, uint64_t base_hi,
-                           uint64_t total, const uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev)
+                           uint64_t total, const uint32_t *start_dev, const uint64_t *src_dev, bool negate, uint64_t *out_dev, uint64_t first, uint64_t count)
 {
     if (C > kMaxScatter || C < 1 || env.b <= 64 || (pt_dev && pt_limbs != 1 && pt_limbs != 2)) return hipErrorInvalidValue;
-    if (total == 0) return hipSuccess;
+    if (first > total || count > total - first || first % kSpanFused || (first + count != total && (first + count) % kSpanFused)) return hipErrorInvalidValue;
+    if (total == 0 || count == 0) return hipSuccess;
     SpanPrfTable tb{};
     for (int c = 0; c < C; c++) {
         if (k[c] >= (1ull << 32)) return hipErrorInvalidValue;
@@ -1168,11 +1171,16 @@ hipError_t launch_span_prf(const LaunchEnv &env, uint32_t iter, int C, const uin
     masks_of(env.b, &lo, &hi);
     const uint64_t n_spans = span_count(total, kSpanFused);
     if (n_spans >= (1ull << 32)) return hipErrorInvalidValue;
-    const dim3 grid(static_cast<unsigned>(std::min<uint64_t>(n_spans, static_cast<uint64_t>(std::max(env.num_cus, 1)))));
+    const uint32_t sp_first = static_cast<uint32_t>(first / kSpanFused), sp_end = static_cast<uint32_t>(span_count(first + count, kSpanFused));
+    // the kernel indexes the dense vectors by absolute position: pointers that address position `first` are moved back by it
+    if (src_dev) src_dev = reinterpret_cast<const uint64_t *>(reinterpret_cast<uintptr_t>(src_dev) - 16 * first);
+    out_dev = reinterpret_cast<uint64_t *>(reinterpret_cast<uintptr_t>(out_dev) - 16 * first);
+    const dim3 grid(static_cast<unsigned>(std::min<uint64_t>(sp_end - sp_first, static_cast<uint64_t>(std::max(env.num_cus, 1)))));
     const char *pe = FLASHE_TUNE_ENV("FLASHE_SPAN_PROBE");
     const int probe = pe ? atoi(pe) : 0;
 #define SPAN_PRF_LAUNCH(E)                                                                                                                    \
-    hipLaunchKernelGGL(span_prf_kernel<E>, grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), start_dev, \
+    hipLaunchKernelGGL(span_prf_kernel<E>, grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), sp_first, \
+                       sp_end, start_dev,                                                                                                          \
                        base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.te0_dev, env.err_flag, probe)
     if (!pt_dev) SPAN_PRF_LAUNCH(0);
     else if (pt_limbs == 1) SPAN_PRF_LAUNCH(1);

@@ -525,6 +525,25 @@ class HipOps:
         else:
             self.engine.packed_resolve_carry_strided_dev(n_limbs, total_bits, self._a(infos), n_below, stride_words, self._a(x))
 
+    # ---- the sparse round by position ranges ----
+    def sparse_span(self):
+        return self.engine.sparse_span()
+
+    def sparse_bounds(self, total, locs, ks, handle=None):
+        """The span bounds of the round's location lists (refs of uint32 lists): a handle, recomputed in place when one is passed."""
+        ptrs = [self._a(r) for r in locs]
+        if handle is not None:
+            return handle.recompute(ptrs, ks)
+        return self.engine.span_bounds(total, ptrs, ks)
+
+    def sparse_encrypt_aggregate(self, it, idx, locs, ks, pts, pt_limbs, zeros, total, n_jobs, cts, agg, bounds, first, count):
+        self.engine.sparse_encrypt_aggregate_dev(it, idx, [self._a(r) for r in locs], ks, [self._a(r) for r in pts], pt_limbs, zeros, total, n_jobs,
+                                                 [self._a(r) for r in cts], self._a(agg), bounds=bounds, position_range=(first, count))
+
+    def sparse_decrypt(self, it, locs, ks, total, n_jobs, agg, out, bounds, first, count):
+        self.engine.sparse_decrypt_dev(it, [self._a(r) for r in locs], ks, total, n_jobs, self._a(agg), self._a(out), bounds=bounds,
+                                       position_range=(first, count))
+
     def zero(self, ref, words):
         self.engine._check(self.engine._lib.flashe_memset_dev(self.engine._h, self._a(ref), 0, int(words) * 8))
 
@@ -964,4 +983,49 @@ class ShardedRound:
         ops.unpack(n, (total, 0), (self.k_agg, 0))
         add_idx, minus_idx = self._prefixes()
         ops.decrypt_range(it, add_idx, minus_idx, n, self.n_jobs, 0, n, (self.k_agg, 0), (self.result, 0))
+        return self.result
+
+
+class SparseShardedRound:
+    """BASELINE config 5's round -- top-s % uploads, single mask over compact positions -- sharded by POSITION ranges of the dense vector
+    (SURVEY.md 8e (i) applied to the sparse path): rank g owns the positions [g S, (g + 1) S), S a whole number of spans, and plays EVERY
+    client on them: the entries of each (sorted) location list that fall into its range are encrypted and summed in one pass
+    (flashe_sparse_encrypt_aggregate_range_dev), the range of the dense minus-mask is rebuilt and subtracted in another
+    (flashe_sparse_decrypt_range_dev).  PRF counters are compact positions of the WHOLE list, so a rank's ciphertext entries are exactly
+    those a single GPU would have produced; nothing is exchanged for the aggregate, the one collective is the optional all-gather of the
+    decrypted ranges.  Every rank holds all location lists (they are what the arbiter redistributes for the decrypt anyway) and the
+    plaintext values of the entries it owns."""
+
+    def __init__(self, ops, total, int_bits, n_clients, n_jobs, rank=0, world=1):
+        self.ops, self.total, self.b, self.C, self.n_jobs, self.rank, self.world = ops, int(total), int_bits, int(n_clients), n_jobs, rank, world
+        if int_bits <= 64:
+            raise ValueError("the position-sharded sparse round runs at int_bits > 64 (the passes with the PRF inside the span reduce)")
+        self.L = 2
+        span = ops.sparse_span()
+        n_spans = -(-self.total // span)
+        self.slice = span * (-(-n_spans // world))
+        self.first = min(self.total, rank * self.slice)
+        self.count = min(self.total, (rank + 1) * self.slice) - self.first
+        self.agg = ops.alloc(max(self.slice, 1) * self.L)
+        self.dec = ops.alloc(max(self.slice, 1) * self.L)
+        self.result = ops.alloc(world * self.slice * self.L) if world > 1 else None
+        self.bounds = None
+
+    def position_range(self):
+        return self.first, self.count
+
+    def run(self, it, locs, ks, pts, pt_limbs, zeros, cts, idx=None, gather=True):
+        """locs / pts / cts: refs per client (uint32 list, compact plaintexts, compact ciphertexts -- whole vectors; only the owned entries
+        of pts are read and of cts written); zeros: the plain quantised zero of every upload.  Returns the ref of the decrypted range
+        (gather=False / one rank) or of the whole decrypted vector."""
+        ops = self.ops
+        idx = list(range(self.C)) if idx is None else idx
+        self.bounds = ops.sparse_bounds(self.total, locs, ks, self.bounds)
+        if self.count:
+            ops.sparse_encrypt_aggregate(it, idx, locs, ks, pts, pt_limbs, zeros, self.total, self.n_jobs, cts, (self.agg, 0), self.bounds,
+                                         self.first, self.count)
+            ops.sparse_decrypt(it, locs, ks, self.total, self.n_jobs, (self.agg, 0), (self.dec, 0), self.bounds, self.first, self.count)
+        if not (gather and self.world > 1):
+            return self.dec
+        ops.all_gather((self.dec, 0), (self.result, 0), self.slice * self.L)
         return self.result

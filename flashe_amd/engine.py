@@ -789,10 +789,12 @@ class Engine:
         self._check(self._lib.flashe_sparse_aggregate_dev(self._h, total, len(locs), pl, ctypes.cast(k, c_u64p), pv,
                                                           ctypes.cast(zz, c_u64p), 1 if sorted_lists else 0, self._ptr(out)))
 
-    def sparse_encrypt_aggregate_dev(self, it, idx, locs, ks, pts, pt_limbs, zeros, total, n_jobs, cts, agg, bounds=None):
+    def sparse_encrypt_aggregate_dev(self, it, idx, locs, ks, pts, pt_limbs, zeros, total, n_jobs, cts, agg, bounds=None, position_range=None):
         """The clients this device plays encrypt their compact uploads (single mask) and the sum of the expanded uploads is written in
         the same pass: cts[c] = encrypt(it, idx[c], SINGLE) of pts[c], agg = sparse_aggregate_dev(locs, cts, zeros).  Strictly increasing
-        location lists.  int_bits > 64: one persistent launch per 64 clients with the PRF inside the span reduce."""
+        location lists.  int_bits > 64: one persistent launch per 64 clients with the PRF inside the span reduce.
+        position_range = (first, count): only the positions [first, first + count) -- one GPU's share of a round sharded by position ranges;
+        `agg` then addresses position `first`, the ciphertexts of entries outside the range are not written."""
         pl, _kl = self._ptr_array(locs)
         pp, _kp = self._ptr_array(pts)
         pc, _kc = self._ptr_array(cts)
@@ -800,9 +802,21 @@ class Engine:
         k = _u64_array(ks)
         ii = idx if isinstance(idx, ctypes.Array) else (ctypes.c_uint32 * max(C, 1))(*[int(v) for v in idx])
         zz = self._zeros_array(zeros)
+        if position_range is not None:
+            first, count = position_range
+            if bounds is None:
+                raise ValueError("a position range needs the span bounds of the lists")
+            self._check(self._lib.flashe_sparse_encrypt_aggregate_range_dev(self._h, it, n_jobs, total, C, ii, pl, ctypes.cast(k, c_u64p), pp, pt_limbs,
+                                                                            ctypes.cast(zz, c_u64p), bounds._h, int(first), int(count), pc, self._ptr(agg)))
+            return
         self._check(self._lib.flashe_sparse_encrypt_aggregate_dev(self._h, it, n_jobs, total, C, ii, pl, ctypes.cast(k, c_u64p), pp, pt_limbs,
                                                                   ctypes.cast(zz, c_u64p), bounds._h if bounds is not None else None, pc,
                                                                   self._ptr(agg)))
+
+    def sparse_span(self):
+        """Positions per span of the sparse passes with the PRF inside: position ranges start (and, unless they end the vector, end) at
+        multiples of it."""
+        return int(self._lib.flashe_sparse_span())
 
     def sparse_minus_mask_dev(self, it, locs, ks, total, n_jobs, out, sorted_lists=False):
         p, _keep = self._ptr_array(locs)
@@ -810,10 +824,18 @@ class Engine:
         fn = self._lib.flashe_sparse_minus_mask_sorted_dev if sorted_lists else self._lib.flashe_sparse_minus_mask_dev
         self._check(fn(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, self._ptr(out)))
 
-    def sparse_decrypt_dev(self, it, locs, ks, total, n_jobs, agg, out, sorted_lists=False, bounds=None):
-        """out = (agg - dense minus-mask of the location lists) mod 2^b in the pass that builds the mask."""
+    def sparse_decrypt_dev(self, it, locs, ks, total, n_jobs, agg, out, sorted_lists=False, bounds=None, position_range=None):
+        """out = (agg - dense minus-mask of the location lists) mod 2^b in the pass that builds the mask.  position_range = (first, count):
+        agg / out address position `first` and hold `count` elements (needs bounds)."""
         p, _keep = self._ptr_array(locs)
         k = _u64_array(ks)
+        if position_range is not None:
+            first, count = position_range
+            if bounds is None:
+                raise ValueError("a position range needs the span bounds of the lists")
+            self._check(self._lib.flashe_sparse_decrypt_range_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, bounds._h,
+                                                                  int(first), int(count), self._ptr(agg), self._ptr(out)))
+            return
         if bounds is not None:
             self._check(self._lib.flashe_sparse_decrypt_bounds_dev(self._h, it, len(locs), p, ctypes.cast(k, c_u64p), total, n_jobs, bounds._h,
                                                                    self._ptr(agg), self._ptr(out)))

@@ -55,6 +55,7 @@ typedef struct flashe_ctx flashe_ctx;
  *      flashe_packed_resolve_carry_strided_dev (element-sharded multi-GPU round); flashe_aggregate_elem_u32_dev; flashe_mt19937_plan;
  *      flashe_sparse_encrypt_aggregate_dev (the clients' sparse encrypts and the aggregate of their uploads in one pass);
  *      flashe_unquantize_model_dev (the model-wide codec back end without a decrypt: the sparse job's way back);
+ *      flashe_sparse_span, flashe_sparse_encrypt_aggregate_range_dev, flashe_sparse_decrypt_range_dev (the sparse round by position ranges);
  *      timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only) */
 #define FLASHE_ABI_VERSION 2
 int flashe_abi_version(void);
@@ -437,6 +438,19 @@ int flashe_sparse_encrypt_aggregate_dev(flashe_ctx *ctx, uint32_t iter, uint32_t
                                         const uint32_t *const *loc_dev, const uint64_t *k, const uint64_t *const *pt_dev, int pt_limbs,
                                         const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t *const *ct_dev,
                                         uint64_t *agg_out_dev);
+/* The sparse round sharded by POSITION ranges over several GPUs (new; SURVEY 8e (i) for the sparse path): GPU g owns the positions
+ * [first, first + count) of the dense vector and runs every client's entries that fall into them -- counters and list indices stay
+ * global (the full lists and their bounds handle are passed), nothing is exchanged for the aggregate.  first is a multiple of
+ * flashe_sparse_span(), first + count one or the end of the vector; agg_out_dev / agg_dev / out_dev address position `first`; only the
+ * ciphertexts of entries inside the range are written.  int_bits > 64 on the table PRF, strictly increasing lists, bounds required. */
+int flashe_sparse_span(void);
+int flashe_sparse_encrypt_aggregate_range_dev(flashe_ctx *ctx, uint32_t iter, uint32_t n_jobs, uint64_t total, int C, const uint32_t *idx,
+                                              const uint32_t *const *loc_dev, const uint64_t *k, const uint64_t *const *pt_dev,
+                                              int pt_limbs, const uint64_t *zeros, const flashe_span_bounds *bounds, uint64_t first,
+                                              uint64_t count, uint64_t *const *ct_dev, uint64_t *agg_out_dev);
+int flashe_sparse_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc_dev, const uint64_t *k,
+                                    uint64_t total, uint32_t n_jobs, const flashe_span_bounds *bounds, uint64_t first, uint64_t count,
+                                    const uint64_t *agg_dev, uint64_t *out_dev);
 int flashe_sparse_minus_mask(flashe_ctx *ctx, uint32_t iter, int C, const uint32_t *const *loc,
                              const uint64_t *k, uint64_t total, uint32_t n_jobs, uint64_t *out);
 /* Dense-position selected masks -- _static_prepare_decrypt_spar as ONE chunk

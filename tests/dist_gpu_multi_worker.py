@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from flashe_amd.dist import HipOps, ShardedRound, deal_clients  # noqa: E402
+from flashe_amd.dist import HipOps, ShardedRound, SparseShardedRound, deal_clients  # noqa: E402
 from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine  # noqa: E402
 from oracle import flashe_oracle as orc  # noqa: E402
 from shm_comm import ShmComm  # noqa: E402
@@ -101,6 +101,34 @@ def main():
         ptsp = [(ops.upload(host[c][lo:lo + cnt]) if cnt else ops.alloc(2), 0) for c in range(C)]
         out = rnd.run_packed(4, ptsp, 1)
         assert np.array_equal(ops.read((out, 0), n * L).reshape(n, L), want_packed), (rank, b, n, C, "elements packed")
+    # ---- the sparse round sharded by POSITION ranges (SparseShardedRound): every rank plays every client on the spans it owns, real kernels
+    # (flashe_sparse_encrypt_aggregate_range_dev / flashe_sparse_decrypt_range_dev), the decrypted ranges all-gathered
+    for b, total, C, k, J in [(128, 300_007, 10, 3_000, 16), (100, 70_001, 3, 700, 16), (128, 1_752 * 2 + 9, 4, 200, 1), (128, 999, 2, 999, 16),
+                              (128, 500_000, 70, 400, 16)]:
+        L = 2
+        eng = Engine(KEY, b, device=0)
+        ops = HipOps(eng, None, comm)
+        rng = [np.random.Generator(np.random.PCG64(270 + c)) for c in range(C)]
+        ks = [k if c != 1 else max(k // 3, 1) for c in range(C)]
+        locs = [np.sort(r.choice(total, kc, replace=False)).astype(np.uint32) for r, kc in zip(rng, ks)]
+        vals = [r.integers(0, 2 ** 60, kc, dtype=np.uint64) for r, kc in zip(rng, ks)]
+        zeros = [17 + c for c in range(C)]
+        rnd = SparseShardedRound(ops, total, b, C, J, rank=rank, world=world)
+        first, count = rnd.position_range()
+        rl, rp = [(ops.upload(l), 0) for l in locs], [(ops.upload(v), 0) for v in vals]
+        rc = [(ops.alloc(max(kc, 1) * L), 0) for kc in ks]
+        out = rnd.run(6, rl, ks, rp, 1, zeros, rc)
+        want = np.full(total, np.uint64(sum(zeros)), dtype=np.uint64)
+        for c in range(C):
+            want[locs[c]] += vals[c] - np.uint64(zeros[c])
+        got = ops.read((out, 0), total * L).reshape(total, L)
+        hi_mask = np.uint64((1 << (b - 64)) - 1) if b < 128 else np.uint64(2 ** 64 - 1)
+        assert np.array_equal(got[:, 0], want) and not (got[:, 1] & hi_mask).any(), (rank, b, total, C, "sparse position-sharded")
+        for c in range(C):                              # this rank's ciphertext entries = the whole-list encrypt's, the others untouched
+            full = orc.encrypt(KEY, 6, c, "single", J, b, vals[c])
+            mine = (locs[c] >= first) & (locs[c] < first + count)
+            have = ops.read(rc[c], ks[c] * L).reshape(ks[c], L)
+            assert np.array_equal(have[mine], full[mine]) and not have[~mine].any(), (rank, b, c, "sparse ct entries")
     # carries rippling through whole element slices of the packed integer
     for b, n in [(128, 256 * world + 5), (64, 300 * world), (20, 256 * world + 17)]:
         L = 2 if b > 64 else 1

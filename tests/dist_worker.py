@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from flashe_amd.dist import ShardedRound, deal_clients  # noqa: E402
+from flashe_amd.dist import ShardedRound, SparseShardedRound, deal_clients  # noqa: E402
 from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE  # noqa: E402
 from oracle import flashe_oracle as orc  # noqa: E402
 from oracle_ops import GlooComm, OracleOps  # noqa: E402
@@ -164,6 +164,54 @@ class CraftedRangeOps(OracleOps):
             self._v(ct, count)[:] = self.patterns[i][first:first + count]
 
 
+def sparse_position_sharded_rounds(rank, world, comm):
+    """SparseShardedRound -- SURVEY.md 8e (i) for the sparse path: every rank plays EVERY client on its own position range of the dense
+    vector (whole spans); the gathered result must be the plain sparse sum, every rank's ciphertext entries those of the whole-list
+    encrypt, and the ranges must tile the vector."""
+    for b, total, C, k, n_jobs in [(128, 20_000, 5, 700, 16), (100, 1_752 * 2 + 5, 3, 60, 1), (128, 900, 4, 900, 16), (128, 1_752 * world, 2, 100, 16)]:
+        L = 2
+        ops = OracleOps(b, comm)
+        rnd = SparseShardedRound(ops, total, b, C, n_jobs, rank=rank, world=world)
+        first, count = rnd.position_range()
+        assert (count == 0 or first % ops.sparse_span() == 0) and first + count <= total
+        rng = [np.random.Generator(np.random.PCG64(500 + c)) for c in range(C)]
+        ks = [k if c != 1 else max(k // 3, 1) for c in range(C)]
+        locs = [np.sort(r.choice(total, kc, replace=False)).astype(np.uint32) for r, kc in zip(rng, ks)]
+        vals = [r.integers(0, 2 ** 60, kc, dtype=np.uint64) for r, kc in zip(rng, ks)]
+        zeros = [11 + c for c in range(C)]
+        idx = [7 * c + 1 for c in range(C)]
+
+        rl, rp = [(ops.upload(l), 0) for l in locs], [(ops.upload(v), 0) for v in vals]
+        rc = [(ops.alloc(max(kc, 1) * L), 0) for kc in ks]
+        out = rnd.run(9, rl, ks, rp, 1, zeros, rc, idx=idx)
+        want = np.full(total, np.uint64(sum(zeros)), dtype=np.uint64)
+        for c in range(C):
+            want[locs[c]] += vals[c] - np.uint64(zeros[c])
+        # the decrypt subtracts the masks of prefixes 0 .. C-1 (set_idx_list_single's sparse branch): with idx = range(C) the round trip
+        # is the plain sum; with other indices compare with the oracle's own aggregate - mask
+        cts_full = [orc.encrypt(KEY, 9, idx[c], "single", n_jobs, b, vals[c]) for c in range(C)]
+        agg = np.zeros((total, L), dtype=np.uint64)
+        for c in range(C):
+            agg = orc.aggregate_elem([agg, orc.expand_to_dense(total, locs[c], cts_full[c], np.array([[zeros[c], 0]], dtype=np.uint64), b)], b)
+        ref = orc.combine(b, agg, None, orc.sparse_minus_mask(KEY, 9, locs, total, n_jobs, b))
+        res = result_of(ops, out, total, L) if world > 1 else None
+        if world > 1:
+            assert np.array_equal(res, ref), (rank, b, total, C, "gathered")
+        own = result_of(ops, rnd.run(9, rl, ks, rp, 1, zeros, rc, idx=idx, gather=False), count, L) if count else np.zeros((0, L), dtype=np.uint64)
+        assert np.array_equal(own, ref[first:first + count]), (rank, b, total, C, "own range")
+        for c in range(C):
+            mine = (locs[c] >= first) & (locs[c] < first + count)
+            got = ops.read(rc[c], ks[c] * L).reshape(ks[c], L)
+            assert np.array_equal(got[mine], cts_full[c][mine]) and not got[~mine].any(), (rank, c, "ciphertext entries")
+        # with the clients' own indices 0 .. C-1 the round trip is the plain sparse sum
+        out2 = rnd.run(9, rl, ks, rp, 1, zeros, rc, gather=False)
+        own2 = result_of(ops, out2, count, L) if count else np.zeros((0, L), dtype=np.uint64)
+        mask_b = np.uint64((1 << 64) - 1)
+        assert np.array_equal(own2[:, 0] & mask_b, want[first:first + count]), (rank, b, total, "plain sum")
+        # the ranges tile the vector: rank g owns [g S, min(total, (g + 1) S)), S whole spans
+        assert first == min(total, rank * rnd.slice) and first + count == min(total, (rank + 1) * rnd.slice) and world * rnd.slice >= total
+
+
 def main():
     dist.init_process_group("gloo")
     comm = GlooComm()
@@ -212,6 +260,7 @@ def main():
                 assert np.array_equal(res[:, 0], want), (rank, b, n, clients, "allreduce", partial)
     packed_rounds(rank, world, comm)
     element_sharded_rounds(rank, world, comm)
+    sparse_position_sharded_rounds(rank, world, comm)
     assert ops.allreduce(float(rank), 0) == world - 1 and ops.allreduce(float(rank + 1), 1) == 1.0
     dist.barrier()
     if rank == 0:

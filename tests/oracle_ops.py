@@ -67,8 +67,10 @@ class OracleOps:
         return HostBuf(max(int(words), 2))
 
     def upload(self, arr):
-        buf = HostBuf(max(np.asarray(arr).size, 2))
-        buf.a[: np.asarray(arr).size] = np.ascontiguousarray(arr).reshape(-1).view(np.uint64)
+        raw = np.ascontiguousarray(arr).reshape(-1).view(np.uint8)              # any element type (uint32 location lists too)
+        raw = np.concatenate([raw, np.zeros(-raw.size % 8, dtype=np.uint8)]).view(np.uint64)
+        buf = HostBuf(max(raw.size, 2))
+        buf.a[:raw.size] = raw
         return buf
 
     def _w(self, ref, words):
@@ -180,6 +182,32 @@ class OracleOps:
         a[:] = np.frombuffer(v.to_bytes(8 * n_limbs, "little"), dtype=np.uint64)
 
     # ---- exchange ----
+    # ---- the sparse round by position ranges (host restatement: whole vectors through the oracle, then the owned range) ----
+    def sparse_span(self):
+        return 1752                                   # any span size works for the arithmetic; the device's is used so that the ranges match
+
+    def sparse_bounds(self, total, locs, ks, handle=None):
+        return "bounds"
+
+    def _list(self, ref, k):
+        buf, off = ref
+        return buf.a[off:].view(np.uint32)[:k].copy()
+
+    def sparse_encrypt_aggregate(self, it, idx, locs, ks, pts, pt_limbs, zeros, total, n_jobs, cts, agg, bounds, first, count):
+        acc = np.zeros((total, self.L), dtype=np.uint64)
+        for c, (i, k) in enumerate(zip(idx, ks)):
+            loc = self._list(locs[c], k)
+            full = orc.encrypt(KEY, it, i, "single", n_jobs, self.b, np.ascontiguousarray(self._v(pts[c], k, pt_limbs))) if k else np.zeros((0, self.L), dtype=np.uint64)
+            own = (loc >= first) & (loc < first + count)
+            self._v(cts[c], k)[own] = full[own]       # (entries of other ranges: not this rank's to write)
+            z = np.array([[int(zeros[c])] + [0] * (self.L - 1)], dtype=np.uint64)
+            acc = orc.aggregate_elem([acc, orc.expand_to_dense(total, loc, full, z, self.b)], self.b)
+        self._v(agg, count)[:] = acc[first:first + count]
+
+    def sparse_decrypt(self, it, locs, ks, total, n_jobs, agg, out, bounds, first, count):
+        mask = orc.sparse_minus_mask(KEY, it, [self._list(l, k) for l, k in zip(locs, ks)], total, n_jobs, self.b)
+        self._v(out, count)[:] = orc.combine(self.b, np.ascontiguousarray(self._v(agg, count)), None, np.ascontiguousarray(mask[first:first + count]))
+
     def all_to_all(self, send, send_stride, recv, recv_stride, words, side=False):
         sb, so = send
         rb, ro = recv

@@ -78,6 +78,30 @@ def test_single_rank_element_sharding(oracle):
             assert np.array_equal(ops.read((rnd.run_packed(3, refs, 1), 0), n * L).reshape(n, L), wantp), (b, n, force, "packed")
 
 
+def test_single_rank_sparse_position_sharding(oracle):
+    """SparseShardedRound on one rank: the position range is the whole vector, the round trip is the plain sparse sum."""
+    import numpy as np
+    from flashe_amd.dist import SparseShardedRound
+    from oracle_ops import OracleOps
+    b, total, C, k = 128, 7_000, 4, 250
+    ops = OracleOps(b)
+    rnd = SparseShardedRound(ops, total, b, C, 16)
+    assert rnd.position_range() == (0, total)
+    rng = [np.random.Generator(np.random.PCG64(900 + c)) for c in range(C)]
+    locs = [np.sort(r.choice(total, k, replace=False)).astype(np.uint32) for r in rng]
+    vals = [r.integers(0, 2 ** 60, k, dtype=np.uint64) for r in rng]
+    rl, rp = [(ops.upload(l), 0) for l in locs], [(ops.upload(v), 0) for v in vals]
+    rc = [(ops.alloc(2 * k), 0) for _ in range(C)]
+    out = rnd.run(2, rl, [k] * C, rp, 1, [5] * C, rc)
+    want = np.full(total, np.uint64(5 * C), dtype=np.uint64)
+    for c in range(C):
+        want[locs[c]] += vals[c] - np.uint64(5)
+    res = ops.read((out, 0), 2 * total).reshape(total, 2)
+    assert np.array_equal(res[:, 0], want) and not res[:, 1].any()
+    for c in range(C):
+        assert np.array_equal(ops.read(rc[c], 2 * k).reshape(k, 2), oracle.encrypt(KEY, 2, c, "single", 16, b, vals[c]))
+
+
 def test_rendezvous_file_hands_the_id_to_every_rank(tmp_path, monkeypatch):
     """The torch-free rendezvous of flashe_amd.dist: rank 0 publishes 128 bytes atomically, the others poll for them."""
     import threading

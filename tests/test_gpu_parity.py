@@ -674,6 +674,17 @@ def _bench_shm(tmp_path, extra, env_extra=None, timeout=600):
     return r, [json.loads(l) for l in lines], time.time() - t0
 
 
+def test_bench_multi_rank_sparse_round(tmp_path):
+    """`bench.py --config 5 --gpus 3` through the comm double: `value` = every rank its own round (replicas), beside it ONE round shared by
+    the ranks by position ranges of the dense vector (SparseShardedRound, parity-gated in-run against the plain sparse sum)."""
+    r, lines, _ = _bench_shm(tmp_path, ["--config", "5", "--clients", "6"])
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = lines[0]
+    assert d["n_gpus"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and "independent replicas" in d["config"]["workload"]
+    assert d["value_position_sharded"] > 0 and d["value_position_sharded_no_gather"] > 0 and d["ms_per_step_position_sharded"] > 0
+
+
 @pytest.mark.parametrize("extra", [["--config", "2", "--clients", "3"], ["--config", "4", "--clients", "5"]])
 def test_bench_multi_rank_flow(extra, tmp_path):
     """bench.py's own N > 1 glue -- process spawn, per-rank parity gate with agreement between ranks, the sequential round timed first,
@@ -1722,3 +1733,63 @@ def test_span_bounds_with_lists_at_any_alignment(E, oracle):
     assert np.array_equal(outs[0][1].reshape(total, 2), oracle.combine(128, outs[0][0].reshape(total, 2), None, want))
     for a, d in outs[1:]:
         assert np.array_equal(a, outs[0][0]) and np.array_equal(d, outs[0][1])
+
+
+@pytest.mark.parametrize("b,C,total,k,parts", [(128, 7, 100_003, 2_000, 3), (128, 70, 50_000, 300, 8), (100, 5, 1_752 * 4, 500, 4), (128, 3, 9_000, 9_000, 5),
+                                              (128, 4, 1_000, 100, 3)])
+def test_sparse_round_sharded_by_position_ranges(E, oracle, b, C, total, k, parts):
+    """flashe_sparse_encrypt_aggregate_range_dev / flashe_sparse_decrypt_range_dev: the dense vector cut into `parts` position ranges
+    (span-aligned, the way the GPUs of a node would share a sparse round) -- every range run on its own, its aggregate and decrypt slices
+    laid side by side equal the whole-vector calls and the oracle; the ciphertext entries a range writes are exactly the entries whose
+    position it owns; ranges that are not span-aligned are refused; empty ranges (more parts than spans) do nothing."""
+    from flashe_amd._lib import FlasheError
+    eng = make(E, b)
+    span = eng.sparse_span()
+    rng = np.random.Generator(np.random.PCG64(b + C + parts))
+    ks = [k] * C
+    if C >= 3:
+        ks[1], ks[2] = max(k // 4, 1), 0
+    locs = [np.sort(rng.choice(total, kc, replace=False)).astype(np.uint32) for kc in ks]
+    pts = [rng.integers(0, 2 ** 62, kc, dtype=np.uint64) for kc in ks]
+    idx = [(5 * c + 2) % 89 for c in range(C)]
+    zeros = [3 + c for c in range(C)]
+    dl = [eng.upload(l) if l.size else eng.alloc(16) for l in locs]
+    dp = [eng.upload(p) if p.size else eng.alloc(16) for p in pts]
+    bnd = eng.span_bounds(total, dl, ks)
+    # the whole vector at once
+    cts0 = [eng.alloc_vec(max(kc, 1)) for kc in ks]
+    agg0, dec0 = eng.alloc_vec(total), eng.alloc_vec(total)
+    eng.sparse_encrypt_aggregate_dev(4, idx, dl, ks, dp, 1, zeros, total, 16, cts0, agg0, bounds=bnd)
+    # (the decrypt twin subtracts the masks of prefixes 0 .. C-1: a consistency check of the range form against the whole-vector form)
+    eng.sparse_decrypt_dev(4, dl, ks, total, 16, agg0, dec0, sorted_lists=True, bounds=bnd)
+    want_agg, want_dec = agg0.download(np.uint64, 2 * total), dec0.download(np.uint64, 2 * total)
+    # position ranges: `parts` contiguous runs of whole spans
+    n_spans = (total + span - 1) // span
+    edges = [min(total, span * ((n_spans * g) // parts)) for g in range(parts)] + [total]
+    cts = [eng.alloc_vec(max(kc, 1)) for kc in ks]
+    for c_ in cts:
+        eng.memset_dev(c_, 0xee, c_.nbytes)
+    got_agg, got_dec = np.zeros(2 * total, dtype=np.uint64), np.zeros(2 * total, dtype=np.uint64)
+    for g in range(parts):
+        first, count = edges[g], edges[g + 1] - edges[g]
+        sl_a, sl_d = eng.alloc_vec(max(count, 1)), eng.alloc_vec(max(count, 1))
+        eng.sparse_encrypt_aggregate_dev(4, idx, dl, ks, dp, 1, zeros, total, 16, cts, sl_a, bounds=bnd, position_range=(first, count))
+        eng.sparse_decrypt_dev(4, dl, ks, total, 16, sl_a, sl_d, bounds=bnd, position_range=(first, count))
+        if count:
+            got_agg[2 * first:2 * (first + count)] = sl_a.download(np.uint64, 2 * count)
+            got_dec[2 * first:2 * (first + count)] = sl_d.download(np.uint64, 2 * count)
+        # so far exactly the entries at positions below edges[g + 1] carry their ciphertext
+        for c in range(C):
+            if ks[c]:
+                have = cts[c].download(np.uint64, 2 * ks[c]).reshape(ks[c], 2)
+                ref = cts0[c].download(np.uint64, 2 * ks[c]).reshape(ks[c], 2)
+                done = locs[c] < edges[g + 1]
+                assert np.array_equal(have[done], ref[done]) and np.all(have[~done] == np.uint64(0xeeeeeeeeeeeeeeee)), (g, c)
+    assert np.array_equal(got_agg, want_agg) and np.array_equal(got_dec, want_dec), (b, C, parts)
+    mask = oracle.sparse_minus_mask(KEY, 4, locs, total, 16, b)
+    assert np.array_equal(got_dec.reshape(total, 2), oracle.combine(b, want_agg.reshape(total, 2), None, mask))
+    if total > span + 5:
+        with pytest.raises(FlasheError):
+            eng.sparse_decrypt_dev(4, dl, ks, total, 16, agg0, dec0, bounds=bnd, position_range=(5, span))
+        with pytest.raises(FlasheError):
+            eng.sparse_decrypt_dev(4, dl, ks, total, 16, agg0, dec0, bounds=bnd, position_range=(0, span + 1))
