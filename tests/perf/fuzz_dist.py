@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off fuzz of the sharded round with real kernels: random world sizes (ranks share GPU 0, exchange through tests/shm_comm.py),
 vector lengths, bit widths, dealings and chunk counts; every schedule of the client-sharded round and -- round 4 -- the element-sharded round
-(element-wise with / without the partial aggregate, and packed) against the oracle.  usage: fuzz_dist.py [cases] [seed]"""
+(element-wise with / without the partial aggregate, and packed) and the sparse round sharded by position ranges against the oracle.  usage: fuzz_dist.py [cases] [seed]"""
 import json
 import os
 import subprocess
@@ -13,7 +13,7 @@ WORKER = r'''
 import json, os, sys
 import numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
-from flashe_amd.dist import HipOps, ShardedRound, deal_clients
+from flashe_amd.dist import HipOps, ShardedRound, SparseShardedRound, deal_clients
 from flashe_amd.engine import SCHEME_DOUBLE, SCHEME_SINGLE, Engine
 from oracle import flashe_oracle as orc
 from shm_comm import ShmComm
@@ -57,6 +57,22 @@ for b, n, C, J, dbl, chunks in json.loads(os.environ["CASES"]):
     ppts = [(ops.upload(host[c][lo:lo + cnt]) if cnt else ops.alloc(2), 0) for c in range(C)]
     got = ops.read((ernd.run_packed(2, ppts, 1), 0), n * L).reshape(n, L)
     assert np.array_equal(got, wantp), (rank, world, b, n, C, J, dbl, "elements packed")
+    if b > 64:
+        # the sparse round by position ranges (round 4): the same vector length as the dense total, random list lengths per client
+        sr = np.random.Generator(np.random.PCG64(n + 31 * C))
+        ks = [int(sr.integers(0, min(n, 3000) + 1)) for _ in range(C)]
+        locs = [np.sort(sr.choice(n, kc, replace=False)).astype(np.uint32) for kc in ks]
+        vals = [sr.integers(0, 2 ** 60, kc, dtype=np.uint64) for kc in ks]
+        zs = [int(z) for z in sr.integers(0, 2 ** 31, C)]
+        srnd = SparseShardedRound(ops, n, b, C, J, rank=rank, world=world)
+        rl = [(ops.upload(l) if l.size else ops.alloc(2), 0) for l in locs]
+        rp = [(ops.upload(v) if v.size else ops.alloc(2), 0) for v in vals]
+        rc = [(ops.alloc(max(kc, 1) * 2), 0) for kc in ks]
+        got = ops.read((srnd.run(3, rl, ks, rp, 1, zs, rc), 0), n * 2).reshape(n, 2)
+        want_s = np.full(n, np.uint64(sum(zs) & (2 ** 64 - 1)), dtype=np.uint64)
+        for c in range(C):
+            want_s[locs[c]] += vals[c] - np.uint64(zs[c])
+        assert np.array_equal(got[:, 0], want_s), (rank, world, b, n, C, J, "sparse position-sharded")
 comm.barrier(eng)
 print("OK")
 ''' % (ROOT, ROOT)
