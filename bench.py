@@ -444,9 +444,44 @@ def traffic_ratio(kernel_key):
     """Measured HBM bytes per algorithmic byte of a kernel, from the committed rocprofv3 PMC passes (profiles/traffic.json)."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return tj.get("kernels", {}).get(kernel_key, {}).get("hbm_bytes_per_algorithmic_byte"), tj.get("source")
+        ent = tj.get("kernels", {}).get(kernel_key, {})
+        # the passes THIS kernel's ratio comes from (the file's top-level "source" is whatever tag was summarised last)
+        return ent.get("hbm_bytes_per_algorithmic_byte"), ent.get("measured_in") or tj.get("source")
     except Exception:
         return None, None
+
+
+XGMI_LINK_GBPS = 153.0      # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU, every GPU pair its own link)
+HBM_STREAM_GBPS = 5900.0    # what the C-way mod-add reduce streams at on one MI355X (profiles/: aggregate_elem_kernel 5.9 TB/s)
+
+
+def predict_multi_gpu_ms(n, b, per_rank_clients, world, aes_blocks_per_s, partial=True):
+    """DESIGN.md section 5's cost model of the dense round on `world` GPUs, evaluated with THIS run's measured AES rate (blocks/s of the
+    chained encrypt launch on rank 0) and one xGMI link per GPU pair at XGMI_LINK_GBPS per direction; collectives NOT overlapped (the
+    sequential schedule).  per_rank_clients: how many clients each rank plays (client sharding); element sharding plays all of them on
+    n / world elements.  A model to read the first multi-GPU measurement against, not a measurement."""
+    L = 2 if b > 64 else 1
+    m = 1 if L == 2 else 128 // b
+    blocks = lambda streams, elems: streams * (-(-int(elems) // m))                  # noqa: E731
+    ms = lambda secs: secs * 1e3                                                      # noqa: E731
+    cmax, total = max(per_rank_clients), sum(per_rank_clients)
+    piece = -(-n // world)                                                            # elements of one exchanged slice
+    piece_bytes = piece * 8 * L
+    link = piece_bytes / (XGMI_LINK_GBPS * 1e9) if world > 1 else 0.0                 # every peer's piece travels on its own link, concurrently
+    enc = blocks(cmax + 1, n) / aes_blocks_per_s                                      # the busiest rank's chain: C_max + 1 streams
+    local_reduce = 0.0 if partial else (cmax + 1) * n * 8 * L / (HBM_STREAM_GBPS * 1e9)
+    slice_dec = max(blocks(2, piece) / aes_blocks_per_s, (world + 2) * piece_bytes / (HBM_STREAM_GBPS * 1e9))
+    client = {"encrypt_busiest_rank": ms(enc), "local_reduce": ms(local_reduce), "all_to_all": ms(link), "reduce_decrypt_of_the_slice": ms(slice_dec),
+              "all_gather": ms(link)}
+    client["round"] = sum(client.values())
+    el_aes = (blocks(total + 1, piece) + blocks(2, piece)) / aes_blocks_per_s
+    elem = {"encrypt_plus_decrypt_of_the_slice": ms(el_aes), "all_gather": ms(link)}
+    elem["round_no_gather"] = ms(el_aes)
+    elem["round"] = ms(el_aes) + ms(link)
+    return {"client_sharded_sequential": client, "element_sharded": elem,
+            "inputs": {"aes_blocks_per_s_measured_this_run": aes_blocks_per_s, "xgmi_link_GBps_per_direction": XGMI_LINK_GBPS,
+                       "hbm_stream_GBps": HBM_STREAM_GBPS, "world": world, "clients_per_rank": list(per_rank_clients), "n": n, "int_bits": b},
+            "note": "DESIGN.md section 5's model (collectives not overlapped, one xGMI link per GPU pair), NOT a measurement"}
 
 
 # ---- configs 2 and 4: dense double-mask round, clients sharded over ranks ------------------------------------------------
@@ -743,6 +778,25 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
         if rank == 0 and line is not None:
             line.update(extra)
         state["reason_key"] = None
+    if rank == 0 and line is not None and (world > 1 or args.force_dist):
+        # what the schedules that ran SHOULD cost by DESIGN.md section 5's model, with this run's own AES rate: lets a reader of the first
+        # real multi-GPU line tell "the exchange is slow" from "the partition has a low ceiling" without the design document
+        per_rank = [len(x) for x in deal_clients(total, world)] if cfg != 2 else [C] * world
+        rate = (seq_line or line)["roofline"]["aes_blocks_per_s"]
+        pred = predict_multi_gpu_ms(n, b, per_rank, world, rate, partial=partial)
+        line["predicted_ms"] = pred
+        seq_ms = line.get("sequential_ms_per_step") or (line["ms_per_step"] if line["config"]["schedule_name"] in ("sequential", "partial-agg") else None)
+        ratios = {"schedule_that_ran_over_sequential_model": line["ms_per_step"] / pred["client_sharded_sequential"]["round"]}
+        if seq_ms:
+            ratios["sequential_over_model"] = seq_ms / pred["client_sharded_sequential"]["round"]
+        for key, mk in (("ms_per_step_element_sharded", "round"), ("ms_per_step_element_sharded_no_gather", "round_no_gather")):
+            if line.get(key):
+                ratios[key.replace("ms_per_step_", "") + "_over_model"] = line[key] / pred["element_sharded"][mk]
+        line["scale_check"] = {"rccl_world_is_n": rccl_world == world, "ranks_counted_by_allreduce_is_n": ranks_counted == world,
+                               "ranks_parity_ok": bool(line["config"].get("ranks_parity_ok")), "measured_over_predicted": ratios,
+                               "how_to_read": "ratios near 1 = the run behaves as modelled; `value` is north_star's client sharding, whose model "
+                                              "ceiling at 8 GPUs is ~2.5x for config 4 (stream sharing needs consecutive clients on one GPU); "
+                                              "value_element_sharded is the partition that scales"}
     wd.arm(args.deadline, "closing")
     if rank != 0:
         return None
@@ -1243,15 +1297,31 @@ def bench_sparse(args, total, ops, rank, world, out):
     bounds = eng.span_bounds(total, t_loc, t_k) if use_bounds else None
     step = step_fused if fused_ok else step_separate
     orc.build()
-    want = np.full(total, np.uint64((C * zero) & (2 ** 64 - 1)), dtype=np.uint64)
+    # the expected dense result as FULL-WIDTH integers (both limbs: with 64-bit values and 50 clients nearly every touched position carries
+    # into the high limb): (C - #clients holding p) * zero + the 128-bit sum of the values uploaded for p, mod 2^b
+    want = np.zeros((total, L), dtype=np.uint64)
+    held = np.zeros(total, dtype=np.uint64)
     for c in range(C):
-        want[locs[c]] += vals[c] - np.uint64(zero)
+        old = want[locs[c], 0]
+        new = old + vals[c]
+        want[locs[c], 0] = new
+        if L == 2:
+            want[locs[c], 1] += (new < old).astype(np.uint64)
+        held[locs[c]] += np.uint64(1)
+    rest = (np.uint64(C) - held) * np.uint64(zero)
+    new = want[:, 0] + rest
+    if L == 2:
+        want[:, 1] += (new < want[:, 0]).astype(np.uint64)
+    want[:, 0] = new
+    if b % 64:
+        want[:, L - 1] &= np.uint64((1 << (b % 64)) - 1)
+    del held, rest, new
     for st in ([step_fused, step_separate] if fused_ok else [step_separate]):
         d_dec.upload(np.zeros(16, dtype=np.uint64))
         st(0)
         # parity: the decrypted dense vector == sum over clients of (value at its locations, zero elsewhere)
         got = d_dec.download(np.uint64, total * L).reshape(total, L)
-        assert np.array_equal(got[:, 0], want if b >= 64 else want & np.uint64((1 << b) - 1)), "PARITY FAILURE (sparse round trip)"
+        assert np.array_equal(got, want), "PARITY FAILURE (sparse round trip, every limb)"
         for c in (3, C - 1):
             assert np.array_equal(d_ct[c].download(np.uint64, k * L).reshape(k, L), orc.encrypt(KEY, 0, c, "single", J, b, vals[c])), f"PARITY FAILURE client {c}"
     sep_ms = None
@@ -1273,7 +1343,7 @@ def bench_sparse(args, total, ops, rank, world, out):
         r_loc, r_val, r_ct = refs(d_loc), refs(d_val), refs(d_ct)
         out_ref = srnd.run(0, r_loc, [k] * C, r_val, 1, [zero] * C, r_ct)
         got = ops.read((out_ref, 0), total * L).reshape(total, L)
-        assert np.array_equal(got[:, 0], want), "PARITY FAILURE (position-sharded sparse round)"
+        assert np.array_equal(got, want), "PARITY FAILURE (position-sharded sparse round, every limb)"
         for it in range(max(W, 2)):
             srnd.run(it, r_loc, [k] * C, r_val, 1, [zero] * C, r_ct)
         shard_ms = timed_region(ops, K, lambda kk: srnd.run(kk, r_loc, [k] * C, r_val, 1, [zero] * C, r_ct)) * 1e3 / K

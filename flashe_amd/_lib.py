@@ -60,6 +60,7 @@ _SIGNATURES = {
     "flashe_ctx_destroy": (c_int, [c_vp]),
     "flashe_ctx_set_key": (c_int, [c_vp, c_u8p]),
     "flashe_ctx_int_bits": (c_int, [c_vp]),
+    "flashe_ctx_compact_layout": (c_int, [c_vp]),
     "flashe_ctx_set_cu_limit": (c_int, [c_vp, c_int]),
     "flashe_ctx_cu_count": (c_int, [c_vp]),
     "flashe_ctx_set_prf_backend": (c_int, [c_vp, c_int]),

@@ -217,6 +217,7 @@ class FlasheCipher(object):
         self._device = device
         self._engine = None
         self._key = None
+        self._ctx_holds = 0           # which precompute caches the engine's ctx may hold (PREPARED_ENCRYPT | PREPARED_DECRYPT bits)
 
     # ------------------------------------------------------------------ simple setters
     def set_num_clients(self, num_clients):
@@ -336,6 +337,20 @@ class FlasheCipher(object):
         if len(vec) != n:
             raise ValueError(f"operands could not be broadcast together with shapes ({n},) ({len(vec)},) ")
 
+    def _reconcile_prepared(self):
+        """The dict entries are handles of masks the ctx holds.  A caller may drop or replace them like any attribute (the reference's
+        are plain dicts: `cipher.next_iter_encrypt_prepared = {}`); whenever a handle is gone while the ctx still holds its masks, the
+        ctx cache is discarded (and its HBM released) so that the two states cannot disagree."""
+        eng = self._engine
+        if not self._ctx_holds or eng is None:
+            return
+        for which, d in ((eng.PREPARED_ENCRYPT, self.next_iter_encrypt_prepared), (eng.PREPARED_DECRYPT, self.next_iter_decrypt_prepared)):
+            if self._ctx_holds & which:
+                h = d.get('add') if isinstance(d, dict) else None
+                if not (isinstance(h, _CtxMask) and h.which == which):
+                    eng.prepared_discard(which)
+                    self._ctx_holds &= ~which
+
     # ---- device-resident operands (new) ----
     @staticmethod
     def _wants_device(value, device):
@@ -348,11 +363,15 @@ class FlasheCipher(object):
         int_bits <= 32 every DeviceVector this class produces is a uint32 array (flashe_encrypt_batch_u32_dev,
         flashe_aggregate_elem_u32_dev, flashe_aggregate_decrypt_u32_dev), and np.uint32 arrays are accepted and returned as such."""
         eng = self._engine
-        return (self.int_bits <= 32 and hasattr(eng, "encrypt_batch_u32_dev") and os.environ.get("FLASHE_CHAIN", "1") != "0")
+        if self.int_bits > 32 or not hasattr(eng, "encrypt_batch_u32_dev"):
+            return False
+        ask = getattr(eng, "compact_supported", None)          # the ctx knows its PRF backend and whether the chained kernels are on
+        return bool(ask()) if ask is not None else os.environ.get("FLASHE_CHAIN", "1") != "0"
 
-    @staticmethod
-    def _is_u32(value):
-        return isinstance(value, np.ndarray) and value.dtype == np.uint32
+    def _is_u32(self, value):
+        """np.uint32 arrays keep their dtype only where a uint32 holds a whole element (int_bits <= 32); at wider moduli they are
+        integer arrays like any other (object-int path: full-width ciphertexts, L-limb operands for the decrypt)."""
+        return self.int_bits <= 32 and isinstance(value, np.ndarray) and value.dtype == np.uint32
 
     def _on_device(self, value, full_width=False):
         """(DeviceVector on this cipher's engine, kind of the host form).  full_width: the operand must have L limbs."""
@@ -436,6 +455,7 @@ class FlasheCipher(object):
                 self._check_prepared_len(add, n)
                 if isinstance(add, _CtxMask):
                     eng.encrypt_prepared_dev(n, dv.buf, dv.limbs, out.buf)          # the ctx adds its cached masks and drops them
+                    self._ctx_holds &= ~eng.PREPARED_ENCRYPT
                 else:
                     eng.combine_dev(n, dv.buf, dv.limbs, add.buf, minus.buf, out.buf)
             ct = self._deliver(out, kind, want_dev)
@@ -470,6 +490,7 @@ class FlasheCipher(object):
                 self.set_idx_list_single(mode="encrypt")
             if not isinstance(plaintext, (np.ndarray, DeviceVector)):
                 return None
+            self._reconcile_prepared()
             t0 = self._begin("encryption")
             out = self._encrypt_double(plaintext, device) if self.masking_scheme == "double" else self._encrypt_single(plaintext, device)
             self._phase("encryption", len(plaintext), t0)
@@ -547,6 +568,7 @@ class FlasheCipher(object):
                 if isinstance(padd, _CtxMask):
                     # the ctx's cached masks, the extras (dropouts) computed online and merged in (:557-564), the cache dropped
                     eng.decrypt_prepared_dev(self.iter_index, add_idx, minus_idx, n, N_JOBS, dv.buf, out.buf)
+                    self._ctx_holds &= ~eng.PREPARED_DECRYPT
                 else:
                     eng.combine_dev(n, dv.buf, eng.limbs, padd.buf, pminus.buf, out.buf)
                     if online:                                            # extras merged in (:557-564)
@@ -571,6 +593,7 @@ class FlasheCipher(object):
         if self.prp_seed is not None:
             if not isinstance(ciphertext, (np.ndarray, DeviceVector)):
                 return None
+            self._reconcile_prepared()
             t0 = self._begin("decryption")
             out = self._decrypt_double(ciphertext, device) if self.masking_scheme == "double" else self._decrypt_single(ciphertext, device)
             self._phase("decryption", len(ciphertext), t0)
@@ -587,6 +610,7 @@ class FlasheCipher(object):
         eng.prepare_encrypt(self.iter_index + 1, self.idx, SCHEME_DOUBLE, n, N_JOBS)
         eng.sync()
         self.next_iter_encrypt_prepared = {'add': _CtxMask(eng.PREPARED_ENCRYPT, 'add', n), 'minus': _CtxMask(eng.PREPARED_ENCRYPT, 'minus', n)}
+        self._ctx_holds |= eng.PREPARED_ENCRYPT
 
     def prepare_decrypt(self):                                           # jzf_flashe.py:633-666
         eng, n = self._engine, self.num_params
@@ -594,6 +618,7 @@ class FlasheCipher(object):
         eng.sync()
         self.next_iter_decrypt_prepared['add'] = _CtxMask(eng.PREPARED_DECRYPT, 'add', n)
         self.next_iter_decrypt_prepared['minus'] = _CtxMask(eng.PREPARED_DECRYPT, 'minus', n)
+        self._ctx_holds |= eng.PREPARED_DECRYPT
         self.next_iter_decrypt_prepared_idx['add'] = [self.num_clients]
         self.next_iter_decrypt_prepared_idx['minus'] = [0]
 

@@ -393,6 +393,13 @@ int flashe_ctx_cu_count(const flashe_ctx *ctx) { return ctx ? ctx->device_cus : 
 
 int flashe_ctx_int_bits(const flashe_ctx *ctx) { return ctx ? ctx->int_bits : FLASHE_EINVAL; }
 
+// the conditions of check_u32 below, as a question a binding can ask before it chooses the uint32 layout
+int flashe_ctx_compact_layout(const flashe_ctx *ctx)
+{
+    if (!ctx) return FLASHE_EINVAL;
+    return ctx->int_bits <= 32 && (ctx->env.prf_backend == PRF_AUTO || ctx->env.prf_backend == PRF_TABLE) && ctx->env.use_chain ? 1 : 0;
+}
+
 const char *flashe_last_error(const flashe_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int flashe_selftest(flashe_ctx *ctx)
@@ -681,6 +688,18 @@ int flashe_event_elapsed_ms(flashe_ctx *ctx, void *start, void *stop, float *ms)
 }
 
 // ---- PRF / encrypt / decrypt ----
+// The double mask of client idx subtracts the stream of prefix idx + 1, and the reference builds that prefix with
+// (self.idx + 1).to_bytes(4, 'big') (jzf_flashe.py:352-353): OverflowError for idx = 2^32 - 1.  The raw ABI refuses the same value
+// instead of wrapping to prefix 0 ("ranges: idx + 1 < 2^32").
+static int check_double_idx(flashe_ctx *ctx, int scheme, const uint32_t *idx, int n_idx)
+{
+    if (scheme != FLASHE_SCHEME_DOUBLE || !idx) return FLASHE_OK;
+    for (int v = 0; v < n_idx; v++)
+        if (idx[v] == 0xffffffffu)
+            return fail(ctx, FLASHE_EINVAL, "double mask: idx + 1 = 2^32 does not fit the 4-byte prefix field (entry %d; the reference raises OverflowError, jzf_flashe.py:352-353)", v);
+    return FLASHE_OK;
+}
+
 static int check_prf_args(flashe_ctx *ctx, int n_add, int n_minus, uint32_t n_jobs, const void *out, const void *in, int in_limbs)
 {
     if (n_add < 0 || n_minus < 0) return fail(ctx, FLASHE_EINVAL, "negative prefix list length: add %d minus %d", n_add, n_minus);
@@ -735,6 +754,7 @@ int flashe_encrypt_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme,
     if (n && (!pt_dev || !ct_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
     int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev, pt_dev, pt_limbs);
     if (rc) return rc;
+    if ((rc = check_double_idx(ctx, scheme, &idx, 1))) return rc;
     const uint32_t add = idx, minus = idx + 1;
     HIP_TRY(ctx, launch_prf(ctx->env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, 0, n, pt_dev, pt_limbs, ct_dev));
     return FLASHE_OK;
@@ -746,6 +766,7 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
     CHECK_CTX(ctx);
     if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
     if (n_vec < 0 || (n_vec && (!idx || !pt_dev || !ct_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
+    if (int rc = check_double_idx(ctx, scheme, idx, n_vec)) return rc;
     for (int v = 0; v < n_vec; v++) {
         if (n && (!pt_dev[v] || !ct_dev[v])) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
         int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev[v], pt_dev[v], pt_limbs);
@@ -795,7 +816,7 @@ int flashe_encrypt_batch_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uin
     if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
     if (n_vec < 0 || (n_vec && (!idx || !pt_dev || !ct_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
     int rc = check_u32(ctx, n, n_jobs);
-    if (rc) return rc;
+    if (rc || (rc = check_double_idx(ctx, scheme, idx, n_vec))) return rc;
     if (n == 0 || n_vec == 0) return FLASHE_OK;
     for (int v = 0; v < n_vec; v++) {
         if (!pt_dev[v] || !ct_dev[v]) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
@@ -882,6 +903,7 @@ int flashe_encrypt_batch_sum_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uin
 {
     CHECK_CTX(ctx);
     if (!sum_out_dev && n && n_vec) return fail(ctx, FLASHE_EINVAL, "flashe_encrypt_batch_sum_dev: null sum_out_dev");
+    if (n_vec > 0) { if (int rc = check_double_idx(ctx, scheme, idx, n_vec)) return rc; }
     if (n && n_vec && ((ctx->limbs == 2 && !aligned16(sum_out_dev)) || (reinterpret_cast<uintptr_t>(sum_out_dev) & 7u)))
         return fail(ctx, FLASHE_EINVAL, "sum_out_dev must be aligned like a ciphertext vector");
     if (n_vec > 0 && n) {
@@ -978,6 +1000,7 @@ int flashe_quantize_encrypt_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, in
     const Codec cq = codec_quantize_front(x_dev, x_is_f64 != 0, alpha, element_bits, u_dev);
     LaunchEnv env = ctx->env;
     env.codec = &cq;
+    if ((rc = check_double_idx(ctx, scheme, &idx, 1))) return rc;
     const uint32_t add = idx, minus = idx + 1;
     HIP_TRY(ctx, launch_prf(env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, 0, n, nullptr, 0, ct_dev));
     return FLASHE_OK;
@@ -1082,6 +1105,7 @@ int flashe_quantize_encrypt_model_dev(flashe_ctx *ctx, uint32_t iter, uint32_t i
     cq.u = u_dev; cq.layers = tab; cq.n_layers = n_tab; cq.k0 = first;
     LaunchEnv env = ctx->env;
     env.codec = &cq;
+    if ((rc = check_double_idx(ctx, scheme, &idx, 1))) return rc;
     const uint32_t add = idx, minus = idx + 1;
     HIP_TRY(ctx, launch_prf(env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, first, count, nullptr, 0, ct_dev));
     return FLASHE_OK;
@@ -1284,6 +1308,7 @@ int flashe_encrypt_range_dev(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int s
     if (count && (!pt_dev || !ct_dev)) return fail(ctx, FLASHE_EINVAL, "null vector");
     int rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev, pt_dev, pt_limbs);
     if (rc || (rc = check_range(ctx, n, first, count))) return rc;
+    if ((rc = check_double_idx(ctx, scheme, &idx, 1))) return rc;
     const uint32_t add = idx, minus = idx + 1;
     HIP_TRY(ctx, launch_prf(ctx->env, iter, &add, 1, &minus, scheme == FLASHE_SCHEME_DOUBLE ? 1 : 0, n, n_jobs, first, count,
                             pt_dev, pt_limbs, ct_dev));
@@ -1300,7 +1325,7 @@ int flashe_encrypt_batch_range_dev(flashe_ctx *ctx, uint32_t iter, int scheme, u
     if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
     if (n_vec < 0 || (n_vec && (!idx || !pt_dev || !ct_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
     int rc = check_range(ctx, n, first, count);
-    if (rc) return rc;
+    if (rc || (rc = check_double_idx(ctx, scheme, idx, n_vec))) return rc;
     if (n_jobs == 0) return fail(ctx, FLASHE_EINVAL, "n_jobs must be >= 1");
     if (ctx->env.prf_backend != PRF_AUTO && ctx->env.prf_backend != PRF_TABLE) return fail(ctx, FLASHE_EINVAL, "encrypt_batch_range runs on the table PRF only");
     for (int v = 0; v < n_vec; v++) {
@@ -1382,6 +1407,9 @@ int flashe_prepare_encrypt(flashe_ctx *ctx, uint32_t iter_next, uint32_t idx, in
 {
     CHECK_CTX(ctx);
     if (scheme != FLASHE_SCHEME_SINGLE && scheme != FLASHE_SCHEME_DOUBLE) return fail(ctx, FLASHE_EINVAL, "unknown scheme %d", scheme);
+    // (iter_next is the caller's iter + 1 already: the reference's own range check of that sum, jzf_flashe.py:606, is the caller's)
+    int rc = check_double_idx(ctx, scheme, &idx, 1);
+    if (rc) return rc;
     return prepare_masks(ctx, ctx->prep_enc, iter_next, idx, scheme == FLASHE_SCHEME_DOUBLE, idx + 1u, num_params, n_jobs);
 }
 
@@ -1406,8 +1434,21 @@ int flashe_prepared_discard(flashe_ctx *ctx, int which)
 {
     if (!ctx) return FLASHE_EINVAL;
     if (which & ~(FLASHE_PREPARED_ENCRYPT | FLASHE_PREPARED_DECRYPT)) return fail(ctx, FLASHE_EINVAL, "unknown cache %d", which);
-    if (which & FLASHE_PREPARED_ENCRYPT) ctx->prep_enc.valid = false;
-    if (which & FLASHE_PREPARED_DECRYPT) ctx->prep_dec.valid = false;
+    // A consumed cache keeps its blocks for the next round's masks (a job prepares every round); an explicit discard is the caller
+    // saying it is done with precompute: the blocks (up to four model-sized vectors) go back to the device.
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    bool synced = false;
+    for (flashe_ctx::Prepared *pr : {(which & FLASHE_PREPARED_ENCRYPT) ? &ctx->prep_enc : nullptr, (which & FLASHE_PREPARED_DECRYPT) ? &ctx->prep_dec : nullptr}) {
+        if (!pr) continue;
+        pr->valid = false;
+        if (ctx->capturing) continue;                                     // (no frees inside a capture; the blocks stay with the ctx)
+        for (flashe_ctx::Buf *b : {&pr->add, &pr->minus}) {
+            if (!b->p) continue;
+            if (!synced) { HIP_TRY(ctx, hipStreamSynchronize(ctx->env.stream)); synced = true; }
+            HIP_TRY(ctx, hipFree(b->p));
+            b->p = nullptr; b->cap = 0;
+        }
+    }
     return FLASHE_OK;
 }
 
@@ -2316,6 +2357,7 @@ int flashe_encrypt(flashe_ctx *ctx, uint32_t iter, uint32_t idx, int scheme, uin
                    int pt_limbs, uint64_t *ct)
 {
     CHECK_CTX(ctx);
+    if (int rc = check_double_idx(ctx, scheme, &idx, 1)) return rc;
     if (n == 0) return FLASHE_OK;
     if (!pt || !ct) return fail(ctx, FLASHE_EINVAL, "null vector");
     if (pt_limbs != 1 && pt_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "pt_limbs must be 1 or %d", ctx->limbs);

@@ -161,13 +161,21 @@ int flashe_rccl_all_to_all(flashe_ctx *ctx, flashe_comm *comm, const void *send_
         if (comm->world == 1) return FLASHE_OK;
     }
     NCCL_TRY(ctx, api.GroupStart());
-    for (int step = self_through_rccl ? 0 : 1; step < comm->world; step++) {
+    // A Send / Recv that fails inside the group must not leave the group open (every later RCCL call of this thread would be queued
+    // into it and never issued): close it first, then report the FIRST failure.
+    ncclResult_t first = ncclSuccess;
+    const char *what = "";
+    for (int step = self_through_rccl ? 0 : 1; step < comm->world && first == ncclSuccess; step++) {
         // rank r sends to r + step and receives from r - step: every pair (and xGMI link) is used once per step
         const int to = (comm->rank + step) % comm->world, from = (comm->rank - step + comm->world) % comm->world;
-        NCCL_TRY(ctx, api.Send(s + to * send_stride, bytes, ncclUint8, to, comm->comm, ctx->env.stream));
-        NCCL_TRY(ctx, api.Recv(r + from * recv_stride, bytes, ncclUint8, from, comm->comm, ctx->env.stream));
+        first = api.Send(s + to * send_stride, bytes, ncclUint8, to, comm->comm, ctx->env.stream);
+        if (first != ncclSuccess) { what = "ncclSend"; break; }
+        first = api.Recv(r + from * recv_stride, bytes, ncclUint8, from, comm->comm, ctx->env.stream);
+        if (first != ncclSuccess) what = "ncclRecv";
     }
-    NCCL_TRY(ctx, api.GroupEnd());
+    const ncclResult_t end = api.GroupEnd();
+    if (first != ncclSuccess) return fail(ctx, FLASHE_EIO, "flashe_rccl_all_to_all: %s failed inside the group (closed): %s", what, api.GetErrorString(first));
+    if (end != ncclSuccess) return fail(ctx, FLASHE_EIO, "flashe_rccl_all_to_all: ncclGroupEnd: %s", api.GetErrorString(end));
     return FLASHE_OK;
 }
 

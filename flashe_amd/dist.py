@@ -532,9 +532,10 @@ class HipOps:
     def sparse_bounds(self, total, locs, ks, handle=None):
         """The span bounds of the round's location lists (refs of uint32 lists): a handle, recomputed in place when one is passed."""
         ptrs = [self._a(r) for r in locs]
+        keep = [r[0] for r in locs]                       # the buffers behind the addresses: the handle keeps them alive
         if handle is not None:
-            return handle.recompute(ptrs, ks)
-        return self.engine.span_bounds(total, ptrs, ks)
+            return handle.recompute(ptrs, ks, keep=keep)
+        return self.engine.span_bounds(total, ptrs, ks, keep=keep)
 
     def sparse_encrypt_aggregate(self, it, idx, locs, ks, pts, pt_limbs, zeros, total, n_jobs, cts, agg, bounds, first, count):
         self.engine.sparse_encrypt_aggregate_dev(it, idx, [self._a(r) for r in locs], ks, [self._a(r) for r in pts], pt_limbs, zeros, total, n_jobs,

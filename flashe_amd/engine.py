@@ -418,22 +418,26 @@ def _u64_array(vals):
 
 class SpanBounds:
     """flashe_span_bounds: where every client's strictly increasing location list enters every span of the dense vector, computed once
-    per round's lists (the lists must stay as they are while the handle is used; it keeps them alive)."""
+    per round's lists.  The handle is a table ABOUT the lists' contents: the C side can check pointers, lengths and total, not that the
+    entries are still the ones the table was built from -- after ANY in-place change of a list call recompute() before the next sparse
+    call that takes the handle (SparseShardedRound does, every round).  The handle keeps the list buffers alive (`keep`: the buffer
+    objects when `locs` are bare addresses)."""
 
-    def __init__(self, engine, total, locs, ks):
-        self.engine, self._keep = engine, locs if isinstance(locs, PtrTable) else list(locs)
+    def __init__(self, engine, total, locs, ks, keep=None):
+        self.engine = engine
+        self._keep = keep if keep is not None else (locs if isinstance(locs, PtrTable) else list(locs))
         p, _k = engine._ptr_array(locs)
         kk = _u64_array(ks)
         h = c_vp()
         engine._check(engine._lib.flashe_span_bounds_create(engine._h, int(total), len(locs), p, ctypes.cast(kk, c_u64p), ctypes.byref(h)))
         self._h = h.value
 
-    def recompute(self, locs, ks):
-        """The table for the next round's lists (same number of clients, same total), in place."""
+    def recompute(self, locs, ks, keep=None):
+        """The table for the next round's lists (same number of clients, same total), in place; mandatory after the lists changed."""
         p, _k = self.engine._ptr_array(locs)
         kk = _u64_array(ks)
         self.engine._check(self.engine._lib.flashe_span_bounds_recompute(self.engine._h, self._h, p, ctypes.cast(kk, c_u64p)))
-        self._keep = locs if isinstance(locs, PtrTable) else list(locs)
+        self._keep = keep if keep is not None else (locs if isinstance(locs, PtrTable) else list(locs))
         return self
 
     def __del__(self):
@@ -497,6 +501,12 @@ class Engine:
     def set_prf_backend(self, backend):
         """0 = auto, 1 = LDS T-table kernel, 2 = bit-sliced VALU kernel (identical results)."""
         self._check(self._lib.flashe_ctx_set_prf_backend(self._h, int(backend)))
+
+    def compact_supported(self):
+        """True when the uint32 entry points (encrypt_batch_u32_dev, aggregate_decrypt_u32_dev, ...) run on this ctx: int_bits <= 32,
+        the table PRF backend, the chained kernels.  The C side decides (flashe_ctx_compact_layout), so a caller never has to guess from
+        environment variables what check_u32 will answer."""
+        return int(self._lib.flashe_ctx_compact_layout(self._h)) == 1
 
     def selftest(self):
         self._check(self._lib.flashe_selftest(self._h))
@@ -769,10 +779,11 @@ class Engine:
         self._check(self._lib.flashe_expand_to_dense_dev(self._h, total, k, self._ptr(loc), self._ptr(vals),
                                                          ctypes.cast(z, c_u64p), self._ptr(out)))
 
-    def span_bounds(self, total, locs, ks):
+    def span_bounds(self, total, locs, ks, keep=None):
         """The span bounds of a round's strictly increasing location lists, computed once: a SpanBounds handle that
-        sparse_aggregate_dev / sparse_decrypt_dev take (bounds=...) instead of recomputing the table for the same lists."""
-        return SpanBounds(self, total, locs, ks)
+        sparse_aggregate_dev / sparse_decrypt_dev take (bounds=...) instead of recomputing the table for the same lists.  After an
+        in-place change of a list: handle.recompute(...) first.  keep: objects the handle should keep alive (locs given as addresses)."""
+        return SpanBounds(self, total, locs, ks, keep=keep)
 
     def sparse_aggregate_dev(self, total, locs, ks, vals, zeros, out, sorted_lists=False, bounds=None):
         """out = sum over clients of expand_to_dense(total, locs[c], vals[c], zeros[c]) mod 2^b, without the dense

@@ -56,8 +56,11 @@ typedef struct flashe_ctx flashe_ctx;
  *      flashe_sparse_encrypt_aggregate_dev (the clients' sparse encrypts and the aggregate of their uploads in one pass);
  *      flashe_unquantize_model_dev (the model-wide codec back end without a decrypt: the sparse job's way back);
  *      flashe_sparse_span, flashe_sparse_encrypt_aggregate_range_dev, flashe_sparse_decrypt_range_dev (the sparse round by position ranges);
- *      timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only) */
-#define FLASHE_ABI_VERSION 2
+ *      timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only)
+ *   3  round 5: flashe_ctx_compact_layout (does this ctx run the *_u32_dev entry points?); the double-mask encrypt entry points
+ *      refuse idx = 2^32 - 1 with FLASHE_EINVAL (the reference's OverflowError, jzf_flashe.py:352-353) instead of wrapping to
+ *      prefix 0; flashe_prepared_discard releases the cached mask buffers */
+#define FLASHE_ABI_VERSION 3
 int flashe_abi_version(void);
 int flashe_device_count(int *count);
 int flashe_limbs(int int_bits);                 /* 1 or 2; 0 if int_bits is out of range */
@@ -71,6 +74,9 @@ int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int
 int flashe_ctx_destroy(flashe_ctx *ctx);
 int flashe_ctx_set_key(flashe_ctx *ctx, const uint8_t key[32]);
 int flashe_ctx_int_bits(const flashe_ctx *ctx);
+/* new: 1 if the compact uint32 entry points (flashe_encrypt_batch_u32_dev, flashe_aggregate_decrypt_u32_dev, ...) run on this ctx --
+ * int_bits <= 32, the table PRF backend and the chained kernels (FLASHE_CHAIN != 0) -- 0 if they would answer FLASHE_EINVAL. */
+int flashe_ctx_compact_layout(const flashe_ctx *ctx);
 /* new: how many compute units the persistent launches of this ctx occupy (0 = the whole device; flashe_ctx_cu_count = what the
  * device has).  The PRF workgroups hold 128 KiB of LDS per CU, so a kernel from ANOTHER stream that needs more than the rest (RCCL's
  * transfer kernels do) runs beside a PRF launch only on CUs that launch leaves free: the multi-GPU schedules that hide the exchange
@@ -192,7 +198,9 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
  *       precompute does not cover (dropouts: what set_idx_list leaves after skipping {num_clients} / {0}, :372-386), computed online
  *       and merged in (:557-564); consumes the cache;
  *   flashe_prepared_query(which, &n, &add_dev, &minus_dev): 1 / 0 = a cache is / is not held; its length and device vectors (valid
- *       until consumed or re-prepared); flashe_prepared_discard(which) drops it (which: FLASHE_PREPARED_ENCRYPT | _DECRYPT).
+ *       until consumed or re-prepared); flashe_prepared_discard(which) drops it (which: FLASHE_PREPARED_ENCRYPT | _DECRYPT) AND
+ *       gives the mask blocks back to the device.  (A cache that is merely consumed keeps its blocks inside the ctx for the next
+ *       round's masks -- up to four vectors of num_params elements per ctx -- until flashe_prepared_discard or flashe_ctx_destroy.)
  * prepare_* are asynchronous on the ctx stream like every *_dev call. */
 #define FLASHE_PREPARED_ENCRYPT 1
 #define FLASHE_PREPARED_DECRYPT 2
@@ -414,8 +422,11 @@ int flashe_sparse_decrypt_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint3
  * aggregate and the sparse decrypt of one round would otherwise both run on the same lists.  (The handle carries the table for both
  * span sizes in use -- the plain reduce's and that of the passes with the PRF inside -- filled by one pass over the lists.)  flashe_span_bounds_create computes the
  * table for C lists (any C) asynchronously on the ctx stream; the *_bounds_dev calls take it instead of recomputing; the handle is valid
- * for exactly these list pointers / lengths / total (checked) and until flashe_span_bounds_destroy.  The lists must not change
- * while a handle built on them is in use. */
+ * for exactly these list pointers / lengths / total (checked) and until flashe_span_bounds_destroy.  The table describes the lists'
+ * CONTENTS, which the check cannot see: the lists must not change while a handle built on them is in use, and after any in-place
+ * rewrite (a job that reuses its upload buffers every round) flashe_span_bounds_recompute is MANDATORY before the next *_bounds_dev /
+ * *_range_dev call -- a stale table stays memory-safe (slices are clamped, an entry outside its span raises the ctx's deferred error
+ * flag) but the sums are wrong. */
 typedef struct flashe_span_bounds flashe_span_bounds;
 int flashe_span_bounds_create(flashe_ctx *ctx, uint64_t total, int C, const uint32_t *const *loc_dev, const uint64_t *k,
                               flashe_span_bounds **out);

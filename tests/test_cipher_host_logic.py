@@ -89,6 +89,71 @@ def test_uint64_fast_path_equals_object_path(cipher_cls):
             assert f.shape == (39,) and [int(v) for v in f] == ints
 
 
+@pytest.mark.parametrize("b", [64, 128, 33])
+def test_uint32_arrays_at_wide_moduli_keep_full_width(cipher_cls, b):
+    """np.uint32 plaintexts are a fast path only where a uint32 holds a whole element (int_bits <= 32).  At wider
+    moduli they are integer arrays like any other: the ciphertext keeps all int_bits bits (it used to come back truncated to its low
+    word) and decrypts back, on host arrays and with device=True / handles."""
+    key = bytes(range(32))
+    cm.N_JOBS = 4
+    vals = (np.arange(1, 40, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(2 ** 32)).astype(np.uint32)
+    cl = []
+    for i in range(2):
+        c = cm.FlasheCipher(b)
+        c.generate_prp_seed(key)
+        c.set_iter_index(3)
+        c.idx = i
+        cl.append(c)
+    want = [cl[i].encrypt(vals.astype(object)) for i in range(2)]
+    assert max(int(v) for v in want[0]) >= 2 ** 32                    # the ciphertext really needs more than a uint32
+    got = [cl[i].encrypt(vals) for i in range(2)]
+    for g, w in zip(got, want):
+        assert g.dtype == object and [int(v) for v in g] == [int(v) for v in w]
+    # handles: same values, full width, and the decrypt of the aggregate returns the sum
+    hd = [cl[i].encrypt(vals, device=True) for i in range(2)]
+    assert hd[0].limbs == cl[0]._engine.limbs
+    agg = cl[0].aggregate(hd)
+    cl[0].set_idx_list(raw_idx_list=[0, 1], mode="decrypt")
+    out = cl[0].decrypt(agg, device=False)
+    assert [int(v) for v in np.asarray(out).reshape(len(vals), -1)[:, 0]] == [2 * int(v) for v in vals]
+    # a uint32 CIPHERTEXT-typed operand (small values) decrypts at full width too: L limbs reach the engine
+    small = np.arange(39, dtype=np.uint32)
+    cl[1].set_idx_list(raw_idx_list=[0, 1], mode="decrypt")
+    d32 = cl[1].decrypt(small)
+    cl[1].set_idx_list(raw_idx_list=[0, 1], mode="decrypt")
+    dobj = cl[1].decrypt(small.astype(object))
+    assert d32.dtype == object and [int(v) for v in d32] == [int(v) for v in dobj]
+
+
+def test_dropped_prepared_handles_discard_the_ctx_cache(cipher_cls):
+    """the dict entries of next_iter_*_prepared are handles of masks the ctx holds.  A caller that resets the dicts
+    (plain attributes in the reference) must not leave a valid cache behind in the ctx."""
+    cm.N_JOBS = 4
+    c = cm.FlasheCipher(64)
+    c.generate_prp_seed(bytes(range(32)))
+    c.set_num_clients(2)
+    c.set_num_params(30)
+    c.set_iter_index(0)
+    c.idx = 0
+    c.prepare_encrypt()
+    c.prepare_decrypt()
+    eng = c._engine
+    assert eng.prepared_download(1, "add") is not None and eng.prepared_download(2, "add") is not None
+    c.next_iter_encrypt_prepared = {}                               # the caller drops the encrypt masks ...
+    vals = np.arange(30, dtype=np.uint64)
+    c.set_iter_index(1)
+    ct = c.encrypt(vals)                                            # ... so this is an ONLINE encrypt of iter 1,
+    from oracle import flashe_oracle as orc
+    assert np.array_equal(ct, orc.encrypt(bytes(range(32)), 1, 0, "double", 4, 64, vals)[:, 0])
+    assert eng.prepared_download(1, "add") is None                  # and the ctx cache is gone with the handle
+    assert eng.prepared_download(2, "add") is not None              # the decrypt cache was not touched
+    del c.next_iter_decrypt_prepared['add'], c.next_iter_decrypt_prepared['minus']
+    c.next_iter_decrypt_prepared_idx = {}
+    c.set_idx_list(raw_idx_list=[0], mode="decrypt")
+    c.decrypt(ct)
+    assert eng.prepared_download(2, "add") is None
+
+
 def test_dynamic_masking_choice_matches_reference_model():
     """jzf_flashe_block.py:92-112 restated literally (object one-hots, Python sum) vs the mirror."""
     from flashe_amd.block import dynamic_masking_choice

@@ -709,6 +709,15 @@ def test_bench_multi_rank_flow(extra, tmp_path):
     # (every rank plays every client on its slice; parity-gated in-run), with and without the all-gather of the decrypted slices
     assert "element_sharded_error" not in d, d.get("element_sharded_error")
     assert d["value_element_sharded"] > 0 and d["value_element_sharded_no_gather"] > 0 and d["ms_per_step_element_sharded"] > 0
+    # the line interprets itself: DESIGN section 5's model evaluated with this run's AES rate, and what RCCL saw
+    pm, sc = d["predicted_ms"], d["scale_check"]
+    cs, es = pm["client_sharded_sequential"], pm["element_sharded"]
+    assert abs(cs["round"] - sum(v for k, v in cs.items() if k != "round")) < 1e-9 and cs["all_to_all"] > 0 and cs["encrypt_busiest_rank"] > 0
+    assert es["round"] > es["round_no_gather"] > 0 and pm["inputs"]["world"] == 3 and pm["inputs"]["aes_blocks_per_s_measured_this_run"] > 0
+    assert pm["inputs"]["clients_per_rank"] == ([3, 3, 3] if extra[1] == "2" else [2, 2, 1])
+    assert sc["ranks_counted_by_allreduce_is_n"] is True and sc["ranks_parity_ok"] is True and isinstance(sc["rccl_world_is_n"], bool)
+    r_ = sc["measured_over_predicted"]
+    assert r_["schedule_that_ran_over_sequential_model"] > 0 and r_["element_sharded_over_model"] > 0 and r_["element_sharded_no_gather_over_model"] > 0
 
 
 def test_bench_multi_rank_allreduce_exchange(tmp_path):
@@ -1408,6 +1417,40 @@ def test_error_codes(E):
     d = eng.alloc_vec(8)
     with pytest.raises(E.FlasheError):
         eng.aggregate_packed_dev([d], 16, 1024, d)      # out aliases an operand
+
+
+def test_double_mask_idx_range_at_the_raw_abi(E, oracle):
+    """jzf_flashe.py:352-353: the double mask's minus prefix is (self.idx + 1).to_bytes(4, 'big') -- OverflowError for idx = 2^32 - 1.
+    The raw C ABI refuses the same value (FLASHE_EINVAL) instead of wrapping to prefix 0, in every encrypt entry point; the single mask
+    (no idx + 1) and idx = 2^32 - 2 still work and equal the oracle."""
+    top = 0xFFFFFFFF
+    for b in (128, 20):
+        eng = make(E, b)
+        n = 64
+        pt = np.arange(n, dtype=np.uint64)
+        dp, dc, ds = eng.upload(pt), eng.alloc_vec(n), eng.alloc_vec(n)
+        bad = [lambda: eng.encrypt(3, top, E.SCHEME_DOUBLE, 4, pt),
+               lambda: eng.encrypt_dev(3, top, E.SCHEME_DOUBLE, n, 4, dp, 1, dc),
+               lambda: eng.encrypt_range_dev(3, top, E.SCHEME_DOUBLE, n, 4, 0, n, dp, 1, dc),
+               lambda: eng.encrypt_batch_dev(3, [0, top], E.SCHEME_DOUBLE, n, 4, [dp, dp], 1, [dc, ds]),
+               lambda: eng.encrypt_batch_sum_dev(3, [top], E.SCHEME_DOUBLE, n, 4, [dp], 1, [dc], ds),
+               lambda: eng.encrypt_batch_range_dev(3, [top], E.SCHEME_DOUBLE, n, 4, 0, n, [dp], 1, [dc]),
+               lambda: eng.prepare_encrypt(4, top, E.SCHEME_DOUBLE, n, 4)]
+        if b <= 32:
+            p32, c32 = eng.upload(pt.astype(np.uint32)), eng.alloc(4 * n)
+            bad.append(lambda: eng.encrypt_batch_u32_dev(3, [top], E.SCHEME_DOUBLE, n, 4, [p32], [c32]))
+        x = eng.upload(np.linspace(-1, 1, n).astype(np.float32))
+        u = eng.upload(np.full(n, 0.5))
+        bad.append(lambda: eng.quantize_encrypt_dev(3, top, E.SCHEME_DOUBLE, n, 4, x, False, 2.0, 16, u, dc))
+        bad.append(lambda: eng.quantize_encrypt_model_dev(3, top, E.SCHEME_DOUBLE, n, 4, 0, n, [(0, x.ptr, 2.0, False)], 16, u, dc))
+        for k, call in enumerate(bad):
+            with pytest.raises(E.FlasheError) as ei:
+                call()
+            assert ei.value.code == -22 and "2^32" in str(ei.value), (b, k, str(ei.value))
+        # neighbours of the refused value
+        assert np.array_equal(eng.encrypt(3, top, E.SCHEME_SINGLE, 4, pt), oracle.encrypt(KEY, 3, top, "single", 4, b, pt))
+        assert np.array_equal(eng.encrypt(3, top - 1, E.SCHEME_DOUBLE, 4, pt), oracle.encrypt(KEY, 3, top - 1, "double", 4, b, pt))
+        assert eng.compact_supported() == (b <= 32)
 
 
 @pytest.mark.parametrize("b,n", [(128, 1_300_003), (20, 2_500_001), (64, 2_100_000)])

@@ -98,6 +98,7 @@ def main(tag):
         if dom_name and short == dom_name and alg:
             ent["algorithmic_bytes_per_launch"] = alg
             ent["hbm_bytes_per_algorithmic_byte"] = e["hbm_bytes_per_launch_avg"] / alg
+            ent["measured_in"] = f"profiles/{tag}_pmc.json"          # per-kernel provenance: a later tag rewrites the file's top level
         if short == "aggregate_elem_kernel":
             ent["note"] = "calibration: this reduce reads exactly C x what it writes, so 2 * FETCH / WRITE must equal C"
         prev = traffic["kernels"].get(short)
