@@ -887,6 +887,15 @@ struct SpanPrfEntry {
     u128 pt;             // ENC: the plaintext
 };
 
+// FLASHE_SPAN_OVERLAP (round 5): the write-out of a span -- accumulators read, zeroed, `from +/- acc` stored -- no longer sits between
+// two barriers with no AES in flight.  Every wave writes its share of the PREVIOUS span out as soon as its own rounds of this span are
+// done (the accumulators receive this span's entries only after the barrier that follows), so the waves that finish early (the ones
+// without entries, the ones on a SIMD with three busy waves) do it under the rounds of the slow ones, and what remains between the two
+// barriers of a span is the entries' atomics.  0 = the round-4 order (A/B builds).
+#ifndef FLASHE_SPAN_OVERLAP
+#define FLASHE_SPAN_OVERLAP 1
+#endif
+
 template <int ENC>
 __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys rk, const SpanPrfTable tb, int C, uint32_t iter0, uint64_t total, uint32_t n_spans,
                                                                uint32_t sp_first, uint32_t sp_end, const uint32_t *__restrict__ start, uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo,
@@ -894,6 +903,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                                                                const uint32_t *__restrict__ te0, uint32_t *err_flag, int probe)
 {
     constexpr int SPAN = kSpanFused, THREADS = kPrfThreads, PER = (SPAN + THREADS - 1) / THREADS;
+    constexpr bool OVERLAP = FLASHE_SPAN_OVERLAP != 0;
     const uint32_t iter = iter0 + te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
     __shared__ unsigned long long acc[2 * SPAN];
@@ -1009,9 +1019,15 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
 #ifdef FLASHE_TUNING
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
+    // OVERLAP: the span whose accumulators are complete and not yet written out (the one of the previous iteration)
+    uint64_t wp0 = 0;
+    uint32_t wlen = 0;
     for (; sp < sp_end; sp += stride, buf ^= 1) {
         const uint64_t p0 = sp * SPAN;
         const uint32_t span_len = static_cast<uint32_t>(total - p0 < SPAN ? total - p0 : SPAN);
+        // the dense vector is read (and written) for the span being WRITTEN OUT: this one in the round-4 order, the previous one here
+        const uint64_t fp0 = OVERLAP ? wp0 : p0;
+        const uint32_t flen = OVERLAP ? wlen : span_len;
         SPAN_PRF_TICK(7);
 #ifdef FLASHE_TUNING
         const unsigned long long head_ = __builtin_readcyclecounter();
@@ -1026,13 +1042,13 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
 #define SPAN_PRF_FROM()                                                                                                  \
         _Pragma("unroll") for (int e = 0; e < PER; e++) {                                                                 \
             const uint32_t r_ = tid + e * THREADS;                                                                        \
-            from[e] = src && r_ < span_len && probe != 4 ? ld128_nt(src + 2 * (p0 + r_)) : base;      /* 4 = no dense read / write */ \
+            from[e] = src && r_ < flen && probe != 4 ? ld128_nt(src + 2 * (fp0 + r_)) : base;      /* 4 = no dense read / write */ \
         }
 #else
 #define SPAN_PRF_FROM()                                                                                                  \
         _Pragma("unroll") for (int e = 0; e < PER; e++) {                                                                 \
             const uint32_t r_ = tid + e * THREADS;                                                                        \
-            from[e] = src && r_ < span_len ? ld128_nt(src + 2 * (p0 + r_)) : base;                                        \
+            from[e] = src && r_ < flen ? ld128_nt(src + 2 * (fp0 + r_)) : base;                                            \
         }
 #endif
         const int nbuf = buf ^ 1;
@@ -1076,7 +1092,10 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                     }
                 } else if (r == 9) {
                     nxt.x = ctr_var(rk, lr, nxt.q);
-                } else if (r == 10) {
+                } else if (r == 10 && !OVERLAP) {
+                    SPAN_PRF_FROM()
+                }
+                if (OVERLAP && r == 3) {                             // (behind the position load of this span's entry, well ahead of its use)
                     SPAN_PRF_FROM()
                 }
                 k = r < 13 ? issue_main(lr, s) : issue_final(lr, s);
@@ -1091,9 +1110,33 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         }
 #undef SPAN_PRF_FROM
         SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14 (+ the next entry's lookup)
+        auto write_out = [&](uint64_t q0, uint32_t qlen) {
+#pragma unroll
+            for (int e = 0; e < PER; e++) {
+                const uint32_t r = tid + e * THREADS;
+                if (r < qlen) {
+                    const u128 a = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
+                    acc[2 * r] = 0; acc[2 * r + 1] = 0;
+#ifdef FLASHE_TUNING
+                    if (probe == 4 && static_cast<uint64_t>(a) != 0x1234567ull) continue;
+#endif
+                    st128_nt(out + 2 * (q0 + r), (negate ? from[e] - a : from[e] + a) & mask);
+                }
+            }
+        };
+        if (OVERLAP) {
+            // this wave's share of the previous span, under the rounds of the waves that are still busy; the accumulators get this
+            // span's entries behind the barrier below.  (every load of the iteration has returned or is about to: one wait, here)
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+            write_out(wp0, wlen);
+            SPAN_PRF_TICK(5);
+            __syncthreads();
+            SPAN_PRF_TICK(4);
+        }
         u128 ct_val = 0;
         uint64_t *ct_to = nullptr;
         settle(cur, s, static_cast<uint32_t>(p0), span_len, &ct_val, &ct_to);
+        if (OVERLAP && ENC && ct_to) st128_nt_g(ct_to, ct_val);
         SPAN_PRF_TICK(2);
         // entries beyond the first 1,024 of a crowded span: looked up and computed one after the other
         for (uint32_t f2 = tid + THREADS; f2 < n_entries; f2 += THREADS) {
@@ -1110,30 +1153,47 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         if (probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
 #endif
         __syncthreads();
-        SPAN_PRF_TICK(4);                                                      // barrier: the slowest wave's entries
-        // every load of this span has returned or is about to (the next entry's were issued rounds ago): saying so HERE, on every wave's
-        // path, keeps the compiler from guarding the reuse of the prefetch registers with waits that would also cover the stores below
-        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
-        if (ENC && ct_to) st128_nt_g(ct_to, ct_val);
-        if (keeper && !early) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
-        __builtin_amdgcn_sched_barrier(0);
+        if (OVERLAP) {
+            SPAN_PRF_TICK(6);                                                  // barrier: every entry of this span is in the accumulators
+            wp0 = p0; wlen = span_len;
+            if (!early) {                                                      // (workgroup-uniform; rare: more than 1,024 entries in a span)
+                // the table of the span in flight was still read by the second pass: published now, and visible before the next
+                // iteration's lookups read it
+                if (keeper) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
+                __syncthreads();
+            }
+        } else {
+            SPAN_PRF_TICK(4);                                                      // barrier: the slowest wave's entries
+            // every load of this span has returned or is about to (the next entry's were issued rounds ago): saying so HERE, on every wave's
+            // path, keeps the compiler from guarding the reuse of the prefetch registers with waits that would also cover the stores below
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+            if (ENC && ct_to) st128_nt_g(ct_to, ct_val);
+            if (keeper && !early) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
+            __builtin_amdgcn_sched_barrier(0);
+            write_out(p0, span_len);
+            SPAN_PRF_TICK(5);                                                      // publish + write-out
+            __syncthreads();
+            SPAN_PRF_TICK(6);
+        }
+        cur = nxt;
+        n_entries = n_next;
+    }
+    if (OVERLAP && wlen) {
+        // the last span of this workgroup: its accumulators are complete (the loop's closing barrier), nothing is left to hide behind
+        u128 from[PER];
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const uint32_t r_ = tid + e * THREADS;
+            from[e] = src && r_ < wlen ? ld128_nt(src + 2 * (wp0 + r_)) : base;
+        }
 #pragma unroll
         for (int e = 0; e < PER; e++) {
             const uint32_t r = tid + e * THREADS;
-            if (r < span_len) {
+            if (r < wlen) {
                 const u128 a = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
-                acc[2 * r] = 0; acc[2 * r + 1] = 0;
-#ifdef FLASHE_TUNING
-                if (probe == 4 && static_cast<uint64_t>(a) != 0x1234567ull) continue;
-#endif
-                st128_nt(out + 2 * (p0 + r), (negate ? from[e] - a : from[e] + a) & mask);
+                st128_nt(out + 2 * (wp0 + r), (negate ? from[e] - a : from[e] + a) & mask);
             }
         }
-        SPAN_PRF_TICK(5);                                                      // publish + write-out
-        __syncthreads();
-        SPAN_PRF_TICK(6);
-        cur = nxt;
-        n_entries = n_next;
     }
 #undef SPAN_PRF_FETCH
 #undef SPAN_PRF_PUBLISH
