@@ -180,7 +180,10 @@ hipError_t launch_scatter(const LaunchEnv &env, uint64_t total, uint64_t k, cons
 constexpr int kMaxScatter = 64;
 // positions per span: the plain reduce keeps 64 KiB of accumulators per workgroup, the passes with the PRF inside (launch_span_prf)
 // what the AES tables leave of a CU's LDS.  A table of span bounds serves the kernels of ONE of the two sizes (launch_span_bounds fills both in one pass).
-constexpr int kSpanReduce = 4096, kSpanFused = 1752;
+#ifndef FLASHE_SPAN_FUSED
+#define FLASHE_SPAN_FUSED 1752
+#endif
+constexpr int kSpanReduce = 4096, kSpanFused = FLASHE_SPAN_FUSED;
 uint64_t span_count(uint64_t total, int span);
 // words of a bounds table that is large enough for either span size
 inline size_t span_table_words(uint64_t total, int C) { return static_cast<size_t>(span_count(total, kSpanFused) + 1) * static_cast<size_t>(C); }

@@ -895,6 +895,9 @@ struct SpanPrfEntry {
 #ifndef FLASHE_SPAN_OVERLAP
 #define FLASHE_SPAN_OVERLAP 1
 #endif
+#ifndef FLASHE_SPAN_PRIO
+#define FLASHE_SPAN_PRIO 1
+#endif
 
 template <int ENC>
 __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys rk, const SpanPrfTable tb, int C, uint32_t iter0, uint64_t total, uint32_t n_spans,
@@ -1072,6 +1075,14 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 2; r < 14; r++) {
+#if FLASHE_SPAN_PRIO
+                // waves that are ahead yield to the ones behind: the span ends at a barrier, and a wave that runs its last rounds alone
+                // on its SIMD sees the full lookup latency every round while the LDS idles
+                if (r == 2) __builtin_amdgcn_s_setprio(3);
+                else if (r == 5) __builtin_amdgcn_s_setprio(2);
+                else if (r == 8) __builtin_amdgcn_s_setprio(1);
+                else if (r == 11) __builtin_amdgcn_s_setprio(0);
+#endif
                 if (r < 10) finish_main(rk, r, k, s);
                 else {
 #pragma unroll
@@ -1110,6 +1121,9 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         }
 #undef SPAN_PRF_FROM
         SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14 (+ the next entry's lookup)
+#ifdef FLASHE_TUNING
+        if (OVERLAP && probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
+#endif
         auto write_out = [&](uint64_t q0, uint32_t qlen) {
 #pragma unroll
             for (int e = 0; e < PER; e++) {
@@ -1150,7 +1164,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         }
         SPAN_PRF_TICK(3);
 #ifdef FLASHE_TUNING
-        if (probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
+        if (!OVERLAP && probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
 #endif
         __syncthreads();
         if (OVERLAP) {

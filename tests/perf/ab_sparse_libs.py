@@ -2,7 +2,9 @@
 """Config 5's two fused sparse passes under two BUILDS of the library alternated inside one process (same box, same clock):
 flashe_sparse_encrypt_aggregate_dev (50 encrypts + the aggregate of their uploads) and flashe_sparse_decrypt_dev, HIP-event times, and
 the results of the two builds compared byte for byte (the GPU suite compares the product build with the oracle).
-usage: ab_sparse_libs.py <other .so in flashe_amd/> [reps]        e.g. after  make -C flashe_amd/csrc ab ABFLAGS=-DFLASHE_SPAN_OVERLAP=0"""
+usage: ab_sparse_libs.py <.so in flashe_amd/> [more .so ...]      e.g. after  make -C flashe_amd/csrc ab ABFLAGS=-DFLASHE_SPAN_OVERLAP=0
+       (the first library named is the reference of the byte comparison; AB_REPS = alternations, default 6; `make ab` builds carry
+       -DFLASHE_TUNING, so compare them with libflashe_hip_tuning.so rather than with the product library)"""
 import os
 import sys
 
@@ -20,8 +22,8 @@ def engine_from(name, b):
     return Engine(bytes(range(32)), b)
 
 
-other = sys.argv[1]
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+libs = sys.argv[1:] if len(sys.argv) > 2 else ["libflashe_hip.so", sys.argv[1]]
+reps = int(os.environ.get("AB_REPS", 6))
 total, C, b, J = int(os.environ.get("AB_TOTAL", 25_557_032)), int(os.environ.get("AB_CLIENTS", 50)), 128, 16
 k = total // 100
 rng = [np.random.Generator(np.random.PCG64(2000 + c)) for c in range(C)]
@@ -29,7 +31,7 @@ locs = [np.sort(r.choice(total, k, replace=False)).astype(np.uint32) for r in rn
 vals = [r.integers(0, 2 ** 64, k, dtype=np.uint64) for r in rng]
 zero = 1 << 31
 runs, outs = {}, {}
-for name in ("libflashe_hip.so", other):
+for name in libs:
     eng = engine_from(name, b)
     d_loc, d_val = [eng.upload(l) for l in locs], [eng.upload(v) for v in vals]
     d_ct = [eng.alloc_vec(k) for _ in range(C)]
@@ -50,8 +52,8 @@ for name in ("libflashe_hip.so", other):
     runs[name] = (eng, enc, dec, rebound, [eng.event() for _ in range(4)], (d_ct, d_agg, d_dec))
     enc(0); dec(0); eng.sync()
     outs[name] = (d_agg.download(np.uint64, 2 * total), d_dec.download(np.uint64, 2 * total), d_ct[0].download(np.uint64, 2 * k), d_ct[C - 1].download(np.uint64, 2 * k))
-a, o = outs["libflashe_hip.so"], outs[other]
-same = all(np.array_equal(x, y) for x, y in zip(a, o))
+a = outs[libs[0]]
+same = all(np.array_equal(x, y) for o in outs.values() for x, y in zip(a, o))
 # the decrypted dense vector is the plain sum: low limb check (the GPU suite and bench.py check every limb against the oracle)
 want = np.full(total, np.uint64((C * zero) & (2 ** 64 - 1)), dtype=np.uint64)
 for c in range(C):

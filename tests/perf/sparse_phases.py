@@ -48,8 +48,13 @@ if os.environ.get("FLASHE_SPAN_PROBE") == "9":              # tuning build: wher
     fn = eng._lib.flashe_tune_span_prf_cycles
     fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int], ctypes.c_int
     fn(eng._h, out, 1)
-    names = ["search + round 1", "rounds 2..14", "position wait + atomics", "loop exit", "barrier 1", "publish + write-out", "barrier 2", "loop head"]
+    # (round 5, FLASHE_SPAN_OVERLAP: order in the loop = head, rounds, wait + write-out of the previous span, barrier A, atomics, second pass,
+    # barrier B; the per-wave figures = loop head -> end of the wave's rounds)
+    names = ["search + round 1", "rounds 2..14", "atomics (+ ct store)", "second pass (crowded spans)", "barrier A (after the write-out)", "wait + write-out of the previous span",
+             "barrier B (entries in)", "loop head"]
     tot = sum(out[:8])
-    print("  head -> barrier 1 per wave:", [int(v) // 1710 for v in out[8:24]])
+    spans = int(os.environ.get("SPANS_PER_CALL", 57)) * 30              # 30 calls of ~57 spans per workgroup (config 5 on 256 CUs)
+    print("  head -> end of rounds per wave, cycles per span:", [int(v) // spans for v in out[8:24]])
+    print("  cycles per span (wave 0):", tot // spans)
     for n, v in zip(names, out):
         print(f"  {n:28s} {v:14d} ticks  {100.0 * v / max(tot, 1):5.1f} %")
