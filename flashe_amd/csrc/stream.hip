@@ -887,17 +887,43 @@ struct SpanPrfEntry {
     u128 pt;             // ENC: the plaintext
 };
 
-// FLASHE_SPAN_OVERLAP (round 5): the write-out of a span -- accumulators read, zeroed, `from +/- acc` stored -- no longer sits between
-// two barriers with no AES in flight.  Every wave writes its share of the PREVIOUS span out as soon as its own rounds of this span are
-// done (the accumulators receive this span's entries only after the barrier that follows), so the waves that finish early (the ones
-// without entries, the ones on a SIMD with three busy waves) do it under the rounds of the slow ones, and what remains between the two
-// barriers of a span is the entries' atomics.  0 = the round-4 order (A/B builds).
-#ifndef FLASHE_SPAN_OVERLAP
-#define FLASHE_SPAN_OVERLAP 1
-#endif
+// Round 5: no barrier in the loop.  A span's accumulators go through two phases -- they RECEIVE the entries' masks (atomics), then they
+// are WRITTEN OUT (read, zeroed, `from +/- sum` stored) -- and each phase may start only when every wave is through with the other.
+// Round 4 put a workgroup barrier at both boundaries: twice per span all sixteen waves stopped, the last ones ran their final rounds
+// alone on their SIMD, and for a fifth of the time no AES lookup was in flight on the CU (58 % LDS-busy).  Now both boundaries are
+// split-phase: a wave ARRIVES (one LDS add) when it is through with a phase and WAITS (polls that counter) only where it needs the
+// other waves -- the write-out of span i - 1 sits in the middle of the rounds of span i (its accumulators were completed at the end of
+// the previous iteration: six rounds earlier), the atomics of span i at the end of its rounds (the accumulators were emptied six rounds
+// earlier) -- so a wait almost never blocks, waves drift up to half a span apart, and one wave's atomics, table reads and loop head run
+// under the other waves' rounds.  The counters only grow (sixteen arrivals per phase and span).
 #ifndef FLASHE_SPAN_PRIO
-#define FLASHE_SPAN_PRIO 1
+#define FLASHE_SPAN_PRIO 1       // waves yield as they advance through the rounds of a span (0 = off, for A/B builds)
 #endif
+
+__device__ __forceinline__ void phase_arrive(uint32_t *ctr)
+{
+    // (workgroup-scope release on this target: s_waitcnt lgkmcnt(0) -- the LDS runs a wave's operations in order, so whatever this wave
+    // did to the accumulators or the span tables is ahead of its arrival; no wait for outstanding global stores)
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// a look at a counter that nobody waits for: the value is used a round later (threaded through the rounds one step ahead of the wait,
+// so that the common case -- everybody arrived long ago -- costs no LDS round trip where the wait stands)
+__device__ __forceinline__ uint32_t phase_peek(uint32_t *ctr)
+{
+    return __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void phase_wait(uint32_t *ctr, uint32_t target, uint32_t peeked)
+{
+    uint32_t seen = __builtin_amdgcn_readfirstlane(peeked);
+    while (static_cast<int32_t>(seen - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    // nothing below moves above the wait -- as a COMPILER barrier: the LDS returns a wave's reads in order, so what follows the read
+    // that saw the count cannot be older than it; an acquire fence at workgroup scope also drains the memory counter on this target
+    // (s_waitcnt vmcnt(0)), i.e. it would wait here for the dense values that were just requested a span ahead
+    asm volatile("" ::: "memory");
+}
 
 template <int ENC>
 __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys rk, const SpanPrfTable tb, int C, uint32_t iter0, uint64_t total, uint32_t n_spans,
@@ -905,11 +931,10 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                                                                uint64_t mask_hi, const uint64_t *src, bool negate, uint64_t *out,
                                                                const uint32_t *__restrict__ te0, uint32_t *err_flag, int probe)
 {
-    constexpr int SPAN = kSpanFused, THREADS = kPrfThreads, PER = (SPAN + THREADS - 1) / THREADS;
-    constexpr bool OVERLAP = FLASHE_SPAN_OVERLAP != 0;
+    constexpr int SPAN = kSpanFused, THREADS = kPrfThreads, PER = (SPAN + THREADS - 1) / THREADS, WAVES = THREADS / 64;
     const uint32_t iter = iter0 + te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
-    __shared__ unsigned long long acc[2 * SPAN];
+    __shared__ __attribute__((aligned(16))) unsigned long long acc[2 * SPAN];
     // (prefix, begin) per client of the span in flight and of the NEXT one: entry f of a span belongs to the client c with
     // pb[c].x <= f < pb[c + 1].x and is entry pb[c].y + (f - pb[c].x) of that client's list; pb[C].x = entries in the span
     __shared__ uint2 s_pb[2][kMaxScatter + 2];
@@ -918,10 +943,12 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
     __shared__ const uint64_t *s_pt[ENC ? kMaxScatter : 1];
     __shared__ uint64_t *s_ct[ENC ? kMaxScatter : 1];
     __shared__ uint64_t s_sub[ENC ? 2 * kMaxScatter : 2];
+    __shared__ uint32_t s_phase[2];                           // arrivals: [0] a wave's entries of a span are in, [1] its share of a span is written out
     fill_tables(tab, te0);
     const LaneRegs lr = lane_regs(tab);
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * SPAN; i += THREADS) acc[i] = 0;
+    if (tid < 2) s_phase[tid] = 0;
     // the LAST wave keeps the span tables: it is the wave with the fewest entries (none at all while a span holds at most 960)
     const int ln = tid & 63;
     const bool keeper = tid >= THREADS - 64;
@@ -936,10 +963,11 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
     const u128 base = (static_cast<u128>(base_hi) << 64) | base_lo;
     const uint32_t stride = gridDim.x;
     // The keeper wave: the slice [f0, f1) of client `ln`'s list in a span (clamped like span_reduce_kernel's) is loaded THREE spans
-    // ahead and published TWO spans ahead -- at the head of an iteration, into the table of the span in flight, which nobody reads any
-    // more (its entry count travels in a register) unless the span is crowded (more than 1,024 entries: a second pass looks entries up
-    // in it; the table is then published behind the entries' barrier).  Every lane can so look its entry of the next span up under
-    // the rounds of this one, and no wave waits for the keeper.  The loads are unconditional (clamped indices).
+    // ahead and published TWO spans ahead -- early in an iteration (behind the wait for the previous span's entries, which every wave
+    // passes in the middle of its rounds), into the table of the span in flight, which nobody reads any more (its entry count travels in
+    // a register) unless the span is crowded (more than 1,024 entries: a second pass looks entries up in it; the table is then published
+    // between two barriers at the end of the iteration).  Every lane can so look its entry of the next span up under the rounds of this
+    // one, and no wave waits for the keeper.  The loads are unconditional (clamped indices).
     uint32_t f0 = 0, f1 = 0;
     bool f_live = false;
     const uint32_t ln_c = static_cast<uint32_t>(min(ln, C - 1));
@@ -976,16 +1004,12 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         return e;
     };
     // what an entry's block is worth once the rounds are done: ENC stores the ciphertext on the way
-    // (ENC: the ciphertext goes to *ct_later / *ct_to when the caller stores it itself -- the first 1,024 entries of a span, whose
-    // store must come BEHIND the wait that follows the entries' barrier, not in front of it)
-    auto settle = [&](const SpanPrfEntry &e, const uint32_t (&s)[4], uint32_t p0_lo, uint32_t span_len, u128 *ct_later, uint64_t **ct_to) {
+    auto settle = [&](const SpanPrfEntry &e, const uint32_t (&s)[4], uint32_t p0_lo, uint32_t span_len) {
         if (!e.valid) return;
         u128 w = words_to_u128(s) & mask;
         if (ENC) {
             w = (e.pt + w) & mask;
-            uint64_t *to = s_ct[e.c] ? s_ct[e.c] + 2 * static_cast<uint64_t>(e.q) : nullptr;
-            if (ct_later) { *ct_later = w; *ct_to = to; }
-            else if (to) st128_nt_g(to, w);
+            if (s_ct[e.c]) st128_nt_g(s_ct[e.c] + 2 * static_cast<uint64_t>(e.q), w);
             w -= (static_cast<u128>(s_sub[2 * e.c + 1]) << 64) | s_sub[2 * e.c];
         }
         const uint32_t r = e.pos - p0_lo;
@@ -1015,59 +1039,85 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
     uint32_t n_entries = s_pb[0][C].x;
     SpanPrfEntry cur = lookup(0, tid, n_entries);
     // (the first entry's loads are waited for HERE: left pending into the loop, they make the compiler guard the entry's use in EVERY
-    // iteration with a full wait -- which then also covers the dense prefetch issued a few rounds earlier)
+    // iteration with a full wait)
     __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
-    __syncthreads();                             // (the keeper's first act in the loop overwrites the table this lookup read)
+    __syncthreads();                             // (the keeper's first act in the loop overwrites the table this lookup read; the last barrier of the common path)
     int buf = 0;
+    // the span whose accumulators are complete and not yet written out (the one of the previous iteration), the dense vector's values at
+    // this lane's positions of it (requested a span ahead of their use: under load a gather from HBM takes several thousand cycles), and
+    // how many iterations are behind this wave (the phase counters stand at sixteen arrivals per finished iteration)
+    uint64_t wp0 = 0;
+    uint32_t wlen = 0, done = 0;
+    u128 from[PER];
+#pragma unroll
+    for (int e = 0; e < PER; e++) from[e] = base;
+    // the write-out of the previous span, in three steps that the rounds thread one by one (or that a wave without entries runs in a row)
+    u128 wa[PER];
+    auto wout_read = [&](uint32_t seen, int buf, bool early, uint64_t sp) {
+        phase_wait(&s_phase[0], WAVES * done, seen);                       // every wave's entries of the previous span are in
+        // ... which also says that every wave is through with the PREVIOUS iteration, where the table of the span now in flight was
+        // searched for this iteration's entries: the keeper may put the table of the span after next in its place
+        if (keeper && early) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const uint32_t r = min(static_cast<uint32_t>(tid + e * THREADS), static_cast<uint32_t>(SPAN - 1));
+            wa[e] = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
+        }
+    };
+    auto wout_store = [&]() {
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const uint32_t r = tid + e * THREADS;
+            if (r < wlen) {
+                acc[2 * r] = 0; acc[2 * r + 1] = 0;
+#ifdef FLASHE_TUNING
+                if (probe == 4 && static_cast<uint64_t>(wa[e]) != 0x1234567ull) continue;      // 4 = no dense read / write
+#endif
+                st128_nt(out + 2 * (wp0 + r), (negate ? from[e] - wa[e] : from[e] + wa[e]) & mask);
+            }
+        }
+        phase_arrive(&s_phase[1]);                                         // this wave's share of the accumulators is empty
+    };
+    auto from_load = [&](uint64_t q0, uint32_t qlen) {                     // for the NEXT iteration's write-out: the span in flight now
+#pragma unroll
+        for (int e = 0; e < PER; e++) {
+            const uint32_t r_ = tid + e * THREADS;
+#ifdef FLASHE_TUNING
+            from[e] = src && r_ < qlen && probe != 4 ? ld128_nt(src + 2 * (q0 + r_)) : base;
+#else
+            from[e] = src && r_ < qlen ? ld128_nt(src + 2 * (q0 + r_)) : base;
+#endif
+        }
+    };
 #ifdef FLASHE_TUNING
     unsigned long long tick_ = __builtin_readcyclecounter();
 #endif
-    // OVERLAP: the span whose accumulators are complete and not yet written out (the one of the previous iteration)
-    uint64_t wp0 = 0;
-    uint32_t wlen = 0;
-    for (; sp < sp_end; sp += stride, buf ^= 1) {
+    for (; sp < sp_end; sp += stride, buf ^= 1, done++) {
         const uint64_t p0 = sp * SPAN;
         const uint32_t span_len = static_cast<uint32_t>(total - p0 < SPAN ? total - p0 : SPAN);
-        // the dense vector is read (and written) for the span being WRITTEN OUT: this one in the round-4 order, the previous one here
-        const uint64_t fp0 = OVERLAP ? wp0 : p0;
-        const uint32_t flen = OVERLAP ? wlen : span_len;
         SPAN_PRF_TICK(7);
 #ifdef FLASHE_TUNING
         const unsigned long long head_ = __builtin_readcyclecounter();
         if (probe == 2) n_entries = 0;                                     // timing probes (wrong results): 1 = no rounds, 2 = no entries, 3 = no atomics
 #endif
         const bool early = n_entries <= THREADS;                           // nobody will look an entry up in this span's table any more
-        if (keeper && early) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
-        // the dense read of the span: requested BEHIND the next entry's loads (the memory counter is in order: what is waited for after
-        // the entries' barrier is everything up to these), still some 4,000 cycles before its use
-        u128 from[PER];
-#ifdef FLASHE_TUNING
-#define SPAN_PRF_FROM()                                                                                                  \
-        _Pragma("unroll") for (int e = 0; e < PER; e++) {                                                                 \
-            const uint32_t r_ = tid + e * THREADS;                                                                        \
-            from[e] = src && r_ < flen && probe != 4 ? ld128_nt(src + 2 * (fp0 + r_)) : base;      /* 4 = no dense read / write */ \
-        }
-#else
-#define SPAN_PRF_FROM()                                                                                                  \
-        _Pragma("unroll") for (int e = 0; e < PER; e++) {                                                                 \
-            const uint32_t r_ = tid + e * THREADS;                                                                        \
-            from[e] = src && r_ < flen ? ld128_nt(src + 2 * (fp0 + r_)) : base;                                            \
-        }
-#endif
         const int nbuf = buf ^ 1;
         const uint32_t n_next = sp + stride < sp_end ? s_pb[nbuf][C].x : 0u;
-        // The first 1,024 entries, one per lane: its block's rounds with the lookup of the lane's entry of the NEXT span threaded
-        // through them -- one step of the owner search per round (each a dependent LDS read), then the entry's position (and plaintext)
-        // load and its round-1 lookups: all of it latency that the sixteen lookups per round hide.
+        // The first 1,024 entries, one per lane: its block's rounds with everything else threaded through them, one step per round (each a
+        // dependent LDS read or a memory request whose latency the sixteen lookups of a round hide): the owner search for the lane's entry
+        // of the NEXT span (r = 2..7), that entry's position / plaintext load (8) and round-1 lookups (9); the write-out of the PREVIOUS
+        // span (4: peek at the arrivals, 5: wait + read the accumulators, 6: zero them, store, arrive), the dense read for the next
+        // write-out (7), a peek at the write-out arrivals for the wait in front of this span's atomics (12).
         SpanPrfEntry nxt;
         nxt.valid = false; nxt.c = 0; nxt.q = 0; nxt.pos = 0; nxt.pt = 0; nxt.pre = make_uint4(0, 0, 0, 0); nxt.x = CtrVar{{0, 0, 0, 0}};
         const uint32_t f = tid;
         uint32_t s[4] = {0, 0, 0, 0};
+        uint32_t seen_out = 0;
         if (__builtin_amdgcn_ballot_w64(cur.valid || f < n_next)) {
             const CtrPrefix pre{{cur.pre.x, cur.pre.y, cur.pre.z, cur.pre.w}};
             ctr_round1(pre, cur.x, s);
             int cn = 0;
-            uint32_t pv;
+            uint32_t pv, seen_in = 0;
             uint2 pbn = make_uint2(0, 0);
             const uint32_t *locn = nullptr;
             Lk16 k = issue_main(lr, s);
@@ -1076,8 +1126,10 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
 #pragma unroll
             for (int r = 2; r < 14; r++) {
 #if FLASHE_SPAN_PRIO
-                // waves that are ahead yield to the ones behind: the span ends at a barrier, and a wave that runs its last rounds alone
-                // on its SIMD sees the full lookup latency every round while the LDS idles
+                // waves that are ahead yield to the ones behind: a wave that runs its rounds alone on its SIMD sees the full lookup latency
+                // every round while the other SIMD slots idle.  (Measured and dropped, tests/perf/experiments/r05_*: the waves in two
+                // priority classes half a span apart, so that one class's atomics / loop head fall into the other's rounds -- the waits
+                // below then block for a round each and the passes get 5-9 % slower; no priorities at all: 15-20 % slower.)
                 if (r == 2) __builtin_amdgcn_s_setprio(3);
                 else if (r == 5) __builtin_amdgcn_s_setprio(2);
                 else if (r == 8) __builtin_amdgcn_s_setprio(1);
@@ -1103,12 +1155,16 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                     }
                 } else if (r == 9) {
                     nxt.x = ctr_var(rk, lr, nxt.q);
-                } else if (r == 10 && !OVERLAP) {
-                    SPAN_PRF_FROM()
                 }
-                if (OVERLAP && r == 3) {                             // (behind the position load of this span's entry, well ahead of its use)
-                    SPAN_PRF_FROM()
+                if (r == 4) seen_in = phase_peek(&s_phase[0]);
+                else if (r == 5) wout_read(seen_in, buf, early, sp);
+                else if (r == 6) {
+                    // (in front of the next entry's loads of r = 8: what is outstanding here was requested a span ago)
+                    __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0)
+                    wout_store();
                 }
+                if (r == 7) from_load(p0, span_len);
+                else if (r == 12) seen_out = phase_peek(&s_phase[1]);
                 k = r < 13 ? issue_main(lr, s) : issue_final(lr, s);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1117,40 +1173,21 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                 s[j] = bfi(0xff000000u, k.v[4 * j], bfi(0x00ff0000u, k.v[4 * j + 1], bfi(0x0000ff00u, k.v[4 * j + 2], k.v[4 * j + 3]))) ^ rkv[16 + j];
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            SPAN_PRF_FROM()
+            // a wave without entries in this span and the next: the same steps in a row
+            wout_read(phase_peek(&s_phase[0]), buf, early, sp);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            wout_store();
+            from_load(p0, span_len);
+            seen_out = phase_peek(&s_phase[1]);
         }
-#undef SPAN_PRF_FROM
-        SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14 (+ the next entry's lookup)
+        SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14 (+ everything threaded through them)
 #ifdef FLASHE_TUNING
-        if (OVERLAP && probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
+        if (probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
 #endif
-        auto write_out = [&](uint64_t q0, uint32_t qlen) {
-#pragma unroll
-            for (int e = 0; e < PER; e++) {
-                const uint32_t r = tid + e * THREADS;
-                if (r < qlen) {
-                    const u128 a = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
-                    acc[2 * r] = 0; acc[2 * r + 1] = 0;
-#ifdef FLASHE_TUNING
-                    if (probe == 4 && static_cast<uint64_t>(a) != 0x1234567ull) continue;
-#endif
-                    st128_nt(out + 2 * (q0 + r), (negate ? from[e] - a : from[e] + a) & mask);
-                }
-            }
-        };
-        if (OVERLAP) {
-            // this wave's share of the previous span, under the rounds of the waves that are still busy; the accumulators get this
-            // span's entries behind the barrier below.  (every load of the iteration has returned or is about to: one wait, here)
-            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
-            write_out(wp0, wlen);
-            SPAN_PRF_TICK(5);
-            __syncthreads();
-            SPAN_PRF_TICK(4);
-        }
-        u128 ct_val = 0;
-        uint64_t *ct_to = nullptr;
-        settle(cur, s, static_cast<uint32_t>(p0), span_len, &ct_val, &ct_to);
-        if (OVERLAP && ENC && ct_to) st128_nt_g(ct_to, ct_val);
+        // this span's entries go into the accumulators once every wave has emptied its share of them (arrivals of THIS iteration's r = 10)
+        phase_wait(&s_phase[1], WAVES * (done + 1), seen_out);
+        SPAN_PRF_TICK(4);
+        settle(cur, s, static_cast<uint32_t>(p0), span_len);
         SPAN_PRF_TICK(2);
         // entries beyond the first 1,024 of a crowded span: looked up and computed one after the other
         for (uint32_t f2 = tid + THREADS; f2 < n_entries; f2 += THREADS) {
@@ -1160,54 +1197,27 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
             ctr_round1(pre, e.x, s2);
             aes256_rounds1_deep<2>(rk, lr, s2);
             __builtin_amdgcn_sched_barrier(0);
-            settle(e, s2, static_cast<uint32_t>(p0), span_len, nullptr, nullptr);
+            settle(e, s2, static_cast<uint32_t>(p0), span_len);
         }
         SPAN_PRF_TICK(3);
-#ifdef FLASHE_TUNING
-        if (!OVERLAP && probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
-#endif
-        __syncthreads();
-        if (OVERLAP) {
-            SPAN_PRF_TICK(6);                                                  // barrier: every entry of this span is in the accumulators
-            wp0 = p0; wlen = span_len;
-            if (!early) {                                                      // (workgroup-uniform; rare: more than 1,024 entries in a span)
-                // the table of the span in flight was still read by the second pass: published now, and visible before the next
-                // iteration's lookups read it
-                if (keeper) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
-                __syncthreads();
-            }
-        } else {
-            SPAN_PRF_TICK(4);                                                      // barrier: the slowest wave's entries
-            // every load of this span has returned or is about to (the next entry's were issued rounds ago): saying so HERE, on every wave's
-            // path, keeps the compiler from guarding the reuse of the prefetch registers with waits that would also cover the stores below
-            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
-            if (ENC && ct_to) st128_nt_g(ct_to, ct_val);
-            if (keeper && !early) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
-            __builtin_amdgcn_sched_barrier(0);
-            write_out(p0, span_len);
-            SPAN_PRF_TICK(5);                                                      // publish + write-out
+        phase_arrive(&s_phase[0]);                                         // this wave's entries of the span are in
+        wp0 = p0; wlen = span_len;
+        if (!early) {                                                      // (workgroup-uniform; rare: more than 1,024 entries in a span)
+            // the table of the span in flight was read by the second pass: published once every wave is through with it, and visible
+            // before the next iteration's lookups read it
             __syncthreads();
-            SPAN_PRF_TICK(6);
+            if (keeper) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
+            __syncthreads();
         }
+        SPAN_PRF_TICK(6);
         cur = nxt;
         n_entries = n_next;
     }
-    if (OVERLAP && wlen) {
-        // the last span of this workgroup: its accumulators are complete (the loop's closing barrier), nothing is left to hide behind
-        u128 from[PER];
-#pragma unroll
-        for (int e = 0; e < PER; e++) {
-            const uint32_t r_ = tid + e * THREADS;
-            from[e] = src && r_ < wlen ? ld128_nt(src + 2 * (wp0 + r_)) : base;
-        }
-#pragma unroll
-        for (int e = 0; e < PER; e++) {
-            const uint32_t r = tid + e * THREADS;
-            if (r < wlen) {
-                const u128 a = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
-                st128_nt(out + 2 * (wp0 + r), (negate ? from[e] - a : from[e] + a) & mask);
-            }
-        }
+    if (wlen) {
+        // the last span of this workgroup: nothing is left to hide behind
+        wout_read(phase_peek(&s_phase[0]), 0, false, 0);
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        wout_store();
     }
 #undef SPAN_PRF_FETCH
 #undef SPAN_PRF_PUBLISH
