@@ -745,6 +745,7 @@ struct SmallParams {
     uint32_t n_jobs, iter;
     int b, m;
     int no_direct;            // A/B knob FLASHE_SMALL_DIRECT: 0 = stage every output through the LDS rows, 2 = general walk instead of the b <= 32 fast walk
+    int no_fixed_width;       // A/B knob FLASHE_SMALL_FIXED=0: the compact layout's kernels with int_bits at run time even at 16 / 20 / 23
     uint32_t m_magic;         // ceil(2^32 / m): x / m == (x * m_magic) >> 32 for x < 2^13
     uint64_t mask_lo;
     uint64_t top_lo, top_hi;  // the top bit of every b-bit slot of the 128-bit word (SWAR subtraction)
@@ -1100,6 +1101,70 @@ __device__ __forceinline__ void small_direct(bool valid, int cnt, uint64_t j0, u
         if (ok[t]) __builtin_nontemporal_store((pt[t] + static_cast<uint64_t>(D >> (p.b * t))) & p.mask_lo, out + (j0 + t - first));
 }
 
+// ---- the compact layout at a COMPILE-TIME width (round 5): int_bits = 16 / 20 / 23, what the reference's un-batched jobs run ----
+// In the uint32 layout the m = 128 / B elements of a lane's AES block are m adjacent 4-byte words, and consecutive lanes of a whole tile
+// hold consecutive blocks: the lane loads, adds and stores ITS OWN block's elements -- 16 + 8 bytes at m = 6, 16 + 4 at m = 5, 16 + 16 at
+// m = 8, a wave covers one contiguous run of 64 m words -- with every slot position a compile-time constant: slot t of a stream is one
+// v_alignbit / shift of two state words, the client's mask term is slot(add stream) - slot(minus stream) per element (no SWAR
+// subtraction with borrow fix-ups over the 128-bit word, no staging of the difference through an LDS row, no funnel shifts at lane-
+// dependent word offsets, no walk state), and the plaintext prefetch holds m registers per block across the AES rounds instead of
+// eight.  Whole tiles inside the range only; chunk ends and range ends keep the general walk.
+template <int M> struct DirectPt { uint32_t v[M]; };
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+template <int M>
+__device__ __forceinline__ DirectPt<M> direct32_load(const uint32_t *__restrict__ in, uint64_t k)
+{
+    DirectPt<M> r;
+#pragma unroll
+    for (int t = 0; t < M; t++) r.v[t] = 0u;
+    if (!in) return r;
+    const uint32_t *q = in + k;
+    int t = 0;
+#pragma unroll
+    for (; t + 4 <= M; t += 4) {
+        const u32x4_a4 x = *reinterpret_cast<const u32x4_a4 *>(q + t);
+        r.v[t] = x[0]; r.v[t + 1] = x[1]; r.v[t + 2] = x[2]; r.v[t + 3] = x[3];
+    }
+    if (M - t >= 2) {
+        const u32x2_a4 x = *reinterpret_cast<const u32x2_a4 *>(q + t);
+        r.v[t] = x[0]; r.v[t + 1] = x[1];
+        t += 2;
+    }
+    if (t < M) r.v[t] = q[t];
+    return r;
+}
+
+// out[k + t] = (pt[t] + slot_t(add) - slot_t(minus)) mod 2^B for the M = 128 / B elements of the lane's block; `single`: no minus stream
+template <int B>
+__device__ __forceinline__ void direct32_store(uint32_t *__restrict__ out, uint64_t k, const DirectPt<128 / B> &pt, u128 add, u128 minus, bool single)
+{
+    constexpr int M = 128 / B;
+    constexpr uint32_t mask = B >= 32 ? 0xffffffffu : ((1u << (B & 31)) - 1u);
+    uint32_t r[M];
+#pragma unroll
+    for (int t = 0; t < M; t++) {
+        const uint32_t a = static_cast<uint32_t>(add >> (B * t)), m = static_cast<uint32_t>(minus >> (B * t));      // (constant shifts: one v_alignbit each)
+        r[t] = (pt.v[t] + a - (single ? 0u : m)) & mask;
+    }
+    uint32_t *q = out + k;
+    int t = 0;
+#pragma unroll
+    for (; t + 4 <= M; t += 4) {
+        u32x4_a4 x;
+        x[0] = r[t]; x[1] = r[t + 1]; x[2] = r[t + 2]; x[3] = r[t + 3];
+        *reinterpret_cast<u32x4_a4 *>(q + t) = x;
+    }
+    if (M - t >= 2) {
+        u32x2_a4 x;
+        x[0] = r[t]; x[1] = r[t + 1];
+        *reinterpret_cast<u32x2_a4 *>(q + t) = x;
+        t += 2;
+    }
+    if (t < M) q[t] = r[t];
+}
+
 // per b-bit slot (prev - cur) mod 2^b of two 128-bit words (SWAR: borrows must not cross slots); b == 64: the slots are the two
 // halves and two plain 64-bit subtractions do it (-2 % on ten 1e7-element vectors: the output arithmetic, not the lookup count,
 // is what separates this kernel from the wide one -- tests/perf/experiments/r03_small_win_kernel.patch)
@@ -1112,10 +1177,14 @@ __device__ __forceinline__ u128 slot_diff(u128 prev, u128 cur, u128 top, int b)
     return ((prev | top) - (cur & ~top)) ^ ((prev ^ ~cur) & top);
 }
 
-template <bool PAIR, class ET = uint64_t>
+// B: 0 = int_bits at run time; 16 / 20 / 23 (compact layout, PAIR only) = the width as a compile-time constant, whole tiles through
+// direct32_load / direct32_store
+template <bool PAIR, class ET = uint64_t, int B = 0>
 __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const RoundKeys rk, const SmallChainTable tb, int n_chains, const SmallParams p)
 {
+    static_assert(B == 0 || (PAIR && sizeof(ET) == 4 && B <= 32), "compile-time widths: the compact layout's paired kernel");
     constexpr uint32_t WAVES = kSmallThreads / 64, TILE = PAIR ? 128u : 64u;
+    constexpr int MB = B ? 128 / B : 1;
     __shared__ uint32_t tab[kTabWords];
     __shared__ uint32_t scratch[(kSmallThreads / 64) * 256 + 8];
     __shared__ __attribute__((aligned(16))) uint32_t pre_lds[(kMaxLinks + kMaxChains) * 4];
@@ -1206,8 +1275,14 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 const CtrPrefix pre = load_prefix(pre_lds, sbase + c);
                 const int link = single ? c : c - 1;
                 WalkPt ptA{}, ptB{};
-                if (link >= 0 && fastA) ptA = small_walk32_load(reinterpret_cast<const ET *>(tb.in[link0 + link]), e0A, first, lane, m32);
-                if (link >= 0 && fastB) ptB = small_walk32_load(reinterpret_cast<const ET *>(tb.in[link0 + link]), e0B, first, lane, m32);
+                DirectPt<MB> dA{}, dB{};
+                if (B) {
+                    if (link >= 0 && fastA) dA = direct32_load<MB>(reinterpret_cast<const uint32_t *>(tb.in[link0 + link]), j0A - first);
+                    if (link >= 0 && fastB) dB = direct32_load<MB>(reinterpret_cast<const uint32_t *>(tb.in[link0 + link]), j0B - first);
+                } else {
+                    if (link >= 0 && fastA) ptA = small_walk32_load(reinterpret_cast<const ET *>(tb.in[link0 + link]), e0A, first, lane, m32);
+                    if (link >= 0 && fastB) ptB = small_walk32_load(reinterpret_cast<const ET *>(tb.in[link0 + link]), e0B, first, lane, m32);
+                }
                 uint32_t s[2][4];
                 ctr_round1(pre, xA, s[0]);
                 ctr_round1(pre, xB, s[1]);
@@ -1218,6 +1293,18 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                     uint64_t *out = tb.out[link0 + link];
                     const ET *ein = reinterpret_cast<const ET *>(in);
                     ET *eout = reinterpret_cast<ET *>(out);
+                    if (B) {
+                        // compile-time width: whole tiles element by element from the two streams' slots, everything else the general walk
+                        if constexpr (B != 0) {
+                            uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
+                            if (fastA) direct32_store<B>(o32, j0A - first, dA, single ? SA : prevA, SA, single);
+                            else small_walk(row0, lane, vA, cntA, j0A, single ? SA : slot_diff(prevA, SA, top, p.b), ein, eout, first, range_end, p);
+                            if (fastB) direct32_store<B>(o32, j0B - first, dB, single ? SB : prevB, SB, single);
+                            else small_walk(row0, lane, vB, cntB, j0B, single ? SB : slot_diff(prevB, SB, top, p.b), ein, eout, first, range_end, p);
+                        }
+                        prevA = SA; prevB = SB;
+                        continue;
+                    }
                     // per slot (previous - current) mod 2^b: the previous stream is this client's add stream, the current its minus stream
                     const u128 DA = single ? SA : slot_diff(prevA, SA, top, p.b);
                     const u128 DB = single ? SB : slot_diff(prevB, SB, top, p.b);
@@ -2051,6 +2138,7 @@ static SmallParams small_params_of(const LaunchEnv &env, uint32_t iter, uint64_t
     SmallParams p{};
     p.n = n; p.n_jobs = n_jobs; p.iter = iter; p.b = env.b; p.m = 128 / env.b; p.te0 = env.te0_dev;
     { static const int v = FLASHE_TUNE_ENV("FLASHE_SMALL_DIRECT") ? atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_DIRECT")) : 1; p.no_direct = v == 0 ? 1 : v == 2 ? 2 : 0; }
+    { static const int v = FLASHE_TUNE_ENV("FLASHE_SMALL_FIXED") ? atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_FIXED")) : 1; p.no_fixed_width = v == 0; }
     p.m_magic = static_cast<uint32_t>(((1ull << 32) + p.m - 1) / p.m);
     uint64_t hi;
     masks_of(env.b, &p.mask_lo, &hi);
@@ -2201,7 +2289,13 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
         const uint64_t cus = static_cast<uint64_t>(env.num_cus);
         const int grid = static_cast<int>(tiles < cus ? tiles : cus);
         if (env.elem32) {
-            if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+            // the widths the reference's job configurations run (examples/configs/*_flashe_q16_*: int_bits 20; 100 clients: 23; 16) with
+            // their slot positions compiled in
+            const int fixed = (pair && !p.no_fixed_width) ? env.b : 0;
+            if (fixed == 20) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t, 20>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+            else if (fixed == 23) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t, 23>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+            else if (fixed == 16) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t, 16>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+            else if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
             else hipLaunchKernelGGL((prf_small_chain_kernel<false, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
         } else if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
         else hipLaunchKernelGGL((prf_small_chain_kernel<false>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);

@@ -191,6 +191,41 @@ def test_encrypt_batch_with_partial_aggregate(E, oracle, b, n, idx, scheme):
         eng.encrypt_batch_sum_dev(6, idx, E.SCHEME_DOUBLE, n, 16, dpt, 1, dct, dct[0])      # the sum must not alias a ciphertext
 
 
+@pytest.mark.parametrize("b,n,J,C,scheme", [(20, 6_400_007, 16, 3, "double"), (23, 5_300_003, 7, 2, "double"), (16, 8_388_608, 1, 2, "double"),
+                                           (20, 6_300_001, 5000, 2, "single"), (16, 4_200_000, 16, 3, "single"), (20, 6_299_999, 16, 2, "double")])
+def test_compact_layout_at_compile_time_widths(E, oracle, b, n, J, C, scheme):
+    """int_bits = 16 / 20 / 23 in the compact layout, launches long enough for the paired kernel (>= 1 M AES blocks per stream): the
+    instantiations of prf_small_chain_kernel with the width compiled in (a lane loads, adds and stores its own block's 128 // b elements,
+    slot positions constant).  EVERY ciphertext word against the oracle's encrypt (jzf_flashe.py:19-45 slot order and chunk-dependent
+    counters, :456-488): whole tiles take the new path; chunk ends (n_jobs = 7, 16, 5000: thousands of partial blocks), the ragged end
+    of the vector and tiles that straddle a chunk take the general walk inside the same kernel.  Plaintexts use all b bits so that the
+    per-slot subtraction wraps; misaligned vectors (4 bytes off a 16-byte boundary) and in-place encryption are covered too."""
+    eng = E.Engine(KEY, b, device=0)
+    assert eng.compact_supported()
+    rng = np.random.Generator(np.random.PCG64(n + 17 * C + b))
+    pts = [rng.integers(0, 2 ** b, n, dtype=np.uint64) for _ in range(C)]
+    idx = list(range(2, 2 + C))
+    sch = E.SCHEME_DOUBLE if scheme == "double" else E.SCHEME_SINGLE
+    d32 = [eng.upload(p.astype(np.uint32)) for p in pts]
+    c32 = [eng.alloc(4 * n + 32) for _ in range(C)]
+    eng.encrypt_batch_u32_dev(4, idx, sch, n, J, d32, c32)
+    want = [oracle.encrypt(KEY, 4, i, scheme, J, b, p)[:, 0].astype(np.uint32) for i, p in zip(idx, pts)]
+    for v in range(C):
+        got = c32[v].download(np.uint32, n)
+        bad = np.flatnonzero(got != want[v])
+        assert bad.size == 0, (b, n, J, v, bad[:8], got[bad[:4]], want[v][bad[:4]])
+    # vectors that start 4 bytes past a 16-byte boundary, output in place
+    off = eng.alloc(4 * n + 64)
+    off.upload_at(4, pts[0].astype(np.uint32))
+    eng.encrypt_batch_u32_dev(4, [idx[0]], sch, n, J, [off.ptr + 4], [off.ptr + 4])
+    assert np.array_equal(off.download(np.uint32, n + 1)[1:], want[0]), (b, n, "misaligned, in place")
+    # the round: reduce fused with the decrypt of the result gives back the plaintext sum
+    if scheme == "double":
+        out = eng.alloc(4 * n + 16)
+        eng.aggregate_decrypt_u32_dev(4, [idx[-1] + 1], [idx[0]], n, J, 0, n, c32, None, out, 4)
+        assert np.array_equal(out.download(np.uint32, n).astype(np.uint64), sum(pts) & np.uint64((1 << b) - 1)), (b, n, "round trip")
+
+
 @pytest.mark.parametrize("b,n,J,C,scheme", [(20, 100_003, 16, 10, "double"), (32, 70_001, 3, 4, "double"), (23, 61_706, 16, 100, "double"),
                                            (16, 2_000_003, 16, 3, "double"), (8, 4099, 1, 2, "single"), (1, 777, 5, 2, "double"),
                                            (31, 12, 16, 3, "double"), (20, 1_500_000, 16, 129, "single"), (25, 300_000, 7, 12, "double")])
