@@ -1530,46 +1530,59 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kern
         const uint32_t j0_lo = static_cast<uint32_t>(j0), j0_hi = static_cast<uint32_t>(j0 >> 32);
         int lane_base = 0;
         if constexpr (sizeof(IT) == 4 && sizeof(OT) == 4) {      // (measured without gain in the one-limb layout: 0.212 against 0.208 ms at b = 20 -- that walk streams 880 MB at 4.2 TB/s as it is)
-            // The regular tile -- 32 whole blocks inside the range, its 32 m elements a 16-byte aligned run of every operand (0x200: the
-            // host checked the pointers): a lane takes 16 BYTES of consecutive elements (four in the compact layout, two one-limb
-            // elements), one 16-byte load per operand and one 16-byte store, up to eight operands in flight -- a quarter / half of the
-            // memory instructions of the element-per-lane walk and more bytes in flight per lane, which is what this HBM-bound pass was
-            // short of (b <= 32: the sums and the slots are 32-bit, only the low word of a one-limb element takes part).
-            constexpr uint32_t EPQ = 16 / sizeof(IT);
+            // The regular tile -- 32 whole blocks inside the range (0x200: the host checked that every pointer is 16-byte aligned): a lane
+            // takes E consecutive elements of its operands in ONE access of 4 E bytes and makes one store, up to eight operands in flight
+            // -- a fraction of the memory instructions of the element-per-lane walk and more bytes in flight per lane, which is what this
+            // HBM-bound pass is short of (b <= 32: the sums and the slots are 32-bit).  E = 2, 3 or 4 (bits 10-11 of has_minus, chosen by the
+            // host, round 5) so that the tile's 32 m elements FILL the wave's accesses: at m = 6 (int_bits 20) a tile is 192 elements -- 48
+            // lanes of 16-byte accesses (round 4: 75 % of every access, 0.119 ms for ten 1e7-element operands), exactly 64 lanes of 12-byte
+            // ones; m = 4: 128 elements = 64 lanes of 8 bytes.
             const uint64_t e0t = static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_lo, 0)) |
                                  (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(j0_hi, 0))) << 32);
+            const uint32_t epl = (static_cast<uint32_t>(has_minus) >> 10) & 3u ? (static_cast<uint32_t>(has_minus) >> 10) & 3u : 4u;      // 0 = 4
             if ((has_minus & 0x200) && valid_mask == 0xffffffffu && partial_mask == 0 && e0t >= first && e0t + 32u * m32 <= range_end &&
-                ((e0t - first) & (EPQ - 1u)) == 0) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                constexpr int QB = 8;                                  // operands in flight per lane (C is wave-uniform: surplus slots issue nothing)
+                (epl != 4u || ((e0t - first) & 3u) == 0)) {
                 const uint64_t k0 = e0t - first;
-                for (uint32_t qd = lane; qd < (32u / EPQ) * m32; qd += 64u) {
-                    const uint64_t kq = k0 + EPQ * qd;
-                    u32x4 sum = {0u, 0u, 0u, 0u};
-                    for (int c = 0; c < C; c += QB) {
-                        u32x4 v[QB];
+                auto regular_tile = [&](auto e_tag) {
+                    constexpr uint32_t E = decltype(e_tag)::value;
+                    // (16-byte accesses are aligned: checked above; the narrower ones need their 4 bytes only)
+                    typedef uint32_t vecE __attribute__((ext_vector_type(E), aligned(E == 4 ? 16 : 4)));
+                    constexpr int QB = 8;                              // operands in flight per lane (C is wave-uniform: surplus slots issue nothing)
+                    for (uint32_t qd = lane; E * qd < 32u * m32; qd += 64u) {
+                        const uint64_t kq = k0 + E * qd;
+                        uint32_t sum[E];
 #pragma unroll
-                        for (int u = 0; u < QB; u++) {
-                            v[u] = u32x4{0u, 0u, 0u, 0u};
-                            if (c + u < C) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(reinterpret_cast<const IT *>(tab_ops[c + u]) + kq));
+                        for (uint32_t tq = 0; tq < E; tq++) sum[tq] = 0u;
+                        for (int c = 0; c < C; c += QB) {
+                            vecE v[QB];
+#pragma unroll
+                            for (int u = 0; u < QB; u++) {
+                                v[u] = vecE(0u);
+                                if (c + u < C) v[u] = __builtin_nontemporal_load(reinterpret_cast<const vecE *>(reinterpret_cast<const IT *>(tab_ops[c + u]) + kq));
+                            }
+#pragma unroll
+                            for (int u = 0; u < QB; u++) {
+#pragma unroll
+                                for (uint32_t tq = 0; tq < E; tq++) sum[tq] += v[u][tq];
+                            }
                         }
+                        vecE res = vecE(0u), ag = vecE(0u);
 #pragma unroll
-                        for (int u = 0; u < QB; u++) sum += v[u];
+                        for (uint32_t tq = 0; tq < E; tq++) {
+                            const uint32_t xx = E * qd + tq;
+                            const uint32_t blk = static_cast<uint32_t>((static_cast<uint64_t>(xx) * p.m_magic) >> 32);
+                            const uint32_t o = static_cast<uint32_t>(p.b) * (xx - blk * m32);
+                            const uint32_t *wa = row0 + 4 * blk + (o >> 5), *wm = wa + 128;
+                            res[tq] = (sum[tq] + __builtin_amdgcn_alignbit(wa[1], wa[0], o & 31u) - __builtin_amdgcn_alignbit(wm[1], wm[0], o & 31u)) & mask;
+                            ag[tq] = sum[tq] & mask;
+                        }
+                        if (agg_out) __builtin_nontemporal_store(ag, reinterpret_cast<vecE *>(agg_out + kq));
+                        __builtin_nontemporal_store(res, reinterpret_cast<vecE *>(out + kq));
                     }
-                    u32x4 res = {0u, 0u, 0u, 0u}, ag = {0u, 0u, 0u, 0u};
-#pragma unroll
-                    for (uint32_t tq = 0; tq < EPQ; tq++) {
-                        const uint32_t xx = EPQ * qd + tq;
-                        const uint32_t blk = static_cast<uint32_t>((static_cast<uint64_t>(xx) * p.m_magic) >> 32);
-                        const uint32_t o = static_cast<uint32_t>(p.b) * (xx - blk * m32);
-                        const uint32_t *wa = row0 + 4 * blk + (o >> 5), *wm = wa + 128;
-                        const uint32_t w = (4u / EPQ) * tq;            // the element's (low) word in the 16 bytes
-                        res[w] = (sum[w] + __builtin_amdgcn_alignbit(wa[1], wa[0], o & 31u) - __builtin_amdgcn_alignbit(wm[1], wm[0], o & 31u)) & mask;
-                        ag[w] = sum[w] & mask;
-                    }
-                    if (agg_out) __builtin_nontemporal_store(ag, reinterpret_cast<u32x4 *>(agg_out + kq));
-                    __builtin_nontemporal_store(res, reinterpret_cast<u32x4 *>(out + kq));
-                }
+                };
+                if (epl == 3u) regular_tile(std::integral_constant<uint32_t, 3>{});
+                else if (epl == 2u) regular_tile(std::integral_constant<uint32_t, 2>{});
+                else regular_tile(std::integral_constant<uint32_t, 4>{});
                 __builtin_amdgcn_wave_barrier();
                 continue;
             }
@@ -2187,7 +2200,23 @@ hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint
         uintptr_t low_bits = reinterpret_cast<uintptr_t>(out_dev) | reinterpret_cast<uintptr_t>(agg_out_dev);
         for (int c = 0; c < C; c++) low_bits |= reinterpret_cast<uintptr_t>(ops[c]);
         static const bool quad_off = FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_QUAD") && atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_QUAD")) == 0;
-        const int quad = (low_bits & 15u) == 0 && !quad_off ? 0x200 : 0;
+        int quad = (low_bits & 15u) == 0 && !quad_off ? 0x200 : 0;
+        if (quad && env.elem32) {
+            // elements per lane and access of the regular tiles (32 m elements): the width among 4, 3, 2 that wastes the fewest lanes of
+            // the wave's accesses (3 needs 32 m divisible by 3; ties go to the wider access)
+            const uint32_t tile_elems = 32u * static_cast<uint32_t>(p.m);
+            uint32_t best = 4;
+            double best_util = 0.0;
+            for (uint32_t e : {4u, 3u, 2u}) {
+                if (tile_elems % e) continue;
+                const uint32_t lanes = tile_elems / e;
+                const double util = static_cast<double>(lanes) / (64.0 * ((lanes + 63u) / 64u));
+                if (util > best_util + 1e-9) { best_util = util; best = e; }
+            }
+            static const int force_e = FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_EPL") ? atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_REDUCE_EPL")) : 0;
+            if (force_e >= 2 && force_e <= 4 && tile_elems % static_cast<uint32_t>(force_e) == 0) best = static_cast<uint32_t>(force_e);
+            quad |= static_cast<int>(best & 3u) << 10;            // (4 travels as 0)
+        }
 #define SRDS_LAUNCH(CB, IT, OT)                                                                                                               \
     hipLaunchKernelGGL((small_reduce_decrypt_split_kernel<CB, IT, OT>), dim3(grid32), dim3(kSmallThreads), 0, env.stream, env.rk, p, add_idx,  \
                        minus_idx, (has_minus ? 1 : 0) | probe | quad, first, count, bf, bc, C, t, agg_out_dev, out_dev)
