@@ -79,6 +79,8 @@ def parse():
                          "when any rank raises there, rank 0 prints the sequential line (config.schedule_fallback_reason says why)")
     ap.add_argument("--no-position-sharded", action="store_true", help="config 5, N > 1: skip the round sharded by position ranges (timed beside the replicas)")
     ap.add_argument("--sparse-separate", action="store_true", help="config 5: the encrypts and the sparse aggregate as separate launches (the round-2 .. 4 form) as `value`")
+    ap.add_argument("--no-fused-online", action="store_true",
+                    help="config 3: the online encrypts and the arbiter's reduce of them as two launches (the round-2 .. 4 form) instead of one pass")
     ap.add_argument("--no-span-bounds", action="store_true",
                     help="config 5: let the sparse aggregate and the sparse decrypt each compute the span bounds of the location lists "
                          "(the round-3 form) instead of computing them once per round")
@@ -1058,6 +1060,7 @@ def bench_precompute(args, n, ops, rank, world, out):
     cts = [eng.alloc_vec(n) for _ in range(C)]
     dmask, agg, dec = eng.alloc_vec(n), eng.alloc_vec(n), eng.alloc_vec(n)
     ev = [[eng.event() for _ in range(4)] for _ in range(K)]
+    fused_online = not args.no_fused_online
 
     def step(it, k=None):
         if k is not None:
@@ -1066,10 +1069,16 @@ def bench_precompute(args, n, ops, rank, world, out):
         eng.prf_jobs_dev(it, n, J, [(c, c + 1, 0, n, None, 0, masks[c]) for c in range(C)] + [(C, 0, 0, n, None, 0, dmask)])
         if k is not None:
             eng.record(ev[k][1])
-        eng.combine_batch_dev(n, pts, 1, masks, None, cts)                 # online encrypts: ct = pt + (add - minus), one launch
+        if fused_online:
+            # online encrypts ct = pt + (add - minus) AND the arbiter's reduce of them from the same pass (round 5: every ciphertext
+            # goes through the registers of the lane that owns the element; the precompute twin of config 2's partial aggregate)
+            eng.combine_batch_sum_dev(n, pts, 1, masks, None, cts, agg)
+        else:
+            eng.combine_batch_dev(n, pts, 1, masks, None, cts)             # online encrypts, one launch
         if k is not None:
             eng.record(ev[k][2])
-        eng.aggregate_elem_dev(cts, n, agg)
+        if not fused_online:
+            eng.aggregate_elem_dev(cts, n, agg)
         eng.combine_dev(n, agg, L, dmask, None, dec)                      # online decrypt
         if k is not None:
             eng.record(ev[k][3])
@@ -1081,6 +1090,17 @@ def bench_precompute(args, n, ops, rank, world, out):
     orc.build()
     for c in (0, C // 2, C - 1):                       # ciphertexts against the oracle's own encrypt
         assert np.array_equal(cts[c].download(np.uint64, n * L).reshape(n, L), orc.encrypt(KEY, 0, c, "double", J, b, host_pts[c])), f"PARITY FAILURE client {c}"
+    # the other form of the online half (two launches / one) beside the timed one, same buffers, parity-gated
+    split_ms = None
+    if fused_online:
+        fused_online = False
+        step(0)
+        got2 = dec.download(np.uint64, n * L).reshape(n, L)
+        assert np.array_equal(got2, got), "PARITY FAILURE (split online half)"
+        for it in range(max(W, 3)):
+            step(it)
+        split_ms = timed_region(ops, K, lambda k: step(k)) * 1e3 / K
+        fused_online = True
     for it in range(max(W, 3)):
         step(it)
     elapsed = timed_region(ops, K, lambda k: step(k, k))
@@ -1115,7 +1135,7 @@ def bench_precompute(args, n, ops, rank, world, out):
         "value": world * C * n / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
         "config": {"workload": f"BASELINE config 3: LeNet-sized gradient (n={n}), {C} clients, double mask + mask precompute, {b}-bit modulus, "
                                f"n_jobs={J}; step = prepare_encrypt x {C} + prepare_decrypt (one launch) + online {C} encrypts + {C}-way "
-                               "aggregate + decrypt (no AES online)" + ("; independent replicas per GPU" if world > 1 else ""),
+                               "aggregate" + (" (one pass)" if fused_online else "") + " + decrypt (no AES online)" + ("; independent replicas per GPU" if world > 1 else ""),
                    "n": n, "int_bits": b, "clients_total": C, "mask": "double+precompute",
                    "parity": "bit-exact (round trip + three clients' ciphertexts vs the oracle, checked in-run)"},
         "roofline": {"kernel": "prf_chain_kernel<1024> (mask precompute: chain of %d clients + decrypt mask difference, in = NULL)" % C if L == 2
@@ -1124,8 +1144,10 @@ def bench_precompute(args, n, ops, rank, world, out):
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": pre_ms, "launches_timed": K,
                      "aes_blocks_per_launch": blocks, "aes_blocks_per_s": blocks / (pre_ms * 1e-3),
                      "note": "launch- and latency-bound at this size (61,706 elements per vector)"},
-        "phases_ms": {"precompute_all_masks": pre_ms, "online_encrypt_xC": float(ph[:, 1].mean()),
-                      "online_aggregate_plus_decrypt": float(ph[:, 2].mean()),
+        "phases_ms": {"precompute_all_masks": pre_ms,
+                      ("online_encrypt_xC_plus_aggregate" if fused_online else "online_encrypt_xC"): float(ph[:, 1].mean()),
+                      ("online_decrypt" if fused_online else "online_aggregate_plus_decrypt"): float(ph[:, 2].mean()),
+                      "ms_per_step_split_online_half": split_ms,
                       "round_as_one_graph_launch": graph_ms,
                       "graph_note": "the round's launches captured once and replayed with an advancing device-side iter shift (every "
                                     "replay is a new round); checked against the oracle at the last replayed iter"},

@@ -1507,6 +1507,29 @@ int flashe_combine_batch_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint6
     return FLASHE_OK;
 }
 
+// out[v] = in[v] + add[v] - minus[v] for every v AND sum_out = sum_v out[v] mod 2^b from the same pass: the online encrypts of the
+// clients this process hosts (masks precomputed, jzf_flashe.py:457, :480-481) and the arbiter's element-wise reduce of what they wrote
+// (jzf_aggregator.py:424-430) -- the precompute twin of flashe_encrypt_batch_sum_dev.
+int flashe_combine_batch_sum_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                 const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev, uint64_t *sum_out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n_vec < 0 || (n_vec && (!in_dev || !out_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
+    if (n && !sum_out_dev) return fail(ctx, FLASHE_EINVAL, "flashe_combine_batch_sum_dev: null sum_out_dev");
+    if (in_limbs != 1 && in_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 or %d", ctx->limbs);
+    if ((ctx->limbs == 2 && !aligned16(sum_out_dev)) || (reinterpret_cast<uintptr_t>(sum_out_dev) & 7u))
+        return fail(ctx, FLASHE_EINVAL, "sum_out_dev must be aligned like a ciphertext vector");
+    for (int v = 0; v < n_vec; v++) {
+        if (n && (!in_dev[v] || !out_dev[v])) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
+        if (n && out_dev[v] == sum_out_dev) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the output vectors");
+        const uint64_t *a = add_dev ? add_dev[v] : nullptr, *m = minus_dev ? minus_dev[v] : nullptr;
+        if (ctx->limbs == 2 && (!aligned16(out_dev[v]) || !aligned16(a) || !aligned16(m) || (in_limbs == 2 && !aligned16(in_dev[v]))))
+            return fail(ctx, FLASHE_EINVAL, "vector %d: device vectors must be 16-byte aligned", v);
+    }
+    HIP_TRY(ctx, launch_combine_batch_sum(ctx->env, n, n_vec, in_dev, in_limbs, add_dev, minus_dev, out_dev, sum_out_dev));
+    return FLASHE_OK;
+}
+
 // ---- arbiter reduce ----
 int flashe_aggregate_elem_dev(flashe_ctx *ctx, int C, const uint64_t *const *cts_dev, uint64_t n, uint64_t *out_dev)
 {

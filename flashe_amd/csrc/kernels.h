@@ -127,6 +127,9 @@ hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_d
 // entries of them may be null)
 hipError_t launch_combine_batch(const LaunchEnv &env, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
                                 const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev);
+// the same and sum_out = sum_v out[v] mod 2^b in one pass (the online encrypts with precomputed masks + the reduce of what they wrote)
+hipError_t launch_combine_batch_sum(const LaunchEnv &env, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                    const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev, uint64_t *sum_out_dev);
 
 // Operand pointers of one reduce pass travel in the kernel argument block (scalar loads).
 constexpr int kMaxOps = 64;

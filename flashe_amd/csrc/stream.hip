@@ -115,6 +115,96 @@ hipError_t launch_combine_batch(const LaunchEnv &env, uint64_t n, int n_vec, con
     return hipSuccess;
 }
 
+// The same combines AND the sum of their results in one pass (round 5): out[v] = in[v] + add[v] - minus[v], sum_out = sum_v out[v]
+// (mod 2^b) -- the online encrypts of the clients a process hosts with precomputed masks plus the arbiter's reduce of what they wrote
+// (jzf_flashe.py:480-481 x C, then jzf_aggregator.py:424-430): every ciphertext passes through the registers of the lane that owns
+// the element, so the reduce costs one more store instead of a second launch that reads all C ciphertexts back (config 3: 100 LeNet-
+// sized vectors, 0.046 + 0.030 ms as two launches).  A lane walks the vectors of its element in steps of kSumStep with all of a step's
+// loads in flight; more than kMaxCombine vectors take several launches that carry the running sum (accumulate).
+// A workgroup owns 64 consecutive elements; its four waves split the vectors among them (wave g takes v = g, g + 4, ...: a hundred
+// LeNet-sized vectors are only 61,706 elements -- one lane per element would leave the chip a single wave per SIMD deep in memory latency)
+// and add their partial sums up through the LDS.
+constexpr int kSumStep = 8, kSumWaves = kStreamThreads / 64;
+template <bool WIDE>
+__global__ __launch_bounds__(kStreamThreads) void combine_batch_sum_kernel(uint64_t n, int n_vec, const CombineTable tb, int in_limbs, bool accumulate, uint64_t *sum_out,
+                                                                           uint64_t mask_lo, uint64_t mask_hi)
+{
+    __shared__ unsigned long long part[kSumWaves][64][2];
+    const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
+    // (the wave index as a scalar: the pointer table is indexed with it -- from a VGPR index the kernel-argument table would be copied to scratch)
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), e = threadIdx.x & 63;
+    const uint64_t n_tiles = (n + 63) / 64;
+    for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint64_t j = t * 64 + e;
+        const bool live = j < n;
+        const uint64_t jc = live ? j : n - 1;                         // (lanes beyond the vector re-read its last element and store nothing)
+        u128 sum = 0;
+        for (int v0 = g; v0 < n_vec; v0 += kSumWaves * kSumStep) {
+            u128 x[kSumStep], a[kSumStep], m[kSumStep];
+#pragma unroll
+            for (int u = 0; u < kSumStep; u++) {
+                const int vv = v0 + kSumWaves * u, v = vv < n_vec ? vv : v0;              // (surplus slots of the last step re-read a vector and are dropped)
+                if (WIDE) {
+                    x[u] = in_limbs == 2 ? ld128_nt(tb.in[v] + 2 * jc) : static_cast<u128>(__builtin_nontemporal_load(tb.in[v] + jc));
+                    a[u] = tb.add[v] ? ld128_nt(tb.add[v] + 2 * jc) : 0;
+                    m[u] = tb.minus[v] ? ld128_nt(tb.minus[v] + 2 * jc) : 0;
+                } else {
+                    x[u] = __builtin_nontemporal_load(tb.in[v] + jc);
+                    a[u] = tb.add[v] ? __builtin_nontemporal_load(tb.add[v] + jc) : 0;
+                    m[u] = tb.minus[v] ? __builtin_nontemporal_load(tb.minus[v] + jc) : 0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kSumStep; u++) {
+                const int vv = v0 + kSumWaves * u;
+                if (vv >= n_vec) continue;
+                const u128 r = (x[u] + a[u] - m[u]) & mask;
+                if (live) {
+                    if (WIDE) st128_nt(tb.out[vv] + 2 * j, r);
+                    else __builtin_nontemporal_store(static_cast<uint64_t>(r), tb.out[vv] + j);
+                }
+                sum += r;
+            }
+        }
+        part[g][e][0] = static_cast<unsigned long long>(sum); part[g][e][1] = static_cast<unsigned long long>(sum >> 64);
+        __syncthreads();
+        if (g == 0 && live) {
+            u128 tot = 0;
+            if (accumulate) tot = WIDE ? ld128(sum_out + 2 * j) : static_cast<u128>(sum_out[j]);
+#pragma unroll
+            for (int w = 0; w < kSumWaves; w++) tot += (static_cast<u128>(part[w][e][1]) << 64) | part[w][e][0];
+            tot &= mask;
+            if (WIDE) st128_nt(sum_out + 2 * j, tot);
+            else sum_out[j] = static_cast<uint64_t>(tot);
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_combine_batch_sum(const LaunchEnv &env, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                    const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev, uint64_t *sum_out_dev)
+{
+    if (n == 0) return hipSuccess;
+    if (n_vec == 0) return hipMemsetAsync(sum_out_dev, 0, static_cast<size_t>(n) * (env.b > 64 ? 16 : 8), env.stream);
+    uint64_t lo, hi;
+    masks_of(env.b, &lo, &hi);
+    for (int v0 = 0; v0 < n_vec; v0 += kMaxCombine) {
+        const int nv = std::min(kMaxCombine, n_vec - v0);
+        CombineTable tb{};
+        for (int v = 0; v < nv; v++) {
+            tb.in[v] = in_dev[v0 + v]; tb.add[v] = add_dev ? add_dev[v0 + v] : nullptr;
+            tb.minus[v] = minus_dev ? minus_dev[v0 + v] : nullptr; tb.out[v] = out_dev[v0 + v];
+        }
+        const uint64_t tiles = (n + 63) / 64, cap = static_cast<uint64_t>(env.num_cus) * 8;
+        const dim3 grid(static_cast<unsigned>(tiles < cap ? tiles : cap));
+        if (env.b > 64) hipLaunchKernelGGL(combine_batch_sum_kernel<true>, grid, dim3(kStreamThreads), 0, env.stream, n, nv, tb, in_limbs, v0 != 0, sum_out_dev, lo, hi);
+        else hipLaunchKernelGGL(combine_batch_sum_kernel<false>, grid, dim3(kStreamThreads), 0, env.stream, n, nv, tb, in_limbs, v0 != 0, sum_out_dev, lo, hi);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_combine(const LaunchEnv &env, uint64_t n, const uint64_t *in_dev, int in_limbs,
                           const uint64_t *add_dev, const uint64_t *minus_dev, uint64_t *out_dev)
 {

@@ -683,6 +683,15 @@ class Engine:
         pm, _d = self._ptr_array(minuses) if minuses is not None else (None, None)
         self._check(self._lib.flashe_combine_batch_dev(self._h, n, len(inps), pi, in_limbs, pa, pm, po))
 
+    def combine_batch_sum_dev(self, n, inps, in_limbs, adds, minuses, outs, sum_out):
+        """combine_batch_dev and sum_out = sum_v outs[v] mod 2^b from the same pass (online encrypts with precomputed masks + the
+        arbiter's reduce of what they wrote)."""
+        pi, _a = self._ptr_array(inps)
+        po, _b = self._ptr_array(outs)
+        pa, _c = self._ptr_array(adds) if adds is not None else (None, None)
+        pm, _d = self._ptr_array(minuses) if minuses is not None else (None, None)
+        self._check(self._lib.flashe_combine_batch_sum_dev(self._h, n, len(inps), pi, in_limbs, pa, pm, po, self._ptr(sum_out)))
+
     def _ptr_array(self, items):
         if isinstance(items, PtrTable):
             return items.ptr, items

@@ -59,7 +59,8 @@ typedef struct flashe_ctx flashe_ctx;
  *      timing probes and tuning knobs compiled out of libflashe_hip.so (-DFLASHE_TUNING build only)
  *   3  round 5: flashe_ctx_compact_layout (does this ctx run the *_u32_dev entry points?); the double-mask encrypt entry points
  *      refuse idx = 2^32 - 1 with FLASHE_EINVAL (the reference's OverflowError, jzf_flashe.py:352-353) instead of wrapping to
- *      prefix 0; flashe_prepared_discard releases the cached mask buffers */
+ *      prefix 0; flashe_prepared_discard releases the cached mask buffers; flashe_combine_batch_sum_dev (online encrypts with
+ *      precomputed masks + their sum in one pass) */
 #define FLASHE_ABI_VERSION 3
 int flashe_abi_version(void);
 int flashe_device_count(int *count);
@@ -304,6 +305,13 @@ int flashe_combine(flashe_ctx *ctx, uint64_t n, const uint64_t *in, int in_limbs
  * minus_dev or single entries of them may be NULL. */
 int flashe_combine_batch_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
                              const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev);
+/* The same combines AND sum_out_dev = sum_v out[v] mod 2^b written by the same pass (new): the online encrypts with precomputed masks
+ * (jzf_flashe.py:457, :480-481) plus the arbiter's element-wise reduce of what they wrote (jzf_aggregator.py:424-430) -- the reduce
+ * costs one more store instead of a launch that reads every ciphertext back; the twin of flashe_encrypt_batch_sum_dev for the
+ * precompute path.  sum_out_dev must not be one of out_dev. */
+int flashe_combine_batch_sum_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                 const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev,
+                                 uint64_t *sum_out_dev);
 
 /* ---- arbiter reduce ----------------------------------------------------------------- */
 /* Element-wise: out[j] = sum_c cts[c][j] mod 2^b -- jzf_aggregator.py:424-430.

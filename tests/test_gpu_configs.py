@@ -90,6 +90,15 @@ def test_config3_lenet_100_clients_with_mask_precompute(E, oracle, b, n_jobs):
     for c in range(C):
         assert np.array_equal(dct[c].download(np.uint64, n * L).reshape(n, L), cts[c]), (b, c, "batched")
     assert np.array_equal(ddec.download(np.uint64, n * L).reshape(n, L), dec)
+    # round 5, what bench.py --config 3 runs by default: the online encrypts AND the arbiter's reduce of them in one pass
+    # (flashe_combine_batch_sum_dev; 100 vectors = two launches that carry the running sum)
+    dct2 = [eng.alloc_vec(n) for _ in range(C)]
+    dagg2 = eng.alloc_vec(n)
+    eng._check(eng._lib.flashe_memset_dev(eng._h, dagg2.ptr, 0x5A, dagg2.nbytes))
+    eng.combine_batch_sum_dev(n, dpt, 1, masks, None, dct2, dagg2)
+    for c in range(C):
+        assert np.array_equal(dct2[c].download(np.uint64, n * L).reshape(n, L), cts[c]), (b, c, "batched + sum")
+    assert np.array_equal(dagg2.download(np.uint64, n * L).reshape(n, L), agg), (b, "sum of the batch")
 
 
 def test_config4_resnet50_ten_clients_one_gpu(E, oracle):

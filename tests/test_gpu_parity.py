@@ -1419,6 +1419,42 @@ def test_error_codes(E):
         eng.aggregate_packed_dev([d], 16, 1024, d)      # out aliases an operand
 
 
+@pytest.mark.parametrize("b,n,V,in_limbs", [(128, 4099, 5, 1), (128, 1000, 70, 2), (100, 33, 3, 1), (64, 5000, 9, 1), (20, 777, 130, 1), (128, 0, 3, 1), (64, 10, 0, 1)])
+def test_combine_batch_sum_vs_oracle(E, oracle, b, n, V, in_limbs):
+    """flashe_combine_batch_sum_dev: out[v] = in[v] + add[v] - minus[v] (jzf_flashe.py:480-481 with precomputed masks) for V vectors and
+    sum_out = the element-wise reduce of the results (jzf_aggregator.py:424-430) from the same pass -- more vectors than one launch's
+    table holds (running sum across launches), missing add / minus entries, two-limb inputs, empty shapes, misuse."""
+    eng = make(E, b)
+    Lb = L(b)
+    rng = np.random.Generator(np.random.PCG64(b * 1000 + n + V))
+    hi = 2 ** min(b, 64)
+    def vec(limbs):
+        a = np.zeros((n, limbs), dtype=np.uint64)
+        a[:, 0] = rng.integers(0, hi, n, dtype=np.uint64) if hi < 2 ** 64 else rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+        if limbs == 2:
+            a[:, 1] = rng.integers(0, 2 ** (b - 64), n, dtype=np.uint64)
+        return a
+    ins = [vec(in_limbs) for _ in range(V)]
+    adds = [vec(Lb) if v % 3 != 2 else None for v in range(V)]
+    mins = [vec(Lb) if v % 4 != 1 else None for v in range(V)]
+    d_in = [eng.upload(x) for x in ins]
+    d_add = [eng.upload(x) if x is not None else None for x in adds]
+    d_min = [eng.upload(x) if x is not None else None for x in mins]
+    outs = [eng.alloc_vec(max(n, 1)) for _ in range(V)]
+    dsum = eng.alloc_vec(max(n, 1))
+    eng._check(eng._lib.flashe_memset_dev(eng._h, dsum.ptr, 0xC3, dsum.nbytes))
+    eng.combine_batch_sum_dev(n, d_in, in_limbs, d_add, d_min, outs, dsum)
+    want = [oracle.combine(b, ins[v], adds[v], mins[v]) for v in range(V)]
+    for v in range(V):
+        assert np.array_equal(outs[v].download(np.uint64, n * Lb).reshape(n, Lb), want[v]), (b, n, v)
+    if n:
+        wsum = oracle.aggregate_elem(want, b) if V else np.zeros((n, Lb), dtype=np.uint64)
+        assert np.array_equal(dsum.download(np.uint64, n * Lb).reshape(n, Lb), wsum), (b, n, V, "sum")
+    if n and V:
+        with pytest.raises(E.FlasheError):
+            eng.combine_batch_sum_dev(n, d_in, in_limbs, d_add, d_min, outs, outs[0])          # the sum must not alias an output
+
+
 def test_double_mask_idx_range_at_the_raw_abi(E, oracle):
     """jzf_flashe.py:352-353: the double mask's minus prefix is (self.idx + 1).to_bytes(4, 'big') -- OverflowError for idx = 2^32 - 1.
     The raw C ABI refuses the same value (FLASHE_EINVAL) instead of wrapping to prefix 0, in every encrypt entry point; the single mask
