@@ -83,6 +83,9 @@ __device__ __forceinline__ void sp_pick(SelectState *st, int shift, uint32_t *hi
     hist[t] = 0;
 }
 
+// The histogram pass over ONE layer (launch_sparsify): a grid of at most two 1,024-lane workgroups per CU strides over the layer with
+// four loads in flight per lane.  With a single layer every workgroup ends on the SAME 256 words of the global histogram, so fewer,
+// larger workgroups beat the 256-lane trips of the model-wide pass below (25.5 M float32 values: 4 x 50 against 4 x 69 us).
 template <typename T>
 __global__ __launch_bounds__(kSpThreads) void sp_hist_kernel(uint64_t n, const T *x, const SelectState *st, int shift, uint32_t *hist)
 {
@@ -104,117 +107,6 @@ __global__ __launch_bounds__(kSpThreads) void sp_hist_kernel(uint64_t n, const T
     }
     __syncthreads();
     if (threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
-}
-
-__global__ void sp_init_kernel(SelectState *st, unsigned long long k, uint32_t *hist)
-{
-    if (threadIdx.x == 0) { st->prefix = 0; st->mask = 0; st->remaining = k; st->total_eq = 0; }
-    hist[threadIdx.x] = 0;
-}
-
-__global__ void sp_pick_digit_kernel(SelectState *st, int shift, uint32_t *hist)
-{
-    sp_pick(st, shift, hist);
-}
-
-template <typename T>
-__global__ __launch_bounds__(kSpThreads) void sp_count_kernel(uint64_t n, const T *x, const SelectState *st, uint32_t *blk_gt, uint32_t *blk_eq)
-{
-    __shared__ uint32_t c[2];
-    if (threadIdx.x < 2) c[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kSpThreads + threadIdx.x;
-    const unsigned long long thr = st->prefix;
-    const unsigned long long key = i < n ? static_cast<unsigned long long>(KeyOf<T>::get(x[i])) : 0ull;
-    const unsigned long long gt = __ballot(i < n && key > thr), eq = __ballot(i < n && key == thr);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&c[0], __popcll(gt)); atomicAdd(&c[1], __popcll(eq)); }
-    __syncthreads();
-    if (threadIdx.x == 0) { blk_gt[blockIdx.x] = c[0]; blk_eq[blockIdx.x] = c[1]; }
-}
-
-// exclusive scans over the per-block counts (one workgroup; n_blocks is a few ten thousand at most)
-__global__ __launch_bounds__(kSpThreads) void sp_scan_kernel(uint32_t n_blocks, uint32_t *blk_gt, uint32_t *blk_eq, SelectState *st)
-{
-    __shared__ unsigned long long sums[2][kSpThreads];
-    const uint32_t per = (n_blocks + kSpThreads - 1) / kSpThreads;
-    const uint32_t b0 = threadIdx.x * per, b1 = min(b0 + per, n_blocks);
-    unsigned long long g = 0, e = 0;
-    for (uint32_t b = b0; b < b1; b++) { g += blk_gt[b]; e += blk_eq[b]; }
-    sums[0][threadIdx.x] = g; sums[1][threadIdx.x] = e;
-    __syncthreads();
-    // inclusive Hillis-Steele scan over the 1024 per-thread totals (10 steps), then shift to exclusive
-    for (int off = 1; off < kSpThreads; off <<= 1) {
-        unsigned long long ag = 0, ae = 0;
-        if (static_cast<int>(threadIdx.x) >= off) { ag = sums[0][threadIdx.x - off]; ae = sums[1][threadIdx.x - off]; }
-        __syncthreads();
-        sums[0][threadIdx.x] += ag; sums[1][threadIdx.x] += ae;
-        __syncthreads();
-    }
-    if (threadIdx.x == kSpThreads - 1) st->total_eq = sums[1][threadIdx.x];
-    const unsigned long long own_g = g, own_e = e;
-    g = sums[0][threadIdx.x] - own_g; e = sums[1][threadIdx.x] - own_e;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t tg = blk_gt[b], te = blk_eq[b];
-        blk_gt[b] = static_cast<uint32_t>(g); blk_eq[b] = static_cast<uint32_t>(e);     // offsets fit: n < 2^32
-        g += tg; e += te;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(kSpThreads) void sp_write_kernel(uint64_t n, const T *x, T *residual, const SelectState *st,
-                                                              const uint32_t *blk_gt_off, const uint32_t *blk_eq_off,
-                                                              uint32_t *loc, T *vals)
-{
-    __shared__ uint32_t wg[kSpThreads / 64], we[kSpThreads / 64];
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kSpThreads + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long thr = st->prefix;
-    const unsigned long long skip = st->total_eq - st->remaining;      // the first `skip` ties (lowest indices) stay out
-    const bool live = i < n;
-    const T xv = live ? x[i] : T(0);
-    const unsigned long long key = KeyOf<T>::get(xv);
-    const bool is_gt = live && key > thr, is_eq = live && key == thr;
-    const unsigned long long mg = __ballot(is_gt), me = __ballot(is_eq);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (lane == 0) { wg[wave] = __popcll(mg); we[wave] = __popcll(me); }
-    __syncthreads();
-    uint32_t og = 0, oe = 0;
-    for (int w = 0; w < wave; w++) { og += wg[w]; oe += we[w]; }
-    const unsigned long long gt_before = blk_gt_off[blockIdx.x] + og + __popcll(mg & below);
-    const unsigned long long eq_before = blk_eq_off[blockIdx.x] + oe + __popcll(me & below);
-    if (!live) return;
-    const bool selected = is_gt || (is_eq && eq_before >= skip);
-    const T v = xv + (residual ? residual[i] : T(0));
-    if (selected) {
-        const unsigned long long pos = gt_before + (eq_before > skip ? eq_before - skip : 0ull);
-        loc[pos] = static_cast<uint32_t>(i);
-        vals[pos] = v;
-        if (residual) residual[i] = T(0);
-    } else if (residual) {
-        residual[i] = v;
-    }
-}
-
-template <typename T>
-static hipError_t sparsify_impl(const LaunchEnv &env, uint64_t n, uint64_t k, const T *x, T *residual, uint32_t *loc, T *vals, void *ws)
-{
-    // workspace: SelectState | hist[256] | blk_gt[nb] | blk_eq[nb]
-    const uint32_t nb = static_cast<uint32_t>((n + kSpThreads - 1) / kSpThreads);
-    SelectState *st = static_cast<SelectState *>(ws);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(st + 1);
-    uint32_t *blk_gt = hist + 256, *blk_eq = blk_gt + nb;
-    hipLaunchKernelGGL(sp_init_kernel, dim3(1), dim3(256), 0, env.stream, st, static_cast<unsigned long long>(k), hist);
-    uint64_t hb = (n + kSpThreads - 1) / kSpThreads;
-    const uint64_t cap = static_cast<uint64_t>(env.num_cus) * 2;
-    if (hb > cap) hb = cap;
-    for (int shift = KeyOf<T>::bits - 8; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(sp_hist_kernel<T>, dim3(static_cast<unsigned>(hb)), dim3(kSpThreads), 0, env.stream, n, x, st, shift, hist);
-        hipLaunchKernelGGL(sp_pick_digit_kernel, dim3(1), dim3(256), 0, env.stream, st, shift, hist);
-    }
-    hipLaunchKernelGGL(sp_count_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, n, x, st, blk_gt, blk_eq);
-    hipLaunchKernelGGL(sp_scan_kernel, dim3(1), dim3(kSpThreads), 0, env.stream, nb, blk_gt, blk_eq, st);
-    hipLaunchKernelGGL(sp_write_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, n, x, residual, st, blk_gt, blk_eq, loc, vals);
-    return hipGetLastError();
 }
 
 // ---- every layer of a model in one set of launches ---------------------------------------------------------------------------
@@ -252,33 +144,111 @@ __global__ void spb_init_kernel(const SpLayer *ly, SelectState *st, uint32_t *hi
     hist[l * 256 + threadIdx.x] = 0;
 }
 
-constexpr uint32_t kSpGroup = 8;        // consecutive blocks per workgroup of the histogram pass (one LDS histogram while the layer stays the same)
+// ---- the streaming passes of the batch form (round 5): a lane owns FOUR CONSECUTIVE elements of a 1024-element block, one 16-byte load
+// per block (two for float64), a workgroup of 256 lanes takes kSpPer consecutive blocks with every load in flight before the first is
+// used.  (Round 3-4: one element per lane, one load per trip: every pass over a ResNet-50-sized model ran at a third to a half of
+// what its bytes need -- 161 / 57 / 138 us for passes whose reads take 25 / 25 / 75 us.)
+constexpr int kSpWg = 256;              // lanes per workgroup of the streaming passes = 1024 elements per block / 4 per lane
+constexpr uint32_t kSpPer = 4;          // consecutive blocks per workgroup trip
 
+// elements i .. i + 3 of a layer of n elements at p (i a multiple of 4); the vector form never reads beyond the layer
 template <typename T>
-__global__ __launch_bounds__(kSpThreads) void spb_hist_kernel(const uint32_t *blk_layer, const SpLayer *ly, uint32_t n_blocks, const T *x,
-                                                                const SelectState *st, int shift, uint32_t *hist)
+__device__ __forceinline__ void sp_load4(const T *__restrict__ p, uint64_t i, uint64_t n, T (&v)[4])
+{
+    if (i + 4 <= n) {
+        if constexpr (sizeof(T) == 4) {
+            typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const f32x4_a4 q = *reinterpret_cast<const f32x4_a4 *>(p + i);
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        } else {
+            typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+            const f64x2_a8 q0 = *reinterpret_cast<const f64x2_a8 *>(p + i), q1 = *reinterpret_cast<const f64x2_a8 *>(p + i + 2);
+            v[0] = q0[0]; v[1] = q0[1]; v[2] = q1[0]; v[3] = q1[1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = i + j < n ? p[i + j] : T(0);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void sp_store4(T *__restrict__ p, uint64_t i, uint64_t n, const T (&v)[4])
+{
+    if (i + 4 <= n) {
+        if constexpr (sizeof(T) == 4) {
+            typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            f32x4_a4 q;
+            q[0] = v[0]; q[1] = v[1]; q[2] = v[2]; q[3] = v[3];
+            *reinterpret_cast<f32x4_a4 *>(p + i) = q;
+        } else {
+            typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+            f64x2_a8 q0, q1;
+            q0[0] = v[0]; q0[1] = v[1]; q1[0] = v[2]; q1[1] = v[3];
+            *reinterpret_cast<f64x2_a8 *>(p + i) = q0; *reinterpret_cast<f64x2_a8 *>(p + i + 2) = q1;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (i + j < n) p[i + j] = v[j];
+    }
+}
+
+// inclusive prefix sum over the 64 lanes (row shifts, then the two row broadcasts of the GFX9 DPP set)
+__device__ __forceinline__ uint32_t sp_wave_scan(uint32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+// The histogram pass: persistent workgroups walk the blocks in trips of kSpPer and keep ONE LDS histogram while the layer stays the
+// same (it goes to the layer's global histogram when the layer changes and at the end: a few hundred global atomics per workgroup
+// instead of 256 per eight blocks -- thousands of workgroups adding to the same 256 words queued up behind each other).
+template <typename T>
+__global__ __launch_bounds__(kSpWg) void spb_hist_kernel(const uint32_t *blk_layer, const SpLayer *ly, uint32_t n_blocks, const T *x,
+                                                           const SelectState *st, int shift, uint32_t *hist)
 {
     __shared__ uint32_t lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
     int cur = -1;
-    for (uint32_t s = 0; s < kSpGroup; s++) {
-        const uint32_t b = blockIdx.x * kSpGroup + s;
-        if (b >= n_blocks) break;
-        const int l = static_cast<int>(blk_layer[b]);
-        if (l != cur) {
-            __syncthreads();                                      // every vote of the layer that ends here is in
-            if (cur >= 0 && threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[cur * 256 + threadIdx.x], lh[threadIdx.x]);
-            __syncthreads();
-            if (threadIdx.x < 256) lh[threadIdx.x] = 0;
-            cur = l;
-            __syncthreads();
+    const uint32_t n_trips = (n_blocks + kSpPer - 1) / kSpPer;
+    for (uint32_t trip = blockIdx.x; trip < n_trips; trip += gridDim.x) {
+        int lay[kSpPer];
+        uint64_t base[kSpPer], nl[kSpPer];
+        T v[kSpPer][4];
+#pragma unroll
+        for (uint32_t s = 0; s < kSpPer; s++) {
+            const uint32_t b = trip * kSpPer + s;
+            lay[s] = b < n_blocks ? __builtin_amdgcn_readfirstlane(static_cast<int>(blk_layer[b])) : -1;
+            const int l = lay[s] < 0 ? 0 : lay[s];
+            base[s] = static_cast<uint64_t>(b - ly[l].blk0) * kSpThreads + 4u * threadIdx.x;
+            nl[s] = lay[s] < 0 ? 0 : ly[l].n;
+            sp_load4(x + ly[l].off, base[s], nl[s], v[s]);
         }
-        const uint64_t i = static_cast<uint64_t>(b - ly[l].blk0) * kSpThreads + threadIdx.x;
-        const bool live = i < ly[l].n;
-        const unsigned long long key = live ? static_cast<unsigned long long>(KeyOf<T>::get(x[ly[l].off + i])) : 0ull;
-        sp_vote(lh, live && (key & st[l].mask) == st[l].prefix, static_cast<uint32_t>((key >> shift) & 255u));
+#pragma unroll
+        for (uint32_t s = 0; s < kSpPer; s++) {
+            const int l = lay[s];
+            if (l < 0) break;
+            if (l != cur) {
+                __syncthreads();                                  // every vote of the layer that ends here is in
+                if (cur >= 0 && lh[threadIdx.x]) atomicAdd(&hist[cur * 256 + threadIdx.x], lh[threadIdx.x]);
+                lh[threadIdx.x] = 0;
+                cur = l;
+                __syncthreads();
+            }
+            const unsigned long long prefix = st[l].prefix, mask = st[l].mask;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned long long key = static_cast<unsigned long long>(KeyOf<T>::get(v[s][j]));
+                sp_vote(lh, base[s] + j < nl[s] && (key & mask) == prefix, static_cast<uint32_t>((key >> shift) & 255u));
+            }
+        }
     }
     __syncthreads();
-    if (cur >= 0 && threadIdx.x < 256 && lh[threadIdx.x]) atomicAdd(&hist[cur * 256 + threadIdx.x], lh[threadIdx.x]);
+    if (cur >= 0 && lh[threadIdx.x]) atomicAdd(&hist[cur * 256 + threadIdx.x], lh[threadIdx.x]);
 }
 
 __global__ void spb_pick_digit_kernel(SelectState *st_all, int shift, uint32_t *hist_all)
@@ -287,90 +257,151 @@ __global__ void spb_pick_digit_kernel(SelectState *st_all, int shift, uint32_t *
 }
 
 template <typename T>
-__global__ __launch_bounds__(kSpThreads) void spb_count_kernel(const uint32_t *blk_layer, const SpLayer *ly, const T *x, const SelectState *st, uint32_t *blk_gt,
-                                                                 uint32_t *blk_eq)
+__global__ __launch_bounds__(kSpWg) void spb_count_kernel(const uint32_t *blk_layer, const SpLayer *ly, uint32_t n_blocks, const T *x, const SelectState *st,
+                                                            uint32_t *blk_gt, uint32_t *blk_eq)
 {
-    __shared__ uint32_t c[2];
-    if (threadIdx.x < 2) c[threadIdx.x] = 0;
+    __shared__ uint32_t c[kSpPer][2];
+    if (threadIdx.x < 2 * kSpPer) c[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+    int lay[kSpPer];
+    uint64_t base[kSpPer], nl[kSpPer];
+    T v[kSpPer][4];
+#pragma unroll
+    for (uint32_t s = 0; s < kSpPer; s++) {
+        const uint32_t b = blockIdx.x * kSpPer + s;
+        lay[s] = b < n_blocks ? __builtin_amdgcn_readfirstlane(static_cast<int>(blk_layer[b])) : -1;
+        const int l = lay[s] < 0 ? 0 : lay[s];
+        base[s] = static_cast<uint64_t>(b - ly[l].blk0) * kSpThreads + 4u * threadIdx.x;
+        nl[s] = lay[s] < 0 ? 0 : ly[l].n;
+        sp_load4(x + ly[l].off, base[s], nl[s], v[s]);
+    }
     __syncthreads();
-    const int l = static_cast<int>(blk_layer[blockIdx.x]);
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x - ly[l].blk0) * kSpThreads + threadIdx.x;
-    const bool live = i < ly[l].n;
-    const unsigned long long thr = st[l].prefix;
-    const unsigned long long key = live ? static_cast<unsigned long long>(KeyOf<T>::get(x[ly[l].off + i])) : 0ull;
-    const unsigned long long gt = __ballot(live && key > thr), eq = __ballot(live && key == thr);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&c[0], __popcll(gt)); atomicAdd(&c[1], __popcll(eq)); }
+#pragma unroll
+    for (uint32_t s = 0; s < kSpPer; s++) {
+        if (lay[s] < 0) break;
+        const unsigned long long thr = st[lay[s]].prefix;
+        uint32_t cg = 0, ce = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long key = static_cast<unsigned long long>(KeyOf<T>::get(v[s][j]));
+            const bool live = base[s] + j < nl[s];
+            cg += live && key > thr; ce += live && key == thr;
+        }
+        const uint32_t tg = sp_wave_scan(cg), te = sp_wave_scan(ce);           // lane 63 holds the wave's totals
+        if ((threadIdx.x & 63) == 63) { atomicAdd(&c[s][0], tg); atomicAdd(&c[s][1], te); }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) { blk_gt[blockIdx.x] = c[0]; blk_eq[blockIdx.x] = c[1]; }
+    if (threadIdx.x < kSpPer && blockIdx.x * kSpPer + threadIdx.x < n_blocks) {
+        blk_gt[blockIdx.x * kSpPer + threadIdx.x] = c[threadIdx.x][0];
+        blk_eq[blockIdx.x * kSpPer + threadIdx.x] = c[threadIdx.x][1];
+    }
 }
 
-// per layer: exclusive scans over its blocks' counts (workgroup l scans layer l)
+// per layer: exclusive scans over its blocks' counts (workgroup l scans layer l).  Round 5: chunk by chunk of 1,024 blocks, one block
+// per lane -- coalesced reads and writes, a DPP scan per wave, the sixteen wave totals through the LDS, a running carry -- instead of a
+// contiguous run of blocks per lane (strided, uncoalesced accesses and 2 x 25 dependent loads per lane for a 25 M-element layer: 70 us).
 __global__ __launch_bounds__(kSpThreads) void spb_scan_kernel(const SpLayer *ly, uint32_t *blk_gt_all, uint32_t *blk_eq_all, SelectState *st_all)
 {
-    __shared__ unsigned long long sums[2][kSpThreads];
+    __shared__ uint32_t wt[2][kSpThreads / 64];
     const uint32_t n_blocks = ly[blockIdx.x].nb;
     uint32_t *blk_gt = blk_gt_all + ly[blockIdx.x].blk0, *blk_eq = blk_eq_all + ly[blockIdx.x].blk0;
-    SelectState *st = st_all + blockIdx.x;
-    const uint32_t per = (n_blocks + kSpThreads - 1) / kSpThreads;
-    const uint32_t b0 = min(threadIdx.x * per, n_blocks), b1 = min(b0 + per, n_blocks);
-    unsigned long long g = 0, e = 0;
-    for (uint32_t b = b0; b < b1; b++) { g += blk_gt[b]; e += blk_eq[b]; }
-    sums[0][threadIdx.x] = g; sums[1][threadIdx.x] = e;
-    __syncthreads();
-    for (int off = 1; off < kSpThreads; off <<= 1) {
-        unsigned long long ag = 0, ae = 0;
-        if (static_cast<int>(threadIdx.x) >= off) { ag = sums[0][threadIdx.x - off]; ae = sums[1][threadIdx.x - off]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long carry_g = 0, carry_e = 0;
+    for (uint32_t c0 = 0; c0 < n_blocks; c0 += kSpThreads) {
+        const uint32_t b = c0 + threadIdx.x;
+        const uint32_t g = b < n_blocks ? blk_gt[b] : 0u, e = b < n_blocks ? blk_eq[b] : 0u;
+        const uint32_t ig = sp_wave_scan(g), ie = sp_wave_scan(e);
+        if (lane == 63) { wt[0][wave] = ig; wt[1][wave] = ie; }
         __syncthreads();
-        sums[0][threadIdx.x] += ag; sums[1][threadIdx.x] += ae;
+        uint32_t og = 0, oe = 0, tg = 0, te = 0;
+#pragma unroll
+        for (int w = 0; w < kSpThreads / 64; w++) {
+            const uint32_t a = wt[0][w], c = wt[1][w];
+            if (w < wave) { og += a; oe += c; }
+            tg += a; te += c;
+        }
+        if (b < n_blocks) {
+            blk_gt[b] = static_cast<uint32_t>(carry_g + og + ig - g);            // offsets fit: n < 2^32
+            blk_eq[b] = static_cast<uint32_t>(carry_e + oe + ie - e);
+        }
+        carry_g += tg; carry_e += te;
         __syncthreads();
     }
-    if (threadIdx.x == kSpThreads - 1) st->total_eq = sums[1][threadIdx.x];
-    const unsigned long long own_g = g, own_e = e;
-    g = sums[0][threadIdx.x] - own_g; e = sums[1][threadIdx.x] - own_e;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t tg = blk_gt[b], te = blk_eq[b];
-        blk_gt[b] = static_cast<uint32_t>(g); blk_eq[b] = static_cast<uint32_t>(e);
-        g += tg; e += te;
-    }
+    if (threadIdx.x == 0) st_all[blockIdx.x].total_eq = carry_e;
 }
 
 template <typename T>
-__global__ __launch_bounds__(kSpThreads) void spb_write_kernel(const uint32_t *blk_layer, const SpLayer *ly, const T *x_all, T *residual_all,
-                                                                 const SelectState *st_all, const uint32_t *blk_gt_off, const uint32_t *blk_eq_off,
-                                                                 uint32_t *loc_all, T *vals_all)
+__global__ __launch_bounds__(kSpWg) void spb_write_kernel(const uint32_t *blk_layer, const SpLayer *ly, uint32_t n_blocks, const T *x_all, T *residual_all,
+                                                            const SelectState *st_all, const uint32_t *blk_gt_off, const uint32_t *blk_eq_off,
+                                                            uint32_t *loc_all, T *vals_all)
 {
-    __shared__ uint32_t wg[kSpThreads / 64], we[kSpThreads / 64];
-    const int l = static_cast<int>(blk_layer[blockIdx.x]);
-    const uint64_t i = static_cast<uint64_t>(blockIdx.x - ly[l].blk0) * kSpThreads + threadIdx.x;
-    const T *x = x_all + ly[l].off;
-    T *residual = residual_all ? residual_all + ly[l].off : nullptr;
-    uint32_t *loc = loc_all + ly[l].koff;
-    T *vals = vals_all + ly[l].koff;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long thr = st_all[l].prefix;
-    const unsigned long long skip = st_all[l].total_eq - st_all[l].remaining;      // the first `skip` ties (lowest indices) stay out
-    const bool live = i < ly[l].n;
-    const T xv = live ? x[i] : T(0);
-    const unsigned long long key = KeyOf<T>::get(xv);
-    const bool is_gt = live && key > thr, is_eq = live && key == thr;
-    const unsigned long long mg = __ballot(is_gt), me = __ballot(is_eq);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (lane == 0) { wg[wave] = __popcll(mg); we[wave] = __popcll(me); }
+    constexpr int WV = kSpWg / 64;
+    __shared__ uint32_t wg[kSpPer][WV], we[kSpPer][WV];
+    const int wave = threadIdx.x >> 6;
+    int lay[kSpPer];
+    uint64_t base[kSpPer], nl[kSpPer];
+    T xv[kSpPer][4], rv[kSpPer][4];
+    uint32_t g0[kSpPer], e0[kSpPer];          // the blocks' offsets in their layers' outputs
+    // every load of the workgroup's kSpPer blocks first (values and residuals), then block by block the ordered compaction
+#pragma unroll
+    for (uint32_t s = 0; s < kSpPer; s++) {
+        const uint32_t b = blockIdx.x * kSpPer + s;
+        lay[s] = b < n_blocks ? __builtin_amdgcn_readfirstlane(static_cast<int>(blk_layer[b])) : -1;
+        const int l = lay[s] < 0 ? 0 : lay[s];
+        base[s] = static_cast<uint64_t>(b - ly[l].blk0) * kSpThreads + 4u * threadIdx.x;
+        nl[s] = lay[s] < 0 ? 0 : ly[l].n;
+        sp_load4(x_all + ly[l].off, base[s], nl[s], xv[s]);
+        if (residual_all) sp_load4(residual_all + ly[l].off, base[s], nl[s], rv[s]);
+        else { rv[s][0] = rv[s][1] = rv[s][2] = rv[s][3] = T(0); }
+        g0[s] = lay[s] < 0 ? 0u : blk_gt_off[b]; e0[s] = lay[s] < 0 ? 0u : blk_eq_off[b];
+    }
+    // per lane: how many of its four elements lie above / at the threshold, and the same summed over the lanes in front of it
+    uint32_t pg[kSpPer], pe[kSpPer];          // exclusive prefix inside the wave
+    uint32_t fg[kSpPer], fe[kSpPer];          // the lane's flags, bit j = element j
+#pragma unroll
+    for (uint32_t s = 0; s < kSpPer; s++) {
+        const unsigned long long thr = st_all[lay[s] < 0 ? 0 : lay[s]].prefix;
+        fg[s] = 0; fe[s] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned long long key = static_cast<unsigned long long>(KeyOf<T>::get(xv[s][j]));
+            const bool live = base[s] + j < nl[s];
+            fg[s] |= static_cast<uint32_t>(live && key > thr) << j;
+            fe[s] |= static_cast<uint32_t>(live && key == thr) << j;
+        }
+        const uint32_t cg = __popc(fg[s]), ce = __popc(fe[s]);
+        const uint32_t ig = sp_wave_scan(cg), ie = sp_wave_scan(ce);
+        pg[s] = ig - cg; pe[s] = ie - ce;
+        if ((threadIdx.x & 63) == 63) { wg[s][wave] = ig; we[s][wave] = ie; }
+    }
     __syncthreads();
-    uint32_t og = 0, oe = 0;
-    for (int w = 0; w < wave; w++) { og += wg[w]; oe += we[w]; }
-    const unsigned long long gt_before = blk_gt_off[blockIdx.x] + og + __popcll(mg & below);
-    const unsigned long long eq_before = blk_eq_off[blockIdx.x] + oe + __popcll(me & below);
-    if (!live) return;
-    const bool selected = ly[l].k != 0 && (is_gt || (is_eq && eq_before >= skip));       // (a layer that keeps nothing only updates its residual)
-    const T v = xv + (residual ? residual[i] : T(0));
-    if (selected) {
-        const unsigned long long pos = gt_before + (eq_before > skip ? eq_before - skip : 0ull);
-        loc[pos] = static_cast<uint32_t>(i);
-        vals[pos] = v;
-        if (residual) residual[i] = T(0);
-    } else if (residual) {
-        residual[i] = v;
+#pragma unroll
+    for (uint32_t s = 0; s < kSpPer; s++) {
+        const int l = lay[s];
+        if (l < 0 || base[s] >= nl[s]) continue;
+        uint32_t og = 0, oe = 0;
+#pragma unroll
+        for (int w = 0; w < WV; w++) { if (w < wave) { og += wg[s][w]; oe += we[s][w]; } }
+        unsigned long long gt_before = static_cast<unsigned long long>(g0[s]) + og + pg[s];
+        unsigned long long eq_before = static_cast<unsigned long long>(e0[s]) + oe + pe[s];
+        const unsigned long long skip = st_all[l].total_eq - st_all[l].remaining;      // the first `skip` ties (lowest indices) stay out
+        const bool any_k = ly[l].k != 0;                                                // (a layer that keeps nothing only updates its residual)
+        uint32_t *loc = loc_all + ly[l].koff;
+        T *vals = vals_all + ly[l].koff;
+        T out_r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool is_gt = (fg[s] >> j) & 1u, is_eq = (fe[s] >> j) & 1u;
+            const bool selected = any_k && (is_gt || (is_eq && eq_before >= skip));
+            const T v = xv[s][j] + rv[s][j];
+            if (selected) {
+                const unsigned long long pos = gt_before + (eq_before > skip ? eq_before - skip : 0ull);
+                loc[pos] = static_cast<uint32_t>(base[s] + j);
+                vals[pos] = v;
+            }
+            out_r[j] = selected ? T(0) : v;
+            gt_before += is_gt; eq_before += is_eq;
+        }
+        if (residual_all) sp_store4(residual_all + ly[l].off, base[s], nl[s], out_r);
     }
 }
 
@@ -395,7 +426,8 @@ uint64_t sparsify_batch_layout(int L, const uint64_t *n, const uint64_t *k, void
 }
 
 template <typename T>
-static hipError_t sparsify_batch_impl(const LaunchEnv &env, int L, uint64_t n_blocks, const T *x, T *residual, uint32_t *loc, T *vals, void *ws)
+static hipError_t sparsify_batch_impl(const LaunchEnv &env, int L, uint64_t n_blocks, const T *x, T *residual, uint32_t *loc, T *vals, void *ws, bool prepared = false,
+                                      uint64_t n_single = 0)
 {
     // workspace: SpLayer[L] (already uploaded) | SelectState[L] | hist[L][256] | blk_gt[n_blocks] | blk_eq[n_blocks] | blk_layer[n_blocks]
     const SpLayer *ly = static_cast<const SpLayer *>(ws);
@@ -403,16 +435,22 @@ static hipError_t sparsify_batch_impl(const LaunchEnv &env, int L, uint64_t n_bl
     uint32_t *hist = reinterpret_cast<uint32_t *>(st + L);
     uint32_t *blk_gt = hist + static_cast<size_t>(L) * 256, *blk_eq = blk_gt + n_blocks, *blk_layer = blk_eq + n_blocks;
     const unsigned nb = static_cast<unsigned>(n_blocks);
-    hipLaunchKernelGGL(spb_map_kernel, dim3((nb + 255) / 256), dim3(256), 0, env.stream, L, ly, nb, blk_layer);
-    hipLaunchKernelGGL(spb_init_kernel, dim3(L), dim3(256), 0, env.stream, ly, st, hist);
-    const unsigned hgrid = (nb + kSpGroup - 1) / kSpGroup;
+    if (!prepared) {                     // (a single layer: launch_sparsify's one kernel has written the table, the map and the select state)
+        hipLaunchKernelGGL(spb_map_kernel, dim3((nb + 255) / 256), dim3(256), 0, env.stream, L, ly, nb, blk_layer);
+        hipLaunchKernelGGL(spb_init_kernel, dim3(L), dim3(256), 0, env.stream, ly, st, hist);
+    }
+    const unsigned trips = (nb + kSpPer - 1) / kSpPer;
+    const unsigned hgrid = std::min<unsigned>(trips, static_cast<unsigned>(std::max(env.num_cus, 1)) * 8u);          // persistent: 8 x 256 lanes per CU (4 x 256 with eight blocks per trip measured 20 % slower)
+    const unsigned sgrid = static_cast<unsigned>(std::min<uint64_t>(n_blocks, static_cast<uint64_t>(std::max(env.num_cus, 1)) * 2));
     for (int shift = KeyOf<T>::bits - 8; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(spb_hist_kernel<T>, dim3(hgrid), dim3(kSpThreads), 0, env.stream, blk_layer, ly, nb, x, st, shift, hist);
+        if (prepared) hipLaunchKernelGGL(sp_hist_kernel<T>, dim3(sgrid), dim3(kSpThreads), 0, env.stream, n_single, x, st, shift, hist);
+        else hipLaunchKernelGGL(spb_hist_kernel<T>, dim3(hgrid), dim3(kSpWg), 0, env.stream, blk_layer, ly, nb, x, st, shift, hist);
         hipLaunchKernelGGL(spb_pick_digit_kernel, dim3(L), dim3(256), 0, env.stream, st, shift, hist);
     }
-    hipLaunchKernelGGL(spb_count_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, blk_layer, ly, x, st, blk_gt, blk_eq);
+    const unsigned pgrid = (nb + kSpPer - 1) / kSpPer;
+    hipLaunchKernelGGL(spb_count_kernel<T>, dim3(pgrid), dim3(kSpWg), 0, env.stream, blk_layer, ly, nb, x, st, blk_gt, blk_eq);
     hipLaunchKernelGGL(spb_scan_kernel, dim3(L), dim3(kSpThreads), 0, env.stream, ly, blk_gt, blk_eq, st);
-    hipLaunchKernelGGL(spb_write_kernel<T>, dim3(nb), dim3(kSpThreads), 0, env.stream, blk_layer, ly, x, residual, st, blk_gt, blk_eq, loc, vals);
+    hipLaunchKernelGGL(spb_write_kernel<T>, dim3(pgrid), dim3(kSpWg), 0, env.stream, blk_layer, ly, nb, x, residual, st, blk_gt, blk_eq, loc, vals);
     return hipGetLastError();
 }
 
@@ -426,20 +464,38 @@ hipError_t launch_sparsify_batch(const LaunchEnv &env, int L, uint64_t n_blocks,
                                                static_cast<float *>(vals), ws);
 }
 
+// One layer: the model-wide passes on a ONE-layer table that a kernel writes on the device -- table, block map, select state and
+// histogram in one launch, no upload, no synchronisation (capturable).  Round 5: the single-layer kernels this replaces kept one element
+// per lane in their count / write passes and a strided single-workgroup scan.
+__global__ void spb_single_kernel(SpLayer *ly, uint64_t n, uint64_t k, uint32_t nb)
+{
+    SelectState *st = reinterpret_cast<SelectState *>(ly + 1);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(st + 1);
+    uint32_t *blk_layer = hist + 256 + 2 * static_cast<size_t>(nb);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) {
+        ly[0] = SpLayer{0, n, k, 0, 0u, nb};
+        st->prefix = 0; st->mask = 0; st->remaining = k; st->total_eq = 0;
+    }
+    if (t < 256) hist[t] = 0;
+    for (uint32_t b = t; b < nb; b += gridDim.x * blockDim.x) blk_layer[b] = 0;
+}
+
 size_t sparsify_workspace_bytes(uint64_t n)
 {
     const uint64_t nb = (n + kSpThreads - 1) / kSpThreads;
-    return sizeof(SelectState) + 256 * 4 + 2 * nb * 4 + 64;
+    return sparsify_batch_workspace_bytes(1, nb) + 64;
 }
 
 hipError_t launch_sparsify(const LaunchEnv &env, uint64_t n, uint64_t k, const void *x, bool is_f64, void *residual, uint32_t *loc,
                            void *vals, void *ws)
 {
     if (n == 0 || k == 0) return hipSuccess;
-    return is_f64 ? sparsify_impl<double>(env, n, k, static_cast<const double *>(x), static_cast<double *>(residual), loc,
-                                          static_cast<double *>(vals), ws)
-                  : sparsify_impl<float>(env, n, k, static_cast<const float *>(x), static_cast<float *>(residual), loc,
-                                         static_cast<float *>(vals), ws);
+    const uint64_t nb = (n + kSpThreads - 1) / kSpThreads;
+    const unsigned g = static_cast<unsigned>(std::min<uint64_t>((nb + 255) / 256, 256));
+    hipLaunchKernelGGL(spb_single_kernel, dim3(g), dim3(256), 0, env.stream, static_cast<SpLayer *>(ws), n, k, static_cast<uint32_t>(nb));
+    return is_f64 ? sparsify_batch_impl<double>(env, 1, nb, static_cast<const double *>(x), static_cast<double *>(residual), loc, static_cast<double *>(vals), ws, true, n)
+                  : sparsify_batch_impl<float>(env, 1, nb, static_cast<const float *>(x), static_cast<float *>(residual), loc, static_cast<float *>(vals), ws, true, n);
 }
 
 }  // namespace flashe
