@@ -1165,6 +1165,24 @@ __device__ __forceinline__ void direct32_store(uint32_t *__restrict__ out, uint6
     if (t < M) q[t] = r[t];
 }
 
+// int_bits = 64 in the one-limb layout at compile time (round 5): the two elements of a lane's block are one 16-byte access, the slots are
+// the two halves of the block -- the plaintext pair is requested BEFORE the AES rounds of the stream that completes the output (the
+// run-time-width kernel loads it behind them), and the instantiation carries none of the walks of the narrower widths (its register
+// budget goes to the rounds: the general kernel sits at 128 VGPRs with scratch).  Whole blocks inside the range; the rest: small_direct.
+__device__ __forceinline__ u64x2 direct64_load(const uint64_t *__restrict__ in, uint64_t k)
+{
+    u64x2 r = {0ull, 0ull};
+    if (in) r = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(in + k));
+    return r;
+}
+__device__ __forceinline__ void direct64_store(uint64_t *__restrict__ out, uint64_t k, u64x2 pt, u128 add, u128 minus, bool single)
+{
+    u64x2 r;
+    r[0] = pt[0] + static_cast<uint64_t>(add) - (single ? 0ull : static_cast<uint64_t>(minus));
+    r[1] = pt[1] + static_cast<uint64_t>(add >> 64) - (single ? 0ull : static_cast<uint64_t>(minus >> 64));
+    __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(out + k));
+}
+
 // per b-bit slot (prev - cur) mod 2^b of two 128-bit words (SWAR: borrows must not cross slots); b == 64: the slots are the two
 // halves and two plain 64-bit subtractions do it (-2 % on ten 1e7-element vectors: the output arithmetic, not the lookup count,
 // is what separates this kernel from the wide one -- tests/perf/experiments/r03_small_win_kernel.patch)
@@ -1182,7 +1200,7 @@ __device__ __forceinline__ u128 slot_diff(u128 prev, u128 cur, u128 top, int b)
 template <bool PAIR, class ET = uint64_t, int B = 0>
 __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const RoundKeys rk, const SmallChainTable tb, int n_chains, const SmallParams p)
 {
-    static_assert(B == 0 || (PAIR && sizeof(ET) == 4 && B <= 32), "compile-time widths: the compact layout's paired kernel");
+    static_assert(B == 0 || (PAIR && ((sizeof(ET) == 4 && B <= 32) || (sizeof(ET) == 8 && B == 64))), "compile-time widths: the paired kernel, compact layout or int_bits 64");
     constexpr uint32_t WAVES = kSmallThreads / 64, TILE = PAIR ? 128u : 64u;
     constexpr int MB = B ? 128 / B : 1;
     __shared__ uint32_t tab[kTabWords];
@@ -1268,6 +1286,9 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 fastB = __ballot(vB && cntB == p.m) == ~0ull && e0B >= first && e0B + 64u * m64 <= range_end;
             }
         }
+        // (int_bits 64 at compile time: the lane's block is whole and inside the range -> one 16-byte access)
+        const bool wholeA = B == 64 && vA && cntA == 2 && j0A >= first && j0A + 2 <= range_end;
+        const bool wholeB = B == 64 && vB && cntB == 2 && j0B >= first && j0B + 2 <= range_end;
         u128 prevA = 0, prevB = 0;
         if (PAIR) {
             // two blocks per lane on the same prefix, one stream per step
@@ -1276,7 +1297,11 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 const int link = single ? c : c - 1;
                 WalkPt ptA{}, ptB{};
                 DirectPt<MB> dA{}, dB{};
-                if (B) {
+                u64x2 qA = {0ull, 0ull}, qB = {0ull, 0ull};
+                if (B == 64) {
+                    if (link >= 0 && wholeA) qA = direct64_load(tb.in[link0 + link], j0A - first);
+                    if (link >= 0 && wholeB) qB = direct64_load(tb.in[link0 + link], j0B - first);
+                } else if (B) {
                     if (link >= 0 && fastA) dA = direct32_load<MB>(reinterpret_cast<const uint32_t *>(tb.in[link0 + link]), j0A - first);
                     if (link >= 0 && fastB) dB = direct32_load<MB>(reinterpret_cast<const uint32_t *>(tb.in[link0 + link]), j0B - first);
                 } else {
@@ -1293,9 +1318,19 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                     uint64_t *out = tb.out[link0 + link];
                     const ET *ein = reinterpret_cast<const ET *>(in);
                     ET *eout = reinterpret_cast<ET *>(out);
+                    if (B == 64) {
+                        if constexpr (B == 64) {
+                            if (wholeA) direct64_store(out, j0A - first, qA, single ? SA : prevA, SA, single);
+                            else small_direct(vA, cntA, j0A, single ? SA : slot_diff(prevA, SA, top, 64), in, out, first, range_end, p);
+                            if (wholeB) direct64_store(out, j0B - first, qB, single ? SB : prevB, SB, single);
+                            else small_direct(vB, cntB, j0B, single ? SB : slot_diff(prevB, SB, top, 64), in, out, first, range_end, p);
+                        }
+                        prevA = SA; prevB = SB;
+                        continue;
+                    }
                     if (B) {
                         // compile-time width: whole tiles element by element from the two streams' slots, everything else the general walk
-                        if constexpr (B != 0) {
+                        if constexpr (B != 0 && B != 64) {
                             uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
                             if (fastA) direct32_store<B>(o32, j0A - first, dA, single ? SA : prevA, SA, single);
                             else small_walk(row0, lane, vA, cntA, j0A, single ? SA : slot_diff(prevA, SA, top, p.b), ein, eout, first, range_end, p);
@@ -2326,7 +2361,9 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
             else if (fixed == 16) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t, 16>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
             else if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
             else hipLaunchKernelGGL((prf_small_chain_kernel<false, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
-        } else if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+        } else if (pair && env.b == 64 && !p.no_fixed_width && !p.no_direct)
+            hipLaunchKernelGGL((prf_small_chain_kernel<true, uint64_t, 64>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+        else if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
         else hipLaunchKernelGGL((prf_small_chain_kernel<false>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -226,6 +226,32 @@ def test_compact_layout_at_compile_time_widths(E, oracle, b, n, J, C, scheme):
         assert np.array_equal(out.download(np.uint32, n).astype(np.uint64), sum(pts) & np.uint64((1 << b) - 1)), (b, n, "round trip")
 
 
+@pytest.mark.parametrize("n,J,C,scheme", [(2_400_001, 16, 3, "double"), (2_300_000, 7, 2, "single"), (2_200_003, 3001, 2, "double")])
+def test_int_bits_64_at_compile_time(E, oracle, n, J, C, scheme):
+    """int_bits = 64 in launches long enough for the paired kernel: the instantiation with the width compiled in (the two elements of a
+    block as one 16-byte access, plaintext requested before the AES rounds).  Every ciphertext word against the oracle (jzf_flashe.py:19-45:
+    low half first, chunk-dependent counters); chunk ends (an odd chunk length leaves a one-element block), the ragged end of the vector
+    and a sub-range whose first element is the SECOND half of a block take the per-element form inside the same kernel."""
+    eng = E.Engine(KEY, 64, device=0)
+    rng = np.random.Generator(np.random.PCG64(n + C))
+    pts = [rng.integers(0, 2 ** 64, n, dtype=np.uint64) for _ in range(C)]
+    idx = list(range(4, 4 + C))
+    sch = E.SCHEME_DOUBLE if scheme == "double" else E.SCHEME_SINGLE
+    dpt = [eng.upload(p) for p in pts]
+    dct = [eng.alloc_vec(n) for _ in range(C)]
+    eng.encrypt_batch_dev(8, idx, sch, n, J, dpt, 1, dct)
+    want = [oracle.encrypt(KEY, 8, i, scheme, J, 64, p)[:, 0] for i, p in zip(idx, pts)]
+    for v in range(C):
+        got = dct[v].download(np.uint64, n)
+        bad = np.flatnonzero(got != want[v])
+        assert bad.size == 0, (n, J, v, bad[:8])
+    # a sub-range that starts one element into the vector (8 bytes off a 16-byte boundary, mid-block)
+    first, count = 1, n - 2
+    out = eng.alloc_vec(n)
+    eng.encrypt_batch_range_dev(8, idx[:2], sch, n, J, first, count, [d.ptr + 8 * first for d in dpt[:2]], 1, [out.ptr + 8 * first, dct[0].ptr + 8 * first])
+    assert np.array_equal(out.download(np.uint64, n)[first:first + count], want[0][first:first + count])
+
+
 @pytest.mark.parametrize("b,n,J,C,scheme", [(20, 100_003, 16, 10, "double"), (32, 70_001, 3, 4, "double"), (23, 61_706, 16, 100, "double"),
                                            (16, 2_000_003, 16, 3, "double"), (8, 4099, 1, 2, "single"), (1, 777, 5, 2, "double"),
                                            (31, 12, 16, 3, "double"), (20, 1_500_000, 16, 129, "single"), (25, 300_000, 7, 12, "double")])
