@@ -1173,35 +1173,48 @@ def bench_compact(args, n, ops, rank, world, out):
     host_pts = [plaintext(c, n, b) for c in range(C)]
     pts = [ops.upload(p.astype(np.uint32)) for p in host_pts]
     cts = [eng.alloc(4 * n + 16) for _ in range(C)]
-    dec = eng.alloc(4 * n + 16)
+    dec, agg = eng.alloc(4 * n + 16), eng.alloc(4 * n + 16)
     idx = list(range(C))
     ev = [[eng.event() for _ in range(3)] for _ in range(K)]
+    # round 5: the encrypt launch also writes the local partial aggregate (the sum of its C ciphertexts), the second
+    # launch decrypts that ONE vector -- the compact twin of the int_bits > 64 default; --no-partial-agg = encrypts, then reduce + decrypt
+    partial = not args.no_partial_agg
+    form = {"partial": partial}
 
     def step(it, k=None):
         if k is not None:
             eng.record(ev[k][0])
-        eng.encrypt_batch_u32_dev(it, idx, SCHEME_DOUBLE, n, J, pts, cts)
+        if form["partial"]:
+            eng.encrypt_batch_sum_u32_dev(it, idx, SCHEME_DOUBLE, n, J, pts, cts, agg)
+        else:
+            eng.encrypt_batch_u32_dev(it, idx, SCHEME_DOUBLE, n, J, pts, cts)
         if k is not None:
             eng.record(ev[k][1])
-        eng.aggregate_decrypt_u32_dev(it, [C], [0], n, J, 0, n, cts, None, dec, 4)
+        eng.aggregate_decrypt_u32_dev(it, [C], [0], n, J, 0, n, [agg] if form["partial"] else cts, None, dec, 4)
         if k is not None:
             eng.record(ev[k][2])
 
-    step(0)
     lo, _hi = sum_mod(host_pts, n, b)
-    assert np.array_equal(dec.download(np.uint32, n).astype(np.uint64), lo), "PARITY FAILURE (round trip)"
     orc.build()
-    for c in (0, C - 1):
-        assert np.array_equal(cts[c].download(np.uint32, n), orc.encrypt(KEY, 0, c, "double", J, b, host_pts[c])[:, 0].astype(np.uint32)), f"PARITY FAILURE client {c}"
-    for it in range(max(W, 12)):
-        step(it)
+    other_ms = None
+    for use_partial in ([not partial, partial]):              # the other form first (parity-gated, timed outside the reported region)
+        form["partial"] = use_partial
+        dec.upload(np.zeros(4, dtype=np.uint32))
+        step(0)
+        assert np.array_equal(dec.download(np.uint32, n).astype(np.uint64), lo), "PARITY FAILURE (round trip)"
+        for c in (0, C - 1):
+            assert np.array_equal(cts[c].download(np.uint32, n), orc.encrypt(KEY, 0, c, "double", J, b, host_pts[c])[:, 0].astype(np.uint32)), f"PARITY FAILURE client {c}"
+        for it in range(max(W, 12)):
+            step(it)
+        if use_partial != partial:
+            other_ms = timed_region(ops, K, lambda k: step(k)) * 1e3 / K
     elapsed = timed_region(ops, K, lambda k: step(k, k))
     if rank != 0:
         return None
     ph = np.array([[eng.elapsed_ms(e[i], e[i + 1]) for i in range(2)] for e in ev])
     enc_ms = float(ph[:, 0].mean())
     m = 128 // b
-    alg_bytes = C * n * (4 + 4)
+    alg_bytes = C * n * (4 + 4) + (n * 4 if partial else 0)
     blocks = (C + 1) * ((n + m - 1) // m)
     achieved = alg_bytes / (enc_ms * 1e-3) / 1e9
     out.update({
@@ -1215,8 +1228,11 @@ def bench_compact(args, n, ops, rank, world, out):
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": enc_ms, "launches_timed": K,
                      "aes_blocks_per_launch": blocks, "aes_blocks_per_s": blocks / (enc_ms * 1e-3)},
-        "phases_ms": {"encrypt_xC": enc_ms, "reduce_plus_decrypt": float(ph[:, 1].mean())},
+        "phases_ms": {("encrypt_xC_plus_partial_aggregate" if partial else "encrypt_xC"): enc_ms,
+                      ("decrypt_of_the_aggregate" if partial else "reduce_plus_decrypt"): float(ph[:, 1].mean())},
+        ("ms_per_step_two_launch" if partial else "ms_per_step_partial_agg"): other_ms,
     })
+    out["config"]["schedule_name"] = "partial-agg" if partial else "two-launch"
     return out
 
 

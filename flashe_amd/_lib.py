@@ -137,6 +137,7 @@ _SIGNATURES = {
     "flashe_aggregate_decrypt_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_int,
                                                    ctypes.POINTER(c_vp), c_vp, c_vp]),
     "flashe_encrypt_batch_u32_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp)]),
+    "flashe_encrypt_batch_sum_u32_dev": (c_int, [c_vp, c_u32, c_int, c_u64, c_u32, c_int, c_u32p, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp), c_vp]),
     "flashe_aggregate_decrypt_u32_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_int,
                                                  ctypes.POINTER(c_vp), c_vp, c_vp, c_int]),
     "flashe_widen_u32_dev": (c_int, [c_vp, c_u64, c_vp, c_vp]),

@@ -908,6 +908,7 @@ struct SmallChainTable {
     uint32_t idx[kMaxLinks + kMaxChains];
     const uint64_t *in[kMaxLinks];
     uint64_t *out[kMaxLinks];
+    uint64_t *sum_out[kMaxChains];                           // optional (compact layout at a compile-time width): sum of the chain's outputs
 };
 
 // block B of the vector (global block numbering) -> first element j0, elements in the block cnt, PRF counter (n < 2^32)
@@ -932,9 +933,11 @@ __device__ __forceinline__ void small_block_params(uint32_t B32, uint32_t nb1_32
 // that lies in [first, range_end), coalesced whenever the tile has at most one partial block (a chunk end).
 // ET: the element type of the vectors in memory -- uint64_t (one limb per element, the ABI's layout) or, for int_bits <= 32,
 // uint32_t (the compact layout of the *_u32_dev entry points: half the bytes of a kernel that is bound by them)
+// sum / sum_first (summed chains, the tiles that do not take the direct path): sum[j] = out[j] for the chain's first output, += for the
+// later ones -- the element -> lane mapping of a tile is the same for every output, so each word is read and written by one lane only
 template <class ET>
 __device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool valid, int cnt, uint64_t j0, u128 D, const ET *in,
-                                           ET *out, uint64_t first, uint64_t range_end, const SmallParams &p)
+                                           ET *out, uint64_t first, uint64_t range_end, const SmallParams &p, ET *sum = nullptr, bool sum_first = false)
 {
     const uint64_t valid_mask = __ballot(valid), partial_mask = __ballot(valid && cnt < p.m);
     if (__popcll(partial_mask) <= 1) {
@@ -963,7 +966,9 @@ __device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool v
                 const uint64_t j = e0 + x;
                 if (j >= first && j < range_end) {
                     const uint64_t pt = in ? static_cast<uint64_t>(__builtin_nontemporal_load(in + (j - first))) : 0ull;
-                    __builtin_nontemporal_store(static_cast<ET>((pt + val) & p.mask_lo), out + (j - first));
+                    const uint64_t r = (pt + val) & p.mask_lo;
+                    __builtin_nontemporal_store(static_cast<ET>(r), out + (j - first));
+                    if (sum) sum[j - first] = static_cast<ET>((r + (sum_first ? 0ull : static_cast<uint64_t>(sum[j - first]))) & p.mask_lo);
                 }
             }
         }
@@ -973,7 +978,9 @@ __device__ __forceinline__ void small_walk(uint32_t *row0, uint32_t lane, bool v
             const uint64_t j = j0 + tt;
             if (j < first || j >= range_end) continue;
             const uint64_t val = extract64(D, p.b * tt);
-            out[j - first] = static_cast<ET>(((in ? static_cast<uint64_t>(in[j - first]) : 0ull) + val) & p.mask_lo);
+            const uint64_t r = ((in ? static_cast<uint64_t>(in[j - first]) : 0ull) + val) & p.mask_lo;
+            out[j - first] = static_cast<ET>(r);
+            if (sum) sum[j - first] = static_cast<ET>((r + (sum_first ? 0ull : static_cast<uint64_t>(sum[j - first]))) & p.mask_lo);
         }
     }
 }
@@ -1137,8 +1144,10 @@ __device__ __forceinline__ DirectPt<M> direct32_load(const uint32_t *__restrict_
 }
 
 // out[k + t] = (pt[t] + slot_t(add) - slot_t(minus)) mod 2^B for the M = 128 / B elements of the lane's block; `single`: no minus stream
+// (acc: the running sum of the chain's outputs for this block, kept in registers -- a summed chain)
 template <int B>
-__device__ __forceinline__ void direct32_store(uint32_t *__restrict__ out, uint64_t k, const DirectPt<128 / B> &pt, u128 add, u128 minus, bool single)
+__device__ __forceinline__ void direct32_store(uint32_t *__restrict__ out, uint64_t k, const DirectPt<128 / B> &pt, u128 add, u128 minus, bool single,
+                                               uint32_t (&acc)[128 / B])
 {
     constexpr int M = 128 / B;
     constexpr uint32_t mask = B >= 32 ? 0xffffffffu : ((1u << (B & 31)) - 1u);
@@ -1147,6 +1156,7 @@ __device__ __forceinline__ void direct32_store(uint32_t *__restrict__ out, uint6
     for (int t = 0; t < M; t++) {
         const uint32_t a = static_cast<uint32_t>(add >> (B * t)), m = static_cast<uint32_t>(minus >> (B * t));      // (constant shifts: one v_alignbit each)
         r[t] = (pt.v[t] + a - (single ? 0u : m)) & mask;
+        acc[t] += r[t];
     }
     uint32_t *q = out + k;
     int t = 0;
@@ -1181,6 +1191,25 @@ __device__ __forceinline__ void direct64_store(uint64_t *__restrict__ out, uint6
     r[0] = pt[0] + static_cast<uint64_t>(add) - (single ? 0ull : static_cast<uint64_t>(minus));
     r[1] = pt[1] + static_cast<uint64_t>(add >> 64) - (single ? 0ull : static_cast<uint64_t>(minus >> 64));
     __builtin_nontemporal_store(r, reinterpret_cast<u64x2 *>(out + k));
+}
+
+template <int M>
+__device__ __forceinline__ void direct32_put(uint32_t *__restrict__ q, const uint32_t (&r)[M], uint32_t mask)
+{
+    int t = 0;
+#pragma unroll
+    for (; t + 4 <= M; t += 4) {
+        u32x4_a4 x;
+        x[0] = r[t] & mask; x[1] = r[t + 1] & mask; x[2] = r[t + 2] & mask; x[3] = r[t + 3] & mask;
+        *reinterpret_cast<u32x4_a4 *>(q + t) = x;
+    }
+    if (M - t >= 2) {
+        u32x2_a4 x;
+        x[0] = r[t] & mask; x[1] = r[t + 1] & mask;
+        *reinterpret_cast<u32x2_a4 *>(q + t) = x;
+        t += 2;
+    }
+    if (t < M) q[t] = r[t] & mask;
 }
 
 // per b-bit slot (prev - cur) mod 2^b of two 128-bit words (SWAR: borrows must not cross slots); b == 64: the slots are the two
@@ -1290,6 +1319,11 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
         const bool wholeA = B == 64 && vA && cntA == 2 && j0A >= first && j0A + 2 <= range_end;
         const bool wholeB = B == 64 && vB && cntB == 2 && j0B >= first && j0B + 2 <= range_end;
         u128 prevA = 0, prevB = 0;
+        // (a summed chain, compile-time width: the blocks' running sums; irregular tiles keep theirs in memory, see small_walk)
+        uint32_t accA[MB], accB[MB];
+#pragma unroll
+        for (int t = 0; t < MB; t++) { accA[t] = 0u; accB[t] = 0u; }
+        uint32_t *const sum32 = B != 0 && B != 64 ? reinterpret_cast<uint32_t *>(tb.sum_out[cur]) : nullptr;
         if (PAIR) {
             // two blocks per lane on the same prefix, one stream per step
             for (int c = 0; c < n_streams; c++) {
@@ -1332,10 +1366,11 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                         // compile-time width: whole tiles element by element from the two streams' slots, everything else the general walk
                         if constexpr (B != 0 && B != 64) {
                             uint32_t *o32 = reinterpret_cast<uint32_t *>(out);
-                            if (fastA) direct32_store<B>(o32, j0A - first, dA, single ? SA : prevA, SA, single);
-                            else small_walk(row0, lane, vA, cntA, j0A, single ? SA : slot_diff(prevA, SA, top, p.b), ein, eout, first, range_end, p);
-                            if (fastB) direct32_store<B>(o32, j0B - first, dB, single ? SB : prevB, SB, single);
-                            else small_walk(row0, lane, vB, cntB, j0B, single ? SB : slot_diff(prevB, SB, top, p.b), ein, eout, first, range_end, p);
+                            ET *const sm = reinterpret_cast<ET *>(sum32);
+                            if (fastA) direct32_store<B>(o32, j0A - first, dA, single ? SA : prevA, SA, single, accA);
+                            else small_walk(row0, lane, vA, cntA, j0A, single ? SA : slot_diff(prevA, SA, top, p.b), ein, eout, first, range_end, p, sm, link == 0);
+                            if (fastB) direct32_store<B>(o32, j0B - first, dB, single ? SB : prevB, SB, single, accB);
+                            else small_walk(row0, lane, vB, cntB, j0B, single ? SB : slot_diff(prevB, SB, top, p.b), ein, eout, first, range_end, p, sm, link == 0);
                         }
                         prevA = SA; prevB = SB;
                         continue;
@@ -1354,6 +1389,13 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                     }
                 }
                 prevA = SA; prevB = SB;
+            }
+            if constexpr (B != 0 && B != 64) {
+                if (sum32) {                                         // the sums of the blocks that took the direct path, one store each
+                    constexpr uint32_t bmask = B >= 32 ? 0xffffffffu : ((1u << (B & 31)) - 1u);
+                    if (fastA) direct32_put<MB>(sum32 + (j0A - first), accA, bmask);
+                    if (fastB) direct32_put<MB>(sum32 + (j0B - first), accB, bmask);
+                }
             }
         } else {
             // one block per lane, TWO STREAMS per step (short launches: half the dependent AES depth per wave; an odd stream count
@@ -2287,8 +2329,13 @@ hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint
 static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs)
 {
     if (env.codec || n >= (1ull << 32) || n == 0) return hipErrorNotSupported;
-    for (int i = 0; i < n_chains; i++) if (chains[i].sum_out_dev) return hipErrorNotSupported;      // the fused sum lives in the wide kernel
     SmallParams p = small_params_of(env, iter, n, n_jobs);
+    // the fused sum of a chain's outputs: the compact layout's compile-time-width kernels carry it (never cut, double mask, paired launch)
+    bool summed = false;
+    for (int i = 0; i < n_chains; i++) summed |= chains[i].sum_out_dev != nullptr;
+    if (summed && !(env.elem32 && !p.no_fixed_width && (env.b == 16 || env.b == 20 || env.b == 23) && n_chains == 1 && !chains[0].single &&
+                    chains[0].n_out <= kMaxLinks))
+        return hipErrorNotSupported;
     if (env.elem32) {
         if (env.b > 32) return hipErrorInvalidValue;
         p.no_direct = 1;                      // the 16-byte direct accesses of m <= 4 assume 8-byte elements: b = 32 walks its rows like b < 32
@@ -2309,6 +2356,7 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
     // two blocks per lane (software pipelined) once every wave has work for several such tiles; short launches run one block per
     // lane and cut long chains so that more waves take part (a cut costs one stream)
     const bool pair = total_blocks >= 2 * 128 * waves;
+    if (summed && !pair) return hipErrorNotSupported;           // (short launches cut their chains for parallelism: the separate reduce is the plan there)
     const uint64_t tile = pair ? 128 : 64;
     uint64_t total_tiles = 0;
     for (const Piece &pc : pieces) total_tiles += (pc.blk_count + tile - 1) / tile;
@@ -2344,6 +2392,7 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
                 tb.in[links + l] = c.in_dev ? c.in_dev[pc.l0 + l] : nullptr;
                 tb.out[links + l] = c.out_dev[pc.l0 + l];
             }
+            tb.sum_out[nc] = c.sum_out_dev;
             const uint64_t t = (pc.blk_count + tile - 1) / tile;
             wend += t * static_cast<uint64_t>(ns);
             tb.wend[nc] = wend;

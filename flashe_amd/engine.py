@@ -740,6 +740,13 @@ class Engine:
         pc, _b = self._ptr_array(cts)
         self._check(self._lib.flashe_encrypt_batch_u32_dev(self._h, it, scheme, n, n_jobs, len(idx_list), pi, pp, pc))
 
+    def encrypt_batch_sum_u32_dev(self, it, idx_list, scheme, n, n_jobs, pts, cts, sum_out):
+        """encrypt_batch_u32_dev and sum_out = sum of the ciphertexts (uint32 [n]) from the same launch where the shape allows it."""
+        pi, _k = _u32_list(idx_list)
+        pp, _a = self._ptr_array(pts)
+        pc, _b = self._ptr_array(cts)
+        self._check(self._lib.flashe_encrypt_batch_sum_u32_dev(self._h, it, scheme, n, n_jobs, len(idx_list), pi, pp, pc, self._ptr(sum_out)))
+
     def aggregate_decrypt_u32_dev(self, it, add_idx, minus_idx, n, n_jobs, first, count, cts, agg_out, out, out_elem_bytes=8):
         """aggregate_decrypt_range_dev on uint32 operands (one add, at most one minus prefix); agg_out / out are uint32 or uint64 arrays."""
         pa, _a = _u32_list(add_idx)

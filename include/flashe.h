@@ -60,7 +60,7 @@ typedef struct flashe_ctx flashe_ctx;
  *   3  round 5: flashe_ctx_compact_layout (does this ctx run the *_u32_dev entry points?); the double-mask encrypt entry points
  *      refuse idx = 2^32 - 1 with FLASHE_EINVAL (the reference's OverflowError, jzf_flashe.py:352-353) instead of wrapping to
  *      prefix 0; flashe_prepared_discard releases the cached mask buffers; flashe_combine_batch_sum_dev (online encrypts with
- *      precomputed masks + their sum in one pass) */
+ *      precomputed masks + their sum in one pass); flashe_encrypt_batch_sum_u32_dev (the compact layout's encrypts + their sum) */
 #define FLASHE_ABI_VERSION 3
 int flashe_abi_version(void);
 int flashe_device_count(int *count);
@@ -344,6 +344,11 @@ int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter,
  * ct[j] here == (uint32) of what the uint64 call writes; n < 2^32; table PRF; pointers address element `first`. */
 int flashe_encrypt_batch_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
                                  const uint32_t *idx, const uint32_t *const *pt_dev, uint32_t *const *ct_dev);
+/* new (round 5): flashe_encrypt_batch_u32_dev and sum_out_dev = sum_v ct_dev[v] mod 2^b from the same launch -- the compact twin of
+ * flashe_encrypt_batch_sum_dev.  One launch for consecutive clients under the double mask at int_bits 16 / 20 / 23 when the vectors are
+ * long enough for the paired kernel; every other shape runs the encrypts and then the reduce of what they wrote (same results). */
+int flashe_encrypt_batch_sum_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec, const uint32_t *idx,
+                                     const uint32_t *const *pt_dev, uint32_t *const *ct_dev, uint32_t *sum_out_dev);
 int flashe_aggregate_decrypt_u32_dev(flashe_ctx *ctx, uint32_t iter,
                                      const uint32_t *add_idx, int n_add, const uint32_t *minus_idx, int n_minus,
                                      uint64_t n, uint32_t n_jobs, uint64_t first, uint64_t count,

@@ -224,6 +224,49 @@ def test_compact_layout_at_compile_time_widths(E, oracle, b, n, J, C, scheme):
         out = eng.alloc(4 * n + 16)
         eng.aggregate_decrypt_u32_dev(4, [idx[-1] + 1], [idx[0]], n, J, 0, n, c32, None, out, 4)
         assert np.array_equal(out.download(np.uint32, n).astype(np.uint64), sum(pts) & np.uint64((1 << b) - 1)), (b, n, "round trip")
+    # the encrypts AND the sum of their ciphertexts from one launch (flashe_encrypt_batch_sum_u32_dev): the same ciphertexts, the sum the
+    # oracle's element-wise reduce gives (jzf_aggregator.py:424-430) -- blocks of whole tiles keep it in registers, chunk ends in memory;
+    # the single mask and short vectors take the two-launch form behind the same entry point
+    c2 = [eng.alloc(4 * n + 32) for _ in range(C)]
+    dsum = eng.alloc(4 * n + 32)
+    eng._check(eng._lib.flashe_memset_dev(eng._h, dsum.ptr, 0x77, dsum.nbytes))
+    eng.encrypt_batch_sum_u32_dev(4, idx, sch, n, J, d32, c2, dsum)
+    for v in range(C):
+        assert np.array_equal(c2[v].download(np.uint32, n), want[v]), (b, n, v, "with the sum")
+    wsum = np.zeros(n, dtype=np.uint64)
+    for w in want:
+        wsum += w
+    bad = np.flatnonzero(dsum.download(np.uint32, n).astype(np.uint64) != (wsum & np.uint64((1 << b) - 1)))
+    assert bad.size == 0, (b, n, J, "sum of the ciphertexts", bad[:8])
+    # and decrypting that one vector is the round
+    if scheme == "double":
+        out2 = eng.alloc(4 * n + 16)
+        eng.aggregate_decrypt_u32_dev(4, [idx[-1] + 1], [idx[0]], n, J, 0, n, [dsum], None, out2, 4)
+        assert np.array_equal(out2.download(np.uint32, n).astype(np.uint64), sum(pts) & np.uint64((1 << b) - 1)), (b, n, "round trip through the sum")
+    with pytest.raises(E.FlasheError):
+        eng.encrypt_batch_sum_u32_dev(4, idx, sch, n, J, d32, c2, c2[0])
+
+
+@pytest.mark.parametrize("b,n,J,C", [(20, 50_001, 16, 4), (25, 900_000, 16, 3), (8, 4099, 3, 5), (20, 6_400_000, 16, 130)])
+def test_compact_encrypt_batch_sum_fallbacks(E, oracle, b, n, J, C):
+    """flashe_encrypt_batch_sum_u32_dev on shapes its one-launch form does not carry (short vectors, other widths, more clients than a
+    launch holds, clients that are not consecutive): the same ciphertexts and the same sum through the encrypts + the reduce."""
+    eng = E.Engine(KEY, b, device=0)
+    rng = np.random.Generator(np.random.PCG64(n + b))
+    idx = list(range(1, 1 + C)) if C != 4 else [1, 2, 4, 5]
+    small = C > 64
+    pts = [rng.integers(0, 2 ** b, n, dtype=np.uint64) for _ in range(2 if small else C)]
+    d32 = [eng.upload(pts[v % len(pts)].astype(np.uint32)) for v in range(C)]
+    c32 = [eng.alloc(4 * n + 16) for _ in range(C)]
+    dsum = eng.alloc(4 * n + 16)
+    eng.encrypt_batch_sum_u32_dev(2, idx, E.SCHEME_DOUBLE, n, J, d32, c32, dsum)
+    wsum = np.zeros(n, dtype=np.uint64)
+    for v in range(C):
+        w = oracle.encrypt(KEY, 2, idx[v], "double", J, b, pts[v % len(pts)])[:, 0]
+        wsum += w
+        if v in (0, C // 2, C - 1):
+            assert np.array_equal(c32[v].download(np.uint32, n).astype(np.uint64), w), (b, n, v)
+    assert np.array_equal(dsum.download(np.uint32, n).astype(np.uint64), wsum & np.uint64((1 << b) - 1)), (b, n, C)
 
 
 @pytest.mark.parametrize("n,J,C,scheme", [(2_400_001, 16, 3, "double"), (2_300_000, 7, 2, "single"), (2_200_003, 3001, 2, "double")])
