@@ -40,3 +40,12 @@ def test_fuzz_round4_entry_points():
     span-bounds handle, dynamic_masking's cost on the device, the backward carry walk of the element-sharded packed reduce, the clients'
     sparse encrypts + the aggregate of their uploads in one pass (ragged and clustered lists)."""
     assert "FUZZ_R4_OK 72 cases" in _run("fuzz_round4.py", 8, 105)
+
+
+def test_fuzz_round5_entry_points():
+    """What round 5 added, on random shapes against the oracle / NumPy: the compact layout at its compile-time widths and int_bits 64 at
+    compile time in paired-kernel launches (chunk ends everywhere, misaligned and in-place vectors, sub-ranges that cut a block), the
+    encrypts + their sum in one launch and every fall-back of that entry point, the online encrypts + their sum with precomputed masks,
+    the rewritten sparsifier passes (random layer tables, ties at the threshold, residuals; one layer and whole models), the idx + 1 range
+    check."""
+    assert "FUZZ_R5_OK 18 cases" in _run("fuzz_round5.py", 3, 106)
