@@ -837,7 +837,7 @@ int flashe_encrypt_batch_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uin
 
 // flashe_encrypt_batch_u32_dev AND sum_out_dev = sum_v ct[v] mod 2^b written by the same launch: the compact twin of
 // flashe_encrypt_batch_sum_dev ("each GPU encrypts and locally mod-adds its share").  One launch for a run of
-// consecutive clients under the double mask at int_bits 16 / 20 / 23 when the launch is long enough for the paired kernel (the lane that
+// consecutive clients under the double mask at the compiled-in widths (int_bits 16 / 20 / 23 / 24 / 32) when the launch is long enough for the paired kernel (the lane that
 // owns a block keeps the running sum of its elements in registers); every other shape: the encrypts, then the reduce of what they wrote.
 int flashe_encrypt_batch_sum_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec, const uint32_t *idx,
                                      const uint32_t *const *pt_dev, uint32_t *const *ct_dev, uint32_t *sum_out_dev)

@@ -745,7 +745,7 @@ struct SmallParams {
     uint32_t n_jobs, iter;
     int b, m;
     int no_direct;            // A/B knob FLASHE_SMALL_DIRECT: 0 = stage every output through the LDS rows, 2 = general walk instead of the b <= 32 fast walk
-    int no_fixed_width;       // A/B knob FLASHE_SMALL_FIXED=0: the compact layout's kernels with int_bits at run time even at 16 / 20 / 23
+    int no_fixed_width;       // A/B knob FLASHE_SMALL_FIXED=0: the compact layout's kernels with int_bits at run time even at the compiled-in widths
     uint32_t m_magic;         // ceil(2^32 / m): x / m == (x * m_magic) >> 32 for x < 2^13
     uint64_t mask_lo;
     uint64_t top_lo, top_hi;  // the top bit of every b-bit slot of the 128-bit word (SWAR subtraction)
@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void small_direct(bool valid, int cnt, uint64_t j0, u
         if (ok[t]) __builtin_nontemporal_store((pt[t] + static_cast<uint64_t>(D >> (p.b * t))) & p.mask_lo, out + (j0 + t - first));
 }
 
-// ---- the compact layout at a COMPILE-TIME width (round 5): int_bits = 16 / 20 / 23, what the reference's un-batched jobs run ----
+// ---- the compact layout at a COMPILE-TIME width (round 5): int_bits in FLASHE_FIXED32_WIDTHS ----
 // In the uint32 layout the m = 128 / B elements of a lane's AES block are m adjacent 4-byte words, and consecutive lanes of a whole tile
 // hold consecutive blocks: the lane loads, adds and stores ITS OWN block's elements -- 16 + 8 bytes at m = 6, 16 + 4 at m = 5, 16 + 16 at
 // m = 8, a wave covers one contiguous run of 64 m words -- with every slot position a compile-time constant: slot t of a stream is one
@@ -1116,6 +1116,22 @@ __device__ __forceinline__ void small_direct(bool valid, int cnt, uint64_t j0, u
 // subtraction with borrow fix-ups over the 128-bit word, no staging of the difference through an LDS row, no funnel shifts at lane-
 // dependent word offsets, no walk state), and the plaintext prefetch holds m registers per block across the AES rounds instead of
 // eight.  Whole tiles inside the range only; chunk ends and range ends keep the general walk.
+// the widths compiled in for the compact layout: what the reference's job configurations run (examples/configs/*_flashe_q16_*: int_bits 20;
+// 100 clients: 23; 16) and the byte-sized ones a caller with uint32 arrays picks (8: sixteen elements per
+// block in registers spill, measured slower than the run-time width)
+#ifndef FLASHE_FIXED32_WIDTHS
+#define FLASHE_FIXED32_WIDTHS(X) X(16) X(20) X(23) X(24) X(32)
+#endif
+static bool fixed32_width(int b)
+{
+    switch (b) {
+#define FLASHE_FIXED32_CASE(B) case B:
+        FLASHE_FIXED32_WIDTHS(FLASHE_FIXED32_CASE)
+#undef FLASHE_FIXED32_CASE
+        return true;
+    default: return false;
+    }
+}
 template <int M> struct DirectPt { uint32_t v[M]; };
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -1224,7 +1240,7 @@ __device__ __forceinline__ u128 slot_diff(u128 prev, u128 cur, u128 top, int b)
     return ((prev | top) - (cur & ~top)) ^ ((prev ^ ~cur) & top);
 }
 
-// B: 0 = int_bits at run time; 16 / 20 / 23 (compact layout, PAIR only) = the width as a compile-time constant, whole tiles through
+// B: 0 = int_bits at run time; FLASHE_FIXED32_WIDTHS (compact layout, PAIR only) = the width as a compile-time constant, whole tiles through
 // direct32_load / direct32_store
 template <bool PAIR, class ET = uint64_t, int B = 0>
 __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const RoundKeys rk, const SmallChainTable tb, int n_chains, const SmallParams p)
@@ -2333,7 +2349,7 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
     // the fused sum of a chain's outputs: the compact layout's compile-time-width kernels carry it (never cut, double mask, paired launch)
     bool summed = false;
     for (int i = 0; i < n_chains; i++) summed |= chains[i].sum_out_dev != nullptr;
-    if (summed && !(env.elem32 && !p.no_fixed_width && (env.b == 16 || env.b == 20 || env.b == 23) && n_chains == 1 && !chains[0].single &&
+    if (summed && !(env.elem32 && !p.no_fixed_width && fixed32_width(env.b) && n_chains == 1 && !chains[0].single &&
                     chains[0].n_out <= kMaxLinks))
         return hipErrorNotSupported;
     if (env.elem32) {
@@ -2402,14 +2418,16 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
         const uint64_t cus = static_cast<uint64_t>(env.num_cus);
         const int grid = static_cast<int>(tiles < cus ? tiles : cus);
         if (env.elem32) {
-            // the widths the reference's job configurations run (examples/configs/*_flashe_q16_*: int_bits 20; 100 clients: 23; 16) with
-            // their slot positions compiled in
+            // FLASHE_FIXED32_WIDTHS with their slot positions compiled in
             const int fixed = (pair && !p.no_fixed_width) ? env.b : 0;
-            if (fixed == 20) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t, 20>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
-            else if (fixed == 23) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t, 23>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
-            else if (fixed == 16) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t, 16>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
-            else if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
-            else hipLaunchKernelGGL((prf_small_chain_kernel<false, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+            switch (fixed) {
+#define FLASHE_FIXED32(B) case B: hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t, B>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p); break;
+                FLASHE_FIXED32_WIDTHS(FLASHE_FIXED32)
+#undef FLASHE_FIXED32
+            default:
+                if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+                else hipLaunchKernelGGL((prf_small_chain_kernel<false, uint32_t>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
+            }
         } else if (pair && env.b == 64 && !p.no_fixed_width && !p.no_direct)
             hipLaunchKernelGGL((prf_small_chain_kernel<true, uint64_t, 64>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);
         else if (pair) hipLaunchKernelGGL((prf_small_chain_kernel<true>), dim3(grid), dim3(kSmallThreads), 0, env.stream, env.rk, tb, nc, p);

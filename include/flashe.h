@@ -345,7 +345,7 @@ int flashe_aggregate_decrypt_range_dev(flashe_ctx *ctx, uint32_t iter,
 int flashe_encrypt_batch_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
                                  const uint32_t *idx, const uint32_t *const *pt_dev, uint32_t *const *ct_dev);
 /* new (round 5): flashe_encrypt_batch_u32_dev and sum_out_dev = sum_v ct_dev[v] mod 2^b from the same launch -- the compact twin of
- * flashe_encrypt_batch_sum_dev.  One launch for consecutive clients under the double mask at int_bits 16 / 20 / 23 when the vectors are
+ * flashe_encrypt_batch_sum_dev.  One launch for consecutive clients under the double mask at int_bits 16 / 20 / 23 / 24 / 32 when the vectors are
  * long enough for the paired kernel; every other shape runs the encrypts and then the reduce of what they wrote (same results). */
 int flashe_encrypt_batch_sum_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec, const uint32_t *idx,
                                      const uint32_t *const *pt_dev, uint32_t *const *ct_dev, uint32_t *sum_out_dev);

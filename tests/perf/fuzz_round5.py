@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential fuzzer for what round 5 added, each family compared with the CPU oracle / NumPy on random shapes:
-  fixed    the compact layout at the compile-time widths (int_bits 16 / 20 / 23) in launches long enough for the paired kernel: random
+  fixed    the compact layout at the compile-time widths (int_bits 16 / 20 / 23 / 24 / 32; 8: the run-time width, paired) in launches long enough for the paired kernel: random
            lengths, chunkings (n_jobs 1 .. thousands: chunk ends everywhere), client runs, single / double mask, in place or not
   fixed64  int_bits 64 at compile time (one-limb layout), whole vectors and element sub-ranges that start or end inside a block
   encsum   flashe_encrypt_batch_sum_u32_dev: the one-launch form (consecutive clients, double mask, long vectors) and every shape that
@@ -29,7 +29,7 @@ def L(b):
 
 
 def fuzz_fixed(rng, case):
-    b = int(rng.choice([20, 20, 23, 16]))
+    b = int(rng.choice([20, 20, 23, 16, 8, 24, 32]))
     m = 128 // b
     # at least 2 * 128 * 4096 blocks per stream so that the paired (compile-time width) kernel runs; sometimes just below (generic kernel)
     n_min = 2 * 128 * 4096 * m

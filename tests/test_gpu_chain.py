@@ -192,9 +192,12 @@ def test_encrypt_batch_with_partial_aggregate(E, oracle, b, n, idx, scheme):
 
 
 @pytest.mark.parametrize("b,n,J,C,scheme", [(20, 6_400_007, 16, 3, "double"), (23, 5_300_003, 7, 2, "double"), (16, 8_388_608, 1, 2, "double"),
-                                           (20, 6_300_001, 5000, 2, "single"), (16, 4_200_000, 16, 3, "single"), (20, 6_299_999, 16, 2, "double")])
+                                           (20, 6_300_001, 5000, 2, "single"), (16, 4_200_000, 16, 3, "single"), (20, 6_299_999, 16, 2, "double"),
+                                           (32, 4_200_011, 16, 2, "double"), (24, 5_300_001, 16, 3, "double"), (8, 16_800_003, 7, 2, "double"),
+                                           (32, 4_194_304, 999, 2, "single")])
 def test_compact_layout_at_compile_time_widths(E, oracle, b, n, J, C, scheme):
-    """int_bits = 16 / 20 / 23 in the compact layout, launches long enough for the paired kernel (>= 1 M AES blocks per stream): the
+    """int_bits = 16 / 20 / 23 / 24 / 32 (FLASHE_FIXED32_WIDTHS, csrc/kernels.hip; 8: the paired kernel at a run-time width) in the compact
+    layout, launches long enough for the paired kernel (>= 1 M AES blocks per stream): the
     instantiations of prf_small_chain_kernel with the width compiled in (a lane loads, adds and stores its own block's 128 // b elements,
     slot positions constant).  EVERY ciphertext word against the oracle's encrypt (jzf_flashe.py:19-45 slot order and chunk-dependent
     counters, :456-488): whole tiles take the new path; chunk ends (n_jobs = 7, 16, 5000: thousands of partial blocks), the ragged end
