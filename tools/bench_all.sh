@@ -19,6 +19,8 @@ run --bits 20 --no-cpu-baseline --no-e2e
 run --bits 20 --layout u32
 run --bits 16 --no-cpu-baseline --no-e2e
 run --bits 16 --layout u32
+run --bits 24 --layout u32 --no-cpu-baseline
+run --bits 32 --layout u32 --no-cpu-baseline
 python - "$OUT" <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
