@@ -395,6 +395,25 @@ class PtrTable(object):
         return self.items[i]
 
 
+class JobTable(object):
+    """The job list of Engine.prf_jobs_dev built ONCE (Engine.job_table(jobs)): a hundred clients' jobs cost more host time to
+    marshal than their launch takes on the device.  Keeps the buffers alive."""
+
+    def __init__(self, engine, jobs):
+        self.jobs = list(jobs)
+        self.arr = (PrfJob * max(len(self.jobs), 1))()
+        for e, job in enumerate(self.jobs):
+            a, m, first, count, inp, in_limbs, out = job[:7]
+            # optional tail: (n_in, in_stride_elements, sum_out_ptr or None) = the reduce of n_in vectors fused in
+            n_in, in_stride, sum_out = job[7:10] if len(job) > 7 else (0, 0, None)
+            self.arr[e] = PrfJob(a, 0 if m is None else m, 0 if m is None else 1, in_limbs, first, count,
+                                 None if inp is None else engine._ptr(inp), engine._ptr(out), n_in, 0, in_stride,
+                                 None if sum_out is None else engine._ptr(sum_out))
+
+    def __len__(self):
+        return len(self.jobs)
+
+
 class U64Table(object):
     """The same for a per-client list of lengths (Engine.u64_table(values))."""
 
@@ -600,16 +619,12 @@ class Engine:
         """jobs: iterable of (add_idx, minus_idx or None, first, count, in_ptr or None, in_limbs, out_ptr); each writes
         out[k] = in[k] + term(it, add_idx, first + k) - term(it, minus_idx, first + k) for k < count (one launch for
         int_bits > 64).  Pointers address element `first`."""
-        jobs = list(jobs)
-        arr = (PrfJob * max(len(jobs), 1))()
-        for e, job in enumerate(jobs):
-            a, m, first, count, inp, in_limbs, out = job[:7]
-            # optional tail: (n_in, in_stride_elements, sum_out_ptr or None) = the reduce of n_in vectors fused in
-            n_in, in_stride, sum_out = job[7:10] if len(job) > 7 else (0, 0, None)
-            arr[e] = PrfJob(a, 0 if m is None else m, 0 if m is None else 1, in_limbs, first, count,
-                            None if inp is None else self._ptr(inp), self._ptr(out), n_in, 0, in_stride,
-                            None if sum_out is None else self._ptr(sum_out))
-        self._check(self._lib.flashe_prf_jobs_dev(self._h, it, n, n_jobs, len(jobs), arr))
+        tab = jobs if isinstance(jobs, JobTable) else JobTable(self, jobs)
+        self._check(self._lib.flashe_prf_jobs_dev(self._h, it, n, n_jobs, len(tab), tab.arr))
+
+    def job_table(self, jobs):
+        """The job list of prf_jobs_dev as a table built once (JobTable): for calls that repeat round after round."""
+        return JobTable(self, jobs)
 
     # -- mask precompute resident in the ctx (FlasheCipher.prepare_encrypt / prepare_decrypt, jzf_flashe.py:599-666) ---------------
     PREPARED_ENCRYPT, PREPARED_DECRYPT = 1, 2
