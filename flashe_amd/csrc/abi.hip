@@ -1571,6 +1571,9 @@ int flashe_combine_batch_sum_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const u
         if (n && (!in_dev[v] || !out_dev[v])) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
         if (n && out_dev[v] == sum_out_dev) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the output vectors");
         const uint64_t *a = add_dev ? add_dev[v] : nullptr, *m = minus_dev ? minus_dev[v] : nullptr;
+        // (more than 64 vectors run as several passes that fold the sum back in: a later pass would read an operand the sum overwrote)
+        if (n && (in_dev[v] == sum_out_dev || a == sum_out_dev || m == sum_out_dev))
+            return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the operands (vector %d)", v);
         if (ctx->limbs == 2 && (!aligned16(out_dev[v]) || !aligned16(a) || !aligned16(m) || (in_limbs == 2 && !aligned16(in_dev[v]))))
             return fail(ctx, FLASHE_EINVAL, "vector %d: device vectors must be 16-byte aligned", v);
     }

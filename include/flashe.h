@@ -308,7 +308,7 @@ int flashe_combine_batch_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint6
 /* The same combines AND sum_out_dev = sum_v out[v] mod 2^b written by the same pass (new): the online encrypts with precomputed masks
  * (jzf_flashe.py:457, :480-481) plus the arbiter's element-wise reduce of what they wrote (jzf_aggregator.py:424-430) -- the reduce
  * costs one more store instead of a launch that reads every ciphertext back; the twin of flashe_encrypt_batch_sum_dev for the
- * precompute path.  sum_out_dev must not be one of out_dev. */
+ * precompute path.  sum_out_dev must not be one of out_dev, in_dev, add_dev or minus_dev (FLASHE_EINVAL). */
 int flashe_combine_batch_sum_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
                                  const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev,
                                  uint64_t *sum_out_dev);

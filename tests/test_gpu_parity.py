@@ -1453,6 +1453,9 @@ def test_combine_batch_sum_vs_oracle(E, oracle, b, n, V, in_limbs):
     if n and V:
         with pytest.raises(E.FlasheError):
             eng.combine_batch_sum_dev(n, d_in, in_limbs, d_add, d_min, outs, outs[0])          # the sum must not alias an output
+        if in_limbs == Lb:
+            with pytest.raises(E.FlasheError):
+                eng.combine_batch_sum_dev(n, d_in, in_limbs, d_add, d_min, outs, d_in[V - 1])   # ... nor an operand
 
 
 def test_double_mask_idx_range_at_the_raw_abi(E, oracle):
