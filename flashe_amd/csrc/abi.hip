@@ -846,7 +846,8 @@ int flashe_encrypt_batch_sum_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme,
     if (n && n_vec > 0 && !sum_out_dev) return fail(ctx, FLASHE_EINVAL, "flashe_encrypt_batch_sum_u32_dev: null sum_out_dev");
     if (reinterpret_cast<uintptr_t>(sum_out_dev) & 3u) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must be 4-byte aligned");
     for (int v = 0; v < n_vec && ct_dev; v++)
-        if (n && ct_dev[v] == sum_out_dev) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the ciphertext vectors");
+        if (n && (ct_dev[v] == sum_out_dev || (pt_dev && pt_dev[v] == sum_out_dev)))
+            return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the plaintext or ciphertext vectors");
     if (scheme == FLASHE_SCHEME_DOUBLE && n && n_vec > 0 && n_vec <= kMaxUniformBatch && idx && pt_dev && ct_dev) {
         int rc = check_u32(ctx, n, n_jobs);
         if (rc || (rc = check_double_idx(ctx, scheme, idx, n_vec))) return rc;
@@ -956,7 +957,8 @@ int flashe_encrypt_batch_sum_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uin
         return fail(ctx, FLASHE_EINVAL, "sum_out_dev must be aligned like a ciphertext vector");
     if (n_vec > 0 && n) {
         for (int v = 0; v < n_vec; v++)
-            if (ct_dev && ct_dev[v] == sum_out_dev) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the ciphertext vectors");
+            if ((ct_dev && ct_dev[v] == sum_out_dev) || (pt_dev && pt_dev[v] == sum_out_dev))
+                return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the plaintext or ciphertext vectors");
     }
     if (scheme == FLASHE_SCHEME_DOUBLE && n && n_vec > 0 && idx && pt_dev && ct_dev) {
         // one launch: the chained encrypt keeps the running sum of its outputs in registers and stores it once
@@ -1378,7 +1380,8 @@ int flashe_encrypt_batch_range_dev(flashe_ctx *ctx, uint32_t iter, int scheme, u
     if (ctx->env.prf_backend != PRF_AUTO && ctx->env.prf_backend != PRF_TABLE) return fail(ctx, FLASHE_EINVAL, "encrypt_batch_range runs on the table PRF only");
     for (int v = 0; v < n_vec; v++) {
         if (count && (!pt_dev[v] || !ct_dev[v])) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
-        if (ct_dev[v] == sum_out_dev && sum_out_dev) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the ciphertext vectors");
+        if (sum_out_dev && (ct_dev[v] == sum_out_dev || pt_dev[v] == sum_out_dev))
+            return fail(ctx, FLASHE_EINVAL, "sum_out_dev must not be one of the plaintext or ciphertext vectors");
         rc = check_prf_args(ctx, 1, scheme, n_jobs, ct_dev[v], pt_dev[v], pt_limbs);
         if (rc) return rc;
     }

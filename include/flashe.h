@@ -230,7 +230,8 @@ int flashe_encrypt_batch_range_dev(flashe_ctx *ctx, uint32_t iter, int scheme, u
  * locally mod-adds its share".  int_bits > 64, double mask, one run of consecutive cipher indices, a vector long enough to fill the
  * device: ONE launch (every ciphertext of an element passes through the lane's registers, the running sum costs one extra 16-byte
  * store per element and the C ciphertexts are never re-read).  Any other shape: the encrypts followed by flashe_aggregate_elem_dev.
- * The ciphertexts are written as by flashe_encrypt_batch_dev; sum_out_dev (n x L limbs) must not be one of them. */
+ * The ciphertexts are written as by flashe_encrypt_batch_dev; sum_out_dev (n x L limbs) must not be one of them nor a plaintext
+ * (FLASHE_EINVAL; the same holds for the _range and _u32 forms). */
 int flashe_encrypt_batch_sum_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_t n, uint32_t n_jobs, int n_vec,
                                  const uint32_t *idx, const uint64_t *const *pt_dev, int pt_limbs, uint64_t *const *ct_dev,
                                  uint64_t *sum_out_dev);

@@ -189,6 +189,8 @@ def test_encrypt_batch_with_partial_aggregate(E, oracle, b, n, idx, scheme):
     assert np.array_equal(dsum.download(np.uint64, n * Lb).reshape(n, Lb), oracle.aggregate_elem(want, b)), (b, n, "partial aggregate")
     with pytest.raises(E.FlasheError):
         eng.encrypt_batch_sum_dev(6, idx, E.SCHEME_DOUBLE, n, 16, dpt, 1, dct, dct[0])      # the sum must not alias a ciphertext
+    with pytest.raises(E.FlasheError):
+        eng.encrypt_batch_sum_dev(6, idx, E.SCHEME_DOUBLE, n, 16, dpt, 1, dct, dpt[-1])     # ... nor a plaintext (chunk ends add to the sum in memory)
 
 
 @pytest.mark.parametrize("b,n,J,C,scheme", [(20, 6_400_007, 16, 3, "double"), (23, 5_300_003, 7, 2, "double"), (16, 8_388_608, 1, 2, "double"),
