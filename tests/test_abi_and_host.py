@@ -245,3 +245,18 @@ def test_mt19937_pass_plan_never_exceeds_the_jump_table():
             assert avail.value == 4096 and 1 <= mx.value <= avail.value, (n, pos, mx.value)
             assert passes.value == -(-n // (((1 << 29) - 624) // 2))
     assert lib.flashe_mt19937_plan(625, 1, ctypes.byref(mx), ctypes.byref(avail), ctypes.byref(passes)) == -22
+
+
+def test_job_table_marshals_the_job_list_once():
+    """Engine.job_table: the flashe_prf_job array of prf_jobs_dev built once (a hundred clients' jobs cost more host time to marshal than
+    their launch takes on the device): the same fields prf_jobs_dev would write per call, optional tails included; no device needed."""
+    jobs = [(3, 4, 0, 100, None, 0, 0x1000), (7, None, 16, 84, 0x2000, 1, 0x3000), (9, 10, 0, 100, 0x4000, 2, 0x5000, 5, 128, 0x6000)]
+    tab = engine.JobTable(engine.Engine, jobs)                  # (Engine._ptr is a static method: the class stands in for an engine)
+    assert len(tab) == 3
+    a, b, c = tab.arr[0], tab.arr[1], tab.arr[2]
+    names = [f[0] for f in engine.PrfJob._fields_]
+    get = lambda j, k: getattr(j, names[k])                    # noqa: E731
+    # field order of flashe_prf_job (include/flashe.h): add_idx, minus_idx, has_minus, in_limbs, first, count, in, out, n_in, reserved, in_stride, sum_out
+    assert [get(a, k) for k in range(6)] == [3, 4, 1, 0, 0, 100] and not get(a, 6) and get(a, 7) == 0x1000
+    assert [get(b, k) for k in range(6)] == [7, 0, 0, 1, 16, 84] and get(b, 6) == 0x2000 and get(b, 7) == 0x3000
+    assert get(c, 8) == 5 and get(c, 10) == 128 and get(c, 11) == 0x6000
