@@ -260,3 +260,15 @@ def test_job_table_marshals_the_job_list_once():
     assert [get(a, k) for k in range(6)] == [3, 4, 1, 0, 0, 100] and not get(a, 6) and get(a, 7) == 0x1000
     assert [get(b, k) for k in range(6)] == [7, 0, 0, 1, 16, 84] and get(b, 6) == 0x2000 and get(b, 7) == 0x3000
     assert get(c, 8) == 5 and get(c, 10) == 128 and get(c, 11) == 0x6000
+
+
+def test_entry_point_index_is_complete_and_current():
+    """include/ENTRY_POINTS.md (generated from the header by tools/gen_entry_index.py: section, reference lines cited, tests that call
+    it) lists every exported symbol exactly once and is what the generator writes today."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_entry_index.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = open(os.path.join(ROOT, "include", "ENTRY_POINTS.md")).read()
+    listed = re.findall(r"^\| `(flashe_\w+)` \|", text, re.M)
+    assert sorted(listed) == sorted(_lib.EXPORTED_SYMBOLS) and len(listed) == len(set(listed))
