@@ -83,6 +83,30 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
 #ifndef FLASHE_CTR2
 #define FLASHE_CTR2 1   // wave-uniform part of rounds 1-2 through the scalar cache
 #endif
+// Wave priority inside the software-pipelined rounds (round 5): a wave RAISES its s_setprio as it advances through the rounds of a
+// block pair (0 until round P1, then 1, 2, 3 from rounds P1 / P2 / P3), so the SIMD's arbiter serves the wave closest to the end of its
+// dependent chain first instead of round-robin -- the waves of a SIMD drift apart and one wave's loads, stores and loop head fall under
+// the others' lookups.  prf_chain_kernel<1024, SUM>: 1.440 -> 1.305 ms (-9.3 %), the decrypt of one vector 0.272 -> 0.250, b = 64
+// -5 %; the VALU-bound compact kernels: 0 ... -3 % (tests/perf/ab_chain_libs.py, ab_compact_libs.py; 0 = off, 1 = falling: -4 %;
+// thresholds 5/8/11, 3/6/9, 3/6/10, 6/9/12 within 1 % of 4/7/10, two levels only -6.7 %).  The span kernel keeps its own, FALLING,
+// schedule: its waves meet at a counter every span (rising measured +5.6 % there).  `prio` is a per-launch choice (the last argument of
+// aes256_rounds): on in the int_bits > 64 kernels; int_bits <= 64 (tests/perf/ab_compact_libs.py, 0 against 2): one-limb layout b = 64
+// -5 % (its reduce + decrypt -11.6 %), 40: -7 %, 32: -5 %, but the staged walk of b <= 25: +15 %; compact layout 23 / 24 / 32: -8 %,
+// 16: -2 %, 20: +1.5 %, their reduce + decrypt +1 ... +3 % -- the launcher's table follows these (small_swp_prio).
+#ifndef FLASHE_SWP_PRIO
+#define FLASHE_SWP_PRIO 2
+#endif
+#ifndef FLASHE_SWP_P1
+#define FLASHE_SWP_P1 4
+#define FLASHE_SWP_P2 7
+#define FLASHE_SWP_P3 10
+#endif
+#ifndef FLASHE_SWP_PRIO_HALF
+#define FLASHE_SWP_PRIO_HALF 1  // prf_chain_kernel's half tiles (short launches, ragged ends): ten 1e6-element vectors -5 %, config 3's shape +-1 %
+#endif
+#ifndef FLASHE_SWP_POST
+#define FLASHE_SWP_POST -1      // >= 0: the priority a wave returns to after the rounds (measured: no difference)
+#endif
 #ifndef FLASHE_SWP
 #define FLASHE_SWP 1   // two-block calls run software pipelined (measured 4.6 % faster than the compiler's own order)
 #endif
@@ -122,13 +146,13 @@ __device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b)
 // Rounds FIRST..13 and the final round on NB independent blocks (state = 4 big-endian column words,
 // already carrying everything up to round FIRST - 1).
 template <int FIRST>
-__device__ __forceinline__ void aes256_rounds2_swp(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[2][4]);
+__device__ __forceinline__ void aes256_rounds2_swp(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[2][4], bool prio);
 
 template <int NB, int FIRST>
-__device__ __forceinline__ void aes256_rounds(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4])
+__device__ __forceinline__ void aes256_rounds(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4], bool prio = false)
 {
     if constexpr (NB == 2 && FLASHE_SWP) {
-        aes256_rounds2_swp<FIRST>(rk, lr, s);
+        aes256_rounds2_swp<FIRST>(rk, lr, s, prio);
         return;
     }
 #pragma unroll
@@ -205,7 +229,7 @@ __device__ __forceinline__ void finish_final(const RoundKeys &rk, const Lk16 &k,
 }
 
 template <int FIRST>
-__device__ __forceinline__ void aes256_rounds2_swp(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[2][4])
+__device__ __forceinline__ void aes256_rounds2_swp(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[2][4], bool prio)
 {
     Lk16 ka = issue_main(lr, s[0]);
     __builtin_amdgcn_sched_barrier(0);
@@ -213,6 +237,18 @@ __device__ __forceinline__ void aes256_rounds2_swp(const RoundKeys &rk, const La
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = FIRST; r < 14; r++) {
+        // (prio: wave-uniform, chosen per launch -- a scalar branch around each s_setprio)
+#if FLASHE_SWP_PRIO == 1            // (falling with the progress through the rounds: the A/B alternative)
+        if (prio && r == FIRST) __builtin_amdgcn_s_setprio(3);
+        else if (prio && r == 5) __builtin_amdgcn_s_setprio(2);
+        else if (prio && r == 8) __builtin_amdgcn_s_setprio(1);
+        else if (prio && r == 11) __builtin_amdgcn_s_setprio(0);
+#elif FLASHE_SWP_PRIO == 2
+        if (prio && r == FIRST) __builtin_amdgcn_s_setprio(0);
+        if (prio && r == FLASHE_SWP_P1) __builtin_amdgcn_s_setprio(1);
+        if (prio && r == FLASHE_SWP_P2) __builtin_amdgcn_s_setprio(2);
+        if (prio && r == FLASHE_SWP_P3) __builtin_amdgcn_s_setprio(3);
+#endif
         finish_main(rk, r, ka, s[0]);
         ka = r < 13 ? issue_main(lr, s[0]) : issue_final(lr, s[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -222,6 +258,9 @@ __device__ __forceinline__ void aes256_rounds2_swp(const RoundKeys &rk, const La
     }
     finish_final(rk, ka, s[0]);
     finish_final(rk, kb, s[1]);
+#if FLASHE_SWP_PRIO == 2 && FLASHE_SWP_POST >= 0
+    if (prio) __builtin_amdgcn_s_setprio(FLASHE_SWP_POST);
+#endif
 }
 
 // One block per lane where there is no second one to pipeline against: all sixteen lookups of a round are issued as their state

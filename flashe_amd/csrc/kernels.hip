@@ -239,12 +239,12 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
                 const uint32_t v0 = T3(static_cast<uint32_t>(j) ^ rk.w[3], SEL_B0);
                 ctr_round2(lr, pre_a.u[0], v0, Ua, s[0]);
                 if (DBL) ctr_round2(lr, pre_b.u[0], v0, Ub, s[DBL ? 1 : 0]);
-                aes256_rounds<DBL ? 2 : 1, 3>(rk, lr, s);
+                aes256_rounds<DBL ? 2 : 1, 3>(rk, lr, s, true);
             } else if (ctr_fast) {
                 const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(j));
                 ctr_round1(pre_a, x, s[0]);
                 if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
-                aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
+                aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s, true);
             } else {
                 set_block(s[0], iter, ia, j);
                 if (DBL) set_block(s[DBL ? 1 : 0], iter, im, j);
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                         uint32_t s[2][4];
                         ctr_round2(lr, pre.u[0], vA0, U, s[0]);
                         ctr_round2(lr, pre.u[0], vA1, U, s[1]);
-                        aes256_rounds<2, 3>(rk, lr, s);
+                        aes256_rounds<2, 3>(rk, lr, s, true);
                         loads_landed(x0, x1);
                         const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
                         const u128 r0 = x0 + (single ? c0 : pA0 - c0), r1 = x1 + (single ? c1 : pA1 - c1);
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                 uint32_t s[2][4];
                 ctr_round1(pre, xv0, s[0]);
                 ctr_round1(pre, xv1, s[1]);
-                aes256_rounds<2, 2>(rk, lr, s);
+                aes256_rounds<2, 2>(rk, lr, s, FLASHE_SWP_PRIO_HALF != 0);
                 loads_landed(x0, x1);
                 const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
                 const u128 r0 = x0 + (single ? c0 : p0 - c0), r1 = x1 + (single ? c1 : p1 - c1);
@@ -745,6 +745,7 @@ struct SmallParams {
     uint32_t n_jobs, iter;
     int b, m;
     int no_direct;            // A/B knob FLASHE_SMALL_DIRECT: 0 = stage every output through the LDS rows, 2 = general walk instead of the b <= 32 fast walk
+    int swp_prio;             // wave priority rising through the rounds of a block pair (device_common.h): set per launch from the measured table
     int no_fixed_width;       // A/B knob FLASHE_SMALL_FIXED=0: the compact layout's kernels with int_bits at run time even at the compiled-in widths
     uint32_t m_magic;         // ceil(2^32 / m): x / m == (x * m_magic) >> 32 for x < 2^13
     uint64_t mask_lo;
@@ -1361,7 +1362,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 uint32_t s[2][4];
                 ctr_round1(pre, xA, s[0]);
                 ctr_round1(pre, xB, s[1]);
-                aes256_rounds<2, 2>(rk, lr, s);
+                aes256_rounds<2, 2>(rk, lr, s, p.swp_prio != 0);
                 const u128 SA = words_to_u128(s[0]), SB = words_to_u128(s[1]);
                 if (link >= 0) {
                     const uint64_t *in = tb.in[link0 + link];
@@ -1496,7 +1497,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_kernel(con
 #ifdef FLASHE_TUNING
         if (!(has_minus & 0x100))                                          // (0x100: timing probe without the rounds, FLASHE_SMALL_REDUCE_PROBE)
 #endif
-        aes256_rounds<2, 2>(rk, lr, s);
+        aes256_rounds<2, 2>(rk, lr, s, p.swp_prio != 0);
         const u128 Sa = words_to_u128(s[0]), Sm = words_to_u128(s[1]);
         const u128 D = (has_minus & 1) ? slot_diff(Sa, Sm, top, p.b) : Sa;
         *reinterpret_cast<uint4 *>(row0 + 4 * lane) = make_uint4(static_cast<uint32_t>(D), static_cast<uint32_t>(D >> 32),
@@ -2269,7 +2270,8 @@ hipError_t launch_small_reduce_decrypt(const LaunchEnv &env, uint32_t iter, uint
     if (out_elem_bytes != 8 && !(out_elem_bytes == 4 && env.elem32)) return hipErrorInvalidValue;
     if (env.prf_backend != PRF_AUTO && env.prf_backend != PRF_TABLE) return hipErrorNotSupported;
     if (count == 0) return hipSuccess;
-    const SmallParams p = small_params_of(env, iter, n, n_jobs);
+    SmallParams p = small_params_of(env, iter, n, n_jobs);
+    p.swp_prio = 1;                           // (small_reduce_decrypt_kernel, one-limb layout: b = 64 -11.6 %, b = 40 +-0; the split kernel has one block per lane)
     const uint64_t bf = block_of(first, n, n_jobs, p.m), bc = block_of(first + count - 1, n, n_jobs, p.m) - bf + 1;
     PtrTable t;
     for (int c = 0; c < kMaxOps; c++) t.p[c] = c < C ? ops[c] : nullptr;
@@ -2356,6 +2358,11 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
         if (env.b > 32) return hipErrorInvalidValue;
         p.no_direct = 1;                      // the 16-byte direct accesses of m <= 4 assume 8-byte elements: b = 32 walks its rows like b < 32
     }
+    // rising wave priority inside the rounds of a block pair (device_common.h), where it was measured to pay: the direct output paths
+    // (one-limb layout at m <= 4: -5 ... -7 %; compact layout at the compiled-in widths: 23 / 24 / 32 -8 %, 16 -2 %) -- not int_bits 20
+    // compact (+1.5 %) and not the staged walk of the one-limb layout at m >= 5 (+15 %)
+    p.swp_prio = env.elem32 ? (!p.no_fixed_width && fixed32_width(env.b) && env.b != 20) : (p.m <= 4 && !p.no_direct);
+    { static const int v = FLASHE_TUNE_ENV("FLASHE_SMALL_PRIO") ? atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_PRIO")) : -1; if (v >= 0) p.swp_prio = v; }
     struct Piece { const PrfChain *ch; int l0, l1; uint64_t blk_first, blk_count; };
     std::vector<Piece> pieces;
     uint64_t total_blocks = 0;
@@ -2478,7 +2485,7 @@ __global__ __launch_bounds__(kPrfThreads) void reduce_decrypt_ptrs_kernel(const 
         uint32_t s[DBL ? 2 : 1][4];
         ctr_round1(pre_a, x, s[0]);
         if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
-        aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
+        aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s, true);
 #pragma unroll
         for (int c = 0; c < kSumRegs; c++)
             if (c < C) acc += (static_cast<u128>(held[c][1]) << 64) | held[c][0];
@@ -2546,7 +2553,7 @@ __global__ __launch_bounds__(THREADS) void reduce_decrypt_probe_kernel(const Rou
         uint32_t s[2][4];
         ctr_round1(pre_a, x, s[0]);
         ctr_round1(pre_b, x, s[1]);
-        aes256_rounds<2, 2>(rk, lr, s);
+        aes256_rounds<2, 2>(rk, lr, s, true);
         u128 acc = 0;
 #pragma unroll
         for (int c = 0; c < kSumRegs; c++)

@@ -1220,10 +1220,10 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                 // every round while the other SIMD slots idle.  (Measured and dropped, tests/perf/experiments/r05_*: the waves in two
                 // priority classes half a span apart, so that one class's atomics / loop head fall into the other's rounds -- the waits
                 // below then block for a round each and the passes get 5-9 % slower; no priorities at all: 15-20 % slower.)
-                if (r == 2) __builtin_amdgcn_s_setprio(3);
-                else if (r == 5) __builtin_amdgcn_s_setprio(2);
-                else if (r == 8) __builtin_amdgcn_s_setprio(1);
-                else if (r == 11) __builtin_amdgcn_s_setprio(0);
+                if (r == 2) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 0 : 3);
+                else if (r == 5) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 1 : 2);
+                else if (r == 8) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 2 : 1);
+                else if (r == 11) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 3 : 0);
 #endif
                 if (r < 10) finish_main(rk, r, k, s);
                 else {
