@@ -104,6 +104,12 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
 #ifndef FLASHE_SWP_PRIO_HALF
 #define FLASHE_SWP_PRIO_HALF 1  // prf_chain_kernel's half tiles (short launches, ragged ends): ten 1e6-element vectors -5 %, config 3's shape +-1 %
 #endif
+#ifndef FLASHE_DEEP_PRIO
+#define FLASHE_DEEP_PRIO 1      // the rising schedule in small_reduce_decrypt_split_kernel (one block per lane): compact b = 20 -6.6 %, 23 -10 %, 16 -2 %
+#endif
+#ifndef FLASHE_SMALL_NP_PRIO
+#define FLASHE_SMALL_NP_PRIO 1  // ... in the two-streams-per-step form of prf_small_chain_kernel and in prf_small_kernel (config 3 at b = 23: -2 %)
+#endif
 #ifndef FLASHE_SWP_POST
 #define FLASHE_SWP_POST -1      // >= 0: the priority a wave returns to after the rounds (measured: no difference)
 #endif
@@ -267,12 +273,16 @@ __device__ __forceinline__ void aes256_rounds2_swp(const RoundKeys &rk, const La
 // words become final, nothing of the next round moves up (left to itself the compiler interleaves the rounds with two or three
 // lookups in flight per wave, and the LDS pipe idles: the span reduce with the PRF inside ran at 46 % of the lookup rate that way).
 template <int FIRST>
-__device__ __forceinline__ void aes256_rounds1_deep(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[4])
+__device__ __forceinline__ void aes256_rounds1_deep(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[4], bool prio = false)
 {
     Lk16 k = issue_main(lr, s);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = FIRST; r < 14; r++) {
+        if (prio && r == FIRST) __builtin_amdgcn_s_setprio(0);           // (the rising schedule of aes256_rounds2_swp)
+        if (prio && r == FLASHE_SWP_P1) __builtin_amdgcn_s_setprio(1);
+        if (prio && r == FLASHE_SWP_P2) __builtin_amdgcn_s_setprio(2);
+        if (prio && r == FLASHE_SWP_P3) __builtin_amdgcn_s_setprio(3);
         finish_main(rk, r, k, s);
         k = r < 13 ? issue_main(lr, s) : issue_final(lr, s);
         __builtin_amdgcn_sched_barrier(0);

@@ -834,7 +834,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_jobs_kernel(const Rou
             const CtrVar x = ctr_var(rk, lr, static_cast<uint32_t>(ctr));
             ctr_round1(pre_a, x, s[0]);
             if (DBL) ctr_round1(pre_b, x, s[DBL ? 1 : 0]);
-            aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s);
+            aes256_rounds<DBL ? 2 : 1, 2>(rk, lr, s, FLASHE_SMALL_NP_PRIO != 0);
         } else {
             set_block(s[0], iter, ia, ctr);
             if (DBL) set_block(s[DBL ? 1 : 0], iter, im, ctr);
@@ -1427,7 +1427,7 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
                 uint32_t s[2][4];
                 ctr_round1(pre0, xA, s[0]);
                 ctr_round1(pre1, xA, s[1]);
-                aes256_rounds<2, 2>(rk, lr, s);
+                aes256_rounds<2, 2>(rk, lr, s, FLASHE_SMALL_NP_PRIO != 0);
                 const u128 S0 = words_to_u128(s[0]), S1 = words_to_u128(s[1]);
                 if (l0 >= 0) {
                     const u128 D = single ? S0 : slot_diff(prevA, S0, top, p.b);
@@ -1614,7 +1614,7 @@ __global__ __launch_bounds__(kSmallThreads) void small_reduce_decrypt_split_kern
 #ifdef FLASHE_TUNING
         if (!(has_minus & 0x100))                                        // (0x100: timing probe without the rounds)
 #endif
-        aes256_rounds1_deep<2>(rk, lr, s[0]);                            // (one block per lane: all sixteen lookups of a round in flight)
+        aes256_rounds1_deep<2>(rk, lr, s[0], FLASHE_DEEP_PRIO != 0);     // (one block per lane: all sixteen lookups of a round in flight)
         // row word order = little-endian words of the 128-bit block value (word 0 = bits 0..31)
         *reinterpret_cast<uint4 *>(row0 + 4 * lane) = drop ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(s[0][3], s[0][2], s[0][1], s[0][0]);
         __builtin_amdgcn_wave_barrier();
