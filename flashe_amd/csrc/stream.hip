@@ -987,7 +987,12 @@ struct SpanPrfEntry {
 // earlier) -- so a wait almost never blocks, waves drift up to half a span apart, and one wave's atomics, table reads and loop head run
 // under the other waves' rounds.  The counters only grow (sixteen arrivals per phase and span).
 #ifndef FLASHE_SPAN_PRIO
-#define FLASHE_SPAN_PRIO 1       // waves yield as they advance through the rounds of a span (0 = off, for A/B builds)
+#define FLASHE_SPAN_PRIO 1       // waves yield as they advance through the rounds of a span (0 = off, 2 = rising: +5.6 %; for A/B builds)
+#endif
+#ifndef FLASHE_SPAN_P1
+#define FLASHE_SPAN_P1 5         // the rounds at which the priority steps down (3 from round 2)
+#define FLASHE_SPAN_P2 8
+#define FLASHE_SPAN_P3 11
 #endif
 
 __device__ __forceinline__ void phase_arrive(uint32_t *ctr)
@@ -1221,9 +1226,9 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                 // priority classes half a span apart, so that one class's atomics / loop head fall into the other's rounds -- the waits
                 // below then block for a round each and the passes get 5-9 % slower; no priorities at all: 15-20 % slower.)
                 if (r == 2) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 0 : 3);
-                else if (r == 5) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 1 : 2);
-                else if (r == 8) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 2 : 1);
-                else if (r == 11) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 3 : 0);
+                else if (r == FLASHE_SPAN_P1) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 1 : 2);
+                else if (r == FLASHE_SPAN_P2) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 2 : 1);
+                else if (r == FLASHE_SPAN_P3) __builtin_amdgcn_s_setprio(FLASHE_SPAN_PRIO == 2 ? 3 : 0);
 #endif
                 if (r < 10) finish_main(rk, r, k, s);
                 else {
