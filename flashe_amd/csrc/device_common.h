@@ -110,6 +110,9 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
 #ifndef FLASHE_SMALL_NP_PRIO
 #define FLASHE_SMALL_NP_PRIO 1  // ... in the two-streams-per-step form of prf_small_chain_kernel and in prf_small_kernel (config 3 at b = 23: -2 %)
 #endif
+#ifndef FLASHE_EDGE_PRIO
+#define FLASHE_EDGE_PRIO 1      // ... in sparse_edge_prf_kernel (the run edges of the sparse double mask)
+#endif
 #ifndef FLASHE_SWP_POST
 #define FLASHE_SWP_POST -1      // >= 0: the priority a wave returns to after the rounds (measured: no difference)
 #endif
@@ -292,13 +295,13 @@ __device__ __forceinline__ void aes256_rounds1_deep(const RoundKeys &rk, const L
 
 // NB independent blocks; s holds the plaintext blocks.
 template <int NB>
-__device__ __forceinline__ void aes256_encrypt(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4])
+__device__ __forceinline__ void aes256_encrypt(const RoundKeys &rk, const LaneRegs lr, uint32_t (&s)[NB][4], bool prio = false)
 {
 #pragma unroll
     for (int q = 0; q < NB; q++) {
         s[q][0] ^= rk.w[0]; s[q][1] ^= rk.w[1]; s[q][2] ^= rk.w[2]; s[q][3] ^= rk.w[3];
     }
-    aes256_rounds<NB, 1>(rk, lr, s);
+    aes256_rounds<NB, 1>(rk, lr, s, prio);
 }
 
 // PRF blocks are iter | idx | counter: within one launch only the low counter word varies between

@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(kPrfThreads) void sparse_edge_prf_kernel(const Roun
         uint32_t s[2][4];
         set_block(s[0], iter, c + 1u, ctr);            // add side: list (prefix) c + 1
         set_block(s[1], iter, c, ctr);                 // minus side: list c
-        aes256_encrypt<2>(rk, lr, s);
+        aes256_encrypt<2>(rk, lr, s, FLASHE_EDGE_PRIO != 0);
         const int sh = static_cast<int>(static_cast<uint32_t>(b) * (p - static_cast<uint32_t>(ctr) * m));
         const u128 A = in_next ? static_cast<u128>(0) : (words_to_u128(s[0]) >> sh) & mask;
         const u128 M = in_prev ? static_cast<u128>(0) : (words_to_u128(s[1]) >> sh) & mask;
