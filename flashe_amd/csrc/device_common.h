@@ -92,7 +92,7 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
 // schedule: its waves meet at a counter every span (rising measured +5.6 % there).  `prio` is a per-launch choice (the last argument of
 // aes256_rounds): on in the int_bits > 64 kernels; int_bits <= 64 (tests/perf/ab_compact_libs.py, 0 against 2): one-limb layout b = 64
 // -5 % (its reduce + decrypt -11.6 %), 40: -7 %, 32: -5 %, but the staged walk of b <= 25: +15 %; compact layout 23 / 24 / 32: -8 %,
-// 16: -2 %, 20: +1.5 %, their reduce + decrypt +1 ... +3 % -- the launcher's table follows these (small_swp_prio).
+// 16: -2 %, 20: +1.5 % -- the launcher's table follows these (small_swp_prio).
 #ifndef FLASHE_SWP_PRIO
 #define FLASHE_SWP_PRIO 2
 #endif
@@ -111,7 +111,7 @@ __device__ __forceinline__ LaneRegs lane_regs(uint32_t *tab)
 #define FLASHE_SMALL_NP_PRIO 1  // ... in the two-streams-per-step form of prf_small_chain_kernel and in prf_small_kernel (config 3 at b = 23: -2 %)
 #endif
 #ifndef FLASHE_EDGE_PRIO
-#define FLASHE_EDGE_PRIO 1      // ... in sparse_edge_prf_kernel (the run edges of the sparse double mask)
+#define FLASHE_EDGE_PRIO 1      // ... in sparse_edge_prf_kernel (the run edges of the sparse double mask): -3.5 %
 #endif
 #ifndef FLASHE_SWP_POST
 #define FLASHE_SWP_POST -1      // >= 0: the priority a wave returns to after the rounds (measured: no difference)
