@@ -323,9 +323,61 @@ class _CStdoutToStderr:
         return False
 
 
-def main(comm_factory=None, device_override=None):
-    """comm_factory(rank, world) / device_override: TEST SEAMS, never set by this script -- tests/bench_shm.py runs this very flow with
-    several ranks on ONE GPU by passing a file-based double of RcclComm (tests/shm_comm.py) and device 0 for every rank."""
+class PreflightError(RuntimeError):
+    """A rank found that this machine cannot carry the launch (message starts with "preflight:"); .info = what it had established."""
+
+    def __init__(self, msg, info):
+        super().__init__(msg)
+        self.info = info
+
+
+def preflight(world, local_rank, need_rccl, test_double=False, devices_override=None):
+    """What a rank checks BEFORE it creates its engine (inside the rank: never in the launcher, never by re-exec): enough visible devices
+    for WORLD_SIZE ranks, LOCAL_RANK among them, direct peer access from its device to every other rank's (what RCCL's point-to-point
+    transport over xGMI needs), an RCCL that loads -- and which build of the library it is running on (basename + sha256[:16]: the line
+    certifies the file that produced it; FLASHE_LIB_NAME can point at another build).  Returns the keys that go into `config`; raises
+    PreflightError("preflight: ...") on the first failed check.  test_double / devices_override: TEST SEAMS (tests/bench_shm.py: several
+    ranks share device 0 through a file-based comm double; the override injects a device count)."""
+    import ctypes
+    import hashlib
+    from flashe_amd import _lib
+    lib = _lib.load()
+    with open(_lib.LIB_PATH, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()[:16]
+    info = {"library": os.path.basename(_lib.LIB_PATH), "library_sha256_16": digest, "abi_version": int(lib.flashe_abi_version()),
+            "devices_visible": None, "peer_access_ok": None, "rccl_version": None}
+    n = ctypes.c_int(0)
+    devices = n.value if lib.flashe_device_count(ctypes.byref(n)) == 0 else 0
+    if devices_override is not None:
+        devices = int(devices_override)
+    info["devices_visible"] = devices
+    one_device_each = not test_double or devices_override is not None
+    if one_device_each and devices < world:
+        raise PreflightError(f"preflight: {devices} devices visible, {world} ranks requested", info)
+    if local_rank >= max(devices, 0) or local_rank < 0:
+        raise PreflightError(f"preflight: LOCAL_RANK {local_rank} but {devices} devices visible", info)
+    if world > 1 and not test_double:
+        blocked = []
+        for peer in range(world):
+            can = ctypes.c_int(0)
+            if lib.flashe_device_peer_access(local_rank, peer, ctypes.byref(can)) != 0 or not can.value:
+                blocked.append(peer)
+        info["peer_access_ok"] = not blocked
+        if blocked:
+            raise PreflightError(f"preflight: device {local_rank} has no peer access to device(s) {blocked}", info)
+    if need_rccl and not test_double:
+        v = ctypes.c_int(0)
+        if lib.flashe_rccl_version(ctypes.byref(v)) != 0:
+            raise PreflightError("preflight: librccl.so could not be loaded (or has no ncclGetVersion)", info)
+        code = v.value
+        info["rccl_version"] = f"{code // 10000}.{code // 100 % 100}.{code % 100} ({code})"
+    return info
+
+
+def main(comm_factory=None, device_override=None, devices_override=None):
+    """comm_factory(rank, world) / device_override / devices_override: TEST SEAMS, never set by this script -- tests/bench_shm.py runs this
+    very flow with several ranks on ONE GPU by passing a file-based double of RcclComm (tests/shm_comm.py) and device 0 for every rank;
+    devices_override injects a visible-device count into the preflight."""
     if len(sys.argv) == 3 and sys.argv[1] == "--py-baseline-child":
         b, C, ns = (int(v) for v in sys.argv[2].split(","))
         print(json.dumps(python_structure_baseline(b, C, [plaintext(c, ns, b) for c in range(C)], ns)), flush=True)
@@ -348,7 +400,14 @@ def main(comm_factory=None, device_override=None):
     # N > 1: RCCL has no timeouts, so every rank runs a watchdog (flashe_amd.dist.Watchdog: per-phase deadline + an abort file any
     # rank can raise).  When it fires, rank 0 prints the best line it already holds -- the plain sequential round is timed FIRST
     # and kept as the fallback -- and every rank leaves through os._exit (an exit, never an exec).
-    state = {"fallback": None}
+    state = {"fallback": None, "preflight": {}}
+
+    def emit(line):
+        """THE one JSON line: whatever produced it, `config` carries the preflight's keys (devices, peer access, RCCL, library hash)."""
+        line = dict(line)
+        line["config"] = dict(line.get("config") or {}, **state["preflight"])
+        print(json.dumps(line), flush=True)
+
     if world > 1:
         from flashe_amd.dist import Watchdog
 
@@ -361,9 +420,11 @@ def main(comm_factory=None, device_override=None):
                 line[state["reason_key"]] = reason             # (the main line is complete: the phase that failed came after it)
             elif line is not None:
                 line["config"]["schedule_fallback_reason"] = reason
+            elif "preflight:" in reason:                       # a rank refused the machine before any engine existed: say exactly that
+                line = dict(out, value=None, ms_per_step=None, error=reason[reason.index("preflight:"):])
             else:
                 line = dict(out, value=None, ms_per_step=None, error=f"no round completed: {reason}")
-            print(json.dumps(line), flush=True)
+            emit(line)
         wd = Watchdog(rank, world, on_fire)
         wd.arm(args.deadline, "start-up (engine, RCCL communicator) and the sequential round")
     else:
@@ -378,6 +439,8 @@ def main(comm_factory=None, device_override=None):
         if cfg == 1 and args.bits == 128:
             b = args.bits = 64                      # config 1 is quoted on a 64-bit modulus
             out["dtype"] = "u64"
+        state["preflight"] = preflight(world, local_rank, need_rccl=(world > 1 or args.force_dist), test_double=comm_factory is not None,
+                                       devices_override=devices_override)
         eng = Engine(KEY, b, device=local_rank)
         eng.selftest()
         backend = {"auto": 0, "table": 1, "bitslice": 2, "hybrid": 3, "bitslice16": 4}[args.prf_backend]
@@ -407,9 +470,14 @@ def main(comm_factory=None, device_override=None):
             time.sleep(30)
             os._exit(wd.exit_code)
         if rank == 0:
-            print(json.dumps(result), flush=True)
+            emit(result)
     except BaseException as exc:
+        if isinstance(exc, PreflightError):
+            state["preflight"] = exc.info
         if world == 1:
+            if isinstance(exc, PreflightError):                # one rank: the same legible line instead of a traceback, exit code 3
+                emit(dict(out, value=None, ms_per_step=None, error=str(exc)))
+                sys.exit(3)
             raise
         # a rank that stops must take the others with it (they would wait in their next collective forever): raise the abort flag,
         # every watchdog fires within a poll interval -- rank 0's prints the fallback line if the sequential round is already in
@@ -566,19 +634,30 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
     orc.build()
     want_ct = {}
 
-    def ciphertext_ok():
-        """The ciphertexts the timed kernels write are the reference's: the first and the last local client's vector at iter 0 against
-        the oracle's encrypt (the round trip alone would pass for ANY mask stream, double masks telescope)."""
-        for c in sorted({0, C - 1}) if C else []:
-            if c not in want_ct:
-                want_ct[c] = orc.encrypt(KEY, 0, mine[c], "double", J, b, host_pts[mine[c]])
-            if not np.array_equal(ops.read(rnd.ct[c], n * L).reshape(n, L), want_ct[c]):
+    def ciphertext_ok(check_partial):
+        """The ciphertexts the timed kernels write are the reference's: EVERY local client's vector at iter 0 against the oracle's encrypt
+        when a rank plays at most 10 clients (first and last otherwise; the round trip alone would pass for ANY mask stream, double masks
+        telescope), and -- one rank, sequential round -- the local aggregate against the oracle's element-wise reduce of them
+        (jzf_aggregator.py:424-430).  Only the first and the last expected vector stay cached (config 4: 409 MB each)."""
+        every = list(range(C)) if C <= 10 else sorted({0, C - 1})
+        want_sum = np.zeros((n, L), dtype=np.uint64) if (check_partial and len(every) == C and C) else None
+        for c in every:
+            want = want_ct.get(c)
+            if want is None:
+                want = orc.encrypt(KEY, 0, mine[c], "double", J, b, host_pts[mine[c]])
+                if c in (0, C - 1):
+                    want_ct[c] = want
+            if not np.array_equal(ops.read(rnd.ct[c], n * L).reshape(n, L), want):
                 return False
+            if want_sum is not None:
+                want_sum = orc.aggregate_elem([want_sum, want], b)
+        if want_sum is not None and not np.array_equal(ops.read((rnd.partial, 0), n * L).reshape(n, L), want_sum):
+            return False
         return True
 
-    def parity_ok(res):
+    def parity_ok(res, check_partial=False):
         got = ops.read((res, 0), n * L).reshape(n, L)
-        good = np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi)) and ciphertext_ok()
+        good = np.array_equal(got[:, 0], lo) and (L == 1 or np.array_equal(got[:, 1], hi)) and ciphertext_ok(check_partial and world == 1)
         return ops.allreduce(1.0 if good else 0.0, 1) > 0.5          # every rank must agree on the schedule used
 
     cus = eng.cu_count
@@ -670,8 +749,9 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
                        "exchange": (("ncclAllReduce(uint64, sum) + mask" if args.collective == "allreduce" else
                                      "grouped ncclSend / ncclRecv all-to-all + local mod-add + ncclAllGather") if ops.comm else None),
                        "rccl_world": rccl_world, "ranks_counted_by_allreduce": ranks_counted, "ranks_parity_ok": bool(parity_all_ranks),
-                       "parity": "bit-exact (on every rank, checked in-run before timing: decrypted aggregate == plaintext sum, and the first and "
-                                 "last local client's ciphertext == the oracle's encrypt)"},
+                       "parity": "bit-exact (on every rank, checked in-run before timing: decrypted aggregate == plaintext sum, "
+                                 + ("EVERY local client's ciphertext" if C <= 10 else "the first and last local client's ciphertext")
+                                 + " == the oracle's encrypt" + (", the local aggregate == the oracle's reduce of them)" if world == 1 and C <= 10 else ")")},
             "roofline": {"kernel": kernel_name, "kernel_key": kernel_key, "bound": "lds" if L == 2 or 128 // b <= 4 else "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "frac_hbm": achieved / HBM_PEAK_GBPS, "frac_lds": frac_lds,
@@ -700,7 +780,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
     # happens in the optional schedules afterwards (exception, disagreement, a hang until the deadline), rank 0 still prints it.
     seq = ("sequential", 0, Qbox["Q"])
     configure(seq)
-    if not parity_ok(run_schedule("sequential", 0)):
+    if not parity_ok(run_schedule("sequential", 0), check_partial=True):
         raise SystemExit(f"rank {rank}: PARITY FAILURE: decrypted aggregate != plaintext sum, or ciphertext != oracle")
     want_explicit = args.schedule in ("fused", "pipelined")
     seq_elapsed = seq_line = None
@@ -834,7 +914,7 @@ def bench_dense(args, cfg, n, ops, rank, world, out, wd, state):
             # the OTHER form of the same round beside `value` (parity first; measured outside the timed region)
             other = not partial
             res = rnd.run(0, pts, 1, partial_agg=other)
-            if not parity_ok(res):
+            if not parity_ok(res, check_partial=True):
                 raise SystemExit("PARITY FAILURE: " + ("partial-agg" if other else "two-launch") + " round")
             for it in range(12):
                 rnd.run(it, pts, 1, partial_agg=other)
@@ -1110,6 +1190,12 @@ def bench_precompute(args, n, ops, rank, world, out):
         if split:
             eng.record(ev[k][3])
 
+    def poison():
+        """Nothing a form of the round skipped may inherit a previous form's correct bytes: every output buffer is overwritten first."""
+        for buf, pat in [(dec, 0x3C), (agg, 0xA5), (dmask, 0x69)] + [(c_, 0x5A) for c_ in cts] + [(m_, 0x96) for m_ in masks]:
+            eng.memset_dev(buf, pat, buf.nbytes)
+
+    poison()
     step(0)
     got = dec.download(np.uint64, n * L).reshape(n, L)
     lo, hi = sum_mod(host_pts, n, b)
@@ -1121,9 +1207,12 @@ def bench_precompute(args, n, ops, rank, world, out):
     split_ms = None
     if fused_online:
         fused_online = False
+        poison()
         step(0)
         got2 = dec.download(np.uint64, n * L).reshape(n, L)
         assert np.array_equal(got2, got), "PARITY FAILURE (split online half)"
+        for c in (0, C // 2, C - 1):
+            assert np.array_equal(cts[c].download(np.uint64, n * L).reshape(n, L), orc.encrypt(KEY, 0, c, "double", J, b, host_pts[c])), f"PARITY FAILURE client {c} (split online half)"
         settle(ops, step)
         for it in range(max(W, 3)):
             step(it)
@@ -1230,7 +1319,8 @@ def bench_compact(args, n, ops, rank, world, out):
     other_ms = None
     for use_partial in ([not partial, partial]):              # the other form first (parity-gated, timed outside the reported region)
         form["partial"] = use_partial
-        dec.upload(np.zeros(4, dtype=np.uint32))
+        for buf, pat in [(dec, 0x3C), (agg, 0xA5)] + [(c_, 0x5A) for c_ in cts]:      # nothing a form skipped may inherit the other form's bytes
+            eng.memset_dev(buf, pat, buf.nbytes)
         step(0)
         assert np.array_equal(dec.download(np.uint32, n).astype(np.uint64), lo), "PARITY FAILURE (round trip)"
         for c in (0, C - 1):
@@ -1385,7 +1475,8 @@ def bench_sparse(args, total, ops, rank, world, out):
         want[:, L - 1] &= np.uint64((1 << (b % 64)) - 1)
     del held, rest, new
     for st in ([step_fused, step_separate] if fused_ok else [step_separate]):
-        d_dec.upload(np.zeros(16, dtype=np.uint64))
+        for buf, pat in [(d_dec, 0x3C), (d_agg, 0xA5)] + [(c_, 0x5A) for c_ in d_ct]:  # nothing a schedule skipped may inherit the other one's bytes
+            eng.memset_dev(buf, pat, buf.nbytes)
         st(0)
         # parity: the decrypted dense vector == sum over clients of (value at its locations, zero elsewhere)
         got = d_dec.download(np.uint64, total * L).reshape(total, L)

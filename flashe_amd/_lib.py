@@ -55,6 +55,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "flashe_abi_version": (c_int, []),
     "flashe_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "flashe_device_peer_access": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
     "flashe_limbs": (c_int, [c_int]),
     "flashe_ctx_create": (c_int, [ctypes.POINTER(c_vp), c_u8p, c_int, c_int, c_vp]),
     "flashe_ctx_destroy": (c_int, [c_vp]),
@@ -198,6 +199,7 @@ _SIGNATURES = {
     "flashe_rccl_allreduce_modadd_u64": (c_int, [c_vp, c_vp, c_vp, c_u64]),
     "flashe_rccl_allreduce_f64": (c_int, [c_vp, c_vp, ctypes.POINTER(ctypes.c_double), c_int]),
     "flashe_rccl_barrier": (c_int, [c_vp, c_vp]),
+    "flashe_rccl_version": (c_int, [ctypes.POINTER(c_int)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -249,6 +249,20 @@ int flashe_device_count(int *count)
     return FLASHE_OK;
 }
 
+int flashe_device_peer_access(int device, int peer, int *can_access)
+{
+    if (!can_access) return FLASHE_EINVAL;
+    *can_access = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return FLASHE_ENODEV;
+    if (device < 0 || peer < 0 || device >= n || peer >= n) return FLASHE_EINVAL;
+    if (device == peer) { *can_access = 1; return FLASHE_OK; }
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess) { (void)hipGetLastError(); return FLASHE_EIO; }
+    *can_access = can ? 1 : 0;
+    return FLASHE_OK;
+}
+
 int flashe_limbs(int int_bits) { return int_bits < 1 || int_bits > 128 ? 0 : (int_bits > 64 ? 2 : 1); }
 
 int flashe_ctx_create(flashe_ctx **out, const uint8_t key[32], int int_bits, int device, void *stream)

@@ -39,6 +39,7 @@ struct RcclApi {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;          // optional
+    decltype(&ncclGetVersion) GetVersion = nullptr;        // optional
 };
 
 RcclApi &rccl()
@@ -68,6 +69,7 @@ RcclApi &rccl()
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
         if (!ok) { dlclose(api.handle); api.handle = nullptr; return; }
         api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.handle, "ncclCommCount"));
+        api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(api.handle, "ncclGetVersion"));
     });
     return api;
 }
@@ -128,6 +130,16 @@ int flashe_rccl_destroy(flashe_comm *comm)
     if (comm->scratch_dev) (void)hipFree(comm->scratch_dev);
     if (comm->comm) (void)rccl().CommDestroy(comm->comm);
     delete comm;
+    return FLASHE_OK;
+}
+
+int flashe_rccl_version(int *version)
+{
+    if (!version) return FLASHE_EINVAL;
+    *version = 0;
+    RcclApi &api = rccl();
+    if (!api.handle) return fail(nullptr, FLASHE_ENODEV, "librccl.so could not be loaded: %s", api.error.c_str());
+    if (!api.GetVersion || api.GetVersion(version) != ncclSuccess) return fail(nullptr, FLASHE_EIO, "ncclGetVersion failed");
     return FLASHE_OK;
 }
 

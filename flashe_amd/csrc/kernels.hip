@@ -1133,6 +1133,9 @@ static bool fixed32_width(int b)
     default: return false;
     }
 }
+#ifndef FLASHE_SMALL_FAST32
+#define FLASHE_SMALL_FAST32 1   // whole tiles of the compile-time-width compact kernels in a loop of their own (small_chain_fast32; 0: the general loop, for A/B builds)
+#endif
 template <int M> struct DirectPt { uint32_t v[M]; };
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -1227,6 +1230,78 @@ __device__ __forceinline__ void direct32_put(uint32_t *__restrict__ q, const uin
         t += 2;
     }
     if (t < M) q[t] = r[t] & mask;
+}
+
+// Round 6: the chain of a tile whose TWO blocks per lane both take the direct path (whole blocks inside the range: all but the chunk
+// ends) as a loop of its own.  What it drops from the general loop, per stream and block: the selects on `single` (a launch-wide
+// flag: fourteen v_cndmask per block at m = 6 -- here a template parameter), the second slot extraction of every stream (a stream is
+// client c's minus term AND client c + 1's add term: its slots stay in registers for the next step instead of being shifted out of
+// the 128-bit word twice), the per-step tests of the two tile kinds; and the stream's prefix is requested one step ahead (its LDS
+// round trip used to stand between a wave and the first lookups of every step).  The running sum of a block's outputs is kept
+// UNMASKED (it is masked when it is stored: sums mod 2^32 agree with sums mod 2^B).  m = 6: 30 slot instructions per block and stream
+// instead of 52.  In-process A/B (ab_compact_libs.py, AB_SUM=1, ten 1e7-element clients): int_bits 20 0.283-0.296 -> 0.274-0.280 ms,
+// 16: 0.2234 -> 0.2156, 23 / 24 / 32: within 1 %.  Measured and dropped (tests/perf/experiments/r06_small_chain_fast32_pipelined.patch):
+// the streams software-pipelined against each other (the next stream's first lookups issued before this stream's outputs): 0.2769
+// against 0.2740 at int_bits 20, 127 VGPRs -- what is left between two steps is not what holds these kernels back.
+template <int B, bool SINGLE>
+__device__ __forceinline__ void small_chain_fast32(const RoundKeys &rk, const LaneRegs lr, const uint32_t *pre_lds, int sbase, int n_streams,
+                                                   const uint64_t *const *in_tab, uint64_t *const *out_tab, const CtrVar &xA, const CtrVar &xB,
+                                                   uint64_t kA, uint64_t kB, uint32_t *sum32, bool prio)
+{
+    constexpr int M = 128 / B;
+    constexpr uint32_t mask = B >= 32 ? 0xffffffffu : ((1u << (B & 31)) - 1u);
+    uint32_t psA[M], psB[M], accA[M], accB[M];
+#pragma unroll
+    for (int t = 0; t < M; t++) { psA[t] = 0u; psB[t] = 0u; accA[t] = 0u; accB[t] = 0u; }
+    auto prefix_of = [&](const uint4 &v) {
+        return CtrPrefix{{static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v.x)), static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v.y)),
+                          static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v.z)), static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(v.w))}};
+    };
+    uint4 pv = *reinterpret_cast<const uint4 *>(pre_lds + 4 * sbase);
+    // the outputs of the stream whose blocks are SA / SB (it completes output `link`), and its slots kept for the next step
+    auto emit = [&](int link, const u128 SA, const u128 SB, const DirectPt<M> &dA, const DirectPt<M> &dB) {
+        uint32_t csA[M], csB[M];
+#pragma unroll
+        for (int t = 0; t < M; t++) {                            // (constant shifts: one v_alignbit / shift each)
+            csA[t] = static_cast<uint32_t>(SA >> (B * t));
+            csB[t] = static_cast<uint32_t>(SB >> (B * t));
+        }
+        if (link >= 0) {
+            uint32_t rA[M], rB[M];
+#pragma unroll
+            for (int t = 0; t < M; t++) {
+                const uint32_t ua = dA.v[t] + (SINGLE ? csA[t] : psA[t] - csA[t]), ub = dB.v[t] + (SINGLE ? csB[t] : psB[t] - csB[t]);
+                accA[t] += ua; accB[t] += ub;
+                rA[t] = ua; rB[t] = ub;
+            }
+            uint32_t *out = reinterpret_cast<uint32_t *>(out_tab[link]);
+            direct32_put<M>(out + kA, rA, mask);
+            direct32_put<M>(out + kB, rB, mask);
+        }
+#pragma unroll
+        for (int t = 0; t < M; t++) { psA[t] = csA[t]; psB[t] = csB[t]; }
+    };
+    for (int c = 0; c < n_streams; c++) {
+        const CtrPrefix pre = prefix_of(pv);
+        // the next stream's prefix: on its way under this stream's rounds (the last step re-reads its own)
+        pv = *reinterpret_cast<const uint4 *>(pre_lds + 4 * (sbase + (c + 1 < n_streams ? c + 1 : c)));
+        const int link = SINGLE ? c : c - 1;
+        DirectPt<M> dA{}, dB{};
+        if (link >= 0) {
+            const uint32_t *in = reinterpret_cast<const uint32_t *>(in_tab[link]);
+            dA = direct32_load<M>(in, kA);
+            dB = direct32_load<M>(in, kB);
+        }
+        uint32_t s[2][4];
+        ctr_round1(pre, xA, s[0]);
+        ctr_round1(pre, xB, s[1]);
+        aes256_rounds<2, 2>(rk, lr, s, prio);
+        emit(link, words_to_u128(s[0]), words_to_u128(s[1]), dA, dB);
+    }
+    if (sum32) {
+        direct32_put<M>(sum32 + kA, accA, mask);
+        direct32_put<M>(sum32 + kB, accB, mask);
+    }
 }
 
 // per b-bit slot (prev - cur) mod 2^b of two 128-bit words (SWAR: borrows must not cross slots); b == 64: the slots are the two
@@ -1341,6 +1416,15 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
 #pragma unroll
         for (int t = 0; t < MB; t++) { accA[t] = 0u; accB[t] = 0u; }
         uint32_t *const sum32 = B != 0 && B != 64 ? reinterpret_cast<uint32_t *>(tb.sum_out[cur]) : nullptr;
+#if FLASHE_SMALL_FAST32
+        if constexpr (PAIR && B != 0 && B != 64) {
+            if (fastA && fastB) {                                  // (wave-uniform) both blocks of every lane whole and inside the range
+                if (single) small_chain_fast32<B, true>(rk, lr, pre_lds, sbase, n_streams, tb.in + link0, tb.out + link0, xA, xB, j0A - first, j0B - first, sum32, p.swp_prio != 0);
+                else small_chain_fast32<B, false>(rk, lr, pre_lds, sbase, n_streams, tb.in + link0, tb.out + link0, xA, xB, j0A - first, j0B - first, sum32, p.swp_prio != 0);
+                continue;
+            }
+        }
+#endif
         if (PAIR) {
             // two blocks per lane on the same prefix, one stream per step
             for (int c = 0; c < n_streams; c++) {
@@ -2359,9 +2443,15 @@ static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n
         p.no_direct = 1;                      // the 16-byte direct accesses of m <= 4 assume 8-byte elements: b = 32 walks its rows like b < 32
     }
     // rising wave priority inside the rounds of a block pair (device_common.h), where it was measured to pay: the direct output paths
-    // (one-limb layout at m <= 4: -5 ... -7 %; compact layout at the compiled-in widths: 23 / 24 / 32 -8 %, 16 -2 %) -- not int_bits 20
-    // compact (+1.5 %) and not the staged walk of the one-limb layout at m >= 5 (+15 %)
-    p.swp_prio = env.elem32 ? (!p.no_fixed_width && fixed32_width(env.b) && env.b != 20) : (p.m <= 4 && !p.no_direct);
+    // (one-limb layout at m <= 4: -5 ... -7 %; compact layout at the compiled-in widths: 23 / 24 / 32 -8 %, 16 -2 %) -- not the long
+    // chains of int_bits 20 compact (ten encrypts + their sum: +5 % in round 6's loop, +1.5 % in round 5's; the decrypt of ONE vector,
+    // a chain of two streams: -9 %, 0.0616 -> 0.0562 ms) and not the staged walk of the one-limb layout at m >= 5 (+15 %)
+    int longest = 0;
+    for (int i = 0; i < n_chains; i++) longest = std::max(longest, chains[i].n_out);
+#ifndef FLASHE_PRIO_B20
+#define FLASHE_PRIO_B20 0      // (A/B builds: the rising wave priority at int_bits 20 in the compact layout whatever the chain length)
+#endif
+    p.swp_prio = env.elem32 ? (!p.no_fixed_width && fixed32_width(env.b) && (FLASHE_PRIO_B20 || env.b != 20 || longest <= 1)) : (p.m <= 4 && !p.no_direct);
     { static const int v = FLASHE_TUNE_ENV("FLASHE_SMALL_PRIO") ? atoi(FLASHE_TUNE_ENV("FLASHE_SMALL_PRIO")) : -1; if (v >= 0) p.swp_prio = v; }
     struct Piece { const PrfChain *ch; int l0, l1; uint64_t blk_first, blk_count; };
     std::vector<Piece> pieces;

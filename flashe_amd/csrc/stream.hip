@@ -986,6 +986,14 @@ struct SpanPrfEntry {
 // the previous iteration: six rounds earlier), the atomics of span i at the end of its rounds (the accumulators were emptied six rounds
 // earlier) -- so a wait almost never blocks, waves drift up to half a span apart, and one wave's atomics, table reads and loop head run
 // under the other waves' rounds.  The counters only grow (sixteen arrivals per phase and span).
+//
+// The protocol leans on two properties of the gfx9 LDS that the C++ memory model does not give: a wave's LDS operations complete in
+// issue order (the arrival that lane 0 issues is behind the other 63 lanes' atomics and stores of the same instruction stream), and
+// what follows the poll that saw the count cannot be older than it.  This library is built for gfx950 alone; another target must
+// not compile these helpers silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "span_prf_kernel's split-phase LDS counters assume the in-order LDS of gfx9 (built for gfx950): port phase_arrive / phase_wait first"
+#endif
 #ifndef FLASHE_SPAN_PRIO
 #define FLASHE_SPAN_PRIO 1       // waves yield as they advance through the rounds of a span (0 = off, 2 = rising: +5.6 %; for A/B builds)
 #endif
@@ -1029,6 +1037,8 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
     constexpr int SPAN = kSpanFused, THREADS = kPrfThreads, PER = (SPAN + THREADS - 1) / THREADS, WAVES = THREADS / 64;
     const uint32_t iter = iter0 + te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
+    // the accumulators, low limbs in [0, SPAN), high limbs in [SPAN, 2 SPAN): with the limbs in planes of their own the two 64-bit
+    // atomics of an entry spread over twice as many banks as with 16-byte slots (round 6, in-process A/B: both passes -2 %)
     __shared__ __attribute__((aligned(16))) unsigned long long acc[2 * SPAN];
     // (prefix, begin) per client of the span in flight and of the NEXT one: entry f of a span belongs to the client c with
     // pb[c].x <= f < pb[c + 1].x and is entry pb[c].y + (f - pb[c].x) of that client's list; pb[C].x = entries in the span
@@ -1111,10 +1121,10 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         if (r >= span_len) { *err_flag = 1; return; }            // a list that is not strictly increasing or reaches beyond the vector
         const unsigned long long wlo = static_cast<unsigned long long>(w), whi = static_cast<unsigned long long>(w >> 64);
 #ifdef FLASHE_TUNING
-        if (probe == 3) { if (wlo == 0x1234567ull) acc[2 * r] = whi; return; }
+        if (probe == 3) { if (wlo == 0x1234567ull) acc[r] = whi; return; }
 #endif
-        const unsigned long long old = atomicAdd(&acc[2 * r], wlo);
-        atomicAdd(&acc[2 * r + 1], whi + (old + wlo < old ? 1ull : 0ull));
+        const unsigned long long old = atomicAdd(&acc[r], wlo);
+        atomicAdd(&acc[SPAN + r], whi + (old + wlo < old ? 1ull : 0ull));
     };
     // The last five round keys live in VGPRs: sixty key words + the kernel's pointers do not fit the SGPR file, and what the compiler
     // spills it re-reads with v_readlane inside the rounds (VALU issue is what bounds them)
@@ -1152,11 +1162,13 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         phase_wait(&s_phase[0], WAVES * done, seen);                       // every wave's entries of the previous span are in
         // ... which also says that every wave is through with the PREVIOUS iteration, where the table of the span now in flight was
         // searched for this iteration's entries: the keeper may put the table of the span after next in its place
-        if (keeper && early) { SPAN_PRF_PUBLISH(buf); SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride)); }
+        // (the loads of the slices three spans ahead are issued BEHIND the write-out, see from_load's call sites: the write-out waits for
+        // everything the wave has in flight, and every wave waits for the keeper's share of the accumulators at the end of its rounds)
+        if (keeper && early) SPAN_PRF_PUBLISH(buf);
 #pragma unroll
         for (int e = 0; e < PER; e++) {
             const uint32_t r = min(static_cast<uint32_t>(tid + e * THREADS), static_cast<uint32_t>(SPAN - 1));
-            wa[e] = (static_cast<u128>(acc[2 * r + 1]) << 64) | acc[2 * r];
+            wa[e] = (static_cast<u128>(acc[SPAN + r]) << 64) | acc[r];
         }
     };
     auto wout_store = [&]() {
@@ -1164,7 +1176,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         for (int e = 0; e < PER; e++) {
             const uint32_t r = tid + e * THREADS;
             if (r < wlen) {
-                acc[2 * r] = 0; acc[2 * r + 1] = 0;
+                acc[r] = 0; acc[SPAN + r] = 0;
 #ifdef FLASHE_TUNING
                 if (probe == 4 && static_cast<uint64_t>(wa[e]) != 0x1234567ull) continue;      // 4 = no dense read / write
 #endif
@@ -1258,7 +1270,10 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                     __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0)
                     wout_store();
                 }
-                if (r == 7) from_load(p0, span_len);
+                if (r == 7) {
+                    from_load(p0, span_len);
+                    if (keeper && early) SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride));
+                }
                 else if (r == 12) seen_out = phase_peek(&s_phase[1]);
                 k = r < 13 ? issue_main(lr, s) : issue_final(lr, s);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1273,6 +1288,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
             __builtin_amdgcn_s_waitcnt(0x0f70);
             wout_store();
             from_load(p0, span_len);
+            if (keeper && early) SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride));
             seen_out = phase_peek(&s_phase[1]);
         }
         SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14 (+ everything threaded through them)

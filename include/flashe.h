@@ -60,10 +60,15 @@ typedef struct flashe_ctx flashe_ctx;
  *   3  round 5: flashe_ctx_compact_layout (does this ctx run the *_u32_dev entry points?); the double-mask encrypt entry points
  *      refuse idx = 2^32 - 1 with FLASHE_EINVAL (the reference's OverflowError, jzf_flashe.py:352-353) instead of wrapping to
  *      prefix 0; flashe_prepared_discard releases the cached mask buffers; flashe_combine_batch_sum_dev (online encrypts with
- *      precomputed masks + their sum in one pass); flashe_encrypt_batch_sum_u32_dev (the compact layout's encrypts + their sum) */
-#define FLASHE_ABI_VERSION 3
+ *      precomputed masks + their sum in one pass); flashe_encrypt_batch_sum_u32_dev (the compact layout's encrypts + their sum)
+ *   4  round 6: flashe_device_peer_access and flashe_rccl_version (the preflight a rank of a multi-GPU launch runs before it creates
+ *      its ctx) */
+#define FLASHE_ABI_VERSION 4
 int flashe_abi_version(void);
 int flashe_device_count(int *count);
+/* Preflight of a multi-GPU launch (new): can `device` read and write `peer`'s memory directly (hipDeviceCanAccessPeer: what RCCL's
+ * point-to-point transport over xGMI needs)?  *can_access = 1 / 0; device == peer gives 1.  Creates no ctx and no stream. */
+int flashe_device_peer_access(int device, int peer, int *can_access);
 int flashe_limbs(int int_bits);                 /* 1 or 2; 0 if int_bits is out of range */
 
 /* ---- context ---------------------------------------------------------------------- */
@@ -649,6 +654,9 @@ int flashe_rccl_init(flashe_ctx *ctx, const uint8_t id[FLASHE_RCCL_ID_BYTES], in
 int flashe_rccl_destroy(flashe_comm *comm);
 int flashe_rccl_rank(const flashe_comm *comm);
 int flashe_rccl_world(const flashe_comm *comm);          /* as RCCL itself reports it (ncclCommCount) */
+/* ncclGetVersion of the librccl.so this library loads (e.g. 22703), without creating a communicator: part of the preflight of a
+ * multi-GPU launch.  FLASHE_ENODEV when librccl.so cannot be loaded. */
+int flashe_rccl_version(int *version);
 /* Piece p (bytes long, at send_dev + p * send_stride) goes to rank p; the piece from rank p lands at recv_dev + p * recv_stride.
  * Grouped ncclSend / ncclRecv: on xGMI every GPU pair has its own link, so the W - 1 transfers run concurrently. */
 int flashe_rccl_all_to_all(flashe_ctx *ctx, flashe_comm *comm, const void *send_dev, size_t send_stride,

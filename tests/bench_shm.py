@@ -5,7 +5,8 @@ every rank.  The printed figure is meaningless and labelled so.
 
 BENCH_SHM_INJECT=raise:R | hang:R makes rank R raise / block forever inside the first overlapped (fused) round -- what a first
 multi-GPU run may meet -- so that the tests can check the fallback: a valid sequential line within the deadline, exit code 0.
-raise_elements:R | hang_elements:R do the same inside the element-sharded phase that follows the main line."""
+raise_elements:R | hang_elements:R do the same inside the element-sharded phase that follows the main line.
+BENCH_SHM_DEVICES=N: the preflight of every rank sees N visible devices (needs no GPU: it fails before an engine exists)."""
 import os
 import sys
 import time
@@ -33,7 +34,9 @@ def main():
                 ShardedRound.run_elements = broken
             else:
                 ShardedRound.run_fused = broken
-    bench.main(comm_factory=lambda rank, world: ShmComm(rank, world, os.environ["BENCH_SHM_DIR"]), device_override=0)
+    fake = os.environ.get("BENCH_SHM_DEVICES")                     # the preflight's view of the machine: "2 devices visible" with 3 ranks
+    bench.main(comm_factory=lambda rank, world: ShmComm(rank, world, os.environ["BENCH_SHM_DIR"]), device_override=0,
+               devices_override=int(fake) if fake else None)
 
 
 if __name__ == "__main__":

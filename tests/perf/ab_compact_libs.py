@@ -2,7 +2,8 @@
 """The compact-layout round (int_bits <= 32, uint32 vectors: ten 1e7-element clients, chained encrypt + reduce fused with the decrypt)
 under several BUILDS of the library alternated inside one process; the builds' ciphertexts and results are compared byte for byte and
 client 3's ciphertext with the oracle.
-usage: ab_compact_libs.py <.so in flashe_amd/> <.so> [...]     bits from AB_BITS (default "20 23 16"), AB_LAYOUT=u64 for the one-limb layout"""
+usage: ab_compact_libs.py <.so in flashe_amd/> <.so> [...]     bits from AB_BITS (default "20 23 16"), AB_LAYOUT=u64 for the one-limb layout,
+       AB_SUM=1: the encrypt launch also writes the sum of its ciphertexts and the second launch decrypts that one vector"""
 import os
 import sys
 
@@ -44,6 +45,10 @@ for b in [int(v) for v in os.environ.get("AB_BITS", "20 23 16").split()]:
             out = eng.alloc(4 * n)
             enc = lambda eng=eng, pt=pt, ct=ct: eng.encrypt_batch_u32_dev(0, idx, SCHEME_DOUBLE, n, J, pt, ct)              # noqa: E731
             dec = lambda eng=eng, ct=ct, out=out: eng.aggregate_decrypt_u32_dev(0, [C], [0], n, J, 0, n, ct, None, out, 4)  # noqa: E731
+            if os.environ.get("AB_SUM"):          # what bench.py --layout u32 times: the encrypts + their sum, then the decrypt of that vector
+                ds = eng.alloc(4 * n)
+                enc = lambda eng=eng, pt=pt, ct=ct, ds=ds: eng.encrypt_batch_sum_u32_dev(0, idx, SCHEME_DOUBLE, n, J, pt, ct, ds)          # noqa: E731
+                dec = lambda eng=eng, ds=ds, out=out: eng.aggregate_decrypt_u32_dev(0, [C], [0], n, J, 0, n, [ds], None, out, 4)           # noqa: E731
             dt = np.uint32
         enc(); dec(); eng.sync()
         outs[name] = (ct[3].download(dt, n), ct[C - 1].download(dt, n), out.download(dt, n))

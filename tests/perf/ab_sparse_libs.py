@@ -16,9 +16,18 @@ from flashe_amd import _lib  # noqa: E402
 from flashe_amd.engine import Engine  # noqa: E402
 
 
+_ALL_SIGNATURES = dict(_lib._SIGNATURES)
+
+
 def engine_from(name, b):
+    import ctypes
     _lib._lib = None
     _lib.LIB_PATH = os.path.join(ROOT, "flashe_amd", name)
+    # (a build kept from an earlier round lacks the entry points added since: bind what it has -- this tool only, the package itself
+    # insists on every symbol of the header)
+    probe = ctypes.CDLL(_lib.LIB_PATH)
+    _lib._SIGNATURES.clear()
+    _lib._SIGNATURES.update({k: v for k, v in _ALL_SIGNATURES.items() if hasattr(probe, k)})
     return Engine(bytes(range(32)), b)
 
 

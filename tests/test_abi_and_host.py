@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/flashe.h but not exported"
     assert sorted(_lib.EXPORTED_SYMBOLS) == names
-    assert lib.flashe_abi_version() == 3
+    assert lib.flashe_abi_version() == 4
     assert [lib.flashe_limbs(b) for b in (0, 1, 64, 65, 128, 129)] == [0, 1, 1, 2, 2, 0]
 
 

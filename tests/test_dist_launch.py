@@ -136,3 +136,44 @@ else:
     open(name, "w").close()
     r = subprocess.run([sys.executable, "-c", code, "squat"], capture_output=True, text=True, timeout=60, env=env2)
     assert r.returncode == 0 and "DIR None" in r.stdout and "FIRED" in r.stdout and "foreign file" in r.stdout, r.stdout + r.stderr[-800:]
+
+
+def _bench_lines(cmd, tmp_path, env_extra=None, timeout=120):
+    import json
+    env = dict(os.environ, FLASHE_RDZV_DIR=str(tmp_path), BENCH_SHM_DIR=str(tmp_path))
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    return r, [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+
+
+def test_bench_preflight_refuses_a_machine_with_too_few_devices(tmp_path):
+    """`bench.py --gpus N` on a machine that cannot carry N ranks must fail LEGIBLY -- every rank runs the preflight
+    before it creates an engine (device count >= WORLD_SIZE, LOCAL_RANK in range, peer access, RCCL), the first failure raises the
+    abort flag, rank 0 prints ONE JSON line {"value": null, "error": "preflight: ..."} with what it established in `config`, and every
+    rank leaves non-zero.  Through the comm double with an injected count ("2 devices, world 3"), and bare on this box (no device)."""
+    r, lines = _bench_lines([os.path.join(ROOT, "tests", "bench_shm.py"), "--gpus", "3", "--n", "1000", "--steps", "1", "--warmup", "0"],
+                            tmp_path, {"BENCH_SHM_DEVICES": "2"})
+    assert r.returncode != 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout[-1000:] + r.stderr[-2000:]
+    d = lines[0]
+    assert d["value"] is None and d["error"] == "preflight: 2 devices visible, 3 ranks requested" and d["n_gpus"] == 3
+    cfg = d["config"]
+    assert cfg["devices_visible"] == 2 and cfg["library"] == "libflashe_hip.so" and len(cfg["library_sha256_16"]) == 16
+    assert "Traceback" not in r.stdout
+
+
+def test_bench_preflight_line_on_a_box_without_devices(tmp_path):
+    """The real launch path (bench.py --gpus 2 spawning its ranks, no double): wherever fewer devices are visible than ranks were
+    asked for, the outcome is the preflight line, not a traceback from rank k.  Skipped where two devices exist."""
+    import ctypes
+    from flashe_amd import _lib
+    n = ctypes.c_int(0)
+    _lib.load().flashe_device_count(ctypes.byref(n))
+    if n.value >= 2:
+        import pytest
+        pytest.skip("two devices visible: the launch would run")
+    r, lines = _bench_lines([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--n", "1000", "--steps", "1", "--warmup", "0"], tmp_path)
+    assert r.returncode != 0 and len(lines) == 1, r.stdout[-1000:] + r.stderr[-2000:]
+    d = lines[0]
+    assert d["value"] is None and d["error"] == f"preflight: {n.value} devices visible, 2 ranks requested", d
+    assert d["config"]["devices_visible"] == n.value and d["config"]["abi_version"] == 4

@@ -230,6 +230,10 @@ def test_bench_lines_on_one_gpu(args, keys):
     rl = d["roofline"]
     assert rl["bound"] in ("hbm", "lds", "mfma") and rl["peak"] == 8000.0 and rl["unit"] == "GB/s" and abs(rl["frac"] - rl["achieved"] / rl["peak"]) < 1e-9
     assert "bit-exact" in d["config"]["parity"]
+    # every line names the library file that produced it and the machine the preflight saw (one rank: no peers; RCCL only with --force-dist)
+    cfg = d["config"]
+    assert cfg["library"] == "libflashe_hip.so" and len(cfg["library_sha256_16"]) == 16 and cfg["devices_visible"] >= 1
+    assert (cfg["rccl_version"] is not None) == ("--force-dist" in args)
     for k in keys:
         assert k in d, k
     if args[:4] == ["--config", "2", "--n", "2300017"] and "--schedule" not in args:

@@ -718,6 +718,13 @@ def test_bench_multi_rank_flow(extra, tmp_path):
     assert sc["ranks_counted_by_allreduce_is_n"] is True and sc["ranks_parity_ok"] is True and isinstance(sc["rccl_world_is_n"], bool)
     r_ = sc["measured_over_predicted"]
     assert r_["schedule_that_ran_over_sequential_model"] > 0 and r_["element_sharded_over_model"] > 0 and r_["element_sharded_no_gather_over_model"] > 0
+    # the line certifies what produced it: the preflight's view of the machine and the library file's hash
+    import hashlib
+    from flashe_amd import _lib
+    cfg = d["config"]
+    assert cfg["devices_visible"] >= 1 and cfg["library"] == os.path.basename(_lib.LIB_PATH) and cfg["abi_version"] == 4
+    assert cfg["library_sha256_16"] == hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    assert cfg["peer_access_ok"] is None and cfg["rccl_version"] is None        # (the comm double: several ranks on one device, no RCCL)
 
 
 def test_bench_multi_rank_allreduce_exchange(tmp_path):
@@ -1295,6 +1302,59 @@ def test_config2_full_size_round(E, oracle):
     assert np.array_equal(got, want)
 
 
+def test_config2_full_size_timed_schedule(E, oracle):
+    """The schedule bench.py TIMES by default ('partial-agg') at BASELINE config 2's full size: flashe_encrypt_batch_sum_dev (ten
+    encrypts as one chain + the running sum of their ciphertexts, prf_chain_kernel<1024, SUM>) at n = 1e7, b = 128, C = 10 -- ALL ten
+    ciphertexts against the oracle's encrypt (jzf_flashe.py:456-488), the sum against the oracle's element-wise reduce of them
+    (jzf_aggregator.py:424-430), then the decrypt of that one vector against the plaintext sum (jzf_flashe.py:537-594)."""
+    n, C, b, it = 10_000_000, 10, 128, 5
+    eng = make(E, b)
+    pts = [np.random.Generator(np.random.PCG64(1000 + c)).integers(0, 2 ** 64, n, dtype=np.uint64) for c in range(C)]
+    dpt = [eng.upload(p) for p in pts]
+    dct = [eng.alloc_vec(n) for _ in range(C)]
+    dsum, dout = eng.alloc_vec(n), eng.alloc_vec(n)
+    for d, pat in [(dsum, 0xA5), (dout, 0x3C)] + [(d, 0x5A) for d in dct]:       # nothing a skipped tile could inherit
+        eng._check(eng._lib.flashe_memset_dev(eng._h, d.ptr, pat, d.nbytes))
+    eng.encrypt_batch_sum_dev(it, list(range(C)), E.SCHEME_DOUBLE, n, 16, dpt, 1, dct, dsum)
+    eng.decrypt_dev(it, [C], [0], n, 16, dsum, dout)
+    want_sum = np.zeros((n, 2), dtype=np.uint64)
+    for c in range(C):
+        want = oracle.encrypt(KEY, it, c, "double", 16, b, pts[c])
+        assert np.array_equal(dct[c].download(np.uint64, 2 * n).reshape(n, 2), want), c
+        want_sum = oracle.aggregate_elem([want_sum, want], b)
+    assert np.array_equal(dsum.download(np.uint64, 2 * n).reshape(n, 2), want_sum), "partial aggregate"
+    out = dout.download(np.uint64, 2 * n).reshape(n, 2)
+    lo, hi = _sum_u64(pts)
+    assert np.array_equal(out[:, 0], lo) and np.array_equal(out[:, 1], hi)
+    assert np.array_equal(out, oracle.decrypt(KEY, it, [C], [0], 16, b, want_sum))
+
+
+def test_compact_layout_full_size_timed_schedule(E, oracle):
+    """What `bench.py --bits 20 --layout u32` times: flashe_encrypt_batch_sum_u32_dev at n = 1e7, b = 20 (the width the reference's
+    un-batched jobs ship), C = 10, n_jobs = 16 -- all ten uint32 ciphertexts and their sum against the oracle
+    (jzf_flashe.py:19-45 slot order and chunk-dependent counters, :456-488; jzf_aggregator.py:424-430), then the decrypt of the sum."""
+    n, C, b, it, J = 10_000_000, 10, 20, 9, 16
+    eng = make(E, b)
+    assert eng.compact_supported()
+    pts = [np.random.Generator(np.random.PCG64(1500 + c)).integers(0, 2 ** b, n, dtype=np.uint64) for c in range(C)]
+    d32 = [eng.upload(p.astype(np.uint32)) for p in pts]
+    c32 = [eng.alloc(4 * n + 16) for _ in range(C)]
+    dsum, dout = eng.alloc(4 * n + 16), eng.alloc(4 * n + 16)
+    for d, pat in [(dsum, 0xA5), (dout, 0x3C)] + [(d, 0x5A) for d in c32]:
+        eng._check(eng._lib.flashe_memset_dev(eng._h, d.ptr, pat, d.nbytes))
+    eng.encrypt_batch_sum_u32_dev(it, list(range(C)), E.SCHEME_DOUBLE, n, J, d32, c32, dsum)
+    eng.aggregate_decrypt_u32_dev(it, [C], [0], n, J, 0, n, [dsum], None, dout, 4)
+    mask = np.uint64((1 << b) - 1)
+    wsum = np.zeros(n, dtype=np.uint64)
+    for c in range(C):
+        want = oracle.encrypt(KEY, it, c, "double", J, b, pts[c])[:, 0]
+        bad = np.flatnonzero(c32[c].download(np.uint32, n).astype(np.uint64) != want)
+        assert bad.size == 0, (c, bad[:8])
+        wsum += want
+    assert np.array_equal(dsum.download(np.uint32, n).astype(np.uint64), wsum & mask), "sum of the ciphertexts"
+    assert np.array_equal(dout.download(np.uint32, n).astype(np.uint64), sum(pts) & mask), "round trip"
+
+
 def test_config4_size_round(E, oracle):
     """BASELINE config 4's vector (ResNet-50, n = 25 557 032, b = 128) on one GPU: round trip with a
     dropout, and the range twins reproduce the full-vector decrypt slice by slice (what the sharded
@@ -1786,6 +1846,56 @@ def test_sparse_encrypt_aggregate_in_one_pass(E, oracle, b, C, total, k, pt_limb
             if ks[c]:
                 assert np.array_equal(cts[c].download(np.uint64, ks[c] * L).reshape(ks[c], L), want_ct[c]), (b, C, c, with_bounds, "ciphertext")
         assert np.array_equal(agg.download(np.uint64, total * L).reshape(total, L), want), (b, C, with_bounds, "aggregate")
+
+
+def test_span_prf_crowded_dense_sparse_and_empty_spans(E, oracle):
+    """The span passes with the PRF inside under stress (the barrier-free phase counters; round 6: the per-window round-2
+    table): ~1,500 spans, six per workgroup, whose density changes from span to span -- crowded (more than 1,024 entries: second pass,
+    tables published between barriers), one client holding EVERY position (more than 256 entries of a client per span: entries beyond
+    its second counter window are computed in full), the usual 1 %, empty, and a client whose slice straddles a 256-entry window in
+    almost every span.  Several rounds back to back (a late wave of one launch meets the next launch's tables); every ciphertext, the
+    aggregate and the decrypted vector against the oracle (jzf_flashe.py:316-343, jzf_aggregator.py:150-165, :424-430)."""
+    b, J, C = 128, 16, 6
+    eng = make(E, b)
+    span = eng.sparse_span()
+    n_spans = 6 * 256 + 3
+    total = span * n_spans - 7
+    rng = np.random.Generator(np.random.PCG64(606))
+    mode = np.arange(n_spans) % 5
+    # per (mode, client) density of a span
+    dens = np.array([[0.30, 0.30, 0.25, 0.02, 0.0, 0.01],       # crowded: ~1,450 entries
+                     [0.01, 0.01, 0.01, 0.01, 0.01, 0.01],      # the usual
+                     [0.0, 0.0, 0.0, 0.0, 0.0, 0.0],            # empty
+                     [1.0, 0.01, 0.0, 0.2, 0.0, 0.01],          # one client holds every position of the span, another a fifth
+                     [0.05, 0.0, 0.0, 0.0, 0.6, 0.0]])          # 1,000 entries of one client (four windows), 90 of another
+    p_of_pos = dens[np.repeat(mode, span)[:total]]               # [total, C]
+    locs = [np.flatnonzero(rng.random(total) < p_of_pos[:, c]).astype(np.uint32) for c in range(C)]
+    ks = [int(l.size) for l in locs]
+    assert max(ks) > 300_000 and min(ks) > 10_000
+    idx = [7, 8, 30, 2, 0, 55]
+    zeros = [1 << 31, 5, (1 << 40) + 3, 0, 77, 1 << 20]
+    dl = [eng.upload(l) for l in locs]
+    agg, dec = eng.alloc_vec(total), eng.alloc_vec(total)
+    bnd = eng.span_bounds(total, dl, ks)
+    for it in (3, 4, 5):
+        pts = [rng.integers(0, 2 ** 64, kc, dtype=np.uint64) for kc in ks]
+        dp = [eng.upload(p) for p in pts]
+        cts = [eng.alloc_vec(kc) for kc in ks]
+        for buf in cts + [agg, dec]:
+            eng.memset_dev(buf, 0xd7, buf.nbytes)
+        # two rounds in a row on the same stream: the second launch's prologue overlaps the first one's last spans
+        eng.sparse_encrypt_aggregate_dev(it, idx, dl, ks, dp, 1, zeros, total, J, cts, agg, bounds=bnd)
+        eng.sparse_decrypt_dev(it, dl, ks, total, J, agg, dec, sorted_lists=True, bounds=bnd)
+        want = np.zeros((total, 2), dtype=np.uint64)
+        for c in range(C):
+            want_ct = oracle.encrypt(KEY, it, idx[c], "single", J, b, pts[c])
+            assert np.array_equal(cts[c].download(np.uint64, 2 * ks[c]).reshape(ks[c], 2), want_ct), (it, c, "ciphertext")
+            z = np.array([[zeros[c], 0]], dtype=np.uint64)
+            want = oracle.aggregate_elem([want, oracle.expand_to_dense(total, locs[c], want_ct, z, b)], b)
+        assert np.array_equal(agg.download(np.uint64, 2 * total).reshape(total, 2), want), (it, "aggregate")
+        # the decrypt twin subtracts term(iter, c, q) of client NUMBER c = 0 .. C-1 (the decrypting party's view of the uploads)
+        mask = oracle.sparse_minus_mask(KEY, it, locs, total, J, b)
+        assert np.array_equal(dec.download(np.uint64, 2 * total).reshape(total, 2), oracle.combine(b, want, None, mask)), (it, "decrypt")
 
 
 def test_span_bounds_with_lists_at_any_alignment(E, oracle):

@@ -19,6 +19,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import kernel_resources  # noqa: E402
 
 
 def newest(pattern):
@@ -45,22 +47,46 @@ def main(tag):
         for r in rows(os.path.join(src, sub, "*", "*_counter_collection.csv")):
             k = r["Kernel_Name"]
             per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            per[k]["_meta"] = [{"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]),
-                                "lds_bytes": int(r["LDS_Block_Size"]), "workgroup": int(r["Workgroup_Size"]),
+            # (rocprofv3's VGPR_Count / SGPR_Count columns are NOT the kernel's registers -- they read 52 / 112 for nearly every kernel
+            # of this library; the resource columns below come from the code objects inside the library that ran: tools/kernel_resources.py)
+            per[k]["_meta"] = [{"lds_bytes_dispatch": int(r["LDS_Block_Size"]), "workgroup": int(r["Workgroup_Size"]),
                                 "grid": int(r["Grid_Size"])}]
-    for r in rows(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
-        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for r in sorted(rows(os.path.join(src, "trace", "*", "*_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"])):
+        dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))      # in launch order
+    # which library the profiled run loaded: its bench line says so (config.library); the product library otherwise
+    lib_name, steps_timed = "libflashe_hip.so", None
+    try:
+        for line in open(os.path.join(src, "trace.log")):
+            if line.startswith('{"metric'):
+                j = json.loads(line)
+                lib_name, steps_timed = j.get("config", {}).get("library", lib_name), j.get("steps")
+    except OSError:
+        pass
+    try:
+        res = {kernel_resources.norm(k): v for k, v in kernel_resources.resources(os.path.join(ROOT, "flashe_amd", lib_name)).items()}
+    except Exception as exc:                               # (no toolchain at hand: the columns are left out, never guessed)
+        print(f"warning: no code-object resources ({exc})", file=sys.stderr)
+        res = {}
     out = {}
     for k, d in per.items():
         if not k.startswith("void flashe::") and not k.startswith("flashe::"):
             continue
-        e = {"launch": d["_meta"][0]}
+        e = {"launch": dict(d["_meta"][0])}
+        co = res.get(kernel_resources.norm(k))
+        if co:
+            e["launch"].update({"vgpr": co["vgpr"], "agpr": co["agpr"], "sgpr": co["sgpr"], "scratch_bytes_per_lane": co["scratch_bytes_per_lane"],
+                                "lds_bytes_static": co["lds_bytes_static"], "waves_per_simd_by_vgpr": kernel_resources.waves_per_simd(co["vgpr"], co["agpr"]),
+                                "resource_source": f"code object inside flashe_amd/{lib_name} (llvm-readelf --notes)"})
         for c, v in d.items():
             if c == "_meta":
                 continue
             e[c] = {"avg": sum(v) / len(v), "min": min(v), "max": max(v), "launches": len(v)}
         if k in dur:
-            e["avg_duration_us_unprofiled_pass"] = sum(dur[k]) / len(dur[k]) / 1e3
+            e["avg_duration_us_unprofiled_pass"] = sum(dur[k]) / len(dur[k]) / 1e3          # every launch of the process, cold ones included
+            if steps_timed and len(dur[k]) >= steps_timed:
+                # the bench's timed region is the END of the trace: the last K launches of a kernel that runs once per round
+                e["avg_us_timed_launches"] = sum(dur[k][-steps_timed:]) / steps_timed / 1e3
+                e["timed_launches"] = steps_timed
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_bytes_per_launch_avg"] = (2 * e["FETCH_SIZE"]["avg"] + e["WRITE_SIZE"]["avg"]) * 1024
         if "GRBM_GUI_ACTIVE" in e and k in dur:
