@@ -218,6 +218,7 @@ class FlasheCipher(object):
         self._engine = None
         self._key = None
         self._ctx_holds = 0           # which precompute caches the engine's ctx may hold (PREPARED_ENCRYPT | PREPARED_DECRYPT bits)
+        self._pt_stage = None         # this cipher's upload block for host plaintexts of device-resident encrypts (_staged)
 
     # ------------------------------------------------------------------ simple setters
     def set_num_clients(self, num_clients):
@@ -373,8 +374,31 @@ class FlasheCipher(object):
         integer arrays like any other (object-int path: full-width ciphertexts, L-limb operands for the decrypt)."""
         return self.int_bits <= 32 and isinstance(value, np.ndarray) and value.dtype == np.uint32
 
-    def _on_device(self, value, full_width=False):
-        """(DeviceVector on this cipher's engine, kind of the host form).  full_width: the operand must have L limbs."""
+    def _staged(self, arr, n, limbs, elem_bytes=8):
+        """A host plaintext in this cipher's own upload block, as a DeviceVector VIEW of it (round 6).
+
+        Why not a fresh block per call: the caching allocator hands a parked block out again only after a DEVICE-WIDE synchronisation
+        (csrc/blockpool.h -- the guarantee hipFree gives), and the plaintext block of the previous call was parked a moment ago: every
+        encrypt(host, device=True) after the first waited there for whatever ran on ANY stream, i.e. for the previous client's encrypt
+        on its own cipher's stream -- ten clients' uploads and encrypts ran strictly one after the other.  The cipher's own block is
+        reused in stream order (the upload is on the ctx stream, behind the kernel that read the block last), no allocator, no device
+        synchronisation: client c + 1's upload runs beside client c's encrypt.  The block (the size of one plaintext) stays with the
+        cipher until release_device_buffers() or the cipher goes away; the view is only ever an INPUT of the call that made it."""
+        eng = self._engine
+        need = max(int(arr.nbytes), 16)
+        st = self._pt_stage
+        if st is None or st.nbytes < need or st.nbytes > 2 * need + (1 << 20):
+            st = self._pt_stage = eng.alloc(need)
+        st.upload(arr)
+        return DeviceVector(eng, n, limbs, buf=st, elem_bytes=elem_bytes)
+
+    def release_device_buffers(self):
+        """Give the cipher's upload block back to the device pool (new; the reference has no device state)."""
+        self._pt_stage = None
+
+    def _on_device(self, value, full_width=False, stage=False):
+        """(DeviceVector on this cipher's engine, kind of the host form).  full_width: the operand must have L limbs.  stage: a host
+        array goes into the cipher's own upload block (the single operand of an encrypt) instead of a block of its own."""
         eng = self._engine
         if isinstance(value, DeviceVector):
             if value.device != getattr(eng, "device", 0):
@@ -387,11 +411,17 @@ class FlasheCipher(object):
             if value.ndim != 1:
                 raise ValueError(f"uint32 input must be [n], got {value.shape}")
             if self._compact_ok():
+                if stage and hasattr(eng, "alloc"):
+                    value = np.ascontiguousarray(value)
+                    return self._staged(value, value.shape[0], 1, elem_bytes=4), "u32"
                 return DeviceVector.from_host(eng, value), "u32"
             return DeviceVector.from_host(eng, value.astype(np.uint64)), "u32"
         limbs, kind = _to_limbs(value, eng.limbs)
         if full_width and limbs.shape[1] != eng.limbs:
             limbs = np.concatenate([limbs, np.zeros((limbs.shape[0], eng.limbs - limbs.shape[1]), dtype=np.uint64)], axis=1)
+        if stage and hasattr(eng, "alloc"):
+            limbs = np.ascontiguousarray(limbs, dtype=np.uint64)
+            return self._staged(limbs, limbs.shape[0], limbs.shape[1]), kind
         return DeviceVector.from_host(eng, limbs), kind
 
     @staticmethod
@@ -414,7 +444,7 @@ class FlasheCipher(object):
     def _encrypt_single(self, value, device=None):                       # jzf_flashe.py:431-454
         eng = self._engine
         if self._wants_device(value, device) or isinstance(value, DeviceVector) or self._is_u32(value):
-            dv, kind = self._on_device(value)
+            dv, kind = self._on_device(value, stage=True)
             want_dev = self._wants_device(value, device)
             if self._compact_ok() and (dv.compact or want_dev):
                 dv = self._as_compact(dv)
@@ -437,7 +467,7 @@ class FlasheCipher(object):
         want_dev = self._wants_device(value, device)
         prepared = 'add' in self.next_iter_encrypt_prepared
         if want_dev or prepared or isinstance(value, DeviceVector) or self._is_u32(value):
-            dv, kind = self._on_device(value)
+            dv, kind = self._on_device(value, stage=True)
             n = len(dv)
             if not prepared and self._compact_ok() and (dv.compact or want_dev):
                 dv = self._as_compact(dv)

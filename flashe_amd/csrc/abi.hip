@@ -857,7 +857,9 @@ int flashe_encrypt_batch_sum_u32_dev(flashe_ctx *ctx, uint32_t iter, int scheme,
                                      const uint32_t *const *pt_dev, uint32_t *const *ct_dev, uint32_t *sum_out_dev)
 {
     CHECK_CTX(ctx);
-    if (n && n_vec > 0 && !sum_out_dev) return fail(ctx, FLASHE_EINVAL, "flashe_encrypt_batch_sum_u32_dev: null sum_out_dev");
+    // (n_vec == 0 clears the sum: it needs the vector just the same -- a null pointer must come back as FLASHE_EINVAL, not as a HIP error
+    // from the memset)
+    if (n && !sum_out_dev) return fail(ctx, FLASHE_EINVAL, "flashe_encrypt_batch_sum_u32_dev: null sum_out_dev");
     if (reinterpret_cast<uintptr_t>(sum_out_dev) & 3u) return fail(ctx, FLASHE_EINVAL, "sum_out_dev must be 4-byte aligned");
     for (int v = 0; v < n_vec && ct_dev; v++)
         if (n && (ct_dev[v] == sum_out_dev || (pt_dev && pt_dev[v] == sum_out_dev)))
@@ -1810,16 +1812,21 @@ struct flashe_span_bounds {
     // the first call that needs it -- a round that runs the fused passes never reads the plain reduce's table, and filling both cost the
     // bounds pass a third of its time (config 5: 0.032 -> 0.023 ms).
     mutable bool have_reduce = false;
+    // the ctx whose stream the lazy fill ran on: a handle used from another ctx / stream has no ordering against that fill
+    mutable const flashe_ctx *reduce_filled_by = nullptr;
 };
 
-// the plain span reduce's table of a handle, filled on first use (same lists, same stream order)
+// The plain span reduce's table of a handle, filled on first use ON THE CALLING CTX'S STREAM (same lists, same stream order).  Inside a
+// graph capture the fill is only RECORDED -- it runs when (and each time) the graph is replayed -- so the flag is left alone there: a
+// later eager call fills the table itself instead of reading what a never-replayed graph never wrote.  A second ctx (another stream)
+// that shares the handle fills the table again on its own stream rather than racing the first one's fill.
 static int ensure_reduce_table(flashe_ctx *ctx, const flashe_span_bounds *b)
 {
-    if (b->have_reduce) return FLASHE_OK;
+    if (b->have_reduce && b->reduce_filled_by == ctx) return FLASHE_OK;
     for (int c0 = 0, g = 0; c0 < b->C; c0 += kMaxScatter, g++)
         HIP_TRY(ctx, launch_span_bounds(ctx->env, std::min(kMaxScatter, b->C - c0), b->loc.data() + c0, b->k.data() + c0, b->total,
                                         b->start + g * b->group_stride, nullptr));
-    b->have_reduce = true;
+    if (!ctx->capturing) { b->have_reduce = true; b->reduce_filled_by = ctx; }
     return FLASHE_OK;
 }
 

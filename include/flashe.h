@@ -207,6 +207,9 @@ int flashe_encrypt_batch_dev(flashe_ctx *ctx, uint32_t iter, int scheme, uint64_
  *       until consumed or re-prepared); flashe_prepared_discard(which) drops it (which: FLASHE_PREPARED_ENCRYPT | _DECRYPT) AND
  *       gives the mask blocks back to the device.  (A cache that is merely consumed keeps its blocks inside the ctx for the next
  *       round's masks -- up to four vectors of num_params elements per ctx -- until flashe_prepared_discard or flashe_ctx_destroy.)
+ *       flashe_prepared_discard SYNCHRONISES the ctx stream before it frees (the only call of this group that does), and what it frees
+ *       is what flashe_prepared_query handed out: pointers from an earlier query, and a graph captured around flashe_*_prepared_dev
+ *       (its kernel arguments are those pointers), must not be used after a discard.  Inside a capture it only marks the cache invalid.
  * prepare_* are asynchronous on the ctx stream like every *_dev call. */
 #define FLASHE_PREPARED_ENCRYPT 1
 #define FLASHE_PREPARED_DECRYPT 2
@@ -438,8 +441,10 @@ int flashe_sparse_decrypt_dev(flashe_ctx *ctx, uint32_t iter, int C, const uint3
                               uint64_t total, uint32_t n_jobs, int sorted, const uint64_t *agg_dev, uint64_t *out_dev);
 /* Span bounds of a round's location lists, computed ONCE (new).  The LDS-staged sparse passes cut the dense vector into spans and
  * first find, for every span, where each client's (strictly increasing) list enters it -- a pass over all lists that the sparse
- * aggregate and the sparse decrypt of one round would otherwise both run on the same lists.  (The handle carries the table for both
- * span sizes in use -- the plain reduce's and that of the passes with the PRF inside -- filled by one pass over the lists.)  flashe_span_bounds_create computes the
+ * aggregate and the sparse decrypt of one round would otherwise both run on the same lists.  (The handle carries a table for both
+ * span sizes in use: the one the ctx's hot passes read -- the passes with the PRF inside where the ctx has them -- is filled by create /
+ * recompute, the plain reduce's by the first call that needs it, on THAT call's ctx stream; inside a graph capture that fill is part
+ * of the graph.)  flashe_span_bounds_create computes the
  * table for C lists (any C) asynchronously on the ctx stream; the *_bounds_dev calls take it instead of recomputing; the handle is valid
  * for exactly these list pointers / lengths / total (checked) and until flashe_span_bounds_destroy.  The table describes the lists'
  * CONTENTS, which the check cannot see: the lists must not change while a handle built on them is in use, and after any in-place

@@ -125,6 +125,17 @@ def test_config4_resnet50_ten_clients_one_gpu(E, oracle):
     want_agg = oracle.aggregate_elem(cts, b)
     del cts
     assert np.array_equal(ops.read((rnd.partial, 0), 2 * n).reshape(n, 2), want_agg)
+    # the schedule bench.py --config 4 TIMES (partial-agg: the encrypt launch also writes the sum of its ten ciphertexts, the second
+    # launch decrypts that one vector): every buffer poisoned first, ALL ten full ciphertexts, the partial aggregate and the result
+    for buf in (rnd.ct_all, rnd.partial, out):
+        eng.memset_dev(buf, 0xb6, buf.nbytes)
+    out_p = rnd.run(it, refs, 1, partial_agg=True)
+    for c in range(C):
+        want_c = oracle.encrypt(KEY, it, c, "double", 16, b, pts[c])
+        assert np.array_equal(ops.read(rnd.ct[c], 2 * n).reshape(n, 2), want_c), (c, "partial-agg schedule")
+        del want_c
+    assert np.array_equal(ops.read((rnd.partial, 0), 2 * n).reshape(n, 2), want_agg), "partial aggregate written by the encrypt launch"
+    assert np.array_equal(ops.read((out_p, 0), 2 * n).reshape(n, 2), got)
     # the fused schedule (chunked chain launches + mask difference) gives the same plaintext aggregate
     side = E.Engine(KEY, b, device=0)
     rnd2 = ShardedRound(HipOps(eng, side), n, b, list(range(C)), 16, total_clients=C)

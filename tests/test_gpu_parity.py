@@ -1666,6 +1666,49 @@ def test_sparse_double_masks_from_location_lists(E, oracle, b, total, C, frac):
             da.download(np.uint64, 2)
 
 
+@pytest.mark.parametrize("b,scheme", [(128, "double"), (128, "single"), (20, "double"), (64, "double")])
+def test_device_resident_encrypts_reuse_the_ciphers_upload_block(oracle, b, scheme):
+    """Round 6: FlasheCipher.encrypt(host array, device=True) stages the plaintext in the cipher's OWN upload block
+    (no fresh block per call: the caching allocator would synchronise the device before it hands the previous call's block out again,
+    which serialised the clients' uploads and encrypts) -- vectors of changing length through the same cipher (the block grows, is
+    kept, shrinks), two ciphers interleaved, uint64 / uint32 / object inputs: every ciphertext equals the oracle's
+    (jzf_flashe.py:431-488), and a handle returned earlier still holds ITS ciphertext after later calls reused the block."""
+    from flashe_amd import cipher as cm
+    cm.N_JOBS = 16
+    it = 11
+    rng = np.random.Generator(np.random.PCG64(b + len(scheme)))
+    ciphers = []
+    for c in range(2):
+        ci = cm.FlasheCipher(b, mask=scheme)
+        ci.set_num_clients(2)
+        ci.generate_prp_seed(KEY)
+        ci.set_iter_index(it)
+        ci.idx = c
+        ciphers.append(ci)
+    kept = []
+    for n in (100_003, 40_001, 100_003, 250_000, 17, 250_000, 3_000):
+        for c, ci in enumerate(ciphers):
+            pt = rng.integers(0, 2 ** min(b, 64), n, dtype=np.uint64)
+            want = oracle.encrypt(KEY, it, c, scheme, 16, b, pt)
+            form = pt.astype(np.uint32) if (b <= 32 and n % 2) else (pt.astype(object) if n == 17 else pt)
+            h = ci.encrypt(form, device=True)
+            got = h.to_host()
+            got = got.astype(np.uint64).reshape(n, -1)
+            assert np.array_equal(got, want[:, :got.shape[1]]), (b, scheme, n, c)
+            assert h.buf is not ci._pt_stage and h.buf.ptr != ci._pt_stage.ptr          # the result never lives in the upload block
+            assert ci._pt_stage.nbytes >= pt.nbytes // (2 if (b <= 32 and n % 2) else 1) or b <= 32
+            kept.append((h, want))
+    for h, want in kept:                                                             # earlier results untouched by later uploads
+        got = h.to_host().astype(np.uint64).reshape(len(h), -1)
+        assert np.array_equal(got, want[:, :got.shape[1]])
+    blocks = {ci._pt_stage.ptr for ci in ciphers}
+    assert len(blocks) == 2
+    ciphers[0].release_device_buffers()
+    assert ciphers[0]._pt_stage is None
+    h = ciphers[0].encrypt(np.arange(5, dtype=np.uint64), device=True)               # ... and comes back on demand
+    assert np.array_equal(h.to_host().astype(np.uint64).reshape(5, -1)[:, 0], oracle.encrypt(KEY, it, 0, scheme, 16, b, np.arange(5, dtype=np.uint64))[:, 0])
+
+
 @pytest.mark.parametrize("b,scheme", [(20, "double"), (32, "double"), (8, "single"), (23, "double")])
 def test_flashe_cipher_compact_layout(oracle, b, scheme):
     """with int_bits <= 32 the drop-in class keeps device-resident vectors as uint32 arrays (half the bytes of the one-limb
