@@ -1177,15 +1177,18 @@ def bench_precompute(args, n, ops, rank, world, out):
         if k is not None:
             eng.record(ev[k][1])
         if fused_online:
-            # online encrypts ct = pt + (add - minus) AND the arbiter's reduce of them from the same pass (round 5: every ciphertext
-            # goes through the registers of the lane that owns the element; the precompute twin of config 2's partial aggregate)
-            eng.combine_batch_sum_dev(n, t_pts, 1, t_masks, None, t_cts, agg)
-        else:
-            eng.combine_batch_dev(n, t_pts, 1, t_masks, None, t_cts)       # online encrypts, one launch
+            # online encrypts ct = pt + (add - minus), the arbiter's reduce of them AND the decrypt of that reduce with the precomputed
+            # decrypt mask from ONE pass (round 5: every ciphertext goes through the registers of the lane that owns the element; round
+            # 6: a hundred clients without a minus operand are one launch, and the workgroup that completes an element's sum decrypts it)
+            eng.combine_batch_sum_decrypt_dev(n, t_pts, 1, t_masks, None, t_cts, agg, dmask, None, dec)
+            if split:
+                eng.record(ev[k][2])
+                eng.record(ev[k][3])
+            return
+        eng.combine_batch_dev(n, t_pts, 1, t_masks, None, t_cts)           # online encrypts, one launch
         if split:
             eng.record(ev[k][2])
-        if not fused_online:
-            eng.aggregate_elem_dev(t_cts, n, agg)
+        eng.aggregate_elem_dev(t_cts, n, agg)
         eng.combine_dev(n, agg, L, dmask, None, dec)                      # online decrypt
         if split:
             eng.record(ev[k][3])
@@ -1256,7 +1259,7 @@ def bench_precompute(args, n, ops, rank, world, out):
         "value": world * C * n / (elapsed / K), "ms_per_step": elapsed * 1e3 / K, "scaling": "weak",
         "config": {"workload": f"BASELINE config 3: LeNet-sized gradient (n={n}), {C} clients, double mask + mask precompute, {b}-bit modulus, "
                                f"n_jobs={J}; step = prepare_encrypt x {C} + prepare_decrypt (one launch) + online {C} encrypts + {C}-way "
-                               "aggregate" + (" (one pass)" if fused_online else "") + " + decrypt (no AES online)" + ("; independent replicas per GPU" if world > 1 else ""),
+                               "aggregate + decrypt" + (" (ONE pass, one launch)" if fused_online else "") + " (no AES online)" + ("; independent replicas per GPU" if world > 1 else ""),
                    "n": n, "int_bits": b, "clients_total": C, "mask": "double+precompute",
                    "parity": "bit-exact (round trip + three clients' ciphertexts vs the oracle, checked in-run)"},
         "roofline": {"kernel": "prf_chain_kernel<1024> (mask precompute: chain of %d clients + decrypt mask difference, in = NULL)" % C if L == 2
@@ -1267,12 +1270,13 @@ def bench_precompute(args, n, ops, rank, world, out):
                      "note": "launch- and latency-bound at this size (61,706 elements per vector)"},
         "phases_note": "precompute launch: HIP events inside the timed region (the only records in it); the online launches: an untimed pass over the same K rounds",
         "phases_ms": {"precompute_all_masks": pre_ms,
-                      ("online_encrypt_xC_plus_aggregate" if fused_online else "online_encrypt_xC"): float(ph[:, 1].mean()),
-                      ("online_decrypt" if fused_online else "online_aggregate_plus_decrypt"): float(ph[:, 2].mean()),
+                      ("online_encrypt_xC_plus_aggregate_plus_decrypt" if fused_online else "online_encrypt_xC"): float(ph[:, 1].mean()),
+                      ("online_decrypt_in_the_same_launch" if fused_online else "online_aggregate_plus_decrypt"): 0.0 if fused_online else float(ph[:, 2].mean()),
                       "ms_per_step_split_online_half": split_ms,
                       "round_as_one_graph_launch": graph_ms,
                       "graph_note": "the round's launches captured once and replayed with an advancing device-side iter shift (every "
-                                    "replay is a new round); checked against the oracle at the last replayed iter"},
+                                    "replay is a new round); checked against the oracle at the last replayed iter.  A measurement, not a "
+                                    "recommendation: a replay costs what the launches it replaces cost (DESIGN 4.4)"},
     })
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(J, b, C, host_pts, n)

@@ -133,6 +133,8 @@ _SIGNATURES = {
                                          ctypes.POINTER(c_vp)]),
     "flashe_combine_batch_sum_dev": (c_int, [c_vp, c_u64, c_int, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
                                              ctypes.POINTER(c_vp), c_vp]),
+    "flashe_combine_batch_sum_decrypt_dev": (c_int, [c_vp, c_u64, c_int, ctypes.POINTER(c_vp), c_int, ctypes.POINTER(c_vp), ctypes.POINTER(c_vp),
+                                                     ctypes.POINTER(c_vp), c_vp, c_vp, c_vp, c_vp]),
     "flashe_aggregate_elem_dev": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_aggregate_elem": (c_int, [c_vp, c_int, ctypes.POINTER(c_vp), c_u64, c_vp]),
     "flashe_aggregate_decrypt_range_dev": (c_int, [c_vp, c_u32, c_u32p, c_int, c_u32p, c_int, c_u64, c_u32, c_u64, c_u64, c_int,

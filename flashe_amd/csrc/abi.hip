@@ -1600,6 +1600,37 @@ int flashe_combine_batch_sum_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const u
     return FLASHE_OK;
 }
 
+// ... and dec_out = (sum_out + dec_add - dec_minus) mod 2^b from the same pass: the decrypt of the arbiter's reduce with the decrypting
+// party's precomputed masks (jzf_flashe.py:557-571 with next_iter_decrypt_prepared populated, :633-666) -- the workgroup that completes
+// an element's sum holds it in registers; one launch instead of the reduce's and the decrypt's (round 6, config 3).
+int flashe_combine_batch_sum_decrypt_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                         const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev, uint64_t *sum_out_dev,
+                                         const uint64_t *dec_add_dev, const uint64_t *dec_minus_dev, uint64_t *dec_out_dev)
+{
+    CHECK_CTX(ctx);
+    if (n && !dec_out_dev) return fail(ctx, FLASHE_EINVAL, "flashe_combine_batch_sum_decrypt_dev: null dec_out_dev");
+    if (n_vec < 0 || (n_vec && (!in_dev || !out_dev))) return fail(ctx, FLASHE_EINVAL, "bad batch arguments");
+    if (n && !sum_out_dev) return fail(ctx, FLASHE_EINVAL, "flashe_combine_batch_sum_decrypt_dev: null sum_out_dev");
+    if (in_limbs != 1 && in_limbs != ctx->limbs) return fail(ctx, FLASHE_EINVAL, "in_limbs must be 1 or %d", ctx->limbs);
+    const uintptr_t need = ctx->limbs == 2 ? 15u : 7u;
+    for (const void *q : {static_cast<const void *>(sum_out_dev), static_cast<const void *>(dec_add_dev), static_cast<const void *>(dec_minus_dev), static_cast<const void *>(dec_out_dev)})
+        if (reinterpret_cast<uintptr_t>(q) & need) return fail(ctx, FLASHE_EINVAL, "sum / decrypt vectors must be aligned like a ciphertext vector");
+    if (n && (dec_out_dev == sum_out_dev || dec_add_dev == sum_out_dev || dec_minus_dev == sum_out_dev))
+        return fail(ctx, FLASHE_EINVAL, "dec_out_dev and the decrypt masks must not be sum_out_dev");
+    for (int v = 0; v < n_vec; v++) {
+        if (n && (!in_dev[v] || !out_dev[v])) return fail(ctx, FLASHE_EINVAL, "null vector %d", v);
+        const uint64_t *a = add_dev ? add_dev[v] : nullptr, *m = minus_dev ? minus_dev[v] : nullptr;
+        if (n && (out_dev[v] == sum_out_dev || out_dev[v] == dec_out_dev || out_dev[v] == dec_add_dev || out_dev[v] == dec_minus_dev))
+            return fail(ctx, FLASHE_EINVAL, "output vector %d is also the sum, the decrypt result or a decrypt mask", v);
+        if (n && (in_dev[v] == sum_out_dev || a == sum_out_dev || m == sum_out_dev || in_dev[v] == dec_out_dev || a == dec_out_dev || m == dec_out_dev))
+            return fail(ctx, FLASHE_EINVAL, "sum_out_dev / dec_out_dev must not be one of the operands (vector %d)", v);
+        if (ctx->limbs == 2 && (!aligned16(out_dev[v]) || !aligned16(a) || !aligned16(m) || (in_limbs == 2 && !aligned16(in_dev[v]))))
+            return fail(ctx, FLASHE_EINVAL, "vector %d: device vectors must be 16-byte aligned", v);
+    }
+    HIP_TRY(ctx, launch_combine_batch_sum(ctx->env, n, n_vec, in_dev, in_limbs, add_dev, minus_dev, out_dev, sum_out_dev, dec_add_dev, dec_minus_dev, dec_out_dev));
+    return FLASHE_OK;
+}
+
 // ---- arbiter reduce ----
 int flashe_aggregate_elem_dev(flashe_ctx *ctx, int C, const uint64_t *const *cts_dev, uint64_t n, uint64_t *out_dev)
 {

@@ -129,7 +129,8 @@ hipError_t launch_combine_batch(const LaunchEnv &env, uint64_t n, int n_vec, con
                                 const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev);
 // the same and sum_out = sum_v out[v] mod 2^b in one pass (the online encrypts with precomputed masks + the reduce of what they wrote)
 hipError_t launch_combine_batch_sum(const LaunchEnv &env, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
-                                    const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev, uint64_t *sum_out_dev);
+                                    const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev, uint64_t *sum_out_dev,
+                                    const uint64_t *dec_add_dev = nullptr, const uint64_t *dec_minus_dev = nullptr, uint64_t *dec_out_dev = nullptr);
 
 // Operand pointers of one reduce pass travel in the kernel argument block (scalar loads).
 constexpr int kMaxOps = 64;

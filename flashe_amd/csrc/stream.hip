@@ -125,9 +125,22 @@ hipError_t launch_combine_batch(const LaunchEnv &env, uint64_t n, int n_vec, con
 // LeNet-sized vectors are only 61,706 elements -- one lane per element would leave the chip a single wave per SIMD deep in memory latency)
 // and add their partial sums up through the LDS.
 constexpr int kSumStep = 8, kSumWaves = kStreamThreads / 64;
-template <bool WIDE>
-__global__ __launch_bounds__(kStreamThreads) void combine_batch_sum_kernel(uint64_t n, int n_vec, const CombineTable tb, int in_limbs, bool accumulate, uint64_t *sum_out,
-                                                                           uint64_t mask_lo, uint64_t mask_hi)
+// Round 6: batches without a minus operand (the online encrypts of the double mask carry ONE precomputed difference per client) take a
+// three-pointer table of kMaxCombine3 entries -- config 3's hundred clients are ONE launch instead of two that hand the running sum
+// over through memory -- and the last launch of a batch may also DECRYPT the sum it has just completed with precomputed masks
+// (dec_out = sum + dec_add - dec_minus: jzf_flashe.py:557-571 on the arbiter's reduce, the lane that owns the element holds it).
+constexpr int kMaxCombine3 = 120;        // 3 x 120 pointers + the scalars stay inside the 4 KiB of kernel arguments
+struct CombineTable3 {
+    const uint64_t *in[kMaxCombine3], *add[kMaxCombine3];
+    uint64_t *out[kMaxCombine3];
+};
+__device__ __forceinline__ const uint64_t *minus_of(const CombineTable &tb, int v) { return tb.minus[v]; }
+__device__ __forceinline__ const uint64_t *minus_of(const CombineTable3 &, int) { return nullptr; }
+struct SumDecrypt { const uint64_t *add, *minus; uint64_t *out; };       // all null: no decrypt in this launch
+
+template <bool WIDE, class TB>
+__global__ __launch_bounds__(kStreamThreads) void combine_batch_sum_kernel(uint64_t n, int n_vec, const TB tb, int in_limbs, bool accumulate, uint64_t *sum_out,
+                                                                           const SumDecrypt dec, uint64_t mask_lo, uint64_t mask_hi)
 {
     __shared__ unsigned long long part[kSumWaves][64][2];
     const u128 mask = (static_cast<u128>(mask_hi) << 64) | mask_lo;
@@ -138,20 +151,27 @@ __global__ __launch_bounds__(kStreamThreads) void combine_batch_sum_kernel(uint6
         const uint64_t j = t * 64 + e;
         const bool live = j < n;
         const uint64_t jc = live ? j : n - 1;                         // (lanes beyond the vector re-read its last element and store nothing)
+        // the decrypt masks of the element, requested before the batch is walked (the first wave finishes the element)
+        u128 da = 0, dm = 0;
+        if (g == 0 && dec.out) {
+            if (WIDE) { da = dec.add ? ld128_nt(dec.add + 2 * jc) : 0; dm = dec.minus ? ld128_nt(dec.minus + 2 * jc) : 0; }
+            else { da = dec.add ? __builtin_nontemporal_load(dec.add + jc) : 0; dm = dec.minus ? __builtin_nontemporal_load(dec.minus + jc) : 0; }
+        }
         u128 sum = 0;
         for (int v0 = g; v0 < n_vec; v0 += kSumWaves * kSumStep) {
             u128 x[kSumStep], a[kSumStep], m[kSumStep];
 #pragma unroll
             for (int u = 0; u < kSumStep; u++) {
                 const int vv = v0 + kSumWaves * u, v = vv < n_vec ? vv : v0;              // (surplus slots of the last step re-read a vector and are dropped)
+                const uint64_t *mv = minus_of(tb, v);
                 if (WIDE) {
                     x[u] = in_limbs == 2 ? ld128_nt(tb.in[v] + 2 * jc) : static_cast<u128>(__builtin_nontemporal_load(tb.in[v] + jc));
                     a[u] = tb.add[v] ? ld128_nt(tb.add[v] + 2 * jc) : 0;
-                    m[u] = tb.minus[v] ? ld128_nt(tb.minus[v] + 2 * jc) : 0;
+                    m[u] = mv ? ld128_nt(mv + 2 * jc) : 0;
                 } else {
                     x[u] = __builtin_nontemporal_load(tb.in[v] + jc);
                     a[u] = tb.add[v] ? __builtin_nontemporal_load(tb.add[v] + jc) : 0;
-                    m[u] = tb.minus[v] ? __builtin_nontemporal_load(tb.minus[v] + jc) : 0;
+                    m[u] = mv ? __builtin_nontemporal_load(mv + jc) : 0;
                 }
             }
 #pragma unroll
@@ -176,29 +196,52 @@ __global__ __launch_bounds__(kStreamThreads) void combine_batch_sum_kernel(uint6
             tot &= mask;
             if (WIDE) st128_nt(sum_out + 2 * j, tot);
             else sum_out[j] = static_cast<uint64_t>(tot);
+            if (dec.out) {
+                const u128 d = (tot + da - dm) & mask;
+                if (WIDE) st128_nt(dec.out + 2 * j, d);
+                else __builtin_nontemporal_store(static_cast<uint64_t>(d), dec.out + j);
+            }
         }
         __syncthreads();
     }
 }
 
+// dec_out_dev (may be null): the decrypt of the completed sum with precomputed masks, written by the LAST launch of the batch
 hipError_t launch_combine_batch_sum(const LaunchEnv &env, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
-                                    const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev, uint64_t *sum_out_dev)
+                                    const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev, uint64_t *sum_out_dev,
+                                    const uint64_t *dec_add_dev, const uint64_t *dec_minus_dev, uint64_t *dec_out_dev)
 {
     if (n == 0) return hipSuccess;
-    if (n_vec == 0) return hipMemsetAsync(sum_out_dev, 0, static_cast<size_t>(n) * (env.b > 64 ? 16 : 8), env.stream);
     uint64_t lo, hi;
     masks_of(env.b, &lo, &hi);
-    for (int v0 = 0; v0 < n_vec; v0 += kMaxCombine) {
-        const int nv = std::min(kMaxCombine, n_vec - v0);
-        CombineTable tb{};
-        for (int v = 0; v < nv; v++) {
-            tb.in[v] = in_dev[v0 + v]; tb.add[v] = add_dev ? add_dev[v0 + v] : nullptr;
-            tb.minus[v] = minus_dev ? minus_dev[v0 + v] : nullptr; tb.out[v] = out_dev[v0 + v];
+    const SumDecrypt dec_all{dec_add_dev, dec_minus_dev, dec_out_dev}, dec_none{nullptr, nullptr, nullptr};
+    if (n_vec == 0) {
+        hipError_t e = hipMemsetAsync(sum_out_dev, 0, static_cast<size_t>(n) * (env.b > 64 ? 16 : 8), env.stream);
+        if (e == hipSuccess && dec_out_dev) e = launch_combine(env, n, sum_out_dev, env.b > 64 ? 2 : 1, dec_add_dev, dec_minus_dev, dec_out_dev);
+        return e;
+    }
+    bool any_minus = false;
+    for (int v = 0; v < n_vec && minus_dev; v++) any_minus = any_minus || minus_dev[v] != nullptr;
+    const uint64_t tiles = (n + 63) / 64, cap = static_cast<uint64_t>(env.num_cus) * 8;
+    const dim3 grid(static_cast<unsigned>(tiles < cap ? tiles : cap));
+    const int per = any_minus ? kMaxCombine : kMaxCombine3;
+    for (int v0 = 0; v0 < n_vec; v0 += per) {
+        const int nv = std::min(per, n_vec - v0);
+        const SumDecrypt &dec = v0 + nv == n_vec ? dec_all : dec_none;
+        if (any_minus) {
+            CombineTable tb{};
+            for (int v = 0; v < nv; v++) {
+                tb.in[v] = in_dev[v0 + v]; tb.add[v] = add_dev ? add_dev[v0 + v] : nullptr;
+                tb.minus[v] = minus_dev[v0 + v]; tb.out[v] = out_dev[v0 + v];
+            }
+            if (env.b > 64) hipLaunchKernelGGL((combine_batch_sum_kernel<true, CombineTable>), grid, dim3(kStreamThreads), 0, env.stream, n, nv, tb, in_limbs, v0 != 0, sum_out_dev, dec, lo, hi);
+            else hipLaunchKernelGGL((combine_batch_sum_kernel<false, CombineTable>), grid, dim3(kStreamThreads), 0, env.stream, n, nv, tb, in_limbs, v0 != 0, sum_out_dev, dec, lo, hi);
+        } else {
+            CombineTable3 tb{};
+            for (int v = 0; v < nv; v++) { tb.in[v] = in_dev[v0 + v]; tb.add[v] = add_dev ? add_dev[v0 + v] : nullptr; tb.out[v] = out_dev[v0 + v]; }
+            if (env.b > 64) hipLaunchKernelGGL((combine_batch_sum_kernel<true, CombineTable3>), grid, dim3(kStreamThreads), 0, env.stream, n, nv, tb, in_limbs, v0 != 0, sum_out_dev, dec, lo, hi);
+            else hipLaunchKernelGGL((combine_batch_sum_kernel<false, CombineTable3>), grid, dim3(kStreamThreads), 0, env.stream, n, nv, tb, in_limbs, v0 != 0, sum_out_dev, dec, lo, hi);
         }
-        const uint64_t tiles = (n + 63) / 64, cap = static_cast<uint64_t>(env.num_cus) * 8;
-        const dim3 grid(static_cast<unsigned>(tiles < cap ? tiles : cap));
-        if (env.b > 64) hipLaunchKernelGGL(combine_batch_sum_kernel<true>, grid, dim3(kStreamThreads), 0, env.stream, n, nv, tb, in_limbs, v0 != 0, sum_out_dev, lo, hi);
-        else hipLaunchKernelGGL(combine_batch_sum_kernel<false>, grid, dim3(kStreamThreads), 0, env.stream, n, nv, tb, in_limbs, v0 != 0, sum_out_dev, lo, hi);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

@@ -707,6 +707,17 @@ class Engine:
         pm, _d = self._ptr_array(minuses) if minuses is not None else (None, None)
         self._check(self._lib.flashe_combine_batch_sum_dev(self._h, n, len(inps), pi, in_limbs, pa, pm, po, self._ptr(sum_out)))
 
+    def combine_batch_sum_decrypt_dev(self, n, inps, in_limbs, adds, minuses, outs, sum_out, dec_add, dec_minus, dec_out):
+        """combine_batch_sum_dev and dec_out = (sum_out + dec_add - dec_minus) mod 2^b from the same pass: the online encrypts with
+        precomputed masks, the arbiter's reduce of them and the decrypt of that reduce with the decrypting party's precomputed masks."""
+        pi, _a = self._ptr_array(inps)
+        po, _b = self._ptr_array(outs)
+        pa, _c = self._ptr_array(adds) if adds is not None else (None, None)
+        pm, _d = self._ptr_array(minuses) if minuses is not None else (None, None)
+        self._check(self._lib.flashe_combine_batch_sum_decrypt_dev(self._h, n, len(inps), pi, in_limbs, pa, pm, po, self._ptr(sum_out),
+                                                                   self._ptr(dec_add) if dec_add is not None else None,
+                                                                   self._ptr(dec_minus) if dec_minus is not None else None, self._ptr(dec_out)))
+
     def _ptr_array(self, items):
         if isinstance(items, PtrTable):
             return items.ptr, items

@@ -62,7 +62,7 @@ typedef struct flashe_ctx flashe_ctx;
  *      prefix 0; flashe_prepared_discard releases the cached mask buffers; flashe_combine_batch_sum_dev (online encrypts with
  *      precomputed masks + their sum in one pass); flashe_encrypt_batch_sum_u32_dev (the compact layout's encrypts + their sum)
  *   4  round 6: flashe_device_peer_access and flashe_rccl_version (the preflight a rank of a multi-GPU launch runs before it creates
- *      its ctx) */
+ *      its ctx); flashe_combine_batch_sum_decrypt_dev (online encrypts + their sum + the decrypt of the sum in one pass) */
 #define FLASHE_ABI_VERSION 4
 int flashe_abi_version(void);
 int flashe_device_count(int *count);
@@ -321,6 +321,13 @@ int flashe_combine_batch_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint6
 int flashe_combine_batch_sum_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
                                  const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev,
                                  uint64_t *sum_out_dev);
+/* ... and the DECRYPT of that sum with the decrypting party's precomputed masks from the same pass (new, ABI 4): dec_out_dev =
+ * (sum_out + dec_add - dec_minus) mod 2^b, i.e. jzf_flashe.py:557-571 with next_iter_decrypt_prepared populated (:633-666) applied to
+ * the reduce of jzf_aggregator.py:424-430 -- the workgroup that completes an element's sum still holds it.  dec_add_dev / dec_minus_dev
+ * may be NULL; dec_out_dev must be a vector of its own (not the sum, an operand or an output: FLASHE_EINVAL). */
+int flashe_combine_batch_sum_decrypt_dev(flashe_ctx *ctx, uint64_t n, int n_vec, const uint64_t *const *in_dev, int in_limbs,
+                                         const uint64_t *const *add_dev, const uint64_t *const *minus_dev, uint64_t *const *out_dev,
+                                         uint64_t *sum_out_dev, const uint64_t *dec_add_dev, const uint64_t *dec_minus_dev, uint64_t *dec_out_dev);
 
 /* ---- arbiter reduce ----------------------------------------------------------------- */
 /* Element-wise: out[j] = sum_c cts[c][j] mod 2^b -- jzf_aggregator.py:424-430.

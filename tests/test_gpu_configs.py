@@ -99,6 +99,17 @@ def test_config3_lenet_100_clients_with_mask_precompute(E, oracle, b, n_jobs):
     for c in range(C):
         assert np.array_equal(dct2[c].download(np.uint64, n * L).reshape(n, L), cts[c]), (b, c, "batched + sum")
     assert np.array_equal(dagg2.download(np.uint64, n * L).reshape(n, L), agg), (b, "sum of the batch")
+    # round 6, the default of bench.py --config 3: the same pass also decrypts the sum it has just completed with the decrypting party's
+    # precomputed mask (flashe_combine_batch_sum_decrypt_dev) -- a hundred clients without a minus operand are ONE launch
+    dct3 = [eng.alloc_vec(n) for _ in range(C)]
+    dagg3, ddec3 = eng.alloc_vec(n), eng.alloc_vec(n)
+    for buf, pat in [(dagg3, 0x5A), (ddec3, 0xC3)] + [(c_, 0x99) for c_ in dct3]:
+        eng.memset_dev(buf, pat, buf.nbytes)
+    eng.combine_batch_sum_decrypt_dev(n, dpt, 1, masks, None, dct3, dagg3, dmask, None, ddec3)
+    for c in range(C):
+        assert np.array_equal(dct3[c].download(np.uint64, n * L).reshape(n, L), cts[c]), (b, c, "batched + sum + decrypt")
+    assert np.array_equal(dagg3.download(np.uint64, n * L).reshape(n, L), agg), (b, "sum of the batch (fused decrypt)")
+    assert np.array_equal(ddec3.download(np.uint64, n * L).reshape(n, L), dec), (b, "decrypt of the sum from the same pass")
 
 
 def test_config4_resnet50_ten_clients_one_gpu(E, oracle):

@@ -1518,6 +1518,55 @@ def test_combine_batch_sum_vs_oracle(E, oracle, b, n, V, in_limbs):
                 eng.combine_batch_sum_dev(n, d_in, in_limbs, d_add, d_min, outs, d_in[V - 1])   # ... nor an operand
 
 
+@pytest.mark.parametrize("b,n,V,in_limbs,minus", [(128, 4099, 5, 1, True), (128, 1000, 70, 2, False), (128, 61_706, 100, 1, False), (128, 900, 125, 1, False),
+                                                  (100, 33, 3, 1, True), (64, 5000, 9, 1, False), (20, 777, 130, 1, True), (23, 61_706, 100, 1, False),
+                                                  (128, 0, 3, 1, False), (64, 10, 0, 1, False)])
+def test_combine_batch_sum_decrypt_vs_oracle(E, oracle, b, n, V, in_limbs, minus):
+    """flashe_combine_batch_sum_decrypt_dev (round 6): the online encrypts out[v] = in[v] + add[v] - minus[v] with precomputed masks
+    (jzf_flashe.py:457, :480-481), their element-wise reduce (jzf_aggregator.py:424-430) AND the decrypt of that reduce with precomputed
+    decrypt masks (jzf_flashe.py:557-571) from one pass.  Batches without a minus operand take the three-pointer table (up to 120
+    vectors per launch: config 3's hundred clients in one; 125 / 130 carry the sum across launches and decrypt in the last one), batches
+    with one the four-pointer table of 64; every output, the sum and the decrypted vector against the oracle; misuse is refused."""
+    eng = make(E, b)
+    Lb = L(b)
+    rng = np.random.Generator(np.random.PCG64(b * 999 + n + V))
+    hi = 2 ** min(b, 64)
+
+    def vec(limbs):
+        a = np.zeros((n, limbs), dtype=np.uint64)
+        a[:, 0] = rng.integers(0, hi, n, dtype=np.uint64) if hi < 2 ** 64 else rng.integers(0, 2 ** 64, n, dtype=np.uint64)
+        if limbs == 2:
+            a[:, 1] = rng.integers(0, 2 ** (b - 64), n, dtype=np.uint64)
+        return a
+    ins = [vec(in_limbs) for _ in range(V)]
+    adds = [vec(Lb) if v % 5 != 4 else None for v in range(V)]
+    mins = [vec(Lb) if (minus and v % 4 != 1) else None for v in range(V)]
+    dec_add, dec_min = vec(Lb), (vec(Lb) if V % 2 else None)
+    d_in = [eng.upload(x) for x in ins]
+    d_add = [eng.upload(x) if x is not None else None for x in adds]
+    d_min = [eng.upload(x) if x is not None else None for x in mins] if minus else None
+    outs = [eng.alloc_vec(max(n, 1)) for _ in range(V)]
+    dsum, ddec = eng.alloc_vec(max(n, 1)), eng.alloc_vec(max(n, 1))
+    d_da, d_dm = eng.upload(dec_add) if n else eng.alloc_vec(1), (eng.upload(dec_min) if (dec_min is not None and n) else None)
+    for buf, pat in [(dsum, 0xC3), (ddec, 0x3C)] + [(o, 0x77) for o in outs]:
+        eng.memset_dev(buf, pat, buf.nbytes)
+    eng.combine_batch_sum_decrypt_dev(n, d_in, in_limbs, d_add, d_min, outs, dsum, d_da, d_dm, ddec)
+    want = [oracle.combine(b, ins[v], adds[v], mins[v]) for v in range(V)]
+    for v in range(V):
+        assert np.array_equal(outs[v].download(np.uint64, n * Lb).reshape(n, Lb), want[v]), (b, n, v)
+    if n:
+        wsum = oracle.aggregate_elem(want, b) if V else np.zeros((n, Lb), dtype=np.uint64)
+        assert np.array_equal(dsum.download(np.uint64, n * Lb).reshape(n, Lb), wsum), (b, n, V, "sum")
+        wdec = oracle.combine(b, wsum, dec_add, dec_min if d_dm is not None else None)
+        assert np.array_equal(ddec.download(np.uint64, n * Lb).reshape(n, Lb), wdec), (b, n, V, "decrypt of the sum")
+    if n and V:
+        for bad in (dict(dec_out=dsum), dict(dec_out=outs[0]), dict(dec_out=d_in[0]) if in_limbs == Lb else dict(dec_out=dsum), dict(sum_out=outs[-1]), dict(dec_add=dsum)):
+            kw = dict(sum_out=dsum, dec_add=d_da, dec_out=ddec)
+            kw.update(bad)
+            with pytest.raises(E.FlasheError):
+                eng.combine_batch_sum_decrypt_dev(n, d_in, in_limbs, d_add, d_min, outs, kw["sum_out"], kw["dec_add"], d_dm, kw["dec_out"])
+
+
 def test_double_mask_idx_range_at_the_raw_abi(E, oracle):
     """jzf_flashe.py:352-353: the double mask's minus prefix is (self.idx + 1).to_bytes(4, 'big') -- OverflowError for idx = 2^32 - 1.
     The raw C ABI refuses the same value (FLASHE_EINVAL) instead of wrapping to prefix 0, in every encrypt entry point; the single mask
