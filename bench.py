@@ -414,6 +414,9 @@ def main(comm_factory=None, device_override=None, devices_override=None):
         def on_fire(reason):
             print(f"rank {rank}: watchdog: {reason}", file=sys.stderr)
             if rank != 0:
+                # (the launcher stops every rank as soon as one has left: give rank 0's watchdog -- same flag, same poll interval -- the
+                # moment it needs to print the line before this rank's exit starts that)
+                time.sleep(1.0)
                 return
             line = state["fallback"]
             if line is not None and state.get("reason_key"):
