@@ -757,18 +757,29 @@ struct ScatterTable {
     uint64_t k[kMaxScatter], sub_lo[kMaxScatter], sub_hi[kMaxScatter];
 };
 
+#ifndef FLASHE_BOUNDS_TR
+#define FLASHE_BOUNDS_TR 0          // 1 (A/B builds): the fused passes' table transposed, start[client][span] -- VERDICT r5 #1 (b), measured in round 6: the
+                                    // bounds pass 0.0225 -> 0.0188 ms, but the two passes that read it 0.2567 -> 0.2589 and 0.2508 -> 0.2520 (the keeper's
+                                    // fifty words now come from fifty lines): round 0.5300 against 0.5297 ms -- nothing gained, the simpler layout stays
+#endif
 constexpr int kBoundsPerThread = 8;
 // entry q of client c (prev = the entry before it, cur = itself; q == k closes the list) opens the spans of SPAN positions between them
-template <int SPAN>
+// TR (an A/B build option, see FLASHE_BOUNDS_TR): the table as start[client][span] (rows of n_spans + 1 words) instead of
+// start[span][client]: a client's consecutive entries open consecutive spans, so with a row per client the stores of a wave fall into
+// one or two lines instead of one line per span (730 k four-byte stores to as many lines in config 5), and a long run of empty spans
+// is one contiguous fill.  The scatter moves to the readers: the keeper wave of span_prf_kernel reads one word per client from C
+// different lines, three spans ahead of their use.
+template <int SPAN, bool TR>
 __device__ __forceinline__ void span_open(uint32_t *start, int C, int c, uint64_t q, bool live, uint64_t k, uint64_t prev, uint64_t cur, uint64_t total,
                                           uint32_t lane)
 {
     const uint64_t n_spans = (total + SPAN - 1) / SPAN;
+    const uint64_t row = TR ? static_cast<uint64_t>(c) * (n_spans + 1) : static_cast<uint64_t>(c), step = TR ? 1 : static_cast<uint64_t>(C);
     const uint64_t s_last = q < k ? std::min<uint64_t>(static_cast<uint32_t>(cur) / static_cast<uint32_t>(SPAN), n_spans) : n_spans;
     const uint64_t s_first = !live ? s_last + 1 : q ? std::min<uint64_t>(static_cast<uint32_t>(prev) / static_cast<uint32_t>(SPAN), n_spans) + 1 : 0;
     const bool is_long = s_first + 16 <= s_last;
     if (!is_long)
-        for (uint64_t sp = s_first; sp <= s_last; sp++) start[sp * C + c] = static_cast<uint32_t>(q);
+        for (uint64_t sp = s_first; sp <= s_last; sp++) start[row + sp * step] = static_cast<uint32_t>(q);
     // a long run of empty spans (a short list over a long vector, an empty client): the wave fills it together instead of one
     // lane storing span after span
     uint64_t pending = __ballot(is_long);
@@ -776,7 +787,7 @@ __device__ __forceinline__ void span_open(uint32_t *start, int C, int c, uint64_
         const int src = __ffsll(static_cast<unsigned long long>(pending)) - 1;
         const uint64_t a = __shfl(s_first, src, 64), b = __shfl(s_last, src, 64);
         const uint32_t qq = static_cast<uint32_t>(__shfl(q, src, 64));
-        for (uint64_t x = a + lane; x <= b; x += 64u) start[x * C + c] = qq;
+        for (uint64_t x = a + lane; x <= b; x += 64u) start[row + x * step] = qq;
         pending &= pending - 1;
     }
 }
@@ -810,8 +821,8 @@ __global__ __launch_bounds__(kStreamThreads) void span_bounds_kernel(const Scatt
         const bool live = q <= k;
         const uint64_t prev = live && q ? v[i] : 0, cur = live && q < k ? v[1 + i] : 0;
         if (live && q < k && (cur >= total || (q && cur <= prev))) *err_flag = 1;
-        if (start_reduce) span_open<kSpanReduce>(start_reduce, C, c, q, live, k, prev, cur, total, lane);
-        if (start_fused) span_open<kSpanFused>(start_fused, C, c, q, live, k, prev, cur, total, lane);
+        if (start_reduce) span_open<kSpanReduce, false>(start_reduce, C, c, q, live, k, prev, cur, total, lane);
+        if (start_fused) span_open<kSpanFused, FLASHE_BOUNDS_TR != 0>(start_fused, C, c, q, live, k, prev, cur, total, lane);
     }
 }
 
@@ -1123,7 +1134,8 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
     do {                                                                                                                 \
         const uint64_t sp_ = (spx), sc_ = sp_ < n_spans ? sp_ : n_spans - 1;                                             \
         f_live = ln < C && sp_ < sp_end;                                                                                 \
-        f0 = start[sc_ * C + ln_c]; f1 = start[(sc_ + 1) * C + ln_c];                                                    \
+        if (FLASHE_BOUNDS_TR) { const uint64_t at_ = static_cast<uint64_t>(ln_c) * (static_cast<uint64_t>(n_spans) + 1) + sc_; f0 = start[at_]; f1 = start[at_ + 1]; } \
+        else { f0 = start[sc_ * C + ln_c]; f1 = start[(sc_ + 1) * C + ln_c]; }                                           \
     } while (0)
 #define SPAN_PRF_PUBLISH(buf)                                                                                            \
     do {                                                                                                                 \

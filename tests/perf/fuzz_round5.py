@@ -5,7 +5,7 @@
   fixed64  int_bits 64 at compile time (one-limb layout), whole vectors and element sub-ranges that start or end inside a block
   encsum   flashe_encrypt_batch_sum_u32_dev: the one-launch form (consecutive clients, double mask, long vectors) and every shape that
            falls back to encrypts + reduce (short vectors, other widths, gaps in the client indices, single mask, > 128 clients)
-  combsum  flashe_combine_batch_sum_dev: 0 .. 150 vectors, missing add / minus entries, one- and two-limb inputs, every modulus class
+  combsum  flashe_combine_batch_sum_dev / flashe_combine_batch_sum_decrypt_dev (round 6): 0 .. 150 vectors, missing add / minus entries, batches without any minus operand, one- and two-limb inputs, every modulus class
   sparsify flashe_sparsify_batch_dev / flashe_sparsify_dev (the rewritten streaming passes): random layer tables incl. empty and tiny
            layers, float32 / float64, ties at the threshold (quantised values), residuals; against a NumPy restatement of
            Client.sparsify's ranking (jzf_aggregator.py:578-623: |x| before the residual is added, ties to the higher index)
@@ -129,8 +129,9 @@ def fuzz_combsum(rng, case):
     pool = [vec(Lb) for _ in range(4)]
     ins = [vec(in_limbs) for _ in range(min(V, 5))]
     pick = lambda arr, v: arr[v % len(arr)]                            # noqa: E731
+    no_minus = rng.random() < 0.5                                       # (round 6: batches without a minus operand take the 120-entry table)
     adds = [None if rng.random() < 0.2 else pick(pool, v) for v in range(V)]
-    mins = [None if rng.random() < 0.3 else pick(pool, v + 1) for v in range(V)]
+    mins = [None if (no_minus or rng.random() < 0.3) else pick(pool, v + 1) for v in range(V)]
     d_pool = [eng.upload(x) if n else eng.alloc(16) for x in pool]
     d_ins = [eng.upload(x) if n else eng.alloc(16) for x in ins]
     d_in = [pick(d_ins, v) for v in range(V)]
@@ -139,14 +140,26 @@ def fuzz_combsum(rng, case):
     outs = [eng.alloc_vec(max(n, 1)) for _ in range(V)]
     dsum = eng.alloc_vec(max(n, 1))
     eng._check(eng._lib.flashe_memset_dev(eng._h, dsum.ptr, 0x3C, dsum.nbytes))
-    eng.combine_batch_sum_dev(n, d_in, in_limbs, d_add, d_min, outs, dsum)
+    # round 6: half of the cases through flashe_combine_batch_sum_decrypt_dev (the same pass also decrypts the sum with precomputed masks)
+    fused_dec = rng.random() < 0.5
+    ddec = eng.alloc_vec(max(n, 1))
+    dec_min = rng.random() < 0.5
+    if fused_dec:
+        eng._check(eng._lib.flashe_memset_dev(eng._h, ddec.ptr, 0x5B, ddec.nbytes))
+        eng.combine_batch_sum_decrypt_dev(n, d_in, in_limbs, d_add, None if no_minus and rng.random() < 0.5 else d_min, outs, dsum,
+                                          d_pool[2], d_pool[3] if dec_min else None, ddec)
+    else:
+        eng.combine_batch_sum_dev(n, d_in, in_limbs, d_add, d_min, outs, dsum)
     if n:
         want = [orc.combine(b, pick(ins, v), adds[v], mins[v]) for v in range(V)]
         for v in ([0, V // 2, V - 1] if V else []):
             assert np.array_equal(outs[v].download(np.uint64, n * Lb).reshape(n, Lb), want[v]), ("combsum/out", case, b, n, V, v)
         wsum = orc.aggregate_elem(want, b) if V else np.zeros((n, Lb), dtype=np.uint64)
         assert np.array_equal(dsum.download(np.uint64, n * Lb).reshape(n, Lb), wsum), ("combsum/sum", case, b, n, V, in_limbs)
-    return f"b={b} n={n} V={V} in_limbs={in_limbs}"
+        if fused_dec:
+            wdec = orc.combine(b, wsum, pool[2], pool[3] if dec_min else None)
+            assert np.array_equal(ddec.download(np.uint64, n * Lb).reshape(n, Lb), wdec), ("combsum/dec", case, b, n, V, in_limbs, no_minus)
+    return f"b={b} n={n} V={V} in_limbs={in_limbs} no_minus={no_minus} fused_dec={fused_dec}"
 
 
 def _topk_ref(x, res, k):
