@@ -284,6 +284,9 @@ __global__ __launch_bounds__(THREADS) void prf_wide_batch_kernel(const RoundKeys
 // left of a workgroup's share after whole rounds is cut into HALF tiles (one pair per lane, one-step shortcut) so
 // that no wave ends up with a whole 256 x (len + 1)-block tile more than its neighbours.  Short launches
 // (all_half) run entirely in half tiles.
+#ifndef FLASHE_HALF_U
+#define FLASHE_HALF_U 0        // A/B builds: the half tiles of prf_chain_kernel with the second counter shortcut too (ctr_uniform per item and stream)
+#endif
 constexpr int kMaxChains = 16;       // chains per launch
 constexpr int kMaxLinks = 128;       // outputs per launch, all chains together
 struct ChainTable {
@@ -390,21 +393,25 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
 #ifdef FLASHE_TUNING
     if (all_half & 0x200) return;
 #endif
+    // (bit 2, round 6: the whole launch in QUARTER tiles -- 64 counters, one block per lane and stream, two STREAMS per step -- for
+    // launches too short to give every wave a half tile: see the quarter branch below)
+    const bool quarter = !CODEC && (all_half & 4) != 0;
     all_half &= 1;
     const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t Ng = uniform64(d_cend[n_chains - 1]);
-    const uint64_t n_full = all_half ? 0 : Ng - Ng % WAVES;
-    const uint64_t n_items = n_full + 2 * (Ng - n_full);
+    const uint64_t n_full = (all_half || quarter) ? 0 : Ng - Ng % WAVES;
+    const uint64_t n_items = quarter ? 4 * Ng : n_full + 2 * (Ng - n_full);
     int cur = 0;
     uint64_t cbeg = 0;                                                     // local index of chain cur's first tile
     for (uint64_t q = wave; q < n_items; q += WAVES) {
         const bool whole = q < n_full;
-        const uint64_t L = whole ? q : n_full + ((q - n_full) >> 1);
-        const uint32_t half = whole ? 0u : static_cast<uint32_t>((q - n_full) & 1u);
+        const uint64_t L = quarter ? (q >> 2) : whole ? q : n_full + ((q - n_full) >> 1);
+        const uint32_t half = whole || quarter ? 0u : static_cast<uint32_t>((q - n_full) & 1u);
         while (L >= uniform64(d_cend[cur])) cbeg = uniform64(d_cend[cur++]);
         const uint64_t first = tb.first[cur], end = first + tb.count[cur];
-        const uint64_t tj = (first & ~255ull) + 256u * (uniform64(d_tlo[cur]) + (L - cbeg)) + 128u * half;   // first counter of the item
+        const uint64_t tj = (first & ~255ull) + 256u * (uniform64(d_tlo[cur]) + (L - cbeg)) + 128u * half +
+                            (quarter ? 64u * static_cast<uint32_t>(q & 3u) : 0u);                             // first counter of the item
         const int link0 = tb.link0[cur], sbase = tb.sbase[cur];
         const bool single = tb.flags[cur] & 1, in2 = tb.flags[cur] & 2;
         const int n_streams = tb.len[cur] + (single ? 0 : 1);
@@ -479,11 +486,58 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                     swap_regs(pA0, pB0); swap_regs(pA1, pB1); swap_regs(vA0, vB0); swap_regs(vA1, vB1);
                 }
             }
+        } else if (quarter) {
+            // ---- 64 elements (round 6): ONE block per lane and stream, the software-pipelined pair is two consecutive STREAMS of the
+            // chain.  For launches that cannot give every wave of the chip a half tile (config 3: a hundred LeNet-sized vectors are
+            // 242 tiles): four times the items, so a chain is cut into a third as many pieces (a cut costs a stream) and every wave
+            // gets ONE item of the same length instead of one or two; and 64 aligned counters share bytes 1 .. 3, so both counter-mode
+            // shortcuts apply (196 lookups per block; the half tiles take only the first: 208).
+            if (!CODEC && tj < end && tj + 64u > first) {
+                const uint64_t j0 = tj + lane, k0 = j0 - first;
+                const bool a0 = j0 >= first && j0 < end;
+                const uint32_t x3 = static_cast<uint32_t>(tj) ^ rk.w[3];
+                const uint32_t v0 = T3(static_cast<uint32_t>(j0) ^ rk.w[3], SEL_B0);
+                u128 pv = 0, qs = 0;
+                uint64_t *const sum_out = SUM ? tb.sum_out[cur] : nullptr;
+                for (int c = 0; c < n_streams; c += 2) {
+                    const bool has1 = c + 1 < n_streams;             // (an odd stream count computes its last stream twice)
+                    const CtrPrefix pre0 = load_prefix(pre_lds, sbase + c), pre1 = load_prefix(pre_lds, sbase + (has1 ? c + 1 : c));
+                    const CtrUniform U0 = ctr_uniform(rk, te0, pre0, x3), U1 = ctr_uniform(rk, te0, pre1, x3);
+                    const int l0 = single ? c : c - 1;               // the output stream c completes; stream c + 1 completes l0 + 1
+                    const uint64_t *in0 = l0 >= 0 ? tb.in[link0 + l0] : nullptr, *in1 = has1 ? tb.in[link0 + l0 + 1] : nullptr;
+                    u128 x0 = 0, x1 = 0;
+                    if (in0 != nullptr && a0) x0 = in2 ? ld128(in0 + 2 * k0) : static_cast<u128>(in0[k0]);
+                    if (in1 != nullptr && a0) x1 = in2 ? ld128(in1 + 2 * k0) : static_cast<u128>(in1[k0]);
+                    uint32_t s[2][4];
+                    ctr_round2(lr, pre0.u[0], v0, U0, s[0]);
+                    ctr_round2(lr, pre1.u[0], v0, U1, s[1]);
+                    aes256_rounds<2, 3>(rk, lr, s, FLASHE_SWP_PRIO_HALF != 0);
+                    loads_landed(x0, x1);
+                    const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
+                    if (l0 >= 0) {
+                        const u128 r0 = (x0 + (single ? c0 : pv - c0)) & mask;
+                        if (a0 && tb.out[link0 + l0] != nullptr) st128(tb.out[link0 + l0] + 2 * k0, r0);
+                        if constexpr (SUM) qs += r0;
+                    }
+                    if (has1) {
+                        const u128 r1 = (x1 + (single ? c1 : c0 - c1)) & mask;
+                        if (a0 && tb.out[link0 + l0 + 1] != nullptr) st128(tb.out[link0 + l0 + 1] + 2 * k0, r1);
+                        if constexpr (SUM) qs += r1;
+                    }
+                    pv = has1 ? c1 : c0;
+                }
+                if constexpr (SUM) {
+                    if (a0 && sum_out != nullptr) st128_nt(sum_out + 2 * k0, qs & mask);
+                }
+            }
         } else if (tj < end && tj + 128u > first) {
             // ---- 128 elements: one pair per lane; the four counter-dependent lookups of round 1 are shared by all streams ----
             const uint64_t j0 = tj + lane, j1 = j0 + 64u, k0 = j0 - first, k1 = j1 - first;
             const bool a0 = j0 >= first && j0 < end, a1 = j1 >= first && j1 < end;
             const CtrVar xv0 = ctr_var(rk, lr, static_cast<uint32_t>(j0)), xv1 = ctr_var(rk, lr, static_cast<uint32_t>(j1));
+#if FLASHE_HALF_U
+            const uint32_t x3h = static_cast<uint32_t>(tj) ^ rk.w[3];        // (a half tile is 128 aligned counters: bytes 1 .. 3 are the wave's)
+#endif
             u128 p0 = 0, p1 = 0, q0 = 0, q1 = 0;
             uint64_t *const sum_out = SUM ? tb.sum_out[cur] : nullptr;
             for (int c = 0; c < n_streams; c++) {
@@ -503,9 +557,18 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                     if (a1) x1 = static_cast<u128>(in[k1]);
                 }
                 uint32_t s[2][4];
+#if FLASHE_HALF_U
+                {
+                    const CtrUniform U = ctr_uniform(rk, te0, pre, x3h);
+                    ctr_round2(lr, pre.u[0], xv0.v[0], U, s[0]);
+                    ctr_round2(lr, pre.u[0], xv1.v[0], U, s[1]);
+                }
+                aes256_rounds<2, 3>(rk, lr, s, FLASHE_SWP_PRIO_HALF != 0);
+#else
                 ctr_round1(pre, xv0, s[0]);
                 ctr_round1(pre, xv1, s[1]);
                 aes256_rounds<2, 2>(rk, lr, s, FLASHE_SWP_PRIO_HALF != 0);
+#endif
                 loads_landed(x0, x1);
                 const u128 c0 = words_to_u128(s[0]), c1 = words_to_u128(s[1]);
                 const u128 r0 = x0 + (single ? c0 : p0 - c0), r1 = x1 + (single ? c1 : p1 - c1);
@@ -2202,6 +2265,9 @@ hipError_t launch_prf_jobs(const LaunchEnv &env, uint32_t iter, bool dbl, int n_
 // cut is computed by both pieces); short launches are cut further so that every wave of the chip gets an item.
 static hipError_t launch_small_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs);
 
+#ifndef FLASHE_CHAIN_QUARTER_DEFAULT
+#define FLASHE_CHAIN_QUARTER_DEFAULT 1   // quarter tiles for the shortest chained launches (0: half tiles as before round 6; A/B builds)
+#endif
 hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, const PrfChain *chains, uint64_t n, uint32_t n_jobs)
 {
     if (env.b <= 64) return launch_small_chains(env, iter, n_chains, chains, n, n_jobs);
@@ -2250,11 +2316,30 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
         if (pc.l1 >= 8 && !pc.ch->sum_out_dev) cuttable_tiles += pc.tiles;
         else fixed_items += 2 * pc.tiles;
     }
+    // Round 6: launches that cannot give every wave a half tile even uncut run in QUARTER tiles (64 counters, two streams per step:
+    // the kernel's quarter branch) -- four items per tile, a chain cut into as few pieces as fill the chip ONCE (every wave one item
+    // of the same length; pieces of at least eight outputs).  Config 3's mask precompute (242 tiles x 101 + 2 streams): 3 pieces of
+    // the hundred-client chain instead of 10-12, 0.111 -> see DESIGN 4.4.  Not with a fused codec (its instantiation keeps half tiles).
+    bool quarter = !env.codec && !single_parts && all_half && 4 * total_tiles <= waves && !force_parts && FLASHE_CHAIN_QUARTER_DEFAULT;
+    if (tune) {                                                            // (tests/perf/quarter_sweep.py: 1 / 0 force the mode on / off)
+        if (const char *e = FLASHE_TUNE_ENV("FLASHE_CHAIN_QUARTER")) quarter = atoi(e) != 0 && !env.codec && !single_parts && all_half;
+    }
     std::vector<Piece> cut;
     for (const Piece &pc : pieces) {
         int parts = (pc.l1 + kMaxLinks - 1) / kMaxLinks;
         if (single_parts) {
             parts = std::max(parts, std::min(single_parts, pc.l1));
+        } else if (quarter && !pc.ch->sum_out_dev && pc.l1 >= 2) {
+            // as many pieces as fill the chip ONCE with quarter-tile items: every wave then has at most one item, and a shorter one
+            // -- while the chip is not full the extra stream a cut costs runs beside the others, not after them (tests/perf/
+            // quarter_sweep.py: 61,706 x 100: 3-8 pieces 95-96 us, 1 piece 177; 61,706 x 10: 3 pieces 25.3, 1 piece 30.8;
+            // 5,000 x 3: 3 pieces 12.3, 1 piece 18.7; 250,000 x 10 / x 100: 1 piece)
+            uint64_t cut4 = 0, fixed4 = 0;
+            for (const Piece &o : pieces) (o.l1 >= 2 && !o.ch->sum_out_dev ? cut4 : fixed4) += 4 * o.tiles;
+            const uint64_t want = fixed4 < waves ? std::max<uint64_t>((waves - fixed4) / cut4, 1) : 1;
+            parts = std::max<int>(parts, static_cast<int>(std::min<uint64_t>(want, static_cast<uint64_t>(pc.l1))));
+            parts = std::min(parts, std::max(1, kMaxChains / static_cast<int>(pieces.size())));
+            parts = std::max(parts, (pc.l1 + kMaxLinks - 1) / kMaxLinks);
         } else if (all_half && 2 * total_tiles < waves && !pc.ch->sum_out_dev) {
             // one half-tile item per wave of the chip, counting what the chains too short to be cut contribute anyway
             // (mask precompute of config 3: a chain of 100 clients beside the one-output decrypt chain)
@@ -2299,7 +2384,7 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
             tiles += pc.tiles;
             links += len; streams += ns; nc++;
         }
-        const uint64_t items = all_half ? 2 * tiles : tiles, cus = static_cast<uint64_t>(env.num_cus);
+        const uint64_t items = quarter ? 4 * tiles : all_half ? 2 * tiles : tiles, cus = static_cast<uint64_t>(env.num_cus);
         int grid = static_cast<int>(items < cus ? items : cus);
         if (force_grid > 0) grid = force_grid;
         Codec cq{};
@@ -2310,13 +2395,13 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
         if (env.codec && summed) return hipErrorInvalidValue;
         if (env.codec)
             hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, false, true>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
-                               (all_half ? 1 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
+                               (all_half ? 1 : 0) | (quarter ? 4 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
         else if (summed)
             hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, true, false>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
-                               (all_half ? 1 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
+                               (all_half ? 1 : 0) | (quarter ? 4 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
         else
             hipLaunchKernelGGL((prf_chain_kernel<kPrfThreads, false, false>), dim3(grid), dim3(kPrfThreads), 0, env.stream, env.rk, tb, nc,
-                               (all_half ? 1 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
+                               (all_half ? 1 : 0) | (quarter ? 4 : 0) | probe, iter, lo, hi, env.te0_dev, cq);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
