@@ -484,8 +484,11 @@ def main(comm_factory=None, device_override=None, devices_override=None):
             raise
         # a rank that stops must take the others with it (they would wait in their next collective forever): raise the abort flag,
         # every watchdog fires within a poll interval -- rank 0's prints the fallback line if the sequential round is already in
-        import traceback
-        traceback.print_exc()
+        if isinstance(exc, PreflightError):
+            print(f"rank {rank}: {exc}", file=sys.stderr)      # (a refusal, not a crash: no traceback)
+        else:
+            import traceback
+            traceback.print_exc()
         wd.abort(f"{type(exc).__name__}: {exc}")
         time.sleep(30)
         os._exit(wd.exit_code)

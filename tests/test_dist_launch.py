@@ -177,3 +177,4 @@ def test_bench_preflight_line_on_a_box_without_devices(tmp_path):
     d = lines[0]
     assert d["value"] is None and d["error"] == f"preflight: {n.value} devices visible, 2 ranks requested", d
     assert d["config"]["devices_visible"] == n.value and d["config"]["abi_version"] == 4
+    assert "Traceback" not in r.stderr, r.stderr[-1500:]                  # a refusal, not a crash
