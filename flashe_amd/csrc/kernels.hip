@@ -1197,6 +1197,15 @@ static bool fixed32_width(int b)
     default: return false;
     }
 }
+#ifndef FLASHE_SMALL_U2
+#define FLASHE_SMALL_U2 1      // small_chain_fast32 takes the second counter shortcut where both of a lane's blocks lie in one 256-counter window each -- on chains of
+                               // at most FLASHE_SMALL_U2_STREAMS streams (the decrypt of one vector: 0.0587 -> 0.0571 ms at int_bits 20, -3 ... -5 % at every width).  On the
+                               // ten-client chain it LOSES 10-15 % (0.278 -> 0.320 ms: thirty dependent scalar loads and two unpipelined lookup steps at the head
+                               // of every one of eleven steps, with one pair per step to spread them over; the wide kernel has two) -- ab_compact_libs.py, round 6
+#ifndef FLASHE_SMALL_U2_STREAMS
+#define FLASHE_SMALL_U2_STREAMS 2
+#endif
+#endif
 #ifndef FLASHE_SMALL_FAST32
 #define FLASHE_SMALL_FAST32 1   // whole tiles of the compile-time-width compact kernels in a loop of their own (small_chain_fast32; 0: the general loop, for A/B builds)
 #endif
@@ -1310,7 +1319,8 @@ __device__ __forceinline__ void direct32_put(uint32_t *__restrict__ q, const uin
 template <int B, bool SINGLE>
 __device__ __forceinline__ void small_chain_fast32(const RoundKeys &rk, const LaneRegs lr, const uint32_t *pre_lds, int sbase, int n_streams,
                                                    const uint64_t *const *in_tab, uint64_t *const *out_tab, const CtrVar &xA, const CtrVar &xB,
-                                                   uint64_t kA, uint64_t kB, uint32_t *sum32, bool prio)
+                                                   uint64_t kA, uint64_t kB, uint32_t *sum32, bool prio,
+                                                   const uint32_t *__restrict__ te4, bool uni, uint32_t x3A, uint32_t x3B)
 {
     constexpr int M = 128 / B;
     constexpr uint32_t mask = B >= 32 ? 0xffffffffu : ((1u << (B & 31)) - 1u);
@@ -1357,9 +1367,18 @@ __device__ __forceinline__ void small_chain_fast32(const RoundKeys &rk, const La
             dB = direct32_load<M>(in, kB);
         }
         uint32_t s[2][4];
-        ctr_round1(pre, xA, s[0]);
-        ctr_round1(pre, xB, s[1]);
-        aes256_rounds<2, 2>(rk, lr, s, prio);
+        if (FLASHE_SMALL_U2 && uni) {
+            // both blocks' sixty-four counters share bytes 1 .. 3 (x3A / x3B): the second counter shortcut of the wide kernel, 196 lookups
+            // per block instead of 208 (the wave-uniform part of rounds 1-2 through the scalar cache, device_common.h)
+            const CtrUniform UA = ctr_uniform(rk, te4, pre, x3A), UB = ctr_uniform(rk, te4, pre, x3B);
+            ctr_round2(lr, pre.u[0], xA.v[0], UA, s[0]);
+            ctr_round2(lr, pre.u[0], xB.v[0], UB, s[1]);
+            aes256_rounds<2, 3>(rk, lr, s, prio);
+        } else {
+            ctr_round1(pre, xA, s[0]);
+            ctr_round1(pre, xB, s[1]);
+            aes256_rounds<2, 2>(rk, lr, s, prio);
+        }
         emit(link, words_to_u128(s[0]), words_to_u128(s[1]), dA, dB);
     }
     if (sum32) {
@@ -1483,8 +1502,15 @@ __global__ __launch_bounds__(kSmallThreads) void prf_small_chain_kernel(const Ro
 #if FLASHE_SMALL_FAST32
         if constexpr (PAIR && B != 0 && B != 64) {
             if (fastA && fastB) {                                  // (wave-uniform) both blocks of every lane whole and inside the range
-                if (single) small_chain_fast32<B, true>(rk, lr, pre_lds, sbase, n_streams, tb.in + link0, tb.out + link0, xA, xB, j0A - first, j0B - first, sum32, p.swp_prio != 0);
-                else small_chain_fast32<B, false>(rk, lr, pre_lds, sbase, n_streams, tb.in + link0, tb.out + link0, xA, xB, j0A - first, j0B - first, sum32, p.swp_prio != 0);
+                // the lanes' counters are consecutive inside a chunk; where a set of sixty-four does not cross a multiple of 256 its
+                // bytes 1 .. 3 are the wave's (three sets of four in the chunks whose first counter is not a multiple of 64)
+                const uint32_t bA = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ctrA)), bB = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(ctrB));
+                const bool uni = FLASHE_SMALL_U2 && n_streams <= FLASHE_SMALL_U2_STREAMS && __ballot(ctrA - bA == lane && ctrB - bB == lane) == ~0ull &&
+                                 (bA & 255u) <= 192u && (bB & 255u) <= 192u;
+                if (single) small_chain_fast32<B, true>(rk, lr, pre_lds, sbase, n_streams, tb.in + link0, tb.out + link0, xA, xB, j0A - first, j0B - first, sum32, p.swp_prio != 0,
+                                                        p.te0, uni, bA ^ rk.w[3], bB ^ rk.w[3]);
+                else small_chain_fast32<B, false>(rk, lr, pre_lds, sbase, n_streams, tb.in + link0, tb.out + link0, xA, xB, j0A - first, j0B - first, sum32, p.swp_prio != 0,
+                                                  p.te0, uni, bA ^ rk.w[3], bB ^ rk.w[3]);
                 continue;
             }
         }
