@@ -1048,6 +1048,11 @@ struct SpanPrfEntry {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
 #error "span_prf_kernel's split-phase LDS counters assume the in-order LDS of gfx9 (built for gfx950): port phase_arrive / phase_wait first"
 #endif
+#ifndef FLASHE_SPAN_WRSPLIT
+#define FLASHE_SPAN_WRSPLIT 0    // 1 (A/B builds): the write-out of a span by the waves of the two lighter SIMDs only -- measured in round 6: the encrypting pass
+                                 // 0.2696 against 0.2704 ms with all sixteen waves writing: nothing (the heavier SIMDs' waves shed a tenth of their instructions
+                                 // and the wait in front of the write-out, and the span's period does not move)
+#endif
 #ifndef FLASHE_SPAN_PRIO
 #define FLASHE_SPAN_PRIO 1       // waves yield as they advance through the rounds of a span (0 = off, 2 = rising: +5.6 %; for A/B builds)
 #endif
@@ -1082,13 +1087,23 @@ __device__ __forceinline__ void phase_wait(uint32_t *ctr, uint32_t target, uint3
     asm volatile("" ::: "memory");
 }
 
-template <int ENC>
+// SRC: the dense vector `src` is given (the sparse decrypt: out = src - masks); without it the result starts from the constant base and
+// the lanes hold no prefetched dense values (sixteen registers with four positions per writing lane: the encrypting instantiations spilled)
+template <int ENC, bool SRC>
 __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys rk, const SpanPrfTable tb, int C, uint32_t iter0, uint64_t total, uint32_t n_spans,
                                                                uint32_t sp_first, uint32_t sp_end, const uint32_t *__restrict__ start, uint64_t base_lo, uint64_t base_hi, uint64_t mask_lo,
                                                                uint64_t mask_hi, const uint64_t *src, bool negate, uint64_t *out,
                                                                const uint32_t *__restrict__ te0, uint32_t *err_flag, int probe)
 {
-    constexpr int SPAN = kSpanFused, THREADS = kPrfThreads, PER = (SPAN + THREADS - 1) / THREADS, WAVES = THREADS / 64;
+    constexpr int SPAN = kSpanFused, THREADS = kPrfThreads, WAVES = THREADS / 64;
+    // Who writes a finished span out (round 6).  A workgroup's waves w and w + 4 share a SIMD; the sixteenth wave keeps the span tables and
+    // the fifteenth has entries in one span of four, so fourteen busy waves are 4 + 4 + 3 + 3 on the four SIMDs, and the waves of the two
+    // fuller SIMDs finish their rounds 800-1,300 cycles after the others (phase probes, profiles/r06_span_probe9.log): they set the span's
+    // period.  FLASHE_SPAN_WRSPLIT: only the waves of the two LIGHTER SIMDs (w mod 4 in {2, 3}: eight waves, four positions per lane)
+    // write out; the other eight carry neither the write-out steps nor the wait in front of them.
+    // (not with a dense source: four prefetched values per writing lane on top of the rounds' registers spill, 24-72 bytes per lane)
+    constexpr bool WRSPLIT = FLASHE_SPAN_WRSPLIT != 0 && !SRC;
+    constexpr int WR_WAVES = WRSPLIT ? WAVES / 2 : WAVES, WR_LANES = 64 * WR_WAVES, PER = (SPAN + WR_LANES - 1) / WR_LANES;
     const uint32_t iter = iter0 + te0[kIterShiftWord];
     __shared__ uint32_t tab[kTabWords];
     // the accumulators, low limbs in [0, SPAN), high limbs in [SPAN, 2 SPAN): with the limbs in planes of their own the two 64-bit
@@ -1108,6 +1123,10 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
     const int tid = threadIdx.x;
     for (int i = tid; i < 2 * SPAN; i += THREADS) acc[i] = 0;
     if (tid < 2) s_phase[tid] = 0;
+    // (writer rank: waves 2, 3, 6, 7, 10, 11, 14, 15 -> 0 .. 7; wtid = this lane's index among the writing lanes)
+    const int wv = tid >> 6;
+    const bool writer = !WRSPLIT || (wv & 2) != 0;
+    const int wtid = WRSPLIT ? ((((wv >> 2) << 1) | (wv & 1)) << 6) | (tid & 63) : tid;
     // the LAST wave keeps the span tables: it is the wave with the fewest entries (none at all while a span holds at most 960)
     const int ln = tid & 63;
     const bool keeper = tid >= THREADS - 64;
@@ -1208,42 +1227,50 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
     // how many iterations are behind this wave (the phase counters stand at sixteen arrivals per finished iteration)
     uint64_t wp0 = 0;
     uint32_t wlen = 0, done = 0;
-    u128 from[PER];
+    u128 from[SRC ? PER : 1];
 #pragma unroll
-    for (int e = 0; e < PER; e++) from[e] = base;
+    for (int e = 0; e < (SRC ? PER : 1); e++) from[e] = base;
     // the write-out of the previous span, in three steps that the rounds thread one by one (or that a wave without entries runs in a row)
-    u128 wa[PER];
-    auto wout_read = [&](uint32_t seen, int buf, bool early, uint64_t sp) {
+    // (WRSPLIT: a writing lane has four positions; they go through the registers two at a time, one half per round -- all four at once
+    // spilled: 84-132 bytes of scratch per lane and the passes 20-70 % slower)
+    constexpr int HALVES = WRSPLIT ? 2 : 1, PH = PER / HALVES;
+    static_assert(PER % HALVES == 0, "positions per writing lane split evenly over the write-out steps");
+    u128 wa[PH];
+    auto wout_wait = [&](uint32_t seen, int buf, bool early) {
         phase_wait(&s_phase[0], WAVES * done, seen);                       // every wave's entries of the previous span are in
         // ... which also says that every wave is through with the PREVIOUS iteration, where the table of the span now in flight was
         // searched for this iteration's entries: the keeper may put the table of the span after next in its place
         // (the loads of the slices three spans ahead are issued BEHIND the write-out, see from_load's call sites: the write-out waits for
         // everything the wave has in flight, and every wave waits for the keeper's share of the accumulators at the end of its rounds)
         if (keeper && early) SPAN_PRF_PUBLISH(buf);
+    };
+    auto wout_read = [&](int h) {
 #pragma unroll
-        for (int e = 0; e < PER; e++) {
-            const uint32_t r = min(static_cast<uint32_t>(tid + e * THREADS), static_cast<uint32_t>(SPAN - 1));
+        for (int e = 0; e < PH; e++) {
+            const uint32_t r = min(static_cast<uint32_t>(wtid + (h * PH + e) * WR_LANES), static_cast<uint32_t>(SPAN - 1));
             wa[e] = (static_cast<u128>(acc[SPAN + r]) << 64) | acc[r];
         }
     };
-    auto wout_store = [&]() {
+    auto wout_store = [&](int h) {
 #pragma unroll
-        for (int e = 0; e < PER; e++) {
-            const uint32_t r = tid + e * THREADS;
+        for (int e = 0; e < PH; e++) {
+            const uint32_t r = wtid + (h * PH + e) * WR_LANES;
             if (r < wlen) {
                 acc[r] = 0; acc[SPAN + r] = 0;
 #ifdef FLASHE_TUNING
                 if (probe == 4 && static_cast<uint64_t>(wa[e]) != 0x1234567ull) continue;      // 4 = no dense read / write
 #endif
-                st128_nt(out + 2 * (wp0 + r), (negate ? from[e] - wa[e] : from[e] + wa[e]) & mask);
+                const u128 fr = SRC ? from[SRC ? h * PH + e : 0] : base;
+                st128_nt(out + 2 * (wp0 + r), (negate ? fr - wa[e] : fr + wa[e]) & mask);
             }
         }
-        phase_arrive(&s_phase[1]);                                         // this wave's share of the accumulators is empty
+        if (h == HALVES - 1) phase_arrive(&s_phase[1]);                    // this wave's share of the accumulators is empty
     };
     auto from_load = [&](uint64_t q0, uint32_t qlen) {                     // for the NEXT iteration's write-out: the span in flight now
+        if (!SRC) return;
 #pragma unroll
-        for (int e = 0; e < PER; e++) {
-            const uint32_t r_ = tid + e * THREADS;
+        for (int e = 0; e < (SRC ? PER : 0); e++) {
+            const uint32_t r_ = wtid + e * WR_LANES;
 #ifdef FLASHE_TUNING
             from[e] = src && r_ < qlen && probe != 4 ? ld128_nt(src + 2 * (q0 + r_)) : base;
 #else
@@ -1318,18 +1345,25 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                 } else if (r == 9) {
                     nxt.x = ctr_var(rk, lr, nxt.q);
                 }
-                if (r == 4) seen_in = phase_peek(&s_phase[0]);
-                else if (r == 5) wout_read(seen_in, buf, early, sp);
-                else if (r == 6) {
-                    // (in front of the next entry's loads of r = 8: what is outstanding here was requested a span ago)
-                    __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0)
-                    wout_store();
+                if (writer) {                                        // (wave-uniform)
+                    // (WRSPLIT: the dense values of the span that is written out NOW, three rounds ahead of their use -- requested a
+                    // span ahead, four of them per lane lived through every round of the span and the decrypt pass spilled)
+                    if (WRSPLIT && r == 3) from_load(wp0, wlen);
+                    if (r == 4) seen_in = phase_peek(&s_phase[0]);
+                    else if (r == 5) { wout_wait(seen_in, buf, early); wout_read(0); }
+                    else if (r == 6) {
+                        // (in front of the next entry's loads of r = 8: what is outstanding here was requested a span ago)
+                        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+                        wout_store(0);
+                        if (HALVES == 2) wout_read(1);
+                    }
+                    if (r == 7) {
+                        if (HALVES == 2) wout_store(1);
+                        if (!WRSPLIT) from_load(p0, span_len);
+                        if (keeper && early) SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride));
+                    }
                 }
-                if (r == 7) {
-                    from_load(p0, span_len);
-                    if (keeper && early) SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride));
-                }
-                else if (r == 12) seen_out = phase_peek(&s_phase[1]);
+                if (r == 12) seen_out = phase_peek(&s_phase[1]);
                 k = r < 13 ? issue_main(lr, s) : issue_final(lr, s);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1339,11 +1373,15 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
             __builtin_amdgcn_sched_barrier(0);
         } else {
             // a wave without entries in this span and the next: the same steps in a row
-            wout_read(phase_peek(&s_phase[0]), buf, early, sp);
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-            wout_store();
-            from_load(p0, span_len);
-            if (keeper && early) SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride));
+            if (writer) {
+                if (WRSPLIT) from_load(wp0, wlen);
+                wout_wait(phase_peek(&s_phase[0]), buf, early);
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll
+                for (int h = 0; h < HALVES; h++) { wout_read(h); wout_store(h); }
+                if (!WRSPLIT) from_load(p0, span_len);
+                if (keeper && early) SPAN_PRF_FETCH(sp + 3 * static_cast<uint64_t>(stride));
+            }
             seen_out = phase_peek(&s_phase[1]);
         }
         SPAN_PRF_TICK(1);                                                  // rounds 2 .. 14 (+ everything threaded through them)
@@ -1351,7 +1389,7 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         if (probe == 9 && blockIdx.x == 0 && (tid & 63) == 0) g_span_prf_cycles[8 + (tid >> 6)] += __builtin_readcyclecounter() - head_;
 #endif
         // this span's entries go into the accumulators once every wave has emptied its share of them (arrivals of THIS iteration's r = 10)
-        phase_wait(&s_phase[1], WAVES * (done + 1), seen_out);
+        phase_wait(&s_phase[1], WR_WAVES * (done + 1), seen_out);
         SPAN_PRF_TICK(4);
         settle(cur, s, static_cast<uint32_t>(p0), span_len);
         SPAN_PRF_TICK(2);
@@ -1379,11 +1417,13 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         cur = nxt;
         n_entries = n_next;
     }
-    if (wlen) {
+    if (wlen && writer) {
         // the last span of this workgroup: nothing is left to hide behind
-        wout_read(phase_peek(&s_phase[0]), 0, false, 0);
+        if (WRSPLIT) from_load(wp0, wlen);
+        wout_wait(phase_peek(&s_phase[0]), 0, false);
         __builtin_amdgcn_s_waitcnt(0x0f70);
-        wout_store();
+#pragma unroll
+        for (int h = 0; h < HALVES; h++) { wout_read(h); wout_store(h); }
     }
 #undef SPAN_PRF_FETCH
 #undef SPAN_PRF_PUBLISH
@@ -1428,13 +1468,14 @@ hipError_t launch_span_prf(const LaunchEnv &env, uint32_t iter, int C, const uin
     const dim3 grid(static_cast<unsigned>(std::min<uint64_t>(sp_end - sp_first, static_cast<uint64_t>(std::max(env.num_cus, 1)))));
     const char *pe = FLASHE_TUNE_ENV("FLASHE_SPAN_PROBE");
     const int probe = pe ? atoi(pe) : 0;
-#define SPAN_PRF_LAUNCH(E)                                                                                                                    \
-    hipLaunchKernelGGL(span_prf_kernel<E>, grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), sp_first, \
+#define SPAN_PRF_LAUNCH(E, S)                                                                                                                 \
+    hipLaunchKernelGGL((span_prf_kernel<E, S>), grid, dim3(kPrfThreads), 0, env.stream, env.rk, tb, C, iter, total, static_cast<uint32_t>(n_spans), sp_first, \
                        sp_end, start_dev,                                                                                                          \
                        base_lo, base_hi, lo, hi, src_dev, negate, out_dev, env.te0_dev, env.err_flag, probe)
-    if (!pt_dev) SPAN_PRF_LAUNCH(0);
-    else if (pt_limbs == 1) SPAN_PRF_LAUNCH(1);
-    else SPAN_PRF_LAUNCH(2);
+    // (the encrypting passes are given a dense source only by the second and later groups of more than kMaxScatter clients)
+    if (!pt_dev) { if (src_dev) SPAN_PRF_LAUNCH(0, true); else SPAN_PRF_LAUNCH(0, false); }
+    else if (pt_limbs == 1) { if (src_dev) SPAN_PRF_LAUNCH(1, true); else SPAN_PRF_LAUNCH(1, false); }
+    else { if (src_dev) SPAN_PRF_LAUNCH(2, true); else SPAN_PRF_LAUNCH(2, false); }
 #undef SPAN_PRF_LAUNCH
     return hipGetLastError();
 }
