@@ -1188,6 +1188,9 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         u128 w = words_to_u128(s) & mask;
         if (ENC) {
             w = (e.pt + w) & mask;
+#ifdef FLASHE_TUNING
+            if (probe != 5)
+#endif
             if (s_ct[e.c]) st128_nt_g(s_ct[e.c] + 2 * static_cast<uint64_t>(e.q), w);
             w -= (static_cast<u128>(s_sub[2 * e.c + 1]) << 64) | s_sub[2 * e.c];
         }
@@ -1287,11 +1290,16 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
         SPAN_PRF_TICK(7);
 #ifdef FLASHE_TUNING
         const unsigned long long head_ = __builtin_readcyclecounter();
-        if (probe == 2) n_entries = 0;                                     // timing probes (wrong results): 1 = no rounds, 2 = no entries, 3 = no atomics
+        if (probe == 2) n_entries = 0;                                     // timing probes (wrong results): 1 = no entries at all (the skeleton: tables, waits, write-out), 2 = no second pass, 3 = no atomics
+        if (probe == 1) cur.valid = false;
 #endif
         const bool early = n_entries <= THREADS;                           // nobody will look an entry up in this span's table any more
         const int nbuf = buf ^ 1;
+#ifdef FLASHE_TUNING
+        const uint32_t n_next = probe == 1 ? 0u : (sp + stride < sp_end ? s_pb[nbuf][C].x : 0u);
+#else
         const uint32_t n_next = sp + stride < sp_end ? s_pb[nbuf][C].x : 0u;
+#endif
         // The first 1,024 entries, one per lane: its block's rounds with everything else threaded through them, one step per round (each a
         // dependent LDS read or a memory request whose latency the sixteen lookups of a round hide): the owner search for the lane's entry
         // of the NEXT span (r = 2..7), that entry's position / plaintext load (8) and round-1 lookups (9); the write-out of the PREVIOUS
@@ -1338,6 +1346,10 @@ __global__ __launch_bounds__(kPrfThreads) void span_prf_kernel(const RoundKeys r
                     nxt.valid = f < n_next;
                     nxt.c = cn;
                     nxt.q = pbn.y + (f - pbn.x);
+#ifdef FLASHE_TUNING
+                    if (probe == 5) { nxt.pos = static_cast<uint32_t>(p0 + SPAN * static_cast<uint64_t>(stride)) + (f & 1023u); }    // 5 = no entry loads, no ciphertext stores
+                    else
+#endif
                     if (nxt.valid) {
                         nxt.pos = ld32_g(locn + nxt.q);
                         if (ENC) nxt.pt = ENC == 2 ? ld128_nt_g(s_pt[cn] + 2 * static_cast<uint64_t>(nxt.q)) : static_cast<u128>(ld64_nt_g(s_pt[cn] + nxt.q));
