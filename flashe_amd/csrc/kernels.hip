@@ -396,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
 #endif
     // (bit 2, round 6: the whole launch in QUARTER tiles -- 64 counters, one block per lane and stream, two STREAMS per step -- for
     // launches too short to give every wave a half tile: see the quarter branch below)
-    const bool quarter = !CODEC && (all_half & 4) != 0;
+    const bool quarter = !CODEC && !SUM && (all_half & 4) != 0;            // (a summed chain is only launched with two whole tiles per wave: launch_prf_batch_sum)
     all_half &= 1;
     const uint32_t wave = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
     const uint32_t lane = threadIdx.x & 63u;
@@ -493,13 +493,12 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
             // 242 tiles): four times the items, so a chain is cut into a third as many pieces (a cut costs a stream) and every wave
             // gets ONE item of the same length instead of one or two; and 64 aligned counters share bytes 1 .. 3, so both counter-mode
             // shortcuts apply (196 lookups per block; the half tiles take only the first: 208).
-            if (!CODEC && tj < end && tj + 64u > first) {
+            if (!CODEC && !SUM && tj < end && tj + 64u > first) {
                 const uint64_t j0 = tj + lane, k0 = j0 - first;
                 const bool a0 = j0 >= first && j0 < end;
                 const uint32_t x3 = static_cast<uint32_t>(tj) ^ rk.w[3];
                 const uint32_t v0 = T3(static_cast<uint32_t>(j0) ^ rk.w[3], SEL_B0);
-                u128 pv = 0, qs = 0;
-                uint64_t *const sum_out = SUM ? tb.sum_out[cur] : nullptr;
+                u128 pv = 0;
                 for (int c = 0; c < n_streams; c += 2) {
                     const bool has1 = c + 1 < n_streams;             // (an odd stream count computes its last stream twice)
                     const CtrPrefix pre0 = load_prefix(pre_lds, sbase + c), pre1 = load_prefix(pre_lds, sbase + (has1 ? c + 1 : c));
@@ -518,17 +517,12 @@ __global__ __launch_bounds__(THREADS) void prf_chain_kernel(const RoundKeys rk, 
                     if (l0 >= 0) {
                         const u128 r0 = (x0 + (single ? c0 : pv - c0)) & mask;
                         if (a0 && tb.out[link0 + l0] != nullptr) st128(tb.out[link0 + l0] + 2 * k0, r0);
-                        if constexpr (SUM) qs += r0;
                     }
                     if (has1) {
                         const u128 r1 = (x1 + (single ? c1 : c0 - c1)) & mask;
                         if (a0 && tb.out[link0 + l0 + 1] != nullptr) st128(tb.out[link0 + l0 + 1] + 2 * k0, r1);
-                        if constexpr (SUM) qs += r1;
                     }
                     pv = has1 ? c1 : c0;
-                }
-                if constexpr (SUM) {
-                    if (a0 && sum_out != nullptr) st128_nt(sum_out + 2 * k0, qs & mask);
                 }
             }
         } else if (tj < end && tj + 128u > first) {
@@ -2347,9 +2341,9 @@ hipError_t launch_prf_chains(const LaunchEnv &env, uint32_t iter, int n_chains, 
     // the kernel's quarter branch) -- four items per tile, a chain cut into as few pieces as fill the chip ONCE (every wave one item
     // of the same length; pieces of at least eight outputs).  Config 3's mask precompute (242 tiles x 101 + 2 streams): 3 pieces of
     // the hundred-client chain instead of 10-12, 0.111 -> see DESIGN 4.4.  Not with a fused codec (its instantiation keeps half tiles).
-    bool quarter = !env.codec && !single_parts && all_half && 4 * total_tiles <= waves && !force_parts && FLASHE_CHAIN_QUARTER_DEFAULT;
+    bool quarter = !env.codec && !summed && !single_parts && all_half && 4 * total_tiles <= waves && !force_parts && FLASHE_CHAIN_QUARTER_DEFAULT;
     if (tune) {                                                            // (tests/perf/quarter_sweep.py: 1 / 0 force the mode on / off)
-        if (const char *e = FLASHE_TUNE_ENV("FLASHE_CHAIN_QUARTER")) quarter = atoi(e) != 0 && !env.codec && !single_parts && all_half;
+        if (const char *e = FLASHE_TUNE_ENV("FLASHE_CHAIN_QUARTER")) quarter = atoi(e) != 0 && !env.codec && !summed && !single_parts && all_half;
     }
     std::vector<Piece> cut;
     for (const Piece &pc : pieces) {
