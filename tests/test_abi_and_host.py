@@ -272,3 +272,27 @@ def test_entry_point_index_is_complete_and_current():
     text = open(os.path.join(ROOT, "include", "ENTRY_POINTS.md")).read()
     listed = re.findall(r"^\| `(flashe_\w+)` \|", text, re.M)
     assert sorted(listed) == sorted(_lib.EXPORTED_SYMBOLS) and len(listed) == len(set(listed))
+
+
+def test_hot_kernels_keep_their_register_budget():
+    """The code objects inside the built library (tools/kernel_resources.py: llvm-readelf on the .hip_fatbin bundles -- the numbers the
+    hardware allocates by, and the source of every resource figure in DESIGN.md / profiles/r06_pmc.json): the kernels of the BASELINE
+    configurations run four 1,024-thread waves per SIMD (at most 128 VGPRs) WITHOUT scratch, inside the 160 KiB of LDS.  Round 6 hit
+    84-132 bytes of scratch per lane twice while restructuring the span kernel (passes 20-70 % slower): this keeps such a build from
+    shipping unnoticed.  (The run-time-width instantiations of prf_small_chain_kernel are known to spill 32 bytes: they are the fall-back
+    of widths that have no compiled-in kernel.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    res = kernel_resources.resources(os.path.join(ROOT, "flashe_amd", "libflashe_hip.so"))
+    assert len(res) > 80
+    hot = [k for k in res if any(t in k for t in ("prf_chain_kernel<", "span_prf_kernel<", "reduce_decrypt_ptrs_kernel<", "combine_batch_sum_kernel<",
+                                                  "aggregate_elem_kernel<", "small_reduce_decrypt", "span_bounds_kernel<", "span_reduce_kernel<"))]
+    hot += [k for k in res if "prf_small_chain_kernel<true, unsigned int, " in k and ", 0>" not in k] + [k for k in res if "prf_small_chain_kernel<true, unsigned long, 64>" in k]
+    assert len(hot) >= 30, len(hot)
+    for k in hot:
+        r = res[k]
+        assert r["scratch_bytes_per_lane"] == 0 and r["vgpr_spills"] == 0, (k, r)
+        assert r["vgpr"] + r["agpr"] <= 128 and r["lds_bytes_static"] <= 163840, (k, r)
+    chain_sum = [r for k, r in res.items() if "prf_chain_kernel<1024, true, false>" in k]
+    assert len(chain_sum) == 1 and chain_sum[0]["vgpr"] <= 104 and chain_sum[0]["lds_bytes_static"] == 133632      # the headline launch: 99 VGPRs
